@@ -1,0 +1,106 @@
+// Common device/host helpers for the gfx950 (MI355X, CDNA4) kernels of the
+// geometric-distillation hot path.  wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+#define GD_F32 0
+#define GD_BF16 1
+
+// ---- host-side error plumbing (definitions in cabi.hip) ----
+void gd_set_error(const char* fmt, ...);
+#define GD_REQUIRE(cond, ...)                 \
+    do {                                      \
+        if (!(cond)) {                        \
+            gd_set_error(__VA_ARGS__);        \
+            return -1;                        \
+        }                                     \
+    } while (0)
+#define GD_LAUNCH_OK()                                                                   \
+    do {                                                                                 \
+        hipError_t e_ = hipGetLastError();                                               \
+        if (e_ != hipSuccess) {                                                          \
+            gd_set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e_)); \
+            return -2;                                                                   \
+        }                                                                                \
+    } while (0)
+
+__host__ __device__ static inline int gd_dtype_size(int dt) { return dt == GD_BF16 ? 2 : 4; }
+static inline int gd_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- scalar conversions ----
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16>(bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf16)v; }
+
+// load/store one element of a runtime-typed buffer (dt = GD_F32 / GD_BF16)
+__device__ __forceinline__ float ld_rt(const void* p, long i, int dt) {
+    return dt == GD_BF16 ? (float)((const bf16*)p)[i] : ((const float*)p)[i];
+}
+__device__ __forceinline__ void st_rt(void* p, long i, int dt, float v) {
+    if (dt == GD_BF16) ((bf16*)p)[i] = (bf16)v; else ((float*)p)[i] = v;
+}
+
+// ---- wave-level reductions (64 lanes) ----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// exact-erf GELU and its derivative (torch.nn.GELU default, approximate='none')
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_f(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+}
+
+// ---- 16x16 MFMA tile abstraction ------------------------------------------------
+// One "K-chunk" is 64 bytes of a row: 32 bf16 or 16 f32.  A fragment is the 16 bytes
+// lane l owns: row (or column) l&15, bytes [16*(l>>4), 16*(l>>4)+16) of the chunk.
+//   bf16: one v_mfma_f32_16x16x32_bf16 (lane holds k = 8*(l>>4)+j, j<8).
+//   f32 : four v_mfma_f32_16x16x4_f32; MFMA j contracts element j of every lane, i.e.
+//         k = 4*(l>>4)+j — the k order inside a chunk is irrelevant as long as the A and
+//         B fragments use the same one (exact f32, fmaf-chain numerics).
+// C/D layout (both): lane l holds C[row = 4*(l>>4)+r][col = l&15], r = 0..3.
+template <typename T> struct Mma;
+template <> struct Mma<bf16> {
+    static constexpr int KC = 32;
+    typedef bf16x8 Frag;
+    static __device__ __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    static constexpr int KC = 16;
+    typedef f32x4 Frag;
+    static __device__ __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], c, 0, 0, 0);
+        return c;
+    }
+};
+
+// XCD-aware bijective remap of a linear workgroup id: blocks b and b+8 share an XCD
+// (round-robin dispatch), so hand each XCD a contiguous chunk of the tile space.
+__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = orig & 7;
+    const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + (orig >> 3);
+}

@@ -1,0 +1,283 @@
+// MFMA GEMMs for the student ViT and the loss contractions (gfx950).
+//
+//   gemm_nt : C[M,N] = epilogue( alpha * A[M,K] . W[N,K]^T )        (both operands K-contiguous:
+//             nn.Linear forward as is, and dX = dY . W with a pre-transposed frozen W)
+//   gemm_tn : G[N,K] += alpha * Y[M,N]^T . X[M,K]                   (weight gradients; f32 MFMA,
+//             fp32 atomics across M-chunks)
+//
+// Tiling (gemm_nt): 128x128 block tile, 4 waves as 2x2, each wave 64x64 = 4x4 MFMA 16x16 tiles,
+// K step = 128 bytes of a row (64 bf16 / 32 f32), register-staged global->LDS with the next
+// tile's loads in flight under the MFMAs, LDS rows padded 128->144 B.
+#include "gd_common.h"
+
+struct GemmNtParams {
+    const void* A; const void* W; void* C;
+    int M, N, K;
+    long lda, ldw, ldc;              // row strides in elements
+    long sA, sW, sC;                 // batch strides in elements (grid.y = batch)
+    int c_dtype;                     // dtype of C / preact / dact_src / residual
+    float alpha;
+    const float* bias;               // [N]
+    const float* lora_t; const float* lora_b; int lora_rt;   // v += sum_r t[m,r] * b[r,n]
+    void* preact; long ldp;          // store v before the activation
+    int act;                         // 0 none, 1 GELU(erf), 2 ReLU
+    const void* dact_src; long ldd; int dact;                 // v *= act'(src): 1 dGELU(pre), 2 (src > 0)
+    const void* residual; long ldr;  // v += residual
+    int accumulate;                  // v += C
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtParams p) {
+    constexpr int BM = 128, BN = 128, BKB = 128, ROWB = 144;
+    __shared__ __attribute__((aligned(16))) char smem[(BM + BN) * ROWB];
+    char* sA = smem;
+    char* sB = smem + BM * ROWB;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int wg = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tm = wg / tiles_n, tn = wg % tiles_n;
+    const long batch = blockIdx.y;
+
+    const char* Ab = (const char*)p.A + batch * p.sA * (long)sizeof(T);
+    const char* Wb = (const char*)p.W + batch * p.sW * (long)sizeof(T);
+    const long lda_b = p.lda * (long)sizeof(T), ldw_b = p.ldw * (long)sizeof(T);
+    const int Kbytes = p.K * (int)sizeof(T);
+    const int nk = (Kbytes + BKB - 1) / BKB;
+
+    uint4 ra[4], rb[4];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + 256 * i, row = c >> 3, cc = c & 7;
+            const int kb = kt * BKB + cc * 16;
+            const int gr = tm * BM + row, gc = tn * BN + row;
+            const bool kin = kb < Kbytes;
+            ra[i] = (kin && gr < p.M) ? *(const uint4*)(Ab + (long)gr * lda_b + kb) : make_uint4(0, 0, 0, 0);
+            rb[i] = (kin && gc < p.N) ? *(const uint4*)(Wb + (long)gc * ldw_b + kb) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto swrite = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + 256 * i, row = c >> 3, cc = c & 7;
+            *(uint4*)(sA + row * ROWB + cc * 16) = ra[i];
+            *(uint4*)(sB + row * ROWB + cc * 16) = rb[i];
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    typedef typename Mma<T>::Frag Frag;
+    const int frow = lane & 15, fcol = (lane >> 4) * 16;
+    gload(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        swrite();
+        __syncthreads();
+        if (kt + 1 < nk) gload(kt + 1);
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            Frag a[4], b[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                a[t] = *(const Frag*)(sA + (wm * 64 + t * 16 + frow) * ROWB + kc * 64 + fcol);
+                b[t] = *(const Frag*)(sB + (wn * 64 + t * 16 + frow) * ROWB + kc * 64 + fcol);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue (C layout: row = 4*(lane>>4)+r, col = lane&15 inside each 16x16 tile) ----
+    const int cdt = p.c_dtype;
+    char* Cb = (char*)p.C + batch * p.sC * (long)gd_dtype_size(cdt);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = tm * BM + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+            if (row >= p.M) continue;
+            float lt[8];
+            if (p.lora_t) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) lt[q] = q < p.lora_rt ? p.lora_t[(long)row * p.lora_rt + q] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = tn * BN + wn * 64 + j * 16 + (lane & 15);
+                if (col >= p.N) continue;
+                float v = p.alpha * acc[i][j][r];
+                if (p.bias) v += p.bias[col];
+                if (p.lora_t) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        if (q < p.lora_rt) v += lt[q] * p.lora_b[(long)q * p.N + col];
+                }
+                if (p.preact) st_rt(p.preact, (long)row * p.ldp + col, cdt, v);
+                if (p.act == 1) v = gelu_f(v);
+                else if (p.act == 2) v = fmaxf(v, 0.f);
+                if (p.dact == 1) v *= dgelu_f(ld_rt(p.dact_src, (long)row * p.ldd + col, cdt));
+                else if (p.dact == 2) v = ld_rt(p.dact_src, (long)row * p.ldd + col, cdt) > 0.f ? v : 0.f;
+                if (p.residual) v += ld_rt(p.residual, (long)row * p.ldr + col, cdt);
+                if (p.accumulate) v += ld_rt(Cb, (long)row * p.ldc + col, cdt);
+                st_rt(Cb, (long)row * p.ldc + col, cdt, v);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// gemm_tn: G[N,K] += alpha * sum_m Y[m,n] X[m,k];  64x64 output tile per block, f32 MFMA 16x16x4,
+// operands converted to f32 while staging (so bf16 activations give fp32-accumulated weight grads).
+// ------------------------------------------------------------------------------------------
+struct GemmTnParams {
+    const void* Y; const void* X; float* G;
+    int M, N, K;
+    long ldy, ldx, ldg;
+    int y_dtype, x_dtype;
+    int mchunk;
+    float alpha;
+};
+
+__device__ __forceinline__ void load8_as_f32(const void* base, long off, int dt, bool ok, float (&o)[8]) {
+    if (!ok) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = 0.f;
+        return;
+    }
+    if (dt == GD_BF16) {
+        bf16x8 v = *(const bf16x8*)((const bf16*)base + off);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
+    } else {
+        const f32x4* q = (const f32x4*)((const float*)base + off);
+        f32x4 a = q[0], b = q[1];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { o[i] = a[i]; o[4 + i] = b[i]; }
+    }
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnParams p) {
+    constexpr int TN_ = 64, TK_ = 64, MR = 32, LD = 80;  // LD: padded row stride (floats)
+    __shared__ __attribute__((aligned(16))) float sY[MR * LD];
+    __shared__ __attribute__((aligned(16))) float sX[MR * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_k = (p.K + TK_ - 1) / TK_;
+    const int tn = blockIdx.x / tiles_k, tk = blockIdx.x % tiles_k;
+    const int m_begin = blockIdx.y * p.mchunk;
+    const int m_end = min(p.M, m_begin + p.mchunk);
+    const int wy = wave >> 1, wx = wave & 1;
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int srow = tid >> 3, scol = (tid & 7) * 8;
+    const int yn = tn * TN_ + scol, xk = tk * TK_ + scol;
+    float ry[8], rx[8];
+    auto gload = [&](int m0) {
+        const int m = m0 + srow;
+        load8_as_f32(p.Y, (long)m * p.ldy + yn, p.y_dtype, m < m_end && yn < p.N, ry);
+        load8_as_f32(p.X, (long)m * p.ldx + xk, p.x_dtype, m < m_end && xk < p.K, rx);
+    };
+    gload(m_begin);
+    for (int m0 = m_begin; m0 < m_end; m0 += MR) {
+        *(f32x4*)(sY + srow * LD + scol) = f32x4{ry[0], ry[1], ry[2], ry[3]};
+        *(f32x4*)(sY + srow * LD + scol + 4) = f32x4{ry[4], ry[5], ry[6], ry[7]};
+        *(f32x4*)(sX + srow * LD + scol) = f32x4{rx[0], rx[1], rx[2], rx[3]};
+        *(f32x4*)(sX + srow * LD + scol + 4) = f32x4{rx[4], rx[5], rx[6], rx[7]};
+        __syncthreads();
+        if (m0 + MR < m_end) gload(m0 + MR);
+#pragma unroll
+        for (int s = 0; s < MR / 4; ++s) {
+            const int mr = s * 4 + (lane >> 4);
+            float a[2], b[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t] = sY[mr * LD + wy * 32 + t * 16 + (lane & 15)];
+                b[t] = sX[mr * LD + wx * 32 + t * 16 + (lane & 15)];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = tn * TN_ + wy * 32 + i * 16 + (lane >> 4) * 4 + r;
+                const int k = tk * TK_ + wx * 32 + j * 16 + (lane & 15);
+                if (n < p.N && k < p.K) atomicAdd(p.G + (long)n * p.ldg + k, p.alpha * acc[i][j][r]);
+            }
+}
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+extern "C" int gd_gemm_nt(const void* A, const void* W, void* C, int M, int N, int K, long lda, long ldw, long ldc,
+                          int batch, long sA, long sW, long sC, int ab_dtype, int c_dtype, float alpha,
+                          const float* bias, const float* lora_t, const float* lora_b, int lora_rt, void* preact,
+                          long ldp, int act, const void* dact_src, long ldd, int dact, const void* residual, long ldr,
+                          int accumulate, void* stream) {
+    GD_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0, "gd_gemm_nt: bad shape M=%d N=%d K=%d batch=%d", M, N, K, batch);
+    GD_REQUIRE(ab_dtype == GD_F32 || ab_dtype == GD_BF16, "gd_gemm_nt: bad ab_dtype %d", ab_dtype);
+    GD_REQUIRE(c_dtype == GD_F32 || c_dtype == GD_BF16, "gd_gemm_nt: bad c_dtype %d", c_dtype);
+    const int es = gd_dtype_size(ab_dtype);
+    GD_REQUIRE((K * es) % 16 == 0 && (lda * es) % 16 == 0 && (ldw * es) % 16 == 0 && (sA * es) % 16 == 0 &&
+                   (sW * es) % 16 == 0,
+               "gd_gemm_nt: K (%d), lda (%ld), ldw (%ld) and batch strides must be multiples of 16 bytes", K, lda, ldw);
+    GD_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0, "gd_gemm_nt: A and W must be 16-byte aligned");
+    GD_REQUIRE(lora_rt >= 0 && lora_rt <= 8, "gd_gemm_nt: lora_rt %d > 8", lora_rt);
+    GD_REQUIRE(batch == 1 || (!bias && !lora_t && !preact && !dact_src && !residual),
+               "gd_gemm_nt: batched calls take no epilogue tensors");
+    GemmNtParams p;
+    p.A = A; p.W = W; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc;
+    p.sA = sA; p.sW = sW; p.sC = sC; p.c_dtype = c_dtype; p.alpha = alpha; p.bias = bias;
+    p.lora_t = lora_t; p.lora_b = lora_b; p.lora_rt = lora_rt; p.preact = preact; p.ldp = ldp; p.act = act;
+    p.dact_src = dact_src; p.ldd = ldd; p.dact = dact_src ? dact : 0; p.residual = residual; p.ldr = ldr;
+    p.accumulate = accumulate;
+    dim3 grid(gd_cdiv(M, 128) * gd_cdiv(N, 128), batch);
+    if (ab_dtype == GD_BF16)
+        hipLaunchKernelGGL(gemm_nt_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(gemm_nt_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    GD_LAUNCH_OK();
+    return 0;
+}
+
+extern "C" int gd_gemm_tn(const void* Y, const void* X, float* G, int M, int N, int K, long ldy, long ldx, long ldg,
+                          int y_dtype, int x_dtype, float alpha, void* stream) {
+    GD_REQUIRE(M > 0 && N > 0 && K > 0, "gd_gemm_tn: bad shape M=%d N=%d K=%d", M, N, K);
+    GD_REQUIRE(N % 8 == 0 && K % 8 == 0 && ldy % 8 == 0 && ldx % 8 == 0,
+               "gd_gemm_tn: N (%d), K (%d), ldy (%ld), ldx (%ld) must be multiples of 8", N, K, ldy, ldx);
+    GD_REQUIRE(((uintptr_t)Y & 15) == 0 && ((uintptr_t)X & 15) == 0, "gd_gemm_tn: Y and X must be 16-byte aligned");
+    GemmTnParams p;
+    p.Y = Y; p.X = X; p.G = G; p.M = M; p.N = N; p.K = K; p.ldy = ldy; p.ldx = ldx; p.ldg = ldg;
+    p.y_dtype = y_dtype; p.x_dtype = x_dtype; p.alpha = alpha;
+    const int tiles = gd_cdiv(N, 64) * gd_cdiv(K, 64);
+    // enough M-chunks to fill the chip (>= ~2048 blocks) without shredding the reduction
+    int splits = (2048 + tiles - 1) / tiles;
+    int mchunk = ((gd_cdiv(M, splits) + 31) / 32) * 32;
+    if (mchunk < 256) mchunk = 256;
+    p.mchunk = mchunk;
+    dim3 grid(tiles, gd_cdiv(M, mchunk));
+    hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    GD_LAUNCH_OK();
+    return 0;
+}

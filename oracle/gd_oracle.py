@@ -1,0 +1,471 @@
+"""CPU oracle for the geometric-distillation hot path (TEST INFRASTRUCTURE ONLY).
+
+This file is a plain-PyTorch (CPU, fp32 or fp64) restatement of the reference's
+arithmetic for SURVEY.md section 8(a).  It is the checker for the HIP kernels: only
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it.  The
+product package (3d-vlm-gd_amd/) never imports anything from oracle/.
+
+Pinning: every function below is compared against the reference's own code (imported
+from /root/reference in the build container by tools/make_golden.py) and against the
+fixtures that script commits under tests/golden/.  One boundary is "parity unpinned":
+timm==0.9.10's VisionTransformer (requirements.txt:21) is not vendored in the
+reference; `vit_forward` restates its published forward and is pinned
+instead on the reference's in-tree DINOv2 ViT (vggt/layers/vision_transformer.py),
+which shares the block arithmetic.
+
+All citations are relative to /root/reference.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+# ----------------------------------------------------------------------------------
+# elementwise / sampling helpers
+# ----------------------------------------------------------------------------------
+
+
+def sigmoid_t(x, temp=1.0):
+    """utils/functions.py:24-33 — temperature sigmoid, exponent clamped to +-50."""
+    e = torch.clamp(-x / temp, min=-50.0, max=50.0)
+    return 1.0 / (1.0 + torch.exp(e))
+
+
+def keypoint_grid_coords(pts, h, w, patch_size, stride):
+    """utils/functions.py:56-65 — pixel (x,y) -> grid_sample coords in [-1,1] with
+    patch-centre alignment.  pts [B,N,2]; h,w = image size in pixels."""
+    last_h = ((h - patch_size) // stride) * stride + (patch_size / 2)
+    last_w = ((w - patch_size) // stride) * stride + (patch_size / 2)
+    ah = 2 / (last_h - (patch_size / 2))
+    aw = 2 / (last_w - (patch_size / 2))
+    bh = 1 - last_h * 2 / (last_h - (patch_size / 2))
+    bw = 1 - last_w * 2 / (last_w - (patch_size / 2))
+    a = torch.tensor([[aw, ah]], dtype=torch.float32).to(pts.device)
+    b = torch.tensor([[bw, bh]], dtype=torch.float32).to(pts.device)
+    return a * pts.float() + b
+
+
+def bilinear_sample_border(desc, g):
+    """F.grid_sample(align_corners=True, padding_mode='border', bilinear) written out.
+    desc [B,C,H,W]; g [B,N,2] in [-1,1] (x,y) -> [B,C,N]."""
+    B, C, H, W = desc.shape
+    x = (g[..., 0] + 1) * 0.5 * (W - 1)
+    y = (g[..., 1] + 1) * 0.5 * (H - 1)
+    x = x.clamp(0, W - 1)
+    y = y.clamp(0, H - 1)
+    x0 = torch.floor(x)
+    y0 = torch.floor(y)
+    wx1 = x - x0
+    wy1 = y - y0
+    x0 = x0.long()
+    y0 = y0.long()
+    x1 = (x0 + 1).clamp(max=W - 1)
+    y1 = (y0 + 1).clamp(max=H - 1)
+    flat = desc.reshape(B, C, H * W)
+
+    def take(yy, xx):
+        idx = (yy * W + xx).unsqueeze(1).expand(B, C, -1)
+        return flat.gather(2, idx)
+
+    w00 = ((1 - wx1) * (1 - wy1)).unsqueeze(1)
+    w01 = (wx1 * (1 - wy1)).unsqueeze(1)
+    w10 = ((1 - wx1) * wy1).unsqueeze(1)
+    w11 = (wx1 * wy1).unsqueeze(1)
+    return take(y0, x0) * w00 + take(y0, x1) * w01 + take(y1, x0) * w10 + take(y1, x1) * w11
+
+
+def interpolate_features(desc, pts, h, w, normalize=True, patch_size=14, stride=14):
+    """utils/functions.py:55-76.  desc [B,C,ph,pw], pts [B,N,2] px -> [B,C,N]."""
+    g = keypoint_grid_coords(pts, h, w, patch_size, stride).to(desc.dtype)
+    out = bilinear_sample_border(desc, g)
+    return F.normalize(out, dim=1) if normalize else out
+
+
+def extract_kp_depth(depth_map, kp, window_size=3):
+    """utils/functions.py:348-372 — 3x3 replicate-padded mean of depth at integer kps.
+    depth_map [H,W]; kp [B,N,2] (x,y) -> [B,N]."""
+    H, W = depth_map.shape[-2:]
+    half = window_size // 2
+    padded = F.pad(depth_map.reshape(1, 1, H, W), (half,) * 4, mode="replicate")
+    means = F.avg_pool2d(padded, window_size, stride=1).reshape(1, H * W)
+    idx = (kp[..., 1] * W + kp[..., 0]).long()
+    return means.expand(kp.shape[0], -1).gather(1, idx)
+
+
+def patch_mask_from_kp(kp_xy, H, W, patch_size):
+    """utils/functions.py:375-399 — bool [ (H//P)*(W//P) ] of patches holding a keypoint."""
+    ph, pw = H // patch_size, W // patch_size
+    ok = (kp_xy[:, 0] >= 0) & (kp_xy[:, 0] < W) & (kp_xy[:, 1] >= 0) & (kp_xy[:, 1] < H)
+    mask = torch.zeros(ph * pw, dtype=torch.bool, device=kp_xy.device)
+    k = kp_xy[ok]
+    if k.shape[0]:
+        mask[(k[:, 1].long() // patch_size) * pw + (k[:, 0].long() // patch_size)] = True
+    return mask
+
+
+# ----------------------------------------------------------------------------------
+# dense cost-volume KL (a14-a16)
+# ----------------------------------------------------------------------------------
+
+
+def masked_patch_cost(cost, row_mask, eps=1e-8, use_softmax=False, temperature=1.0):
+    """utils/functions.py:402-422 with mask_patch_2=None: zero masked-out rows, then
+    softmax(/T) or divide by clamp_min(row_sum, eps)."""
+    c = cost * row_mask.to(cost.dtype).reshape(1, -1, 1)
+    if use_softmax:
+        return torch.softmax(c / temperature, dim=-1)
+    return c / c.sum(-1, keepdim=True).clamp_min(eps)
+
+
+def kl_divergence_map(t, p, eps=1e-8):
+    """utils/losses.py:5-15."""
+    t = t.clamp_min(eps)
+    p = p.clamp_min(eps)
+    return (t * torch.log(t / p)).sum(-1).mean()
+
+
+def cost_volume_kl(f1, f2, t1, t2, m1, m2, variant):
+    """calculate_cost_loss: src/finetune_timm_vggt.py:509-533 (variant='vggt') and
+    src/finetune_timm_mast3r.py:522-540 (variant='mast3r').
+    f1,f2 [1,hw,C] raw student features; t1,t2 [1,hw,hw] teacher maps; m1,m2 bool [hw]."""
+    a = F.normalize(f1, p=2, dim=-1)
+    b = F.normalize(f2, p=2, dim=-1)
+    s12 = a @ b.transpose(-1, -2)
+    s21 = b @ a.transpose(-1, -2)
+    tt1 = masked_patch_cost(t1, m1)
+    tt2 = masked_patch_cost(t2, m2)
+    if variant == "vggt":
+        p12 = masked_patch_cost(torch.softmax(s12, -1), m1)
+        p21 = masked_patch_cost(torch.softmax(s21, -1), m2)
+    elif variant == "mast3r":
+        p12 = masked_patch_cost(s12, m1, use_softmax=True)
+        p21 = masked_patch_cost(s21, m2, use_softmax=True)
+    else:
+        raise ValueError(variant)
+    return 0.5 * (kl_divergence_map(tt1, p12) + kl_divergence_map(tt2, p21))
+
+
+# ----------------------------------------------------------------------------------
+# sparse correspondence smooth-AP (a8)
+# ----------------------------------------------------------------------------------
+
+
+def smooth_ap_loss(desc1, desc2, pts3d_1, pts3d_2, variant, thres3d_neg=0.1, temp=0.01):
+    """calculate_matching_loss on L2-normalised descriptors.
+    src/finetune_timm_vggt.py:543-572 (variant='vggt': ap1 uses sigmoid(1-pos)),
+    src/finetune_timm_mast3r.py:560-589 (variant='mast3r': ap1 uses sigmoid(pos-1)).
+    desc [1,N,C]; pts3d [1,N,3]."""
+    N = desc1.shape[1]
+    eye = torch.eye(N, dtype=torch.bool, device=desc1.device).unsqueeze(0)
+    neg = ((torch.cdist(pts3d_1, pts3d_2) > thres3d_neg) & ~eye)[0].to(desc1.dtype)
+    sim = (desc1 @ desc2.transpose(-1, -2))[0]
+    pos = sim.diagonal()
+    if variant == "vggt":
+        rpos1 = sigmoid_t(1.0 - pos, temp) + 1
+    else:
+        rpos1 = sigmoid_t(pos - 1.0, temp) + 1
+    ap1 = rpos1 / (rpos1 + (sigmoid_t(sim - 1.0, temp) * neg).sum(-1))
+    rpos2 = sigmoid_t(1.0 - pos, temp) + 1
+    ap2 = rpos2 / (rpos2 + (sigmoid_t(sim - pos[:, None], temp) * neg).sum(-1))
+    return torch.mean(1.0 - (ap1 + ap2) / 2)
+
+
+def smooth_ap_loss_me(desc1, desc2, pts3d_1, pts3d_2, thres3d_pos=5e-3, thres3d_neg=0.1, temp=0.01):
+    """ME variant, src/finetune_timm_me.py:191-220: positives are every (i,j) with
+    3-D distance < thres3d_pos (dynamic count), negatives distance > thres3d_neg."""
+    d = torch.cdist(pts3d_1, pts3d_2)[0]
+    sim = (desc1 @ desc2.transpose(-1, -2))[0]
+    negm = (d > thres3d_neg).to(sim.dtype)
+    ii, jj = torch.nonzero(d < thres3d_pos, as_tuple=True)
+    pos = sim[ii, jj]
+    rows = sim[ii]
+    nrows = negm[ii]
+    rpos = sigmoid_t(pos - 1.0, temp) + 1
+    ap1 = rpos / (rpos + (sigmoid_t(rows - 1.0, temp) * nrows).sum(-1))
+    rpos2 = sigmoid_t(1.0 - pos, temp) + 1
+    ap2 = rpos2 / (rpos2 + (sigmoid_t(rows - pos[:, None], temp) * nrows).sum(-1))
+    return torch.mean(1.0 - (ap1 + ap2) / 2)
+
+
+# ----------------------------------------------------------------------------------
+# relative-depth head and ranking loss (a10-a12)
+# ----------------------------------------------------------------------------------
+
+
+def depth_head(x, hp):
+    """DepthAwareFeatureFusion.forward with depths=None (utils/model.py:101-127):
+    tanh(Linear(128->1)(GELU(LayerNorm(Linear(D->128)(x))))).  hp: dict of tensors
+    'w1'[128,D] 'b1'[128] 'ln_w'[128] 'ln_b'[128] 'w2'[1,128] 'b2'[1]."""
+    h = F.linear(x, hp["w1"], hp["b1"])
+    h = F.layer_norm(h, (h.shape[-1],), hp["ln_w"], hp["ln_b"], 1e-5)
+    h = F.gelu(h)
+    return torch.tanh(F.linear(h, hp["w2"], hp["b2"])).squeeze(-1)
+
+
+def pairwise_ranking_loss(hp, feats, depths, depth_threshold=0.05):
+    """utils/losses.py:18-41 — head(f_j - f_i) against sign(d_j - d_i) over pairs with
+    |d_j - d_i| > threshold; log(1+exp(-alpha*s)) mean.  feats [1,N,D], depths [1,N]."""
+    f = feats[0]
+    d = depths[0]
+    diff = f.unsqueeze(0) - f.unsqueeze(1)  # [i, j, :] = f_j - f_i
+    s = depth_head(diff, hp)
+    dd = d.unsqueeze(0) - d.unsqueeze(1)  # d_j - d_i
+    alpha = torch.sign(dd)
+    valid = dd.abs() > depth_threshold
+    if not bool(valid.any()):
+        return torch.zeros((), dtype=feats.dtype, device=feats.device)
+    per = torch.log(1.0 + torch.exp(-alpha * s))
+    return per[valid].mean()
+
+
+def depth_losses(hp, kp_feat_1, kp_feat_2, kp_depth_1, kp_depth_2, depth_threshold=0.05):
+    """calculate_depth_loss tail (src/finetune_timm_vggt.py:472-485,
+    src/finetune_timm_mast3r.py:487-501): L1(head(f1-f2), tanh(d1-d2)) and the mean of
+    the two intra-view ranking losses."""
+    pred = depth_head(kp_feat_1 - kp_feat_2, hp)
+    l1 = (pred - torch.tanh(kp_depth_1 - kp_depth_2)).abs().mean()
+    r = 0.5 * (pairwise_ranking_loss(hp, kp_feat_1, kp_depth_1, depth_threshold)
+               + pairwise_ranking_loss(hp, kp_feat_2, kp_depth_2, depth_threshold))
+    return l1, r
+
+
+# ----------------------------------------------------------------------------------
+# student ViT (a1-a3): timm/DINOv2-style pre-LN transformer with LoRA(q,v) + adapters
+# ----------------------------------------------------------------------------------
+
+
+def resample_pos_embed(pos_embed, gh, gw, num_prefix, mode="dinov2", interpolate_offset=0.1):
+    """Learned abs-pos-embed resampled to a gh x gw token grid.
+    mode='dinov2': vggt/layers/vision_transformer.py:181-213 (bicubic, scale_factor kludge
+    with +0.1 offset, no antialias).  mode='timm': timm 0.9.10 resample_abs_pos_embed
+    (bicubic, antialias=True, explicit size) — unpinned (timm not vendored)."""
+    pe = pos_embed.float()
+    prefix, grid = pe[:, :num_prefix], pe[:, num_prefix:]
+    n = grid.shape[1]
+    m = int(math.sqrt(n))
+    assert m * m == n
+    dim = pe.shape[-1]
+    if m == gh and m == gw:
+        return pe
+    g = grid.reshape(1, m, m, dim).permute(0, 3, 1, 2)
+    if mode == "dinov2":
+        if interpolate_offset:
+            g = F.interpolate(g, mode="bicubic", antialias=False,
+                              scale_factor=(float(gh + interpolate_offset) / m, float(gw + interpolate_offset) / m))
+        else:
+            g = F.interpolate(g, mode="bicubic", antialias=False, size=(gh, gw))
+    else:
+        g = F.interpolate(g, mode="bicubic", antialias=True, size=(gh, gw), align_corners=False)
+    assert g.shape[-2:] == (gh, gw)
+    g = g.permute(0, 2, 3, 1).reshape(1, gh * gw, dim)
+    return torch.cat([prefix, g], dim=1)
+
+
+def lora_qkv(x, w, b, lora):
+    """utils/model.py:57-71 — qkv = Wx+b; q-slice += B_q A_q x; v-slice += B_v A_v x."""
+    qkv = F.linear(x, w, b)
+    if lora is not None:
+        D = x.shape[-1]
+        dq = F.linear(F.linear(x, lora["a_q"]), lora["b_q"])
+        dv = F.linear(F.linear(x, lora["a_v"]), lora["b_v"])
+        qkv = torch.cat([qkv[..., :D] + dq, qkv[..., D:2 * D], qkv[..., 2 * D:] + dv], dim=-1)
+    return qkv
+
+
+def adapter(x, ad):
+    """utils/model.py:7-25 — BlockWithAdapter: out + up(relu(down(out)))."""
+    return x + F.linear(F.relu(F.linear(x, ad["down"])), ad["up"])
+
+
+def vit_block(x, p, i, cfg, lora=None, ad=None):
+    """One pre-LN block (vggt/layers/block.py:81-134 eval path):
+    x += ls1(proj(sdpa(qkv(norm1 x)))) ; x += ls2(fc2(gelu(fc1(norm2 x)))) ; [adapter]."""
+    pre = f"blocks.{i}."
+    B, N, D = x.shape
+    h = cfg["heads"]
+    d = D // h
+    eps = cfg["ln_eps"]
+    y = F.layer_norm(x, (D,), p[pre + "norm1.weight"], p[pre + "norm1.bias"], eps)
+    qkv = lora_qkv(y, p[pre + "attn.qkv.weight"], p.get(pre + "attn.qkv.bias"), lora)
+    q, k, v = qkv.reshape(B, N, 3, h, d).permute(2, 0, 3, 1, 4).unbind(0)
+    s = (q * d ** -0.5) @ k.transpose(-1, -2)
+    a = torch.softmax(s, dim=-1) @ v
+    a = a.transpose(1, 2).reshape(B, N, D)
+    a = F.linear(a, p[pre + "attn.proj.weight"], p.get(pre + "attn.proj.bias"))
+    if pre + "ls1.gamma" in p:
+        a = a * p[pre + "ls1.gamma"]
+    x = x + a
+    y = F.layer_norm(x, (D,), p[pre + "norm2.weight"], p[pre + "norm2.bias"], eps)
+    y = F.gelu(F.linear(y, p[pre + "mlp.fc1.weight"], p.get(pre + "mlp.fc1.bias")))
+    y = F.linear(y, p[pre + "mlp.fc2.weight"], p.get(pre + "mlp.fc2.bias"))
+    if pre + "ls2.gamma" in p:
+        y = y * p[pre + "ls2.gamma"]
+    x = x + y
+    if ad is not None:
+        x = adapter(x, ad)
+    return x
+
+
+def vit_tokens(img, p, cfg):
+    """patch-embed conv (PxP stride P) + cls + resampled pos-embed (+ norm_pre when
+    cfg['pre_norm']).  img [B,3,H,W] already normalised."""
+    P = cfg["patch"]
+    x = F.conv2d(img, p["patch_embed.proj.weight"], p.get("patch_embed.proj.bias"), stride=P)
+    B, D, gh, gw = x.shape
+    x = x.flatten(2).transpose(1, 2)
+    x = torch.cat([p["cls_token"].expand(B, -1, -1), x], dim=1)
+    x = x + resample_pos_embed(p["pos_embed"], gh, gw, 1, cfg.get("pos_interp", "dinov2")).to(x.dtype)
+    if cfg.get("pre_norm", False):
+        x = F.layer_norm(x, (D,), p["norm_pre.weight"], p["norm_pre.bias"], cfg["ln_eps"])
+    return x
+
+
+def vit_forward(img, p, cfg, trainable=None, taps=()):
+    """Returns (list of tap outputs [B,Nt,D] in `taps` order, x after the last block).
+    trainable: {'lora': {blk: {...}}, 'adapter': {blk: {...}}} or None."""
+    x = vit_tokens(img, p, cfg)
+    outs = {}
+    for i in range(cfg["depth"]):
+        lo = trainable["lora"].get(i) if trainable else None
+        ad = trainable["adapter"].get(i) if trainable else None
+        x = vit_block(x, p, i, cfg, lo, ad)
+        if i in taps:
+            outs[i] = x
+    return [outs[i] for i in taps], x
+
+
+def final_norm(x, p, cfg):
+    return F.layer_norm(x, (x.shape[-1],), p["norm.weight"], p["norm.bias"], cfg["ln_eps"])
+
+
+def normalize_image(img, mean, std):
+    """a0: timm Normalize (src/finetune_timm_mast3r.py:103-104,153)."""
+    m = torch.tensor(mean, dtype=img.dtype, device=img.device).reshape(1, 3, 1, 1)
+    s = torch.tensor(std, dtype=img.dtype, device=img.device).reshape(1, 3, 1, 1)
+    return (img - m) / s
+
+
+def resize_bilinear(img, size):
+    """a0: torchvision 0.16.2 tensor resize = bilinear, align_corners=False, no antialias."""
+    if tuple(img.shape[-2:]) == tuple(size):
+        return img
+    return F.interpolate(img, size=tuple(size), mode="bilinear", align_corners=False, antialias=False)
+
+
+# ----------------------------------------------------------------------------------
+# feature extractors (a4-a6) and the full loss / optimiser step (a21)
+# ----------------------------------------------------------------------------------
+
+
+def keypoint_geometry(h, w, cfg):
+    """Token grid used for keypoint features.  'reference': target_res/downsample_factor
+    (src/finetune_timm_vggt.py:265-270); 'shared': the cost grid itself."""
+    if cfg.get("geometry", "reference") == "shared":
+        return h // cfg["teacher_patch"], w // cfg["teacher_patch"]
+    tr, ds = cfg.get("target_res", 640), cfg.get("downsample_factor", 8)
+    if h > w:
+        tgt = (tr, int(w * tr / h))
+    else:
+        tgt = (int(h * tr / w), tr)
+    return tgt[0] // ds, tgt[1] // ds
+
+
+def student_features(img, kp, p, cfg, trainable, refine):
+    """One image through the three extractors of the reference step.
+    img [1,3,h,w] in [0,1]; kp [1,N,2] px (x,y) in the (h,w) frame.
+    Returns kp_feat [1,N,D] (get_intermediate_feature), desc [1,N,D] unit (get_feature),
+    cost_feat [1,hw,D] (get_feature_cost).
+    src/finetune_timm_vggt.py:256-355, src/finetune_timm_mast3r.py:242-342."""
+    P = cfg["patch"]
+    h, w = img.shape[-2:]
+    gh, gw = keypoint_geometry(h, w, cfg)
+    big = normalize_image(resize_bilinear(img, (gh * P, gw * P)), cfg["mean"], cfg["std"])
+    sc = torch.tensor([(gw * P) / w, (gh * P) / h], dtype=torch.float32)
+    pts = kp * sc
+    taps, x = vit_forward(big, p, cfg, trainable, taps=(4, 5, 6, 7))
+
+    def grid(t):
+        return t[:, 1:].reshape(1, gh, gw, -1).permute(0, 3, 1, 2)
+
+    samp = [interpolate_features(grid(final_norm(t, p, cfg)), pts, gh * P, gw * P, False, P, P) for t in taps]
+    kp_feat = torch.stack(samp, 0).mean(0).permute(0, 2, 1)
+    fmap = F.conv2d(grid(final_norm(x, p, cfg)), refine["weight"], refine["bias"], padding=1)
+    desc = F.normalize(interpolate_features(fmap, pts, gh * P, gw * P, False, P, P).permute(0, 2, 1), dim=-1)
+
+    tp = cfg["teacher_patch"]
+    ch, cw = h // tp, w // tp
+    small = normalize_image(resize_bilinear(img, (ch * P, cw * P)), cfg["mean"], cfg["std"])
+    if cfg["variant"] == "vggt":
+        ctaps = (7,)
+    else:
+        ctaps = (4, 5, 6, 7)
+    if (ch, cw) == (gh, gw):
+        ct = [taps[(4, 5, 6, 7).index(i)] for i in ctaps]
+    else:
+        ct, _ = vit_forward(small, p, cfg, trainable, taps=ctaps)
+    cost_feat = torch.stack([t[:, 1:] for t in ct], 0).mean(0)
+    return kp_feat, desc, cost_feat
+
+
+def pair_losses(batch, p, cfg, trainable, refine, hp):
+    """Loss terms of one image pair = training_step body after the teacher
+    (src/finetune_timm_vggt.py:599-616, src/finetune_timm_mast3r.py:635-653)."""
+    f1 = student_features(batch["rgb_1"], batch["kp_1"], p, cfg, trainable, refine)
+    f2 = student_features(batch["rgb_2"], batch["kp_2"], p, cfg, trainable, refine)
+    d1 = extract_kp_depth(batch["depth_1"], batch["kp_1"])
+    d2 = extract_kp_depth(batch["depth_2"], batch["kp_2"])
+    depth_l1, intra = depth_losses(hp, f1[0], f2[0], d1, d2)
+    h, w = batch["rgb_1"].shape[-2:]
+    if cfg["variant"] == "vggt":
+        m1, m2 = batch["mask_patch_1"], batch["mask_patch_2"]
+    else:
+        m1 = patch_mask_from_kp(batch["kp_1"][0], h, w, cfg["patch"])
+        m2 = patch_mask_from_kp(batch["kp_2"][0], h, w, cfg["patch"])
+    kl = cost_volume_kl(f1[2], f2[2], batch["cost_1"], batch["cost_2"], m1, m2, cfg["variant"])
+    ap = smooth_ap_loss(f1[1], f2[1], batch["pts3d_1"], batch["pts3d_2"], cfg["variant"])
+    return {"ap": ap, "depth": depth_l1, "intra": intra, "kl": kl}
+
+
+def total_loss(terms, weights):
+    return (weights["ap"] * terms["ap"] + weights["depth"] * terms["depth"]
+            + weights["intra"] * terms["intra"] + weights["kl"] * terms["kl"])
+
+
+def clip_and_adamw(params, grads, state, step, lr=1e-5, wd=1e-4, betas=(0.9, 0.999), eps=1e-8, max_norm=1.0):
+    """Lightning gradient_clip_val=1.0 (global L2 norm, src/main.py:153) followed by
+    torch.optim.AdamW(lr=1e-5, weight_decay=1e-4) (src/finetune_timm_vggt.py:642-648).
+    In place on `params`; `state` = list of (exp_avg, exp_avg_sq); `step` 1-based."""
+    total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads)).float()
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    for q, g, (m, v) in zip(params, grads, state):
+        g = g * coef
+        q.mul_(1 - lr * wd)
+        m.mul_(betas[0]).add_(g, alpha=1 - betas[0])
+        v.mul_(betas[1]).addcmul_(g, g, value=1 - betas[1])
+        bc1 = 1 - betas[0] ** step
+        bc2 = 1 - betas[1] ** step
+        q.addcdiv_(m, (v.sqrt() / math.sqrt(bc2)).add_(eps), value=-lr / bc1)
+    return total
+
+
+# ----------------------------------------------------------------------------------
+# teacher-side native op: 2-D RoPE
+# ----------------------------------------------------------------------------------
+
+
+def rope_2d(tokens, positions, base=100.0, fwd=1.0):
+    """dust3r/croco/models/curope/curope.cpp:11-47 / kernels.cu:17-82.
+    tokens [B,N,H,D] (returns a new tensor); positions int64 [B,N,2] (y,x);
+    D = 4 quarters [u_Y, v_Y, u_X, v_X]; theta = pos*fwd / base^(i/Q)."""
+    B, N, H, D = tokens.shape
+    Q = D // 4
+    inv = fwd / (base ** (torch.arange(Q, dtype=torch.float32) / Q))
+    out = tokens.clone()
+    for ax in range(2):
+        th = positions[..., ax].float().unsqueeze(-1) * inv  # [B,N,Q]
+        c, s = torch.cos(th).unsqueeze(2), torch.sin(th).unsqueeze(2)
+        u = tokens[..., (2 * ax) * Q:(2 * ax + 1) * Q]
+        v = tokens[..., (2 * ax + 1) * Q:(2 * ax + 2) * Q]
+        out[..., (2 * ax) * Q:(2 * ax + 1) * Q] = u * c - v * s
+        out[..., (2 * ax + 1) * Q:(2 * ax + 2) * Q] = v * c + u * s
+    return out
