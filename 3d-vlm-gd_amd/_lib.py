@@ -1,0 +1,77 @@
+"""ctypes binding of lib/libgd_hip.so (the C ABI declared in include/gd_hip.h).
+
+There is NO CPU fallback: if the library is missing or a kernel reports an error the call
+raises.  `lib()` loads lazily so that CPU-only tooling can import the package."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgd_hip.so")
+_lib = None
+
+F32, BF16 = 0, 1
+
+c_int, c_long, c_float, c_void_p, c_size_t = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+
+# name -> (restype, argtypes).  Must list every symbol of include/gd_hip.h (tests check this).
+SIGNATURES = {
+    "gd_last_error": (ctypes.c_char_p, []),
+    "gd_abi_version": (c_int, []),
+    "gd_gemm_nt": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_long, c_long,
+                           c_int, c_long, c_long, c_long, c_int, c_int, c_float,
+                           c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_long, c_int,
+                           c_void_p, c_long, c_int, c_void_p, c_long, c_int, c_void_p]),
+    "gd_gemm_tn": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_long, c_long,
+                           c_int, c_int, c_float, c_void_p]),
+    "gd_attention_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "gd_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                 c_int, c_float, c_int, c_void_p]),
+    "gd_cost_volume_kl_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "gd_cost_volume_kl_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                      c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gd_cost_volume_kl_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                      c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+}
+
+
+class GdHipError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GdHipError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback for the HIP path)")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise GdHipError(f"{what} failed (rc={rc}): {lib().gd_last_error().decode()}")
+
+
+def dtype_code(t):
+    import torch
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise GdHipError(f"unsupported dtype {t.dtype}")
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

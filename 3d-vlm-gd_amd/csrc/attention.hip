@@ -1,0 +1,452 @@
+// Flash-style multi-head self-attention for the student ViT (head_dim 64), forward and backward,
+// on 16x16 MFMA tiles in a TRANSPOSED formulation (gfx950):
+//
+//   forward, per wave 32 queries:   S^T = K Q^T   (keys on C-rows, queries on C-columns = lanes)
+//                                   O^T += V^T P^T
+//   With queries on the lane axis the softmax statistics (m, l) and the rescale factor are per-lane
+//   scalars, the row reductions are in-register plus two cross-lane-group shuffles, and the S^T
+//   accumulator tiles are directly the B operand of the second product (k-slot permutation shared
+//   with the transposed V tile) — P never goes through LDS.
+//
+//   backward = two kernels (deterministic, no atomics):
+//     attn_bwd_dq  (query owner): recompute S^T, dP^T = V dO^T, dS^T = P^T o (dP^T - delta), dQ^T += K^T dS^T
+//     attn_bwd_dkv (key owner)  : S = Q K^T, dP = dO V^T, dV^T += dO^T P, dK^T += Q^T dS
+//
+// Replaces F.scaled_dot_product_attention inside timm's Attention (restated from
+// vggt/layers/attention.py:51-71): softmax((q*scale) k^T) v with scale = head_dim^-0.5.
+// qkv is the packed [B, N, 3, H, 64] output of the QKV GEMM; o is [B, N, H*64]; lse is [B, H, N] (natural log).
+#include "gd_common.h"
+
+#define HD 64
+
+template <typename T> struct AT;
+template <> struct AT<bf16> {
+    static constexpr int NF = 2;        // fragments per 64-wide contraction
+    static constexpr int ROWB = 144;    // LDS row: 64 el * 2 B + 16 pad
+    static constexpr int CPR = 8;       // 16-byte chunks per 64-element row
+    static constexpr int EPC = 8;       // elements per chunk
+};
+template <> struct AT<float> {
+    static constexpr int NF = 4;
+    static constexpr int ROWB = 272;
+    static constexpr int CPR = 16;
+    static constexpr int EPC = 4;
+};
+
+// four C-layout tiles that span 64 contraction indices (index = 16*tile + 4*g + r) -> B fragment u
+template <typename T> __device__ __forceinline__ typename Mma<T>::Frag acc_to_bfrag(const f32x4 (&t)[4], int u);
+template <> __device__ __forceinline__ bf16x8 acc_to_bfrag<bf16>(const f32x4 (&t)[4], int u) {
+    const f32x4 a = t[2 * u], b = t[2 * u + 1];
+    return bf16x8{(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};
+}
+template <> __device__ __forceinline__ f32x4 acc_to_bfrag<float>(const f32x4 (&t)[4], int u) { return t[u]; }
+
+// matching A fragment from a transposed LDS tile row (64 contraction indices contiguous)
+template <typename T> __device__ __forceinline__ typename Mma<T>::Frag load_tfrag(const char* row, int u, int g);
+template <> __device__ __forceinline__ bf16x8 load_tfrag<bf16>(const char* row, int u, int g) {
+    const bf16x4 a = *(const bf16x4*)(row + (32 * u + 4 * g) * 2);
+    const bf16x4 b = *(const bf16x4*)(row + (32 * u + 16 + 4 * g) * 2);
+    return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+template <> __device__ __forceinline__ f32x4 load_tfrag<float>(const char* row, int u, int g) {
+    return *(const f32x4*)(row + (16 * u + 4 * g) * 4);
+}
+
+// natural fragment u (16 bytes) of a [row][64] LDS tile row / global row
+template <typename T> __device__ __forceinline__ typename Mma<T>::Frag load_nfrag(const char* row, int u, int g) {
+    return *(const typename Mma<T>::Frag*)(row + u * 64 + g * 16);
+}
+
+// Stage `rows` (<= 64) rows of a [*, 64]-element matrix (global row stride ld_b bytes) into LDS, both as a
+// natural tile sN[row][64] and/or a transposed tile sT[col][row].  Rows >= valid read as zero.
+template <typename T, bool NAT, bool TRN>
+__device__ __forceinline__ void stage_tile(const char* gbase, long ld_b, int row0, int nvalid, char* sN, char* sT) {
+    constexpr int CPR = AT<T>::CPR, EPC = AT<T>::EPC, ROWB = AT<T>::ROWB;
+    for (int ch = threadIdx.x; ch < 64 * CPR; ch += 256) {
+        const int r = ch / CPR, cc = ch % CPR;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row0 + r < nvalid) v = *(const uint4*)(gbase + (long)(row0 + r) * ld_b + cc * 16);
+        if (NAT) *(uint4*)(sN + r * ROWB + cc * 16) = v;
+        if (TRN) {
+            const T* e = (const T*)&v;
+#pragma unroll
+            for (int k = 0; k < EPC; ++k) *(T*)(sT + (cc * EPC + k) * ROWB + r * (int)sizeof(T)) = e[k];
+        }
+    }
+}
+
+template <typename T> __device__ __forceinline__ void store4(T* p, f32x4 v);
+template <> __device__ __forceinline__ void store4<float>(float* p, f32x4 v) { *(f32x4*)p = v; }
+template <> __device__ __forceinline__ void store4<bf16>(bf16* p, f32x4 v) {
+    *(bf16x4*)p = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+}
+
+// ------------------------------------------------------------------------------------------ forward
+template <typename T>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* qkv, T* o, float* lse, int N, int H, float scale) {
+    constexpr int NF = AT<T>::NF, ROWB = AT<T>::ROWB;
+    typedef typename Mma<T>::Frag Frag;
+    __shared__ __attribute__((aligned(16))) char sK[64 * ROWB];
+    __shared__ __attribute__((aligned(16))) char sVt[64 * ROWB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128 + wave * 32;
+    const long ld_b = (long)3 * H * HD * sizeof(T);
+    const char* base = (const char*)qkv + (long)b * N * ld_b;
+    const char* qb = base + (long)(0 * H + h) * HD * sizeof(T);
+    const char* kb = base + (long)(1 * H + h) * HD * sizeof(T);
+    const char* vb = base + (long)(2 * H + h) * HD * sizeof(T);
+
+    Frag qf[2][NF];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int q = q0 + qt * 16 + c;
+#pragma unroll
+        for (int u = 0; u < NF; ++u) {
+            if (q < N) qf[qt][u] = load_nfrag<T>(qb + (long)q * ld_b, u, g);
+            else { Frag z = {}; qf[qt][u] = z; }
+        }
+    }
+    f32x4 oacc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) oacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m[2] = {-1e30f, -1e30f}, l[2] = {0.f, 0.f};
+
+    for (int k0 = 0; k0 < N; k0 += 64) {
+        __syncthreads();
+        stage_tile<T, true, false>(kb, ld_b, k0, N, sK, nullptr);
+        stage_tile<T, false, true>(vb, ld_b, k0, N, nullptr, sVt);
+        __syncthreads();
+        f32x4 s[2][4];  // [qt][key tile]
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            Frag kf[NF];
+#pragma unroll
+            for (int u = 0; u < NF; ++u) kf[u] = load_nfrag<T>(sK + (kt * 16 + c) * ROWB, u, g);
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < NF; ++u) a = Mma<T>::mma(kf[u], qf[qt][u], a);
+                s[qt][kt] = a;
+            }
+        }
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            float tmax = -1e30f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = k0 + kt * 16 + g * 4 + r;
+                    const float v = key < N ? s[qt][kt][r] * scale : -1e30f;
+                    s[qt][kt][r] = v;
+                    tmax = fmaxf(tmax, v);
+                }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float mn = fmaxf(m[qt], tmax);
+            const float alpha = __expf(m[qt] - mn);
+            float ps = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __expf(s[qt][kt][r] - mn);
+                    s[qt][kt][r] = p;
+                    ps += p;
+                }
+            ps += __shfl_xor(ps, 16, 64);
+            ps += __shfl_xor(ps, 32, 64);
+            l[qt] = l[qt] * alpha + ps;
+            m[qt] = mn;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) oacc[dt][qt] *= alpha;
+        }
+#pragma unroll
+        for (int u = 0; u < NF; ++u) {
+            Frag pf[2];
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) pf[qt] = acc_to_bfrag<T>(s[qt], u);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const Frag vf = load_tfrag<T>(sVt + (dt * 16 + c) * ROWB, u, g);
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) oacc[dt][qt] = Mma<T>::mma(vf, pf[qt], oacc[dt][qt]);
+            }
+        }
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int q = q0 + qt * 16 + c;
+        if (q >= N) continue;
+        const float inv = 1.0f / l[qt];
+        T* orow = o + ((long)b * N + q) * H * HD + h * HD;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) store4<T>(orow + dt * 16 + g * 4, oacc[dt][qt] * inv);
+        if (g == 0) lse[((long)b * H + h) * N + q] = m[qt] + __logf(l[qt]);
+    }
+}
+
+// delta[b,h,q] = sum_d dO[b,q,h,d] * O[b,q,h,d]
+template <typename T>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const T* o, const T* dout, float* delta, int N, int H, long total) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;  // over B*N*H*16 : 16 lanes x 4 elements per (b,q,h)
+    const long item = idx >> 4;
+    const int part = idx & 15;
+    float acc = 0.f;
+    if (item < total) {
+        const T* po = o + item * HD + part * 4;
+        const T* pd = dout + item * HD + part * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc += to_f32<T>(po[k]) * to_f32<T>(pd[k]);
+    }
+#pragma unroll
+    for (int ofs = 1; ofs < 16; ofs <<= 1) acc += __shfl_xor(acc, ofs, 64);
+    if (item < total && part == 0) {
+        const long bq = item / H;
+        const int h = item % H;
+        const long bb = bq / N;
+        const int q = bq % N;
+        delta[(bb * H + h) * N + q] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ backward: dQ
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* qkv, const T* dout, const float* lse,
+                                                          const float* delta, T* dqkv, int N, int H, float scale) {
+    constexpr int NF = AT<T>::NF, ROWB = AT<T>::ROWB;
+    typedef typename Mma<T>::Frag Frag;
+    __shared__ __attribute__((aligned(16))) char sK[64 * ROWB];
+    __shared__ __attribute__((aligned(16))) char sKt[64 * ROWB];
+    __shared__ __attribute__((aligned(16))) char sV[64 * ROWB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128 + wave * 32;
+    const long ld_b = (long)3 * H * HD * sizeof(T);
+    const char* base = (const char*)qkv + (long)b * N * ld_b;
+    const char* qb = base + (long)(0 * H + h) * HD * sizeof(T);
+    const char* kb = base + (long)(1 * H + h) * HD * sizeof(T);
+    const char* vb = base + (long)(2 * H + h) * HD * sizeof(T);
+    const long ldo_b = (long)H * HD * sizeof(T);
+    const char* dob = (const char*)dout + (long)b * N * ldo_b + (long)h * HD * sizeof(T);
+
+    Frag qf[2][NF], dof[2][NF];
+    float lq[2], dl[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int q = q0 + qt * 16 + c;
+        const bool ok = q < N;
+#pragma unroll
+        for (int u = 0; u < NF; ++u) {
+            Frag z = {};
+            qf[qt][u] = ok ? load_nfrag<T>(qb + (long)q * ld_b, u, g) : z;
+            dof[qt][u] = ok ? load_nfrag<T>(dob + (long)q * ldo_b, u, g) : z;
+        }
+        lq[qt] = ok ? lse[((long)b * H + h) * N + q] : 0.f;
+        dl[qt] = ok ? delta[((long)b * H + h) * N + q] : 0.f;
+    }
+    f32x4 dq[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) dq[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int k0 = 0; k0 < N; k0 += 64) {
+        __syncthreads();
+        stage_tile<T, true, true>(kb, ld_b, k0, N, sK, sKt);
+        stage_tile<T, true, false>(vb, ld_b, k0, N, sV, nullptr);
+        __syncthreads();
+        f32x4 ds[2][4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            Frag kf[NF], vf[NF];
+#pragma unroll
+            for (int u = 0; u < NF; ++u) {
+                kf[u] = load_nfrag<T>(sK + (kt * 16 + c) * ROWB, u, g);
+                vf[u] = load_nfrag<T>(sV + (kt * 16 + c) * ROWB, u, g);
+            }
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < NF; ++u) {
+                    s = Mma<T>::mma(kf[u], qf[qt][u], s);
+                    dp = Mma<T>::mma(vf[u], dof[qt][u], dp);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = k0 + kt * 16 + g * 4 + r;
+                    const float p = key < N ? __expf(s[r] * scale - lq[qt]) : 0.f;
+                    ds[qt][kt][r] = p * (dp[r] - dl[qt]) * scale;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NF; ++u) {
+            Frag df[2];
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) df[qt] = acc_to_bfrag<T>(ds[qt], u);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const Frag kf = load_tfrag<T>(sKt + (dt * 16 + c) * ROWB, u, g);
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) dq[dt][qt] = Mma<T>::mma(kf, df[qt], dq[dt][qt]);
+            }
+        }
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int q = q0 + qt * 16 + c;
+        if (q >= N) continue;
+        T* row = dqkv + ((long)b * N + q) * 3 * H * HD + (long)(0 * H + h) * HD;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) store4<T>(row + dt * 16 + g * 4, dq[dt][qt]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ backward: dK, dV
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* qkv, const T* dout, const float* lse,
+                                                           const float* delta, T* dqkv, int N, int H, float scale) {
+    constexpr int NF = AT<T>::NF, ROWB = AT<T>::ROWB;
+    typedef typename Mma<T>::Frag Frag;
+    __shared__ __attribute__((aligned(16))) char sQ[64 * ROWB];
+    __shared__ __attribute__((aligned(16))) char sQt[64 * ROWB];
+    __shared__ __attribute__((aligned(16))) char sD[64 * ROWB];
+    __shared__ __attribute__((aligned(16))) char sDt[64 * ROWB];
+    __shared__ float sL[64], sDl[64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+    const int b = blockIdx.z, h = blockIdx.y, key0 = blockIdx.x * 128 + wave * 32;
+    const long ld_b = (long)3 * H * HD * sizeof(T);
+    const char* base = (const char*)qkv + (long)b * N * ld_b;
+    const char* qb = base + (long)(0 * H + h) * HD * sizeof(T);
+    const char* kb = base + (long)(1 * H + h) * HD * sizeof(T);
+    const char* vb = base + (long)(2 * H + h) * HD * sizeof(T);
+    const long ldo_b = (long)H * HD * sizeof(T);
+    const char* dob = (const char*)dout + (long)b * N * ldo_b + (long)h * HD * sizeof(T);
+
+    Frag kf[2][NF], vf[2][NF];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        const int key = key0 + kt * 16 + c;
+#pragma unroll
+        for (int u = 0; u < NF; ++u) {
+            Frag z = {};
+            kf[kt][u] = key < N ? load_nfrag<T>(kb + (long)key * ld_b, u, g) : z;
+            vf[kt][u] = key < N ? load_nfrag<T>(vb + (long)key * ld_b, u, g) : z;
+        }
+    }
+    f32x4 dk[4][2], dv[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { dk[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    for (int q0 = 0; q0 < N; q0 += 64) {
+        __syncthreads();
+        stage_tile<T, true, true>(qb, ld_b, q0, N, sQ, sQt);
+        stage_tile<T, true, true>(dob, ldo_b, q0, N, sD, sDt);
+        if (threadIdx.x < 64) {
+            const int q = q0 + threadIdx.x;
+            sL[threadIdx.x] = q < N ? lse[((long)b * H + h) * N + q] : 0.f;
+            sDl[threadIdx.x] = q < N ? delta[((long)b * H + h) * N + q] : 0.f;
+        }
+        __syncthreads();
+        f32x4 pp[2][4], dsv[2][4];  // [key tile][query tile]
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {
+            Frag qf[NF], df[NF];
+#pragma unroll
+            for (int u = 0; u < NF; ++u) {
+                qf[u] = load_nfrag<T>(sQ + (qt * 16 + c) * ROWB, u, g);
+                df[u] = load_nfrag<T>(sD + (qt * 16 + c) * ROWB, u, g);
+            }
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < NF; ++u) {
+                    s = Mma<T>::mma(qf[u], kf[kt][u], s);    // rows: queries, cols: keys
+                    dp = Mma<T>::mma(df[u], vf[kt][u], dp);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ql = qt * 16 + g * 4 + r;
+                    const float p = (q0 + ql < N) ? __expf(s[r] * scale - sL[ql]) : 0.f;
+                    pp[kt][qt][r] = p;
+                    dsv[kt][qt][r] = p * (dp[r] - sDl[ql]) * scale;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NF; ++u) {
+            Frag pf[2], sf[2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) { pf[kt] = acc_to_bfrag<T>(pp[kt], u); sf[kt] = acc_to_bfrag<T>(dsv[kt], u); }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const Frag dot = load_tfrag<T>(sDt + (dt * 16 + c) * ROWB, u, g);
+                const Frag qt_ = load_tfrag<T>(sQt + (dt * 16 + c) * ROWB, u, g);
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    dv[dt][kt] = Mma<T>::mma(dot, pf[kt], dv[dt][kt]);
+                    dk[dt][kt] = Mma<T>::mma(qt_, sf[kt], dk[dt][kt]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        const int key = key0 + kt * 16 + c;
+        if (key >= N) continue;
+        T* rk = dqkv + ((long)b * N + key) * 3 * H * HD + (long)(1 * H + h) * HD;
+        T* rv = dqkv + ((long)b * N + key) * 3 * H * HD + (long)(2 * H + h) * HD;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            store4<T>(rk + dt * 16 + g * 4, dk[dt][kt]);
+            store4<T>(rv + dt * 16 + g * 4, dv[dt][kt]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ C ABI
+extern "C" int gd_attention_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, int head_dim, float scale,
+                                int dtype, void* stream) {
+    GD_REQUIRE(B > 0 && N > 0 && H > 0, "gd_attention_fwd: bad shape B=%d N=%d H=%d", B, N, H);
+    GD_REQUIRE(head_dim == HD, "gd_attention_fwd: head_dim must be 64 (got %d)", head_dim);
+    GD_REQUIRE(dtype == GD_F32 || dtype == GD_BF16, "gd_attention_fwd: bad dtype %d", dtype);
+    GD_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)o & 15) == 0, "gd_attention_fwd: pointers must be 16-byte aligned");
+    dim3 grid(gd_cdiv(N, 128), H, B);
+    if (dtype == GD_BF16)
+        hipLaunchKernelGGL(attn_fwd_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale);
+    else
+        hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)qkv, (float*)o, lse, N, H, scale);
+    GD_LAUNCH_OK();
+    return 0;
+}
+
+extern "C" int gd_attention_bwd(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv,
+                                float* delta_ws, int B, int N, int H, int head_dim, float scale, int dtype,
+                                void* stream) {
+    GD_REQUIRE(B > 0 && N > 0 && H > 0, "gd_attention_bwd: bad shape B=%d N=%d H=%d", B, N, H);
+    GD_REQUIRE(head_dim == HD, "gd_attention_bwd: head_dim must be 64 (got %d)", head_dim);
+    GD_REQUIRE(dtype == GD_F32 || dtype == GD_BF16, "gd_attention_bwd: bad dtype %d", dtype);
+    GD_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)dout & 15) == 0 && ((uintptr_t)dqkv & 15) == 0,
+               "gd_attention_bwd: pointers must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)B * N * H;
+    dim3 grid(gd_cdiv(N, 128), H, B);
+    if (dtype == GD_BF16) {
+        hipLaunchKernelGGL(attn_delta_kernel<bf16>, dim3(gd_cdiv(total * 16, 256)), dim3(256), 0, s, (const bf16*)o, (const bf16*)dout, delta_ws, N, H, total);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)qkv, (const bf16*)dout, lse, delta_ws, (bf16*)dqkv, N, H, scale);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)qkv, (const bf16*)dout, lse, delta_ws, (bf16*)dqkv, N, H, scale);
+    } else {
+        hipLaunchKernelGGL(attn_delta_kernel<float>, dim3(gd_cdiv(total * 16, 256)), dim3(256), 0, s, (const float*)o, (const float*)dout, delta_ws, N, H, total);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<float>, grid, dim3(256), 0, s, (const float*)qkv, (const float*)dout, lse, delta_ws, (float*)dqkv, N, H, scale);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<float>, grid, dim3(256), 0, s, (const float*)qkv, (const float*)dout, lse, delta_ws, (float*)dqkv, N, H, scale);
+    }
+    GD_LAUNCH_OK();
+    return 0;
+}

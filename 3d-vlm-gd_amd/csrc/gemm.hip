@@ -9,6 +9,7 @@
 // K step = 128 bytes of a row (64 bf16 / 32 f32), register-staged global->LDS with the next
 // tile's loads in flight under the MFMAs, LDS rows padded 128->144 B.
 #include "gd_common.h"
+#include "gemm_tile.h"
 
 struct GemmNtParams {
     const void* A; const void* W; void* C;
@@ -28,11 +29,8 @@ struct GemmNtParams {
 
 template <typename T>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtParams p) {
-    constexpr int BM = 128, BN = 128, BKB = 128, ROWB = 144;
-    __shared__ __attribute__((aligned(16))) char smem[(BM + BN) * ROWB];
-    char* sA = smem;
-    char* sB = smem + BM * ROWB;
-
+    constexpr int BM = 128, BN = 128;
+    __shared__ __attribute__((aligned(16))) char smem[GD_TILE_SMEM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
@@ -42,59 +40,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtParams p) {
 
     const char* Ab = (const char*)p.A + batch * p.sA * (long)sizeof(T);
     const char* Wb = (const char*)p.W + batch * p.sW * (long)sizeof(T);
-    const long lda_b = p.lda * (long)sizeof(T), ldw_b = p.ldw * (long)sizeof(T);
-    const int Kbytes = p.K * (int)sizeof(T);
-    const int nk = (Kbytes + BKB - 1) / BKB;
-
-    uint4 ra[4], rb[4];
-    auto gload = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = tid + 256 * i, row = c >> 3, cc = c & 7;
-            const int kb = kt * BKB + cc * 16;
-            const int gr = tm * BM + row, gc = tn * BN + row;
-            const bool kin = kb < Kbytes;
-            ra[i] = (kin && gr < p.M) ? *(const uint4*)(Ab + (long)gr * lda_b + kb) : make_uint4(0, 0, 0, 0);
-            rb[i] = (kin && gc < p.N) ? *(const uint4*)(Wb + (long)gc * ldw_b + kb) : make_uint4(0, 0, 0, 0);
-        }
-    };
-    auto swrite = [&]() {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = tid + 256 * i, row = c >> 3, cc = c & 7;
-            *(uint4*)(sA + row * ROWB + cc * 16) = ra[i];
-            *(uint4*)(sB + row * ROWB + cc * 16) = rb[i];
-        }
-    };
-
     f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    typedef typename Mma<T>::Frag Frag;
-    const int frow = lane & 15, fcol = (lane >> 4) * 16;
-    gload(0);
-    for (int kt = 0; kt < nk; ++kt) {
-        swrite();
-        __syncthreads();
-        if (kt + 1 < nk) gload(kt + 1);
-#pragma unroll
-        for (int kc = 0; kc < 2; ++kc) {
-            Frag a[4], b[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                a[t] = *(const Frag*)(sA + (wm * 64 + t * 16 + frow) * ROWB + kc * 64 + fcol);
-                b[t] = *(const Frag*)(sB + (wn * 64 + t * 16 + frow) * ROWB + kc * 64 + fcol);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(a[i], b[j], acc[i][j]);
-        }
-        __syncthreads();
-    }
+    mma_tile_128x128<T>(Ab, p.lda * (long)sizeof(T), p.M, Wb, p.ldw * (long)sizeof(T), p.N, p.K * (int)sizeof(T),
+                        tm, tn, smem, acc);
 
     // ---- epilogue (C layout: row = 4*(lane>>4)+r, col = lane&15 inside each 16x16 tile) ----
     const int cdt = p.c_dtype;

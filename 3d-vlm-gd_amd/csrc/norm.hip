@@ -1,0 +1,185 @@
+// LayerNorm forward / backward-to-input (the student's norm layers are frozen: no dgamma/dbeta) and
+// row L2 normalisation, one wave per row, rows held in registers (D <= 2048, D % 4 == 0).
+// Replaces nn.LayerNorm in timm's Block / model.norm and F.normalize
+// (src/finetune_timm_vggt.py:328).
+#include "gd_common.h"
+
+#define LN_MAXV 8  // 8 x (64 lanes x 4 elements) = 2048 columns
+
+template <typename T> __device__ __forceinline__ f32x4 load4(const T* p);
+template <> __device__ __forceinline__ f32x4 load4<float>(const float* p) { return *(const f32x4*)p; }
+template <> __device__ __forceinline__ f32x4 load4<bf16>(const bf16* p) {
+    const bf16x4 v = *(const bf16x4*)p;
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+template <typename T> __device__ __forceinline__ void store4n(T* p, f32x4 v);
+template <> __device__ __forceinline__ void store4n<float>(float* p, f32x4 v) { *(f32x4*)p = v; }
+template <> __device__ __forceinline__ void store4n<bf16>(bf16* p, f32x4 v) {
+    *(bf16x4*)p = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+}
+
+template <typename T, typename TO>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* x, const float* gamma, const float* beta, TO* y,
+                                                     float* mean, float* rstd, int M, int D, long ldx, long ldy,
+                                                     float eps) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const T* xr = x + (long)row * ldx;
+    f32x4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < D) {
+            v[i] = load4<T>(xr + c);
+            s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        }
+    }
+    const float mu = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < D) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float d = v[i][k] - mu; q += d * d; }
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+    if (lane == 0 && mean) { mean[row] = mu; rstd[row] = rs; }
+    TO* yr = y + (long)row * ldy;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < D) {
+            const f32x4 g = *(const f32x4*)(gamma + c), b = *(const f32x4*)(beta + c);
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = (v[i][k] - mu) * rs * g[k] + b[k];
+            store4n<TO>(yr + c, o);
+        }
+    }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;  dx += dres when given
+template <typename T, typename TD>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* dy, const T* x, const float* gamma, const float* mean,
+                                                     const float* rstd, const T* dres, T* dx, int M, int D, long ldd,
+                                                     long ldx, float dyscale) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float mu = mean[row], rs = rstd[row];
+    const T* xr = x + (long)row * ldx;
+    const TD* dr = dy + (long)row * ldd;
+    f32x4 xh[LN_MAXV], g[LN_MAXV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < D) {
+            const f32x4 xv = load4<T>(xr + c), dv = load4<TD>(dr + c), gm = *(const f32x4*)(gamma + c);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                xh[i][k] = (xv[k] - mu) * rs;
+                g[i][k] = dv[k] * dyscale * gm[k];
+                s1 += g[i][k];
+                s2 += g[i][k] * xh[i][k];
+            }
+        }
+    }
+    s1 = wave_sum(s1) / (float)D;
+    s2 = wave_sum(s2) / (float)D;
+    T* or_ = dx + (long)row * ldx;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < D) {
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = rs * (g[i][k] - s1 - xh[i][k] * s2);
+            if (dres) {
+                const f32x4 r = load4<T>(dres + (long)row * ldx + c);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] += r[k];
+            }
+            store4n<T>(or_ + c, o);
+        }
+    }
+}
+
+// y = x / max(||x||, eps) on fp32 rows; backward dx = (dy - y (y.dy)) / max(||x||, eps)
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* x, float* y, float* inv, int M, int D, float eps) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) { const float v = x[(long)row * D + c]; s += v * v; }
+    const float iv = 1.0f / fmaxf(sqrtf(wave_sum(s)), eps);
+    if (lane == 0 && inv) inv[row] = iv;
+    for (int c = lane; c < D; c += 64) y[(long)row * D + c] = x[(long)row * D + c] * iv;
+}
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* y, const float* dy, const float* inv, float* dx,
+                                                         int M, int D) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) s += y[(long)row * D + c] * dy[(long)row * D + c];
+    s = wave_sum(s);
+    const float iv = inv[row];
+    for (int c = lane; c < D; c += 64) dx[(long)row * D + c] = (dy[(long)row * D + c] - y[(long)row * D + c] * s) * iv;
+}
+
+extern "C" int gd_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                                float* rstd, int M, int D, long ldx, long ldy, float eps, int dtype, int y_dtype,
+                                void* stream) {
+    GD_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * LN_MAXV, "gd_layernorm_fwd: D=%d must be a multiple of 4 and <= 2048", D);
+    GD_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0, "gd_layernorm_fwd: row strides must be multiples of 4 elements");
+    GD_REQUIRE((mean == nullptr) == (rstd == nullptr), "gd_layernorm_fwd: pass both mean and rstd or neither");
+    dim3 grid(gd_cdiv(M, 4)), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == GD_BF16 && y_dtype == GD_BF16)
+        hipLaunchKernelGGL((ln_fwd_kernel<bf16, bf16>), grid, blk, 0, s, (const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, M, D, ldx, ldy, eps);
+    else if (dtype == GD_BF16 && y_dtype == GD_F32)
+        hipLaunchKernelGGL((ln_fwd_kernel<bf16, float>), grid, blk, 0, s, (const bf16*)x, gamma, beta, (float*)y, mean, rstd, M, D, ldx, ldy, eps);
+    else if (dtype == GD_F32 && y_dtype == GD_F32)
+        hipLaunchKernelGGL((ln_fwd_kernel<float, float>), grid, blk, 0, s, (const float*)x, gamma, beta, (float*)y, mean, rstd, M, D, ldx, ldy, eps);
+    else {
+        gd_set_error("gd_layernorm_fwd: unsupported dtype pair %d -> %d", dtype, y_dtype);
+        return -1;
+    }
+    GD_LAUNCH_OK();
+    return 0;
+}
+
+extern "C" int gd_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+                                const float* rstd, const void* dres, void* dx, int M, int D, long ldd, long ldx,
+                                float dyscale, int dtype, int dy_dtype, void* stream) {
+    GD_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * LN_MAXV, "gd_layernorm_bwd: D=%d must be a multiple of 4 and <= 2048", D);
+    GD_REQUIRE(ldx % 4 == 0 && ldd % 4 == 0, "gd_layernorm_bwd: row strides must be multiples of 4 elements");
+    dim3 grid(gd_cdiv(M, 4)), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == GD_BF16 && dy_dtype == GD_BF16)
+        hipLaunchKernelGGL((ln_bwd_kernel<bf16, bf16>), grid, blk, 0, s, (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx, M, D, ldd, ldx, dyscale);
+    else if (dtype == GD_BF16 && dy_dtype == GD_F32)
+        hipLaunchKernelGGL((ln_bwd_kernel<bf16, float>), grid, blk, 0, s, (const float*)dy, (const bf16*)x, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx, M, D, ldd, ldx, dyscale);
+    else if (dtype == GD_F32 && dy_dtype == GD_F32)
+        hipLaunchKernelGGL((ln_bwd_kernel<float, float>), grid, blk, 0, s, (const float*)dy, (const float*)x, gamma, mean, rstd, (const float*)dres, (float*)dx, M, D, ldd, ldx, dyscale);
+    else {
+        gd_set_error("gd_layernorm_bwd: unsupported dtype pair x=%d dy=%d", dtype, dy_dtype);
+        return -1;
+    }
+    GD_LAUNCH_OK();
+    return 0;
+}
+
+extern "C" int gd_l2norm_fwd(const float* x, float* y, float* inv, int M, int D, float eps, void* stream) {
+    GD_REQUIRE(M > 0 && D > 0, "gd_l2norm_fwd: bad shape");
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(gd_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, y, inv, M, D, eps);
+    GD_LAUNCH_OK();
+    return 0;
+}
+extern "C" int gd_l2norm_bwd(const float* y, const float* dy, const float* inv, float* dx, int M, int D, void* stream) {
+    GD_REQUIRE(M > 0 && D > 0, "gd_l2norm_bwd: bad shape");
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(gd_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, y, dy, inv, dx, M, D);
+    GD_LAUNCH_OK();
+    return 0;
+}

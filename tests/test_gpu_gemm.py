@@ -1,0 +1,80 @@
+"""GPU parity: MFMA GEMMs (through the C ABI) against plain torch fp32/fp64 matmul."""
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(shape, dtype, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return torch.randn(shape, generator=g, device="cuda", dtype=torch.float32).to(dtype)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 5e-6), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 96), (1370, 2304, 768), (77, 8, 768), (513, 768, 3072),
+                                   (1000, 64, 768), (640, 768, 64), (200, 136, 8)])
+def test_gemm_nt_plain(dtype, tol, M, N, K):
+    from gd_amd import ops
+    a, w = _mk((M, K), dtype, 1), _mk((N, K), dtype, 2)
+    out = ops.gemm_nt(a, w)
+    ref = a.double() @ w.double().t()
+    assert out.dtype == dtype and rel_err(out, ref) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 5e-6), (torch.bfloat16, 2e-2)])
+def test_gemm_nt_epilogues(dtype, tol):
+    from gd_amd import ops
+    M, N, K = 333, 200, 160
+    a, w = _mk((M, K), dtype, 3), _mk((N, K), dtype, 4)
+    bias = _mk((N,), torch.float32, 5)
+    lt, lb = _mk((M, 8), torch.float32, 6), _mk((8, N), torch.float32, 7)
+    res = _mk((M, N), dtype, 8)
+    base = a.double() @ w.double().t() * 0.5 + bias.double() + lt.double() @ lb.double()
+    pre = torch.empty(M, N, dtype=dtype, device="cuda")
+    out = ops.gemm_nt(a, w, alpha=0.5, bias=bias, lora_t=lt, lora_b=lb, preact=pre, act=1, residual=res)
+    assert rel_err(pre, base) < tol
+    assert rel_err(out, torch.nn.functional.gelu(base) + res.double()) < tol
+    out2 = ops.gemm_nt(a, w, alpha=0.5, bias=bias, act=2)
+    assert rel_err(out2, torch.relu(a.double() @ w.double().t() * 0.5 + bias.double())) < tol
+    # dact: v * gelu'(src) and v * (src > 0); accumulate into an fp32 output from bf16 operands
+    src = _mk((M, N), dtype, 9)
+    x = src.double().requires_grad_(True)
+    torch.nn.functional.gelu(x).sum().backward()
+    plain = a.double() @ w.double().t()
+    assert rel_err(ops.gemm_nt(a, w, dact_src=src, dact=1), plain * x.grad) < tol
+    assert rel_err(ops.gemm_nt(a, w, dact_src=src, dact=2), plain * (src.double() > 0)) < tol
+    acc = _mk((M, N), torch.float32, 10)
+    want = acc.double() + plain
+    ops.gemm_nt(a, w, out=acc, accumulate=True)
+    assert acc.dtype == torch.float32 and rel_err(acc, want) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 1e-2)])
+def test_gemm_nt_batched_strided(dtype, tol):
+    from gd_amd import ops
+    a, w = _mk((3, 150, 72), dtype, 11), _mk((3, 90, 72), dtype, 12)
+    assert rel_err(ops.gemm_nt(a, w), a.double() @ w.double().transpose(1, 2)) < tol
+    big = _mk((257, 3 * 64), dtype, 13)          # strided view: the "k" slice of a packed qkv
+    wv = _mk((40, 64), dtype, 14)
+    assert rel_err(ops.gemm_nt(big[:, 64:128], wv), big[:, 64:128].double() @ wv.double().t()) < tol
+
+
+@pytest.mark.parametrize("ydt,xdt", [(torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16),
+                                     (torch.float32, torch.bfloat16)])
+@pytest.mark.parametrize("M,N,K", [(1000, 64, 768), (5000, 8, 2304), (777, 768, 64), (4096, 128, 200)])
+def test_gemm_tn(ydt, xdt, M, N, K):
+    from gd_amd import ops
+    y, x = _mk((M, N), ydt, 15), _mk((M, K), xdt, 16)
+    out = ops.gemm_tn(y, x, alpha=0.25)
+    assert rel_err(out, 0.25 * y.double().t() @ x.double()) < 5e-6
+    ops.gemm_tn(y, x, out=out, alpha=0.25)   # accumulates
+    assert rel_err(out, 0.5 * y.double().t() @ x.double()) < 5e-6
+
+
+def test_gemm_rejects_bad_arguments():
+    from gd_amd import ops, _lib
+    a = torch.randn(16, 10, device="cuda")   # K*4 = 40 bytes: not a multiple of 16
+    with pytest.raises(_lib.GdHipError):
+        ops.gemm_nt(a, torch.randn(8, 10, device="cuda"))

@@ -1,0 +1,144 @@
+"""CPU: the oracle/ restatement against the fixtures generated from the REFERENCE's own code
+(tools/make_golden.py).  These pin the checker; they run without a GPU."""
+import torch
+import torch.nn.functional as F
+
+import gd_oracle as O
+from conftest import load_golden, rel_err
+
+
+def test_sigmoid():
+    g = load_golden("g01_sigmoid")
+    assert rel_err(O.sigmoid_t(g["x"], g["temp"]), g["y"]) < 1e-7
+
+
+def test_interpolate_features():
+    for P in (14, 16):
+        g = load_golden(f"g02_interp_p{P}")
+        desc = g["desc"].clone().requires_grad_(True)
+        out = O.interpolate_features(desc, g["pts"], g["h"], g["w"], False, P, P)
+        assert rel_err(out, g["out"]) < 1e-6
+        (out * g["gout"]).sum().backward()
+        assert rel_err(desc.grad, g["gdesc"]) < 1e-6
+        assert rel_err(O.interpolate_features(desc.detach(), g["pts"], g["h"], g["w"], True, P, P), g["out_norm"]) < 1e-6
+
+
+def test_patch_mask():
+    g = load_golden("g03_patch_mask")
+    assert torch.equal(O.patch_mask_from_kp(g["kp"], g["H"], g["W"], g["patch"]), g["mask"])
+
+
+def test_masked_cost_and_kl():
+    g = load_golden("g04_masked_cost")
+    assert rel_err(O.masked_patch_cost(g["cost"], g["row_mask"]), g["renorm"]) < 1e-6
+    assert rel_err(O.masked_patch_cost(g["cost"] * 4 - 2, g["row_mask"], use_softmax=True, temperature=0.7),
+                   g["softmax_t07"]) < 1e-6
+    assert rel_err(O.kl_divergence_map(g["kl_t"], g["kl_p"]), torch.as_tensor(g["kl"])) < 1e-6
+
+
+def test_cost_loss_variants():
+    for v in ("vggt", "mast3r"):
+        g = load_golden(f"g06_cost_{v}")
+        f1 = g["f1"][None].clone().requires_grad_(True)
+        f2 = g["f2"][None].clone().requires_grad_(True)
+        loss = O.cost_volume_kl(f1, f2, g["t1"][None], g["t2"][None], g["m1"], g["m2"], v)
+        assert abs(loss.item() - g["loss"]) < 1e-5 * abs(g["loss"])
+        loss.backward()
+        assert rel_err(f1.grad[0], g["g1"]) < 1e-4 and rel_err(f2.grad[0], g["g2"]) < 1e-4
+
+
+def _hp(g):
+    return {k: g["hp_" + k] for k in ("w1", "b1", "ln_w", "ln_b", "w2", "b2")}
+
+
+def test_ranking_loss():
+    g = load_golden("g07_ranking")
+    hp = {k: v.clone().requires_grad_(True) for k, v in _hp(g).items()}
+    feats = g["feats"].clone().requires_grad_(True)
+    loss = O.pairwise_ranking_loss(hp, feats, g["depths"], g["thr"])
+    assert abs(loss.item() - g["loss"]) < 1e-5
+    loss.backward()
+    assert rel_err(feats.grad, g["gfeats"]) < 1e-4
+    for k in hp:
+        assert rel_err(hp[k].grad, g["g_" + k]) < 1e-4, k
+
+
+def test_matching_loss():
+    for v in ("vggt", "mast3r"):
+        g = load_golden(f"g08_match_{v}")
+        d1 = g["desc1"].clone().requires_grad_(True)
+        d2 = g["desc2"].clone().requires_grad_(True)
+        loss = O.smooth_ap_loss(d1, d2, g["pts3d_1"], g["pts3d_2"], v)
+        assert abs(loss.item() - g["loss"]) < 1e-6
+        loss.backward()
+        assert rel_err(d1.grad, g["gdesc1"]) < 1e-5 and rel_err(d2.grad, g["gdesc2"]) < 1e-5
+
+
+def test_kp_depth():
+    g = load_golden("g09_kp_depth")
+    assert rel_err(O.extract_kp_depth(g["depth"], g["kp"]), g["out"]) < 1e-6
+
+
+def test_lora_adapter():
+    g = load_golden("g10_lora_adapter")
+    x = g["x"].clone().requires_grad_(True)
+    lo = {k: g[k].clone().requires_grad_(True) for k in ("a_q", "b_q", "a_v", "b_v")}
+    y = O.lora_qkv(x, g["qkv_w"], g["qkv_b"], lo)
+    assert rel_err(y, g["y"]) < 1e-6
+    (y * g["gy"]).sum().backward()
+    assert rel_err(x.grad, g["gx"]) < 1e-5
+    for k in lo:
+        assert rel_err(lo[k].grad, g["g_" + k]) < 1e-5
+    ad = {"down": g["ad_down"].clone().requires_grad_(True), "up": g["ad_up"].clone().requires_grad_(True)}
+    x2 = g["ad_x"].clone().requires_grad_(True)
+    y2 = O.adapter(x2, ad)
+    assert rel_err(y2, g["ad_y"]) < 1e-6
+    (y2 * g["ad_gy"]).sum().backward()
+    assert rel_err(x2.grad, g["ad_gx"]) < 1e-5
+    assert rel_err(ad["down"].grad, g["ad_g_down"]) < 1e-5 and rel_err(ad["up"].grad, g["ad_g_up"]) < 1e-5
+
+
+def test_depth_loss():
+    g = load_golden("g11_depth_loss")
+    hp = _hp(g)
+    d1 = O.extract_kp_depth(g["depth_1"], g["kp_1"])
+    d2 = O.extract_kp_depth(g["depth_2"], g["kp_2"])
+    l1, intra = O.depth_losses(hp, g["kf1"], g["kf2"], d1, d2)
+    assert abs(l1.item() - g["depth_loss"]) < 1e-6 and abs(intra.item() - g["intra_loss"]) < 1e-6
+
+
+def _vit_inputs(size):
+    g = load_golden(f"g12_vit_{size}")
+    sd = {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+    tr = {"lora": {}, "adapter": {}}
+    for bi in (4, 5):
+        tr["lora"][bi] = {k: g[f"lora_{bi}_{k}"] for k in ("a_q", "b_q", "a_v", "b_v")}
+        tr["adapter"][bi] = {k: g[f"adapter_{bi}_{k}"] for k in ("down", "up")}
+    cfg = dict(patch=14, dim=64, depth=6, heads=4, ln_eps=1e-6, pos_interp="dinov2")
+    return g, sd, tr, cfg
+
+
+def test_vit_forward_backward():
+    for size in (56, 70):
+        g, sd, tr, cfg = _vit_inputs(size)
+        for d in tr.values():
+            for blk in d.values():
+                for k in blk:
+                    blk[k] = blk[k].clone().requires_grad_(True)
+        taps, x = O.vit_forward(g["img"], sd, cfg, tr, taps=(4, 5))
+        assert rel_err(taps[0], g["tap4"]) < 2e-5 and rel_err(taps[1], g["tap5"]) < 2e-5
+        assert rel_err(O.final_norm(x, sd, cfg), g["xnorm"]) < 2e-5
+        ((taps[0] * g["wt4"]).sum() + (taps[1] * g["wt5"]).sum()).backward()
+        for bi in (4, 5):
+            for k in ("a_q", "b_q", "a_v", "b_v"):
+                assert rel_err(tr["lora"][bi][k].grad, g[f"g_{k}_{bi}"]) < 1e-4, (bi, k)
+            for k in ("down", "up"):
+                assert rel_err(tr["adapter"][bi][k].grad, g[f"g_{k}_{bi}"]) < 1e-4, (bi, k)
+
+
+def test_rope2d():
+    g = load_golden("g13_rope2d")
+    tok = g["tokens_bhnd"].transpose(1, 2).contiguous()
+    out = O.rope_2d(tok, g["positions"], g["base"], 1.0)
+    assert rel_err(out.transpose(1, 2), g["out_bhnd"]) < 1e-5
+    assert rel_err(O.rope_2d(out, g["positions"], g["base"], -1.0), tok) < 1e-5

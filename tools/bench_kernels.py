@@ -1,0 +1,68 @@
+"""Micro-benchmarks of individual kernels on the GPU box (diagnostics; the contract bench is bench.py).
+Usage: python tools/bench_kernels.py [gemm] [cv]"""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import gd_amd  # noqa: E402,F401
+from gd_amd import ops  # noqa: E402
+
+
+def timeit(fn, warm=3, it=10):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(it):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / it * 1e-3
+
+
+def bench_gemm():
+    for dt in (torch.bfloat16, torch.float32):
+        for (M, N, K) in [(87680, 2304, 768), (87680, 768, 768), (87680, 3072, 768), (87680, 768, 3072), (4096, 4096, 4096)]:
+            a = torch.randn(M, K, device="cuda").to(dt)
+            w = torch.randn(N, K, device="cuda").to(dt)
+            out = torch.empty(M, N, device="cuda", dtype=dt)
+            t = timeit(lambda: ops.gemm_nt(a, w, out=out))
+            t2 = timeit(lambda: torch.matmul(a, w.t()))
+            print(f"gemm_nt {str(dt)[6:]:9s} {M}x{N}x{K}: {t*1e3:8.3f} ms  {2*M*N*K/t/1e12:7.1f} TF/s   (torch/hipblaslt {2*M*N*K/t2/1e12:7.1f} TF/s)")
+
+
+def bench_cv():
+    for dt in (torch.bfloat16, torch.float32):
+        for P in (1, 8, 32):
+            hw, C = 1369, 768
+            f1 = torch.randn(P, hw, C, device="cuda").to(dt).requires_grad_(True)
+            f2 = torch.randn(P, hw, C, device="cuda").to(dt).requires_grad_(True)
+            t1 = torch.softmax(3 * torch.randn(P, hw, hw, device="cuda"), -1)
+            t2 = torch.softmax(3 * torch.randn(P, hw, hw, device="cuda"), -1)
+            m1 = torch.rand(P, hw, device="cuda") > 0.3
+            m2 = torch.rand(P, hw, device="cuda") > 0.3
+            es = 2 if dt == torch.bfloat16 else 4
+            fwd_bytes = P * (2 * hw * C * es + 2 * hw * hw * 4 + 2 * hw)
+            bwd_bytes = fwd_bytes + P * 2 * hw * C * es
+            with torch.no_grad():
+                tf = timeit(lambda: ops.cost_volume_kl(f1, f2, t1, t2, m1, m2, "vggt"))
+
+            def fb():
+                f1.grad = f2.grad = None
+                ops.cost_volume_kl(f1, f2, t1, t2, m1, m2, "vggt").sum().backward()
+            tfb = timeit(fb)
+            print(f"cost_volume {str(dt)[6:]:9s} P={P:2d}: fwd {tf*1e6/P:8.1f} us/pair {fwd_bytes/tf/1e9:8.1f} GB/s | "
+                  f"fwd+bwd {tfb*1e6/P:8.1f} us/pair {(fwd_bytes+bwd_bytes)/tfb/1e9:8.1f} GB/s")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["gemm", "cv"]
+    if "gemm" in which:
+        bench_gemm()
+    if "cv" in which:
+        bench_cv()
