@@ -22,7 +22,39 @@ SIGNATURES = {
                            c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_long, c_int,
                            c_void_p, c_long, c_int, c_void_p, c_long, c_int, c_void_p]),
     "gd_gemm_tn": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_long, c_long,
-                           c_int, c_int, c_float, c_void_p]),
+                           c_int, c_long, c_long, c_long, c_int, c_int, c_float, c_void_p]),
+    "gd_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_long,
+                                 c_long, c_float, c_int, c_int, c_void_p]),
+    "gd_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                 c_long, c_long, c_float, c_int, c_int, c_void_p]),
+    "gd_l2norm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "gd_l2norm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "gd_patch_im2col": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_int, c_void_p]),
+    "gd_assemble_tokens": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "gd_im2col3x3": (c_int, [c_void_p, c_long, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "gd_col2im3x3": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "gd_kp_gather_fwd": (c_int, [ctypes.POINTER(c_void_p), c_int, c_long, c_int, c_void_p, c_void_p, c_int, c_int,
+                                 c_int, c_int, c_int, c_float, c_float, c_int, c_int, c_int, c_int, c_void_p]),
+    "gd_kp_gather_bwd": (c_int, [ctypes.POINTER(c_void_p), c_int, c_long, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                 c_int, c_float, c_float, c_int, c_int, c_int, c_int, c_void_p]),
+    "gd_tap_mean_fwd": (c_int, [ctypes.POINTER(c_void_p), c_int, c_long, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                                c_void_p]),
+    "gd_tap_mean_bwd": (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                                c_void_p]),
+    "gd_kp_depth": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "gd_patch_mask": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "gd_smooth_ap": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float,
+                             c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gd_pair_rank_workspace_bytes": (c_size_t, [c_int]),
+    "gd_pair_rank": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p,
+                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gd_depth_l1": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gd_adamw_workspace_bytes": (c_size_t, []),
+    "gd_clip_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_float, c_float, c_float,
+                                   c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    "gd_cast": (c_int, [c_void_p, c_void_p, c_long, c_float, c_int, c_int, c_void_p]),
     "gd_attention_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "gd_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                  c_int, c_float, c_int, c_void_p]),

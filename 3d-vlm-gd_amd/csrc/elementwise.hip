@@ -1,0 +1,430 @@
+// Memory-bound glue kernels of the student step (gfx950): image prep + patch im2col, token assembly,
+// 3x3 im2col / col2im for refine_conv, keypoint bilinear gather / scatter, keypoint depth, patch masks,
+// global-norm clip + AdamW on the flat trainable buffer.
+#include "gd_common.h"
+
+// ---------------------------------------------------------------------------------------------------
+// a0 + patch-embed prologue: bilinear resize (torchvision tensor semantics: align_corners=False, no
+// antialias; src/finetune_timm_vggt.py:270,340) -> Normalize(mean,std) (:153) -> im2col for the PxP/stride-P
+// patch conv.  col[(b,gy,gx), c*P*P + py*P + px], zero padded to Kp columns.
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void patch_im2col_kernel(const float* img, T* col, int B, int h, int w, int H,
+                                                           int W, int P, int Kp, float m0, float m1, float m2,
+                                                           float s0, float s1, float s2) {
+    const int gw = W / P, gh = H / P;
+    const long total = (long)B * gh * gw * Kp;
+    const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int k = idx % Kp;
+        const long row = idx / Kp;
+        float v = 0.f;
+        if (k < 3 * P * P) {
+            const int c = k / (P * P), py = (k / P) % P, px = k % P;
+            const int gx = row % gw, gy = (row / gw) % gh, b = row / ((long)gw * gh);
+            const int Y = gy * P + py, X = gx * P + px;
+            const float* src = img + ((long)b * 3 + c) * h * w;
+            float pix;
+            if (h == H && w == W) {
+                pix = src[(long)Y * w + X];
+            } else {
+                float fy = fmaxf(((float)Y + 0.5f) * sy - 0.5f, 0.f), fx = fmaxf(((float)X + 0.5f) * sx - 0.5f, 0.f);
+                const int y0 = min((int)fy, h - 1), x0 = min((int)fx, w - 1);
+                const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+                const float wy = fy - (float)y0, wx = fx - (float)x0;
+                pix = (1.f - wy) * ((1.f - wx) * src[(long)y0 * w + x0] + wx * src[(long)y0 * w + x1]) +
+                      wy * ((1.f - wx) * src[(long)y1 * w + x0] + wx * src[(long)y1 * w + x1]);
+            }
+            const float mu = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+            v = (pix - mu) / sd;
+        }
+        col[idx] = from_f32<T>(v);
+    }
+}
+
+// tokens[b,0] = cls + pos[0];  tokens[b,1+i] = patch[b,i] + pos[1+i]     (timm _pos_embed)
+template <typename T>
+__global__ __launch_bounds__(256) void assemble_tokens_kernel(const T* patch, const float* cls, const float* pos,
+                                                              T* out, int B, int Np, int D) {
+    const long total = (long)B * (Np + 1) * D;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int d = idx % D;
+        const int n = (idx / D) % (Np + 1);
+        const long b = idx / ((long)D * (Np + 1));
+        const float v = n == 0 ? cls[d] : to_f32<T>(patch[(b * Np + (n - 1)) * D + d]);
+        out[idx] = from_f32<T>(v + pos[(long)n * D + d]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// refine_conv 3x3 pad 1 (src/finetune_timm_vggt.py:146,325) as im2col + GEMM.  x is the token-major grid
+// x[b][y][x][:] = base + b*bstride + (y*gw+x)*D.  col[(b,y,x)][(ky*3+kx)*D + c]  (weights re-laid to match).
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const T* x, long bstride, T* col, int B, int gh, int gw,
+                                                        int D) {
+    const int vec = 16 / (int)sizeof(T), dv = D / vec;
+    const long total = (long)B * gh * gw * 9 * dv;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = idx % dv;
+        const int tap = (idx / dv) % 9;
+        const long row = idx / ((long)dv * 9);
+        const int px = row % gw, py = (row / gw) % gh;
+        const long b = row / ((long)gw * gh);
+        const int yy = py + tap / 3 - 1, xx = px + tap % 3 - 1;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (yy >= 0 && yy < gh && xx >= 0 && xx < gw) v = *(const uint4*)(x + b * bstride + ((long)yy * gw + xx) * D + c * vec);
+        *(uint4*)(col + (row * 9 + tap) * D + c * vec) = v;
+    }
+}
+
+// dx[b][y][x][c] = sum_taps dcol[(b, y-ky+1, x-kx+1)][(ky*3+kx)*D + c]
+template <typename T>
+__global__ __launch_bounds__(256) void col2im3x3_kernel(const T* dcol, T* dx, long bstride, int B, int gh, int gw,
+                                                        int D) {
+    const long total = (long)B * gh * gw * D;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = idx % D;
+        const long row = idx / D;
+        const int px = row % gw, py = (row / gw) % gh;
+        const long b = row / ((long)gw * gh);
+        float acc = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yy = py - (tap / 3 - 1), xx = px - (tap % 3 - 1);
+            if (yy >= 0 && yy < gh && xx >= 0 && xx < gw)
+                acc += to_f32<T>(dcol[(((b * gh + yy) * gw + xx) * 9 + tap) * D + c]);
+        }
+        dx[b * bstride + ((long)py * gw + px) * D + c] = from_f32<T>(acc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// interpolate_features (utils/functions.py:55-76): F.grid_sample(bilinear, align_corners=True, border) at
+// keypoints, on up to 4 token-major grids averaged (get_intermediate_feature, src/finetune_timm_vggt.py:291-296).
+// kp [B,Nk,2] pixels (x,y) in the source frame; (kx,ky) = kp * (sx,sy) then a*k+b -> [-1,1] -> grid coords.
+// ---------------------------------------------------------------------------------------------------
+struct GatherParams {
+    const void* grid[4]; int ngrid; long bstride; int grid_dtype;
+    const float* kp; float* out; float* dgrid[4]; const float* dout;
+    int B, Nk, gh, gw, D;
+    float sx, sy, ax, bx, ay, by;
+};
+
+__device__ __forceinline__ void gather_coords(const GatherParams& p, long bk, int& x0, int& y0, int& x1, int& y1,
+                                              float& wx, float& wy) {
+    const float px = p.kp[bk * 2 + 0] * p.sx, py = p.kp[bk * 2 + 1] * p.sy;
+    float gx = (p.ax * px + p.bx + 1.f) * 0.5f * (float)(p.gw - 1);
+    float gy = (p.ay * py + p.by + 1.f) * 0.5f * (float)(p.gh - 1);
+    gx = fminf(fmaxf(gx, 0.f), (float)(p.gw - 1));
+    gy = fminf(fmaxf(gy, 0.f), (float)(p.gh - 1));
+    x0 = (int)floorf(gx); y0 = (int)floorf(gy);
+    wx = gx - (float)x0; wy = gy - (float)y0;
+    x1 = min(x0 + 1, p.gw - 1); y1 = min(y0 + 1, p.gh - 1);
+}
+
+__global__ __launch_bounds__(256) void kp_gather_fwd_kernel(GatherParams p) {
+    const long bk = blockIdx.x;  // one block per (b, keypoint)
+    const long b = bk / p.Nk;
+    int x0, y0, x1, y1; float wx, wy;
+    gather_coords(p, bk, x0, y0, x1, y1, wx, wy);
+    const float w00 = (1.f - wx) * (1.f - wy), w01 = wx * (1.f - wy), w10 = (1.f - wx) * wy, w11 = wx * wy;
+    const float inv = 1.0f / (float)p.ngrid;
+    for (int d = threadIdx.x; d < p.D; d += 256) {
+        float acc = 0.f;
+        for (int t = 0; t < p.ngrid; ++t) {
+            const long base = b * p.bstride + d;
+            acc += w00 * ld_rt(p.grid[t], base + ((long)y0 * p.gw + x0) * p.D, p.grid_dtype) +
+                   w01 * ld_rt(p.grid[t], base + ((long)y0 * p.gw + x1) * p.D, p.grid_dtype) +
+                   w10 * ld_rt(p.grid[t], base + ((long)y1 * p.gw + x0) * p.D, p.grid_dtype) +
+                   w11 * ld_rt(p.grid[t], base + ((long)y1 * p.gw + x1) * p.D, p.grid_dtype);
+        }
+        p.out[bk * p.D + d] = acc * inv;
+    }
+}
+
+// scatter: dgrid[t] (fp32, batch stride p.bstride elements, pre-zeroed) += w * dout / ngrid
+__global__ __launch_bounds__(256) void kp_gather_bwd_kernel(GatherParams p) {
+    const long bk = blockIdx.x;
+    const long b = bk / p.Nk;
+    int x0, y0, x1, y1; float wx, wy;
+    gather_coords(p, bk, x0, y0, x1, y1, wx, wy);
+    const float inv = 1.0f / (float)p.ngrid;
+    const float w00 = (1.f - wx) * (1.f - wy) * inv, w01 = wx * (1.f - wy) * inv, w10 = (1.f - wx) * wy * inv,
+                w11 = wx * wy * inv;
+    const long gs = p.bstride;
+    for (int d = threadIdx.x; d < p.D; d += 256) {
+        const float g = p.dout[bk * p.D + d];
+        for (int t = 0; t < p.ngrid; ++t) {
+            float* dg = p.dgrid[t] + b * gs + d;
+            atomicAdd(dg + ((long)y0 * p.gw + x0) * p.D, w00 * g);
+            atomicAdd(dg + ((long)y0 * p.gw + x1) * p.D, w01 * g);
+            atomicAdd(dg + ((long)y1 * p.gw + x0) * p.D, w10 * g);
+            atomicAdd(dg + ((long)y1 * p.gw + x1) * p.D, w11 * g);
+        }
+    }
+}
+
+// extract_kp_depth (utils/functions.py:348-372): 3x3 replicate-padded mean of depth at integer keypoints
+__global__ void kp_depth_kernel(const float* depth, const float* kp, float* out, int B, int Nk, int H, int W) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)B * Nk) return;
+    const long b = i / Nk;
+    long lin = (long)(kp[i * 2 + 1] * (float)W + kp[i * 2 + 0]);  // reference: (y*W + x).long()
+    lin = lin < 0 ? 0 : (lin >= (long)H * W ? (long)H * W - 1 : lin);  // padded (out-of-image) keypoints stay in bounds
+    const int y = (int)(lin / W), x = (int)(lin % W);
+    float acc = 0.f;
+    for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int yy = min(max(y + dy, 0), H - 1), xx = min(max(x + dx, 0), W - 1);
+            acc += depth[(b * H + yy) * W + xx];
+        }
+    out[i] = acc / 9.0f;
+}
+
+// get_patch_mask_from_kp_tensor (utils/functions.py:375-399); mask [B, ph*pw] uint8, pre-zeroed
+__global__ void patch_mask_kernel(const float* kp, unsigned char* mask, int B, int Nk, int H, int W, int P) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)B * Nk) return;
+    const long b = i / Nk;
+    const float x = kp[i * 2 + 0], y = kp[i * 2 + 1];
+    if (x >= 0.f && x < (float)W && y >= 0.f && y < (float)H) {
+        const int pw = W / P, ph = H / P;
+        const int xi = (int)x / P, yi = (int)y / P;
+        if (xi < pw && yi < ph) mask[b * ph * pw + yi * pw + xi] = 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// gradient_clip_val=1.0 (global L2 norm, src/main.py:153) + AdamW (src/finetune_timm_vggt.py:642-648) on the
+// flat fp32 trainable buffer.  sumsq: partial[blockIdx] ; adamw reads the total from partial[0..nblk).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* g, long n, double* partial) {
+    double acc = 0.0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) acc += (double)g[i] * g[i];
+    __shared__ double red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, long n,
+                                                    const double* partial, int nblk, float max_norm, float lr,
+                                                    float wd, float b1, float b2, float eps, float bc1, float bc2,
+                                                    float gscale, float* norm_out) {
+    double tot = 0.0;
+    for (int i = 0; i < nblk; ++i) tot += partial[i];
+    const float gnorm = (float)sqrt(tot) * gscale;
+    float coef = max_norm > 0.f ? fminf(max_norm / (gnorm + 1e-6f), 1.0f) : 1.0f;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out) *norm_out = gnorm;
+    coef *= gscale;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float gi = g[i] * coef;
+        float pi = p[i] * (1.f - lr * wd);
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        pi -= (lr / bc1) * mi / (sqrtf(vi) / sqrtf(bc2) + eps);
+        p[i] = pi;
+    }
+}
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void cast_kernel(const TI* in, TO* out, long n, float scale) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        out[i] = from_f32<TO>(to_f32<TI>(in[i]) * scale);
+}
+
+// get_feature_cost (src/finetune_timm_mast3r.py:321-337, src/finetune_timm_vggt.py:342-353): mean of the tap
+// outputs with the prefix token dropped -> contiguous [B, hw, D];  backward scatters dout/ngrid back.
+struct TapMeanParams { const void* grid[4]; void* dgrid[4]; int ngrid; long bstride; int prefix; };
+template <typename T>
+__global__ __launch_bounds__(256) void tap_mean_fwd_kernel(TapMeanParams p, T* out, int B, int hw, int D) {
+    const long total = (long)B * hw * D;
+    const float inv = 1.0f / (float)p.ngrid;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long b = idx / ((long)hw * D), rem = idx % ((long)hw * D);
+        const long src = b * p.bstride + (long)p.prefix * D + rem;
+        float acc = 0.f;
+        for (int t = 0; t < p.ngrid; ++t) acc += to_f32<T>(((const T*)p.grid[t])[src]);
+        out[idx] = from_f32<T>(acc * inv);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void tap_mean_bwd_kernel(TapMeanParams p, const T* dout, int B, int hw, int D) {
+    const long total = (long)B * p.bstride;   // bstride = (prefix + hw) * D
+    const float inv = 1.0f / (float)p.ngrid;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long b = idx / p.bstride, rem = idx % p.bstride;
+        float v = 0.f;
+        if (rem >= (long)p.prefix * D) v = to_f32<T>(dout[b * (long)hw * D + rem - (long)p.prefix * D]) * inv;
+        for (int t = 0; t < p.ngrid; ++t) ((T*)p.dgrid[t])[idx] = from_f32<T>(v);
+    }
+}
+
+static inline int ew_blocks(long total) { long b = (total + 255) / 256; return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
+
+// ---------------------------------------------------------------------------------------------------
+extern "C" int gd_patch_im2col(const float* img, void* col, int B, int h, int w, int H, int W, int P, int Kp,
+                               const float* mean3, const float* std3, int dtype, void* stream) {
+    GD_REQUIRE(B > 0 && H % P == 0 && W % P == 0 && Kp >= 3 * P * P, "gd_patch_im2col: bad geometry H=%d W=%d P=%d Kp=%d", H, W, P, Kp);
+    const long total = (long)B * (H / P) * (W / P) * Kp;
+    if (dtype == GD_BF16)
+        hipLaunchKernelGGL(patch_im2col_kernel<bf16>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, img, (bf16*)col, B, h, w, H, W, P, Kp, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+    else
+        hipLaunchKernelGGL(patch_im2col_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, img, (float*)col, B, h, w, H, W, P, Kp, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+    GD_LAUNCH_OK();
+    return 0;
+}
+
+extern "C" int gd_assemble_tokens(const void* patch, const float* cls, const float* pos, void* out, int B, int Np,
+                                  int D, int dtype, void* stream) {
+    GD_REQUIRE(B > 0 && Np > 0 && D > 0, "gd_assemble_tokens: bad shape");
+    const long total = (long)B * (Np + 1) * D;
+    if (dtype == GD_BF16)
+        hipLaunchKernelGGL(assemble_tokens_kernel<bf16>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, (const bf16*)patch, cls, pos, (bf16*)out, B, Np, D);
+    else
+        hipLaunchKernelGGL(assemble_tokens_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, (const float*)patch, cls, pos, (float*)out, B, Np, D);
+    GD_LAUNCH_OK();
+    return 0;
+}
+
+extern "C" int gd_im2col3x3(const void* x, long bstride, void* col, int B, int gh, int gw, int D, int dtype,
+                            void* stream) {
+    GD_REQUIRE(B > 0 && gh > 0 && gw > 0 && (D * gd_dtype_size(dtype)) % 16 == 0 && (bstride * gd_dtype_size(dtype)) % 16 == 0 &&
+                   ((uintptr_t)x & 15) == 0,
+               "gd_im2col3x3: D and bstride must be multiples of 16 bytes, x 16-byte aligned");
+    const long total = (long)B * gh * gw * 9 * (D / (16 / gd_dtype_size(dtype)));
+    if (dtype == GD_BF16)
+        hipLaunchKernelGGL(im2col3x3_kernel<bf16>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, bstride, (bf16*)col, B, gh, gw, D);
+    else
+        hipLaunchKernelGGL(im2col3x3_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, (const float*)x, bstride, (float*)col, B, gh, gw, D);
+    GD_LAUNCH_OK();
+    return 0;
+}
+
+extern "C" int gd_col2im3x3(const void* dcol, void* dx, long bstride, int B, int gh, int gw, int D, int dtype,
+                            void* stream) {
+    GD_REQUIRE(B > 0 && gh > 0 && gw > 0 && D > 0, "gd_col2im3x3: bad shape");
+    const long total = (long)B * gh * gw * D;
+    if (dtype == GD_BF16)
+        hipLaunchKernelGGL(col2im3x3_kernel<bf16>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, (const bf16*)dcol, (bf16*)dx, bstride, B, gh, gw, D);
+    else
+        hipLaunchKernelGGL(col2im3x3_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, (const float*)dcol, (float*)dx, bstride, B, gh, gw, D);
+    GD_LAUNCH_OK();
+    return 0;
+}
+
+static int fill_gather(GatherParams& p, const void* const* grids, int ngrid, long bstride, int grid_dtype,
+                       const float* kp, int B, int Nk, int gh, int gw, int D, float sx, float sy, int img_h,
+                       int img_w, int patch, int stride) {
+    GD_REQUIRE(ngrid >= 1 && ngrid <= 4, "kp_gather: 1..4 grids (got %d)", ngrid);
+    GD_REQUIRE(B > 0 && Nk > 0 && gh > 0 && gw > 0 && D > 0, "kp_gather: bad shape");
+    for (int t = 0; t < 4; ++t) p.grid[t] = t < ngrid ? grids[t] : nullptr;
+    p.ngrid = ngrid; p.bstride = bstride; p.grid_dtype = grid_dtype; p.kp = kp;
+    p.B = B; p.Nk = Nk; p.gh = gh; p.gw = gw; p.D = D; p.sx = sx; p.sy = sy;
+    // utils/functions.py:56-65 (python float64 arithmetic, then cast to float32 tensors)
+    const double half = patch / 2.0;
+    const double last_h = ((img_h - patch) / stride) * stride + half, last_w = ((img_w - patch) / stride) * stride + half;
+    p.ay = (float)(2.0 / (last_h - half)); p.ax = (float)(2.0 / (last_w - half));
+    p.by = (float)(1.0 - last_h * 2.0 / (last_h - half)); p.bx = (float)(1.0 - last_w * 2.0 / (last_w - half));
+    return 0;
+}
+
+extern "C" int gd_kp_gather_fwd(const void* const* grids, int ngrid, long bstride, int grid_dtype, const float* kp,
+                                float* out, int B, int Nk, int gh, int gw, int D, float sx, float sy, int img_h,
+                                int img_w, int patch, int stride, void* stream) {
+    GatherParams p = {};
+    if (fill_gather(p, grids, ngrid, bstride, grid_dtype, kp, B, Nk, gh, gw, D, sx, sy, img_h, img_w, patch, stride)) return -1;
+    p.out = out;
+    hipLaunchKernelGGL(kp_gather_fwd_kernel, dim3(B * Nk), dim3(256), 0, (hipStream_t)stream, p);
+    GD_LAUNCH_OK();
+    return 0;
+}
+
+extern "C" int gd_kp_gather_bwd(float* const* dgrids, int ngrid, long bstride, const float* kp, const float* dout,
+                                int B, int Nk, int gh, int gw, int D, float sx, float sy, int img_h, int img_w,
+                                int patch, int stride, void* stream) {
+    GatherParams p = {};
+    const void* dummy[4] = {dgrids[0], dgrids[0], dgrids[0], dgrids[0]};
+    if (fill_gather(p, dummy, ngrid, bstride, GD_F32, kp, B, Nk, gh, gw, D, sx, sy, img_h, img_w, patch, stride)) return -1;
+    for (int t = 0; t < 4; ++t) p.dgrid[t] = t < ngrid ? dgrids[t] : nullptr;
+    p.dout = dout;
+    hipLaunchKernelGGL(kp_gather_bwd_kernel, dim3(B * Nk), dim3(256), 0, (hipStream_t)stream, p);
+    GD_LAUNCH_OK();
+    return 0;
+}
+
+extern "C" int gd_kp_depth(const float* depth, const float* kp, float* out, int B, int Nk, int H, int W, void* stream) {
+    GD_REQUIRE(B > 0 && Nk > 0 && H > 0 && W > 0, "gd_kp_depth: bad shape");
+    hipLaunchKernelGGL(kp_depth_kernel, dim3(gd_cdiv((long)B * Nk, 256)), dim3(256), 0, (hipStream_t)stream, depth, kp, out, B, Nk, H, W);
+    GD_LAUNCH_OK();
+    return 0;
+}
+
+extern "C" int gd_patch_mask(const float* kp, unsigned char* mask, int B, int Nk, int H, int W, int P, void* stream) {
+    GD_REQUIRE(B > 0 && Nk > 0 && P > 0, "gd_patch_mask: bad shape");
+    hipLaunchKernelGGL(patch_mask_kernel, dim3(gd_cdiv((long)B * Nk, 256)), dim3(256), 0, (hipStream_t)stream, kp, mask, B, Nk, H, W, P);
+    GD_LAUNCH_OK();
+    return 0;
+}
+
+#define GD_SUMSQ_BLOCKS 256
+extern "C" size_t gd_adamw_workspace_bytes(void) { return GD_SUMSQ_BLOCKS * sizeof(double); }
+
+extern "C" int gd_clip_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n,
+                                  int step, float lr, float weight_decay, float beta1, float beta2, float eps,
+                                  float max_norm, float grad_scale, float* grad_norm_out, void* workspace,
+                                  void* stream) {
+    GD_REQUIRE(n > 0 && step >= 1, "gd_clip_adamw_step: bad n/step");
+    hipStream_t s = (hipStream_t)stream;
+    double* partial = (double*)workspace;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(GD_SUMSQ_BLOCKS), dim3(256), 0, s, grads, n, partial);
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adamw_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq, n, partial,
+                       GD_SUMSQ_BLOCKS, max_norm, lr, weight_decay, beta1, beta2, eps, bc1, bc2, grad_scale, grad_norm_out);
+    GD_LAUNCH_OK();
+    return 0;
+}
+
+extern "C" int gd_cast(const void* in, void* out, long n, float scale, int in_dtype, int out_dtype, void* stream) {
+    GD_REQUIRE(n > 0, "gd_cast: n must be positive");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 g(ew_blocks(n)), b(256);
+    if (in_dtype == GD_F32 && out_dtype == GD_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16>), g, b, 0, s, (const float*)in, (bf16*)out, n, scale);
+    else if (in_dtype == GD_BF16 && out_dtype == GD_F32) hipLaunchKernelGGL((cast_kernel<bf16, float>), g, b, 0, s, (const bf16*)in, (float*)out, n, scale);
+    else if (in_dtype == GD_F32 && out_dtype == GD_F32) hipLaunchKernelGGL((cast_kernel<float, float>), g, b, 0, s, (const float*)in, (float*)out, n, scale);
+    else hipLaunchKernelGGL((cast_kernel<bf16, bf16>), g, b, 0, s, (const bf16*)in, (bf16*)out, n, scale);
+    GD_LAUNCH_OK();
+    return 0;
+}
+
+extern "C" int gd_tap_mean_fwd(const void* const* grids, int ngrid, long bstride, int prefix, void* out, int B, int hw,
+                               int D, int dtype, void* stream) {
+    GD_REQUIRE(ngrid >= 1 && ngrid <= 4 && B > 0 && hw > 0 && D > 0, "gd_tap_mean_fwd: bad arguments");
+    TapMeanParams p = {};
+    for (int t = 0; t < ngrid; ++t) p.grid[t] = grids[t];
+    p.ngrid = ngrid; p.bstride = bstride; p.prefix = prefix;
+    const long total = (long)B * hw * D;
+    if (dtype == GD_BF16) hipLaunchKernelGGL(tap_mean_fwd_kernel<bf16>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, p, (bf16*)out, B, hw, D);
+    else hipLaunchKernelGGL(tap_mean_fwd_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, p, (float*)out, B, hw, D);
+    GD_LAUNCH_OK();
+    return 0;
+}
+
+extern "C" int gd_tap_mean_bwd(void* const* dgrids, int ngrid, int prefix, const void* dout, int B, int hw, int D,
+                               int dtype, void* stream) {
+    GD_REQUIRE(ngrid >= 1 && ngrid <= 4 && B > 0 && hw > 0 && D > 0, "gd_tap_mean_bwd: bad arguments");
+    TapMeanParams p = {};
+    for (int t = 0; t < ngrid; ++t) p.dgrid[t] = dgrids[t];
+    p.ngrid = ngrid; p.bstride = (long)(prefix + hw) * D; p.prefix = prefix;
+    const long total = (long)B * p.bstride;
+    if (dtype == GD_BF16) hipLaunchKernelGGL(tap_mean_bwd_kernel<bf16>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, p, (const bf16*)dout, B, hw, D);
+    else hipLaunchKernelGGL(tap_mean_bwd_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, p, (const float*)dout, B, hw, D);
+    GD_LAUNCH_OK();
+    return 0;
+}

@@ -93,6 +93,7 @@ struct GemmTnParams {
     int y_dtype, x_dtype;
     int mchunk;
     float alpha;
+    long sY, sX, sG;   // batch strides in elements (grid.z = batch)
 };
 
 __device__ __forceinline__ void load8_as_f32(const void* base, long off, int dt, bool ok, float (&o)[8]) {
@@ -133,6 +134,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnParams p) {
     const int srow = tid >> 3, scol = (tid & 7) * 8;
     const int yn = tn * TN_ + scol, xk = tk * TK_ + scol;
     float ry[8], rx[8];
+    p.Y = (const char*)p.Y + (long)blockIdx.z * p.sY * gd_dtype_size(p.y_dtype);
+    p.X = (const char*)p.X + (long)blockIdx.z * p.sX * gd_dtype_size(p.x_dtype);
+    p.G += (long)blockIdx.z * p.sG;
     auto gload = [&](int m0) {
         const int m = m0 + srow;
         load8_as_f32(p.Y, (long)m * p.ldy + yn, p.y_dtype, m < m_end && yn < p.N, ry);
@@ -210,21 +214,22 @@ extern "C" int gd_gemm_nt(const void* A, const void* W, void* C, int M, int N, i
 }
 
 extern "C" int gd_gemm_tn(const void* Y, const void* X, float* G, int M, int N, int K, long ldy, long ldx, long ldg,
-                          int y_dtype, int x_dtype, float alpha, void* stream) {
+                          int batch, long sY, long sX, long sG, int y_dtype, int x_dtype, float alpha, void* stream) {
     GD_REQUIRE(M > 0 && N > 0 && K > 0, "gd_gemm_tn: bad shape M=%d N=%d K=%d", M, N, K);
     GD_REQUIRE(N % 8 == 0 && K % 8 == 0 && ldy % 8 == 0 && ldx % 8 == 0,
                "gd_gemm_tn: N (%d), K (%d), ldy (%ld), ldx (%ld) must be multiples of 8", N, K, ldy, ldx);
     GD_REQUIRE(((uintptr_t)Y & 15) == 0 && ((uintptr_t)X & 15) == 0, "gd_gemm_tn: Y and X must be 16-byte aligned");
     GemmTnParams p;
     p.Y = Y; p.X = X; p.G = G; p.M = M; p.N = N; p.K = K; p.ldy = ldy; p.ldx = ldx; p.ldg = ldg;
-    p.y_dtype = y_dtype; p.x_dtype = x_dtype; p.alpha = alpha;
+    p.y_dtype = y_dtype; p.x_dtype = x_dtype; p.alpha = alpha; p.sY = sY; p.sX = sX; p.sG = sG;
+    GD_REQUIRE(batch >= 1 && sY % 8 == 0 && sX % 8 == 0, "gd_gemm_tn: bad batch / batch strides");
     const int tiles = gd_cdiv(N, 64) * gd_cdiv(K, 64);
     // enough M-chunks to fill the chip (>= ~2048 blocks) without shredding the reduction
-    int splits = (2048 + tiles - 1) / tiles;
+    int splits = (2048 + tiles * batch - 1) / (tiles * batch);
     int mchunk = ((gd_cdiv(M, splits) + 31) / 32) * 32;
     if (mchunk < 256) mchunk = 256;
     p.mchunk = mchunk;
-    dim3 grid(tiles, gd_cdiv(M, mchunk));
+    dim3 grid(tiles, gd_cdiv(M, mchunk), batch);
     hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
     GD_LAUNCH_OK();
     return 0;

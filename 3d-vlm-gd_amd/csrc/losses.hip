@@ -1,0 +1,335 @@
+// Sparse distillation losses on keypoint features (gfx950): smooth-AP correspondence loss (a8/a9), the
+// relative-depth head (a12) with its L1 term and the pairwise logistic ranking loss (a10/a11).
+// All fp32: with temperature 0.01 the smooth-AP sigmoids are numerically fragile, and N is small.
+#include "gd_common.h"
+
+// ---------------------------------------------------------------------------------------------------
+// smooth-AP (src/finetune_timm_vggt.py:543-572 variant 0, src/finetune_timm_mast3r.py:560-589 variant 1;
+// sigmoid = utils/functions.py:24-33 with temp 0.01 and exponent clamp +-50).
+// sim [P,Nmax,Nmax] = desc1 desc2^T (unit descriptors, from gd_gemm_nt); one block per (pair, row i).
+// Emits the per-row loss and dsim = d(sum_i loss_i / n_p) / d sim, fused (the step always needs both).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sig_t(float x, float inv_temp, float& dsig) {
+    float e = -x * inv_temp;
+    const bool in = e >= -50.f && e <= 50.f;
+    e = fminf(fmaxf(e, -50.f), 50.f);
+    const float y = 1.0f / (1.0f + expf(e));
+    dsig = in ? y * (1.0f - y) * inv_temp : 0.f;
+    return y;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void smooth_ap_kernel(const float* sim, const float* pts1, const float* pts2,
+                                                        const int* counts, float* row_loss, float* dsim, int Nmax,
+                                                        int variant, float thr, float inv_temp) {
+    __shared__ float red[4];
+    const int p = blockIdx.y, i = blockIdx.x, n = counts ? counts[p] : Nmax;
+    const float* srow = sim + ((long)p * Nmax + i) * Nmax;
+    float* drow = dsim + ((long)p * Nmax + i) * Nmax;
+    if (i >= n) {
+        for (int j = threadIdx.x; j < Nmax; j += 256) drow[j] = 0.f;
+        if (threadIdx.x == 0) row_loss[(long)p * Nmax + i] = 0.f;
+        return;
+    }
+    const float pos = srow[i];
+    const float ax = pts1[((long)p * Nmax + i) * 3 + 0], ay = pts1[((long)p * Nmax + i) * 3 + 1],
+                az = pts1[((long)p * Nmax + i) * 3 + 2];
+    float A1 = 0.f, A2 = 0.f, D2 = 0.f;
+    for (int j = threadIdx.x; j < n; j += 256) {
+        const float* q = pts2 + ((long)p * Nmax + j) * 3;
+        const float dx = ax - q[0], dy = ay - q[1], dz = az - q[2];
+        const bool neg = (j != i) && (sqrtf(dx * dx + dy * dy + dz * dz) > thr);
+        if (neg) {
+            float d1, d2;
+            A1 += sig_t(srow[j] - 1.0f, inv_temp, d1);
+            A2 += sig_t(srow[j] - pos, inv_temp, d2);
+            D2 += d2;
+        }
+    }
+    A1 = block_sum(A1, red);
+    A2 = block_sum(A2, red);
+    D2 = block_sum(D2, red);
+    float dr1, dr2;
+    const float rpos1 = (variant == 0 ? sig_t(1.0f - pos, inv_temp, dr1) : sig_t(pos - 1.0f, inv_temp, dr1)) + 1.0f;
+    const float drpos1 = variant == 0 ? -dr1 : dr1;   // d rpos1 / d pos
+    const float rpos2 = sig_t(1.0f - pos, inv_temp, dr2) + 1.0f;
+    const float drpos2 = -dr2;
+    const float den1 = rpos1 + A1, den2 = rpos2 + A2;
+    const float ap1 = rpos1 / den1, ap2 = rpos2 / den2;
+    const float dap1_dA = -rpos1 / (den1 * den1), dap2_dA = -rpos2 / (den2 * den2);
+    const float dap1_dr = A1 / (den1 * den1), dap2_dr = A2 / (den2 * den2);
+    const float w = -0.5f / (float)n;   // loss_i = 1 - (ap1+ap2)/2, mean over n rows
+    for (int j = threadIdx.x; j < Nmax; j += 256) {
+        float gj = 0.f;
+        if (j < n && j != i) {
+            const float* q = pts2 + ((long)p * Nmax + j) * 3;
+            const float dx = ax - q[0], dy = ay - q[1], dz = az - q[2];
+            if (sqrtf(dx * dx + dy * dy + dz * dz) > thr) {
+                float d1, d2;
+                sig_t(srow[j] - 1.0f, inv_temp, d1);
+                sig_t(srow[j] - pos, inv_temp, d2);
+                gj = w * (dap1_dA * d1 + dap2_dA * d2);
+            }
+        } else if (j == i) {
+            gj = w * (dap1_dr * drpos1 + dap2_dr * drpos2 - dap2_dA * D2);
+        }
+        drow[j] = gj;
+    }
+    if (threadIdx.x == 0) row_loss[(long)p * Nmax + i] = (1.0f - 0.5f * (ap1 + ap2)) / (float)n;
+}
+
+// out[p] = sum_i rows[p, i]   (deterministic)
+__global__ __launch_bounds__(256) void row_sum_kernel(const float* rows, float* out, int n) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += rows[(long)blockIdx.x * n + i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Depth head on pre-projected features: DepthAwareFeatureFusion.fusion_layer (utils/model.py:100-127) is
+// tanh(w2 . GELU(LN_128(W1 x + b1)) + b2).  Every argument the losses feed it is a DIFFERENCE of keypoint
+// features, and W1 (f_j - f_i) = u_j - u_i with u = W1 f, so the D->128 projection is done once per
+// keypoint by gd_gemm_nt and the kernels below work on 128-vectors (2 per lane, one wave per evaluation).
+// Head-parameter gradients are accumulated un-normalised in hg[set][HG_SIZE] with fp32 atomics:
+//   [0:128) b1, [128:256) ln_w, [256:384) ln_b, [384:512) w2, [512] b2.
+// ---------------------------------------------------------------------------------------------------
+#define HG_SIZE 516
+struct HeadW { float b1[2], lw[2], lb[2], w2[2], b2; };
+
+__device__ __forceinline__ HeadW load_head(const float* b1, const float* lw, const float* lb, const float* w2,
+                                           const float* b2, int lane) {
+    HeadW h;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        h.b1[e] = b1[lane + 64 * e]; h.lw[e] = lw[lane + 64 * e]; h.lb[e] = lb[lane + 64 * e]; h.w2[e] = w2[lane + 64 * e];
+    }
+    h.b2 = b2[0];
+    return h;
+}
+
+struct HeadCache { float yh[2], y[2], a[2], rstd, s; };
+
+__device__ __forceinline__ float head_eval(const float (&z)[2], const HeadW& h, HeadCache& c) {
+    const float mu = wave_sum(z[0] + z[1]) * (1.0f / 128.0f);
+    const float d0 = z[0] - mu, d1 = z[1] - mu;
+    const float var = wave_sum(d0 * d0 + d1 * d1) * (1.0f / 128.0f);
+    c.rstd = rsqrtf(var + 1e-5f);
+    c.yh[0] = d0 * c.rstd; c.yh[1] = d1 * c.rstd;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) { c.y[e] = c.yh[e] * h.lw[e] + h.lb[e]; c.a[e] = gelu_f(c.y[e]); }
+    const float o = wave_sum(c.a[0] * h.w2[0] + c.a[1] * h.w2[1]) + h.b2;
+    c.s = tanhf(o);
+    return c.s;
+}
+
+// given dL/ds: returns dz (2 per lane); when acc != null adds this evaluation's head-parameter grads
+__device__ __forceinline__ void head_back(float dLds, const HeadW& h, const HeadCache& c, float (&dz)[2],
+                                          float (*acc)[2], float& acc_b2) {
+    const float dof = dLds * (1.0f - c.s * c.s);
+    float dyh[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const float dy = dof * h.w2[e] * dgelu_f(c.y[e]);
+        dyh[e] = dy * h.lw[e];
+        if (acc) { acc[1][e] += dy * c.yh[e]; acc[2][e] += dy; acc[3][e] += dof * c.a[e]; }
+    }
+    if (acc) acc_b2 += dof;
+    float m1 = dyh[0] + dyh[1], m2 = dyh[0] * c.yh[0] + dyh[1] * c.yh[1];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { m1 += __shfl_xor(m1, o, 64); m2 += __shfl_xor(m2, o, 64); }
+    m1 *= (1.0f / 128.0f); m2 *= (1.0f / 128.0f);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        dz[e] = c.rstd * (dyh[e] - m1 - c.yh[e] * m2);
+        if (acc) acc[0][e] += dz[e];
+    }
+}
+
+// pairwise_logistic_ranking_loss (utils/losses.py:18-41) for one keypoint set per blockIdx.y:
+// block (set, i) walks all j.  It evaluates pair (i,j) [s = head(u_j - u_i)] for the loss, the head grads and
+// -dz into du_i, and the mirrored pair (j,i) [head(u_i - u_j)] only for its +dz into du_i, so du_i is owned
+// by one block: no atomics on du.  Un-normalised; gd_pair_rank scales by gloss/count afterwards.
+__global__ __launch_bounds__(256) void pair_rank_kernel(const float* u, const float* depth, const int* counts,
+                                                        const float* b1, const float* lw, const float* lb,
+                                                        const float* w2, const float* b2, float* du, float* hg,
+                                                        float* loss_sum, int* pair_cnt, int Nmax, float thr) {
+    __shared__ float sacc[4][5][128];
+    __shared__ float sred[4][2];
+    const int set = blockIdx.y, i = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = counts ? counts[set] : Nmax;
+    float* dui = du + ((long)set * Nmax + i) * 128;
+    if (i >= n) {
+        if (threadIdx.x < 128) dui[threadIdx.x] = 0.f;
+        return;
+    }
+    const HeadW h = load_head(b1, lw, lb, w2, b2, lane);
+    const float* ub = u + (long)set * Nmax * 128;
+    const float ui[2] = {ub[(long)i * 128 + lane], ub[(long)i * 128 + lane + 64]};
+    const float di = depth[(long)set * Nmax + i];
+    float acc[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+    float acc_b2 = 0.f, dacc[2] = {0.f, 0.f}, lsum = 0.f;
+    int cnt = 0;
+    for (int j = wave; j < n; j += 4) {
+        const float dd = depth[(long)set * Nmax + j] - di;   // d_j - d_i
+        if (!(fabsf(dd) > thr)) continue;                   // wave-uniform
+        const float alpha = dd > 0.f ? 1.f : -1.f;
+        const float uj[2] = {ub[(long)j * 128 + lane], ub[(long)j * 128 + lane + 64]};
+        HeadCache c;
+        float z[2] = {uj[0] - ui[0] + h.b1[0], uj[1] - ui[1] + h.b1[1]};
+        float dz[2];
+        // pair (i, j): alpha_ij = sign(d_j - d_i)
+        float s = head_eval(z, h, c);
+        lsum += log1pf(expf(-alpha * s));
+        head_back(-alpha / (1.0f + expf(alpha * s)), h, c, dz, acc, acc_b2);
+        dacc[0] -= dz[0]; dacc[1] -= dz[1];
+        ++cnt;
+        // mirrored pair (j, i): z' = u_i - u_j + b1, alpha_ji = -alpha
+        z[0] = ui[0] - uj[0] + h.b1[0]; z[1] = ui[1] - uj[1] + h.b1[1];
+        s = head_eval(z, h, c);
+        head_back(alpha / (1.0f + expf(-alpha * s)), h, c, dz, nullptr, acc_b2);
+        dacc[0] += dz[0]; dacc[1] += dz[1];
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        sacc[wave][0][lane + 64 * e] = dacc[e];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) sacc[wave][1 + t][lane + 64 * e] = acc[t][e];
+    }
+    if (lane == 0) { sred[wave][0] = acc_b2; sred[wave][1] = lsum; }
+    __shared__ int scnt[4];
+    if (lane == 0) scnt[wave] = cnt;
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 5 * 128; idx += 256) {
+        const int t = idx >> 7, k = idx & 127;
+        const float v = sacc[0][t][k] + sacc[1][t][k] + sacc[2][t][k] + sacc[3][t][k];
+        if (t == 0) dui[k] = v;
+        else atomicAdd(hg + (long)set * HG_SIZE + (t - 1) * 128 + k, v);
+    }
+    if (threadIdx.x == 0) {
+        atomicAdd(hg + (long)set * HG_SIZE + 512, sred[0][0] + sred[1][0] + sred[2][0] + sred[3][0]);
+        atomicAdd(loss_sum + set, sred[0][1] + sred[1][1] + sred[2][1] + sred[3][1]);
+        atomicAdd(pair_cnt + set, scnt[0] + scnt[1] + scnt[2] + scnt[3]);
+    }
+}
+
+// L1(head(f1 - f2), tanh(d1 - d2)) rows (src/finetune_timm_vggt.py:475-479): one wave per keypoint.
+// u holds [P][2][Nmax][128]; writes du for both views (du1 = +dz, du2 = -dz, scaled by gscale[p]/n),
+// head grads (scaled) into hg[p], loss_sum[p] += |s - t| / n.
+__global__ __launch_bounds__(256) void depth_l1_kernel(const float* u, const float* d1, const float* d2,
+                                                       const int* counts, const float* gscale, const float* b1,
+                                                       const float* lw, const float* lb, const float* w2,
+                                                       const float* b2, float* du, float* hg, float* loss_sum,
+                                                       int Nmax) {
+    const int p = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = blockIdx.x * 4 + wave, n = counts ? counts[p] : Nmax;
+    if (k >= Nmax) return;
+    float* du1 = du + (((long)p * 2 + 0) * Nmax + k) * 128;
+    float* du2 = du + (((long)p * 2 + 1) * Nmax + k) * 128;
+    if (k >= n) {
+        du1[lane] = du1[lane + 64] = du2[lane] = du2[lane + 64] = 0.f;
+        return;
+    }
+    const HeadW h = load_head(b1, lw, lb, w2, b2, lane);
+    const float* u1 = u + (((long)p * 2 + 0) * Nmax + k) * 128;
+    const float* u2 = u + (((long)p * 2 + 1) * Nmax + k) * 128;
+    float z[2] = {u1[lane] - u2[lane] + h.b1[0], u1[lane + 64] - u2[lane + 64] + h.b1[1]};
+    HeadCache c;
+    const float s = head_eval(z, h, c);
+    const float t = tanhf(d1[(long)p * Nmax + k] - d2[(long)p * Nmax + k]);
+    const float diff = s - t, w = gscale[p] / (float)n;
+    float acc[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+    float acc_b2 = 0.f, dz[2];
+    head_back((diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f)) * w, h, c, dz, acc, acc_b2);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        du1[lane + 64 * e] = dz[e];
+        du2[lane + 64 * e] = -dz[e];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) atomicAdd(hg + (long)p * HG_SIZE + tt * 128 + lane + 64 * e, acc[tt][e]);
+    }
+    if (lane == 0) {
+        atomicAdd(hg + (long)p * HG_SIZE + 512, acc_b2);
+        atomicAdd(loss_sum + p, fabsf(diff) / (float)n);
+    }
+}
+
+// du[set] *= g[set]/cnt, hg_out += hg[set] * g[set]/cnt, loss[set] = loss_sum/cnt (0 when no valid pair)
+__global__ __launch_bounds__(256) void pair_rank_finalize_kernel(float* du, const float* hg, const float* loss_sum,
+                                                                 const int* pair_cnt, const float* gscale,
+                                                                 float* hg_out, float* loss, int Nmax) {
+    const int set = blockIdx.x;
+    const int cnt = pair_cnt[set];
+    const float sc = cnt > 0 ? gscale[set] / (float)cnt : 0.f;
+    for (long idx = threadIdx.x; idx < (long)Nmax * 128; idx += 256) du[(long)set * Nmax * 128 + idx] *= sc;
+    for (int idx = threadIdx.x; idx < HG_SIZE; idx += 256)
+        if (idx <= 512) atomicAdd(hg_out + idx, hg[(long)set * HG_SIZE + idx] * sc);
+    if (threadIdx.x == 0) loss[set] = cnt > 0 ? loss_sum[set] / (float)cnt : 0.f;
+}
+
+// out[c] += sum_r in[r][c]
+__global__ __launch_bounds__(256) void row_sum_cols_kernel(const float* in, float* out, int rows, int cols) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += in[(long)r * cols + c];
+    out[c] += s;
+}
+
+// ---------------------------------------------------------------------------------------------------
+extern "C" int gd_smooth_ap(const float* sim, const float* pts3d_1, const float* pts3d_2, const int* counts, int P,
+                            int Nmax, int variant, float thres3d_neg, float temp, float* loss, float* dsim,
+                            float* row_ws, void* stream) {
+    GD_REQUIRE(P > 0 && Nmax > 0 && temp > 0.f, "gd_smooth_ap: bad arguments");
+    GD_REQUIRE(variant == 0 || variant == 1, "gd_smooth_ap: variant must be 0 (vggt) or 1 (mast3r)");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(smooth_ap_kernel, dim3(Nmax, P), dim3(256), 0, s, sim, pts3d_1, pts3d_2, counts, row_ws, dsim,
+                       Nmax, variant, thres3d_neg, 1.0f / temp);
+    hipLaunchKernelGGL(row_sum_kernel, dim3(P), dim3(256), 0, s, row_ws, loss, Nmax);
+    GD_LAUNCH_OK();
+    return 0;
+}
+
+// workspace floats: hg [S,516] | loss_sum [S] | pair_cnt [S] (int)
+extern "C" size_t gd_pair_rank_workspace_bytes(int S) { return (size_t)S * (HG_SIZE + 2) * sizeof(float); }
+
+extern "C" int gd_pair_rank(const float* u, const float* depth, const int* counts, const float* gscale, int S,
+                            int Nmax, float depth_threshold, const float* b1, const float* ln_w, const float* ln_b,
+                            const float* w2, const float* b2, float* loss, float* du, float* head_grad,
+                            void* workspace, void* stream) {
+    GD_REQUIRE(S > 0 && Nmax > 0, "gd_pair_rank: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    float* hg = (float*)workspace;
+    float* lsum = hg + (long)S * HG_SIZE;
+    int* cnt = (int*)(lsum + S);
+    hipMemsetAsync(workspace, 0, gd_pair_rank_workspace_bytes(S), s);
+    hipLaunchKernelGGL(pair_rank_kernel, dim3(Nmax, S), dim3(256), 0, s, u, depth, counts, b1, ln_w, ln_b, w2, b2, du,
+                       hg, lsum, cnt, Nmax, depth_threshold);
+    hipLaunchKernelGGL(pair_rank_finalize_kernel, dim3(S), dim3(256), 0, s, du, hg, lsum, cnt, gscale, head_grad, loss,
+                       Nmax);
+    GD_LAUNCH_OK();
+    return 0;
+}
+
+extern "C" int gd_depth_l1(const float* u, const float* d1, const float* d2, const int* counts, const float* gscale,
+                           int P, int Nmax, const float* b1, const float* ln_w, const float* ln_b, const float* w2,
+                           const float* b2, float* loss, float* du, float* head_grad, void* workspace, void* stream) {
+    GD_REQUIRE(P > 0 && Nmax > 0, "gd_depth_l1: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    float* hg = (float*)workspace;   // [P, 516] scratch
+    hipMemsetAsync(hg, 0, (size_t)P * HG_SIZE * sizeof(float), s);
+    hipMemsetAsync(loss, 0, (size_t)P * sizeof(float), s);
+    hipLaunchKernelGGL(depth_l1_kernel, dim3(gd_cdiv(Nmax, 4), P), dim3(256), 0, s, u, d1, d2, counts, gscale, b1, ln_w,
+                       ln_b, w2, b2, du, hg, loss, Nmax);
+    hipLaunchKernelGGL(row_sum_cols_kernel, dim3(gd_cdiv(HG_SIZE, 256)), dim3(256), 0, s, hg, head_grad, P, HG_SIZE);
+    GD_LAUNCH_OK();
+    return 0;
+}

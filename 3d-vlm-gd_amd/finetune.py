@@ -1,0 +1,240 @@
+"""Geometric-distillation fine-tuning step on HIP kernels — the host-side mirror of the reference's
+LightningModules `FinetuneVGGTTIMM` (src/finetune_timm_vggt.py:81-648) and `FinetuneMASt3RTIMM`
+(src/finetune_timm_mast3r.py:72-689), with the same method names and argument meaning, batched over P
+image pairs (the reference is hard-wired to one pair per rank; P pairs here = P data-parallel ranks of it,
+the loss is the mean over pairs).
+
+The frozen teacher (MASt3R / VGGT) is OUTSIDE this module: `training_step` takes its outputs (cost maps,
+keypoints, 3-D points, depth maps, co-view masks) as the batch's teacher targets (a18-a20 run as
+cached PyTorch-ROCm inference; for benchmarks they are synthetic).
+
+geometry = "reference": keypoint features at target_res/downsample_factor tokens (640/8 = 80 on the long
+side), cost features at the teacher grid — the reference's three resolutions (two distinct forwards).
+geometry = "shared": one forward per image at the teacher grid feeds all three extractors (BASELINE 518^2).
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .model import Adapter, BlockWithAdapter, DepthAwareFeatureFusion, _LoRA_qkv
+from .vit import conv3x3_tokens, create_vit, kp_gather
+
+
+class FinetuneGD(nn.Module):
+    def __init__(self, r=4, backbone="vit_base", patch_size=14, img_size=518, variant="vggt", geometry="shared",
+                 dtype="bf16", ap_loss_weight=1.0, depth_loss_weight=None, intra_depth_loss_weight=1.0,
+                 kl_loss_weight=1.0, teacher_patch=None, adapter_start_idx=4, bottleneck_dim=64, vit_kwargs=None,
+                 lora_b_std=0.0, seed=0):
+        super().__init__()
+        assert r > 0 and variant in ("vggt", "mast3r") and geometry in ("shared", "reference")
+        self.variant, self.geometry = variant, geometry
+        self.ap_loss_weight = ap_loss_weight
+        # reference defaults: MASt3R depth_loss_weight=0.0 (finetune_timm_mast3r.py:79-82), VGGT 1.0 (:86-89)
+        self.depth_loss_weight = (0.0 if variant == "mast3r" else 1.0) if depth_loss_weight is None else depth_loss_weight
+        self.intra_depth_loss_weight = intra_depth_loss_weight
+        self.kl_loss_weight = kl_loss_weight
+        model = create_vit(backbone, patch_size=patch_size, img_size=img_size, dtype=dtype, **(vit_kwargs or {}))
+        self.embedding_dim = model.embed_dim
+        for p in model.parameters():
+            p.requires_grad = False
+        # --- LoRA(q,v) + adapters on blocks[adapter_start_idx:]  (src/finetune_timm_vggt.py:134-162) ---
+        self.w_As, self.w_Bs = [], []
+        self.adapters = nn.ModuleList()
+        g = torch.Generator().manual_seed(seed + 1)
+        for blk_idx in range(adapter_start_idx, len(model.blocks)):
+            blk = model.blocks[blk_idx]
+            w_qkv_linear = blk.attn.qkv
+            self.dim = w_qkv_linear.in_features
+            w_a_q, w_b_q = nn.Linear(self.dim, r, bias=False), nn.Linear(r, self.dim, bias=False)
+            w_a_v, w_b_v = nn.Linear(self.dim, r, bias=False), nn.Linear(r, self.dim, bias=False)
+            self.w_As += [w_a_q, w_a_v]
+            self.w_Bs += [w_b_q, w_b_v]
+            blk.attn.qkv = _LoRA_qkv(w_qkv_linear, w_a_q, w_b_q, w_a_v, w_b_v)
+            adapter = Adapter(dim=self.embedding_dim, bottleneck_dim=bottleneck_dim)
+            model.blocks[blk_idx] = BlockWithAdapter(blk, adapter)
+            self.adapters.append(adapter)
+        self.reset_parameters(lora_b_std, g)
+        self.model = model
+        self.downsample_factor = 8
+        self.refine_conv = nn.Conv2d(self.embedding_dim, self.embedding_dim, kernel_size=3, stride=1, padding=1)
+        self.thres3d_neg = 0.1
+        self.patch_size = model.patch_embed.patch_size[0]
+        self.target_res = 640
+        self.depth_diff_head = DepthAwareFeatureFusion(input_dim=self.embedding_dim, use_tanh=True)
+        self.resize_patch_size = teacher_patch or (14 if variant == "vggt" else self.patch_size)
+        self._fwd_cache = {}
+        self._flat = None
+
+    def reset_parameters(self, lora_b_std=0.0, generator=None):
+        """A: kaiming-uniform(a=sqrt 5), B: zeros (src/finetune_timm_vggt.py:166-170).  lora_b_std > 0 gives the
+        small non-zero B that gradient-parity runs use (zero-init hides bugs)."""
+        for w_A in self.w_As:
+            nn.init.kaiming_uniform_(w_A.weight, a=math.sqrt(5), generator=generator)
+        for w_B in self.w_Bs:
+            if lora_b_std > 0:
+                nn.init.normal_(w_B.weight, std=lora_b_std, generator=generator)
+            else:
+                nn.init.zeros_(w_B.weight)
+
+    # ------------------------------------------------------------------ optimiser state (flat buffers)
+    def trainable_parameters(self):
+        """Order of configure_optimizers (src/finetune_timm_vggt.py:642-648)."""
+        return ([l.weight for l in self.w_As] + [l.weight for l in self.w_Bs] + list(self.refine_conv.parameters())
+                + list(self.depth_diff_head.parameters()) + list(self.adapters.parameters()))
+
+    def configure_optimizers(self, lr=1e-5, weight_decay=1e-4, max_norm=1.0):
+        """Re-seat every trainable tensor as a view of ONE flat fp32 buffer (params / grads / Adam moments):
+        one fused clip+AdamW launch and one all-reduce message per step."""
+        ps = self.trainable_parameters()
+        al = lambda k: (k + 3) // 4 * 4          # every tensor starts 16-byte aligned (GEMM operand requirement);
+        n = sum(al(p.numel()) for p in ps)       # the pad elements stay zero in params, grads and moments
+        dev = ps[0].device
+        flat_p = torch.zeros(n, dtype=torch.float32, device=dev)
+        flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        for p in ps:
+            k = p.numel()
+            flat_p[off:off + k] = p.detach().reshape(-1)
+            p.data = flat_p[off:off + k].view(p.shape)
+            p.grad = flat_g[off:off + k].view(p.shape)
+            off += al(k)
+        self._flat = {"p": flat_p, "g": flat_g, "m": torch.zeros_like(flat_p), "v": torch.zeros_like(flat_p),
+                      "step": 0, "lr": lr, "wd": weight_decay, "max_norm": max_norm}
+        return self._flat
+
+    def zero_grad_flat(self):
+        self._flat["g"].zero_()
+
+    def optimizer_step(self, grad_scale=1.0):
+        f = self._flat
+        f["step"] += 1
+        return ops.clip_adamw_step(f["p"], f["g"], f["m"], f["v"], f["step"], lr=f["lr"], weight_decay=f["wd"],
+                                   max_norm=f["max_norm"], grad_scale=grad_scale)
+
+    # ------------------------------------------------------------------ checkpoint layout
+    def on_save_checkpoint(self, checkpoint):
+        checkpoint["state_dict"] = {"refine_conv": self.refine_conv.state_dict()}
+        for i, l in enumerate(self.w_As):
+            checkpoint[f"w_a_{i:03d}"] = l.weight
+        for i, l in enumerate(self.w_Bs):
+            checkpoint[f"w_b_{i:03d}"] = l.weight
+        checkpoint["depth_diff_head"] = self.depth_diff_head.state_dict()
+        for i, a in enumerate(self.adapters):
+            checkpoint[f"adapter_{i:03d}"] = a.state_dict()
+        return checkpoint
+
+    def on_load_checkpoint(self, checkpoint):
+        with torch.no_grad():
+            self.refine_conv.load_state_dict(checkpoint["state_dict"]["refine_conv"])
+            for i, l in enumerate(self.w_As):
+                l.weight.copy_(checkpoint[f"w_a_{i:03d}"])
+            for i, l in enumerate(self.w_Bs):
+                l.weight.copy_(checkpoint[f"w_b_{i:03d}"])
+            self.depth_diff_head.load_state_dict(checkpoint["depth_diff_head"])
+            for i, a in enumerate(self.adapters):
+                a.load_state_dict(checkpoint[f"adapter_{i:03d}"])
+
+    # ------------------------------------------------------------------ student forwards
+    def _kp_grid(self, h, w):
+        if self.geometry == "shared":
+            return h // self.resize_patch_size, w // self.resize_patch_size
+        tr, ds = self.target_res, self.downsample_factor
+        tgt = (tr, int(w * tr / h)) if h > w else (int(h * tr / w), tr)
+        return tgt[0] // ds, tgt[1] // ds
+
+    def _forward(self, rgbs, gh, gw):
+        """taps [4..7] + last block output at a gh x gw token grid; cached per (image tensor, grid) so that the three
+        extractors of one step share a forward where their resolutions coincide."""
+        key = (rgbs.data_ptr(), rgbs._version, tuple(rgbs.shape), gh, gw)
+        if key not in self._fwd_cache:
+            P = self.patch_size
+            taps, x = self.model.forward_all(rgbs, (4, 5, 6, 7), size=(gh * P, gw * P))
+            self._fwd_cache[key] = (taps, x)
+        return self._fwd_cache[key]
+
+    def clear_cache(self):
+        self._fwd_cache = {}
+
+    def get_intermediate_feature(self, rgbs, pts=None, n=(4, 5, 6, 7), normalize=True):
+        """src/finetune_timm_vggt.py:256-302 (reshape=True path): mean over taps of bilinear samples of the
+        (final-normed) tap grids at the keypoints -> [B, N, D] fp32."""
+        h, w = rgbs.shape[-2:]
+        gh, gw = self._kp_grid(h, w)
+        P = self.patch_size
+        taps, _ = self._forward(rgbs, gh, gw)
+        sel = [taps[(4, 5, 6, 7).index(i)] for i in n]
+        grids = [self.model.norm(t) for t in sel] if normalize else sel
+        return kp_gather(grids, pts, gh, gw, (gw * P) / w, (gh * P) / h, gh * P, gw * P, P)
+
+    def get_feature(self, rgbs, pts, normalize=True):
+        """src/finetune_timm_vggt.py:304-332: forward_features -> refine_conv -> bilinear sample -> L2 normalise."""
+        h, w = rgbs.shape[-2:]
+        gh, gw = self._kp_grid(h, w)
+        P = self.patch_size
+        _, x = self._forward(rgbs, gh, gw)
+        fmap = conv3x3_tokens(self.model.norm(x), self.refine_conv.weight, self.refine_conv.bias, gh, gw)
+        feat = kp_gather([fmap], pts, gh, gw, (gw * P) / w, (gh * P) / h, gh * P, gw * P, P)
+        return ops.l2_normalize(feat) if normalize else feat
+
+    def get_feature_cost(self, rgbs):
+        """src/finetune_timm_vggt.py:335-355 (tap 7) / src/finetune_timm_mast3r.py:321-342 (mean of taps 4-7), no
+        norm, prefix dropped -> [B, hw, D] in the engine dtype."""
+        h, w = rgbs.shape[-2:]
+        ch, cw = h // self.resize_patch_size, w // self.resize_patch_size
+        taps, _ = self._forward(rgbs, ch, cw)
+        sel = [taps[3]] if self.variant == "vggt" else list(taps)
+        return ops.tap_mean(sel, prefix=self.model.num_prefix_tokens)
+
+    # ------------------------------------------------------------------ losses (per-pair vectors [P])
+    def calculate_depth_loss(self, depth_1, depth_2, rgbs, kp_1, kp_2, counts=None, indices=(4, 5, 6, 7)):
+        """src/finetune_timm_vggt.py:465-485.  rgbs = cat(rgb_1, rgb_2) [2P,3,h,w]; depth_k [P,H,W]."""
+        P = kp_1.shape[0]
+        kp = torch.cat([kp_1, kp_2], 0)
+        feat = self.get_intermediate_feature(rgbs, pts=kp, n=indices, normalize=True)       # [2P,N,D]
+        feats = torch.stack([feat[:P], feat[P:]], 1)                                         # [P,2,N,D]
+        d1, d2 = ops.kp_depth(depth_1, kp_1), ops.kp_depth(depth_2, kp_2)
+        return ops.depth_losses(feats, d1, d2, self.depth_diff_head.head_params(), counts=counts, depth_threshold=0.05)
+
+    def calculate_cost_loss(self, rgbs, cost_1, cost_2, kp_1=None, kp_2=None, mask_1=None, mask_2=None):
+        """src/finetune_timm_vggt.py:488-533 / src/finetune_timm_mast3r.py:504-540."""
+        h, w = rgbs.shape[-2:]
+        P = rgbs.shape[0] // 2
+        f = self.get_feature_cost(rgbs)
+        ph, pw = h // self.resize_patch_size, w // self.resize_patch_size
+        if self.variant == "mast3r" or mask_1 is None:
+            m1 = ops.patch_mask(kp_1, h, w, self.patch_size)
+            m2 = ops.patch_mask(kp_2, h, w, self.patch_size)
+        else:
+            m1 = F.interpolate(mask_1[:, None].float(), size=(ph, pw), mode="nearest").reshape(P, -1) > 0
+            m2 = F.interpolate(mask_2[:, None].float(), size=(ph, pw), mode="nearest").reshape(P, -1) > 0
+        return ops.cost_volume_kl(f[:P], f[P:], cost_1, cost_2, m1, m2, self.variant)
+
+    def calculate_matching_loss(self, rgbs, kp_1, kp_2, pts3d_1, pts3d_2, counts=None):
+        """src/finetune_timm_vggt.py:536-574 / src/finetune_timm_mast3r.py:543-589.  pts3d_k [P,N,3] are the
+        teacher's 3-D points already gathered at the keypoints."""
+        P = kp_1.shape[0]
+        desc = self.get_feature(rgbs, torch.cat([kp_1, kp_2], 0), normalize=True)
+        return ops.smooth_ap(desc[:P], desc[P:], pts3d_1, pts3d_2, counts, self.variant, self.thres3d_neg, 0.01)
+
+    def training_step(self, batch):
+        """Loss of P pairs = mean over pairs of the reference's per-pair loss (src/finetune_timm_vggt.py:599-616).
+        batch: rgb_1, rgb_2 [P,3,h,w] in [0,1]; kp_1, kp_2 [P,N,2] px; counts int32 [P] (optional);
+        pts3d_1, pts3d_2 [P,N,3]; depth_1, depth_2 [P,h,w]; cost_1, cost_2 [P,hw,hw];
+        mask_1, mask_2 [P,h,w] bool (vggt)."""
+        self.clear_cache()
+        rgbs = torch.cat([batch["rgb_1"], batch["rgb_2"]], 0).contiguous()
+        counts = batch.get("counts")
+        depth_loss, intra = self.calculate_depth_loss(batch["depth_1"], batch["depth_2"], rgbs, batch["kp_1"],
+                                                      batch["kp_2"], counts)
+        kl = self.calculate_cost_loss(rgbs, batch["cost_1"], batch["cost_2"], batch["kp_1"], batch["kp_2"],
+                                      batch.get("mask_1"), batch.get("mask_2"))
+        ap = self.calculate_matching_loss(rgbs, batch["kp_1"], batch["kp_2"], batch["pts3d_1"], batch["pts3d_2"], counts)
+        per_pair = (self.ap_loss_weight * ap + self.depth_loss_weight * depth_loss
+                    + self.intra_depth_loss_weight * intra + self.kl_loss_weight * kl)
+        self.clear_cache()
+        terms = {"ap_loss": ap.detach(), "depth_loss": depth_loss.detach(), "intra_depth_loss": intra.detach(),
+                 "kl_loss": kl.detach()}
+        return per_pair.mean(), terms

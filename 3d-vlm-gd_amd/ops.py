@@ -11,6 +11,40 @@ def _req(cond, msg):
         raise _lib.GdHipError(msg)
 
 
+class GemmProfiler:
+    """HIP-event bracket around every gd_gemm_nt launch on the current stream (bench.py's roofline leg)."""
+
+    def __init__(self):
+        self.records = []
+
+    def totals(self):
+        torch.cuda.synchronize()
+        flops = sum(r[2] for r in self.records)
+        ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
+        return flops, ms, len(self.records)
+
+
+_PROFILER = None
+
+
+def set_gemm_profiler(p):
+    global _PROFILER
+    _PROFILER = p
+
+
+def time_on_stream(fn, warm=2, iters=5):
+    """seconds per call, HIP events on the current stream."""
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+
 def gemm_nt(a, w, out=None, *, out_dtype=None, alpha=1.0, bias=None, lora_t=None, lora_b=None, preact=None,
             act=0, dact_src=None, dact=0, residual=None, accumulate=False):
     """out[M,N] = epilogue(alpha * a[M,K] @ w[N,K]^T).  a, w: same dtype (f32 | bf16), last dim contiguous.
@@ -45,26 +79,35 @@ def gemm_nt(a, w, out=None, *, out_dtype=None, alpha=1.0, bias=None, lora_t=None
     if lora_t is not None:
         rt = lora_t.shape[1]
         _req(tuple(lora_t.shape) == (M, rt) and tuple(lora_b.shape) == (rt, N), "gemm_nt: bad lora shapes")
+    if _PROFILER is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     rc = lib().gd_gemm_nt(ptr(a), ptr(w), ptr(out), M, N, K, lda, ldw, out.stride(-2), B, sA, sW,
                           out.stride(0) if batched else 0, dtype_code(a), cdt, float(alpha), ptr(bias), ptr(lora_t),
                           ptr(lora_b), rt, ptr(preact), preact.stride(0) if preact is not None else 0, int(act),
                           ptr(dact_src), dact_src.stride(0) if dact_src is not None else 0, int(dact), ptr(residual),
                           residual.stride(0) if residual is not None else 0, 1 if accumulate else 0, stream())
+    if _PROFILER is not None:
+        e1.record()
+        _PROFILER.records.append((e0, e1, 2.0 * M * N * K * B))
     check(rc, "gd_gemm_nt")
     return out
 
 
 def gemm_tn(y, x, out=None, *, alpha=1.0):
     """out[N,K] (fp32) += alpha * y[M,N]^T @ x[M,K]   (weight gradients; fp32 accumulation)."""
-    _req(y.is_cuda and x.is_cuda and y.stride(-1) == 1 and x.stride(-1) == 1 and y.shape[0] == x.shape[0],
+    _req(y.is_cuda and x.is_cuda and y.stride(-1) == 1 and x.stride(-1) == 1 and y.shape[:-1] == x.shape[:-1],
          "gemm_tn: bad operands")
-    M, N = y.shape
-    K = x.shape[1]
+    batched = y.dim() == 3
+    M, N = y.shape[-2:]
+    K = x.shape[-1]
+    B = y.shape[0] if batched else 1
     if out is None:
-        out = torch.zeros((N, K), dtype=torch.float32, device=y.device)
+        out = torch.zeros((B, N, K) if batched else (N, K), dtype=torch.float32, device=y.device)
     _req(out.dtype == torch.float32 and out.stride(-1) == 1, "gemm_tn: out must be fp32, contiguous rows")
-    rc = lib().gd_gemm_tn(ptr(y), ptr(x), ptr(out), M, N, K, y.stride(0), x.stride(0), out.stride(0), dtype_code(y),
-                          dtype_code(x), float(alpha), stream())
+    rc = lib().gd_gemm_tn(ptr(y), ptr(x), ptr(out), M, N, K, y.stride(-2), x.stride(-2), out.stride(-2), B,
+                          y.stride(0) if batched else 0, x.stride(0) if batched else 0,
+                          out.stride(0) if batched else 0, dtype_code(y), dtype_code(x), float(alpha), stream())
     check(rc, "gd_gemm_tn")
     return out
 
@@ -129,3 +172,291 @@ def attention_bwd(qkv, o, dout, lse, B, N, H):
                                 64 ** -0.5, dtype_code(qkv), stream())
     check(rc, "gd_attention_bwd")
     return dqkv
+
+
+# ----------------------------------------------------------------------------------------------
+# normalisation
+# ----------------------------------------------------------------------------------------------
+def layernorm_fwd(x, gamma, beta, eps, *, save_stats=True, out_dtype=None):
+    """x [M,D] (rows may be strided) -> y [M,D], mean [M], rstd [M] (fp32; None when save_stats=False)."""
+    M, D = x.shape
+    y = torch.empty(M, D, dtype=out_dtype or x.dtype, device=x.device)
+    mean = torch.empty(M, dtype=torch.float32, device=x.device) if save_stats else None
+    rstd = torch.empty(M, dtype=torch.float32, device=x.device) if save_stats else None
+    rc = lib().gd_layernorm_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), M, D, x.stride(0),
+                                y.stride(0), float(eps), dtype_code(x), dtype_code(y), stream())
+    check(rc, "gd_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, dyscale=1.0):
+    """dx [M,D] (dtype of x) = LN'(dy * dyscale) (+ dres)."""
+    M, D = x.shape
+    _req(x.is_contiguous() and dy.stride(-1) == 1 and (dres is None or dres.is_contiguous()), "layernorm_bwd: layout")
+    dx = torch.empty_like(x)
+    rc = lib().gd_layernorm_bwd(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), M, D,
+                                dy.stride(0), x.stride(0), float(dyscale), dtype_code(x), dtype_code(dy), stream())
+    check(rc, "gd_layernorm_bwd")
+    return dx
+
+
+class _L2Norm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, eps):
+        x = x.contiguous().float()
+        M, D = x.numel() // x.shape[-1], x.shape[-1]
+        y = torch.empty_like(x)
+        inv = torch.empty(M, dtype=torch.float32, device=x.device)
+        check(lib().gd_l2norm_fwd(ptr(x), ptr(y), ptr(inv), M, D, float(eps), stream()), "gd_l2norm_fwd")
+        ctx.save_for_backward(y, inv)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, inv = ctx.saved_tensors
+        dy = dy.contiguous().float()
+        dx = torch.empty_like(y)
+        check(lib().gd_l2norm_bwd(ptr(y), ptr(dy), ptr(inv), ptr(dx), inv.numel(), y.shape[-1], stream()), "gd_l2norm_bwd")
+        return dx, None
+
+
+def l2_normalize(x, eps=1e-12):
+    """F.normalize(x, p=2, dim=-1) on fp32 rows, HIP forward/backward."""
+    return _L2Norm.apply(x, eps)
+
+
+# ----------------------------------------------------------------------------------------------
+# image prep / tokens / conv glue
+# ----------------------------------------------------------------------------------------------
+def patch_im2col(img, H, W, P, Kp, mean, std, dtype):
+    """img [B,3,h,w] fp32 in [0,1] -> col [B*(H/P)*(W/P), Kp]: resize to (H,W) + Normalize + im2col, zero padded."""
+    import ctypes
+    img = img.contiguous().float()
+    B, _, h, w = img.shape
+    col = torch.empty(B * (H // P) * (W // P), Kp, dtype=dtype, device=img.device)
+    m3, s3 = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
+    check(lib().gd_patch_im2col(ptr(img), ptr(col), B, h, w, H, W, P, Kp, m3, s3, dtype_code(col), stream()),
+          "gd_patch_im2col")
+    return col
+
+
+def assemble_tokens(patch, cls, pos, B, Np):
+    D = patch.shape[-1]
+    out = torch.empty(B * (Np + 1), D, dtype=patch.dtype, device=patch.device)
+    check(lib().gd_assemble_tokens(ptr(patch), ptr(cls), ptr(pos), ptr(out), B, Np, D, dtype_code(patch), stream()),
+          "gd_assemble_tokens")
+    return out
+
+
+def im2col3x3(x, bstride, B, gh, gw, D):
+    """x: tensor whose data_ptr is grid element (b=0,y=0,x=0,c=0); batch stride `bstride` elements."""
+    col = torch.empty(B * gh * gw, 9 * D, dtype=x.dtype, device=x.device)
+    check(lib().gd_im2col3x3(ptr(x), bstride, ptr(col), B, gh, gw, D, dtype_code(x), stream()), "gd_im2col3x3")
+    return col
+
+
+def col2im3x3(dcol, B, gh, gw, D):
+    dx = torch.empty(B * gh * gw, D, dtype=dcol.dtype, device=dcol.device)
+    check(lib().gd_col2im3x3(ptr(dcol), ptr(dx), gh * gw * D, B, gh, gw, D, dtype_code(dcol), stream()), "gd_col2im3x3")
+    return dx
+
+
+def _ptr_array(tensors):
+    import ctypes
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def kp_gather_fwd(grids, bstride, kp, B, Nk, gh, gw, D, sx, sy, img_h, img_w, patch):
+    """grids: list (1..4) of tensors whose data_ptr is the (b=0, token 0 of the grid) element."""
+    out = torch.empty(B, Nk, D, dtype=torch.float32, device=kp.device)
+    check(lib().gd_kp_gather_fwd(_ptr_array(grids), len(grids), bstride, dtype_code(grids[0]), ptr(kp), ptr(out), B,
+                                 Nk, gh, gw, D, float(sx), float(sy), img_h, img_w, patch, patch, stream()),
+          "gd_kp_gather_fwd")
+    return out
+
+
+def kp_gather_bwd(ngrid, kp, dout, B, Nk, gh, gw, D, sx, sy, img_h, img_w, patch, prefix=0):
+    """-> list of ngrid fp32 gradient buffers [B, prefix + gh*gw, D] (prefix-token rows stay zero)."""
+    dg = [torch.zeros(B, prefix + gh * gw, D, dtype=torch.float32, device=kp.device) for _ in range(ngrid)]
+    dout = dout.contiguous().float()
+    check(lib().gd_kp_gather_bwd(_ptr_array([t[:, prefix:] for t in dg]), ngrid, (prefix + gh * gw) * D, ptr(kp), ptr(dout), B, Nk, gh, gw, D, float(sx), float(sy),
+                                 img_h, img_w, patch, patch, stream()), "gd_kp_gather_bwd")
+    return dg
+
+
+class _TapMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, prefix, *grids):
+        B, Nt, D = grids[0].shape
+        gs = [g.contiguous() for g in grids]
+        out = torch.empty(B, Nt - prefix, D, dtype=gs[0].dtype, device=gs[0].device)
+        check(lib().gd_tap_mean_fwd(_ptr_array(gs), len(gs), Nt * D, prefix, ptr(out), B, Nt - prefix, D,
+                                    dtype_code(out), stream()), "gd_tap_mean_fwd")
+        ctx.meta = (prefix, len(gs), B, Nt, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        prefix, ng, B, Nt, D = ctx.meta
+        dout = dout.contiguous()
+        dg = [torch.empty(B, Nt, D, dtype=dout.dtype, device=dout.device) for _ in range(ng)]
+        check(lib().gd_tap_mean_bwd(_ptr_array(dg), ng, prefix, ptr(dout), B, Nt - prefix, D, dtype_code(dout),
+                                    stream()), "gd_tap_mean_bwd")
+        return (None,) + tuple(dg)
+
+
+def tap_mean(grids, prefix=1):
+    """mean of 1..4 tap outputs [B, prefix+hw, D], prefix tokens dropped -> contiguous [B, hw, D]."""
+    return _TapMean.apply(prefix, *grids)
+
+
+def kp_depth(depth, kp):
+    """depth [B,H,W] f32, kp [B,Nk,2] (x,y) -> [B,Nk] 3x3 mean depth (extract_kp_depth)."""
+    B, H, W = depth.shape
+    Nk = kp.shape[1]
+    out = torch.empty(B, Nk, dtype=torch.float32, device=kp.device)
+    dm, kq = depth.contiguous().float(), kp.contiguous().float()      # keep both alive across the launch
+    check(lib().gd_kp_depth(ptr(dm), ptr(kq), ptr(out), B, Nk, H, W, stream()), "gd_kp_depth")
+    return out
+
+
+def patch_mask(kp, H, W, P):
+    """kp [B,Nk,2] -> uint8 [B, (H//P)*(W//P)] (get_patch_mask_from_kp_tensor)."""
+    B, Nk, _ = kp.shape
+    mask = torch.zeros(B, (H // P) * (W // P), dtype=torch.uint8, device=kp.device)
+    kq = kp.contiguous().float()
+    check(lib().gd_patch_mask(ptr(kq), ptr(mask), B, Nk, H, W, P, stream()), "gd_patch_mask")
+    return mask
+
+
+# ----------------------------------------------------------------------------------------------
+# sparse losses
+# ----------------------------------------------------------------------------------------------
+class _SmoothAP(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, desc1, desc2, pts1, pts2, counts, variant, thr, temp):
+        P, N0, C = desc1.shape
+        N = (N0 + 7) // 8 * 8                                      # gemm_tn wants multiples of 8: zero-pad keypoints
+        dev = desc1.device
+        if counts is None:
+            counts = torch.full((P,), N0, dtype=torch.int32, device=dev)
+
+        def pad(t, w):
+            out = torch.zeros(P, N, w, dtype=torch.float32, device=dev)
+            out[:, :N0] = t
+            return out
+        d1, d2, p1, p2 = pad(desc1, C), pad(desc2, C), pad(pts1, 3), pad(pts2, 3)
+        sim = gemm_nt(d1, d2)                                     # [P,N,N] fp32, exact-f32 MFMA
+        loss = torch.empty(P, dtype=torch.float32, device=dev)
+        dsim = torch.empty_like(sim)
+        rows = torch.empty(P, N, dtype=torch.float32, device=dev)
+        rc = lib().gd_smooth_ap(ptr(sim), ptr(p1), ptr(p2), ptr(counts), P, N, VARIANTS[variant], float(thr),
+                                float(temp), ptr(loss), ptr(dsim), ptr(rows), stream())
+        check(rc, "gd_smooth_ap")
+        ctx.save_for_backward(d1, d2, dsim)
+        ctx.n0 = N0
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        d1, d2, dsim = ctx.saved_tensors
+        gs = dsim * g.float().view(-1, 1, 1)
+        dd2 = gemm_tn(gs, d1)                                     # [P,N,C] = dsim^T d1
+        dd1 = gemm_tn(gs.transpose(1, 2).contiguous(), d2)        # [P,N,C] = dsim d2
+        return dd1[:, :ctx.n0], dd2[:, :ctx.n0], None, None, None, None, None, None
+
+
+def smooth_ap(desc1, desc2, pts3d_1, pts3d_2, counts=None, variant="vggt", thres3d_neg=0.1, temp=0.01):
+    """desc [P,N,C] unit descriptors, pts3d [P,N,3], counts int32 [P] (valid keypoints per pair) -> loss [P]."""
+    return _SmoothAP.apply(desc1, desc2, pts3d_1, pts3d_2, counts, variant, thres3d_neg, temp)
+
+
+HEAD_KEYS = ("w1", "b1", "ln_w", "ln_b", "w2", "b2")
+
+
+class _DepthLosses(torch.autograd.Function):
+    """depth L1 + intra-view ranking on keypoint features [P,2,N,D] with the DepthAwareFeatureFusion head."""
+
+    @staticmethod
+    def forward(ctx, feats, d1, d2, counts, thr, w1, b1, ln_w, ln_b, w2, b2):
+        P, _, N, D = feats.shape
+        f = feats.contiguous().float()
+        u = gemm_nt(f.view(P * 2 * N, D), w1.contiguous())         # [P*2*N,128] = W1 f
+        depth = torch.stack([d1, d2], 1).contiguous().float()      # [P,2,N]
+        dv1, dv2 = depth[:, 0].contiguous(), depth[:, 1].contiguous()
+        cnt2 = counts.repeat_interleave(2).contiguous() if counts is not None else None
+        ones_s = torch.ones(2 * P, dtype=torch.float32, device=f.device)
+        ones_p = torch.ones(P, dtype=torch.float32, device=f.device)
+        hp = [t.contiguous().float() for t in (b1, ln_w, ln_b, w2.view(-1), b2)]
+        rank = torch.empty(2 * P, dtype=torch.float32, device=f.device)
+        du_r = torch.empty(2 * P, N, 128, dtype=torch.float32, device=f.device)
+        hg_r = torch.zeros(516, dtype=torch.float32, device=f.device)
+        ws = torch.empty(lib().gd_pair_rank_workspace_bytes(2 * P), dtype=torch.uint8, device=f.device)
+        check(lib().gd_pair_rank(ptr(u), ptr(depth), ptr(cnt2), ptr(ones_s), 2 * P, N, float(thr), *[ptr(t) for t in hp],
+                                 ptr(rank), ptr(du_r), ptr(hg_r), ptr(ws), stream()), "gd_pair_rank")
+        l1 = torch.empty(P, dtype=torch.float32, device=f.device)
+        du_l = torch.empty(P, 2, N, 128, dtype=torch.float32, device=f.device)
+        hg_l = torch.zeros(516, dtype=torch.float32, device=f.device)
+        ws2 = torch.empty(P * 516 * 4, dtype=torch.uint8, device=f.device)
+        check(lib().gd_depth_l1(ptr(u), ptr(dv1), ptr(dv2), ptr(counts),
+                                ptr(ones_p), P, N, *[ptr(t) for t in hp], ptr(l1), ptr(du_l), ptr(hg_l), ptr(ws2),
+                                stream()), "gd_depth_l1")
+        # per-set gradients are linear in the upstream scale, so keep the per-set pieces for backward
+        ctx.save_for_backward(f, w1, du_r, du_l, u)
+        ctx.hp = hp
+        ctx.aux = (depth, dv1, dv2, cnt2, counts, thr, P, N, D)
+        intra = 0.5 * (rank.view(P, 2)[:, 0] + rank.view(P, 2)[:, 1])
+        return l1, intra
+
+    @staticmethod
+    def backward(ctx, g_l1, g_intra):
+        f, w1, du_r, du_l, u = ctx.saved_tensors
+        depth, dv1, dv2, cnt2, counts, thr, P, N, D = ctx.aux
+        hp = ctx.hp
+        dev = f.device
+        # re-run the two loss kernels with the upstream scales folded in (cheap: N^2 x 128 work)
+        gs = (0.5 * g_intra.float()).repeat_interleave(2).contiguous()
+        rank = torch.empty(2 * P, dtype=torch.float32, device=dev)
+        hg = torch.zeros(516, dtype=torch.float32, device=dev)
+        ws = torch.empty(lib().gd_pair_rank_workspace_bytes(2 * P), dtype=torch.uint8, device=dev)
+        check(lib().gd_pair_rank(ptr(u), ptr(depth), ptr(cnt2), ptr(gs), 2 * P, N, float(thr), *[ptr(t) for t in hp],
+                                 ptr(rank), ptr(du_r), ptr(hg), ptr(ws), stream()), "gd_pair_rank")
+        l1 = torch.empty(P, dtype=torch.float32, device=dev)
+        ws2 = torch.empty(P * 516 * 4, dtype=torch.uint8, device=dev)
+        gl = g_l1.contiguous().float()
+        check(lib().gd_depth_l1(ptr(u), ptr(dv1), ptr(dv2), ptr(counts),
+                                ptr(gl), P, N, *[ptr(t) for t in hp], ptr(l1), ptr(du_l), ptr(hg), ptr(ws2), stream()),
+              "gd_depth_l1")
+        du = (du_r.view(P, 2, N, 128) + du_l).view(P * 2 * N, 128)
+        df = gemm_nt(du, w1.t().contiguous()).view(P, 2, N, D)     # du . W1
+        dw1 = gemm_tn(du, f.view(P * 2 * N, D))                    # du^T f  [128, D]
+        return (df, None, None, None, None, dw1, hg[0:128].clone(), hg[128:256].clone(), hg[256:384].clone(),
+                hg[384:512].view(1, 128).clone(), hg[512:513].clone())
+
+
+def depth_losses(feats, depth_1, depth_2, head, counts=None, depth_threshold=0.05):
+    """feats [P,2,N,D] keypoint features of both views, depth_k [P,N]; head: dict w1,b1,ln_w,ln_b,w2,b2.
+    -> (depth_l1 [P], intra_rank [P])  (calculate_depth_loss tail)."""
+    return _DepthLosses.apply(feats, depth_1, depth_2, counts, depth_threshold, head["w1"], head["b1"], head["ln_w"],
+                              head["ln_b"], head["w2"], head["b2"])
+
+
+# ----------------------------------------------------------------------------------------------
+# optimiser
+# ----------------------------------------------------------------------------------------------
+def clip_adamw_step(params, grads, exp_avg, exp_avg_sq, step, lr=1e-5, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8,
+                    max_norm=1.0, grad_scale=1.0):
+    """In place on the flat fp32 buffers; returns the pre-clip global grad norm (device scalar)."""
+    norm = torch.empty(1, dtype=torch.float32, device=params.device)
+    ws = torch.empty(lib().gd_adamw_workspace_bytes(), dtype=torch.uint8, device=params.device)
+    check(lib().gd_clip_adamw_step(ptr(params), ptr(grads), ptr(exp_avg), ptr(exp_avg_sq), params.numel(), int(step),
+                                   lr, weight_decay, betas[0], betas[1], eps, max_norm, grad_scale, ptr(norm), ptr(ws),
+                                   stream()), "gd_clip_adamw_step")
+    return norm
+
+
+def cast(x, dtype, scale=1.0):
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    check(lib().gd_cast(ptr(x), ptr(out), x.numel(), float(scale), dtype_code(x), dtype_code(out), stream()), "gd_cast")
+    return out

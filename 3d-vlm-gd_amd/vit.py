@@ -1,0 +1,446 @@
+"""Student ViT on HIP kernels behind the timm `VisionTransformer` attribute surface.
+
+What the reference touches on the timm model keeps working: `model.blocks` (indexable, sliceable,
+item-assignable), `blk.attn.qkv` (`nn.Linear`, replaceable by `_LoRA_qkv`), blocks replaceable by
+`BlockWithAdapter`, `patch_embed.patch_size` / `.proj`, `norm`, `num_prefix_tokens`,
+`_intermediate_layers(x, n)`, `forward_features(x)`, `parameters()` (src/finetune_timm_vggt.py:106-162,
+276, 317-320).  Parameter names follow timm / the in-tree DINOv2 ViT (vggt/layers/vision_transformer.py),
+so those state_dicts load.
+
+Each transformer block — including a LoRA-wrapped qkv and an Adapter wrapper discovered on the module
+list — runs as ONE autograd.Function over the C ABI: LN -> QKV GEMM (+bias, + rank-r LoRA epilogue) ->
+flash attention -> proj GEMM (+residual) -> LN -> fc1 GEMM (+GELU) -> fc2 GEMM (+residual) -> adapter.
+The backbone is frozen: the backward computes dX only (pre-transposed frozen weights, LayerScale folded
+into proj/fc2 at plan time) plus the LoRA / adapter weight gradients, and blocks that see no
+grad-requiring input run forward-only.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .model import Adapter, BlockWithAdapter, _LoRA_qkv  # noqa: F401
+
+
+def _dt(name):
+    return {"f32": torch.float32, "bf16": torch.bfloat16, torch.float32: torch.float32,
+            torch.bfloat16: torch.bfloat16}[name]
+
+
+class GDAttention(nn.Module):
+    def __init__(self, dim, num_heads, qkv_bias=True, proj_bias=True):
+        super().__init__()
+        assert dim % num_heads == 0 and dim // num_heads == 64, "HIP attention is built for head_dim 64"
+        self.num_heads = num_heads
+        self.head_dim = dim // num_heads
+        self.scale = self.head_dim ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim, bias=proj_bias)
+
+
+class GDMlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.act = nn.GELU()
+        self.fc2 = nn.Linear(hidden, dim)
+
+
+class GDLayerScale(nn.Module):
+    def __init__(self, dim, init_values):
+        super().__init__()
+        self.gamma = nn.Parameter(init_values * torch.ones(dim))
+
+
+class GDBlock(nn.Module):
+    """Parameter container of one pre-LN block; executed by `run_block`."""
+
+    def __init__(self, dim, num_heads, mlp_ratio=4.0, init_values=None, eps=1e-6):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=eps)
+        self.attn = GDAttention(dim, num_heads)
+        self.ls1 = GDLayerScale(dim, init_values) if init_values else nn.Identity()
+        self.norm2 = nn.LayerNorm(dim, eps=eps)
+        self.mlp = GDMlp(dim, int(dim * mlp_ratio))
+        self.ls2 = GDLayerScale(dim, init_values) if init_values else nn.Identity()
+        self._plan = None
+
+    def forward(self, x):
+        return run_block(self, x)
+
+    # ---- frozen-weight plan: casted / folded / pre-transposed copies, built once per dtype ----
+    def plan(self, dtype):
+        if self._plan is not None and self._plan["dtype"] == dtype:
+            return self._plan
+        base = self.attn.qkv.qkv if isinstance(self.attn.qkv, _LoRA_qkv) else self.attn.qkv
+        dev = base.weight.device
+        D = base.in_features
+
+        def f32(t):
+            return t.detach().float().contiguous()
+
+        def zeros(n):
+            return torch.zeros(n, dtype=torch.float32, device=dev)
+
+        g1 = f32(self.ls1.gamma) if isinstance(self.ls1, GDLayerScale) else None
+        g2 = f32(self.ls2.gamma) if isinstance(self.ls2, GDLayerScale) else None
+        wproj, bproj = f32(self.attn.proj.weight), f32(self.attn.proj.bias) if self.attn.proj.bias is not None else zeros(D)
+        wfc2, bfc2 = f32(self.mlp.fc2.weight), f32(self.mlp.fc2.bias) if self.mlp.fc2.bias is not None else zeros(D)
+        if g1 is not None:
+            wproj, bproj = wproj * g1[:, None], bproj * g1
+        if g2 is not None:
+            wfc2, bfc2 = wfc2 * g2[:, None], bfc2 * g2
+        wqkv, w1 = f32(base.weight), f32(self.mlp.fc1.weight)
+
+        def both(w):
+            return w.to(dtype).contiguous(), w.t().to(dtype).contiguous()
+
+        p = {"dtype": dtype, "D": D, "H": self.attn.num_heads, "eps1": self.norm1.eps, "eps2": self.norm2.eps,
+             "ln1_w": f32(self.norm1.weight), "ln1_b": f32(self.norm1.bias),
+             "ln2_w": f32(self.norm2.weight), "ln2_b": f32(self.norm2.bias),
+             "bqkv": f32(base.bias) if base.bias is not None else zeros(3 * D), "bproj": bproj.contiguous(),
+             "b1": f32(self.mlp.fc1.bias) if self.mlp.fc1.bias is not None else zeros(w1.shape[0]),
+             "b2": bfc2.contiguous()}
+        p["wqkv"], p["wqkv_t"] = both(wqkv)
+        p["wproj"], p["wproj_t"] = both(wproj)
+        p["w1"], p["w1_t"] = both(w1)
+        p["w2"], p["w2_t"] = both(wfc2)
+        self._plan = p
+        return p
+
+
+def _unwrap(blk):
+    """-> (GDBlock, lora module or None, adapter module or None)."""
+    adapter = None
+    if isinstance(blk, BlockWithAdapter) or (hasattr(blk, "block") and hasattr(blk, "adapter")):
+        adapter, blk = blk.adapter, blk.block
+    if not isinstance(blk, GDBlock):
+        raise ops._lib.GdHipError(f"cannot fuse block of type {type(blk).__name__}")
+    q = blk.attn.qkv
+    lora = q if hasattr(q, "linear_a_q") else None
+    return blk, lora, adapter
+
+
+class _BlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, plan, B, Nt, a_q, b_q, a_v, b_v, down, up):
+        T, D, H = plan["dtype"], plan["D"], plan["H"]
+        M = B * Nt
+        x = x.contiguous()
+        need = x.requires_grad or any(t is not None and t.requires_grad for t in (a_q, b_q, a_v, b_v, down, up))
+        y1, mean1, rstd1 = ops.layernorm_fwd(x, plan["ln1_w"], plan["ln1_b"], plan["eps1"], save_stats=need)
+        t = at = bt = None
+        if a_q is not None:
+            r = a_q.shape[0]
+            at = torch.cat([a_q, a_v], 0).detach()                              # [2r, D] fp32
+            bt = torch.zeros(2 * r, 3 * D, dtype=torch.float32, device=x.device)
+            bt[:r, :D] = b_q.detach().t()
+            bt[r:, 2 * D:] = b_v.detach().t()
+            t = ops.gemm_nt(y1, at.to(T).contiguous(), out_dtype=torch.float32)  # [M, 2r]
+        qkv = ops.gemm_nt(y1, plan["wqkv"], bias=plan["bqkv"], lora_t=t, lora_b=bt)
+        o, lse = ops.attention_fwd(qkv, B, Nt, H)
+        x1 = ops.gemm_nt(o, plan["wproj"], bias=plan["bproj"], residual=x)
+        y2, mean2, rstd2 = ops.layernorm_fwd(x1, plan["ln2_w"], plan["ln2_b"], plan["eps2"], save_stats=need)
+        pre = torch.empty(M, plan["w1"].shape[0], dtype=T, device=x.device) if need else None
+        h = ops.gemm_nt(y2, plan["w1"], bias=plan["b1"], act=1, preact=pre)
+        x2 = ops.gemm_nt(h, plan["w2"], bias=plan["b2"], residual=x1)
+        out, hd = x2, None
+        if down is not None:
+            hd = ops.gemm_nt(x2, down.detach().to(T).contiguous(), act=2)
+            out = ops.gemm_nt(hd, up.detach().to(T).contiguous(), residual=x2)
+        if need:
+            ctx.plan, ctx.dims = plan, (B, Nt)
+            ctx.has_lora, ctx.has_ad = a_q is not None, down is not None
+            ctx.save_for_backward(x, mean1, rstd1, y1, t, at, bt, qkv, o, lse, x1, mean2, rstd2, pre, x2, hd,
+                                  down, up)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x, mean1, rstd1, y1, t, at, bt, qkv, o, lse, x1, mean2, rstd2, pre, x2, hd, down, up) = ctx.saved_tensors
+        plan, (B, Nt) = ctx.plan, ctx.dims
+        T, D, H = plan["dtype"], plan["D"], plan["H"]
+        dout = dout.contiguous().to(T)
+        g_down = g_up = g_aq = g_bq = g_av = g_bv = None
+        dx2 = dout
+        if ctx.has_ad:
+            dhp = ops.gemm_nt(dout, up.detach().t().to(T).contiguous(), dact_src=hd, dact=2)       # [M, 64]
+            g_up = ops.gemm_tn(dout, hd)                                                          # [D, 64]
+            g_down = ops.gemm_tn(dhp, x2)                                                         # [64, D]
+            dx2 = ops.gemm_nt(dhp, down.detach().t().to(T).contiguous(), residual=dout)
+        dpre = ops.gemm_nt(dx2, plan["w2_t"], dact_src=pre, dact=1)                               # [M, 4D]
+        dy2 = ops.gemm_nt(dpre, plan["w1_t"])
+        del dpre
+        dx1 = ops.layernorm_bwd(dy2, x1, plan["ln2_w"], mean2, rstd2, dres=dx2)
+        do = ops.gemm_nt(dx1, plan["wproj_t"])
+        dqkv = ops.attention_bwd(qkv, o, do, lse, B, Nt, H)
+        dy1 = ops.gemm_nt(dqkv, plan["wqkv_t"])
+        if ctx.has_lora:
+            r = at.shape[0] // 2
+            dt = ops.gemm_nt(dqkv, bt.to(T).contiguous(), out_dtype=torch.float32)                 # [M, 2r]
+            gbt = ops.gemm_tn(t, dqkv)                                                            # [2r, 3D]
+            gat = ops.gemm_tn(dt, y1)                                                             # [2r, D]
+            ops.gemm_nt(dt, at.t().contiguous(), out=dy1, accumulate=True)                        # += dt . At
+            g_bq, g_bv = gbt[:r, :D].t().contiguous(), gbt[r:, 2 * D:].t().contiguous()
+            g_aq, g_av = gat[:r].contiguous(), gat[r:].contiguous()
+        dx = ops.layernorm_bwd(dy1, x, plan["ln1_w"], mean1, rstd1, dres=dx1)
+        return dx, None, None, None, g_aq, g_bq, g_av, g_bv, g_down, g_up
+
+
+def run_block(blk, x):
+    """x [B, Nt, D] (engine dtype) -> block output, fused with its LoRA / adapter wrappers."""
+    inner, lora, adapter = _unwrap(blk)
+    B, Nt, D = x.shape
+    plan = inner.plan(x.dtype)
+    a_q = b_q = a_v = b_v = down = up = None
+    if lora is not None:
+        if lora.linear_a_k is not None or lora.linear_a_v is None:
+            raise ops._lib.GdHipError("the fused LoRA epilogue implements the reference's q+v configuration")
+        a_q, b_q = lora.linear_a_q.weight, lora.linear_b_q.weight
+        a_v, b_v = lora.linear_a_v.weight, lora.linear_b_v.weight
+        if 2 * a_q.shape[0] > 8:
+            raise ops._lib.GdHipError("LoRA rank > 4 not supported by the fused epilogue")
+    if adapter is not None:
+        down, up = adapter.down.weight, adapter.up.weight
+    out = _BlockFn.apply(x.reshape(B * Nt, D), plan, B, Nt, a_q, b_q, a_v, b_v, down, up)
+    return out.view(B, Nt, D)
+
+
+class _LNFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1]).contiguous()
+        wf, bf = w.detach().float().contiguous(), b.detach().float().contiguous()
+        y, mean, rstd = ops.layernorm_fwd(x2, wf, bf, eps, save_stats=x.requires_grad)
+        if x.requires_grad:
+            ctx.save_for_backward(x2, wf, mean, rstd)
+            ctx.shp = shp
+        return y.view(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, wf, mean, rstd = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
+        if dy2.dtype not in (torch.float32, x2.dtype):
+            dy2 = dy2.float()
+        if x2.dtype == torch.float32 and dy2.dtype != torch.float32:
+            dy2 = dy2.float()
+        return ops.layernorm_bwd(dy2, x2, wf, mean, rstd).view(ctx.shp), None, None, None
+
+
+class GDLayerNorm(nn.LayerNorm):
+    """`model.norm` / `norm_pre`: frozen affine, HIP forward and backward-to-input."""
+
+    def forward(self, x):
+        return _LNFn.apply(x, self.weight, self.bias, self.eps)
+
+
+class GDPatchEmbed(nn.Module):
+    def __init__(self, patch_size, in_chans, embed_dim, bias=True):
+        super().__init__()
+        self.patch_size = (patch_size, patch_size)
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size, bias=bias)
+
+
+VIT_PRESETS = {
+    # name: (dim, depth, heads)
+    "vit_tiny_test": (64, 8, 1), "vit_small": (384, 12, 6), "vit_base": (768, 12, 12), "vit_large": (1024, 24, 16),
+}
+
+
+class GDViT(nn.Module):
+    """Parametric pre-LN ViT (patch, dim, depth, heads, LayerScale, pre_norm, LN eps, pos-embed resampling) covering
+    the reference's CLIP ViT-B/16 and BASELINE.json's DINOv2 /14 variants."""
+
+    def __init__(self, img_size=518, patch_size=14, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4.0,
+                 init_values=None, pre_norm=False, ln_eps=1e-6, pos_interp="dinov2", mean=(0.485, 0.456, 0.406),
+                 std=(0.229, 0.224, 0.225), dtype="bf16"):
+        super().__init__()
+        self.embed_dim = self.num_features = embed_dim
+        self.num_prefix_tokens = 1
+        self.patch_embed = GDPatchEmbed(patch_size, 3, embed_dim, bias=not pre_norm)
+        g = img_size // patch_size
+        self.native_grid = g
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, g * g + 1, embed_dim))
+        self.norm_pre = GDLayerNorm(embed_dim, eps=ln_eps) if pre_norm else nn.Identity()
+        self.blocks = nn.ModuleList([GDBlock(embed_dim, num_heads, mlp_ratio, init_values, ln_eps) for _ in range(depth)])
+        self.norm = GDLayerNorm(embed_dim, eps=ln_eps)
+        self.pos_interp = pos_interp
+        self.mean, self.std = tuple(mean), tuple(std)
+        self.dtype = _dt(dtype)
+        self._pos_cache = {}
+        self._pe_plan = None
+        self.init_weights()
+
+    def init_weights(self, seed=0):
+        g = torch.Generator().manual_seed(seed)
+        with torch.no_grad():
+            for m in self.modules():
+                if isinstance(m, nn.Linear):
+                    m.weight.copy_(torch.nn.init.trunc_normal_(torch.empty_like(m.weight), std=0.02, generator=g))
+                    if m.bias is not None:
+                        m.bias.zero_()
+            self.pos_embed.copy_(torch.nn.init.trunc_normal_(torch.empty_like(self.pos_embed), std=0.02, generator=g))
+            self.cls_token.copy_(torch.randn(self.cls_token.shape, generator=g) * 1e-6)
+            w = self.patch_embed.proj.weight
+            w.copy_(torch.nn.init.trunc_normal_(torch.empty_like(w), std=0.02, generator=g))
+            if self.patch_embed.proj.bias is not None:
+                self.patch_embed.proj.bias.zero_()
+
+    def invalidate_plans(self):
+        self._pos_cache, self._pe_plan = {}, None
+        for b in self.blocks:
+            _unwrap(b)[0]._plan = None
+
+    # ---- frozen prologue pieces ----
+    def _pos(self, gh, gw):
+        key = (gh, gw)
+        if key not in self._pos_cache:
+            pe = self.pos_embed.detach().float()
+            m = self.native_grid
+            if (gh, gw) != (m, m):
+                grid = pe[:, 1:].reshape(1, m, m, -1).permute(0, 3, 1, 2)
+                if self.pos_interp == "dinov2":   # vggt/layers/vision_transformer.py:181-213
+                    grid = F.interpolate(grid, mode="bicubic", antialias=False,
+                                         scale_factor=(float(gh + 0.1) / m, float(gw + 0.1) / m))
+                else:                             # timm resample_abs_pos_embed (bicubic, antialias)
+                    grid = F.interpolate(grid, size=(gh, gw), mode="bicubic", antialias=True, align_corners=False)
+                assert grid.shape[-2:] == (gh, gw)
+                pe = torch.cat([pe[:, :1], grid.permute(0, 2, 3, 1).reshape(1, gh * gw, -1)], 1)
+            self._pos_cache[key] = pe[0].contiguous()
+        return self._pos_cache[key]
+
+    def _patch_plan(self):
+        if self._pe_plan is None or self._pe_plan["dtype"] != self.dtype:
+            w = self.patch_embed.proj.weight.detach().float()
+            D, K = w.shape[0], w[0].numel()
+            Kp = (K + 63) // 64 * 64
+            wp = torch.zeros(D, Kp, dtype=torch.float32, device=w.device)
+            wp[:, :K] = w.reshape(D, K)
+            b = self.patch_embed.proj.bias
+            self._pe_plan = {"dtype": self.dtype, "w": wp.to(self.dtype).contiguous(), "Kp": Kp,
+                             "b": b.detach().float().contiguous() if b is not None else None,
+                             "cls": self.cls_token.detach().float().reshape(-1).contiguous()}
+        return self._pe_plan
+
+    def embed(self, img, size=None):
+        """img [B,3,h,w] fp32 in [0,1] (NOT normalised: Normalize and the optional bilinear resize to `size`
+        are fused into the im2col kernel) -> tokens [B, 1+gh*gw, D]."""
+        P = self.patch_embed.patch_size[0]
+        B, _, h, w = img.shape
+        H, W = size if size is not None else (h, w)
+        assert H % P == 0 and W % P == 0, f"image size {(H, W)} not a multiple of patch {P}"
+        gh, gw = H // P, W // P
+        pp = self._patch_plan()
+        col = ops.patch_im2col(img, H, W, P, pp["Kp"], self.mean, self.std, self.dtype)
+        tok = ops.gemm_nt(col, pp["w"], bias=pp["b"])
+        x = ops.assemble_tokens(tok, pp["cls"], self._pos(gh, gw), B, gh * gw).view(B, gh * gw + 1, -1)
+        if not isinstance(self.norm_pre, nn.Identity):
+            x = self.norm_pre(x)
+        return x
+
+    # ---- timm surface ----
+    def _intermediate_layers(self, x, n=1, size=None):
+        """timm VisionTransformer._intermediate_layers: outputs of the blocks listed in n (or the last n).
+        x is the image batch in [0,1]; see `embed`."""
+        take = set(range(len(self.blocks) - n, len(self.blocks)) if isinstance(n, int) else n)
+        x = self.embed(x, size)
+        outs = []
+        for i, blk in enumerate(self.blocks):
+            x = blk(x)
+            if i in take:
+                outs.append(x)
+        return outs
+
+    def forward_features(self, x, size=None):
+        x = self.embed(x, size)
+        for blk in self.blocks:
+            x = blk(x)
+        return self.norm(x)
+
+    def forward_all(self, x, taps, size=None):
+        """One pass: (tap outputs in `taps` order, last block output) — the shared-forward mode."""
+        x = self.embed(x, size)
+        outs = {}
+        for i, blk in enumerate(self.blocks):
+            x = blk(x)
+            if i in taps:
+                outs[i] = x
+        return [outs[i] for i in taps], x
+
+    def forward(self, x):
+        return self.forward_features(x)
+
+
+def create_vit(name="vit_base", patch_size=14, img_size=518, **kw):
+    dim, depth, heads = VIT_PRESETS[name]
+    return GDViT(img_size=img_size, patch_size=patch_size, embed_dim=dim, depth=depth, num_heads=heads, **kw)
+
+
+# ------------------------------------------------------------------------------------------------
+# refine_conv on token grids and keypoint sampling (autograd over the C ABI)
+# ------------------------------------------------------------------------------------------------
+class _Conv3x3Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tok, weight, bias, gh, gw):
+        """tok [B, 1+gh*gw, D] (prefix token skipped) -> [B, gh*gw, D] fp32."""
+        B, Nt, D = tok.shape
+        tok = tok.contiguous()
+        T = tok.dtype
+        col = ops.im2col3x3(tok[:, Nt - gh * gw:], Nt * D, B, gh, gw, D)
+        wk = weight.detach().permute(0, 2, 3, 1).reshape(D, 9 * D).to(T).contiguous()
+        out = ops.gemm_nt(col, wk, bias=bias.detach().float().contiguous(), out_dtype=torch.float32)
+        ctx.save_for_backward(col, wk)
+        ctx.dims = (B, Nt, D, gh, gw)
+        return out.view(B, gh * gw, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        col, wk = ctx.saved_tensors
+        B, Nt, D, gh, gw = ctx.dims
+        T = col.dtype
+        dyf = dy.reshape(B * gh * gw, D).contiguous().float()
+        dyt = dyf if T == torch.float32 else ops.cast(dyf, T)
+        gw_ = ops.gemm_tn(dyt, col)                                         # [Dout, 9*Din]
+        gweight = gw_.view(D, 3, 3, D).permute(0, 3, 1, 2).contiguous()
+        gbias = dyf.sum(0)
+        dcol = ops.gemm_nt(dyt, wk.t().contiguous())                        # [M, 9D]
+        dxg = ops.col2im3x3(dcol, B, gh, gw, D).view(B, gh * gw, D)
+        dtok = torch.zeros(B, Nt, D, dtype=T, device=dy.device)
+        dtok[:, Nt - gh * gw:] = dxg
+        return dtok, gweight, gbias, None, None
+
+
+def conv3x3_tokens(tok, weight, bias, gh, gw):
+    return _Conv3x3Fn.apply(tok, weight, bias, gh, gw)
+
+
+class _GatherFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, kp, geom, *grids):
+        gh, gw, sx, sy, img_h, img_w, patch = geom
+        B, Ng, D = grids[0].shape
+        prefix = Ng - gh * gw
+        gs = [g.contiguous() for g in grids]
+        kp = kp.contiguous().float()
+        out = ops.kp_gather_fwd([g[:, prefix:] for g in gs], Ng * D, kp, B, kp.shape[1], gh, gw, D, sx, sy, img_h,
+                                img_w, patch)
+        ctx.save_for_backward(kp)
+        ctx.meta = (geom, B, Ng, D, prefix, len(gs), gs[0].dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (kp,) = ctx.saved_tensors
+        (gh, gw, sx, sy, img_h, img_w, patch), B, Ng, D, prefix, ng, T = ctx.meta
+        dg = ops.kp_gather_bwd(ng, kp, dout, B, kp.shape[1], gh, gw, D, sx, sy, img_h, img_w, patch, prefix=prefix)
+        return (None, None) + tuple(dg)     # fp32 gradients; LN / conv backward accept them
+
+
+def kp_gather(grids, kp, gh, gw, sx, sy, img_h, img_w, patch):
+    """interpolate_features on token-major grids [B, prefix+gh*gw, D] (mean over the list) -> [B, Nk, D] fp32."""
+    return _GatherFn.apply(kp, (gh, gw, float(sx), float(sy), int(img_h), int(img_w), int(patch)), *grids)

@@ -36,7 +36,7 @@ int gd_gemm_nt(const void* A, const void* W, void* C, int M, int N, int K, long 
 /* G[N,K](f32) += alpha * Y[M,N]^T . X[M,K]; weight gradients of the trainable LoRA / Adapter / refine_conv
  * tensors (autograd of utils/model.py:7-71, src/finetune_timm_vggt.py:146 refine_conv). */
 int gd_gemm_tn(const void* Y, const void* X, float* G, int M, int N, int K, long ldy, long ldx, long ldg,
-               int y_dtype, int x_dtype, float alpha, void* stream);
+               int batch, long sY, long sX, long sG, int y_dtype, int x_dtype, float alpha, void* stream);
 
 /* Multi-head self-attention, head_dim 64, flash-style (no N x N matrix): replaces F.scaled_dot_product_attention in
  * timm Attention.forward (same arithmetic as vggt/layers/attention.py:51-71).  qkv [B,N,3,H,64] packed
@@ -59,6 +59,69 @@ int gd_cost_volume_kl_fwd(const void* f1, const void* f2, const float* t1, const
 int gd_cost_volume_kl_bwd(const void* f1, const void* f2, const float* t1, const float* t2, const unsigned char* m1,
                           const unsigned char* m2, int P, int hw, int C, int dtype, const float* gloss,
                           const float* stats, void* df1, void* df2, void* workspace, void* stream);
+
+/* nn.LayerNorm forward / backward-to-input (timm Block.norm1/norm2, model.norm; frozen affine).  dres (optional)
+ * is added to dx (residual-stream gradient).  dy may be f32 while x is bf16 (dy_dtype). */
+int gd_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int M,
+                     int D, long ldx, long ldy, float eps, int dtype, int y_dtype, void* stream);
+int gd_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                     const void* dres, void* dx, int M, int D, long ldd, long ldx, float dyscale, int dtype,
+                     int dy_dtype, void* stream);
+/* F.normalize(p=2, dim=-1) on fp32 rows (src/finetune_timm_vggt.py:328) and its backward. */
+int gd_l2norm_fwd(const float* x, float* y, float* inv, int M, int D, float eps, void* stream);
+int gd_l2norm_bwd(const float* y, const float* dy, const float* inv, float* dx, int M, int D, void* stream);
+
+/* a0 + patch-embed prologue: torchvision bilinear resize (h,w)->(H,W) (src/finetune_timm_vggt.py:270,340), timm
+ * Normalize (:153), im2col for the PxP/stride-P conv of timm PatchEmbed; col [B*(H/P)*(W/P), Kp] zero-padded. */
+int gd_patch_im2col(const float* img, void* col, int B, int h, int w, int H, int W, int P, int Kp,
+                    const float* mean3, const float* std3, int dtype, void* stream);
+/* timm _pos_embed: cls + pos[0] | patch + pos[1:]  ->  tokens [B, Np+1, D]. */
+int gd_assemble_tokens(const void* patch, const float* cls, const float* pos, void* out, int B, int Np, int D,
+                       int dtype, void* stream);
+/* refine_conv 3x3/pad 1 (src/finetune_timm_vggt.py:146,325) as im2col / col2im around gd_gemm_nt / gd_gemm_tn. */
+int gd_im2col3x3(const void* x, long bstride, void* col, int B, int gh, int gw, int D, int dtype, void* stream);
+int gd_col2im3x3(const void* dcol, void* dx, long bstride, int B, int gh, int gw, int D, int dtype, void* stream);
+/* interpolate_features (utils/functions.py:55-76) on 1..4 token-major grids, averaged; backward scatters into fp32
+ * gradient grids (batch stride bstride elements, pre-zeroed). */
+int gd_kp_gather_fwd(const void* const* grids, int ngrid, long bstride, int grid_dtype, const float* kp, float* out,
+                     int B, int Nk, int gh, int gw, int D, float sx, float sy, int img_h, int img_w, int patch,
+                     int stride, void* stream);
+int gd_kp_gather_bwd(float* const* dgrids, int ngrid, long bstride, const float* kp, const float* dout, int B, int Nk,
+                     int gh, int gw, int D, float sx, float sy, int img_h, int img_w, int patch, int stride,
+                     void* stream);
+/* extract_kp_depth (utils/functions.py:348-372) and get_patch_mask_from_kp_tensor (:375-399; mask pre-zeroed). */
+int gd_kp_depth(const float* depth, const float* kp, float* out, int B, int Nk, int H, int W, void* stream);
+int gd_patch_mask(const float* kp, unsigned char* mask, int B, int Nk, int H, int W, int P, void* stream);
+
+/* get_feature_cost tail (src/finetune_timm_mast3r.py:321-337, src/finetune_timm_vggt.py:342-353): mean of 1..4 tap
+ * outputs [B, prefix+hw, D] with the prefix token dropped -> [B,hw,D]; backward fills dgrids [B, prefix+hw, D]. */
+int gd_tap_mean_fwd(const void* const* grids, int ngrid, long bstride, int prefix, void* out, int B, int hw, int D,
+                    int dtype, void* stream);
+int gd_tap_mean_bwd(void* const* dgrids, int ngrid, int prefix, const void* dout, int B, int hw, int D, int dtype,
+                    void* stream);
+
+/* calculate_matching_loss after the descriptor GEMM (src/finetune_timm_vggt.py:543-572 variant 0,
+ * src/finetune_timm_mast3r.py:560-589 variant 1): sim [P,Nmax,Nmax] -> loss [P] and dsim = dloss/dsim (fused). */
+int gd_smooth_ap(const float* sim, const float* pts3d_1, const float* pts3d_2, const int* counts, int P, int Nmax,
+                 int variant, float thres3d_neg, float temp, float* loss, float* dsim, float* row_ws, void* stream);
+/* pairwise_logistic_ranking_loss (utils/losses.py:18-41) with DepthAwareFeatureFusion (utils/model.py:100-127) on
+ * pre-projected u = W1 f [S,Nmax,128]: loss [S], du (scaled by gscale/count), head_grad[516] += {b1,ln_w,ln_b,w2,b2}. */
+size_t gd_pair_rank_workspace_bytes(int S);
+int gd_pair_rank(const float* u, const float* depth, const int* counts, const float* gscale, int S, int Nmax,
+                 float depth_threshold, const float* b1, const float* ln_w, const float* ln_b, const float* w2,
+                 const float* b2, float* loss, float* du, float* head_grad, void* workspace, void* stream);
+/* F.l1_loss(head(f1 - f2), tanh(d1 - d2)) (src/finetune_timm_vggt.py:475-479); u [P,2,Nmax,128]. */
+int gd_depth_l1(const float* u, const float* d1, const float* d2, const int* counts, const float* gscale, int P,
+                int Nmax, const float* b1, const float* ln_w, const float* ln_b, const float* w2, const float* b2,
+                float* loss, float* du, float* head_grad, void* workspace, void* stream);
+
+/* Lightning gradient_clip_val=1.0 (src/main.py:153) + torch.optim.AdamW (src/finetune_timm_vggt.py:642-648) on the
+ * flat fp32 trainable buffer; grads are multiplied by grad_scale first. */
+size_t gd_adamw_workspace_bytes(void);
+int gd_clip_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, int step,
+                       float lr, float weight_decay, float beta1, float beta2, float eps, float max_norm,
+                       float grad_scale, float* grad_norm_out, void* workspace, void* stream);
+int gd_cast(const void* in, void* out, long n, float scale, int in_dtype, int out_dtype, void* stream);
 
 #ifdef __cplusplus
 }

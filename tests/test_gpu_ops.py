@@ -1,0 +1,250 @@
+"""GPU parity: normalisation, image prep, conv glue, keypoint gather, sparse losses and the optimiser
+(all through the C ABI) against the CPU oracle / reference-generated fixtures."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import gd_oracle as O
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _g(seed):
+    return torch.Generator(device="cuda").manual_seed(seed)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("M,D", [(5, 64), (1370, 768), (300, 1024), (33, 384)])
+def test_layernorm(dtype, tol, M, D):
+    from gd_amd import ops
+    x = (torch.randn(M, D, generator=_g(1), device="cuda") * 2 + 0.5).to(dtype)
+    gm = torch.randn(D, generator=_g(2), device="cuda")
+    bt = torch.randn(D, generator=_g(3), device="cuda")
+    dy = torch.randn(M, D, generator=_g(4), device="cuda").to(dtype)
+    dres = torch.randn(M, D, generator=_g(5), device="cuda").to(dtype)
+    y, mean, rstd = ops.layernorm_fwd(x, gm, bt, 1e-6)
+    xr = x.double().requires_grad_(True)
+    yr = F.layer_norm(xr, (D,), gm.double(), bt.double(), 1e-6)
+    assert rel_err(y, yr) < tol
+    yr.backward(dy.double())
+    dx = ops.layernorm_bwd(dy, x, gm, mean, rstd, dres=dres)
+    assert rel_err(dx, xr.grad + dres.double()) < tol * 3
+    # fp32 dy against bf16 x, with a scale
+    dx2 = ops.layernorm_bwd(dy.float(), x, gm, mean, rstd, dyscale=0.25)
+    assert rel_err(dx2, 0.25 * xr.grad) < tol * 3
+
+
+def test_l2norm():
+    from gd_amd import ops
+    x = torch.randn(2, 37, 96, generator=_g(6), device="cuda").requires_grad_(True)
+    w = torch.randn(2, 37, 96, generator=_g(7), device="cuda")
+    y = ops.l2_normalize(x)
+    (y * w).sum().backward()
+    xr = x.detach().double().requires_grad_(True)
+    yr = F.normalize(xr, dim=-1)
+    (yr * w.double()).sum().backward()
+    assert rel_err(y, yr) < 1e-6 and rel_err(x.grad, xr.grad) < 1e-5
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("hw_in,HW", [((56, 70), (56, 70)), ((40, 52), (56, 84))])
+def test_patch_im2col_and_tokens(dtype, tol, hw_in, HW):
+    from gd_amd import ops
+    P, B, D = 14, 2, 32
+    mean, std = (0.48, 0.45, 0.40), (0.26, 0.25, 0.27)
+    img = torch.rand(B, 3, *hw_in, generator=_g(8), device="cuda")
+    Kp = 640
+    col = ops.patch_im2col(img, HW[0], HW[1], P, Kp, mean, std, dtype)
+    ref = O.normalize_image(O.resize_bilinear(img.cpu(), HW), mean, std)
+    refcol = F.unfold(ref, P, stride=P).transpose(1, 2).reshape(-1, 3 * P * P)
+    assert rel_err(col[:, :3 * P * P], refcol) < tol and float(col[:, 3 * P * P:].abs().max()) == 0.0
+    Np = (HW[0] // P) * (HW[1] // P)
+    patch = torch.randn(B * Np, D, generator=_g(9), device="cuda").to(dtype)
+    cls = torch.randn(D, generator=_g(10), device="cuda")
+    pos = torch.randn(Np + 1, D, generator=_g(11), device="cuda")
+    tok = ops.assemble_tokens(patch, cls, pos, B, Np).view(B, Np + 1, D)
+    want = torch.cat([cls.expand(B, 1, D), patch.float().view(B, Np, D)], 1) + pos
+    assert rel_err(tok, want) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
+def test_conv3x3_via_im2col(dtype, tol):
+    from gd_amd import ops
+    B, gh, gw, D = 2, 5, 7, 64
+    tok = torch.randn(B, 1 + gh * gw, D, generator=_g(12), device="cuda").to(dtype)   # with a prefix token
+    w = torch.randn(D, D, 3, 3, generator=_g(13), device="cuda") * 0.05
+    bias = torch.randn(D, generator=_g(14), device="cuda")
+    col = ops.im2col3x3(tok[:, 1:], (1 + gh * gw) * D, B, gh, gw, D)
+    wk = w.permute(0, 2, 3, 1).reshape(D, 9 * D).contiguous().to(dtype)           # [Dout, (ky,kx), Din]
+    out = ops.gemm_nt(col, wk, bias=bias, out_dtype=torch.float32)
+    x = tok[:, 1:].double().reshape(B, gh, gw, D).permute(0, 3, 1, 2).requires_grad_(True)
+    ref = F.conv2d(x, w.double(), bias.double(), padding=1)
+    assert rel_err(out.view(B, gh, gw, D).permute(0, 3, 1, 2), ref) < tol
+    dy = torch.randn(B * gh * gw, D, generator=_g(15), device="cuda").to(dtype)
+    ref.backward(dy.double().view(B, gh, gw, D).permute(0, 3, 1, 2))
+    dcol = ops.gemm_nt(dy, wk.t().contiguous())                                    # [M, 9D]
+    dx = ops.col2im3x3(dcol, B, gh, gw, D)
+    assert rel_err(dx.view(B, gh, gw, D).permute(0, 3, 1, 2), x.grad) < tol * 2
+
+
+@pytest.mark.parametrize("P", [14, 16])
+def test_kp_gather_golden(P):
+    from gd_amd import ops
+    g = load_golden(f"g02_interp_p{P}")
+    desc = g["desc"].cuda()                                   # [1,C,ph,pw]
+    _, C, ph, pw = desc.shape
+    grid = desc.permute(0, 2, 3, 1).reshape(1, ph * pw, C).contiguous()
+    kp = g["pts"].cuda()
+    out = ops.kp_gather_fwd([grid], ph * pw * C, kp, 1, kp.shape[1], ph, pw, C, 1.0, 1.0, g["h"], g["w"], P)
+    assert rel_err(out[0].t(), g["out"][0]) < 1e-5
+    dg = ops.kp_gather_bwd(1, kp, g["gout"][0].t().contiguous().cuda()[None], 1, kp.shape[1], ph, pw, C, 1.0, 1.0,
+                           g["h"], g["w"], P)[0]
+    assert rel_err(dg.view(ph, pw, C).permute(2, 0, 1), g["gdesc"][0]) < 1e-5
+
+
+def test_kp_gather_multi_grid_mean():
+    from gd_amd import ops
+    B, gh, gw, D, Nk, P = 2, 6, 5, 48, 11, 14
+    toks = [torch.randn(B, 1 + gh * gw, D, generator=_g(20 + t), device="cuda").bfloat16() for t in range(4)]
+    kp = torch.rand(B, Nk, 2, generator=_g(30), device="cuda") * torch.tensor([gw * P * 0.5, gh * P * 0.5], device="cuda")
+    out = ops.kp_gather_fwd([t[:, 1:] for t in toks], (1 + gh * gw) * D, kp, B, Nk, gh, gw, D, 2.0, 2.0, gh * P, gw * P, P)
+    ref = 0
+    for t in toks:
+        grid = t[:, 1:].float().cpu().reshape(B, gh, gw, D).permute(0, 3, 1, 2)
+        ref = ref + O.interpolate_features(grid, kp.cpu() * 2.0, gh * P, gw * P, False, P, P).permute(0, 2, 1)
+    assert rel_err(out, ref / 4) < 1e-5
+
+
+def test_kp_depth_and_patch_mask_golden():
+    from gd_amd import ops
+    g = load_golden("g09_kp_depth")
+    out = ops.kp_depth(g["depth"][None].cuda(), g["kp"].cuda())
+    assert rel_err(out, g["out"]) < 1e-6
+    g = load_golden("g03_patch_mask")
+    m = ops.patch_mask(g["kp"][None].cuda(), g["H"], g["W"], g["patch"])
+    assert torch.equal(m[0].bool().cpu(), g["mask"])
+
+
+@pytest.mark.parametrize("variant", ["vggt", "mast3r"])
+def test_smooth_ap_golden(variant):
+    from gd_amd import ops
+    g = load_golden(f"g08_match_{variant}")
+    d1 = g["desc1"].cuda().requires_grad_(True)
+    d2 = g["desc2"].cuda().requires_grad_(True)
+    loss = ops.smooth_ap(d1, d2, g["pts3d_1"].cuda(), g["pts3d_2"].cuda(), None, variant)
+    assert abs(loss.item() - g["loss"]) < 2e-5
+    loss.sum().backward()
+    assert rel_err(d1.grad, g["gdesc1"]) < 2e-3 and rel_err(d2.grad, g["gdesc2"]) < 2e-3
+
+
+@pytest.mark.parametrize("variant", ["vggt", "mast3r"])
+def test_smooth_ap_batched_ragged(variant):
+    from gd_amd import ops
+    P, N, C = 3, 300, 128
+    r1 = torch.randn(P, N, C, generator=_g(40), device="cuda")
+    d1 = F.normalize(r1, dim=-1)
+    d2 = F.normalize(d1 + 0.04 * torch.randn(P, N, C, generator=_g(41), device="cuda"), dim=-1)
+    p1 = torch.rand(P, N, 3, generator=_g(42), device="cuda") * 2
+    p2 = p1 + 0.02 * torch.randn(P, N, 3, generator=_g(43), device="cuda")
+    counts = torch.tensor([300, 123, 1], dtype=torch.int32, device="cuda")
+    a, b = d1.clone().requires_grad_(True), d2.clone().requires_grad_(True)
+    loss = ops.smooth_ap(a, b, p1, p2, counts, variant)
+    (loss * torch.tensor([1.0, 2.0, 0.5], device="cuda")).sum().backward()
+    for p, w in zip(range(P), (1.0, 2.0, 0.5)):
+        n = int(counts[p])
+        x = d1[p:p + 1, :n].double().cpu().requires_grad_(True)
+        y = d2[p:p + 1, :n].double().cpu().requires_grad_(True)
+        ref = O.smooth_ap_loss(x, y, p1[p:p + 1, :n].double().cpu(), p2[p:p + 1, :n].double().cpu(), variant)
+        ref.backward()
+        assert abs(loss[p].item() - ref.item()) < 2e-4 * max(1.0, abs(ref.item()))
+        gscale = max(1e-12, float(x.grad.abs().max()))
+        assert float((a.grad[p, :n].cpu().double() - w * x.grad[0]).abs().max()) < 2e-2 * w * gscale
+        assert float(a.grad[p, n:].abs().max()) == 0.0 if n < N else True
+
+
+def _head(g, dev="cuda"):
+    return {k: g["hp_" + k].to(dev).clone().requires_grad_(True) for k in ("w1", "b1", "ln_w", "ln_b", "w2", "b2")}
+
+
+def test_depth_losses_golden():
+    from gd_amd import ops
+    g = load_golden("g11_depth_loss")
+    head = _head(g)
+    feats = torch.stack([g["kf1"][0], g["kf2"][0]], 0)[None].cuda().requires_grad_(True)     # [1,2,N,D]
+    d1 = ops.kp_depth(g["depth_1"][None].cuda(), g["kp_1"].cuda())
+    d2 = ops.kp_depth(g["depth_2"][None].cuda(), g["kp_2"].cuda())
+    l1, intra = ops.depth_losses(feats, d1, d2, head)
+    assert abs(l1.item() - g["depth_loss"]) < 1e-5 and abs(intra.item() - g["intra_loss"]) < 1e-5
+    (l1 + intra).sum().backward()
+    assert rel_err(feats.grad[0, 0], g["g_kf1"][0]) < 1e-3 and rel_err(feats.grad[0, 1], g["g_kf2"][0]) < 1e-3
+    assert rel_err(head["w1"].grad, g["g_w1"]) < 1e-3
+    assert rel_err(head["w2"].grad, g["g_w2"]) < 1e-3
+    assert rel_err(head["ln_w"].grad, g["g_ln_w"]) < 1e-3
+
+
+def test_ranking_golden_and_batched():
+    from gd_amd import ops
+    g = load_golden("g07_ranking")
+    head = _head(g)
+    f = g["feats"][0].cuda()
+    feats = torch.stack([f, f], 0)[None].clone().requires_grad_(True)
+    d = g["depths"].cuda()
+    l1, intra = ops.depth_losses(feats, d, d, head, depth_threshold=g["thr"])
+    assert abs(intra.item() - g["loss"]) < 1e-5
+    intra.sum().backward()
+    # both views carry the same set: each gets half the fixture's gradient
+    assert rel_err(feats.grad[0, 0], 0.5 * g["gfeats"][0]) < 1e-3
+    for k in ("w1", "b1", "ln_w", "ln_b", "w2", "b2"):
+        assert rel_err(head[k].grad, g["g_" + k]) < 2e-3, k
+    # ragged batch vs oracle
+    P, N, D = 2, 40, 64
+    hp = {k: v.detach().cpu() for k, v in _head(load_golden("g11_depth_loss"), "cpu").items()}
+    hp["w1"] = torch.randn(128, D, generator=torch.Generator().manual_seed(1)) * 0.1
+    hd = {k: v.cuda().clone().requires_grad_(True) for k, v in hp.items()}
+    ft = torch.randn(P, 2, N, D, generator=_g(50), device="cuda").requires_grad_(True)
+    dd1 = torch.rand(P, N, generator=_g(51), device="cuda") * 3
+    dd2 = torch.rand(P, N, generator=_g(52), device="cuda") * 3
+    counts = torch.tensor([40, 17], dtype=torch.int32, device="cuda")
+    l1, intra = ops.depth_losses(ft, dd1, dd2, hd, counts=counts)
+    (l1 * 0.7 + intra).sum().backward()
+    tot = 0
+    hpr = {k: v.double().requires_grad_(True) for k, v in hp.items()}
+    fr = ft.detach().double().cpu().requires_grad_(True)
+    for p in range(P):
+        n = int(counts[p])
+        a, b = O.depth_losses(hpr, fr[p, 0:1, :n], fr[p, 1:2, :n], dd1[p:p + 1, :n].double().cpu(), dd2[p:p + 1, :n].double().cpu())
+        assert abs(l1[p].item() - a.item()) < 1e-5 and abs(intra[p].item() - b.item()) < 1e-5
+        tot = tot + 0.7 * a + b
+    tot.backward()
+    assert rel_err(ft.grad, fr.grad) < 1e-3
+    for k in hd:
+        assert rel_err(hd[k].grad, hpr[k].grad) < 2e-3, k
+
+
+def test_clip_adamw_matches_oracle():
+    from gd_amd import ops
+    n = 100_003
+    p = torch.randn(n, generator=_g(60), device="cuda")
+    g = torch.randn(n, generator=_g(61), device="cuda") * 0.01
+    m = torch.zeros(n, device="cuda")
+    v = torch.zeros(n, device="cuda")
+    pc, gc = p.cpu().clone(), g.cpu().clone()
+    st = [(torch.zeros(n), torch.zeros(n))]
+    for step in (1, 2, 3):
+        norm = ops.clip_adamw_step(p, g, m, v, step, grad_scale=0.5)
+        rn = O.clip_and_adamw([pc], [gc * 0.5], st, step)
+        assert abs(norm.item() - rn.item()) < 1e-5 * rn.item()
+    assert rel_err(p, pc) < 1e-6
+    # a real torch AdamW + clip_grad_norm_ agrees as well
+    q = torch.nn.Parameter(torch.randn(1000, generator=torch.Generator().manual_seed(3)))
+    opt = torch.optim.AdamW([q], lr=1e-5, weight_decay=1e-4)
+    p2 = q.detach().cuda().clone()
+    m2, v2 = torch.zeros_like(p2), torch.zeros_like(p2)
+    for step in (1, 2):
+        gr = torch.randn(1000, generator=torch.Generator().manual_seed(10 + step)) * 3
+        q.grad = gr.clone()
+        torch.nn.utils.clip_grad_norm_([q], 1.0)
+        opt.step()
+        ops.clip_adamw_step(p2, gr.cuda(), m2, v2, step)
+    assert rel_err(p2, q.detach()) < 1e-6

@@ -188,11 +188,14 @@ class _MatchSelf:
 
 def match_fixture(name, variant, seed):
     N, C, Hh, Ww = 23, 16, 12, 14
-    r1 = torch.randn(1, N, C, generator=g(seed), requires_grad=True)
+    # clustered descriptors: within-cluster similarities sit next to the positives' (~0.99), so the temp-0.01
+    # sigmoids are NOT all saturated and loss / gradients are informative
+    centers = F.normalize(torch.randn(6, C, generator=g(seed + 9)), dim=-1)
+    assign = torch.randint(0, 6, (N,), generator=g(seed + 10))
+    r1 = (centers[assign] + 0.03 * torch.randn(N, C, generator=g(seed)))[None].requires_grad_(True)
     r2 = torch.randn(1, N, C, generator=g(seed + 1), requires_grad=True)
-    # correlated descriptors so that positives sit near sim ~ 1 and the sigmoids are not all saturated
     d1 = F.normalize(r1, dim=-1)
-    d2 = F.normalize(d1.detach() + 0.05 * r2, dim=-1)
+    d2 = F.normalize(d1.detach() + 0.03 * r2, dim=-1)
     pm1 = torch.rand(Hh, Ww, 3, generator=g(seed + 2)) * 2
     kp1 = torch.stack([torch.randint(0, Ww, (N,), generator=g(seed + 3)),
                        torch.randint(0, Hh, (N,), generator=g(seed + 4))], -1).float()[None]
@@ -216,6 +219,8 @@ def match_fixture(name, variant, seed):
     d1n = d1.detach().clone().requires_grad_(True)
     d2n = d2.detach().clone().requires_grad_(True)
     O.smooth_ap_loss(d1n, d2n, pts1, pts2, variant).backward()
+    print(f"  matching loss {variant}: {loss.item():.6f}  max|grad| {d1n.grad.abs().max().item():.3e}")
+    assert loss.item() > 0.05 and d1n.grad.abs().max().item() > 1e-4
     save(name, desc1=d1.detach(), desc2=d2.detach(), pts3d_1=pts1, pts3d_2=pts2, loss=loss,
          gdesc1=d1n.grad, gdesc2=d2n.grad, graw1=r1.grad)
 
