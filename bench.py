@@ -119,7 +119,7 @@ def main():
                                       f"blocks 4-11, {img}^2 pairs, shared-518 geometry, {args.variant} losses "
                                       f"(AP+depth+intra+cost-KL), {P} pairs/GPU, {N} keypoints/pair, hw={hw}",
                           "pairs_per_gpu": P, "global_pairs": P * world, "parallelism": f"dp{world}"},
-               "loss": round(float(loss), 6),
+               "loss": round(float(loss.detach()), 6),
                "vit_algorithmic_tflops": round(pairs_per_s / world * flop_pair / 1e12, 2),
                "vit_frac_of_mfma_peak": round(pairs_per_s / world * flop_pair / 1e12 / PEAK_TFLOPS[args.dtype], 4)}
         if prof:
@@ -171,7 +171,7 @@ def cpu_baseline(eng, batch, args):
     import gd_oracle as O
     import torch.nn.functional as F
     from gd_testutil import oracle_params
-    cores = os.cpu_count()
+    cores = min(os.cpu_count(), 32)       # torch CPU ops stop scaling (and oversubscribe) well before 256 threads
     torch.set_num_threads(cores)
     p, tr, refine, head, cfg = oracle_params(eng)
     leaves = []
