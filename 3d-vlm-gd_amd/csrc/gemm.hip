@@ -25,10 +25,12 @@ struct GemmNtParams {
     const void* dact_src; long ldd; int dact;                 // v *= act'(src): 1 dGELU(pre), 2 (src > 0)
     const void* residual; long ldr;  // v += residual
     int accumulate;                  // v += C
+    int vec_epilogue;                // every epilogue tensor is 16-byte aligned with 16-byte-multiple row strides
 };
 
+// Fallback: register-staged main loop (any K with K*elsize % 16 == 0, any alignment of rows), scalar epilogue.
 template <typename T>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtParams p) {
+__global__ __launch_bounds__(256) void gemm_nt_regstage_kernel(GemmNtParams p) {
     constexpr int BM = 128, BN = 128;
     __shared__ __attribute__((aligned(16))) char smem[GD_TILE_SMEM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -79,6 +81,206 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtParams p) {
                 st_rt(Cb, (long)row * p.ldc + col, cdt, v);
             }
         }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Main kernel: LDS-DMA (global_load_lds_dwordx4) staging into a 2-deep LDS ring, one barrier per K-step, the
+// next tile's DMA in flight under the MFMAs; XOR-swizzled LDS image (swizzle applied to the per-lane SOURCE
+// address, LDS destination stays lane-linear) so the ds_read_b128 fragment reads are bank-conflict-free;
+// epilogue staged through LDS so that every global access of the epilogue (C, preact, residual, dact_src) is a
+// 16-byte row-coalesced vector.  Requires K*elsize % 128 == 0.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
+
+__device__ __forceinline__ void ld8_rt(const void* p, long i, int dt, float (&o)[8]) {
+    if (dt == GD_BF16) {
+        const bf16x8 v = *(const bf16x8*)((const bf16*)p + i);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (float)v[k];
+    } else {
+        const f32x4 a = *(const f32x4*)((const float*)p + i), b = *(const f32x4*)((const float*)p + i + 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { o[k] = a[k]; o[4 + k] = b[k]; }
+    }
+}
+__device__ __forceinline__ void st8_rt(void* p, long i, int dt, const float (&v)[8]) {
+    if (dt == GD_BF16) {
+        *(bf16x8*)((bf16*)p + i) = bf16x8{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
+    } else {
+        *(f32x4*)((float*)p + i) = f32x4{v[0], v[1], v[2], v[3]};
+        *(f32x4*)((float*)p + i + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtParams p) {
+    constexpr int BM = 128, BN = 128, STAGE = 32768, EPLD = 132;
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int wg = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tm = wg / tiles_n, tn = wg % tiles_n;
+    const long batch = blockIdx.y;
+    const char* Ab = (const char*)p.A + batch * p.sA * (long)sizeof(T);
+    const char* Wb = (const char*)p.W + batch * p.sW * (long)sizeof(T);
+    const long lda_b = p.lda * (long)sizeof(T), ldw_b = p.ldw * (long)sizeof(T);
+    const int nk = p.K * (int)sizeof(T) / 128;
+
+    // per-lane source pointers of this thread's 4 + 4 DMA pieces (LDS piece pc = wave*4+i holds rows pc*8..pc*8+7)
+    const char* asrc[4];
+    const char* wsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ swz(row);
+        const int ar = min(tm * BM + row, p.M - 1), wr = min(tn * BN + row, p.N - 1);
+        asrc[i] = Ab + (long)ar * lda_b + c * 16;
+        wsrc[i] = Wb + (long)wr * ldw_b + c * 16;
+    }
+    auto issue = [&](int kt, int buf) {
+        char* sA = smem + buf * STAGE;
+        char* sB = sA + 16384;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pc = wave * 4 + i;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + (long)kt * 128),
+                                             (__attribute__((address_space(3))) void*)(sA + pc * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + (long)kt * 128),
+                                             (__attribute__((address_space(3))) void*)(sB + pc * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    typedef typename Mma<T>::Frag Frag;
+    const int fr = lane & 15, g = lane >> 4;
+    int aoff[4], boff[4];   // LDS byte offsets of this lane's rows; chunk swizzle folded in per kc below
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        aoff[t] = (wm * 64 + t * 16 + fr) * 128;
+        boff[t] = 16384 + (wn * 64 + t * 16 + fr) * 128;
+    }
+    const int sa = swz(fr);  // rows differ by multiples of 16 across t / wave halves: (row>>1)&7 == (fr>>1)&7
+
+    issue(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* sb = smem + (kt & 1) * STAGE;
+        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            const int co = (((kc * 4 + g) ^ sa) * 16);
+            Frag a[4], b[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                a[t] = *(const Frag*)(sb + aoff[t] + co);
+                b[t] = *(const Frag*)(sb + boff[t] + co);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: two 64-row halves through LDS (fp32), then 8-column vectors per thread ----
+    const int cdt = p.c_dtype;
+    char* Cb = (char*)p.C + batch * p.sC * (long)gd_dtype_size(cdt);
+    float* se = (float*)smem;  // [64][EPLD]
+    const bool vec = p.vec_epilogue != 0;
+    for (int half = 0; half < 2; ++half) {
+        if (wm == half) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        se[(i * 16 + g * 4 + r) * EPLD + wn * 64 + j * 16 + fr] = acc[i][j][r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int lr = (tid >> 4) + 16 * q, cc = (tid & 15) * 8;
+            const int row = tm * BM + half * 64 + lr, col0 = tn * BN + cc;
+            if (row >= p.M || col0 >= p.N) continue;
+            float v[8];
+            {
+                const f32x4 x0 = *(const f32x4*)(se + lr * EPLD + cc), x1 = *(const f32x4*)(se + lr * EPLD + cc + 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { v[k] = p.alpha * x0[k]; v[4 + k] = p.alpha * x1[k]; }
+            }
+            if (vec && col0 + 8 <= p.N) {
+                if (p.bias) {
+                    const f32x4 b0 = *(const f32x4*)(p.bias + col0), b1 = *(const f32x4*)(p.bias + col0 + 4);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { v[k] += b0[k]; v[4 + k] += b1[k]; }
+                }
+                if (p.lora_t) {
+                    for (int qq = 0; qq < p.lora_rt; ++qq) {
+                        const float tq = p.lora_t[(long)row * p.lora_rt + qq];
+                        const f32x4 b0 = *(const f32x4*)(p.lora_b + (long)qq * p.N + col0),
+                                    b1 = *(const f32x4*)(p.lora_b + (long)qq * p.N + col0 + 4);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { v[k] += tq * b0[k]; v[4 + k] += tq * b1[k]; }
+                    }
+                }
+                if (p.preact) st8_rt(p.preact, (long)row * p.ldp + col0, cdt, v);
+                if (p.act == 1) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = gelu_f(v[k]);
+                } else if (p.act == 2) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+                }
+                if (p.dact) {
+                    float s[8];
+                    ld8_rt(p.dact_src, (long)row * p.ldd + col0, cdt, s);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = p.dact == 1 ? v[k] * dgelu_f(s[k]) : (s[k] > 0.f ? v[k] : 0.f);
+                }
+                if (p.residual) {
+                    float s[8];
+                    ld8_rt(p.residual, (long)row * p.ldr + col0, cdt, s);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] += s[k];
+                }
+                if (p.accumulate) {
+                    float s[8];
+                    ld8_rt(Cb, (long)row * p.ldc + col0, cdt, s);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] += s[k];
+                }
+                st8_rt(Cb, (long)row * p.ldc + col0, cdt, v);
+            } else {
+                for (int k = 0; k < 8; ++k) {
+                    const int col = col0 + k;
+                    if (col >= p.N) break;
+                    float x = v[k];
+                    if (p.bias) x += p.bias[col];
+                    if (p.lora_t)
+                        for (int qq = 0; qq < p.lora_rt; ++qq) x += p.lora_t[(long)row * p.lora_rt + qq] * p.lora_b[(long)qq * p.N + col];
+                    if (p.preact) st_rt(p.preact, (long)row * p.ldp + col, cdt, x);
+                    if (p.act == 1) x = gelu_f(x);
+                    else if (p.act == 2) x = fmaxf(x, 0.f);
+                    if (p.dact == 1) x *= dgelu_f(ld_rt(p.dact_src, (long)row * p.ldd + col, cdt));
+                    else if (p.dact == 2) x = ld_rt(p.dact_src, (long)row * p.ldd + col, cdt) > 0.f ? x : 0.f;
+                    if (p.residual) x += ld_rt(p.residual, (long)row * p.ldr + col, cdt);
+                    if (p.accumulate) x += ld_rt(Cb, (long)row * p.ldc + col, cdt);
+                    st_rt(Cb, (long)row * p.ldc + col, cdt, x);
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -204,11 +406,19 @@ extern "C" int gd_gemm_nt(const void* A, const void* W, void* C, int M, int N, i
     p.lora_t = lora_t; p.lora_b = lora_b; p.lora_rt = lora_rt; p.preact = preact; p.ldp = ldp; p.act = act;
     p.dact_src = dact_src; p.ldd = ldd; p.dact = dact_src ? dact : 0; p.residual = residual; p.ldr = ldr;
     p.accumulate = accumulate;
+    const int cs = gd_dtype_size(c_dtype);
+    auto al = [&](const void* q, long ld) { return q == nullptr || ((((uintptr_t)q) & 15) == 0 && (ld * cs) % 16 == 0); };
+    p.vec_epilogue = al(C, ldc) && (sC * cs) % 16 == 0 && al(preact, ldp) && al(dact_src, ldd) && al(residual, ldr) &&
+                     (bias == nullptr || ((uintptr_t)bias & 15) == 0) && (lora_b == nullptr || (((uintptr_t)lora_b & 15) == 0 && N % 4 == 0));
     dim3 grid(gd_cdiv(M, 128) * gd_cdiv(N, 128), batch);
-    if (ab_dtype == GD_BF16)
-        hipLaunchKernelGGL(gemm_nt_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, p);
-    else
-        hipLaunchKernelGGL(gemm_nt_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    const bool dma = (K * es) % 128 == 0;
+    if (ab_dtype == GD_BF16) {
+        if (dma) hipLaunchKernelGGL(gemm_nt_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL(gemm_nt_regstage_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    } else {
+        if (dma) hipLaunchKernelGGL(gemm_nt_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL(gemm_nt_regstage_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    }
     GD_LAUNCH_OK();
     return 0;
 }
