@@ -57,23 +57,61 @@ template <typename T> __device__ __forceinline__ typename Mma<T>::Frag load_nfra
     return *(const typename Mma<T>::Frag*)(row + u * 64 + g * 16);
 }
 
-// Stage `rows` (<= 64) rows of a [*, 64]-element matrix (global row stride ld_b bytes) into LDS, both as a
-// natural tile sN[row][64] and/or a transposed tile sT[col][row].  Rows >= valid read as zero.
-template <typename T, bool NAT, bool TRN>
-__device__ __forceinline__ void stage_tile(const char* gbase, long ld_b, int row0, int nvalid, char* sN, char* sT) {
-    constexpr int CPR = AT<T>::CPR, EPC = AT<T>::EPC, ROWB = AT<T>::ROWB;
-    for (int ch = threadIdx.x; ch < 64 * CPR; ch += 256) {
-        const int r = ch / CPR, cc = ch % CPR;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (row0 + r < nvalid) v = *(const uint4*)(gbase + (long)(row0 + r) * ld_b + cc * 16);
-        if (NAT) *(uint4*)(sN + r * ROWB + cc * 16) = v;
-        if (TRN) {
-            const T* e = (const T*)&v;
+// Tile staging, split T14-style: `tile_load` issues the global loads of a 64 x 64-element tile into registers
+// (rows >= nvalid read as zero) and `tile_store` writes them to LDS later — as a natural tile sN[row][64]
+// and/or a transposed tile sT[col][row] — so the next tile's HBM/L2 latency hides under the current tile's MFMAs.
+template <typename T> struct TileRegs { uint4 v[AT<T>::CPR * 64 / 256]; };
+
+template <typename T>
+__device__ __forceinline__ void tile_load(TileRegs<T>& r, const char* gbase, long ld_b, int row0, int nvalid) {
+    constexpr int CPR = AT<T>::CPR, NCH = CPR * 64 / 256;
 #pragma unroll
-            for (int k = 0; k < EPC; ++k) *(T*)(sT + (cc * EPC + k) * ROWB + r * (int)sizeof(T)) = e[k];
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = threadIdx.x + 256 * i, rr = ch / CPR, cc = ch % CPR;
+        r.v[i] = (row0 + rr < nvalid) ? *(const uint4*)(gbase + (long)(row0 + rr) * ld_b + cc * 16) : make_uint4(0, 0, 0, 0);
+    }
+}
+template <typename T, bool NAT, bool TRN>
+__device__ __forceinline__ void tile_store(const TileRegs<T>& r, char* sN, char* sT) {
+    constexpr int CPR = AT<T>::CPR, EPC = AT<T>::EPC, ROWB = AT<T>::ROWB, NCH = CPR * 64 / 256;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = threadIdx.x + 256 * i, rr = ch / CPR, cc = ch % CPR;
+        if (NAT) *(uint4*)(sN + rr * ROWB + cc * 16) = r.v[i];
+        if (TRN) {
+            const T* e = (const T*)&r.v[i];
+#pragma unroll
+            for (int k = 0; k < EPC; ++k) *(T*)(sT + (cc * EPC + k) * ROWB + rr * (int)sizeof(T)) = e[k];
         }
     }
 }
+
+// The "transposed operand" A[row = column c of the tile][k-slot = tile row]:
+//   bf16: read straight from the NATURAL tile with ds_read_b64_tr_b16 (hardware 4x16 transpose per 16-lane group:
+//         lane 4q+p supplies the address of block row q, columns 4p..4p+3; lane i receives column i of the 4 rows)
+//   f32 : 16-byte read from an explicitly transposed LDS tile.
+template <typename T> struct TOp;
+template <> struct TOp<bf16> {
+    static constexpr bool kNeedT = false;
+    static __device__ __forceinline__ bf16x8 load(const char* sN, const char*, int dt, int u, int g, int lane) {
+        typedef __attribute__((ext_vector_type(4))) short s16x4;
+        const int i = lane & 15, q = i >> 2, p = i & 3;
+        const char* a0 = sN + (32 * u + 4 * g + q) * AT<bf16>::ROWB + (dt * 16 + 4 * p) * 2;
+        const char* a1 = a0 + 16 * AT<bf16>::ROWB;
+        const s16x4 x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
+        const s16x4 y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1);
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        const s16x8 z = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+        return __builtin_bit_cast(bf16x8, z);
+    }
+};
+template <> struct TOp<float> {
+    static constexpr bool kNeedT = true;
+    static __device__ __forceinline__ f32x4 load(const char*, const char* sT, int dt, int u, int g, int lane) {
+        return load_tfrag<float>(sT + (dt * 16 + (lane & 15)) * AT<float>::ROWB, u, g);
+    }
+};
+#define TSZ(T) (TOp<T>::kNeedT ? 64 * AT<T>::ROWB : 16)
 
 template <typename T> __device__ __forceinline__ void store4(T* p, f32x4 v);
 template <> __device__ __forceinline__ void store4<float>(float* p, f32x4 v) { *(f32x4*)p = v; }
@@ -87,7 +125,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* qkv, T* o, float
     constexpr int NF = AT<T>::NF, ROWB = AT<T>::ROWB;
     typedef typename Mma<T>::Frag Frag;
     __shared__ __attribute__((aligned(16))) char sK[64 * ROWB];
-    __shared__ __attribute__((aligned(16))) char sVt[64 * ROWB];
+    __shared__ __attribute__((aligned(16))) char sV[TOp<T>::kNeedT ? 16 : 64 * ROWB];
+    __shared__ __attribute__((aligned(16))) char sVt[TSZ(T)];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
     const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128 + wave * 32;
     const long ld_b = (long)3 * H * HD * sizeof(T);
@@ -113,11 +152,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* qkv, T* o, float
         for (int j = 0; j < 2; ++j) oacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m[2] = {-1e30f, -1e30f}, l[2] = {0.f, 0.f};
 
+    TileRegs<T> rk, rv;
+    tile_load<T>(rk, kb, ld_b, 0, N);
+    tile_load<T>(rv, vb, ld_b, 0, N);
     for (int k0 = 0; k0 < N; k0 += 64) {
         __syncthreads();
-        stage_tile<T, true, false>(kb, ld_b, k0, N, sK, nullptr);
-        stage_tile<T, false, true>(vb, ld_b, k0, N, nullptr, sVt);
+        tile_store<T, true, false>(rk, sK, nullptr);
+        tile_store<T, !TOp<T>::kNeedT, TOp<T>::kNeedT>(rv, sV, sVt);
         __syncthreads();
+        if (k0 + 64 < N) {
+            tile_load<T>(rk, kb, ld_b, k0 + 64, N);
+            tile_load<T>(rv, vb, ld_b, k0 + 64, N);
+        }
         f32x4 s[2][4];  // [qt][key tile]
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
@@ -171,7 +217,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* qkv, T* o, float
             for (int qt = 0; qt < 2; ++qt) pf[qt] = acc_to_bfrag<T>(s[qt], u);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const Frag vf = load_tfrag<T>(sVt + (dt * 16 + c) * ROWB, u, g);
+                const Frag vf = TOp<T>::load(sV, sVt, dt, u, g, lane);
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt) oacc[dt][qt] = Mma<T>::mma(vf, pf[qt], oacc[dt][qt]);
             }
@@ -220,7 +266,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* qkv, const T*
     constexpr int NF = AT<T>::NF, ROWB = AT<T>::ROWB;
     typedef typename Mma<T>::Frag Frag;
     __shared__ __attribute__((aligned(16))) char sK[64 * ROWB];
-    __shared__ __attribute__((aligned(16))) char sKt[64 * ROWB];
+    __shared__ __attribute__((aligned(16))) char sKt[TSZ(T)];
     __shared__ __attribute__((aligned(16))) char sV[64 * ROWB];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
     const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128 + wave * 32;
@@ -253,11 +299,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* qkv, const T*
 #pragma unroll
         for (int j = 0; j < 2; ++j) dq[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    TileRegs<T> rk, rv;
+    tile_load<T>(rk, kb, ld_b, 0, N);
+    tile_load<T>(rv, vb, ld_b, 0, N);
     for (int k0 = 0; k0 < N; k0 += 64) {
         __syncthreads();
-        stage_tile<T, true, true>(kb, ld_b, k0, N, sK, sKt);
-        stage_tile<T, true, false>(vb, ld_b, k0, N, sV, nullptr);
+        tile_store<T, true, TOp<T>::kNeedT>(rk, sK, sKt);
+        tile_store<T, true, false>(rv, sV, nullptr);
         __syncthreads();
+        if (k0 + 64 < N) {
+            tile_load<T>(rk, kb, ld_b, k0 + 64, N);
+            tile_load<T>(rv, vb, ld_b, k0 + 64, N);
+        }
         f32x4 ds[2][4];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
@@ -290,7 +343,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* qkv, const T*
             for (int qt = 0; qt < 2; ++qt) df[qt] = acc_to_bfrag<T>(ds[qt], u);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const Frag kf = load_tfrag<T>(sKt + (dt * 16 + c) * ROWB, u, g);
+                const Frag kf = TOp<T>::load(sK, sKt, dt, u, g, lane);
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt) dq[dt][qt] = Mma<T>::mma(kf, df[qt], dq[dt][qt]);
             }
@@ -313,9 +366,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* qkv, const T
     constexpr int NF = AT<T>::NF, ROWB = AT<T>::ROWB;
     typedef typename Mma<T>::Frag Frag;
     __shared__ __attribute__((aligned(16))) char sQ[64 * ROWB];
-    __shared__ __attribute__((aligned(16))) char sQt[64 * ROWB];
+    __shared__ __attribute__((aligned(16))) char sQt[TSZ(T)];
     __shared__ __attribute__((aligned(16))) char sD[64 * ROWB];
-    __shared__ __attribute__((aligned(16))) char sDt[64 * ROWB];
+    __shared__ __attribute__((aligned(16))) char sDt[TSZ(T)];
     __shared__ float sL[64], sDl[64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
     const int b = blockIdx.z, h = blockIdx.y, key0 = blockIdx.x * 128 + wave * 32;
@@ -344,10 +397,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* qkv, const T
 #pragma unroll
         for (int j = 0; j < 2; ++j) { dk[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
+    TileRegs<T> rq, rd;
+    tile_load<T>(rq, qb, ld_b, 0, N);
+    tile_load<T>(rd, dob, ldo_b, 0, N);
     for (int q0 = 0; q0 < N; q0 += 64) {
         __syncthreads();
-        stage_tile<T, true, true>(qb, ld_b, q0, N, sQ, sQt);
-        stage_tile<T, true, true>(dob, ldo_b, q0, N, sD, sDt);
+        tile_store<T, true, TOp<T>::kNeedT>(rq, sQ, sQt);
+        tile_store<T, true, TOp<T>::kNeedT>(rd, sD, sDt);
+        if (q0 + 64 < N) {
+            tile_load<T>(rq, qb, ld_b, q0 + 64, N);
+            tile_load<T>(rd, dob, ldo_b, q0 + 64, N);
+        }
         if (threadIdx.x < 64) {
             const int q = q0 + threadIdx.x;
             sL[threadIdx.x] = q < N ? lse[((long)b * H + h) * N + q] : 0.f;
@@ -387,8 +447,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* qkv, const T
             for (int kt = 0; kt < 2; ++kt) { pf[kt] = acc_to_bfrag<T>(pp[kt], u); sf[kt] = acc_to_bfrag<T>(dsv[kt], u); }
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const Frag dot = load_tfrag<T>(sDt + (dt * 16 + c) * ROWB, u, g);
-                const Frag qt_ = load_tfrag<T>(sQt + (dt * 16 + c) * ROWB, u, g);
+                const Frag dot = TOp<T>::load(sD, sDt, dt, u, g, lane);
+                const Frag qt_ = TOp<T>::load(sQ, sQt, dt, u, g, lane);
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt) {
                     dv[dt][kt] = Mma<T>::mma(dot, pf[kt], dv[dt][kt]);
