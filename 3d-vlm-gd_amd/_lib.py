@@ -48,9 +48,9 @@ SIGNATURES = {
                              c_void_p, c_void_p, c_void_p, c_void_p]),
     "gd_pair_rank_workspace_bytes": (c_size_t, [c_int]),
     "gd_pair_rank": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p,
-                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gd_depth_l1": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
-                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gd_adamw_workspace_bytes": (c_size_t, []),
     "gd_clip_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_float, c_float, c_float,
                                    c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),

@@ -400,6 +400,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* qkv, const T
     TileRegs<T> rq, rd;
     tile_load<T>(rq, qb, ld_b, 0, N);
     tile_load<T>(rd, dob, ldo_b, 0, N);
+    float rl = 0.f, rdl = 0.f;   // next tile's lse / delta rows, prefetched with the tile
+    if (threadIdx.x < 64 && threadIdx.x < N) {
+        rl = lse[((long)b * H + h) * N + threadIdx.x];
+        rdl = delta[((long)b * H + h) * N + threadIdx.x];
+    }
     for (int q0 = 0; q0 < N; q0 += 64) {
         __syncthreads();
         tile_store<T, true, TOp<T>::kNeedT>(rq, sQ, sQt);
@@ -408,10 +413,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* qkv, const T
             tile_load<T>(rq, qb, ld_b, q0 + 64, N);
             tile_load<T>(rd, dob, ldo_b, q0 + 64, N);
         }
-        if (threadIdx.x < 64) {
-            const int q = q0 + threadIdx.x;
-            sL[threadIdx.x] = q < N ? lse[((long)b * H + h) * N + q] : 0.f;
-            sDl[threadIdx.x] = q < N ? delta[((long)b * H + h) * N + q] : 0.f;
+        if (threadIdx.x < 64) { sL[threadIdx.x] = rl; sDl[threadIdx.x] = rdl; }
+        if (q0 + 64 < N && threadIdx.x < 64) {
+            const int q = q0 + 64 + threadIdx.x;
+            rl = q < N ? lse[((long)b * H + h) * N + q] : 0.f;
+            rdl = q < N ? delta[((long)b * H + h) * N + q] : 0.f;
         }
         __syncthreads();
         f32x4 pp[2][4], dsv[2][4];  // [key tile][query tile]

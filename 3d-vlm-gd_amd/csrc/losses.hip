@@ -265,13 +265,16 @@ __global__ __launch_bounds__(256) void depth_l1_kernel(const float* u, const flo
 // du[set] *= g[set]/cnt, hg_out += hg[set] * g[set]/cnt, loss[set] = loss_sum/cnt (0 when no valid pair)
 __global__ __launch_bounds__(256) void pair_rank_finalize_kernel(float* du, const float* hg, const float* loss_sum,
                                                                  const int* pair_cnt, const float* gscale,
-                                                                 float* hg_out, float* loss, int Nmax) {
+                                                                 float* hg_out, float* hg_sets, float* loss, int Nmax) {
     const int set = blockIdx.x;
     const int cnt = pair_cnt[set];
     const float sc = cnt > 0 ? gscale[set] / (float)cnt : 0.f;
     for (long idx = threadIdx.x; idx < (long)Nmax * 128; idx += 256) du[(long)set * Nmax * 128 + idx] *= sc;
-    for (int idx = threadIdx.x; idx < HG_SIZE; idx += 256)
-        if (idx <= 512) atomicAdd(hg_out + idx, hg[(long)set * HG_SIZE + idx] * sc);
+    for (int idx = threadIdx.x; idx < HG_SIZE; idx += 256) {
+        const float v = idx <= 512 ? hg[(long)set * HG_SIZE + idx] * sc : 0.f;
+        if (hg_sets) hg_sets[(long)set * HG_SIZE + idx] = v;
+        if (hg_out && idx <= 512) atomicAdd(hg_out + idx, v);
+    }
     if (threadIdx.x == 0) loss[set] = cnt > 0 ? loss_sum[set] / (float)cnt : 0.f;
 }
 
@@ -304,7 +307,7 @@ extern "C" size_t gd_pair_rank_workspace_bytes(int S) { return (size_t)S * (HG_S
 extern "C" int gd_pair_rank(const float* u, const float* depth, const int* counts, const float* gscale, int S,
                             int Nmax, float depth_threshold, const float* b1, const float* ln_w, const float* ln_b,
                             const float* w2, const float* b2, float* loss, float* du, float* head_grad,
-                            void* workspace, void* stream) {
+                            float* head_grad_sets, void* workspace, void* stream) {
     GD_REQUIRE(S > 0 && Nmax > 0, "gd_pair_rank: bad shape");
     hipStream_t s = (hipStream_t)stream;
     float* hg = (float*)workspace;
@@ -313,8 +316,8 @@ extern "C" int gd_pair_rank(const float* u, const float* depth, const int* count
     hipMemsetAsync(workspace, 0, gd_pair_rank_workspace_bytes(S), s);
     hipLaunchKernelGGL(pair_rank_kernel, dim3(Nmax, S), dim3(256), 0, s, u, depth, counts, b1, ln_w, ln_b, w2, b2, du,
                        hg, lsum, cnt, Nmax, depth_threshold);
-    hipLaunchKernelGGL(pair_rank_finalize_kernel, dim3(S), dim3(256), 0, s, du, hg, lsum, cnt, gscale, head_grad, loss,
-                       Nmax);
+    hipLaunchKernelGGL(pair_rank_finalize_kernel, dim3(S), dim3(256), 0, s, du, hg, lsum, cnt, gscale, head_grad,
+                       head_grad_sets, loss, Nmax);
     GD_LAUNCH_OK();
     return 0;
 }
@@ -329,7 +332,7 @@ extern "C" int gd_depth_l1(const float* u, const float* d1, const float* d2, con
     hipMemsetAsync(loss, 0, (size_t)P * sizeof(float), s);
     hipLaunchKernelGGL(depth_l1_kernel, dim3(gd_cdiv(Nmax, 4), P), dim3(256), 0, s, u, d1, d2, counts, gscale, b1, ln_w,
                        ln_b, w2, b2, du, hg, loss, Nmax);
-    hipLaunchKernelGGL(row_sum_cols_kernel, dim3(gd_cdiv(HG_SIZE, 256)), dim3(256), 0, s, hg, head_grad, P, HG_SIZE);
+    if (head_grad) hipLaunchKernelGGL(row_sum_cols_kernel, dim3(gd_cdiv(HG_SIZE, 256)), dim3(256), 0, s, hg, head_grad, P, HG_SIZE);
     GD_LAUNCH_OK();
     return 0;
 }

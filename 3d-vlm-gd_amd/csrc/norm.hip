@@ -18,17 +18,17 @@ template <> __device__ __forceinline__ void store4n<bf16>(bf16* p, f32x4 v) {
     *(bf16x4*)p = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
 }
 
-template <typename T, typename TO>
+template <typename T, typename TO, int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* x, const float* gamma, const float* beta, TO* y,
                                                      float* mean, float* rstd, int M, int D, long ldx, long ldy,
                                                      float eps) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const T* xr = x + (long)row * ldx;
-    f32x4 v[LN_MAXV];
+    f32x4 v[NV];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = (lane + 64 * i) * 4;
         if (c < D) {
             v[i] = load4<T>(xr + c);
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* x, const float* ga
     const float mu = wave_sum(s) / (float)D;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = (lane + 64 * i) * 4;
         if (c < D) {
 #pragma unroll
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* x, const float* ga
     if (lane == 0 && mean) { mean[row] = mu; rstd[row] = rs; }
     TO* yr = y + (long)row * ldy;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = (lane + 64 * i) * 4;
         if (c < D) {
             const f32x4 g = *(const f32x4*)(gamma + c), b = *(const f32x4*)(beta + c);
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* x, const float* ga
 }
 
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;  dx += dres when given
-template <typename T, typename TD>
+template <typename T, typename TD, int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* dy, const T* x, const float* gamma, const float* mean,
                                                      const float* rstd, const T* dres, T* dx, int M, int D, long ldd,
                                                      long ldx, float dyscale) {
@@ -71,10 +71,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* dy, const T* x, c
     const float mu = mean[row], rs = rstd[row];
     const T* xr = x + (long)row * ldx;
     const TD* dr = dy + (long)row * ldd;
-    f32x4 xh[LN_MAXV], g[LN_MAXV];
+    f32x4 xh[NV], g[NV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = (lane + 64 * i) * 4;
         if (c < D) {
             const f32x4 xv = load4<T>(xr + c), dv = load4<TD>(dr + c), gm = *(const f32x4*)(gamma + c);
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* dy, const T* x, c
     s2 = wave_sum(s2) / (float)D;
     T* or_ = dx + (long)row * ldx;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = (lane + 64 * i) * 4;
         if (c < D) {
             f32x4 o;
@@ -128,6 +128,18 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* y, const f
     for (int c = lane; c < D; c += 64) dx[(long)row * D + c] = (dy[(long)row * D + c] - y[(long)row * D + c] * s) * iv;
 }
 
+// NV = number of 256-column slabs a wave walks: keeps the register footprint proportional to D
+#define LN_DISPATCH_NV(D, CALL)                     \
+    do {                                            \
+        const int nv_ = ((D) + 255) / 256;          \
+        if (nv_ <= 1) { CALL(1); }                  \
+        else if (nv_ <= 2) { CALL(2); }             \
+        else if (nv_ <= 3) { CALL(3); }             \
+        else if (nv_ <= 4) { CALL(4); }             \
+        else if (nv_ <= 6) { CALL(6); }             \
+        else { CALL(8); }                           \
+    } while (0)
+
 extern "C" int gd_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
                                 float* rstd, int M, int D, long ldx, long ldy, float eps, int dtype, int y_dtype,
                                 void* stream) {
@@ -136,12 +148,12 @@ extern "C" int gd_layernorm_fwd(const void* x, const float* gamma, const float* 
     GD_REQUIRE((mean == nullptr) == (rstd == nullptr), "gd_layernorm_fwd: pass both mean and rstd or neither");
     dim3 grid(gd_cdiv(M, 4)), blk(256);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == GD_BF16 && y_dtype == GD_BF16)
-        hipLaunchKernelGGL((ln_fwd_kernel<bf16, bf16>), grid, blk, 0, s, (const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, M, D, ldx, ldy, eps);
-    else if (dtype == GD_BF16 && y_dtype == GD_F32)
-        hipLaunchKernelGGL((ln_fwd_kernel<bf16, float>), grid, blk, 0, s, (const bf16*)x, gamma, beta, (float*)y, mean, rstd, M, D, ldx, ldy, eps);
-    else if (dtype == GD_F32 && y_dtype == GD_F32)
-        hipLaunchKernelGGL((ln_fwd_kernel<float, float>), grid, blk, 0, s, (const float*)x, gamma, beta, (float*)y, mean, rstd, M, D, ldx, ldy, eps);
+#define F_BB(NV) hipLaunchKernelGGL((ln_fwd_kernel<bf16, bf16, NV>), grid, blk, 0, s, (const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, M, D, ldx, ldy, eps)
+#define F_BF(NV) hipLaunchKernelGGL((ln_fwd_kernel<bf16, float, NV>), grid, blk, 0, s, (const bf16*)x, gamma, beta, (float*)y, mean, rstd, M, D, ldx, ldy, eps)
+#define F_FF(NV) hipLaunchKernelGGL((ln_fwd_kernel<float, float, NV>), grid, blk, 0, s, (const float*)x, gamma, beta, (float*)y, mean, rstd, M, D, ldx, ldy, eps)
+    if (dtype == GD_BF16 && y_dtype == GD_BF16) LN_DISPATCH_NV(D, F_BB);
+    else if (dtype == GD_BF16 && y_dtype == GD_F32) LN_DISPATCH_NV(D, F_BF);
+    else if (dtype == GD_F32 && y_dtype == GD_F32) LN_DISPATCH_NV(D, F_FF);
     else {
         gd_set_error("gd_layernorm_fwd: unsupported dtype pair %d -> %d", dtype, y_dtype);
         return -1;
@@ -157,12 +169,12 @@ extern "C" int gd_layernorm_bwd(const void* dy, const void* x, const float* gamm
     GD_REQUIRE(ldx % 4 == 0 && ldd % 4 == 0, "gd_layernorm_bwd: row strides must be multiples of 4 elements");
     dim3 grid(gd_cdiv(M, 4)), blk(256);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == GD_BF16 && dy_dtype == GD_BF16)
-        hipLaunchKernelGGL((ln_bwd_kernel<bf16, bf16>), grid, blk, 0, s, (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx, M, D, ldd, ldx, dyscale);
-    else if (dtype == GD_BF16 && dy_dtype == GD_F32)
-        hipLaunchKernelGGL((ln_bwd_kernel<bf16, float>), grid, blk, 0, s, (const float*)dy, (const bf16*)x, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx, M, D, ldd, ldx, dyscale);
-    else if (dtype == GD_F32 && dy_dtype == GD_F32)
-        hipLaunchKernelGGL((ln_bwd_kernel<float, float>), grid, blk, 0, s, (const float*)dy, (const float*)x, gamma, mean, rstd, (const float*)dres, (float*)dx, M, D, ldd, ldx, dyscale);
+#define B_BB(NV) hipLaunchKernelGGL((ln_bwd_kernel<bf16, bf16, NV>), grid, blk, 0, s, (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx, M, D, ldd, ldx, dyscale)
+#define B_BF(NV) hipLaunchKernelGGL((ln_bwd_kernel<bf16, float, NV>), grid, blk, 0, s, (const float*)dy, (const bf16*)x, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx, M, D, ldd, ldx, dyscale)
+#define B_FF(NV) hipLaunchKernelGGL((ln_bwd_kernel<float, float, NV>), grid, blk, 0, s, (const float*)dy, (const float*)x, gamma, mean, rstd, (const float*)dres, (float*)dx, M, D, ldd, ldx, dyscale)
+    if (dtype == GD_BF16 && dy_dtype == GD_BF16) LN_DISPATCH_NV(D, B_BB);
+    else if (dtype == GD_BF16 && dy_dtype == GD_F32) LN_DISPATCH_NV(D, B_BF);
+    else if (dtype == GD_F32 && dy_dtype == GD_F32) LN_DISPATCH_NV(D, B_FF);
     else {
         gd_set_error("gd_layernorm_bwd: unsupported dtype pair x=%d dy=%d", dtype, dy_dtype);
         return -1;

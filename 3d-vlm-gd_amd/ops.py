@@ -375,59 +375,45 @@ HEAD_KEYS = ("w1", "b1", "ln_w", "ln_b", "w2", "b2")
 
 
 class _DepthLosses(torch.autograd.Function):
-    """depth L1 + intra-view ranking on keypoint features [P,2,N,D] with the DepthAwareFeatureFusion head."""
+    """depth L1 + intra-view ranking on keypoint features [P,2,N,D] with the DepthAwareFeatureFusion head.
+    The loss kernels are fused forward+backward: they emit, per keypoint set, the loss AND its gradients for a
+    unit upstream gradient; backward() only scales and contracts them."""
 
     @staticmethod
     def forward(ctx, feats, d1, d2, counts, thr, w1, b1, ln_w, ln_b, w2, b2):
         P, _, N, D = feats.shape
+        dev = feats.device
         f = feats.contiguous().float()
         u = gemm_nt(f.view(P * 2 * N, D), w1.contiguous())         # [P*2*N,128] = W1 f
         depth = torch.stack([d1, d2], 1).contiguous().float()      # [P,2,N]
         dv1, dv2 = depth[:, 0].contiguous(), depth[:, 1].contiguous()
         cnt2 = counts.repeat_interleave(2).contiguous() if counts is not None else None
-        ones_s = torch.ones(2 * P, dtype=torch.float32, device=f.device)
-        ones_p = torch.ones(P, dtype=torch.float32, device=f.device)
+        ones = torch.ones(2 * P, dtype=torch.float32, device=dev)
         hp = [t.contiguous().float() for t in (b1, ln_w, ln_b, w2.view(-1), b2)]
-        rank = torch.empty(2 * P, dtype=torch.float32, device=f.device)
-        du_r = torch.empty(2 * P, N, 128, dtype=torch.float32, device=f.device)
-        hg_r = torch.zeros(516, dtype=torch.float32, device=f.device)
-        ws = torch.empty(lib().gd_pair_rank_workspace_bytes(2 * P), dtype=torch.uint8, device=f.device)
-        check(lib().gd_pair_rank(ptr(u), ptr(depth), ptr(cnt2), ptr(ones_s), 2 * P, N, float(thr), *[ptr(t) for t in hp],
-                                 ptr(rank), ptr(du_r), ptr(hg_r), ptr(ws), stream()), "gd_pair_rank")
-        l1 = torch.empty(P, dtype=torch.float32, device=f.device)
-        du_l = torch.empty(P, 2, N, 128, dtype=torch.float32, device=f.device)
-        hg_l = torch.zeros(516, dtype=torch.float32, device=f.device)
-        ws2 = torch.empty(P * 516 * 4, dtype=torch.uint8, device=f.device)
-        check(lib().gd_depth_l1(ptr(u), ptr(dv1), ptr(dv2), ptr(counts),
-                                ptr(ones_p), P, N, *[ptr(t) for t in hp], ptr(l1), ptr(du_l), ptr(hg_l), ptr(ws2),
-                                stream()), "gd_depth_l1")
-        # per-set gradients are linear in the upstream scale, so keep the per-set pieces for backward
-        ctx.save_for_backward(f, w1, du_r, du_l, u)
-        ctx.hp = hp
-        ctx.aux = (depth, dv1, dv2, cnt2, counts, thr, P, N, D)
+        rank = torch.empty(2 * P, dtype=torch.float32, device=dev)
+        du_r = torch.empty(2 * P, N, 128, dtype=torch.float32, device=dev)
+        hg_r = torch.empty(2 * P, 516, dtype=torch.float32, device=dev)
+        ws = torch.empty(lib().gd_pair_rank_workspace_bytes(2 * P), dtype=torch.uint8, device=dev)
+        check(lib().gd_pair_rank(ptr(u), ptr(depth), ptr(cnt2), ptr(ones), 2 * P, N, float(thr), *[ptr(t) for t in hp],
+                                 ptr(rank), ptr(du_r), None, ptr(hg_r), ptr(ws), stream()), "gd_pair_rank")
+        l1 = torch.empty(P, dtype=torch.float32, device=dev)
+        du_l = torch.empty(P, 2, N, 128, dtype=torch.float32, device=dev)
+        hg_l = torch.empty(P, 516, dtype=torch.float32, device=dev)
+        check(lib().gd_depth_l1(ptr(u), ptr(dv1), ptr(dv2), ptr(counts), ptr(ones), P, N, *[ptr(t) for t in hp],
+                                ptr(l1), ptr(du_l), None, ptr(hg_l), None, stream()), "gd_depth_l1")
+        ctx.save_for_backward(f, w1, du_r, du_l, hg_r, hg_l)
+        ctx.dims = (P, N, D)
         intra = 0.5 * (rank.view(P, 2)[:, 0] + rank.view(P, 2)[:, 1])
         return l1, intra
 
     @staticmethod
     def backward(ctx, g_l1, g_intra):
-        f, w1, du_r, du_l, u = ctx.saved_tensors
-        depth, dv1, dv2, cnt2, counts, thr, P, N, D = ctx.aux
-        hp = ctx.hp
-        dev = f.device
-        # re-run the two loss kernels with the upstream scales folded in (cheap: N^2 x 128 work)
-        gs = (0.5 * g_intra.float()).repeat_interleave(2).contiguous()
-        rank = torch.empty(2 * P, dtype=torch.float32, device=dev)
-        hg = torch.zeros(516, dtype=torch.float32, device=dev)
-        ws = torch.empty(lib().gd_pair_rank_workspace_bytes(2 * P), dtype=torch.uint8, device=dev)
-        check(lib().gd_pair_rank(ptr(u), ptr(depth), ptr(cnt2), ptr(gs), 2 * P, N, float(thr), *[ptr(t) for t in hp],
-                                 ptr(rank), ptr(du_r), ptr(hg), ptr(ws), stream()), "gd_pair_rank")
-        l1 = torch.empty(P, dtype=torch.float32, device=dev)
-        ws2 = torch.empty(P * 516 * 4, dtype=torch.uint8, device=dev)
-        gl = g_l1.contiguous().float()
-        check(lib().gd_depth_l1(ptr(u), ptr(dv1), ptr(dv2), ptr(counts),
-                                ptr(gl), P, N, *[ptr(t) for t in hp], ptr(l1), ptr(du_l), ptr(hg), ptr(ws2), stream()),
-              "gd_depth_l1")
-        du = (du_r.view(P, 2, N, 128) + du_l).view(P * 2 * N, 128)
+        f, w1, du_r, du_l, hg_r, hg_l = ctx.saved_tensors
+        P, N, D = ctx.dims
+        gi = (0.5 * g_intra.float()).repeat_interleave(2)                       # per keypoint set
+        gl = g_l1.float()
+        du = (du_r.view(P, 2, N, 128) * gi.view(P, 2, 1, 1) + du_l * gl.view(P, 1, 1, 1)).view(P * 2 * N, 128)
+        hg = (hg_r * gi[:, None]).sum(0) + (hg_l * gl[:, None]).sum(0)
         df = gemm_nt(du, w1.t().contiguous()).view(P, 2, N, D)     # du . W1
         dw1 = gemm_tn(du, f.view(P * 2 * N, D))                    # du^T f  [128, D]
         return (df, None, None, None, None, dw1, hg[0:128].clone(), hg[128:256].clone(), hg[256:384].clone(),

@@ -105,15 +105,17 @@ int gd_tap_mean_bwd(void* const* dgrids, int ngrid, int prefix, const void* dout
 int gd_smooth_ap(const float* sim, const float* pts3d_1, const float* pts3d_2, const int* counts, int P, int Nmax,
                  int variant, float thres3d_neg, float temp, float* loss, float* dsim, float* row_ws, void* stream);
 /* pairwise_logistic_ranking_loss (utils/losses.py:18-41) with DepthAwareFeatureFusion (utils/model.py:100-127) on
- * pre-projected u = W1 f [S,Nmax,128]: loss [S], du (scaled by gscale/count), head_grad[516] += {b1,ln_w,ln_b,w2,b2}. */
+ * pre-projected u = W1 f [S,Nmax,128]: loss [S], du (scaled by gscale/count), head_grad[516] += {b1,ln_w,ln_b,w2,b2} (nullable),
+ * head_grad_sets [S,516] = the same per set (nullable). */
 size_t gd_pair_rank_workspace_bytes(int S);
 int gd_pair_rank(const float* u, const float* depth, const int* counts, const float* gscale, int S, int Nmax,
                  float depth_threshold, const float* b1, const float* ln_w, const float* ln_b, const float* w2,
-                 const float* b2, float* loss, float* du, float* head_grad, void* workspace, void* stream);
+                 const float* b2, float* loss, float* du, float* head_grad, float* head_grad_sets, void* workspace,
+                 void* stream);
 /* F.l1_loss(head(f1 - f2), tanh(d1 - d2)) (src/finetune_timm_vggt.py:475-479); u [P,2,Nmax,128]. */
 int gd_depth_l1(const float* u, const float* d1, const float* d2, const int* counts, const float* gscale, int P,
                 int Nmax, const float* b1, const float* ln_w, const float* ln_b, const float* w2, const float* b2,
-                float* loss, float* du, float* head_grad, void* workspace, void* stream);
+                float* loss, float* du, float* head_grad, float* head_grad_sets, void* workspace, void* stream);
 
 /* Lightning gradient_clip_val=1.0 (src/main.py:153) + torch.optim.AdamW (src/finetune_timm_vggt.py:642-648) on the
  * flat fp32 trainable buffer; grads are multiplied by grad_scale first. */
