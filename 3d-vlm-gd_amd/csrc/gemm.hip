@@ -10,6 +10,7 @@
 // tile's loads in flight under the MFMAs, LDS rows padded 128->144 B.
 #include "gd_common.h"
 #include "gemm_tile.h"
+#include <stdlib.h>
 
 struct GemmNtParams {
     const void* A; const void* W; void* C;
@@ -114,13 +115,20 @@ __device__ __forceinline__ void st8_rt(void* p, long i, int dt, const float (&v)
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtParams p) {
-    constexpr int BM = 128, BN = 128, STAGE = 32768, EPLD = 132;
+// Tile configurations:  NWM x NWN waves, each wave owns WMT x 4 MFMA tiles (16*WMT rows x 64 columns).
+//   <2,2,4> : 128 x 128 block, 256 threads, 64 KB LDS ring (2 blocks / CU)      — skinny N / small problems
+//   <2,4,8> : 256 x 256 block, 512 threads, 128 KB LDS ring (1 block / CU, 2 waves / SIMD); wave tile 128 x 64
+//             => 12 fragment reads per 32 MFMAs instead of 8 per 16: less LDS traffic per FLOP.
+template <typename T, int NWM, int NWN, int WMT>
+__global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(GemmNtParams p) {
+    constexpr int NW = NWM * NWN, NT = 64 * NW, BM = NWM * WMT * 16, BN = NWN * 64;
+    constexpr int ABYTES = BM * 128, STAGE = (BM + BN) * 128, EPLD = BN + 4;
+    constexpr int APW = BM / 8 / NW, BPW = BN / 8 / NW;   // 1-KB DMA pieces per wave per operand per K-step
+    static_assert(64 * EPLD * 4 <= 2 * STAGE, "epilogue staging must fit in the ring");
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / NWN, wn = wave % NWN;
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
     const int wg = xcd_remap(blockIdx.x, tiles_m * tiles_n);
     const int tm = wg / tiles_n, tn = wg % tiles_n;
@@ -130,45 +138,42 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtParams p) {
     const long lda_b = p.lda * (long)sizeof(T), ldw_b = p.ldw * (long)sizeof(T);
     const int nk = p.K * (int)sizeof(T) / 128;
 
-    // per-lane source pointers of this thread's 4 + 4 DMA pieces (LDS piece pc = wave*4+i holds rows pc*8..pc*8+7)
-    const char* asrc[4];
-    const char* wsrc[4];
+    // per-lane source pointers of this wave's DMA pieces (LDS piece pc holds rows pc*8 .. pc*8+7, 128 B each)
+    const char* asrc[APW];
+    const char* wsrc[BPW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (wave * 4 + i) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ swz(row);
-        const int ar = min(tm * BM + row, p.M - 1), wr = min(tn * BN + row, p.N - 1);
-        asrc[i] = Ab + (long)ar * lda_b + c * 16;
-        wsrc[i] = Wb + (long)wr * ldw_b + c * 16;
+    for (int i = 0; i < APW; ++i) {
+        const int row = (wave * APW + i) * 8 + (lane >> 3);
+        asrc[i] = Ab + (long)min(tm * BM + row, p.M - 1) * lda_b + (((lane & 7) ^ swz(row)) * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < BPW; ++i) {
+        const int row = (wave * BPW + i) * 8 + (lane >> 3);
+        wsrc[i] = Wb + (long)min(tn * BN + row, p.N - 1) * ldw_b + (((lane & 7) ^ swz(row)) * 16);
     }
     auto issue = [&](int kt, int buf) {
         char* sA = smem + buf * STAGE;
-        char* sB = sA + 16384;
+        char* sB = sA + ABYTES;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int pc = wave * 4 + i;
+        for (int i = 0; i < APW; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + (long)kt * 128),
-                                             (__attribute__((address_space(3))) void*)(sA + pc * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(sA + (wave * APW + i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < BPW; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + (long)kt * 128),
-                                             (__attribute__((address_space(3))) void*)(sB + pc * 1024), 16, 0, 0);
-        }
+                                             (__attribute__((address_space(3))) void*)(sB + (wave * BPW + i) * 1024), 16, 0, 0);
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[WMT][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < WMT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     typedef typename Mma<T>::Frag Frag;
     const int fr = lane & 15, g = lane >> 4;
-    int aoff[4], boff[4];   // LDS byte offsets of this lane's rows; chunk swizzle folded in per kc below
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        aoff[t] = (wm * 64 + t * 16 + fr) * 128;
-        boff[t] = 16384 + (wn * 64 + t * 16 + fr) * 128;
-    }
-    const int sa = swz(fr);  // rows differ by multiples of 16 across t / wave halves: (row>>1)&7 == (fr>>1)&7
+    const int abase = (wm * WMT * 16 + fr) * 128, bbase = ABYTES + (wn * 64 + fr) * 128;
+    const int sa = swz(fr);  // every row this lane reads is fr + multiple of 16: (row>>1)&7 == (fr>>1)&7
 
     issue(0, 0);
     __syncthreads();
@@ -178,40 +183,43 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtParams p) {
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc) {
             const int co = (((kc * 4 + g) ^ sa) * 16);
-            Frag a[4], b[4];
+            Frag a[WMT], b[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                a[t] = *(const Frag*)(sb + aoff[t] + co);
-                b[t] = *(const Frag*)(sb + boff[t] + co);
-            }
+            for (int t = 0; t < 4; ++t) b[t] = *(const Frag*)(sb + bbase + t * 2048 + co);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int t = 0; t < WMT; ++t) a[t] = *(const Frag*)(sb + abase + t * 2048 + co);
+#pragma unroll
+            for (int i = 0; i < WMT; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(a[i], b[j], acc[i][j]);
         }
         __syncthreads();
     }
 
-    // ---- epilogue: two 64-row halves through LDS (fp32), then 8-column vectors per thread ----
+    // ---- epilogue: 64-row passes through LDS (fp32), then 8-column vectors per thread ----
     const int cdt = p.c_dtype;
     char* Cb = (char*)p.C + batch * p.sC * (long)gd_dtype_size(cdt);
     float* se = (float*)smem;  // [64][EPLD]
     const bool vec = p.vec_epilogue != 0;
-    for (int half = 0; half < 2; ++half) {
-        if (wm == half) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+    for (int ps = 0; ps < BM / 64; ++ps) {
+        constexpr int RPW = WMT * 16;                       // rows per wave
+        const int owner = (ps * 64) / RPW, i0 = ((ps * 64) % RPW) / 16;
+        if (wm == owner) {
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        se[(i * 16 + g * 4 + r) * EPLD + wn * 64 + j * 16 + fr] = acc[i][j][r];
+                        se[(ii * 16 + g * 4 + r) * EPLD + wn * 64 + j * 16 + fr] = acc[i0 + ii][j][r];
         }
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int lr = (tid >> 4) + 16 * q, cc = (tid & 15) * 8;
-            const int row = tm * BM + half * 64 + lr, col0 = tn * BN + cc;
+            const int item = tid + NT * q;
+            const int lr = item / (BN / 8), cc = (item % (BN / 8)) * 8;
+            const int row = tm * BM + ps * 64 + lr, col0 = tn * BN + cc;
             if (row >= p.M || col0 >= p.N) continue;
             float v[8];
             {
@@ -384,6 +392,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnParams p) {
 // ------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------
+static bool gd_force_small_tiles() {   // GD_GEMM_SMALL_TILES=1: A/B switch for benchmarking the tile configurations
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("GD_GEMM_SMALL_TILES"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+
 extern "C" int gd_gemm_nt(const void* A, const void* W, void* C, int M, int N, int K, long lda, long ldw, long ldc,
                           int batch, long sA, long sW, long sC, int ab_dtype, int c_dtype, float alpha,
                           const float* bias, const float* lora_t, const float* lora_b, int lora_rt, void* preact,
@@ -412,12 +426,17 @@ extern "C" int gd_gemm_nt(const void* A, const void* W, void* C, int M, int N, i
                      (bias == nullptr || ((uintptr_t)bias & 15) == 0) && (lora_b == nullptr || (((uintptr_t)lora_b & 15) == 0 && N % 4 == 0));
     dim3 grid(gd_cdiv(M, 128) * gd_cdiv(N, 128), batch);
     const bool dma = (K * es) % 128 == 0;
+    const bool big = dma && N >= 256 && M >= 1024 && !gd_force_small_tiles();
+    dim3 gridb(gd_cdiv(M, 256) * gd_cdiv(N, 256), batch);
+    hipStream_t st = (hipStream_t)stream;
     if (ab_dtype == GD_BF16) {
-        if (dma) hipLaunchKernelGGL(gemm_nt_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL(gemm_nt_regstage_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, p);
+        if (big) hipLaunchKernelGGL((gemm_nt_kernel<bf16, 2, 4, 8>), gridb, dim3(512), 0, st, p);
+        else if (dma) hipLaunchKernelGGL((gemm_nt_kernel<bf16, 2, 2, 4>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(gemm_nt_regstage_kernel<bf16>, grid, dim3(256), 0, st, p);
     } else {
-        if (dma) hipLaunchKernelGGL(gemm_nt_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL(gemm_nt_regstage_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, p);
+        if (big) hipLaunchKernelGGL((gemm_nt_kernel<float, 2, 4, 8>), gridb, dim3(512), 0, st, p);
+        else if (dma) hipLaunchKernelGGL((gemm_nt_kernel<float, 2, 2, 4>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(gemm_nt_regstage_kernel<float>, grid, dim3(256), 0, st, p);
     }
     GD_LAUNCH_OK();
     return 0;
