@@ -60,23 +60,23 @@ template <typename T> __device__ __forceinline__ typename Mma<T>::Frag load_nfra
 // Tile staging, split T14-style: `tile_load` issues the global loads of a 64 x 64-element tile into registers
 // (rows >= nvalid read as zero) and `tile_store` writes them to LDS later — as a natural tile sN[row][64]
 // and/or a transposed tile sT[col][row] — so the next tile's HBM/L2 latency hides under the current tile's MFMAs.
-template <typename T> struct TileRegs { uint4 v[AT<T>::CPR * 64 / 256]; };
+template <typename T, int NT = 256> struct TileRegs { uint4 v[AT<T>::CPR * 64 / NT]; };
 
-template <typename T>
-__device__ __forceinline__ void tile_load(TileRegs<T>& r, const char* gbase, long ld_b, int row0, int nvalid) {
-    constexpr int CPR = AT<T>::CPR, NCH = CPR * 64 / 256;
+template <typename T, int NT = 256>
+__device__ __forceinline__ void tile_load(TileRegs<T, NT>& r, const char* gbase, long ld_b, int row0, int nvalid) {
+    constexpr int CPR = AT<T>::CPR, NCH = CPR * 64 / NT;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-        const int ch = threadIdx.x + 256 * i, rr = ch / CPR, cc = ch % CPR;
+        const int ch = threadIdx.x + NT * i, rr = ch / CPR, cc = ch % CPR;
         r.v[i] = (row0 + rr < nvalid) ? *(const uint4*)(gbase + (long)(row0 + rr) * ld_b + cc * 16) : make_uint4(0, 0, 0, 0);
     }
 }
-template <typename T, bool NAT, bool TRN>
-__device__ __forceinline__ void tile_store(const TileRegs<T>& r, char* sN, char* sT) {
-    constexpr int CPR = AT<T>::CPR, EPC = AT<T>::EPC, ROWB = AT<T>::ROWB, NCH = CPR * 64 / 256;
+template <typename T, bool NAT, bool TRN, int NT = 256>
+__device__ __forceinline__ void tile_store(const TileRegs<T, NT>& r, char* sN, char* sT) {
+    constexpr int CPR = AT<T>::CPR, EPC = AT<T>::EPC, ROWB = AT<T>::ROWB, NCH = CPR * 64 / NT;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-        const int ch = threadIdx.x + 256 * i, rr = ch / CPR, cc = ch % CPR;
+        const int ch = threadIdx.x + NT * i, rr = ch / CPR, cc = ch % CPR;
         if (NAT) *(uint4*)(sN + rr * ROWB + cc * 16) = r.v[i];
         if (TRN) {
             const T* e = (const T*)&r.v[i];
@@ -360,8 +360,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* qkv, const T*
 }
 
 // ------------------------------------------------------------------------------------------ backward: dK, dV
-template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* qkv, const T* dout, const float* lse,
+template <typename T, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const T* qkv, const T* dout, const float* lse,
                                                            const float* delta, T* dqkv, int N, int H, float scale) {
     constexpr int NF = AT<T>::NF, ROWB = AT<T>::ROWB;
     typedef typename Mma<T>::Frag Frag;
@@ -371,7 +371,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* qkv, const T
     __shared__ __attribute__((aligned(16))) char sDt[TSZ(T)];
     __shared__ float sL[64], sDl[64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
-    const int b = blockIdx.z, h = blockIdx.y, key0 = blockIdx.x * 128 + wave * 32;
+    constexpr int NT = 64 * NW;
+    const int b = blockIdx.z, h = blockIdx.y, key0 = blockIdx.x * (32 * NW) + wave * 32;
     const long ld_b = (long)3 * H * HD * sizeof(T);
     const char* base = (const char*)qkv + (long)b * N * ld_b;
     const char* qb = base + (long)(0 * H + h) * HD * sizeof(T);
@@ -397,9 +398,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* qkv, const T
 #pragma unroll
         for (int j = 0; j < 2; ++j) { dk[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-    TileRegs<T> rq, rd;
-    tile_load<T>(rq, qb, ld_b, 0, N);
-    tile_load<T>(rd, dob, ldo_b, 0, N);
+    TileRegs<T, NT> rq, rd;
+    tile_load<T, NT>(rq, qb, ld_b, 0, N);
+    tile_load<T, NT>(rd, dob, ldo_b, 0, N);
     float rl = 0.f, rdl = 0.f;   // next tile's lse / delta rows, prefetched with the tile
     if (threadIdx.x < 64 && threadIdx.x < N) {
         rl = lse[((long)b * H + h) * N + threadIdx.x];
@@ -407,11 +408,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* qkv, const T
     }
     for (int q0 = 0; q0 < N; q0 += 64) {
         __syncthreads();
-        tile_store<T, true, TOp<T>::kNeedT>(rq, sQ, sQt);
-        tile_store<T, true, TOp<T>::kNeedT>(rd, sD, sDt);
+        tile_store<T, true, TOp<T>::kNeedT, NT>(rq, sQ, sQt);
+        tile_store<T, true, TOp<T>::kNeedT, NT>(rd, sD, sDt);
         if (q0 + 64 < N) {
-            tile_load<T>(rq, qb, ld_b, q0 + 64, N);
-            tile_load<T>(rd, dob, ldo_b, q0 + 64, N);
+            tile_load<T, NT>(rq, qb, ld_b, q0 + 64, N);
+            tile_load<T, NT>(rd, dob, ldo_b, q0 + 64, N);
         }
         if (threadIdx.x < 64) { sL[threadIdx.x] = rl; sDl[threadIdx.x] = rdl; }
         if (q0 + 64 < N && threadIdx.x < 64) {
@@ -507,11 +508,11 @@ extern "C" int gd_attention_bwd(const void* qkv, const void* o, const void* dout
     if (dtype == GD_BF16) {
         hipLaunchKernelGGL(attn_delta_kernel<bf16>, dim3(gd_cdiv(total * 16, 256)), dim3(256), 0, s, (const bf16*)o, (const bf16*)dout, delta_ws, N, H, total);
         hipLaunchKernelGGL(attn_bwd_dq_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)qkv, (const bf16*)dout, lse, delta_ws, (bf16*)dqkv, N, H, scale);
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)qkv, (const bf16*)dout, lse, delta_ws, (bf16*)dqkv, N, H, scale);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<bf16, 8>), dim3(gd_cdiv(N, 256), H, B), dim3(512), 0, s, (const bf16*)qkv, (const bf16*)dout, lse, delta_ws, (bf16*)dqkv, N, H, scale);
     } else {
         hipLaunchKernelGGL(attn_delta_kernel<float>, dim3(gd_cdiv(total * 16, 256)), dim3(256), 0, s, (const float*)o, (const float*)dout, delta_ws, N, H, total);
         hipLaunchKernelGGL(attn_bwd_dq_kernel<float>, grid, dim3(256), 0, s, (const float*)qkv, (const float*)dout, lse, delta_ws, (float*)dqkv, N, H, scale);
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<float>, grid, dim3(256), 0, s, (const float*)qkv, (const float*)dout, lse, delta_ws, (float*)dqkv, N, H, scale);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<float, 8>), dim3(gd_cdiv(N, 256), H, B), dim3(512), 0, s, (const float*)qkv, (const float*)dout, lse, delta_ws, (float*)dqkv, N, H, scale);
     }
     GD_LAUNCH_OK();
     return 0;

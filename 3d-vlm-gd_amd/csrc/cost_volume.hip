@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void cv_norm_bwd_kernel(const T* f1, const T* 
 // ------------------------------------------------------------------------------------------
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline int cv_tiles(int hw) { return (hw + 127) / 128; }
-static inline int cv_hwp(int hw) { return (hw + 7) & ~7; }
+static inline int cv_hwp(int hw) { return (hw + 63) & ~63; }   // K of the two backward GEMMs: multiple of 128 bytes (LDS-DMA path)
 
 extern "C" size_t gd_cost_volume_kl_workspace_bytes(int P, int hw, int C, int dtype, int backward) {
     const size_t es = (size_t)gd_dtype_size(dtype);

@@ -390,6 +390,89 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// gemm_tn for bf16 operands on the bf16 MFMA: G[N,K] += alpha * Y[M,N]^T X[M,K].  Both MFMA operands contract over
+// the tile ROW index (m), i.e. both are "transposed" reads of row-major tiles: served by ds_read_b64_tr_b16 from
+// natural LDS tiles Y[m][n], X[m][k] (same k-slot permutation on both sides).  128 x 128 output tile, 4 waves 2x2,
+// 64-row m stages, register-prefetched; M split across blockIdx.y with fp32 atomics.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int rowb, int col0, int u, int lane) {
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
+    const char* a0 = tile + (32 * u + 4 * g + q) * rowb + (col0 + 4 * pp) * 2;
+    const s16x4 x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
+    const s16x4 y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 16 * rowb));
+    const s16x8 z = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+    return __builtin_bit_cast(bf16x8, z);
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmTnParams p) {
+    constexpr int ROWB = 272;   // 128 bf16 + 16 B pad
+    __shared__ __attribute__((aligned(16))) char sY[64 * ROWB];
+    __shared__ __attribute__((aligned(16))) char sX[64 * ROWB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wy = wave >> 1, wx = wave & 1;
+    const int tiles_k = (p.K + 127) / 128;
+    const int tn = blockIdx.x / tiles_k, tk = blockIdx.x % tiles_k;
+    const int m_begin = blockIdx.y * p.mchunk, m_end = min(p.M, m_begin + p.mchunk);
+    const bf16* Y = (const bf16*)p.Y + (long)blockIdx.z * p.sY;
+    const bf16* X = (const bf16*)p.X + (long)blockIdx.z * p.sX;
+    float* G = p.G + (long)blockIdx.z * p.sG;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    uint4 ry[4], rx[4];   // 64 rows x 16 chunks (of 8 bf16) = 1024 chunks / 256 threads per operand
+    auto gload = [&](int m0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ch = tid + 256 * i, rr = ch >> 4, cc = (ch & 15) * 8;
+            const int m = m0 + rr, yn = tn * 128 + cc, xk = tk * 128 + cc;
+            ry[i] = (m < m_end && yn < p.N) ? *(const uint4*)(Y + (long)m * p.ldy + yn) : make_uint4(0, 0, 0, 0);
+            rx[i] = (m < m_end && xk < p.K) ? *(const uint4*)(X + (long)m * p.ldx + xk) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    gload(m_begin);
+    for (int m0 = m_begin; m0 < m_end; m0 += 64) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ch = tid + 256 * i, rr = ch >> 4, cc = ch & 15;
+            *(uint4*)(sY + rr * ROWB + cc * 16) = ry[i];
+            *(uint4*)(sX + rr * ROWB + cc * 16) = rx[i];
+        }
+        __syncthreads();
+        if (m0 + 64 < m_end) gload(m0 + 64);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            bf16x8 a[4], b[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                a[t] = tr_frag(sY, ROWB, wy * 64 + t * 16, u, lane);
+                b[t] = tr_frag(sX, ROWB, wx * 64 + t * 16, u, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = tn * 128 + wy * 64 + i * 16 + (lane >> 4) * 4 + r;
+                const int k = tk * 128 + wx * 64 + j * 16 + (lane & 15);
+                if (n < p.N && k < p.K) atomicAdd(G + (long)n * p.ldg + k, p.alpha * acc[i][j][r]);
+            }
+}
+
+// ------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------
 static bool gd_force_small_tiles() {   // GD_GEMM_SMALL_TILES=1: A/B switch for benchmarking the tile configurations
@@ -452,14 +535,17 @@ extern "C" int gd_gemm_tn(const void* Y, const void* X, float* G, int M, int N, 
     p.Y = Y; p.X = X; p.G = G; p.M = M; p.N = N; p.K = K; p.ldy = ldy; p.ldx = ldx; p.ldg = ldg;
     p.y_dtype = y_dtype; p.x_dtype = x_dtype; p.alpha = alpha; p.sY = sY; p.sX = sX; p.sG = sG;
     GD_REQUIRE(batch >= 1 && sY % 8 == 0 && sX % 8 == 0, "gd_gemm_tn: bad batch / batch strides");
-    const int tiles = gd_cdiv(N, 64) * gd_cdiv(K, 64);
-    // enough M-chunks to fill the chip (>= ~2048 blocks) without shredding the reduction
-    int splits = (2048 + tiles * batch - 1) / (tiles * batch);
-    int mchunk = ((gd_cdiv(M, splits) + 31) / 32) * 32;
+    const bool bf = y_dtype == GD_BF16 && x_dtype == GD_BF16 && N >= 64 && K >= 64;   // bf16 MFMA + transpose reads
+    const int tl = bf ? 128 : 64;
+    const int tiles = gd_cdiv(N, tl) * gd_cdiv(K, tl);
+    // enough M-chunks to fill the chip without shredding the reduction
+    int splits = ((bf ? 1024 : 2048) + tiles * batch - 1) / (tiles * batch);
+    int mchunk = ((gd_cdiv(M, splits) + 63) / 64) * 64;
     if (mchunk < 256) mchunk = 256;
     p.mchunk = mchunk;
     dim3 grid(tiles, gd_cdiv(M, mchunk), batch);
-    hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    if (bf) hipLaunchKernelGGL(gemm_tn_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
     GD_LAUNCH_OK();
     return 0;
 }

@@ -176,15 +176,16 @@ class _BlockFn(torch.autograd.Function):
         dx1 = ops.layernorm_bwd(dy2, x1, plan["ln2_w"], mean2, rstd2, dres=dx2)
         do = ops.gemm_nt(dx1, plan["wproj_t"])
         dqkv = ops.attention_bwd(qkv, o, do, lse, B, Nt, H)
-        dy1 = ops.gemm_nt(dqkv, plan["wqkv_t"])
         if ctx.has_lora:
             r = at.shape[0] // 2
             dt = ops.gemm_nt(dqkv, bt.to(T).contiguous(), out_dtype=torch.float32)                 # [M, 2r]
             gbt = ops.gemm_tn(t, dqkv)                                                            # [2r, 3D]
             gat = ops.gemm_tn(dt, y1)                                                             # [2r, D]
-            ops.gemm_nt(dt, at.t().contiguous(), out=dy1, accumulate=True)                        # += dt . At
+            dy1 = ops.gemm_nt(dqkv, plan["wqkv_t"], lora_t=dt, lora_b=at.contiguous())            # dqkv.W + dt.At
             g_bq, g_bv = gbt[:r, :D].t().contiguous(), gbt[r:, 2 * D:].t().contiguous()
             g_aq, g_av = gat[:r].contiguous(), gat[r:].contiguous()
+        else:
+            dy1 = ops.gemm_nt(dqkv, plan["wqkv_t"])
         dx = ops.layernorm_bwd(dy1, x, plan["ln1_w"], mean1, rstd1, dres=dx1)
         return dx, None, None, None, g_aq, g_bq, g_av, g_bv, g_down, g_up
 
