@@ -27,7 +27,10 @@ extern "C" int gd_gemm_nt(const void* A, const void* W, void* C, int M, int N, i
 
 #define CV_EPS 1e-8f
 
+
 // stats layout: [P][2][hw][4] = {inv_norm, teacher_rowsum(clamped), logZ, W}
+// one wave per (pair, view, row): 16-byte feature loads; teacher row (4-byte aligned only: hw is odd) read as a
+// scalar head + aligned float4 body + scalar tail.
 __global__ __launch_bounds__(256) void cv_prep_kernel(const void* f1, const void* f2, const float* t1,
                                                       const float* t2, float* stats, int hw, int C, int dtype) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -37,12 +40,31 @@ __global__ __launch_bounds__(256) void cv_prep_kernel(const void* f1, const void
     const float* t = (which ? t2 : t1) + ((long)p * hw + row) * hw;
     const long fo = ((long)p * hw + row) * C;
     float ss = 0.f;
-    for (int c = lane; c < C; c += 64) {
-        const float v = ld_rt(f, fo + c, dtype);
-        ss += v * v;
+    if (dtype == GD_BF16) {
+        const bf16x8* fv = (const bf16x8*)((const bf16*)f + fo);
+        for (int c = lane; c < C / 8; c += 64) {
+            const bf16x8 v = fv[c];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) ss += (float)v[k] * (float)v[k];
+        }
+    } else {
+        const f32x4* fv = (const f32x4*)((const float*)f + fo);
+        for (int c = lane; c < C / 4; c += 64) {
+            const f32x4 v = fv[c];
+            ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        }
     }
+    const int head = (4 - (int)(((uintptr_t)t >> 2) & 3)) & 3;   // floats until 16-byte alignment
     float rs = 0.f;
-    for (int j = lane; j < hw; j += 64) rs += t[j];
+    if (lane < head && lane < hw) rs += t[lane];
+    const int nvec = hw > head ? (hw - head) >> 2 : 0;
+    const f32x4* tv = (const f32x4*)(t + head);
+    for (int j = lane; j < nvec; j += 64) {
+        const f32x4 v = tv[j];
+        rs += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    const int tail0 = head + nvec * 4;
+    if (tail0 + lane < hw) rs += t[tail0 + lane];
     ss = wave_sum(ss);
     rs = wave_sum(rs);
     if (lane == 0) {
@@ -61,128 +83,160 @@ struct CvTileParams {
     void* G1; void* G2; int hwp;
 };
 
+// S tile (cosine similarities, fp32) parked in LDS so that BOTH teacher sweeps read global memory row-contiguously:
+// element (i, j) of a [rows][ncol] tile lives at i*ncol + (j ^ (i & 31)) — row reads and column reads are both
+// bank-conflict-free.
+#define CV_RING 65536
+__device__ __forceinline__ int sidx(int i, int j, int ncol) { return i * ncol + (j ^ (i & 31)); }
+
+// Per-tile row / column statistics staged in LDS once (4 floats each): {inv_norm, 1/teacher_rowsum, logZ, W or -1 when
+// the row is masked out (or out of range)}.  sSt[0..127] = tile rows (view 1), sSt[128..255] = tile columns (view 2).
+__device__ __forceinline__ void cv_stage_stats(const CvTileParams& q, int p, int tm, int tn, f32x4* sSt) {
+    const int t = threadIdx.x, hw = q.hw;
+    const int which = t >> 7, idx = (which ? tn : tm) * 128 + (t & 127);
+    f32x4 o = {0.f, 0.f, 0.f, -1.f};
+    if (idx < hw) {
+        const f32x4 v = *(const f32x4*)(q.stats + (((long)p * 2 + which) * hw + idx) * 4);
+        const unsigned char* m = which ? q.m2 : q.m1;
+        const bool keep = m == nullptr || m[(long)p * hw + idx] != 0;
+        o = f32x4{v[0], 1.0f / v[1], v[2], keep ? v[3] : -1.f};
+    }
+    sSt[t] = o;
+}
+
 template <typename T>
-__global__ __launch_bounds__(256) void cv_fwd_tile_kernel(CvTileParams q) {
-    __shared__ __attribute__((aligned(16))) char smem[GD_TILE_SMEM];
+__device__ __forceinline__ void cv_s_tile(const CvTileParams& q, int p, int tm, int tn, char* smem, const f32x4* sSt,
+                                          f32x4 (&acc)[4][4]) {
+    const int hw = q.hw;
+    const long rowb = (long)q.C * sizeof(T);
+    const char* Ab = (const char*)q.f1 + (long)p * hw * rowb;
+    const char* Wb = (const char*)q.f2 + (long)p * hw * rowb;
+    if (rowb % 128 == 0) dma_mainloop<T, 2, 2, 4>(Ab, rowb, hw, Wb, rowb, hw, (int)(rowb / 128), tm, tn, smem, acc);
+    else mma_tile_128x128<T>(Ab, rowb, hw, Wb, rowb, hw, (int)rowb, tm, tn, smem, acc);
+    // scale to cosine similarity: s = acc * inv1[i] * inv2[j]   (stats were staged before the main loop's barriers)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1, g = lane >> 4, c = lane & 15;
+    float inv2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) inv2[j] = sSt[128 + wn * 64 + j * 16 + c][0];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float inv1 = sSt[wm * 64 + i * 16 + g * 4 + r][0];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j][r] *= inv1 * inv2[j];
+        }
+}
+
+// Teacher tiles are PRELOADED into registers before the MFMA main loop (128 independent 4-byte loads per lane,
+// in flight under the contraction), because the sweeps below are otherwise one exposed HBM latency per row.
+// Sweep shape: a wave instruction covers 4 tile rows x 16 columns (64-byte row segments); each lane accumulates
+// its 8 column groups locally, so a row statistic costs a 4-step reduction inside 16 lanes.
+template <typename T>
+__global__ __launch_bounds__(256, 2) void cv_fwd_tile_kernel(CvTileParams q) {
+    __shared__ __attribute__((aligned(16))) char smem[CV_RING + 4096];   // ONE LDS object: ring | tile statistics
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, g = lane >> 4, c = lane & 15;
     const int p = blockIdx.y, hw = q.hw;
     const int wg = xcd_remap(blockIdx.x, q.tiles * q.tiles);
     const int tm = wg / q.tiles, tn = wg % q.tiles;
-    const long rowb = (long)q.C * sizeof(T);
-    const char* Ab = (const char*)q.f1 + (long)p * hw * rowb;
-    const char* Wb = (const char*)q.f2 + (long)p * hw * rowb;
-    f32x4 acc[4][4];
-    mma_tile_128x128<T>(Ab, rowb, hw, Wb, rowb, hw, (int)rowb, tm, tn, smem, acc);
-
-    const float* st1 = q.stats + ((long)p * 2 + 0) * hw * 4;
-    const float* st2 = q.stats + ((long)p * 2 + 1) * hw * 4;
-    // scale to cosine similarity: s = acc * inv1[i] * inv2[j]
-    float inv2[4], r2[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int col = tn * 128 + wn * 64 + j * 16 + c;
-        inv2[j] = col < hw ? st2[col * 4 + 0] : 0.f;
-        r2[j] = col < hw ? st2[col * 4 + 1] : 1.f;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = tm * 128 + wm * 64 + i * 16 + g * 4 + r;
-            const float inv1 = row < hw ? st1[row * 4 + 0] : 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j][r] *= inv1 * inv2[j];
-        }
-
-    // ---- direction 1: per-row partial sums over this wave's 64 columns ----
     const float* T1 = q.t1 + (long)p * hw * hw;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = tm * 128 + wm * 64 + i * 16 + g * 4 + r;
-            const bool rok = row < hw;
-            const float ir1 = rok ? 1.0f / st1[row * 4 + 1] : 0.f;
-            float Z = 0.f, Wt = 0.f, A = 0.f, B = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int col = tn * 128 + wn * 64 + j * 16 + c;
-                if (rok && col < hw) {
-                    const float s = acc[i][j][r];
-                    const float t = fmaxf(T1[(long)row * hw + col] * ir1, CV_EPS);
-                    Z += __expf(s);
-                    Wt += t;
-                    A += t * __logf(t);
-                    B += t * s;
-                }
-            }
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-                Z += __shfl_xor(Z, o, 64);
-                Wt += __shfl_xor(Wt, o, 64);
-                A += __shfl_xor(A, o, 64);
-                B += __shfl_xor(B, o, 64);
-            }
-            if (c == 0 && rok)
-                *(f32x4*)(q.part1 + (((long)p * q.nslab + tn * 2 + wn) * hw + row) * 4) = f32x4{Z, Wt, A, B};
-        }
-
-    // ---- direction 2: per-column partial sums over this wave's 64 rows; teacher T2[j, i] is staged
-    //      through LDS (coalesced along i) in two halves of 64 j-rows ----
     const float* T2 = q.t2 + (long)p * hw * hw;
-    float* sT = (float*)smem;  // [64][129]
-    for (int h = 0; h < 2; ++h) {
-        for (int qq = 0; qq < 32; ++qq) {
-            const int idx = tid + 256 * qq, jj = idx >> 7, ii = idx & 127;
-            const int j = tn * 128 + h * 64 + jj, i = tm * 128 + ii;
-            sT[jj * 129 + ii] = (j < hw && i < hw) ? T2[(long)j * hw + i] : 0.f;
+    f32x4* sSt = (f32x4*)(smem + CV_RING);
+    cv_stage_stats(q, p, tm, tn, sSt);
+    // direction-1 teacher tile: in flight under the main loop.  (Both tiles at once would cost 128 VGPRs and halve
+    // the occupancy; with one block per CU every K-step of the 2-deep DMA ring exposes a full memory latency.)
+    float t1v[8][8], t2v[8][8];   // [4-row step][16-column group]
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+        const int row = tm * 128 + wave * 32 + st * 4 + g;     // dir 1: teacher row = tile row
+#pragma unroll
+        for (int cg = 0; cg < 8; ++cg) {
+            const int col = tn * 128 + cg * 16 + c;
+            t1v[st][cg] = (row < hw && col < hw) ? T1[(long)row * hw + col] : 0.f;
         }
-        __syncthreads();
-        if (wn == h) {
+    }
+    {
+        f32x4 acc[4][4];
+        cv_s_tile<T>(q, p, tm, tn, smem, sSt, acc);
+        float* sS_ = (float*)smem;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int col = tn * 128 + wn * 64 + j * 16 + c;
-                const bool cok = col < hw;
-                const float ir2 = 1.0f / r2[j];
-                float Z = 0.f, Wt = 0.f, A = 0.f, B = 0.f;
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int lr = wm * 64 + i * 16 + g * 4 + r;
-                        if (cok && tm * 128 + lr < hw) {
-                            const float s = acc[i][j][r];
-                            const float t = fmaxf(sT[(j * 16 + c) * 129 + lr] * ir2, CV_EPS);
-                            Z += __expf(s);
-                            Wt += t;
-                            A += t * __logf(t);
-                            B += t * s;
-                        }
-                    }
+                for (int r = 0; r < 4; ++r)
+                    sS_[sidx(wm * 64 + i * 16 + g * 4 + r, wn * 64 + j * 16 + c, 128)] = acc[i][j][r];
+    }
+    float* sS = (float*)smem;   // [128][128] swizzled
+    // direction-2 teacher tile: issued now, lands under the direction-1 sweep
 #pragma unroll
-                for (int o = 16; o < 64; o <<= 1) {
-                    Z += __shfl_xor(Z, o, 64);
-                    Wt += __shfl_xor(Wt, o, 64);
-                    A += __shfl_xor(A, o, 64);
-                    B += __shfl_xor(B, o, 64);
-                }
-                if (g == 0 && cok)
-                    *(f32x4*)(q.part2 + (((long)p * q.nslab + tm * 2 + wm) * hw + col) * 4) = f32x4{Z, Wt, A, B};
+    for (int st = 0; st < 8; ++st) {
+        const int trow = tn * 128 + wave * 32 + st * 4 + g;    // dir 2: teacher row = tile column
+#pragma unroll
+        for (int cg = 0; cg < 8; ++cg) {
+            const int ti = tm * 128 + cg * 16 + c;
+            t2v[st][cg] = (trow < hw && ti < hw) ? T2[(long)trow * hw + ti] : 0.f;
+        }
+    }
+    __syncthreads();
+
+    // ---- direction 1: rows of S against teacher rows T1[i, :] ----
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+        const int rl = wave * 32 + st * 4 + g, row = tm * 128 + rl;
+        const bool rok = row < hw;
+        const float ir1 = sSt[rl][1];
+        float Z = 0.f, Wt = 0.f, A = 0.f, B = 0.f;
+#pragma unroll
+        for (int cg = 0; cg < 8; ++cg) {
+            const int cl = cg * 16 + c;
+            if (rok && tn * 128 + cl < hw) {
+                const float s = sS[sidx(rl, cl, 128)];
+                const float t = fmaxf(t1v[st][cg] * ir1, CV_EPS);
+                Z += __expf(s); Wt += t; A += t * __logf(t); B += t * s;
             }
         }
-        __syncthreads();
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            Z += __shfl_xor(Z, o, 64); Wt += __shfl_xor(Wt, o, 64); A += __shfl_xor(A, o, 64); B += __shfl_xor(B, o, 64);
+        }
+        if (c == 0 && rok) *(f32x4*)(q.part1 + (((long)p * q.nslab + tn) * hw + row) * 4) = f32x4{Z, Wt, A, B};
+    }
+    // ---- direction 2: columns of S against teacher rows T2[j, :] ----
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+        const int jl = wave * 32 + st * 4 + g, col = tn * 128 + jl;
+        const bool cok = col < hw;
+        const float ir2 = sSt[128 + jl][1];
+        float Z = 0.f, Wt = 0.f, A = 0.f, B = 0.f;
+#pragma unroll
+        for (int ig = 0; ig < 8; ++ig) {
+            const int il = ig * 16 + c;
+            if (cok && tm * 128 + il < hw) {
+                const float s = sS[sidx(il, jl, 128)];
+                const float t = fmaxf(t2v[st][ig] * ir2, CV_EPS);
+                Z += __expf(s); Wt += t; A += t * __logf(t); B += t * s;
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            Z += __shfl_xor(Z, o, 64); Wt += __shfl_xor(Wt, o, 64); A += __shfl_xor(A, o, 64); B += __shfl_xor(B, o, 64);
+        }
+        if (c == 0 && cok) *(f32x4*)(q.part2 + (((long)p * q.nslab + tm) * hw + col) * 4) = f32x4{Z, Wt, A, B};
     }
 }
 
-// one block per pair: reduce the slabs, emit loss[p], save logZ and W for the backward
+// reduce the slabs, save logZ and W for the backward, emit per-chunk partial losses (CV_FCH chunks per pair), then sum
+#define CV_FCH 8
 __global__ __launch_bounds__(256) void cv_finalize_kernel(const float* part1, const float* part2,
                                                           const unsigned char* m1, const unsigned char* m2,
-                                                          float* stats, float* loss, int hw, int nslab, int variant) {
-    const int p = blockIdx.x, tid = threadIdx.x;
+                                                          float* stats, double* chunk_loss, int hw, int nslab, int variant) {
+    const int p = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
     const float masked_const = variant == 1 ? (float)hw * (CV_EPS * logf(CV_EPS * (float)hw)) : 0.f;
     double total = 0.0;
-    for (int idx = tid; idx < 2 * hw; idx += 256) {
+    const int per = (2 * hw + CV_FCH - 1) / CV_FCH;
+    for (int idx = ch * per + tid; idx < min(2 * hw, (ch + 1) * per); idx += 256) {
         const int d = idx >= hw, row = d ? idx - hw : idx;
         const float* part = d ? part2 : part1;
         float Z = 0.f, Wt = 0.f, A = 0.f, B = 0.f;
@@ -204,106 +258,100 @@ __global__ __launch_bounds__(256) void cv_finalize_kernel(const float* part1, co
         if (tid < o) red[tid] += red[tid + o];
         __syncthreads();
     }
-    if (tid == 0) loss[p] = (float)(0.5 * red[0] / (double)hw);
+    if (tid == 0) chunk_loss[p * CV_FCH + ch] = red[0];
+}
+__global__ void cv_loss_kernel(const double* chunk_loss, float* loss, int P, int hw) {
+    const int p = blockIdx.x * 64 + threadIdx.x;
+    if (p >= P) return;
+    double s = 0.0;
+    for (int c = 0; c < CV_FCH; ++c) s += chunk_loss[p * CV_FCH + c];   // fixed order: deterministic
+    loss[p] = (float)(0.5 * s / (double)hw);
 }
 
-// ---- backward: G = dloss/dS per tile, written as G1[i][j] = G*inv2[j] and G2[j][i] = G*inv1[i] ----
+// ---- backward: G = dloss/dS per tile, written as G1[i][j] = G*inv2[j] and G2[j][i] = G*inv1[i] (both row-contiguous
+//      stores).  Teacher tiles are preloaded into registers before the main loop; the tile is processed in two
+//      64-column halves with s and the accumulating G in LDS (2 x 32 KB), per-row/column statistics in LDS. ----
 template <typename T>
-__global__ __launch_bounds__(256) void cv_bwd_tile_kernel(CvTileParams q) {
-    __shared__ __attribute__((aligned(16))) char smem[GD_TILE_SMEM];
+__global__ __launch_bounds__(256, 2) void cv_bwd_tile_kernel(CvTileParams q) {
+    __shared__ __attribute__((aligned(16))) char smem[CV_RING + 4096];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, g = lane >> 4, c = lane & 15;
     const int p = blockIdx.y, hw = q.hw, hwp = q.hwp;
     const int wg = xcd_remap(blockIdx.x, q.tiles * q.tiles);
     const int tm = wg / q.tiles, tn = wg % q.tiles;
-    const long rowb = (long)q.C * sizeof(T);
-    const char* Ab = (const char*)q.f1 + (long)p * hw * rowb;
-    const char* Wb = (const char*)q.f2 + (long)p * hw * rowb;
-    f32x4 acc[4][4];
-    mma_tile_128x128<T>(Ab, rowb, hw, Wb, rowb, hw, (int)rowb, tm, tn, smem, acc);
-
-    const float* st1 = q.stats + ((long)p * 2 + 0) * hw * 4;
-    const float* st2 = q.stats + ((long)p * 2 + 1) * hw * 4;
     const float* T1 = q.t1 + (long)p * hw * hw;
     const float* T2 = q.t2 + (long)p * hw * hw;
-    const unsigned char* M1 = q.m1 + (long)p * hw;
-    const unsigned char* M2 = q.m2 + (long)p * hw;
+    f32x4* sSt = (f32x4*)(smem + CV_RING);
+    cv_stage_stats(q, p, tm, tn, sSt);
+    float t1v[2][32];   // pass-A teacher values of both halves: in flight under the main loop
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {   // pass A: tile row wave+4k, column = 64h + lane
+            const int row = tm * 128 + wave + 4 * k, col = tn * 128 + 64 * h + lane;
+            t1v[h][k] = (row < hw && col < hw) ? T1[(long)row * hw + col] : 0.f;
+        }
+    f32x4 acc[4][4];
+    cv_s_tile<T>(q, p, tm, tn, smem, sSt, acc);
+    float* sS = (float*)smem;            // [128][64]
+    float* sG = (float*)smem + 128 * 64; // [128][64]
     const float coef = q.gloss[p] * 0.5f / (float)hw;
     T* G1 = (T*)q.G1 + (long)p * hw * hwp;
     T* G2 = (T*)q.G2 + (long)p * hw * hwp;
-    float* sT = (float*)smem;
 
-    f32x4 cs2[4];  // per column: inv2, 1/r2, logZ2, W2*keep2
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int col = tn * 128 + wn * 64 + j * 16 + c;
-        if (col < hw) {
-            const f32x4 v = *(const f32x4*)(st2 + col * 4);
-            cs2[j] = f32x4{v[0], 1.0f / v[1], v[2], M2[col] ? v[3] : -1.f};
-        } else {
-            cs2[j] = f32x4{0.f, 0.f, 0.f, -1.f};
-        }
-    }
-    // pass A: direction-1 part of G (registers), scaled s kept in acc
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = tm * 128 + wm * 64 + i * 16 + g * 4 + r;
-            const bool rok = row < hw;
-            f32x4 v = rok ? *(const f32x4*)(st1 + row * 4) : f32x4{0.f, 1.f, 0.f, 0.f};
-            const bool keep1 = rok && M1[row];
-            const float ir1 = 1.0f / v[1];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int col = tn * 128 + wn * 64 + j * 16 + c;
-                const float s = acc[i][j][r] * v[0] * cs2[j][0];
-                float gg = 0.f;
-                if (rok && col < hw) {
-                    if (keep1) {
-                        const float t = fmaxf(T1[(long)row * hw + col] * ir1, CV_EPS);
-                        gg += v[3] * __expf(s - v[2]) - t;
-                    }
-                    if (cs2[j][3] >= 0.f) gg += cs2[j][3] * __expf(s - cs2[j][2]);
-                }
-                acc[i][j][r] = gg;  // the dir-2 teacher term is subtracted in pass B
-            }
-        }
-    // pass B: subtract t2 (staged through LDS), then store
     for (int h = 0; h < 2; ++h) {
-        for (int qq = 0; qq < 32; ++qq) {
-            const int idx = tid + 256 * qq, jj = idx >> 7, ii = idx & 127;
-            const int j = tn * 128 + h * 64 + jj, i = tm * 128 + ii;
-            sT[jj * 129 + ii] = (j < hw && i < hw) ? T2[(long)j * hw + i] : 0.f;
-        }
-        __syncthreads();
         if (wn == h) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int col = tn * 128 + wn * 64 + j * 16 + c;
-                const bool keep2 = cs2[j][3] >= 0.f;
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int row0 = tm * 128 + wm * 64 + i * 16 + g * 4;
-                    float o1[4], o2[4];
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = row0 + r;
-                        float gg = acc[i][j][r];
-                        if (keep2 && row < hw && col < hw)
-                            gg -= fmaxf(sT[(j * 16 + c) * 129 + (row - tm * 128)] * cs2[j][1], CV_EPS);
-                        gg = (row < hw && col < hw) ? gg * coef : 0.f;
-                        o1[r] = gg * cs2[j][0];
-                        o2[r] = gg * (row < hw ? st1[row * 4] : 0.f);
-                        if (row < hw && col < hwp) G1[(long)row * hwp + col] = from_f32<T>(o1[r]);
-                    }
-                    if (col < hw) {
+                    for (int r = 0; r < 4; ++r) sS[sidx(wm * 64 + i * 16 + g * 4 + r, j * 16 + c, 64)] = acc[i][j][r];
+        }
+        const int col0 = tn * 128 + 64 * h;
+        float t2v[16][2];   // pass-B teacher values of this half: issued here, land under pass A
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (row0 + r < hwp) G2[(long)col * hwp + row0 + r] = from_f32<T>(o2[r]);
-                    }
-                }
+        for (int k = 0; k < 16; ++k)     // teacher row (tile column) 64h + wave+4k, tile rows lane, lane+64
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int col = col0 + wave + 4 * k, row = tm * 128 + lane + 64 * e;
+                t2v[k][e] = (row < hw && col < hw) ? T2[(long)col * hw + row] : 0.f;
             }
+        __syncthreads();
+        // pass A: direction-1 term (lane = column)
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            const int rr = wave + 4 * k;
+            const f32x4 v = sSt[rr];
+            float term = 0.f;
+            if (v[3] >= 0.f && col0 + lane < hw)
+                term = v[3] * __expf(sS[sidx(rr, lane, 64)] - v[2]) - fmaxf(t1v[h][k] * v[1], CV_EPS);
+            sG[sidx(rr, lane, 64)] = term;
+        }
+        __syncthreads();
+        // pass B: direction-2 term (lane = tile row), then G2 rows
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int jl = wave + 4 * k, col = col0 + jl;
+            const bool cok = col < hw;
+            const f32x4 v = sSt[128 + 64 * h + jl];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int il = lane + 64 * e, row = tm * 128 + il;
+                float gg = sG[sidx(il, jl, 64)];
+                if (v[3] >= 0.f && row < hw)
+                    gg += v[3] * __expf(sS[sidx(il, jl, 64)] - v[2]) - fmaxf(t2v[k][e] * v[1], CV_EPS);
+                gg = (cok && row < hw) ? gg * coef : 0.f;
+                sG[sidx(il, jl, 64)] = gg;
+                if (cok && row < hwp) G2[(long)col * hwp + row] = from_f32<T>(gg * sSt[il][0]);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            const int rr = wave + 4 * k, row = tm * 128 + rr, col = col0 + lane;
+            if (row < hw && col < hwp) G1[(long)row * hwp + col] = from_f32<T>(sG[sidx(rr, lane, 64)] * sSt[128 + 64 * h + lane][0]);
         }
         __syncthreads();
     }
@@ -356,7 +404,7 @@ static inline int cv_hwp(int hw) { return (hw + 63) & ~63; }   // K of the two b
 
 extern "C" size_t gd_cost_volume_kl_workspace_bytes(int P, int hw, int C, int dtype, int backward) {
     const size_t es = (size_t)gd_dtype_size(dtype);
-    if (!backward) return 2 * align256((size_t)P * 2 * cv_tiles(hw) * hw * 4 * sizeof(float));
+    if (!backward) return 2 * align256((size_t)P * 2 * cv_tiles(hw) * hw * 4 * sizeof(float)) + align256((size_t)P * CV_FCH * sizeof(double));
     const size_t hwp = (size_t)cv_hwp(hw);
     return 2 * align256((size_t)P * hw * hwp * es) + 2 * align256((size_t)P * C * hwp * es) +
            2 * align256((size_t)P * hw * C * sizeof(float));
@@ -375,9 +423,10 @@ extern "C" int gd_cost_volume_kl_fwd(const void* f1, const void* f2, const float
                    ((uintptr_t)workspace & 15) == 0,
                "gd_cost_volume_kl_fwd: f1, f2, stats, workspace must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    const int tiles = cv_tiles(hw), nslab = 2 * tiles;
+    const int tiles = cv_tiles(hw), nslab = tiles;
     float* part1 = (float*)workspace;
     float* part2 = (float*)((char*)workspace + align256((size_t)P * nslab * hw * 4 * sizeof(float)));
+    double* chunk_loss = (double*)((char*)workspace + 2 * align256((size_t)P * 2 * tiles * hw * 4 * sizeof(float)));
     hipLaunchKernelGGL(cv_prep_kernel, dim3(gd_cdiv(hw, 4), 2, P), dim3(256), 0, s, f1, f2, t1, t2, stats, hw, C,
                        dtype);
     GD_LAUNCH_OK();
@@ -389,8 +438,9 @@ extern "C" int gd_cost_volume_kl_fwd(const void* f1, const void* f2, const float
     else
         hipLaunchKernelGGL(cv_fwd_tile_kernel<float>, dim3(tiles * tiles, P), dim3(256), 0, s, q);
     GD_LAUNCH_OK();
-    hipLaunchKernelGGL(cv_finalize_kernel, dim3(P), dim3(256), 0, s, part1, part2, m1, m2, stats, loss, hw, nslab,
-                       variant);
+    hipLaunchKernelGGL(cv_finalize_kernel, dim3(P, CV_FCH), dim3(256), 0, s, part1, part2, m1, m2, stats, chunk_loss, hw,
+                       nslab, variant);
+    hipLaunchKernelGGL(cv_loss_kernel, dim3(gd_cdiv(P, 64)), dim3(64), 0, s, chunk_loss, loss, P, hw);
     GD_LAUNCH_OK();
     return 0;
 }

@@ -93,7 +93,6 @@ __global__ __launch_bounds__(256) void gemm_nt_regstage_kernel(GemmNtParams p) {
 // epilogue staged through LDS so that every global access of the epilogue (C, preact, residual, dact_src) is a
 // 16-byte row-coalesced vector.  Requires K*elsize % 128 == 0.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 
 __device__ __forceinline__ void ld8_rt(const void* p, long i, int dt, float (&o)[8]) {
     if (dt == GD_BF16) {
@@ -122,8 +121,7 @@ __device__ __forceinline__ void st8_rt(void* p, long i, int dt, const float (&v)
 template <typename T, int NWM, int NWN, int WMT>
 __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(GemmNtParams p) {
     constexpr int NW = NWM * NWN, NT = 64 * NW, BM = NWM * WMT * 16, BN = NWN * 64;
-    constexpr int ABYTES = BM * 128, STAGE = (BM + BN) * 128, EPLD = BN + 4;
-    constexpr int APW = BM / 8 / NW, BPW = BN / 8 / NW;   // 1-KB DMA pieces per wave per operand per K-step
+    constexpr int STAGE = (BM + BN) * 128, EPLD = BN + 4;
     static_assert(64 * EPLD * 4 <= 2 * STAGE, "epilogue staging must fit in the ring");
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -135,66 +133,10 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(GemmNtParams p)
     const long batch = blockIdx.y;
     const char* Ab = (const char*)p.A + batch * p.sA * (long)sizeof(T);
     const char* Wb = (const char*)p.W + batch * p.sW * (long)sizeof(T);
-    const long lda_b = p.lda * (long)sizeof(T), ldw_b = p.ldw * (long)sizeof(T);
-    const int nk = p.K * (int)sizeof(T) / 128;
-
-    // per-lane source pointers of this wave's DMA pieces (LDS piece pc holds rows pc*8 .. pc*8+7, 128 B each)
-    const char* asrc[APW];
-    const char* wsrc[BPW];
-#pragma unroll
-    for (int i = 0; i < APW; ++i) {
-        const int row = (wave * APW + i) * 8 + (lane >> 3);
-        asrc[i] = Ab + (long)min(tm * BM + row, p.M - 1) * lda_b + (((lane & 7) ^ swz(row)) * 16);
-    }
-#pragma unroll
-    for (int i = 0; i < BPW; ++i) {
-        const int row = (wave * BPW + i) * 8 + (lane >> 3);
-        wsrc[i] = Wb + (long)min(tn * BN + row, p.N - 1) * ldw_b + (((lane & 7) ^ swz(row)) * 16);
-    }
-    auto issue = [&](int kt, int buf) {
-        char* sA = smem + buf * STAGE;
-        char* sB = sA + ABYTES;
-#pragma unroll
-        for (int i = 0; i < APW; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + (long)kt * 128),
-                                             (__attribute__((address_space(3))) void*)(sA + (wave * APW + i) * 1024), 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < BPW; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + (long)kt * 128),
-                                             (__attribute__((address_space(3))) void*)(sB + (wave * BPW + i) * 1024), 16, 0, 0);
-    };
-
     f32x4 acc[WMT][4];
-#pragma unroll
-    for (int i = 0; i < WMT; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    typedef typename Mma<T>::Frag Frag;
+    dma_mainloop<T, NWM, NWN, WMT>(Ab, p.lda * (long)sizeof(T), p.M, Wb, p.ldw * (long)sizeof(T), p.N,
+                                   p.K * (int)sizeof(T) / 128, tm, tn, smem, acc);
     const int fr = lane & 15, g = lane >> 4;
-    const int abase = (wm * WMT * 16 + fr) * 128, bbase = ABYTES + (wn * 64 + fr) * 128;
-    const int sa = swz(fr);  // every row this lane reads is fr + multiple of 16: (row>>1)&7 == (fr>>1)&7
-
-    issue(0, 0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const char* sb = smem + (kt & 1) * STAGE;
-        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-#pragma unroll
-        for (int kc = 0; kc < 2; ++kc) {
-            const int co = (((kc * 4 + g) ^ sa) * 16);
-            Frag a[WMT], b[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) b[t] = *(const Frag*)(sb + bbase + t * 2048 + co);
-#pragma unroll
-            for (int t = 0; t < WMT; ++t) a[t] = *(const Frag*)(sb + abase + t * 2048 + co);
-#pragma unroll
-            for (int i = 0; i < WMT; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(a[i], b[j], acc[i][j]);
-        }
-        __syncthreads();
-    }
 
     // ---- epilogue: 64-row passes through LDS (fp32), then 8-column vectors per thread ----
     const int cdt = p.c_dtype;
@@ -206,13 +148,16 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(GemmNtParams p)
         constexpr int RPW = WMT * 16;                       // rows per wave
         const int owner = (ps * 64) / RPW, i0 = ((ps * 64) % RPW) / 16;
         if (wm == owner) {
+            // static register index i, runtime predicate: acc must never be dynamically indexed (it would go to scratch)
 #pragma unroll
-            for (int ii = 0; ii < 4; ++ii)
+            for (int i = 0; i < WMT; ++i) {
+                if ((i >> 2) != (i0 >> 2)) continue;
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        se[(ii * 16 + g * 4 + r) * EPLD + wn * 64 + j * 16 + fr] = acc[i0 + ii][j][r];
+                        se[((i & 3) * 16 + g * 4 + r) * EPLD + wn * 64 + j * 16 + fr] = acc[i][j][r];
+            }
         }
         __syncthreads();
 #pragma unroll
