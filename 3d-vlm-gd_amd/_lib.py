@@ -54,6 +54,7 @@ SIGNATURES = {
     "gd_adamw_workspace_bytes": (c_size_t, []),
     "gd_clip_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_float, c_float, c_float,
                                    c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    "gd_rope_2d": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_long, c_float, c_float, c_int, c_void_p]),
     "gd_cast": (c_int, [c_void_p, c_void_p, c_long, c_float, c_int, c_int, c_void_p]),
     "gd_attention_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "gd_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,

@@ -125,6 +125,12 @@ int gd_clip_adamw_step(float* params, const float* grads, float* exp_avg, float*
                        float grad_scale, float* grad_norm_out, void* workspace, void* stream);
 int gd_cast(const void* in, void* out, long n, float scale, int in_dtype, int out_dtype, void* stream);
 
+/* In-place 2-D RoPE of the frozen MASt3R teacher: replaces curope.rope_2d(tokens, positions, base, fwd)
+ * (dust3r/croco/models/curope/curope.cpp:49-69, kernels.cu:17-82).  tokens [B,N,H,D] (token stride ld_tok elements),
+ * positions int64 [B,N,2] (y,x); fwd = +F0 forward / -F0 backward. */
+int gd_rope_2d(void* tokens, const long* positions, int B, int N, int H, int D, long ld_tok, float base, float fwd,
+               int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
