@@ -60,9 +60,36 @@ def bench_cv():
                   f"fwd+bwd {tfb*1e6/P:8.1f} us/pair {(fwd_bytes+bwd_bytes)/tfb/1e9:8.1f} GB/s")
 
 
+def pmc_cv():
+    """one configuration, few launches: the target of `rocprofv3 --pmc ...` runs (profiles/README.md)."""
+    P, hw, C = 32, 1369, 768
+    f1 = torch.randn(P, hw, C, device="cuda").bfloat16().requires_grad_(True)
+    f2 = torch.randn(P, hw, C, device="cuda").bfloat16().requires_grad_(True)
+    t1 = torch.softmax(3 * torch.randn(P, hw, hw, device="cuda"), -1)
+    t2 = torch.softmax(3 * torch.randn(P, hw, hw, device="cuda"), -1)
+    m1 = torch.rand(P, hw, device="cuda") > 0.3
+    m2 = torch.rand(P, hw, device="cuda") > 0.3
+    for _ in range(3):
+        f1.grad = f2.grad = None
+        ops.cost_volume_kl(f1, f2, t1, t2, m1, m2, "vggt").sum().backward()
+    torch.cuda.synchronize()
+
+
+def pmc_gemm():
+    a = torch.randn(87680, 768, device="cuda").bfloat16()
+    w = torch.randn(2304, 768, device="cuda").bfloat16()
+    for _ in range(3):
+        ops.gemm_nt(a, w)
+    torch.cuda.synchronize()
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gemm", "cv"]
     if "gemm" in which:
         bench_gemm()
     if "cv" in which:
         bench_cv()
+    if "pmc_cv" in which:
+        pmc_cv()
+    if "pmc_gemm" in which:
+        pmc_gemm()
