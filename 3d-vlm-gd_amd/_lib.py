@@ -54,6 +54,12 @@ SIGNATURES = {
     "gd_adamw_workspace_bytes": (c_size_t, []),
     "gd_clip_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_float, c_float, c_float,
                                    c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    "gd_unproject_depth": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "gd_coview_masks": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_void_p]),
+    "gd_nms_keypoints": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                 c_void_p]),
+    "gd_nn_argmax": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "gd_point_cloud_to_depth": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "gd_rope_2d": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_long, c_float, c_float, c_int, c_void_p]),
     "gd_cast": (c_int, [c_void_p, c_void_p, c_long, c_float, c_int, c_int, c_void_p]),
     "gd_attention_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),

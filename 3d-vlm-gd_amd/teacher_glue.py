@@ -1,0 +1,135 @@
+"""Device-side teacher -> target glue: the reference's functions of the same names, without the
+numpy / CPU round-trips of `extract_vggt_features`, `sample_keypoints`, `filter_and_match_keypoints`
+(src/finetune_timm_vggt.py:357-449, src/finetune_timm_mast3r.py:345-469).  Heavy parts are HIP kernels over the C ABI;
+torch is used only for the final dynamic-size `unique` / `sort` / boolean indexing of a few hundred keypoints."""
+import torch
+
+from ._lib import check, lib, ptr, stream, GdHipError
+
+
+def _f(t):
+    return t.contiguous().float()
+
+
+def unproject_depth_map_to_point_map(depth_map, extrinsics_cam, intrinsics_cam):
+    """vggt/utils/geometry.py:12-42 on the device: depth [S,H,W(,1)], extrinsic [S,3,4], intrinsic [S,3,3] -> [S,H,W,3]."""
+    d = _f(depth_map.squeeze(-1) if depth_map.dim() == 4 else depth_map)
+    S, H, W = d.shape
+    e, k = _f(extrinsics_cam), _f(intrinsics_cam)
+    out = torch.empty(S, H, W, 3, dtype=torch.float32, device=d.device)
+    check(lib().gd_unproject_depth(ptr(d), ptr(e), ptr(k), ptr(out), S, H, W, stream()), "gd_unproject_depth")
+    return out
+
+
+def get_coview_masks(point_map_view1, point_map_view2, intrinsic1, extrinsic1, intrinsic2, extrinsic2, image_shape):
+    """utils/functions.py:462-472.  Point maps [H,W,3] (or [P,H,W,3] with [P,3,3]/[P,3,4] cameras) -> bool masks."""
+    single = point_map_view1.dim() == 3
+    pm1, pm2 = _f(point_map_view1), _f(point_map_view2)
+    if single:
+        pm1, pm2 = pm1[None], pm2[None]
+    P, H, W, _ = pm1.shape
+    if tuple(image_shape) != (H, W):
+        raise GdHipError("image_shape must equal the point-map resolution")
+    K1, E1, K2, E2 = (_f(t).reshape(P, -1) for t in (intrinsic1, extrinsic1, intrinsic2, extrinsic2))
+    m1 = torch.empty(P, H, W, dtype=torch.uint8, device=pm1.device)
+    m2 = torch.empty_like(m1)
+    check(lib().gd_coview_masks(ptr(pm1), ptr(pm2), ptr(K1), ptr(E1), ptr(K2), ptr(E2), ptr(m1), ptr(m2), P, H, W,
+                                stream()), "gd_coview_masks")
+    m1, m2 = m1.bool(), m2.bool()
+    return (m1[0], m2[0]) if single else (m1, m2)
+
+
+def sample_keypoints_nms(mask, conf, N, min_distance, generator=None):
+    """utils/functions.py:475-507: (row, col) of the NMS survivors, row-major; a random subset of N when more survive
+    (the reference draws torch.randperm on the device — same distribution, different stream).  mask/conf [H,W]."""
+    H, W = mask.shape
+    mk = mask.contiguous().to(torch.uint8)[None]
+    cf = _f(conf)[None]
+    cap = H * W
+    keep = torch.empty(1, H, W, dtype=torch.uint8, device=mask.device)
+    idx = torch.empty(1, cap, dtype=torch.int32, device=mask.device)
+    cnt = torch.empty(1, dtype=torch.int32, device=mask.device)
+    check(lib().gd_nms_keypoints(ptr(mk), ptr(cf), int(min_distance), ptr(keep), ptr(idx), ptr(cnt), 1, H, W, cap,
+                                 stream()), "gd_nms_keypoints")
+    M = int(cnt.item())                      # the only host sync: the keypoint count sizes everything downstream
+    if M == 0:
+        return None
+    lin = idx[0, :M].long()
+    if M > N:
+        lin = lin[torch.randperm(M, device=mask.device, generator=generator)[:N]]
+    return torch.stack([lin // W, lin % W], 1)
+
+
+def nn_argmax(queries, database, active=None, out=None):
+    """argmax_j <q_i, db_j> for the active queries (dist='dot' of mast3r/fast_nn.py:11-62) -> int32 [Nq]."""
+    q, db = _f(queries), _f(database)
+    Nq, D = q.shape
+    if out is None:
+        out = torch.full((Nq,), -1, dtype=torch.int32, device=q.device)
+    keys = torch.empty(Nq, dtype=torch.int64, device=q.device)
+    act = active.contiguous().to(torch.uint8) if active is not None else None
+    check(lib().gd_nn_argmax(ptr(q), ptr(db), ptr(act), ptr(out), ptr(keys), Nq, db.shape[0], D, stream()), "gd_nn_argmax")
+    return out
+
+
+def fast_reciprocal_NNs(pts1, pts2, subsample_or_initxy1=8, max_iter=10):
+    """mast3r/fast_nn.py:109-188 (integer subsample, pixel_tol=0, dist='dot', ret_xy=True) with the whole iteration
+    on the device: no numpy round-trip per step, the convergence masks are tensors, and the loop always runs max_iter
+    rounds (converged seeds are skipped inside the kernel), so there is no host sync until the final `unique`.
+    pts [H,W,D] descriptors -> (xy1 [M,2], xy2 [M,2]) int64 (x,y), unique, sorted on the view-1 index."""
+    H1, W1, D = pts1.shape
+    H2, W2, _ = pts2.shape
+    dev = pts1.device
+    p1, p2 = _f(pts1).reshape(-1, D), _f(pts2).reshape(-1, D)
+    S = int(subsample_or_initxy1)
+    ys, xs = torch.meshgrid(torch.arange(S // 2, H1, S, device=dev), torch.arange(S // 2, W1, S, device=dev), indexing="ij")
+    xy1 = (xs.reshape(-1) + W1 * ys.reshape(-1)).to(torch.int32)     # strictly increasing: already unique
+    xy2 = torch.full_like(xy1, -1)
+    old1, old2 = xy1.clone(), xy2.clone()
+    notyet = torch.ones_like(xy1, dtype=torch.bool)
+    for it in range(max_iter):
+        nn_argmax(p1[xy1.long()], p2, notyet, out=xy2)
+        notyet = notyet & (old2 != xy2)
+        nn_argmax(p2[xy2.clamp_min(0).long()], p1, notyet, out=xy1)
+        notyet = notyet & (old1 != xy1)
+        if it + 1 < max_iter:
+            old2, old1 = xy2.clone(), xy1.clone()
+    conv = ~notyet
+    key = torch.unique(xy1[conv].long() * (H2 * W2 + 1) + xy2[conv].long())
+    i1, i2 = key // (H2 * W2 + 1), key % (H2 * W2 + 1)
+    return torch.stack([i1 % W1, i1 // W1], 1), torch.stack([i2 % W2, i2 // W2], 1)
+
+
+def filter_kp_by_conf(kp, conf_mask):
+    """utils/functions.py:199-207."""
+    k = kp[0]
+    valid = conf_mask[k[:, 1].round().long(), k[:, 0].round().long()]
+    idx = valid.nonzero(as_tuple=False).squeeze(1)
+    return kp[:, idx], idx
+
+
+def filter_and_match_keypoints(desc_1, desc_2, conf_1, conf_2, subsample=16, min_conf_thr=10):
+    """src/finetune_timm_mast3r.py:414-459 on the device: reciprocal NNs, 3-px border filter, union of the two
+    percentile-confidence filters.  -> kp_1, kp_2 float [1,N,2] (x,y)."""
+    kp1, kp2 = fast_reciprocal_NNs(desc_1, desc_2, subsample)
+    H1, W1 = conf_1.shape
+    H2, W2 = conf_2.shape
+    ok = ((kp1[:, 0] >= 3) & (kp1[:, 0] < W1 - 3) & (kp1[:, 1] >= 3) & (kp1[:, 1] < H1 - 3)
+          & (kp2[:, 0] >= 3) & (kp2[:, 0] < W2 - 3) & (kp2[:, 1] >= 3) & (kp2[:, 1] < H2 - 3))
+    a, b = kp1[ok].float()[None], kp2[ok].float()[None]
+    th1 = conf_1.reshape(-1).sort()[0][int(conf_1.numel() * float(min_conf_thr) * 0.01)]
+    th2 = conf_2.reshape(-1).sort()[0][int(conf_2.numel() * float(min_conf_thr) * 0.01)]
+    _, i1 = filter_kp_by_conf(a, conf_1 >= th1)
+    _, i2 = filter_kp_by_conf(b, conf_2 >= th2)
+    keep = torch.unique(torch.cat([i1, i2], 0))
+    return a[:, keep], b[:, keep]
+
+
+def point_cloud_to_depth(points, K, w, h, device=None):
+    """utils/functions.py:218-259: points [N,3] (camera frame), K [3,3] -> depth [1,1,h,w]."""
+    pts, k = _f(points)[None], _f(K).reshape(1, 9)
+    depth = torch.empty(1, h, w, dtype=torch.float32, device=pts.device)
+    cnt = torch.empty_like(depth)
+    check(lib().gd_point_cloud_to_depth(ptr(pts), ptr(k), ptr(depth), ptr(cnt), 1, pts.shape[1], w, h, stream()),
+          "gd_point_cloud_to_depth")
+    return depth.view(1, 1, h, w)

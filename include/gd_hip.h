@@ -125,6 +125,26 @@ int gd_clip_adamw_step(float* params, const float* grads, float* exp_avg, float*
                        float grad_scale, float* grad_norm_out, void* workspace, void* stream);
 int gd_cast(const void* in, void* out, long n, float scale, int in_dtype, int out_dtype, void* stream);
 
+/* Teacher -> target glue on the device.
+ * gd_unproject_depth: vggt/utils/geometry.py:12-110 unproject_depth_map_to_point_map (depth [S,H,W], extrinsic [S,3,4],
+ *   intrinsic [S,3,3] -> world points [S,H,W,3]).
+ * gd_coview_masks: utils/functions.py:425-472 get_coview_masks, batched over P pairs (point maps [P,H,W,3]).
+ * gd_nms_keypoints: utils/functions.py:475-507 sample_keypoints_nms up to the ordered candidate list: idx [P,cap]
+ *   row-major linear indices of the local maxima, count [P]; keep_ws [P,H,W] scratch.
+ * gd_nn_argmax: mast3r/fast_nn.py:11-62 bruteforce NN with dist='dot' (queries [Nq,D], database [Nb,D], D <= 32,
+ *   optional active mask): idx [Nq] int32 (inactive entries untouched); key_ws [Nq] u64 scratch.
+ * gd_point_cloud_to_depth: utils/functions.py:218-259 (points [P,Np,3], K [P,3,3] -> depth [P,h,w]); cnt_ws [P,h,w]. */
+int gd_unproject_depth(const float* depth, const float* extrinsic, const float* intrinsic, float* out, int S, int H,
+                       int W, void* stream);
+int gd_coview_masks(const float* pm1, const float* pm2, const float* K1, const float* E1, const float* K2,
+                    const float* E2, unsigned char* m1, unsigned char* m2, int P, int H, int W, void* stream);
+int gd_nms_keypoints(const unsigned char* mask, const float* conf, int min_distance, unsigned char* keep_ws, int* idx,
+                     int* count, int P, int H, int W, int cap, void* stream);
+int gd_nn_argmax(const float* queries, const float* database, const unsigned char* active, int* idx,
+                 unsigned long long* key_ws, int Nq, int Nb, int D, void* stream);
+int gd_point_cloud_to_depth(const float* points, const float* K, float* depth, float* cnt_ws, int P, int Np, int w,
+                            int h, void* stream);
+
 /* In-place 2-D RoPE of the frozen MASt3R teacher: replaces curope.rope_2d(tokens, positions, base, fwd)
  * (dust3r/croco/models/curope/curope.cpp:49-69, kernels.cu:17-82).  tokens [B,N,H,D] (token stride ld_tok elements),
  * positions int64 [B,N,2] (y,x); fwd = +F0 forward / -F0 backward. */

@@ -469,3 +469,130 @@ def rope_2d(tokens, positions, base=100.0, fwd=1.0):
         out[..., (2 * ax) * Q:(2 * ax + 1) * Q] = u * c - v * s
         out[..., (2 * ax + 1) * Q:(2 * ax + 2) * Q] = v * c + u * s
     return out
+
+
+# ----------------------------------------------------------------------------------
+# teacher -> target glue (a18, a19)
+# ----------------------------------------------------------------------------------
+
+
+def unproject_depth(depth, extrinsic, intrinsic):
+    """vggt/utils/geometry.py:12-110 — depth [S,H,W], extrinsic [S,3,4] (cam from world), intrinsic [S,3,3]
+    -> world points [S,H,W,3]: x_cam = (u-cu) d / fu, then R^T (x_cam - t)."""
+    S, H, W = depth.shape
+    v, u = torch.meshgrid(torch.arange(H, dtype=depth.dtype), torch.arange(W, dtype=depth.dtype), indexing="ij")
+    out = []
+    for s in range(S):
+        fu, fv, cu, cv = intrinsic[s, 0, 0], intrinsic[s, 1, 1], intrinsic[s, 0, 2], intrinsic[s, 1, 2]
+        cam = torch.stack([(u - cu) * depth[s] / fu, (v - cv) * depth[s] / fv, depth[s]], -1)
+        R, t = extrinsic[s, :, :3], extrinsic[s, :, 3]
+        Rinv = R.t()
+        out.append(cam @ Rinv.t() + (-(Rinv @ t)))
+    return torch.stack(out, 0)
+
+
+def coview_masks(pm1, pm2, K1, E1, K2, E2, image_shape):
+    """utils/functions.py:425-472 get_coview_masks.  NOTE the reference converts BOTH point maps with extrinsic1
+    (`convert_camera_to_world(point_map_view2, extrinsic1)`, :464) — reproduced as is."""
+    H, W = image_shape
+
+    def to_world(pm, E):
+        return (pm - E[:, 3].unsqueeze(0)) @ E[:, :3].t()       # torch.matmul(pm - t, R_inv) with R_inv = R.t(), as written (:452-456)
+
+    def project(P, pts):
+        flat = pts.reshape(-1, 3)
+        ph = (P @ torch.cat([flat, torch.ones(flat.shape[0], 1, dtype=flat.dtype)], 1).t()).t()
+        uv = ph[:, :2] / (ph[:, 2:3] + 1e-8)
+        return uv.reshape(*pts.shape[:-1], 2)
+
+    def inside(uv):
+        return (uv[..., 0] >= 0) & (uv[..., 0] < W) & (uv[..., 1] >= 0) & (uv[..., 1] < H)
+
+    w1, w2 = to_world(pm1, E1), to_world(pm2, E1)
+    return inside(project(K2 @ E2, w1)), inside(project(K1 @ E1, w2))
+
+
+def nms_keypoints(mask, conf, N, min_distance, perm=None):
+    """utils/functions.py:475-507 sample_keypoints_nms: local maxima of the masked confidence under a
+    (2*min_distance+1)^2 max-pool, as (row, col) in row-major order; when more than N survive the reference draws
+    torch.randperm — here the permutation is an argument."""
+    score = torch.where(mask, conf, torch.zeros_like(conf)).float()
+    k = int(min_distance) * 2 + 1
+    pooled = F.max_pool2d(score[None, None], kernel_size=k, stride=1, padding=k // 2)[0, 0]
+    keep = ((score - pooled).abs() < 1e-6) & mask
+    kps = torch.nonzero(keep, as_tuple=False)
+    if kps.shape[0] == 0:
+        return None
+    if kps.shape[0] > N:
+        kps = kps[perm[:N]]
+    return kps
+
+
+def point_cloud_to_depth(points, K, w, h):
+    """utils/functions.py:218-259 — mean z of the points that round to each pixel."""
+    pts = points[points[:, 2] > 0]
+    out = torch.zeros(h * w, dtype=torch.float32)
+    if pts.shape[0] == 0:
+        return out.view(1, 1, h, w)
+    u = torch.round(pts[:, 0] / pts[:, 2] * K[0, 0] + K[0, 2]).long()
+    v = torch.round(pts[:, 1] / pts[:, 2] * K[1, 1] + K[1, 2]).long()
+    ok = (u >= 0) & (u < w) & (v >= 0) & (v < h)
+    idx, z = (v * w + u)[ok], pts[:, 2][ok]
+    acc = torch.zeros(h * w, dtype=torch.float32).index_add_(0, idx, z.float())
+    cnt = torch.zeros(h * w, dtype=torch.float32).index_add_(0, idx, torch.ones_like(z, dtype=torch.float32))
+    hit = cnt > 0
+    out[hit] = acc[hit] / cnt[hit]
+    return out.view(1, 1, h, w)
+
+
+def filter_kp_by_conf(kp, conf_mask):
+    """utils/functions.py:199-207."""
+    k = kp[0]
+    valid = conf_mask[k[:, 1].round().long(), k[:, 0].round().long()]
+    idx = valid.nonzero(as_tuple=False).squeeze(1)
+    return kp[:, idx], idx
+
+
+def reciprocal_nns(desc1, desc2, subsample=16, max_iter=10):
+    """mast3r/fast_nn.py:109-188 fast_reciprocal_NNs(dist='dot', pixel_tol=0, ret_xy=True): iterate
+    seed -> NN in view 2 -> NN back in view 1 until the cycle closes, keep converged, unique, sorted on view-1 index.
+    desc [H,W,D] -> (xy1 [M,2], xy2 [M,2]) int (x,y)."""
+    H1, W1, D = desc1.shape
+    H2, W2, _ = desc2.shape
+    p1, p2 = desc1.reshape(-1, D), desc2.reshape(-1, D)
+    S = subsample
+    ys, xs = torch.meshgrid(torch.arange(S // 2, H1, S), torch.arange(S // 2, W1, S), indexing="ij")
+    xy1 = torch.unique(xs.reshape(-1) + W1 * ys.reshape(-1))
+    xy2 = torch.full_like(xy1, -1)
+    old1, old2 = xy1.clone(), xy2.clone()
+    notyet = torch.ones_like(xy1, dtype=torch.bool)
+    niter = 0
+    while bool(notyet.any()):
+        xy2[notyet] = (p1[xy1[notyet]] @ p2.t()).argmax(1)
+        notyet &= old2 != xy2
+        if bool(notyet.any()):
+            xy1[notyet] = (p2[xy2[notyet]] @ p1.t()).argmax(1)
+        notyet &= old1 != xy1
+        niter += 1
+        if niter >= max_iter:
+            break
+        old2, old1 = xy2.clone(), xy1.clone()
+    conv = ~notyet
+    key = torch.unique(xy1[conv] * (H2 * W2 + 1) + xy2[conv])      # unique pairs, sorted on xy1 then xy2
+    i1, i2 = key // (H2 * W2 + 1), key % (H2 * W2 + 1)
+    return torch.stack([i1 % W1, i1 // W1], 1), torch.stack([i2 % W2, i2 // W2], 1)
+
+
+def mast3r_keypoint_filter(kp1, kp2, conf1, conf2, min_conf_thr=10):
+    """src/finetune_timm_mast3r.py:420-459: drop matches within 3 px of a border, then keep those whose keypoint is
+    above the min_conf_thr-th percentile confidence in EITHER view (union, :456).  kp [M,2] (x,y); conf [H,W]."""
+    H, W = conf1.shape
+    ok = ((kp1[:, 0] >= 3) & (kp1[:, 0] < W - 3) & (kp1[:, 1] >= 3) & (kp1[:, 1] < H - 3)
+          & (kp2[:, 0] >= 3) & (kp2[:, 0] < conf2.shape[1] - 3) & (kp2[:, 1] >= 3) & (kp2[:, 1] < conf2.shape[0] - 3))
+    a, b = kp1[ok].float()[None], kp2[ok].float()[None]
+    th1 = conf1.reshape(-1).sort()[0][int(conf1.numel() * float(min_conf_thr) * 0.01)]
+    th2 = conf2.reshape(-1).sort()[0][int(conf2.numel() * float(min_conf_thr) * 0.01)]
+    _, i1 = filter_kp_by_conf(a, conf1 >= th1)
+    _, i2 = filter_kp_by_conf(b, conf2 >= th2)
+    keep = torch.unique(torch.cat([i1, i2], 0))
+    return a[:, keep], b[:, keep]

@@ -142,3 +142,22 @@ def test_rope2d():
     out = O.rope_2d(tok, g["positions"], g["base"], 1.0)
     assert rel_err(out.transpose(1, 2), g["out_bhnd"]) < 1e-5
     assert rel_err(O.rope_2d(out, g["positions"], g["base"], -1.0), tok) < 1e-5
+
+
+def test_teacher_glue_vggt_side():
+    g = load_golden("g15_teacher_glue")
+    pm = O.unproject_depth(g["depth"], torch.stack([g["E1"], g["E2"]]), torch.stack([g["K1"], g["K2"]]))
+    assert rel_err(pm, g["point_maps"]) < 1e-5
+    m1, m2 = O.coview_masks(g["point_maps"][0], g["point_maps"][1], g["K1"], g["E1"], g["K2"], g["E2"], tuple(g["depth"].shape[1:]))
+    assert torch.equal(m1, g["mask_1"]) and torch.equal(m2, g["mask_2"])
+    assert torch.equal(O.nms_keypoints(g["mask_1"], g["conf"], 400, g["nms_min_distance"]), g["nms_kps"])
+    assert rel_err(O.point_cloud_to_depth(g["pc_points"], g["K1"], g["depth"].shape[2], g["depth"].shape[1]), g["pc_depth"]) < 1e-6
+    assert torch.equal(O.filter_kp_by_conf(g["fk_kp"], g["fk_mask"])[1], g["fk_idx"])
+
+
+def test_reciprocal_nns():
+    g = load_golden("g16_reciprocal_nns")
+    xy1, xy2 = O.reciprocal_nns(g["desc1"], g["desc2"], g["subsample"])
+    assert torch.equal(xy1, g["xy1"].long()) and torch.equal(xy2, g["xy2"].long())
+    k1, k2 = O.mast3r_keypoint_filter(xy1, xy2, g["conf1"], g["conf2"])
+    assert torch.equal(k1[0], g["kp1_filtered"]) and torch.equal(k2[0], g["kp2_filtered"])

@@ -376,3 +376,66 @@ except Exception as e:  # pragma: no cover
     print("  [skip] rope2d fixture:", type(e).__name__, e)
 
 print("all golden fixtures written; oracle pinned against the reference")
+
+# ---------------------------------------------------------------- G15 teacher glue (VGGT side) + depth rasteriser
+from vggt.utils.geometry import unproject_depth_map_to_point_map  # noqa: E402
+
+torch.manual_seed(15)
+S, Hh, Ww = 2, 18, 22
+
+
+def rand_cam(seed):
+    gg = g(seed)
+    A = torch.randn(3, 3, generator=gg)
+    Rm, _ = torch.linalg.qr(A)
+    if torch.det(Rm) < 0:
+        Rm[:, 0] = -Rm[:, 0]
+    Rm = torch.matrix_exp(0.15 * (A - A.t()))          # a small rotation
+    t = 0.2 * torch.randn(3, generator=gg)
+    E = torch.cat([Rm, t[:, None]], 1)
+    Kc = torch.tensor([[20.0, 0, Ww / 2], [0, 21.0, Hh / 2], [0, 0, 1]])
+    return E, Kc
+
+
+E1, K1 = rand_cam(151)
+E2, K2 = rand_cam(152)
+depth = 1.0 + 2 * torch.rand(S, Hh, Ww, generator=g(153))
+pm = torch.from_numpy(unproject_depth_map_to_point_map(depth.unsqueeze(-1).numpy(), torch.stack([E1, E2]).numpy(),
+                                                       torch.stack([K1, K2]).numpy())).float()
+close(O.unproject_depth(depth, torch.stack([E1, E2]), torch.stack([K1, K2])), pm, 1e-5, "unproject")
+m1, m2 = Fn.get_coview_masks(pm[0], pm[1], K1, E1, K2, E2, (Hh, Ww))
+o1, o2 = O.coview_masks(pm[0], pm[1], K1, E1, K2, E2, (Hh, Ww))
+assert torch.equal(m1, o1) and torch.equal(m2, o2) and 0 < int(m1.sum()) < Hh * Ww
+conf = 1 + torch.rand(Hh, Ww, generator=g(154))
+kps = Fn.sample_keypoints_nms(m1, conf, N=400, min_distance=2)      # M <= N: no RNG involved
+assert torch.equal(kps, O.nms_keypoints(m1, conf, 400, 2))
+pts = torch.randn(500, 3, generator=g(155)) * torch.tensor([1.0, 1.0, 0.5]) + torch.tensor([0, 0, 2.0])
+pts[:40, 2] = -1.0
+dimg = Fn.point_cloud_to_depth(pts, K1, Ww, Hh, torch.device("cpu"))
+close(O.point_cloud_to_depth(pts, K1, Ww, Hh), dimg, 1e-6, "point_cloud_to_depth")
+kpf = torch.stack([torch.randint(0, Ww, (30,), generator=g(156)), torch.randint(0, Hh, (30,), generator=g(157))], -1).float()[None]
+cmask = torch.rand(Hh, Ww, generator=g(158)) > 0.4
+fk, fi = Fn.filter_kp_by_conf(kpf, cmask)
+ok_, oi_ = O.filter_kp_by_conf(kpf, cmask)
+assert torch.equal(fk, ok_) and torch.equal(fi, oi_)
+save("g15_teacher_glue", depth=depth, E1=E1, K1=K1, E2=E2, K2=K2, point_maps=pm, mask_1=m1, mask_2=m2, conf=conf,
+     nms_kps=kps, nms_min_distance=2, pc_points=pts, pc_depth=dimg, fk_kp=kpf, fk_mask=cmask, fk_idx=fi)
+
+# ---------------------------------------------------------------- G16 fast_reciprocal_NNs (MASt3R side)
+from mast3r.fast_nn import fast_reciprocal_NNs  # noqa: E402
+
+Hd, Wd, Dd = 24, 32, 24
+base = F.normalize(torch.randn(Hd, Wd, Dd, generator=g(160)), dim=-1)
+shift = torch.roll(base, shifts=(1, -2), dims=(0, 1))
+d1 = base
+d2 = F.normalize(shift + 0.15 * torch.randn(Hd, Wd, Dd, generator=g(161)), dim=-1)
+xy1, xy2 = fast_reciprocal_NNs(d1, d2, subsample_or_initxy1=4, device="cpu", dist="dot", block_size=2 ** 13)
+o1, o2 = O.reciprocal_nns(d1, d2, subsample=4)
+assert np.array_equal(np.asarray(xy1), o1.numpy()) and np.array_equal(np.asarray(xy2), o2.numpy()), "reciprocal NNs"
+print(f"  reciprocal NNs: {len(xy1)} matches from {(Hd // 4) * (Wd // 4)} seeds")
+c1 = torch.rand(Hd, Wd, generator=g(162))
+c2 = torch.rand(Hd, Wd, generator=g(163))
+k1f, k2f = O.mast3r_keypoint_filter(torch.as_tensor(np.asarray(xy1).copy()), torch.as_tensor(np.asarray(xy2).copy()), c1, c2)
+save("g16_reciprocal_nns", desc1=d1, desc2=d2, subsample=4, xy1=np.asarray(xy1).copy(), xy2=np.asarray(xy2).copy(),
+     conf1=c1, conf2=c2, kp1_filtered=k1f[0], kp2_filtered=k2f[0])
+print("teacher-glue fixtures written")
