@@ -197,10 +197,7 @@ __global__ __launch_bounds__(256, 2) void cv_fwd_tile_kernel(CvTileParams q) {
                 Z += __expf(s); Wt += t; A += t * __logf(t); B += t * s;
             }
         }
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-            Z += __shfl_xor(Z, o, 64); Wt += __shfl_xor(Wt, o, 64); A += __shfl_xor(A, o, 64); B += __shfl_xor(B, o, 64);
-        }
+        Z = row16_sum(Z); Wt = row16_sum(Wt); A = row16_sum(A); B = row16_sum(B);
         if (c == 0 && rok) *(f32x4*)(q.part1 + (((long)p * q.nslab + tn) * hw + row) * 4) = f32x4{Z, Wt, A, B};
     }
     // ---- direction 2: columns of S against teacher rows T2[j, :] ----
@@ -219,10 +216,7 @@ __global__ __launch_bounds__(256, 2) void cv_fwd_tile_kernel(CvTileParams q) {
                 Z += __expf(s); Wt += t; A += t * __logf(t); B += t * s;
             }
         }
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-            Z += __shfl_xor(Z, o, 64); Wt += __shfl_xor(Wt, o, 64); A += __shfl_xor(A, o, 64); B += __shfl_xor(B, o, 64);
-        }
+        Z = row16_sum(Z); Wt = row16_sum(Wt); A = row16_sum(A); B = row16_sum(B);
         if (c == 0 && cok) *(f32x4*)(q.part2 + (((long)p * q.nslab + tm) * hw + col) * 4) = f32x4{Z, Wt, A, B};
     }
 }

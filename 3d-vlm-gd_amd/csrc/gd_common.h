@@ -51,11 +51,24 @@ __device__ __forceinline__ void st_rt(void* p, long i, int dt, float v) {
     if (dt == GD_BF16) ((bf16*)p)[i] = (bf16)v; else ((float*)p)[i] = v;
 }
 
-// ---- wave-level reductions (64 lanes) ----
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// ---- wave-level reductions (64 lanes) on DPP (VALU cross-lane operands; no LDS-crossbar ds_bpermute round trips) ----
+template <int CTRL, int RMASK> __device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, RMASK, 0xF, false));
+}
+// sum over each row of 16 lanes, result in every lane of the row
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f32<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+    v += dpp_f32<0x141, 0xF>(v);   // row_half_mirror
+    v += dpp_f32<0x140, 0xF>(v);   // row_mirror
     return v;
+}
+// sum over the 64 lanes, result uniform (via lane 63)
+__device__ __forceinline__ float wave_sum(float v) {
+    v = row16_sum(v);
+    v += dpp_f32<0x142, 0xA>(v);   // row_bcast:15 into rows 1, 3
+    v += dpp_f32<0x143, 0xC>(v);   // row_bcast:31 into rows 2, 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

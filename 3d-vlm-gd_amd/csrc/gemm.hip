@@ -27,6 +27,8 @@ struct GemmNtParams {
     const void* residual; long ldr;  // v += residual
     int accumulate;                  // v += C
     int vec_epilogue;                // every epilogue tensor is 16-byte aligned with 16-byte-multiple row strides
+    int c_policy;                    // 0 plain C stores, 1 write-through (sc1) C stores (GD_GEMM_CSTORE, default 1)
+    int tile_order;                  // experiment knob (GD_GEMM_ORDER): 0 XCD chunks, tn fastest; 1 no remap; 2 XCD chunks, 4-wide tn bands
 };
 
 // Fallback: register-staged main loop (any K with K*elsize % 16 == 0, any alignment of rows), scalar epilogue.
@@ -118,6 +120,18 @@ __device__ __forceinline__ void st8_rt(void* p, long i, int dt, const float (&v)
 //   <2,2,4> : 128 x 128 block, 256 threads, 64 KB LDS ring (2 blocks / CU)      — skinny N / small problems
 //   <2,4,8> : 256 x 256 block, 512 threads, 128 KB LDS ring (1 block / CU, 2 waves / SIMD); wave tile 128 x 64
 //             => 12 fragment reads per 32 MFMAs instead of 8 per 16: less LDS traffic per FLOP.
+__device__ __forceinline__ void st8_wt(__amdgpu_buffer_rsrc_t rs, int byte_off, int dt, const float (&v)[8]) {
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    if (dt == GD_BF16) {
+        const bf16x8 b = bf16x8{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, b), rs, byte_off, 0, 16);
+    } else {
+        const f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, a), rs, byte_off, 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, b), rs, byte_off + 16, 0, 16);
+    }
+}
+
 template <typename T, int NWM, int NWN, int WMT>
 __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(GemmNtParams p) {
     constexpr int NW = NWM * NWN, NT = 64 * NW, BM = NWM * WMT * 16, BN = NWN * 64;
@@ -128,8 +142,14 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(GemmNtParams p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / NWN, wn = wave % NWN;
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-    const int wg = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    const int tm = wg / tiles_n, tn = wg % tiles_n;
+    const int wg = p.tile_order == 1 ? (int)blockIdx.x : xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    int tm = wg / tiles_n, tn = wg % tiles_n;
+    if (p.tile_order == 2) {   // bands of 4 column tiles, row tiles fastest inside a band
+        const int band = 4, full = (tiles_n / band) * band;
+        const int per_band = band * tiles_m;
+        if (wg < (tiles_n / band) * per_band) { const int b = wg / per_band, r = wg % per_band; tn = b * band + r % band; tm = r / band; }
+        else { const int r = wg - (tiles_n / band) * per_band, rem = tiles_n - full; tn = full + r % rem; tm = r / rem; }
+    }
     const long batch = blockIdx.y;
     const char* Ab = (const char*)p.A + batch * p.sA * (long)sizeof(T);
     const char* Wb = (const char*)p.W + batch * p.sW * (long)sizeof(T);
@@ -143,6 +163,12 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(GemmNtParams p)
     char* Cb = (char*)p.C + batch * p.sC * (long)gd_dtype_size(cdt);
     float* se = (float*)smem;  // [64][EPLD]
     const bool vec = p.vec_epilogue != 0;
+    // C leaves through write-through (sc1) stores: a plain store keeps its line in the XCD's L2, and one tile round of C
+    // (32 blocks x 128 KB) would flush the 4 MB L2 that the operand panels are being re-read from.
+    const int csz = gd_dtype_size(cdt);
+    const long tile_row0 = (long)tm * BM * p.ldc * csz;
+    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(Cb + tile_row0), (short)0, (int)min((long)0x7fffffff, (long)BM * p.ldc * csz), 0x00020000);
 #pragma unroll
     for (int ps = 0; ps < BM / 64; ++ps) {
         constexpr int RPW = WMT * 16;                       // rows per wave
@@ -213,7 +239,8 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(GemmNtParams p)
 #pragma unroll
                     for (int k = 0; k < 8; ++k) v[k] += s[k];
                 }
-                st8_rt(Cb, (long)row * p.ldc + col0, cdt, v);
+                if (p.c_policy == 0) st8_rt(Cb, (long)row * p.ldc + col0, cdt, v);
+                else st8_wt(crs, (int)((long)(ps * 64 + lr) * p.ldc * csz + (long)col0 * csz), cdt, v);
             } else {
                 for (int k = 0; k < 8; ++k) {
                     const int col = col0 + k;
@@ -454,6 +481,9 @@ extern "C" int gd_gemm_nt(const void* A, const void* W, void* C, int M, int N, i
                      (bias == nullptr || ((uintptr_t)bias & 15) == 0) && (lora_b == nullptr || (((uintptr_t)lora_b & 15) == 0 && N % 4 == 0));
     dim3 grid(gd_cdiv(M, 128) * gd_cdiv(N, 128), batch);
     const bool dma = (K * es) % 128 == 0;
+    { static int cp = -1; if (cp < 0) { const char* e = getenv("GD_GEMM_CSTORE"); cp = e ? atoi(e) : 1; }
+      p.c_policy = (cp && (long)256 * ldc * gd_dtype_size(c_dtype) < 0x7fffffffL && !accumulate) ? 1 : 0; }
+    { static int ord = -1; if (ord < 0) { const char* e = getenv("GD_GEMM_ORDER"); ord = e ? atoi(e) : 0; } p.tile_order = ord; }
     const bool big = dma && N >= 256 && M >= 1024 && !gd_force_small_tiles();
     dim3 gridb(gd_cdiv(M, 256) * gd_cdiv(N, 256), batch);
     hipStream_t st = (hipStream_t)stream;

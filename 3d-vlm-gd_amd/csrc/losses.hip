@@ -143,10 +143,8 @@ __device__ __forceinline__ void head_back(float dLds, const HeadW& h, const Head
         if (acc) { acc[1][e] += dy * c.yh[e]; acc[2][e] += dy; acc[3][e] += dof * c.a[e]; }
     }
     if (acc) acc_b2 += dof;
-    float m1 = dyh[0] + dyh[1], m2 = dyh[0] * c.yh[0] + dyh[1] * c.yh[1];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { m1 += __shfl_xor(m1, o, 64); m2 += __shfl_xor(m2, o, 64); }
-    m1 *= (1.0f / 128.0f); m2 *= (1.0f / 128.0f);
+    const float m1 = wave_sum(dyh[0] + dyh[1]) * (1.0f / 128.0f);
+    const float m2 = wave_sum(dyh[0] * c.yh[0] + dyh[1] * c.yh[1]) * (1.0f / 128.0f);
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         dz[e] = c.rstd * (dyh[e] - m1 - c.yh[e] * m2);
