@@ -18,6 +18,7 @@
 #include "gd_common.h"
 
 #define HD 64
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // bare v_exp_f32
 
 template <typename T> struct AT;
 template <> struct AT<bf16> {
@@ -150,7 +151,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* qkv, T* o, float
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) oacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m[2] = {-1e30f, -1e30f}, l[2] = {0.f, 0.f};
+    float m[2] = {-1e30f, -1e30f}, l[2] = {0.f, 0.f};   // m in log2 units
+    const float c2 = scale * 1.4426950408889634f;
 
     TileRegs<T> rk, rv;
     tile_load<T>(rk, kb, ld_b, 0, N);
@@ -178,6 +180,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* qkv, T* o, float
                 s[qt][kt] = a;
             }
         }
+        // online softmax in the exp2 domain: p = 2^(s*c2 - m2), c2 = scale*log2(e) — one FMA + one v_exp per score;
+        // key masking only on the (wave-uniform) partial last tile; O is rescaled only when some row maximum moved.
+        const bool tail = k0 + 64 > N;
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
             float tmax = -1e30f;
@@ -185,30 +190,31 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* qkv, T* o, float
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int key = k0 + kt * 16 + g * 4 + r;
-                    const float v = key < N ? s[qt][kt][r] * scale : -1e30f;
-                    s[qt][kt][r] = v;
-                    tmax = fmaxf(tmax, v);
+                    if (tail && k0 + kt * 16 + g * 4 + r >= N) s[qt][kt][r] = -1e30f;
+                    tmax = fmaxf(tmax, s[qt][kt][r]);
                 }
             tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            const float mn = fmaxf(m[qt], tmax);
-            const float alpha = __expf(m[qt] - mn);
+            const float mn = fmaxf(m[qt], tmax * c2);      // c2 > 0: max commutes with the scaling
+            const float alpha = fast_exp2(m[qt] - mn);
             float ps = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = __expf(s[qt][kt][r] - mn);
+                    const float p = fast_exp2(fmaf(s[qt][kt][r], c2, -mn));
                     s[qt][kt][r] = p;
                     ps += p;
                 }
             ps += __shfl_xor(ps, 16, 64);
             ps += __shfl_xor(ps, 32, 64);
             l[qt] = l[qt] * alpha + ps;
+            const bool moved = mn != m[qt];
             m[qt] = mn;
+            if (__any(moved)) {
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) oacc[dt][qt] *= alpha;
+                for (int dt = 0; dt < 4; ++dt) oacc[dt][qt] *= alpha;
+            }
         }
 #pragma unroll
         for (int u = 0; u < NF; ++u) {
@@ -231,7 +237,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* qkv, T* o, float
         T* orow = o + ((long)b * N + q) * H * HD + h * HD;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) store4<T>(orow + dt * 16 + g * 4, oacc[dt][qt] * inv);
-        if (g == 0) lse[((long)b * H + h) * N + q] = m[qt] + __logf(l[qt]);
+        if (g == 0) lse[((long)b * H + h) * N + q] = (m[qt] + log2f(l[qt])) * 0.6931471805599453f;   // natural log
     }
 }
 
@@ -290,7 +296,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* qkv, const T*
             qf[qt][u] = ok ? load_nfrag<T>(qb + (long)q * ld_b, u, g) : z;
             dof[qt][u] = ok ? load_nfrag<T>(dob + (long)q * ldo_b, u, g) : z;
         }
-        lq[qt] = ok ? lse[((long)b * H + h) * N + q] : 0.f;
+        lq[qt] = ok ? lse[((long)b * H + h) * N + q] * 1.4426950408889634f : 0.f;   // log2 units
         dl[qt] = ok ? delta[((long)b * H + h) * N + q] : 0.f;
     }
     f32x4 dq[4][2];
@@ -298,6 +304,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* qkv, const T*
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) dq[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float c2 = scale * 1.4426950408889634f;
 
     TileRegs<T> rk, rv;
     tile_load<T>(rk, kb, ld_b, 0, N);
@@ -312,6 +319,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* qkv, const T*
             tile_load<T>(rv, vb, ld_b, k0 + 64, N);
         }
         f32x4 ds[2][4];
+        const bool tail = k0 + 64 > N;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
             Frag kf[NF], vf[NF];
@@ -330,9 +338,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* qkv, const T*
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int key = k0 + kt * 16 + g * 4 + r;
-                    const float p = key < N ? __expf(s[r] * scale - lq[qt]) : 0.f;
-                    ds[qt][kt][r] = p * (dp[r] - dl[qt]) * scale;
+                    float p = fast_exp2(fmaf(s[r], c2, -lq[qt]));
+                    if (tail && k0 + kt * 16 + g * 4 + r >= N) p = 0.f;
+                    ds[qt][kt][r] = p * (dp[r] - dl[qt]);          // the 1/sqrt(d) factor is applied once, to dQ
                 }
             }
         }
@@ -355,7 +363,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* qkv, const T*
         if (q >= N) continue;
         T* row = dqkv + ((long)b * N + q) * 3 * H * HD + (long)(0 * H + h) * HD;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) store4<T>(row + dt * 16 + g * 4, dq[dt][qt]);
+        for (int dt = 0; dt < 4; ++dt) store4<T>(row + dt * 16 + g * 4, dq[dt][qt] * scale);
     }
 }
 
@@ -392,6 +400,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const T* qkv, con
             vf[kt][u] = key < N ? load_nfrag<T>(vb + (long)key * ld_b, u, g) : z;
         }
     }
+    const float c2 = scale * 1.4426950408889634f;
     f32x4 dk[4][2], dv[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -414,7 +423,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const T* qkv, con
             tile_load<T, NT>(rq, qb, ld_b, q0 + 64, N);
             tile_load<T, NT>(rd, dob, ldo_b, q0 + 64, N);
         }
-        if (threadIdx.x < 64) { sL[threadIdx.x] = rl; sDl[threadIdx.x] = rdl; }
+        if (threadIdx.x < 64) { sL[threadIdx.x] = rl * 1.4426950408889634f; sDl[threadIdx.x] = rdl; }   // lse in log2 units
         if (q0 + 64 < N && threadIdx.x < 64) {
             const int q = q0 + 64 + threadIdx.x;
             rl = q < N ? lse[((long)b * H + h) * N + q] : 0.f;
@@ -422,6 +431,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const T* qkv, con
         }
         __syncthreads();
         f32x4 pp[2][4], dsv[2][4];  // [key tile][query tile]
+        const bool tail = q0 + 64 > N;
 #pragma unroll
         for (int qt = 0; qt < 4; ++qt) {
             Frag qf[NF], df[NF];
@@ -441,9 +451,10 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const T* qkv, con
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int ql = qt * 16 + g * 4 + r;
-                    const float p = (q0 + ql < N) ? __expf(s[r] * scale - sL[ql]) : 0.f;
+                    float p = fast_exp2(fmaf(s[r], c2, -sL[ql]));
+                    if (tail && q0 + ql >= N) p = 0.f;
                     pp[kt][qt][r] = p;
-                    dsv[kt][qt][r] = p * (dp[r] - sDl[ql]) * scale;
+                    dsv[kt][qt][r] = p * (dp[r] - sDl[ql]);        // the 1/sqrt(d) factor is applied once, to dK
                 }
             }
         }
@@ -472,7 +483,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const T* qkv, con
         T* rv = dqkv + ((long)b * N + key) * 3 * H * HD + (long)(2 * H + h) * HD;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-            store4<T>(rk + dt * 16 + g * 4, dk[dt][kt]);
+            store4<T>(rk + dt * 16 + g * 4, dk[dt][kt] * scale);
             store4<T>(rv + dt * 16 + g * 4, dv[dt][kt]);
         }
     }

@@ -215,8 +215,13 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(GemmNtParams p)
                 }
                 if (p.preact) st8_rt(p.preact, (long)row * p.ldp + col0, cdt, v);
                 if (p.act == 1) {
+                    if (cdt == GD_BF16) {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = gelu_f(v[k]);
+                        for (int k = 0; k < 8; ++k) v[k] = gelu_fast(v[k]);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] = gelu_f(v[k]);
+                    }
                 } else if (p.act == 2) {
 #pragma unroll
                     for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
@@ -224,8 +229,13 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(GemmNtParams p)
                 if (p.dact) {
                     float s[8];
                     ld8_rt(p.dact_src, (long)row * p.ldd + col0, cdt, s);
+                    if (p.dact == 1 && cdt == GD_BF16) {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = p.dact == 1 ? v[k] * dgelu_f(s[k]) : (s[k] > 0.f ? v[k] : 0.f);
+                        for (int k = 0; k < 8; ++k) v[k] *= dgelu_fast(s[k]);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] = p.dact == 1 ? v[k] * dgelu_f(s[k]) : (s[k] > 0.f ? v[k] : 0.f);
+                    }
                 }
                 if (p.residual) {
                     float s[8];

@@ -116,7 +116,7 @@ __device__ __forceinline__ HeadW load_head(const float* b1, const float* lw, con
     return h;
 }
 
-struct HeadCache { float yh[2], y[2], a[2], rstd, s; };
+struct HeadCache { float yh[2], y[2], a[2], dg[2], rstd, s; };   // a = GELU(y), dg = GELU'(y) from one shared exponential
 
 __device__ __forceinline__ float head_eval(const float (&z)[2], const HeadW& h, HeadCache& c) {
     const float mu = wave_sum(z[0] + z[1]) * (1.0f / 128.0f);
@@ -125,7 +125,13 @@ __device__ __forceinline__ float head_eval(const float (&z)[2], const HeadW& h, 
     c.rstd = rsqrtf(var + 1e-5f);
     c.yh[0] = d0 * c.rstd; c.yh[1] = d1 * c.rstd;
 #pragma unroll
-    for (int e = 0; e < 2; ++e) { c.y[e] = c.yh[e] * h.lw[e] + h.lb[e]; c.a[e] = gelu_f(c.y[e]); }
+    for (int e = 0; e < 2; ++e) {
+        c.y[e] = c.yh[e] * h.lw[e] + h.lb[e];
+        float Phi, ex;
+        gelu_parts(c.y[e], Phi, ex);
+        c.a[e] = c.y[e] * Phi;
+        c.dg[e] = Phi + c.y[e] * ex * 0.39894228040143268f;
+    }
     const float o = wave_sum(c.a[0] * h.w2[0] + c.a[1] * h.w2[1]) + h.b2;
     c.s = tanhf(o);
     return c.s;
@@ -138,7 +144,7 @@ __device__ __forceinline__ void head_back(float dLds, const HeadW& h, const Head
     float dyh[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-        const float dy = dof * h.w2[e] * dgelu_f(c.y[e]);
+        const float dy = dof * h.w2[e] * c.dg[e];
         dyh[e] = dy * h.lw[e];
         if (acc) { acc[1][e] += dy * c.yh[e]; acc[2][e] += dy; acc[3][e] += dof * c.a[e]; }
     }

@@ -36,6 +36,29 @@ def bench_gemm():
             print(f"gemm_nt {str(dt)[6:]:9s} {M}x{N}x{K}: {t*1e3:8.3f} ms  {2*M*N*K/t/1e12:7.1f} TF/s   (torch/hipblaslt {2*M*N*K/t2/1e12:7.1f} TF/s)")
 
 
+def bench_gelu():
+    M, N, K = 87680, 3072, 768
+    a = torch.randn(M, K, device="cuda").bfloat16()
+    w = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
+    bias = torch.zeros(N, device="cuda")
+    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    pre = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    t0 = timeit(lambda: ops.gemm_nt(a, w, out=out))
+    t1 = timeit(lambda: ops.gemm_nt(a, w, out=out, bias=bias, act=1))
+    t2 = timeit(lambda: ops.gemm_nt(a, w, out=out, bias=bias, act=1, preact=pre))
+    a2 = torch.randn(M, N, device="cuda").bfloat16()
+    w2 = (torch.randn(768, N, device="cuda") * 0.05).bfloat16()
+    o2 = torch.empty(M, 768, device="cuda", dtype=torch.bfloat16)
+    res = torch.randn(M, 768, device="cuda").bfloat16()
+    t3 = timeit(lambda: ops.gemm_nt(a2, w2, out=o2))
+    t4 = timeit(lambda: ops.gemm_nt(a2, w2, out=o2, bias=bias[:768].contiguous(), residual=res))
+    wt = (torch.randn(N, 768, device="cuda") * 0.05).bfloat16()
+    dy = torch.randn(M, 768, device="cuda").bfloat16()
+    t5 = timeit(lambda: ops.gemm_nt(dy, wt, out=out))
+    t6 = timeit(lambda: ops.gemm_nt(dy, wt, out=out, dact_src=pre, dact=1))
+    print(f"fc1 plain {t0*1e3:.3f} ms | +bias+GELU {t1*1e3:.3f} | +preact {t2*1e3:.3f} || fc2 plain {t3*1e3:.3f} | +bias+residual {t4*1e3:.3f} || dfc2 plain {t5*1e3:.3f} | +dGELU {t6*1e3:.3f}")
+
+
 def bench_cv():
     for dt in (torch.bfloat16, torch.float32):
         for P in (1, 8, 32):
@@ -89,6 +112,8 @@ if __name__ == "__main__":
         bench_gemm()
     if "cv" in which:
         bench_cv()
+    if "gelu" in which:
+        bench_gelu()
     if "pmc_cv" in which:
         pmc_cv()
     if "pmc_gemm" in which:
