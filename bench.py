@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--keypoints", type=int, default=300)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); 'gloo' lets two "
+                    "ranks share one GPU for a functional check of the N>1 path")
     return ap.parse_args()
 
 
@@ -59,8 +61,12 @@ def main():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from gd_testutil import synthetic_batch
 
-    rank, local, world = dp.init_from_env()
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    ndev = torch.cuda.device_count()
+    if args.backend == "gloo":      # functional check only: every rank may share device 0
+        os.environ["LOCAL_RANK"] = str(int(os.environ.get("LOCAL_RANK", "0")) % ndev)
+    rank, local, world = dp.init_from_env(backend=args.backend)
+    local = local % ndev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     P, img, N = args.pairs_per_gpu, args.img, args.keypoints
