@@ -28,6 +28,7 @@ struct GemmNtParams {
     int accumulate;                  // v += C
     int vec_epilogue;                // every epilogue tensor is 16-byte aligned with 16-byte-multiple row strides
     int c_policy;                    // 0 plain C stores, 1 write-through (sc1) C stores (GD_GEMM_CSTORE, default 1)
+    int deep_ring;                   // 256x256 config: 4-slot ring of 64-byte K stages with counted waits (GD_GEMM_DEEP=1; measured 10 % SLOWER than the 2-deep ring: twice the barriers)
     int tile_order;                  // experiment knob (GD_GEMM_ORDER): 0 XCD chunks, tn fastest; 1 no remap; 2 XCD chunks, 4-wide tn bands
 };
 
@@ -154,8 +155,17 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(GemmNtParams p)
     const char* Ab = (const char*)p.A + batch * p.sA * (long)sizeof(T);
     const char* Wb = (const char*)p.W + batch * p.sW * (long)sizeof(T);
     f32x4 acc[WMT][4];
-    dma_mainloop<T, NWM, NWN, WMT>(Ab, p.lda * (long)sizeof(T), p.M, Wb, p.ldw * (long)sizeof(T), p.N,
-                                   p.K * (int)sizeof(T) / 128, tm, tn, smem, acc);
+    bool done = false;
+    if constexpr (NWM * NWN == 8) {
+        if (p.deep_ring) {
+            dma_mainloop_deep<T, NWM, NWN, WMT>(Ab, p.lda * (long)sizeof(T), p.M, Wb, p.ldw * (long)sizeof(T), p.N,
+                                                p.K * (int)sizeof(T) / 128, tm, tn, smem, acc);
+            done = true;
+        }
+    }
+    if (!done)
+        dma_mainloop<T, NWM, NWN, WMT>(Ab, p.lda * (long)sizeof(T), p.M, Wb, p.ldw * (long)sizeof(T), p.N,
+                                       p.K * (int)sizeof(T) / 128, tm, tn, smem, acc);
     const int fr = lane & 15, g = lane >> 4;
 
     // ---- epilogue: 64-row passes through LDS (fp32), then 8-column vectors per thread ----
@@ -457,6 +467,11 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmTnParams p) {
 // ------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------
+static bool gd_f32_big_tiles() {   // f32: the 128x128 config at 2 blocks/CU measured 125-138 TF/s vs 97-120 for 256x256
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("GD_GEMM_F32_BIG"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
 static bool gd_force_small_tiles() {   // GD_GEMM_SMALL_TILES=1: A/B switch for benchmarking the tile configurations
     static int v = -1;
     if (v < 0) { const char* e = getenv("GD_GEMM_SMALL_TILES"); v = (e && e[0] == '1') ? 1 : 0; }
@@ -493,6 +508,7 @@ extern "C" int gd_gemm_nt(const void* A, const void* W, void* C, int M, int N, i
     const bool dma = (K * es) % 128 == 0;
     { static int cp = -1; if (cp < 0) { const char* e = getenv("GD_GEMM_CSTORE"); cp = e ? atoi(e) : 1; }
       p.c_policy = (cp && (long)256 * ldc * gd_dtype_size(c_dtype) < 0x7fffffffL && !accumulate) ? 1 : 0; }
+    { static int dr = -1; if (dr < 0) { const char* e = getenv("GD_GEMM_DEEP"); dr = e ? atoi(e) : 0; } p.deep_ring = dr; }
     { static int ord = -1; if (ord < 0) { const char* e = getenv("GD_GEMM_ORDER"); ord = e ? atoi(e) : 0; } p.tile_order = ord; }
     const bool big = dma && N >= 256 && M >= 1024 && !gd_force_small_tiles();
     dim3 gridb(gd_cdiv(M, 256) * gd_cdiv(N, 256), batch);
@@ -502,7 +518,7 @@ extern "C" int gd_gemm_nt(const void* A, const void* W, void* C, int M, int N, i
         else if (dma) hipLaunchKernelGGL((gemm_nt_kernel<bf16, 2, 2, 4>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL(gemm_nt_regstage_kernel<bf16>, grid, dim3(256), 0, st, p);
     } else {
-        if (big) hipLaunchKernelGGL((gemm_nt_kernel<float, 2, 4, 8>), gridb, dim3(512), 0, st, p);
+        if (big && gd_f32_big_tiles()) hipLaunchKernelGGL((gemm_nt_kernel<float, 2, 4, 8>), gridb, dim3(512), 0, st, p);
         else if (dma) hipLaunchKernelGGL((gemm_nt_kernel<float, 2, 2, 4>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL(gemm_nt_regstage_kernel<float>, grid, dim3(256), 0, st, p);
     }
