@@ -122,7 +122,7 @@ template <> __device__ __forceinline__ void store4<bf16>(bf16* p, f32x4 v) {
 
 // ------------------------------------------------------------------------------------------ forward
 template <typename T>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* qkv, T* o, float* lse, int N, int H, float scale) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* qkv, T* o, float* lse, int N, int H, float scale) {
     constexpr int NF = AT<T>::NF, ROWB = AT<T>::ROWB;
     typedef typename Mma<T>::Frag Frag;
     __shared__ __attribute__((aligned(16))) char sK[64 * ROWB];
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const T* o, const T* do
 
 // ------------------------------------------------------------------------------------------ backward: dQ
 template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* qkv, const T* dout, const float* lse,
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const T* qkv, const T* dout, const float* lse,
                                                           const float* delta, T* dqkv, int N, int H, float scale) {
     constexpr int NF = AT<T>::NF, ROWB = AT<T>::ROWB;
     typedef typename Mma<T>::Frag Frag;

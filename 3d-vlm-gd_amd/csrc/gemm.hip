@@ -138,7 +138,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(GemmNtParams p)
     constexpr int NW = NWM * NWN, NT = 64 * NW, BM = NWM * WMT * 16, BN = NWN * 64;
     constexpr int STAGE = (BM + BN) * 128, EPLD = BN + 4;
     static_assert(64 * EPLD * 4 <= 2 * STAGE, "epilogue staging must fit in the ring");
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + (BM + BN) * 32];   // ring + f32 LoRA tiles
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / NWN, wn = wave % NWN;
@@ -155,6 +155,18 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(GemmNtParams p)
     const char* Ab = (const char*)p.A + batch * p.sA * (long)sizeof(T);
     const char* Wb = (const char*)p.W + batch * p.sW * (long)sizeof(T);
     f32x4 acc[WMT][4];
+    const bool lora_mma = p.lora_t && p.lora_rt == 8 && p.vec_epilogue;
+    if (lora_mma) {   // one 16-byte LDS-DMA per thread per operand (2*BM == 2*BN == NT lanes); clamped rows/cols are never stored
+        static_assert(2 * BM == NT && 2 * BN == NT, "LoRA tile DMA assumes square tiles");
+        char* lT = smem + 2 * STAGE;
+        char* lB = lT + BM * 32;
+        const int trow = min(tm * BM + (tid >> 1), p.M - 1);
+        const int bk = tid / (BN / 4), bc = min(tn * BN + (tid % (BN / 4)) * 4, p.N - 4);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.lora_t + (long)trow * 8 + (tid & 1) * 4),
+                                         (__attribute__((address_space(3))) void*)(lT + wave * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.lora_b + (long)bk * p.N + bc),
+                                         (__attribute__((address_space(3))) void*)(lB + wave * 1024), 16, 0, 0);
+    }
     bool done = false;
     if constexpr (NWM * NWN == 8) {
         if (p.deep_ring) {
@@ -168,6 +180,36 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(GemmNtParams p)
                                        p.K * (int)sizeof(T) / 128, tm, tn, smem, acc);
     const int fr = lane & 15, g = lane >> 4;
 
+    // ---- LoRA rank update  acc += (T / alpha) . B  as ONE extra MFMA K-chunk per accumulator tile: lane (g, fr) owns
+    // k = KPL*g + j of the chunk, so only k < 8 is populated.  The f32 T tile [BM][8] and B tile [8][BN] were DMA'd to
+    // the LDS tail before the main loop (no registers, latency hidden); fragments are converted on the way out.
+    // (The scalar form, 8 FMAs per output element on the VALU in the epilogue, cost 35 % of the K = 768 QKV GEMM.)
+    if (lora_mma) {
+        typedef typename Mma<T>::Frag Frag;
+        constexpr int KPL = sizeof(Frag) / sizeof(T);
+        const float* lT = (const float*)(smem + 2 * STAGE);
+        const float* lB = lT + BM * 8;
+        const float ia = 1.0f / p.alpha;
+        const bool live = KPL * g < 8;
+        Frag bf[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < KPL; ++k) {
+                const float x = lB[((KPL * g + k) & 7) * BN + wn * 64 + j * 16 + fr];
+                bf[j][k] = (T)(live ? x : 0.f);
+            }
+#pragma unroll
+        for (int i = 0; i < WMT; ++i) {
+            const float* tr = lT + (wm * WMT * 16 + i * 16 + fr) * 8 + ((KPL * g) & 7);
+            Frag af;
+#pragma unroll
+            for (int k = 0; k < KPL; ++k) af[k] = (T)(live ? ia * tr[k] : 0.f);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(af, bf[j], acc[i][j]);
+        }
+    }
+
     // ---- epilogue: 64-row passes through LDS (fp32), then 8-column vectors per thread ----
     const int cdt = p.c_dtype;
     char* Cb = (char*)p.C + batch * p.sC * (long)gd_dtype_size(cdt);
@@ -179,6 +221,25 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(GemmNtParams p)
     const long tile_row0 = (long)tm * BM * p.ldc * csz;
     const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(Cb + tile_row0), (short)0, (int)min((long)0x7fffffff, (long)BM * p.ldc * csz), 0x00020000);
+    // dact_src / residual tiles of a bf16 output are fetched ONE PASS AHEAD (16 B per item) so their HBM latency hides
+    // under the staging barrier and the previous pass's arithmetic instead of being paid four times per tile.
+    // One shared slot array: it carries dact_src when there is one, else the residual (a call with both reads the
+    // residual directly) — 16 registers, the 256 x 256 tile has no more to spare next to its 128 accumulators.
+    const bool pre = vec && cdt == GD_BF16 && (p.dact || p.residual);
+    const bool pre_d = pre && p.dact, pre_r = pre && !p.dact;
+    const bf16* side_src = (const bf16*)(p.dact ? p.dact_src : p.residual);
+    const long side_ld = p.dact ? p.ldd : p.ldr;
+    uint4 sd[4] = {};
+    auto side_load = [&](int ps, int q) {
+        const int item = tid + NT * q;
+        const int lr = item / (BN / 8), cc = (item % (BN / 8)) * 8;
+        const int row = tm * BM + ps * 64 + lr, col0 = tn * BN + cc;
+        if (row < p.M && col0 + 8 <= p.N) sd[q] = *(const uint4*)(side_src + (long)row * side_ld + col0);
+    };
+    if (pre) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) side_load(0, q);
+    }
 #pragma unroll
     for (int ps = 0; ps < BM / 64; ++ps) {
         constexpr int RPW = WMT * 16;                       // rows per wave
@@ -201,7 +262,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(GemmNtParams p)
             const int item = tid + NT * q;
             const int lr = item / (BN / 8), cc = (item % (BN / 8)) * 8;
             const int row = tm * BM + ps * 64 + lr, col0 = tn * BN + cc;
-            if (row >= p.M || col0 >= p.N) continue;
+            if (row < p.M && col0 < p.N) {
             float v[8];
             {
                 const f32x4 x0 = *(const f32x4*)(se + lr * EPLD + cc), x1 = *(const f32x4*)(se + lr * EPLD + cc + 4);
@@ -214,7 +275,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(GemmNtParams p)
 #pragma unroll
                     for (int k = 0; k < 4; ++k) { v[k] += b0[k]; v[4 + k] += b1[k]; }
                 }
-                if (p.lora_t) {
+                if (p.lora_t && !lora_mma) {
                     for (int qq = 0; qq < p.lora_rt; ++qq) {
                         const float tq = p.lora_t[(long)row * p.lora_rt + qq];
                         const f32x4 b0 = *(const f32x4*)(p.lora_b + (long)qq * p.N + col0),
@@ -238,7 +299,11 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(GemmNtParams p)
                 }
                 if (p.dact) {
                     float s[8];
-                    ld8_rt(p.dact_src, (long)row * p.ldd + col0, cdt, s);
+                    if (pre_d) {
+                        const bf16x8 t = __builtin_bit_cast(bf16x8, sd[q]);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) s[k] = (float)t[k];
+                    } else ld8_rt(p.dact_src, (long)row * p.ldd + col0, cdt, s);
                     if (p.dact == 1 && cdt == GD_BF16) {
 #pragma unroll
                         for (int k = 0; k < 8; ++k) v[k] *= dgelu_fast(s[k]);
@@ -249,7 +314,11 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(GemmNtParams p)
                 }
                 if (p.residual) {
                     float s[8];
-                    ld8_rt(p.residual, (long)row * p.ldr + col0, cdt, s);
+                    if (pre_r) {
+                        const bf16x8 t = __builtin_bit_cast(bf16x8, sd[q]);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) s[k] = (float)t[k];
+                    } else ld8_rt(p.residual, (long)row * p.ldr + col0, cdt, s);
 #pragma unroll
                     for (int k = 0; k < 8; ++k) v[k] += s[k];
                 }
@@ -267,7 +336,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(GemmNtParams p)
                     if (col >= p.N) break;
                     float x = v[k];
                     if (p.bias) x += p.bias[col];
-                    if (p.lora_t)
+                    if (p.lora_t && !lora_mma)   // (otherwise already in acc via the MFMA rank update)
                         for (int qq = 0; qq < p.lora_rt; ++qq) x += p.lora_t[(long)row * p.lora_rt + qq] * p.lora_b[(long)qq * p.N + col];
                     if (p.preact) st_rt(p.preact, (long)row * p.ldp + col, cdt, x);
                     if (p.act == 1) x = gelu_f(x);
@@ -279,6 +348,8 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(GemmNtParams p)
                     st_rt(Cb, (long)row * p.ldc + col, cdt, x);
                 }
             }
+            }
+            if (pre && ps + 1 < BM / 64) side_load(ps + 1, q);   // refill the slot just consumed
         }
         __syncthreads();
     }
@@ -492,6 +563,7 @@ extern "C" int gd_gemm_nt(const void* A, const void* W, void* C, int M, int N, i
                "gd_gemm_nt: K (%d), lda (%ld), ldw (%ld) and batch strides must be multiples of 16 bytes", K, lda, ldw);
     GD_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0, "gd_gemm_nt: A and W must be 16-byte aligned");
     GD_REQUIRE(lora_rt >= 0 && lora_rt <= 8, "gd_gemm_nt: lora_rt %d > 8", lora_rt);
+    GD_REQUIRE(!lora_t || alpha != 0.f, "gd_gemm_nt: the LoRA rank update needs alpha != 0");
     GD_REQUIRE(batch == 1 || (!bias && !lora_t && !preact && !dact_src && !residual),
                "gd_gemm_nt: batched calls take no epilogue tensors");
     GemmNtParams p;

@@ -23,6 +23,15 @@ class GemmProfiler:
         ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
         return flops, ms, len(self.records)
 
+    def by_shape(self):
+        """{(M, N, K, B, epilogue tag): (launches, ms, TFLOP/s)} — where the step's GEMM time goes."""
+        torch.cuda.synchronize()
+        acc = {}
+        for r in self.records:
+            n, ms, fl = acc.get(r[3], (0, 0.0, 0.0))
+            acc[r[3]] = (n + 1, ms + r[0].elapsed_time(r[1]), fl + r[2])
+        return {k: (n, ms, fl / ms / 1e9 if ms > 0 else 0.0) for k, (n, ms, fl) in acc.items()}
+
 
 _PROFILER = None
 
@@ -89,7 +98,8 @@ def gemm_nt(a, w, out=None, *, out_dtype=None, alpha=1.0, bias=None, lora_t=None
                           residual.stride(0) if residual is not None else 0, 1 if accumulate else 0, stream())
     if _PROFILER is not None:
         e1.record()
-        _PROFILER.records.append((e0, e1, 2.0 * M * N * K * B))
+        tag = "".join(c for c, t in (("b", bias), ("l", lora_t), ("p", preact), ("d", dact_src), ("r", residual)) if t is not None)
+        _PROFILER.records.append((e0, e1, 2.0 * M * N * K * B, (M, N, K, B, f"{tag}a{act}{'+' if accumulate else ''}", str(out.dtype)[6:])))
     check(rc, "gd_gemm_nt")
     return out
 

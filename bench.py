@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--img", type=int, default=518)
     ap.add_argument("--keypoints", type=int, default=300)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gemm-shapes", action="store_true", help="per-shape gemm_nt breakdown on stderr")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); 'gloo' lets two "
                     "ranks share one GPU for a functional check of the N>1 path")
@@ -136,6 +137,9 @@ def main():
                                "frac": round(ach / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
                                "launches": n, "avg_launch_us": round(ms / max(n, 1) * 1e3, 2),
                                "share_of_step": round(ms / (dt * 1e3), 3)}
+            if args.gemm_shapes:
+                for k, (cnt, sms, tf) in sorted(prof.by_shape().items(), key=lambda kv: -kv[1][1]):
+                    print(f"gemm_nt {str(k):58s} x{cnt:4d} {sms / args.steps:8.3f} ms/step {tf:7.1f} TF/s", file=sys.stderr)
         # ---- cost-volume kernel on its own (HBM-bound; algorithmic bytes per SURVEY 8d) ----
         es = 2 if args.dtype == "bf16" else 4
         b = batches[0]

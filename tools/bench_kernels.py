@@ -98,6 +98,28 @@ def pmc_cv():
     torch.cuda.synchronize()
 
 
+def bench_attn():
+    B, N, H = 64, 1370, 12
+    qkv = torch.randn(B * N, 3 * H * 64, device="cuda").bfloat16()
+    dout = torch.randn(B * N, H * 64, device="cuda").bfloat16()
+    o, lse = ops.attention_fwd(qkv, B, N, H)
+    fl = 4.0 * B * H * N * N * 64
+    t = timeit(lambda: ops.attention_fwd(qkv, B, N, H))
+    print(f"attn fwd  {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TF/s")
+    t = timeit(lambda: ops.attention_bwd(qkv, o, dout, lse, B, N, H))
+    print(f"attn bwd  {t*1e6:8.1f} us  {2.5*fl/t/1e12:7.1f} TF/s (algorithmic 5 products)")
+
+
+def pmc_attn():
+    B, N, H = 64, 1370, 12
+    qkv = torch.randn(B * N, 3 * H * 64, device="cuda").bfloat16()
+    dout = torch.randn(B * N, H * 64, device="cuda").bfloat16()
+    for _ in range(2):
+        o, lse = ops.attention_fwd(qkv, B, N, H)
+        ops.attention_bwd(qkv, o, dout, lse, B, N, H)
+    torch.cuda.synchronize()
+
+
 def pmc_gemm():
     a = torch.randn(87680, 768, device="cuda").bfloat16()
     w = torch.randn(2304, 768, device="cuda").bfloat16()
@@ -116,5 +138,9 @@ if __name__ == "__main__":
         bench_gelu()
     if "pmc_cv" in which:
         pmc_cv()
+    if "attn" in which:
+        bench_attn()
+    if "pmc_attn" in which:
+        pmc_attn()
     if "pmc_gemm" in which:
         pmc_gemm()
