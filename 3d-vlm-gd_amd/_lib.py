@@ -17,6 +17,7 @@ c_int, c_long, c_float, c_void_p, c_size_t = ctypes.c_int, ctypes.c_long, ctypes
 SIGNATURES = {
     "gd_last_error": (ctypes.c_char_p, []),
     "gd_abi_version": (c_int, []),
+    "gd_gemm_phase_probe": (c_int, [c_int, c_void_p]),
     "gd_gemm_nt": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_long, c_long,
                            c_int, c_long, c_long, c_long, c_int, c_int, c_float,
                            c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_long, c_int,

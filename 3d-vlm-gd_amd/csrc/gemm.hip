@@ -29,6 +29,8 @@ struct GemmNtParams {
     int vec_epilogue;                // every epilogue tensor is 16-byte aligned with 16-byte-multiple row strides
     int c_policy;                    // 0 plain C stores, 1 write-through (sc1) C stores (GD_GEMM_CSTORE, default 1)
     int deep_ring;                   // 256x256 config: 4-slot ring of 64-byte K stages with counted waits (GD_GEMM_DEEP=1; measured 10 % SLOWER than the 2-deep ring: twice the barriers)
+    unsigned long long* probe;       // gd_gemm_phase_probe accumulators (device), or null
+    int stagger;                     // persistent kernel experiment (GD_GEMM_STAGGER): start-up skew between CUs, units of ~0.85 us
     int tile_order;                  // experiment knob (GD_GEMM_ORDER): 0 XCD chunks, tn fastest; 1 no remap; 2 XCD chunks, 4-wide tn bands
 };
 
@@ -355,6 +357,22 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(GemmNtParams p)
     }
 }
 
+#include "gemm_persist.h"
+
+static unsigned long long* g_probe = nullptr;
+extern "C" int gd_gemm_phase_probe(int enable, unsigned long long* out4) {
+    if (out4 && g_probe) {
+        hipDeviceSynchronize();
+        hipMemcpy(out4, g_probe, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    }
+    if (enable && !g_probe) {
+        GD_REQUIRE(hipMalloc(&g_probe, 8 * sizeof(unsigned long long)) == hipSuccess, "gd_gemm_phase_probe: hipMalloc failed");
+    }
+    if (enable) hipMemset(g_probe, 0, 8 * sizeof(unsigned long long));
+    if (!enable && g_probe) { hipFree(g_probe); g_probe = nullptr; }
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------
 // gemm_tn: G[N,K] += alpha * sum_m Y[m,n] X[m,k];  64x64 output tile per block, f32 MFMA 16x16x4,
 // operands converted to f32 while staging (so bf16 activations give fp32-accumulated weight grads).
@@ -579,12 +597,40 @@ extern "C" int gd_gemm_nt(const void* A, const void* W, void* C, int M, int N, i
     dim3 grid(gd_cdiv(M, 128) * gd_cdiv(N, 128), batch);
     const bool dma = (K * es) % 128 == 0;
     { static int cp = -1; if (cp < 0) { const char* e = getenv("GD_GEMM_CSTORE"); cp = e ? atoi(e) : 1; }
-      p.c_policy = (cp && (long)256 * ldc * gd_dtype_size(c_dtype) < 0x7fffffffL && !accumulate) ? 1 : 0; }
+      p.c_policy = (cp && (long)256 * ldc * gd_dtype_size(c_dtype) < 0x7fffffffL && !accumulate) ? cp : 0; }
     { static int dr = -1; if (dr < 0) { const char* e = getenv("GD_GEMM_DEEP"); dr = e ? atoi(e) : 0; } p.deep_ring = dr; }
+    p.probe = g_probe;
+    { static int sg = -1; if (sg < 0) { const char* e = getenv("GD_GEMM_STAGGER"); sg = e ? atoi(e) : 0; } p.stagger = sg; }
     { static int ord = -1; if (ord < 0) { const char* e = getenv("GD_GEMM_ORDER"); ord = e ? atoi(e) : 0; } p.tile_order = ord; }
     const bool big = dma && N >= 256 && M >= 1024 && !gd_force_small_tiles();
     dim3 gridb(gd_cdiv(M, 256) * gd_cdiv(N, 256), batch);
     hipStream_t st = (hipStream_t)stream;
+    static int persist = -1, ncu = 256;
+    if (persist < 0) {
+        const char* e = getenv("GD_GEMM_PERSIST");
+        persist = e ? atoi(e) : 1;
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+    }
+    const long ldmax = (ldc > ldp ? ldc : ldp) > (ldd > ldr ? ldd : ldr) ? (ldc > ldp ? ldc : ldp) : (ldd > ldr ? ldd : ldr);
+    // persistent kernel (bf16 operands): the epilogue combinations of the student step, each its own instantiation
+    void (*pk)(GemmNtParams) = nullptr;
+    if (ab_dtype == GD_BF16 && !accumulate && !(dact_src && residual)) {
+        const bool cb = c_dtype == GD_BF16;
+        if (!dact_src && !residual) {
+            if (act == 0 && !preact) pk = cb ? gemm_nt_persist_kernel<bf16, 0, 0, false, false> : gemm_nt_persist_kernel<bf16, 0, 0, false, true>;
+            else if (act == 1 && !preact && cb) pk = gemm_nt_persist_kernel<bf16, 0, 1, false, false>;
+            else if (act == 1 && preact && cb) pk = gemm_nt_persist_kernel<bf16, 0, 1, true, false>;
+        } else if (dact_src && dact == 1 && act == 0 && !preact && cb) pk = gemm_nt_persist_kernel<bf16, 1, 0, false, false>;
+        else if (residual && act == 0 && !preact && cb) pk = gemm_nt_persist_kernel<bf16, 2, 0, false, false>;
+    }
+    if (big && persist && pk && p.vec_epilogue && N % 8 == 0 && (!lora_t || lora_rt == 8) && 256 * ldmax * cs < 0x7fffffffL) {
+        const int ntiles = gd_cdiv(M, 256) * gd_cdiv(N, 256);
+        dim3 gridp(ntiles < ncu ? ntiles : ncu, batch);
+        hipLaunchKernelGGL(pk, gridp, dim3(512), 0, st, p);
+        GD_LAUNCH_OK();
+        return 0;
+    }
     if (ab_dtype == GD_BF16) {
         if (big) hipLaunchKernelGGL((gemm_nt_kernel<bf16, 2, 4, 8>), gridb, dim3(512), 0, st, p);
         else if (dma) hipLaunchKernelGGL((gemm_nt_kernel<bf16, 2, 2, 4>), grid, dim3(256), 0, st, p);

@@ -1,0 +1,341 @@
+// Persistent 256 x 256 gemm_nt for gfx950: one 512-thread block per CU walks its XCD's chunk of the tile space.
+//
+// What it changes against gemm_nt_kernel<T,2,4,8> (same LDS-DMA ring, same swizzle, same wave tiling 2 x 4 of 128 x 64):
+//   * TRANSPOSED accumulators: every MFMA takes the W fragment as its first operand, so lane (g, fr) holds
+//     D[n = 4g+r][m = fr] — four COLUMNS of one output row.  The W rows are DMA'd into the LDS image in a permuted
+//     order (nperm64) that makes the two n-tiles 2u, 2u+1 interleave into 8 consecutive columns per lane: the whole
+//     epilogue (bias, activation, gating, residual, 16-byte stores) runs straight from the accumulators —
+//     no LDS staging, no barriers (the staged epilogue spent 8 block-wide barriers per tile).
+//   * the next tile's first K stage, its LoRA tiles and its bias slice are DMA'd BEFORE the epilogue of the current
+//     tile starts, so the pipeline-fill latency of a tile hides under the previous tile's epilogue, and there is no
+//     block relaunch between tiles.
+//   * the LoRA rank update is applied at the START of a tile (first MFMA chunk), bias comes from LDS.
+#pragma once
+#include "gemm_tile.h"
+
+__device__ __forceinline__ int nperm64(int rho) {   // LDS W-row -> column offset inside the 256-wide tile
+    const int t = (rho >> 4) & 3, i = rho & 15;
+    return (rho & ~63) | ((t >> 1) << 5) | ((i >> 2) << 3) | ((t & 1) << 2) | (i & 3);
+}
+
+// LDS reads of this kernel go through inline asm: for a ds_read the compiler can see, it inserts `s_waitcnt vmcnt`
+// up to the most recent LDS-DMA (it cannot tell ring slots apart), which at the top of a tile means waiting for the
+// previous tile's epilogue stores and the just-issued prefetch — exactly the overlap this kernel exists for.
+// Results are "released" by a counted `s_waitcnt lgkmcnt(N)` that lists them as read-write operands (LDS returns in order).
+#define GD_DSR128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
+#define GD_DSR32(dst, addr, off) asm volatile("ds_read_b32 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
+__device__ __forceinline__ unsigned lds_off(const void* p) {
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+
+template <typename T>
+__device__ __forceinline__ void mma_row(f32x4 (&acc)[4], f32x4 a, f32x4 b0, f32x4 b1, f32x4 b2, f32x4 b3) {
+    typedef typename Mma<T>::Frag Frag;
+    const Frag fa = __builtin_bit_cast(Frag, a);
+    acc[0] = Mma<T>::mma(__builtin_bit_cast(Frag, b0), fa, acc[0]);
+    acc[1] = Mma<T>::mma(__builtin_bit_cast(Frag, b1), fa, acc[1]);
+    acc[2] = Mma<T>::mma(__builtin_bit_cast(Frag, b2), fa, acc[2]);
+    acc[3] = Mma<T>::mma(__builtin_bit_cast(Frag, b3), fa, acc[3]);
+}
+
+// one 64-byte K chunk of the 128 x 64 wave tile: 12 fragment reads, 32 (transposed) MFMAs
+template <typename T>
+__device__ __forceinline__ void chunk_mma(unsigned aaddr, unsigned baddr, f32x4 (&acc)[8][4]) {
+    f32x4 b0, b1, b2, b3, a0, a1, a2, a3, a4, a5, a6, a7;
+    GD_DSR128(b0, baddr, 0); GD_DSR128(b1, baddr, 2048); GD_DSR128(b2, baddr, 4096); GD_DSR128(b3, baddr, 6144);
+    GD_DSR128(a0, aaddr, 0); GD_DSR128(a1, aaddr, 2048); GD_DSR128(a2, aaddr, 4096); GD_DSR128(a3, aaddr, 6144);
+    GD_DSR128(a4, aaddr, 8192); GD_DSR128(a5, aaddr, 10240); GD_DSR128(a6, aaddr, 12288); GD_DSR128(a7, aaddr, 14336);
+    asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(a0), "+v"(a1));
+    mma_row<T>(acc[0], a0, b0, b1, b2, b3);
+    mma_row<T>(acc[1], a1, b0, b1, b2, b3);
+    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a2), "+v"(a3));
+    mma_row<T>(acc[2], a2, b0, b1, b2, b3);
+    mma_row<T>(acc[3], a3, b0, b1, b2, b3);
+    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a4), "+v"(a5));
+    mma_row<T>(acc[4], a4, b0, b1, b2, b3);
+    mma_row<T>(acc[5], a5, b0, b1, b2, b3);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a6), "+v"(a7));
+    mma_row<T>(acc[6], a6, b0, b1, b2, b3);
+    mma_row<T>(acc[7], a7, b0, b1, b2, b3);
+}
+
+// wait until at most n vector-memory operations of this wave are outstanding (n rounded DOWN to a multiple of 8:
+// conservative).  VMEM operations retire in issue order on gfx9-family parts, so "the S youngest may stay in flight"
+// is how a wave lets its epilogue stores drain under the next tile's main loop while still seeing its DMA land.
+__device__ __forceinline__ void wait_vm_le(int n) {
+    if (n >= 48) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+    else if (n >= 40) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+    else if (n >= 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    else if (n >= 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if (n >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+typedef __attribute__((ext_vector_type(4))) unsigned gd_u32x4;
+template <int AUX>
+__device__ __forceinline__ void bst8_aux(__amdgpu_buffer_rsrc_t rs, int off, int dt, const float (&v)[8]) {
+    if (dt == GD_BF16) {
+        const bf16x8 b = bf16x8{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(gd_u32x4, b), rs, off, 0, AUX);
+    } else {
+        const f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(gd_u32x4, a), rs, off, 0, AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(gd_u32x4, b), rs, off + 16, 0, AUX);
+    }
+}
+// Store cache policy (aux bits: 1 sc0, 2 nt, 16 sc1).  C leaves with nt|sc1: measured on MI355X (87680 x 3072 x 768)
+// plain / sc1 stores stretch the NEXT tile's main loop from 31.7 k to 46 k cycles (the written lines fight the operand
+// panels for the L2 and the drain blocks the vmcnt-ordered DMA); with the non-temporal hint the main loop is unaffected.
+#ifndef GD_PERSIST_STORE_AUX
+#define GD_PERSIST_STORE_AUX 18
+#endif
+
+// Compile-time epilogue: SIDE 0 none | 1 v *= dGELU(dact_src) | 2 v += residual (bf16 side tensor, prefetched);
+// ACT 0 none | 1 GELU | 2 ReLU; PREACT store v before the activation; CF32 C / preact are f32 (else bf16).
+// (With these as run-time flags the 16-item unrolled epilogue was ~160 scalar branches per tile: 4 k cycles of a
+// 45 k-cycle tile with nothing to do.)  Other combinations stay on gemm_nt_kernel.
+template <typename T, int SIDE, int ACT, bool PREACT, bool CF32>
+__global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
+    constexpr int NWN = 4, WMT = 8, NW = 8, BM = 256, BN = 256;
+    constexpr int ABYTES = BM * 128, STAGE = (BM + BN) * 128, APW = BM / 8 / NW, BPW = BN / 8 / NW;
+    constexpr int SDEP = 8;   // side-input prefetch depth (16-byte slots per lane)
+    constexpr int LORA_OFF = 2 * STAGE, BIAS_OFF = LORA_OFF + (BM + BN) * 32;
+    __shared__ __attribute__((aligned(16))) char smem[BIAS_OFF + 2 * BN * 4];
+    typedef typename Mma<T>::Frag Frag;
+    constexpr int KPL = sizeof(Frag) / sizeof(T);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / NWN, wn = wave % NWN;
+    const int fr = lane & 15, g = lane >> 4;
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM, ntiles = tiles_m * tiles_n;
+    const long batch = blockIdx.y;
+    const char* Ab = (const char*)p.A + batch * p.sA * (long)sizeof(T);
+    const char* Wb = (const char*)p.W + batch * p.sW * (long)sizeof(T);
+    const long lda_b = p.lda * (long)sizeof(T), ldw_b = p.ldw * (long)sizeof(T);
+    const int nk = p.K * (int)sizeof(T) / 128;
+    constexpr int cdt = CF32 ? GD_F32 : GD_BF16, csz = CF32 ? 4 : 2;
+    char* Cb = (char*)p.C + batch * p.sC * (long)csz;
+    const bool lora = p.lora_t != nullptr;
+    const float ia = 1.0f / p.alpha;
+
+    // DMA sources: wave-uniform tile base (SGPRs) + one 32-bit byte offset per lane and 1-KB piece.  LDS row rho of
+    // piece i is (wave*APW + i)*8 + (lane>>3); rows past the matrix edge are clamped (read, never stored).
+    const char* abase_t;
+    const char* wbase_t;
+    unsigned aoff[APW], woff[BPW];
+    auto set_tile = [&](int tm, int tn) {
+        abase_t = Ab + (long)tm * BM * lda_b;
+        wbase_t = Wb + (long)tn * BN * ldw_b;
+        const int av = min(BM, p.M - tm * BM) - 1, wv = min(BN, p.N - tn * BN) - 1;
+#pragma unroll
+        for (int i = 0; i < APW; ++i) {
+            const int row = (wave * APW + i) * 8 + (lane >> 3);
+            aoff[i] = (unsigned)(min(row, av) * (int)lda_b + ((lane & 7) ^ swz(row)) * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < BPW; ++i) {
+            const int row = (wave * BPW + i) * 8 + (lane >> 3);
+            woff[i] = (unsigned)(min(nperm64(row), wv) * (int)ldw_b + ((lane & 7) ^ swz(row)) * 16);
+        }
+    };
+    auto issue = [&](int kt, int buf) {
+        char* sA = smem + buf * STAGE;
+        char* sB = sA + ABYTES;
+#pragma unroll
+        for (int i = 0; i < APW; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(abase_t + kt * 128 + aoff[i]),
+                                             (__attribute__((address_space(3))) void*)(sA + (wave * APW + i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < BPW; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wbase_t + kt * 128 + woff[i]),
+                                             (__attribute__((address_space(3))) void*)(sB + (wave * BPW + i) * 1024), 16, 0, 0);
+    };
+    // f32 LoRA tiles T[BM][8], B[8][BN] and the bias slice [BN] (slot = tile parity: the epilogue still reads the
+    // current slice while the next one lands)
+    auto issue_side = [&](int tm, int tn, int slot) {
+        if (lora) {
+            char* lT = smem + LORA_OFF;
+            char* lB = lT + BM * 32;
+            const int trow = min(tm * BM + (tid >> 1), p.M - 1);
+            const int bk = tid / (BN / 4), bc = min(tn * BN + (tid % (BN / 4)) * 4, p.N - 4);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.lora_t + (long)trow * 8 + (tid & 1) * 4),
+                                             (__attribute__((address_space(3))) void*)(lT + wave * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.lora_b + (long)bk * p.N + bc),
+                                             (__attribute__((address_space(3))) void*)(lB + wave * 1024), 16, 0, 0);
+        }
+        if (p.bias && wave == 0) {
+            const int bc = min(tn * BN + lane * 4, p.N - 4);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bias + bc),
+                                             (__attribute__((address_space(3))) void*)(smem + BIAS_OFF + slot * BN * 4), 16, 0, 0);
+        }
+    };
+
+    const int abase = (wm * WMT * 16 + fr) * 128, bbase = ABYTES + (wn * 64 + fr) * 128;
+    const int sa = swz(fr);
+    const unsigned lds0 = lds_off(smem);
+    constexpr bool pre = SIDE != 0;
+    const bf16* side_src = (const bf16*)(SIDE == 1 ? p.dact_src : p.residual);
+    const long side_ld = SIDE == 1 ? p.ldd : p.ldr;
+
+    int t = blockIdx.x, slot = 0;
+    if (t >= ntiles) return;
+    for (int i = 0; i < (int)((blockIdx.x >> 3) & 7) * p.stagger; ++i) __builtin_amdgcn_s_sleep(32);
+    int wg = xcd_remap(t, ntiles);
+    int tm = wg / tiles_n, tn = wg % tiles_n;
+    set_tile(tm, tn);
+    issue(0, 0);
+    issue_side(tm, tn, slot);
+    if (nk > 1) issue(1, 1);
+    // VMEM instructions every wave issues unconditionally in one epilogue (buffer ops, range-checked by the hardware)
+    constexpr int cper = CF32 ? 2 : 1;
+    constexpr int ep_ops = 2 * WMT * (cper + (PREACT ? cper : 0) + (pre ? 1 : 0));
+    int after = 0;   // of those, how many were issued after this tile's stage-1 DMA (0 for the block's first tile)
+
+    unsigned long long pc0 = 0, pw = 0, pm = 0, pe = 0, pn = 0, pd = 0;
+    for (;;) {
+        if (p.probe) pc0 = __builtin_amdgcn_s_memtime();
+        f32x4 acc[WMT][4];
+#pragma unroll
+        for (int i = 0; i < WMT; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        wait_vm_le(after + (nk > 1 ? APW + BPW : 0));   // stage 0, LoRA tiles and bias of this tile have landed
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (p.probe) { const unsigned long long c = __builtin_amdgcn_s_memtime(); pw += c - pc0; pc0 = c; }
+        if (lora) {
+            const bool live = KPL * g < 8;
+            // B tile [8][BN] f32: this lane's k rows start at (KPL*g)&7, its column for n-tile j is n0 + 32*(j>>1) + 4*(j&1)
+            const unsigned baddr = lds_off(smem + LORA_OFF + BM * 32) + 4 * (((KPL * g) & 7) * BN + nperm64(wn * 64 + fr));
+            const unsigned taddr = lds_off(smem + LORA_OFF) + 4 * ((wm * WMT * 16 + fr) * 8 + ((KPL * g) & 7));
+            Frag bf[4];
+#define GD_LB(j, JOFF)                                                                                             \
+            {                                                                                                          \
+                float x0, x1, x2, x3, x4 = 0.f, x5 = 0.f, x6 = 0.f, x7 = 0.f;                                          \
+                GD_DSR32(x0, baddr, 0 + JOFF); GD_DSR32(x1, baddr, 1024 + JOFF); GD_DSR32(x2, baddr, 2048 + JOFF);     \
+                GD_DSR32(x3, baddr, 3072 + JOFF);                                                                      \
+                if (KPL == 8) {                                                                                        \
+                    GD_DSR32(x4, baddr, 4096 + JOFF); GD_DSR32(x5, baddr, 5120 + JOFF); GD_DSR32(x6, baddr, 6144 + JOFF); \
+                    GD_DSR32(x7, baddr, 7168 + JOFF);                                                                  \
+                }                                                                                                      \
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)); \
+                const float xs[8] = {x0, x1, x2, x3, x4, x5, x6, x7};                                                  \
+                _Pragma("unroll") for (int k = 0; k < KPL; ++k) bf[j][k] = (T)(live ? xs[k] : 0.f);                    \
+            }
+            GD_LB(0, 0) GD_LB(1, 16) GD_LB(2, 128) GD_LB(3, 144)
+#undef GD_LB
+#define GD_LT(i, IOFF)                                                                                             \
+            {                                                                                                          \
+                f32x4 t0, t1 = {0.f, 0.f, 0.f, 0.f};                                                                   \
+                GD_DSR128(t0, taddr, IOFF);                                                                            \
+                if (KPL == 8) GD_DSR128(t1, taddr, IOFF + 16);                                                         \
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t0), "+v"(t1));                                             \
+                const float ts[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};                          \
+                Frag af;                                                                                               \
+                _Pragma("unroll") for (int k = 0; k < KPL; ++k) af[k] = (T)(live ? ia * ts[k] : 0.f);                  \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(bf[j], af, acc[i][j]);           \
+            }
+            GD_LT(0, 0) GD_LT(1, 512) GD_LT(2, 1024) GD_LT(3, 1536) GD_LT(4, 2048) GD_LT(5, 2560) GD_LT(6, 3072) GD_LT(7, 3584)
+#undef GD_LT
+        }
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt >= 1 && kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);   // (stage 1 went out together with stage 0)
+            const unsigned sbo = lds0 + (kt & 1) * STAGE;
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) {
+                const int co = (((kc * 4 + g) ^ sa) * 16);
+                chunk_mma<T>(sbo + abase + co, sbo + bbase + co, acc);
+            }
+            if (kt == 0) wait_vm_le(after);   // stage 1 is older than the previous epilogue's stores: those may still drain
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        const int ctm = tm, ctn = tn, cslot = slot;
+        if (p.probe) { const unsigned long long c = __builtin_amdgcn_s_memtime(); pm += c - pc0; pc0 = c; }
+        // ---- epilogue set-up; the first side-input loads go out BEFORE the next tile's DMA (VMEM retires in order: a side
+        // load younger than the DMA could only be consumed after the whole prefetch has landed)
+        // ---- epilogue from the accumulators: lane (g, fr) owns row fr of m-tile i, columns 32u + 8g .. +8 ----
+        const int vrows = min(BM, p.M - ctm * BM);
+        auto mk = [&](const void* base, long ld) {
+            return __builtin_amdgcn_make_buffer_rsrc((void*)((char*)base + (long)ctm * BM * ld * csz), (short)0,
+                                                     (int)min((long)0x7fffffff, (long)vrows * ld * csz), 0x00020000);
+        };
+        const __amdgpu_buffer_rsrc_t crs = mk(Cb, p.ldc);
+        const __amdgpu_buffer_rsrc_t prs = mk(PREACT ? p.preact : Cb, PREACT ? p.ldp : p.ldc);
+        const __amdgpu_buffer_rsrc_t srs = mk(pre ? (const void*)side_src : (const void*)Cb, pre ? side_ld : p.ldc);
+        const unsigned biasaddr = lds_off(smem + BIAS_OFF) + cslot * BN * 4 + (wn * 64 + g * 8) * 4;
+        f32x4 b0, b1;
+        int rloc = wm * WMT * 16 + fr, cbase = ctn * BN + wn * 64 + g * 8;
+        asm volatile("" : "+v"(rloc), "+v"(cbase));   // keep the 48 per-item byte offsets out of the main loop's live range (LICM)
+        const int OOB = 0x7ffffff0;   // beyond every num_records: the hardware drops the access
+        gd_u32x4 sd[SDEP] = {};
+        auto side_load = [&](int idx) {   // idx = u * WMT + i
+            const int col0 = cbase + (idx / WMT) * 32;
+            const int off = col0 < p.N ? (int)((long)(rloc + (idx % WMT) * 16) * side_ld * 2 + col0 * 2) : OOB;
+            sd[idx % SDEP] = __builtin_amdgcn_raw_buffer_load_b128(srs, off, 0, 0);
+        };
+        if (pre) {
+#pragma unroll
+            for (int idx = 0; idx < SDEP; ++idx) side_load(idx);
+        }
+        // ---- the ring is free: start the next tile's pipeline before this tile's epilogue ----
+        t += gridDim.x;
+        const bool more = t < ntiles;
+        if (more) {
+            wg = xcd_remap(t, ntiles);
+            tm = wg / tiles_n; tn = wg % tiles_n; slot ^= 1;
+            set_tile(tm, tn);
+            issue(0, 0);
+            issue_side(tm, tn, slot);
+            if (nk > 1) issue(1, 1);
+        }
+        asm volatile("" ::: "memory");            // nothing of the epilogue may be hoisted above the DMA: `after` counts on it
+        if (p.probe) { const unsigned long long c = __builtin_amdgcn_s_memtime(); pd += c - pc0; pc0 = c; }
+        after = ep_ops - (pre ? SDEP : 0);        // epilogue VMEM instructions younger than the stage-1 DMA
+#pragma unroll
+        for (int idx = 0; idx < 2 * WMT; ++idx) {
+            const int i = idx % WMT, u = idx / WMT;
+            const int rl = rloc + i * 16, row = ctm * BM + rl, col0 = cbase + u * 32;
+            if (i == 0) {
+                b0 = f32x4{0.f, 0.f, 0.f, 0.f}; b1 = b0;
+                if (p.bias) {
+                    if (u == 0) { GD_DSR128(b0, biasaddr, 0); GD_DSR128(b1, biasaddr, 16); }
+                    else { GD_DSR128(b0, biasaddr, 128); GD_DSR128(b1, biasaddr, 144); }
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b0), "+v"(b1));
+                }
+            }
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v[k] = fmaf(p.alpha, acc[i][2 * u][k], b0[k]);
+                v[4 + k] = fmaf(p.alpha, acc[i][2 * u + 1][k], b1[k]);
+            }
+            if (PREACT) bst8_aux<0>(prs, col0 < p.N ? (int)((long)rl * p.ldp * csz + (long)col0 * csz) : OOB, cdt, v);
+            if (ACT == 1) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = CF32 ? gelu_f(v[k]) : gelu_fast(v[k]);
+            } else if (ACT == 2) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+            }
+            if (SIDE == 1) {
+                const bf16x8 x = __builtin_bit_cast(bf16x8, sd[idx % SDEP]);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] *= dgelu_fast((float)x[k]);
+            }
+            if (SIDE == 2) {
+                const bf16x8 x = __builtin_bit_cast(bf16x8, sd[idx % SDEP]);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] += (float)x[k];
+            }
+            bst8_aux<GD_PERSIST_STORE_AUX>(crs, col0 < p.N ? (int)((long)rl * p.ldc * csz + (long)col0 * csz) : OOB, cdt, v);
+            if (pre && idx + SDEP < 2 * WMT) side_load(idx + SDEP);
+        }
+        if (p.probe) { const unsigned long long c = __builtin_amdgcn_s_memtime(); pe += c - pc0; pn += 1; }
+        if (!more) break;
+    }
+    if (p.probe && tid == 0) {
+        atomicAdd(p.probe + 0, pw); atomicAdd(p.probe + 1, pm); atomicAdd(p.probe + 2, pe); atomicAdd(p.probe + 3, pn); atomicAdd(p.probe + 4, pd);
+    }
+}

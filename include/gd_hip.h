@@ -23,6 +23,12 @@ extern "C" {
 const char* gd_last_error(void);
 int gd_abi_version(void);
 
+/* Diagnostic (no reference counterpart): per-phase shader-clock cycles of the persistent gemm_nt kernel.
+ * enable=1 arms the probe for subsequent gd_gemm_nt calls, enable=0 disarms it; out5 (host, may be NULL) receives the
+ * sums over blocks since arming: [0] waiting for a tile's first K stage, [1] main loop, [2] epilogue items,
+ * [3] tiles, [4] epilogue set-up + next-tile DMA issue. */
+int gd_gemm_phase_probe(int enable, unsigned long long* out5);
+
 /* C[M,N] = epilogue(alpha * A[M,K] . W[N,K]^T); replaces torch nn.Linear / torch.bmm on the student path
  * (timm VisionTransformer qkv/proj/fc1/fc2, utils/model.py:57-71 LoRA, :7-25 Adapter; src/finetune_timm_vggt.py:516-517).
  * Epilogue order: +bias[N](f32) -> +lora_t[M,rt].lora_b[rt,N](f32, rt<=8) -> store preact -> act(1 GELU erf,2 ReLU)

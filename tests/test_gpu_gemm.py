@@ -51,6 +51,35 @@ def test_gemm_nt_epilogues(dtype, tol):
     assert acc.dtype == torch.float32 and rel_err(acc, want) < tol
 
 
+@pytest.mark.parametrize("M,N,K", [(1500, 512, 256), (20000, 1024, 192), (1100, 768, 64)])
+def test_gemm_nt_persistent_epilogues(M, N, K):
+    """the 256x256 persistent kernel (bf16 operands, M >= 1024, N >= 256): every compile-time epilogue it is instantiated
+    for, ragged last row tile, several tiles per block (20000 x 1024 -> 316 tiles on 256 CUs)."""
+    from gd_amd import ops
+    dt, tol = torch.bfloat16, 2e-2
+    a, w = _mk((M, K), dt, 21), _mk((N, K), dt, 22)
+    bias = _mk((N,), torch.float32, 23)
+    lt, lb = _mk((M, 8), torch.float32, 24), _mk((8, N), torch.float32, 25)
+    res, src = _mk((M, N), dt, 26), _mk((M, N), dt, 27)
+    plain = a.double() @ w.double().t()
+    gelu = torch.nn.functional.gelu
+    assert rel_err(ops.gemm_nt(a, w), plain) < tol
+    assert rel_err(ops.gemm_nt(a, w, alpha=0.5, bias=bias), 0.5 * plain + bias.double()) < tol
+    assert rel_err(ops.gemm_nt(a, w, out_dtype=torch.float32, bias=bias), plain + bias.double()) < 1e-5
+    lora = lt.double() @ lb.double()
+    assert rel_err(ops.gemm_nt(a, w, bias=bias, lora_t=lt, lora_b=lb), plain + bias.double() + lora) < tol
+    assert rel_err(ops.gemm_nt(a, w, alpha=0.25, lora_t=lt, lora_b=lb), 0.25 * plain + lora) < tol
+    assert rel_err(ops.gemm_nt(a, w, bias=bias, act=1), gelu(plain + bias.double())) < tol
+    pre = torch.empty(M, N, dtype=dt, device="cuda")
+    out = ops.gemm_nt(a, w, bias=bias, preact=pre, act=1)
+    assert rel_err(pre, plain + bias.double()) < tol and rel_err(out, gelu(plain + bias.double())) < tol
+    x = src.double().requires_grad_(True)
+    gelu(x).sum().backward()
+    assert rel_err(ops.gemm_nt(a, w, dact_src=src, dact=1), plain * x.grad) < tol
+    assert rel_err(ops.gemm_nt(a, w, bias=bias, residual=res), plain + bias.double() + res.double()) < tol
+    assert rel_err(ops.gemm_nt(a, w, residual=res), plain + res.double()) < tol
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 1e-2)])
 def test_gemm_nt_batched_strided(dtype, tol):
     from gd_amd import ops

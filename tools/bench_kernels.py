@@ -110,6 +110,34 @@ def bench_attn():
     print(f"attn bwd  {t*1e6:8.1f} us  {2.5*fl/t/1e12:7.1f} TF/s (algorithmic 5 products)")
 
 
+def probe_gemm():
+    """phase split of the persistent gemm_nt kernel (gd_gemm_phase_probe): cycles per tile in each phase."""
+    import ctypes
+    from gd_amd import _lib
+    L = _lib.lib()
+    out = (ctypes.c_ulonglong * 5)()
+    cases = [("a0", 87680, 3072, 768, {}), ("a0", 87680, 768, 3072, {}), ("a0", 87680, 768, 768, {}),
+             ("ba1", 87680, 3072, 768, dict(bias=True, act=1)), ("bpa1", 87680, 3072, 768, dict(bias=True, act=1, preact=True)),
+             ("da0", 87680, 3072, 768, dict(dact=True)), ("bra0", 87680, 768, 3072, dict(bias=True, residual=True))]
+    for tag, M, N, K, o in cases:
+        a = torch.randn(M, K, device="cuda").bfloat16()
+        w = torch.randn(N, K, device="cuda").bfloat16()
+        out_t = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        kw = {}
+        if o.get("bias"): kw["bias"] = torch.randn(N, device="cuda")
+        if o.get("act"): kw["act"] = o["act"]
+        if o.get("preact"): kw["preact"] = torch.empty_like(out_t)
+        if o.get("dact"): kw.update(dact_src=torch.randn(M, N, device="cuda").bfloat16(), dact=1)
+        if o.get("residual"): kw["residual"] = torch.randn(M, N, device="cuda").bfloat16()
+        f = lambda: ops.gemm_nt(a, w, out=out_t, **kw)
+        t = timeit(f)
+        L.gd_gemm_phase_probe(1, None)
+        f()
+        L.gd_gemm_phase_probe(0, out)
+        n = max(out[3], 1)
+        print(f"probe {tag:5s} {M}x{N}x{K}: {t*1e6:7.1f} us {2*M*N*K/t/1e12:7.1f} TF/s | per tile (100 MHz ticks?) wait {out[0]/n:8.1f}  main {out[1]/n:8.1f}  dma-issue {out[4]/n:8.1f}  epi {out[2]/n:8.1f}  tiles/blk {n/256:5.2f}")
+
+
 def pmc_attn():
     B, N, H = 64, 1370, 12
     qkv = torch.randn(B * N, 3 * H * 64, device="cuda").bfloat16()
@@ -140,6 +168,8 @@ if __name__ == "__main__":
         pmc_cv()
     if "attn" in which:
         bench_attn()
+    if "probe" in which:
+        probe_gemm()
     if "pmc_attn" in which:
         pmc_attn()
     if "pmc_gemm" in which:
