@@ -89,6 +89,9 @@ __device__ __forceinline__ void bst8_aux(__amdgpu_buffer_rsrc_t rs, int off, int
 #ifndef GD_PERSIST_STORE_AUX
 #define GD_PERSIST_STORE_AUX 18
 #endif
+#ifndef GD_PERSIST_SIDE_AUX
+#define GD_PERSIST_SIDE_AUX 2     // side tensors are read once: stream them past the L2's operand panels
+#endif
 
 // Compile-time epilogue: SIDE 0 none | 1 v *= dGELU(dact_src) | 2 v += residual (bf16 side tensor, prefetched);
 // ACT 0 none | 1 GELU | 2 ReLU; PREACT store v before the activation; CF32 C / preact are f32 (else bf16).
@@ -188,7 +191,6 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
     if (nk > 1) issue(1, 1);
     // VMEM instructions every wave issues unconditionally in one epilogue (buffer ops, range-checked by the hardware)
     constexpr int cper = CF32 ? 2 : 1;
-    constexpr int ep_ops = 2 * WMT * (cper + (PREACT ? cper : 0) + (pre ? 1 : 0));
     int after = 0;   // of those, how many were issued after this tile's stage-1 DMA (0 for the block's first tile)
 
     unsigned long long pc0 = 0, pw = 0, pm = 0, pe = 0, pn = 0, pd = 0;
@@ -273,29 +275,35 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
         auto side_load = [&](int idx) {   // idx = u * WMT + i
             const int col0 = cbase + (idx / WMT) * 32;
             const int off = col0 < p.N ? (int)((long)(rloc + (idx % WMT) * 16) * side_ld * 2 + col0 * 2) : OOB;
-            sd[idx % SDEP] = __builtin_amdgcn_raw_buffer_load_b128(srs, off, 0, 0);
+            sd[idx % SDEP] = __builtin_amdgcn_raw_buffer_load_b128(srs, off, 0, GD_PERSIST_SIDE_AUX);
         };
         if (pre) {
 #pragma unroll
             for (int idx = 0; idx < SDEP; ++idx) side_load(idx);
         }
-        // ---- the ring is free: start the next tile's pipeline before this tile's epilogue ----
+        // ---- the ring is free: the next tile's pipeline starts before (SIDE 0) or in the middle of (SIDE 1/2) this
+        // tile's epilogue.  VMEM retires in issue order, so a side load younger than the DMA could only be consumed once the
+        // whole prefetch has landed: with a side tensor all 2*WMT side loads go out first (SDEP up front, the rest
+        // while items 0..DMA_AT-1 are processed) and the DMA follows at item DMA_AT.
+        constexpr int DMA_AT = pre ? 2 * WMT - SDEP : 0;
         t += gridDim.x;
         const bool more = t < ntiles;
-        if (more) {
-            wg = xcd_remap(t, ntiles);
-            tm = wg / tiles_n; tn = wg % tiles_n; slot ^= 1;
-            set_tile(tm, tn);
-            issue(0, 0);
-            issue_side(tm, tn, slot);
-            if (nk > 1) issue(1, 1);
-        }
-        asm volatile("" ::: "memory");            // nothing of the epilogue may be hoisted above the DMA: `after` counts on it
-        if (p.probe) { const unsigned long long c = __builtin_amdgcn_s_memtime(); pd += c - pc0; pc0 = c; }
-        after = ep_ops - (pre ? SDEP : 0);        // epilogue VMEM instructions younger than the stage-1 DMA
+        after = (2 * WMT - DMA_AT) * (cper + (PREACT ? cper : 0));   // epilogue VMEM instructions younger than the stage-1 DMA
 #pragma unroll
         for (int idx = 0; idx < 2 * WMT; ++idx) {
             const int i = idx % WMT, u = idx / WMT;
+            if (idx == DMA_AT) {
+                if (more) {
+                    wg = xcd_remap(t, ntiles);
+                    tm = wg / tiles_n; tn = wg % tiles_n; slot ^= 1;
+                    set_tile(tm, tn);
+                    issue(0, 0);
+                    issue_side(tm, tn, slot);
+                    if (nk > 1) issue(1, 1);
+                }
+                asm volatile("" ::: "memory");   // nothing younger may be hoisted above the DMA: `after` counts on it
+                if (p.probe) { const unsigned long long c = __builtin_amdgcn_s_memtime(); pd += c - pc0; pc0 = c; }
+            }
             const int rl = rloc + i * 16, row = ctm * BM + rl, col0 = cbase + u * 32;
             if (i == 0) {
                 b0 = f32x4{0.f, 0.f, 0.f, 0.f}; b1 = b0;
@@ -311,7 +319,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
                 v[k] = fmaf(p.alpha, acc[i][2 * u][k], b0[k]);
                 v[4 + k] = fmaf(p.alpha, acc[i][2 * u + 1][k], b1[k]);
             }
-            if (PREACT) bst8_aux<0>(prs, col0 < p.N ? (int)((long)rl * p.ldp * csz + (long)col0 * csz) : OOB, cdt, v);
+            if (PREACT) bst8_aux<GD_PERSIST_STORE_AUX>(prs, col0 < p.N ? (int)((long)rl * p.ldp * csz + (long)col0 * csz) : OOB, cdt, v);
             if (ACT == 1) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[k] = CF32 ? gelu_f(v[k]) : gelu_fast(v[k]);

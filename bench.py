@@ -132,7 +132,7 @@ def main():
         if prof:
             fl, ms, n = prof.totals()
             ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            out["roofline"] = {"kernel": f"gemm_nt_kernel<{args.dtype}>", "bound": "mfma", "achieved": round(ach, 2),
+            out["roofline"] = {"kernel": f"gd_gemm_nt<{args.dtype}> (gemm_nt_persist_kernel 256x256 + gemm_nt_kernel 128x128)", "bound": "mfma", "achieved": round(ach, 2),
                                "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                                "frac": round(ach / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
                                "launches": n, "avg_launch_us": round(ms / max(n, 1) * 1e3, 2),
