@@ -16,6 +16,7 @@
 // vggt/layers/attention.py:51-71): softmax((q*scale) k^T) v with scale = head_dim^-0.5.
 // qkv is the packed [B, N, 3, H, 64] output of the QKV GEMM; o is [B, N, H*64]; lse is [B, H, N] (natural log).
 #include "gd_common.h"
+#include <type_traits>
 
 #define HD 64
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // bare v_exp_f32
@@ -157,7 +158,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* qkv, T* o, fl
     TileRegs<T> rk, rv;
     tile_load<T>(rk, kb, ld_b, 0, N);
     tile_load<T>(rv, vb, ld_b, 0, N);
-    for (int k0 = 0; k0 < N; k0 += 64) {
+    // one 64-key tile; TAIL (compile-time) = the partial last tile, the only one whose keys need masking — as a run-time
+    // flag the mask was if-converted into 60 compare/select instructions in EVERY tile of a VALU-bound loop
+    auto key_tile = [&](int k0, auto tail_tag) {
+        constexpr bool tail = decltype(tail_tag)::value;
         __syncthreads();
         tile_store<T, true, false>(rk, sK, nullptr);
         tile_store<T, !TOp<T>::kNeedT, TOp<T>::kNeedT>(rv, sV, sVt);
@@ -181,8 +185,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* qkv, T* o, fl
             }
         }
         // online softmax in the exp2 domain: p = 2^(s*c2 - m2), c2 = scale*log2(e) — one FMA + one v_exp per score;
-        // key masking only on the (wave-uniform) partial last tile; O is rescaled only when some row maximum moved.
-        const bool tail = k0 + 64 > N;
+        // O is rescaled only when some row maximum moved.
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
             float tmax = -1e30f;
@@ -228,7 +231,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* qkv, T* o, fl
                 for (int qt = 0; qt < 2; ++qt) oacc[dt][qt] = Mma<T>::mma(vf, pf[qt], oacc[dt][qt]);
             }
         }
-    }
+    };
+    int k0 = 0;
+    for (; k0 + 64 <= N; k0 += 64) key_tile(k0, std::false_type{});
+    if (k0 < N) key_tile(k0, std::true_type{});
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         const int q = q0 + qt * 16 + c;
@@ -319,7 +325,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const T* qkv, const
             tile_load<T>(rv, vb, ld_b, k0 + 64, N);
         }
         f32x4 ds[2][4];
-        const bool tail = k0 + 64 > N;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
             Frag kf[NF], vf[NF];
@@ -338,8 +343,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const T* qkv, const
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float p = fast_exp2(fmaf(s[r], c2, -lq[qt]));
-                    if (tail && k0 + kt * 16 + g * 4 + r >= N) p = 0.f;
+                    // keys >= N need no mask: their K rows are staged as zeros, so whatever dS they get never reaches dQ
+                    const float p = fast_exp2(fmaf(s[r], c2, -lq[qt]));
                     ds[qt][kt][r] = p * (dp[r] - dl[qt]);          // the 1/sqrt(d) factor is applied once, to dQ
                 }
             }
@@ -411,9 +416,11 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const T* qkv, con
     tile_load<T, NT>(rq, qb, ld_b, 0, N);
     tile_load<T, NT>(rd, dob, ldo_b, 0, N);
     float rl = 0.f, rdl = 0.f;   // next tile's lse / delta rows, prefetched with the tile
-    if (threadIdx.x < 64 && threadIdx.x < N) {
-        rl = lse[((long)b * H + h) * N + threadIdx.x];
-        rdl = delta[((long)b * H + h) * N + threadIdx.x];
+    // queries >= N: lse = +1e30 makes p = 2^(0 - 1e30) = 0 (their Q / dO rows are staged as zeros) — no mask in the loop
+    const float LSE_PAD = 1e30f;
+    if (threadIdx.x < 64) {
+        rl = threadIdx.x < N ? lse[((long)b * H + h) * N + threadIdx.x] : LSE_PAD;
+        rdl = threadIdx.x < N ? delta[((long)b * H + h) * N + threadIdx.x] : 0.f;
     }
     for (int q0 = 0; q0 < N; q0 += 64) {
         __syncthreads();
@@ -426,12 +433,11 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const T* qkv, con
         if (threadIdx.x < 64) { sL[threadIdx.x] = rl * 1.4426950408889634f; sDl[threadIdx.x] = rdl; }   // lse in log2 units
         if (q0 + 64 < N && threadIdx.x < 64) {
             const int q = q0 + 64 + threadIdx.x;
-            rl = q < N ? lse[((long)b * H + h) * N + q] : 0.f;
+            rl = q < N ? lse[((long)b * H + h) * N + q] : LSE_PAD;
             rdl = q < N ? delta[((long)b * H + h) * N + q] : 0.f;
         }
         __syncthreads();
         f32x4 pp[2][4], dsv[2][4];  // [key tile][query tile]
-        const bool tail = q0 + 64 > N;
 #pragma unroll
         for (int qt = 0; qt < 4; ++qt) {
             Frag qf[NF], df[NF];
@@ -451,8 +457,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const T* qkv, con
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int ql = qt * 16 + g * 4 + r;
-                    float p = fast_exp2(fmaf(s[r], c2, -sL[ql]));
-                    if (tail && q0 + ql >= N) p = 0.f;
+                    const float p = fast_exp2(fmaf(s[r], c2, -sL[ql]));
                     pp[kt][qt][r] = p;
                     dsv[kt][qt][r] = p * (dp[r] - sDl[ql]);        // the 1/sqrt(d) factor is applied once, to dK
                 }

@@ -2,6 +2,7 @@
 // relative-depth head (a12) with its L1 term and the pairwise logistic ranking loss (a10/a11).
 // All fp32: with temperature 0.01 the smooth-AP sigmoids are numerically fragile, and N is small.
 #include "gd_common.h"
+#include <stdlib.h>
 
 // ---------------------------------------------------------------------------------------------------
 // smooth-AP (src/finetune_timm_vggt.py:543-572 variant 0, src/finetune_timm_mast3r.py:560-589 variant 1;
@@ -225,6 +226,169 @@ __global__ __launch_bounds__(256) void pair_rank_kernel(const float* u, const fl
     }
 }
 
+// ---- the same loss with EIGHT lanes per pair (16 of the 128 head channels per lane, 8 pairs per wave-instruction).
+// The wave-per-pair kernel above spends most of its instructions on 64-lane reductions (5 per head evaluation) and on
+// tanh / exp / log1p replicated over 64 lanes; here a reduction is 3 DPP steps inside an 8-lane group and the scalar
+// tail is shared by 8 pairs.  Measured on MI355X (64 sets x 300 keypoints): 3.78 ms -> see profiles/README.md.
+__device__ __forceinline__ float oct_sum(float v) {   // sum over the lane's 8-lane group, result in all 8 lanes
+    v += dpp_f32<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+    v += dpp_f32<0x141, 0xF>(v);   // row_half_mirror
+    return v;
+}
+
+struct Head8 { float yh[16], dg[16], a[16], rstd, s; };
+
+// z = sign * d + b1 ; returns s = tanh(w2 . GELU(LN(z)) + b2) and caches what the backward needs
+__device__ __forceinline__ float head8_eval(const float (&d)[16], float sign, const float (*sh)[128], int k0, float hb2, Head8& c) {
+    float z[16], sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { z[e] = fmaf(sign, d[e], sh[0][k0 + e]); sum += z[e]; }
+    const float mu = oct_sum(sum) * (1.0f / 128.0f);
+    float var = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { z[e] -= mu; var = fmaf(z[e], z[e], var); }
+    c.rstd = rsqrtf(oct_sum(var) * (1.0f / 128.0f) + 1e-5f);
+    float o = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        c.yh[e] = z[e] * c.rstd;
+        const float y = fmaf(c.yh[e], sh[1][k0 + e], sh[2][k0 + e]);
+        float Phi, ex;
+        gelu_parts(y, Phi, ex);
+        c.a[e] = y * Phi;
+        c.dg[e] = Phi + y * ex * 0.39894228040143268f;
+        o = fmaf(c.a[e], sh[3][k0 + e], o);
+    }
+    c.s = tanhf(oct_sum(o) + hb2);
+    return c.s;
+}
+
+template <bool ACC>
+__device__ __forceinline__ void head8_back(float dLds, const float (*sh)[128], int k0, const Head8& c, float (&dz)[16],
+                                           float (*acc)[16], float& acc_b2) {
+    const float dof = dLds * (1.0f - c.s * c.s);
+    float dyh[16], m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const float dy = dof * sh[3][k0 + e] * c.dg[e];
+        dyh[e] = dy * sh[1][k0 + e];
+        m1 += dyh[e];
+        m2 = fmaf(dyh[e], c.yh[e], m2);
+        if (ACC) { acc[1][e] = fmaf(dy, c.yh[e], acc[1][e]); acc[2][e] += dy; acc[3][e] = fmaf(dof, c.a[e], acc[3][e]); }
+    }
+    if (ACC) acc_b2 += dof;
+    m1 = oct_sum(m1) * (1.0f / 128.0f);
+    m2 = oct_sum(m2) * (1.0f / 128.0f);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        dz[e] = c.rstd * (dyh[e] - m1 - c.yh[e] * m2);
+        if (ACC) acc[0][e] += dz[e];
+    }
+}
+
+__global__ __launch_bounds__(256) void pair_rank8_kernel(const float* u, const float* depth, const int* counts,
+                                                         const float* b1, const float* lw, const float* lb,
+                                                         const float* w2, const float* b2, float* du, float* hg,
+                                                         float* loss_sum, int* pair_cnt, int Nmax, float thr) {
+    __shared__ __attribute__((aligned(16))) float sh[4][128];   // b1, ln_w, ln_b, w2
+    __shared__ float sacc[4][5][128];
+    __shared__ float sred[4][2];
+    __shared__ int scnt[4];
+    const int set = blockIdx.y, i = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane & 7, ps = lane >> 3, k0 = sub * 16;
+    const int n = counts ? counts[set] : Nmax;
+    float* dui = du + ((long)set * Nmax + i) * 128;
+    if (i >= n) {
+        if (threadIdx.x < 128) dui[threadIdx.x] = 0.f;
+        return;
+    }
+    if (threadIdx.x < 128) {
+        sh[0][threadIdx.x] = b1[threadIdx.x]; sh[1][threadIdx.x] = lw[threadIdx.x];
+        sh[2][threadIdx.x] = lb[threadIdx.x]; sh[3][threadIdx.x] = w2[threadIdx.x];
+    }
+    __syncthreads();
+    const float hb2 = b2[0];
+    const float* ub = u + (long)set * Nmax * 128;
+    float ui[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = *(const f32x4*)(ub + (long)i * 128 + k0 + 4 * q);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ui[4 * q + k] = v[k];
+    }
+    const float di = depth[(long)set * Nmax + i];
+    float acc[4][16], dacc[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc[0][e] = acc[1][e] = acc[2][e] = acc[3][e] = 0.f; dacc[e] = 0.f; }
+    float acc_b2 = 0.f, lsum = 0.f;
+    int cnt = 0;
+    for (int jb = wave * 8; jb < n; jb += 32) {
+        const int j = jb + ps;
+        const bool inr = j < n;
+        const float dd = inr ? depth[(long)set * Nmax + j] - di : 0.f;   // d_j - d_i
+        const bool valid = inr && fabsf(dd) > thr;
+        if (!__any(valid)) continue;
+        const float alpha = dd > 0.f ? 1.f : -1.f, vf = valid ? 1.f : 0.f;
+        float d[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (inr) v = *(const f32x4*)(ub + (long)j * 128 + k0 + 4 * q);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d[4 * q + k] = v[k] - ui[4 * q + k];
+        }
+        Head8 c;
+        float dz[16];
+        // pair (i, j): z = u_j - u_i + b1, alpha_ij = sign(d_j - d_i)
+        float s = head8_eval(d, 1.0f, sh, k0, hb2, c);
+        lsum += vf * log1pf(expf(-alpha * s));
+        head8_back<true>(vf * (-alpha / (1.0f + expf(alpha * s))), sh, k0, c, dz, acc, acc_b2);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dacc[e] -= dz[e];
+        cnt += valid ? 1 : 0;
+        // mirrored pair (j, i): z' = u_i - u_j + b1, alpha_ji = -alpha; only its dz reaches du_i
+        s = head8_eval(d, -1.0f, sh, k0, hb2, c);
+        head8_back<false>(vf * (alpha / (1.0f + expf(-alpha * s))), sh, k0, c, dz, nullptr, acc_b2);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dacc[e] += dz[e];
+    }
+    // sum the 8 pair slots of the wave (lanes with equal sub), then the 4 waves through LDS
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) {
+            dacc[e] += __shfl_xor(dacc[e], o, 64);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t][e] += __shfl_xor(acc[t][e], o, 64);
+        }
+    }
+    if (ps == 0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            sacc[wave][0][k0 + e] = dacc[e];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) sacc[wave][1 + t][k0 + e] = acc[t][e];
+        }
+    }
+    // per-pair scalars live replicated in the 8 lanes of a group: count them once
+    const float b2s = wave_sum(sub == 0 ? acc_b2 : 0.f), ls = wave_sum(sub == 0 ? lsum : 0.f);
+    const float cs = wave_sum(sub == 0 ? (float)cnt : 0.f);
+    if (lane == 0) { sred[wave][0] = b2s; sred[wave][1] = ls; scnt[wave] = (int)(cs + 0.5f); }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 5 * 128; idx += 256) {
+        const int t = idx >> 7, k = idx & 127;
+        const float v = sacc[0][t][k] + sacc[1][t][k] + sacc[2][t][k] + sacc[3][t][k];
+        if (t == 0) dui[k] = v;
+        else atomicAdd(hg + (long)set * HG_SIZE + (t - 1) * 128 + k, v);
+    }
+    if (threadIdx.x == 0) {
+        atomicAdd(hg + (long)set * HG_SIZE + 512, sred[0][0] + sred[1][0] + sred[2][0] + sred[3][0]);
+        atomicAdd(loss_sum + set, sred[0][1] + sred[1][1] + sred[2][1] + sred[3][1]);
+        atomicAdd(pair_cnt + set, scnt[0] + scnt[1] + scnt[2] + scnt[3]);
+    }
+}
+
 // L1(head(f1 - f2), tanh(d1 - d2)) rows (src/finetune_timm_vggt.py:475-479): one wave per keypoint.
 // u holds [P][2][Nmax][128]; writes du for both views (du1 = +dz, du2 = -dz, scaled by gscale[p]/n),
 // head grads (scaled) into hg[p], loss_sum[p] += |s - t| / n.
@@ -318,8 +482,12 @@ extern "C" int gd_pair_rank(const float* u, const float* depth, const int* count
     float* lsum = hg + (long)S * HG_SIZE;
     int* cnt = (int*)(lsum + S);
     hipMemsetAsync(workspace, 0, gd_pair_rank_workspace_bytes(S), s);
-    hipLaunchKernelGGL(pair_rank_kernel, dim3(Nmax, S), dim3(256), 0, s, u, depth, counts, b1, ln_w, ln_b, w2, b2, du,
-                       hg, lsum, cnt, Nmax, depth_threshold);
+    static int wide = -1;   // GD_PAIR_RANK_WAVE=1 selects the older one-wave-per-pair kernel (A/B testing)
+    if (wide < 0) { const char* e = getenv("GD_PAIR_RANK_WAVE"); wide = e ? atoi(e) : 0; }
+    if (wide) hipLaunchKernelGGL(pair_rank_kernel, dim3(Nmax, S), dim3(256), 0, s, u, depth, counts, b1, ln_w, ln_b, w2, b2, du,
+                                 hg, lsum, cnt, Nmax, depth_threshold);
+    else hipLaunchKernelGGL(pair_rank8_kernel, dim3(Nmax, S), dim3(256), 0, s, u, depth, counts, b1, ln_w, ln_b, w2, b2, du,
+                            hg, lsum, cnt, Nmax, depth_threshold);
     hipLaunchKernelGGL(pair_rank_finalize_kernel, dim3(S), dim3(256), 0, s, du, hg, lsum, cnt, gscale, head_grad,
                        head_grad_sets, loss, Nmax);
     GD_LAUNCH_OK();

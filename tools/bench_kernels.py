@@ -110,6 +110,26 @@ def bench_attn():
     print(f"attn bwd  {t*1e6:8.1f} us  {2.5*fl/t/1e12:7.1f} TF/s (algorithmic 5 products)")
 
 
+def bench_rank():
+    """depth head losses at the bench shape: 32 pairs x 2 views x 300 keypoints, D = 768."""
+    P, N, D = 32, 300, 768
+    g = torch.Generator(device="cuda").manual_seed(0)
+    head = {"w1": torch.randn(128, D, device="cuda", generator=g) * 0.05, "b1": torch.zeros(128, device="cuda"),
+            "ln_w": torch.ones(128, device="cuda"), "ln_b": torch.zeros(128, device="cuda"),
+            "w2": torch.randn(1, 128, device="cuda", generator=g) * 0.1, "b2": torch.zeros(1, device="cuda")}
+    head = {k: v.requires_grad_(True) for k, v in head.items()}
+    feats = torch.randn(P, 2, N, D, device="cuda", generator=g).requires_grad_(True)
+    d1 = torch.rand(P, N, device="cuda", generator=g) * 3
+    d2 = torch.rand(P, N, device="cuda", generator=g) * 3
+
+    def f():
+        l1, intra = ops.depth_losses(feats, d1, d2, head)
+        return l1, intra
+    t = timeit(f)
+    l1, intra = f()
+    print(f"depth_losses fwd+bwd (fused): {t*1e6:8.1f} us   l1 {l1.mean().item():.6f} intra {intra.mean().item():.6f}")
+
+
 def probe_gemm():
     """phase split of the persistent gemm_nt kernel (gd_gemm_phase_probe): cycles per tile in each phase."""
     import ctypes
@@ -168,6 +188,8 @@ if __name__ == "__main__":
         pmc_cv()
     if "attn" in which:
         bench_attn()
+    if "rank" in which:
+        bench_rank()
     if "probe" in which:
         probe_gemm()
     if "pmc_attn" in which:
