@@ -563,6 +563,78 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmTnParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// gemm_tn for a SKINNY left operand (N <= 8, f32): the LoRA weight gradients  G[8, K] += T[M, 8]^T X[M, K].
+// HBM-bound (X is read once, 404 MB for the q/v LoRA of one block) and far too thin for MFMA tiles: the 64x64-tile
+// kernel above ran it at 1.6 TB/s.  Here a thread owns 8 consecutive columns of X (one 16-byte load per row) and all
+// 8 rows of G (64 fp32 accumulators); the T row is wave-uniform (scalar loads), rows are unrolled 8 deep so every wave
+// keeps 8 independent loads in flight; the block's partial is transposed through LDS once so the closing fp32 atomics
+// are lane-contiguous.
+// ------------------------------------------------------------------------------------------
+template <typename TX>
+__global__ __launch_bounds__(320) void gemm_tn_skinny_kernel(GemmTnParams p) {
+    __shared__ float sG[320 * 8];   // one G row of the block at a time
+    const int tid = threadIdx.x, nth = blockDim.x, kc = tid * 8;
+    const bool live = kc < p.K;
+    const float* __restrict__ Y = (const float*)p.Y;
+    const TX* __restrict__ X = (const TX*)p.X;
+    const int m_begin = blockIdx.y * p.mchunk, m_end = min(p.M, m_begin + p.mchunk);
+    float acc[8][8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[n][k] = 0.f;
+    constexpr int U = 8;
+    const int kcl = live ? kc : 0;   // threads past K read column 0 (their results are never written): no divergent load
+    auto load_x = [&](int m, float (&x)[8]) {
+        if (sizeof(TX) == 2) {
+            const bf16x8 v = *(const bf16x8*)((const bf16*)X + (long)m * p.ldx + kcl);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x[k] = (float)v[k];
+        } else {
+            const f32x4 a = *(const f32x4*)((const float*)X + (long)m * p.ldx + kcl), b = *(const f32x4*)((const float*)X + (long)m * p.ldx + kcl + 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { x[k] = a[k]; x[4 + k] = b[k]; }
+        }
+    };
+    int m0 = m_begin;
+    for (; m0 + U <= m_end; m0 += U) {   // full groups: the 8 T rows are one contiguous, wave-uniform 256-byte block (scalar loads, no branches)
+        float x[U][8];
+#pragma unroll
+        for (int r = 0; r < U; ++r) load_x(m0 + r, x[r]);
+        const float* __restrict__ trow = Y + (long)m0 * 8;
+#pragma unroll
+        for (int r = 0; r < U; ++r)
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+                const float t = trow[r * 8 + n];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[n][k] = fmaf(t, x[r][k], acc[n][k]);
+            }
+    }
+    for (; m0 < m_end; ++m0) {
+        float x[8];
+        load_x(m0, x);
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            const float t = Y[(long)m0 * 8 + n];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[n][k] = fmaf(t, x[k], acc[n][k]);
+        }
+    }
+    const int W = nth * 8;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        if (n >= p.N) break;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sG[kc + k] = acc[n][k];
+        __syncthreads();
+        for (int k = tid; k < W; k += nth)
+            if (k < p.K) atomicAdd(p.G + (long)n * p.ldg + k, p.alpha * sG[k]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------
 static bool gd_f32_big_tiles() {   // f32: the 128x128 config at 2 blocks/CU measured 125-138 TF/s vs 97-120 for 256x256
@@ -675,6 +747,17 @@ extern "C" int gd_gemm_tn(const void* Y, const void* X, float* G, int M, int N, 
     p.Y = Y; p.X = X; p.G = G; p.M = M; p.N = N; p.K = K; p.ldy = ldy; p.ldx = ldx; p.ldg = ldg;
     p.y_dtype = y_dtype; p.x_dtype = x_dtype; p.alpha = alpha; p.sY = sY; p.sX = sX; p.sG = sG;
     GD_REQUIRE(batch >= 1 && sY % 8 == 0 && sX % 8 == 0, "gd_gemm_tn: bad batch / batch strides");
+    if (N == 8 && ldy == 8 && y_dtype == GD_F32 && batch == 1 && K <= 2560 && ((uintptr_t)X & 15) == 0 && ((uintptr_t)Y & 15) == 0) {   // LoRA weight gradients
+        const int nth = gd_cdiv(gd_cdiv(K, 8), 64) * 64;
+        int mchunk = ((gd_cdiv(M, 512) + 7) / 8) * 8;   // 512 blocks (more, narrower chunks measured slower: 63 vs 56 us at K = 768)
+        if (mchunk < 64) mchunk = 64;
+        p.mchunk = mchunk;
+        dim3 grid(1, gd_cdiv(M, mchunk), 1);
+        if (x_dtype == GD_BF16) hipLaunchKernelGGL(gemm_tn_skinny_kernel<bf16>, grid, dim3(nth), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL(gemm_tn_skinny_kernel<float>, grid, dim3(nth), 0, (hipStream_t)stream, p);
+        GD_LAUNCH_OK();
+        return 0;
+    }
     const bool bf = y_dtype == GD_BF16 && x_dtype == GD_BF16 && N >= 64 && K >= 64;   // bf16 MFMA + transpose reads
     const int tl = bf ? 128 : 64;
     const int tiles = gd_cdiv(N, tl) * gd_cdiv(K, tl);

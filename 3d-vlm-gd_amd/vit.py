@@ -181,9 +181,12 @@ class _BlockFn(torch.autograd.Function):
             dt = ops.gemm_nt(dqkv, bt.to(T).contiguous(), out_dtype=torch.float32)                 # [M, 2r]
             gbt = ops.gemm_tn(t, dqkv)                                                            # [2r, 3D]
             gat = ops.gemm_tn(dt, y1)                                                             # [2r, D]
-            dy1 = ops.gemm_nt(dqkv, plan["wqkv_t"], lora_t=dt, lora_b=at.contiguous())            # dqkv.W + dt.At
             g_bq, g_bv = gbt[:r, :D].t().contiguous(), gbt[r:, 2 * D:].t().contiguous()
             g_aq, g_av = gat[:r].contiguous(), gat[r:].contiguous()
+        if not ctx.needs_input_grad[0]:   # first trainable block: nothing below it learns, skip dX (one GEMM + one LN backward)
+            return None, None, None, None, g_aq, g_bq, g_av, g_bv, g_down, g_up
+        if ctx.has_lora:
+            dy1 = ops.gemm_nt(dqkv, plan["wqkv_t"], lora_t=dt, lora_b=at.contiguous())            # dqkv.W + dt.At
         else:
             dy1 = ops.gemm_nt(dqkv, plan["wqkv_t"])
         dx = ops.layernorm_bwd(dy1, x, plan["ln1_w"], mean1, rstd1, dres=dx1)

@@ -110,6 +110,21 @@ def bench_attn():
     print(f"attn bwd  {t*1e6:8.1f} us  {2.5*fl/t/1e12:7.1f} TF/s (algorithmic 5 products)")
 
 
+def bench_tn():
+    M = 87680
+    for (N, K, ydt, xdt) in [(8, 2304, torch.float32, torch.bfloat16), (8, 768, torch.float32, torch.bfloat16),
+                             (768, 64, torch.bfloat16, torch.bfloat16), (64, 768, torch.bfloat16, torch.bfloat16)]:
+        y = torch.randn(M, N, device="cuda").to(ydt)
+        x = torch.randn(M, K, device="cuda").to(xdt)
+        out = torch.zeros(N, K, device="cuda")
+        t = timeit(lambda: ops.gemm_tn(y, x, out=out))
+        by = y.numel() * y.element_size() + x.numel() * x.element_size()
+        ref = y.double().t() @ x.double()
+        got = ops.gemm_tn(y, x)
+        err = float((got.double() - ref).norm() / ref.norm())
+        print(f"gemm_tn N={N:4d} K={K:5d}: {t*1e6:8.1f} us  {by/t/1e12:5.2f} TB/s  rel err {err:.2e}")
+
+
 def bench_rank():
     """depth head losses at the bench shape: 32 pairs x 2 views x 300 keypoints, D = 768."""
     P, N, D = 32, 300, 768
@@ -188,6 +203,8 @@ if __name__ == "__main__":
         pmc_cv()
     if "attn" in which:
         bench_attn()
+    if "tn" in which:
+        bench_tn()
     if "rank" in which:
         bench_rank()
     if "probe" in which:
