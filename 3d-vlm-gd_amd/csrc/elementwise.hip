@@ -79,6 +79,45 @@ __global__ __launch_bounds__(256) void im2col3x3_kernel(const T* x, long bstride
 }
 
 // dx[b][y][x][c] = sum_taps dcol[(b, y-ky+1, x-kx+1)][(ky*3+kx)*D + c]
+// 16 bytes of channels per thread; the nine taps are loaded UNCONDITIONALLY from clamped coordinates and zeroed by a
+// 0/1 weight (a load under `if (inside)` followed by its conversion compiles to load + s_waitcnt vmcnt(0) inside an
+// exec-masked block: nine serialised HBM latencies per element — this kernel ran at 1.6 TB/s that way).
+template <typename T>
+__global__ __launch_bounds__(256) void col2im3x3_vec_kernel(const T* dcol, T* dx, long bstride, int B, int gh, int gw, int D) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    const int dv = D / VEC;
+    const long total = (long)B * gh * gw * dv;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (idx % dv) * VEC;
+        const long row = idx / dv;
+        const int px = row % gw, py = (row / gw) % gh;
+        const long b = row / ((long)gw * gh);
+        uint4 v[9];
+        float w[9];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yy = py - (tap / 3 - 1), xx = px - (tap % 3 - 1);
+            w[tap] = (yy >= 0 && yy < gh && xx >= 0 && xx < gw) ? 1.f : 0.f;
+            const int yc = min(max(yy, 0), gh - 1), xc = min(max(xx, 0), gw - 1);
+            v[tap] = *(const uint4*)(dcol + (((b * gh + yc) * gw + xc) * 9 + tap) * D + c);
+        }
+        float acc[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const T* e = (const T*)&v[tap];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[k] = fmaf(w[tap], to_f32<T>(e[k]), acc[k]);
+        }
+        uint4 o;
+        T* oe = (T*)&o;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) oe[k] = from_f32<T>(acc[k]);
+        *(uint4*)(dx + b * bstride + ((long)py * gw + px) * D + c) = o;
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void col2im3x3_kernel(const T* dcol, T* dx, long bstride, int B, int gh, int gw,
                                                         int D) {
@@ -310,6 +349,16 @@ extern "C" int gd_im2col3x3(const void* x, long bstride, void* col, int B, int g
 extern "C" int gd_col2im3x3(const void* dcol, void* dx, long bstride, int B, int gh, int gw, int D, int dtype,
                             void* stream) {
     GD_REQUIRE(B > 0 && gh > 0 && gw > 0 && D > 0, "gd_col2im3x3: bad shape");
+    const int es = gd_dtype_size(dtype);
+    if ((D * es) % 16 == 0 && (bstride * es) % 16 == 0 && ((uintptr_t)dcol & 15) == 0 && ((uintptr_t)dx & 15) == 0) {
+        const long totalv = (long)B * gh * gw * (D / (16 / es));
+        if (dtype == GD_BF16)
+            hipLaunchKernelGGL(col2im3x3_vec_kernel<bf16>, dim3(ew_blocks(totalv)), dim3(256), 0, (hipStream_t)stream, (const bf16*)dcol, (bf16*)dx, bstride, B, gh, gw, D);
+        else
+            hipLaunchKernelGGL(col2im3x3_vec_kernel<float>, dim3(ew_blocks(totalv)), dim3(256), 0, (hipStream_t)stream, (const float*)dcol, (float*)dx, bstride, B, gh, gw, D);
+        GD_LAUNCH_OK();
+        return 0;
+    }
     const long total = (long)B * gh * gw * D;
     if (dtype == GD_BF16)
         hipLaunchKernelGGL(col2im3x3_kernel<bf16>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, (const bf16*)dcol, (bf16*)dx, bstride, B, gh, gw, D);
