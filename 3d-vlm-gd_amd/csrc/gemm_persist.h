@@ -38,25 +38,39 @@ __device__ __forceinline__ void mma_row(f32x4 (&acc)[4], f32x4 a, f32x4 b0, f32x
     acc[3] = Mma<T>::mma(__builtin_bit_cast(Frag, b3), fa, acc[3]);
 }
 
-// one 64-byte K chunk of the 128 x 64 wave tile: 12 fragment reads, 32 (transposed) MFMAs
+// One 64-byte K chunk of the 128 x 64 wave tile = 12 fragment reads + 32 (transposed) MFMAs, software-pipelined:
+// the FIRST six fragment reads of a chunk (b0..b3, a0, a1) are issued
+// before the previous chunk's last two MFMA rows, and — across a K step — right after the stage barrier, which itself
+// moves up to the point where the wave's LDS reads of the stage are complete (the eight MFMAs that follow need
+// registers only).  The read latency at the head of every chunk and the barrier skew then sit under MFMA work instead
+// of in front of it.  Register cost: none — the prefetched set reuses the registers of a0..a5, dead by then.
+struct FragHead { f32x4 b0, b1, b2, b3, a0, a1; };
+__device__ __forceinline__ void frag_head_issue(FragHead& h, unsigned aaddr, unsigned baddr) {
+    GD_DSR128(h.b0, baddr, 0); GD_DSR128(h.b1, baddr, 2048); GD_DSR128(h.b2, baddr, 4096); GD_DSR128(h.b3, baddr, 6144);
+    GD_DSR128(h.a0, aaddr, 0); GD_DSR128(h.a1, aaddr, 2048);
+}
+struct FragTail { f32x4 a6, a7; };
+// rows 0..5 of a chunk whose head is already in flight; returns with a6, a7 landed (every LDS read of the chunk done)
 template <typename T>
-__device__ __forceinline__ void chunk_mma(unsigned aaddr, unsigned baddr, f32x4 (&acc)[8][4]) {
-    f32x4 b0, b1, b2, b3, a0, a1, a2, a3, a4, a5, a6, a7;
-    GD_DSR128(b0, baddr, 0); GD_DSR128(b1, baddr, 2048); GD_DSR128(b2, baddr, 4096); GD_DSR128(b3, baddr, 6144);
-    GD_DSR128(a0, aaddr, 0); GD_DSR128(a1, aaddr, 2048); GD_DSR128(a2, aaddr, 4096); GD_DSR128(a3, aaddr, 6144);
-    GD_DSR128(a4, aaddr, 8192); GD_DSR128(a5, aaddr, 10240); GD_DSR128(a6, aaddr, 12288); GD_DSR128(a7, aaddr, 14336);
-    asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(a0), "+v"(a1));
-    mma_row<T>(acc[0], a0, b0, b1, b2, b3);
-    mma_row<T>(acc[1], a1, b0, b1, b2, b3);
+__device__ __forceinline__ void chunk_rows05(FragHead& h, FragTail& t, unsigned aaddr, f32x4 (&acc)[8][4]) {
+    f32x4 a2, a3, a4, a5;
+    GD_DSR128(a2, aaddr, 4096); GD_DSR128(a3, aaddr, 6144); GD_DSR128(a4, aaddr, 8192); GD_DSR128(a5, aaddr, 10240);
+    GD_DSR128(t.a6, aaddr, 12288); GD_DSR128(t.a7, aaddr, 14336);
+    asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(h.b0), "+v"(h.b1), "+v"(h.b2), "+v"(h.b3), "+v"(h.a0), "+v"(h.a1));
+    mma_row<T>(acc[0], h.a0, h.b0, h.b1, h.b2, h.b3);
+    mma_row<T>(acc[1], h.a1, h.b0, h.b1, h.b2, h.b3);
     asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a2), "+v"(a3));
-    mma_row<T>(acc[2], a2, b0, b1, b2, b3);
-    mma_row<T>(acc[3], a3, b0, b1, b2, b3);
+    mma_row<T>(acc[2], a2, h.b0, h.b1, h.b2, h.b3);
+    mma_row<T>(acc[3], a3, h.b0, h.b1, h.b2, h.b3);
     asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a4), "+v"(a5));
-    mma_row<T>(acc[4], a4, b0, b1, b2, b3);
-    mma_row<T>(acc[5], a5, b0, b1, b2, b3);
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a6), "+v"(a7));
-    mma_row<T>(acc[6], a6, b0, b1, b2, b3);
-    mma_row<T>(acc[7], a7, b0, b1, b2, b3);
+    mma_row<T>(acc[4], a4, h.b0, h.b1, h.b2, h.b3);
+    mma_row<T>(acc[5], a5, h.b0, h.b1, h.b2, h.b3);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t.a6), "+v"(t.a7));
+}
+template <typename T>
+__device__ __forceinline__ void chunk_rows67(const FragHead& h, const FragTail& t, f32x4 (&acc)[8][4]) {
+    mma_row<T>(acc[6], t.a6, h.b0, h.b1, h.b2, h.b3);
+    mma_row<T>(acc[7], t.a7, h.b0, h.b1, h.b2, h.b3);
 }
 
 // wait until at most n vector-memory operations of this wave are outstanding (n rounded DOWN to a multiple of 8:
@@ -241,18 +255,24 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
             GD_LT(0, 0) GD_LT(1, 512) GD_LT(2, 1024) GD_LT(3, 1536) GD_LT(4, 2048) GD_LT(5, 2560) GD_LT(6, 3072) GD_LT(7, 3584)
 #undef GD_LT
         }
+        const int co0 = ((g ^ sa) * 16), co1 = (((4 + g) ^ sa) * 16);
+        FragHead P, Q;
+        FragTail tl;
+        frag_head_issue(P, lds0 + abase + co0, lds0 + bbase + co0);
         for (int kt = 0; kt < nk; ++kt) {
-            if (kt >= 1 && kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);   // (stage 1 went out together with stage 0)
-            const unsigned sbo = lds0 + (kt & 1) * STAGE;
-#pragma unroll
-            for (int kc = 0; kc < 2; ++kc) {
-                const int co = (((kc * 4 + g) ^ sa) * 16);
-                chunk_mma<T>(sbo + abase + co, sbo + bbase + co, acc);
-            }
+            const unsigned sbo = lds0 + (kt & 1) * STAGE, nsbo = lds0 + ((kt + 1) & 1) * STAGE;
+            chunk_rows05<T>(P, tl, sbo + abase + co0, acc);
+            frag_head_issue(Q, sbo + abase + co1, sbo + bbase + co1);
+            chunk_rows67<T>(P, tl, acc);
+            chunk_rows05<T>(Q, tl, sbo + abase + co1, acc);
+            // every LDS read of stage kt is done: stage barrier (stage kt+1 landed, slot kt&1 free), then refill the slot
             if (kt == 0) wait_vm_le(after);   // stage 1 is older than the previous epilogue's stores: those may still drain
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            if (kt + 2 < nk) issue(kt + 2, kt & 1);
+            if (kt + 1 < nk) frag_head_issue(P, nsbo + abase + co0, nsbo + bbase + co0);
+            chunk_rows67<T>(Q, tl, acc);
         }
         const int ctm = tm, ctn = tn, cslot = slot;
         if (p.probe) { const unsigned long long c = __builtin_amdgcn_s_memtime(); pm += c - pc0; pc0 = c; }
