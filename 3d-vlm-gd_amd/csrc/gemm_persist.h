@@ -1,21 +1,21 @@
 // Persistent 256 x 256 gemm_nt for gfx950: one 512-thread block per CU walks its XCD's chunk of the tile space.
 //
 // What it changes against gemm_nt_kernel<T,2,4,8> (same LDS-DMA ring, same swizzle, same wave tiling 2 x 4 of 128 x 64):
-//   * TRANSPOSED accumulators: every MFMA takes the W fragment as its first operand, so lane (g, fr) holds
-//     D[n = 4g+r][m = fr] — four COLUMNS of one output row.  The W rows are DMA'd into the LDS image in a permuted
-//     order (nperm64) that makes the two n-tiles 2u, 2u+1 interleave into 8 consecutive columns per lane: the whole
-//     epilogue (bias, activation, gating, residual, 16-byte stores) runs straight from the accumulators —
-//     no LDS staging, no barriers (the staged epilogue spent 8 block-wide barriers per tile).
-//   * the next tile's first K stage, its LoRA tiles and its bias slice are DMA'd BEFORE the epilogue of the current
-//     tile starts, so the pipeline-fill latency of a tile hides under the previous tile's epilogue, and there is no
-//     block relaunch between tiles.
+//   * PERMUTED W rows: the W rows of a wave's 64 columns are DMA'd into the LDS image in the order n = 4*fr + j
+//     (nperm64), so after the MFMAs lane (g, fr) holds, for row 4g+r of m-tile i, the FOUR CONSECUTIVE columns
+//     4fr..4fr+3 (one per n-tile j).  An output item (i, r) is then one `buffer_store_dwordx2` whose 16 consecutive
+//     lanes cover one 128-byte row segment (4 rows per instruction): measured 40 B/clk per CU against 18 B/clk for
+//     stores whose lanes land in 16 different rows (tools/micro/store_pattern.hip).  The whole epilogue (bias,
+//     activation, gating, residual, stores) runs straight from the accumulators — no LDS staging, no barriers.
+//   * the next tile's first two K stages, its LoRA tiles and its bias slice are DMA'd BEFORE (or in the middle of) the
+//     epilogue of the current tile, so the pipeline-fill latency of a tile hides under the previous tile's epilogue,
+//     and there is no block relaunch between tiles.
 //   * the LoRA rank update is applied at the START of a tile (first MFMA chunk), bias comes from LDS.
 #pragma once
 #include "gemm_tile.h"
 
-__device__ __forceinline__ int nperm64(int rho) {   // LDS W-row -> column offset inside the 256-wide tile
-    const int t = (rho >> 4) & 3, i = rho & 15;
-    return (rho & ~63) | ((t >> 1) << 5) | ((i >> 2) << 3) | ((t & 1) << 2) | (i & 3);
+__device__ __forceinline__ int nperm64(int rho) {   // LDS W-row (64w + 16j + fr) -> column 64w + 4fr + j of the 256-wide tile
+    return (rho & ~63) | ((rho & 15) << 2) | ((rho >> 4) & 3);
 }
 
 // LDS reads of this kernel go through inline asm: for a ds_read the compiler can see, it inserts `s_waitcnt vmcnt`
@@ -32,10 +32,10 @@ template <typename T>
 __device__ __forceinline__ void mma_row(f32x4 (&acc)[4], f32x4 a, f32x4 b0, f32x4 b1, f32x4 b2, f32x4 b3) {
     typedef typename Mma<T>::Frag Frag;
     const Frag fa = __builtin_bit_cast(Frag, a);
-    acc[0] = Mma<T>::mma(__builtin_bit_cast(Frag, b0), fa, acc[0]);
-    acc[1] = Mma<T>::mma(__builtin_bit_cast(Frag, b1), fa, acc[1]);
-    acc[2] = Mma<T>::mma(__builtin_bit_cast(Frag, b2), fa, acc[2]);
-    acc[3] = Mma<T>::mma(__builtin_bit_cast(Frag, b3), fa, acc[3]);
+    acc[0] = Mma<T>::mma(fa, __builtin_bit_cast(Frag, b0), acc[0]);
+    acc[1] = Mma<T>::mma(fa, __builtin_bit_cast(Frag, b1), acc[1]);
+    acc[2] = Mma<T>::mma(fa, __builtin_bit_cast(Frag, b2), acc[2]);
+    acc[3] = Mma<T>::mma(fa, __builtin_bit_cast(Frag, b3), acc[3]);
 }
 
 // One 64-byte K chunk of the 128 x 64 wave tile = 12 fragment reads + 32 (transposed) MFMAs, software-pipelined:
@@ -44,21 +44,22 @@ __device__ __forceinline__ void mma_row(f32x4 (&acc)[4], f32x4 a, f32x4 b0, f32x
 // moves up to the point where the wave's LDS reads of the stage are complete (the eight MFMAs that follow need
 // registers only).  The read latency at the head of every chunk and the barrier skew then sit under MFMA work instead
 // of in front of it.  Register cost: none — the prefetched set reuses the registers of a0..a5, dead by then.
-struct FragHead { f32x4 b0, b1, b2, b3, a0, a1; };
+struct FragHead { f32x4 b0, b1, b2, b3, a0; };   // (five, not six: P and Q are both live at the stage barrier — 8 VGPRs decide spill / no spill)
 __device__ __forceinline__ void frag_head_issue(FragHead& h, unsigned aaddr, unsigned baddr) {
     GD_DSR128(h.b0, baddr, 0); GD_DSR128(h.b1, baddr, 2048); GD_DSR128(h.b2, baddr, 4096); GD_DSR128(h.b3, baddr, 6144);
-    GD_DSR128(h.a0, aaddr, 0); GD_DSR128(h.a1, aaddr, 2048);
+    GD_DSR128(h.a0, aaddr, 0);
 }
 struct FragTail { f32x4 a6, a7; };
 // rows 0..5 of a chunk whose head is already in flight; returns with a6, a7 landed (every LDS read of the chunk done)
 template <typename T>
 __device__ __forceinline__ void chunk_rows05(FragHead& h, FragTail& t, unsigned aaddr, f32x4 (&acc)[8][4]) {
-    f32x4 a2, a3, a4, a5;
-    GD_DSR128(a2, aaddr, 4096); GD_DSR128(a3, aaddr, 6144); GD_DSR128(a4, aaddr, 8192); GD_DSR128(a5, aaddr, 10240);
-    GD_DSR128(t.a6, aaddr, 12288); GD_DSR128(t.a7, aaddr, 14336);
-    asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(h.b0), "+v"(h.b1), "+v"(h.b2), "+v"(h.b3), "+v"(h.a0), "+v"(h.a1));
+    f32x4 a1, a2, a3, a4, a5;
+    GD_DSR128(a1, aaddr, 2048); GD_DSR128(a2, aaddr, 4096); GD_DSR128(a3, aaddr, 6144); GD_DSR128(a4, aaddr, 8192);
+    GD_DSR128(a5, aaddr, 10240); GD_DSR128(t.a6, aaddr, 12288); GD_DSR128(t.a7, aaddr, 14336);
+    asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(h.b0), "+v"(h.b1), "+v"(h.b2), "+v"(h.b3), "+v"(h.a0));
     mma_row<T>(acc[0], h.a0, h.b0, h.b1, h.b2, h.b3);
-    mma_row<T>(acc[1], h.a1, h.b0, h.b1, h.b2, h.b3);
+    asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a1));
+    mma_row<T>(acc[1], a1, h.b0, h.b1, h.b2, h.b3);
     asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a2), "+v"(a3));
     mma_row<T>(acc[2], a2, h.b0, h.b1, h.b2, h.b3);
     mma_row<T>(acc[3], a3, h.b0, h.b1, h.b2, h.b3);
@@ -86,15 +87,15 @@ __device__ __forceinline__ void wait_vm_le(int n) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 typedef __attribute__((ext_vector_type(4))) unsigned gd_u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned gd_u32x2;
 template <int AUX>
-__device__ __forceinline__ void bst8_aux(__amdgpu_buffer_rsrc_t rs, int off, int dt, const float (&v)[8]) {
+__device__ __forceinline__ void bst4_aux(__amdgpu_buffer_rsrc_t rs, int off, int dt, const float (&v)[4]) {
     if (dt == GD_BF16) {
-        const bf16x8 b = bf16x8{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(gd_u32x4, b), rs, off, 0, AUX);
+        const bf16x4 b = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(gd_u32x2, b), rs, off, 0, AUX);
     } else {
-        const f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+        const f32x4 a = {v[0], v[1], v[2], v[3]};
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(gd_u32x4, a), rs, off, 0, AUX);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(gd_u32x4, b), rs, off + 16, 0, AUX);
     }
 }
 // Store cache policy (aux bits: 1 sc0, 2 nt, 16 sc1).  C leaves with nt|sc1: measured on MI355X (87680 x 3072 x 768)
@@ -115,7 +116,7 @@ template <typename T, int SIDE, int ACT, bool PREACT, bool CF32>
 __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
     constexpr int NWN = 4, WMT = 8, NW = 8, BM = 256, BN = 256;
     constexpr int ABYTES = BM * 128, STAGE = (BM + BN) * 128, APW = BM / 8 / NW, BPW = BN / 8 / NW;
-    constexpr int SDEP = 8;   // side-input prefetch depth (16-byte slots per lane)
+    constexpr int SDEP = 16;   // side-input prefetch depth (16-byte slots per lane)
     constexpr int LORA_OFF = 2 * STAGE, BIAS_OFF = LORA_OFF + (BM + BN) * 32;
     __shared__ __attribute__((aligned(16))) char smem[BIAS_OFF + 2 * BN * 4];
     typedef typename Mma<T>::Frag Frag;
@@ -205,7 +206,6 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
     issue_side(tm, tn, slot);
     if (nk > 1) issue(1, 1);
     // VMEM instructions every wave issues unconditionally in one epilogue (buffer ops, range-checked by the hardware)
-    constexpr int cper = CF32 ? 2 : 1;
     int after = 0;   // of those, how many were issued after this tile's stage-1 DMA (0 for the block's first tile)
 
     unsigned long long pc0 = 0, pw = 0, pm = 0, pe = 0, pn = 0, pd = 0;
@@ -222,25 +222,22 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
         if (p.probe) { const unsigned long long c = __builtin_amdgcn_s_memtime(); pw += c - pc0; pc0 = c; }
         if (lora) {
             const bool live = KPL * g < 8;
-            // B tile [8][BN] f32: this lane's k rows start at (KPL*g)&7, its column for n-tile j is n0 + 32*(j>>1) + 4*(j&1)
-            const unsigned baddr = lds_off(smem + LORA_OFF + BM * 32) + 4 * (((KPL * g) & 7) * BN + nperm64(wn * 64 + fr));
+            // B tile [8][BN] f32: this lane's k rows start at (KPL*g)&7; its columns for the n-tiles j = 0..3 are the four
+            // consecutive floats 64*wn + 4*fr + j: one 16-byte read per k row
+            const unsigned baddr = lds_off(smem + LORA_OFF + BM * 32) + 4 * (((KPL * g) & 7) * BN + wn * 64 + 4 * fr);
             const unsigned taddr = lds_off(smem + LORA_OFF) + 4 * ((wm * WMT * 16 + fr) * 8 + ((KPL * g) & 7));
             Frag bf[4];
-#define GD_LB(j, JOFF)                                                                                             \
-            {                                                                                                          \
-                float x0, x1, x2, x3, x4 = 0.f, x5 = 0.f, x6 = 0.f, x7 = 0.f;                                          \
-                GD_DSR32(x0, baddr, 0 + JOFF); GD_DSR32(x1, baddr, 1024 + JOFF); GD_DSR32(x2, baddr, 2048 + JOFF);     \
-                GD_DSR32(x3, baddr, 3072 + JOFF);                                                                      \
-                if (KPL == 8) {                                                                                        \
-                    GD_DSR32(x4, baddr, 4096 + JOFF); GD_DSR32(x5, baddr, 5120 + JOFF); GD_DSR32(x6, baddr, 6144 + JOFF); \
-                    GD_DSR32(x7, baddr, 7168 + JOFF);                                                                  \
-                }                                                                                                      \
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)); \
-                const float xs[8] = {x0, x1, x2, x3, x4, x5, x6, x7};                                                  \
-                _Pragma("unroll") for (int k = 0; k < KPL; ++k) bf[j][k] = (T)(live ? xs[k] : 0.f);                    \
+            {
+                f32x4 q0, q1, q2, q3, q4 = {0.f, 0.f, 0.f, 0.f}, q5 = q4, q6 = q4, q7 = q4;
+                GD_DSR128(q0, baddr, 0); GD_DSR128(q1, baddr, 1024); GD_DSR128(q2, baddr, 2048); GD_DSR128(q3, baddr, 3072);
+                if (KPL == 8) { GD_DSR128(q4, baddr, 4096); GD_DSR128(q5, baddr, 5120); GD_DSR128(q6, baddr, 6144); GD_DSR128(q7, baddr, 7168); }
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4), "+v"(q5), "+v"(q6), "+v"(q7));
+                const f32x4 qs[8] = {q0, q1, q2, q3, q4, q5, q6, q7};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int k = 0; k < KPL; ++k) bf[j][k] = (T)(live ? qs[k][j] : 0.f);
             }
-            GD_LB(0, 0) GD_LB(1, 16) GD_LB(2, 128) GD_LB(3, 144)
-#undef GD_LB
 #define GD_LT(i, IOFF)                                                                                             \
             {                                                                                                          \
                 f32x4 t0, t1 = {0.f, 0.f, 0.f, 0.f};                                                                   \
@@ -250,7 +247,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
                 const float ts[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};                          \
                 Frag af;                                                                                               \
                 _Pragma("unroll") for (int k = 0; k < KPL; ++k) af[k] = (T)(live ? ia * ts[k] : 0.f);                  \
-                _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(bf[j], af, acc[i][j]);           \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(af, bf[j], acc[i][j]);           \
             }
             GD_LT(0, 0) GD_LT(1, 512) GD_LT(2, 1024) GD_LT(3, 1536) GD_LT(4, 2048) GD_LT(5, 2560) GD_LT(6, 3072) GD_LT(7, 3584)
 #undef GD_LT
@@ -276,27 +273,32 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
         }
         const int ctm = tm, ctn = tn, cslot = slot;
         if (p.probe) { const unsigned long long c = __builtin_amdgcn_s_memtime(); pm += c - pc0; pc0 = c; }
-        // ---- epilogue set-up; the first side-input loads go out BEFORE the next tile's DMA (VMEM retires in order: a side
-        // load younger than the DMA could only be consumed after the whole prefetch has landed)
-        // ---- epilogue from the accumulators: lane (g, fr) owns row fr of m-tile i, columns 32u + 8g .. +8 ----
+        // ---- epilogue from the accumulators.  Item (i, r) = row 16i + 4g + r of the wave tile, this lane's four columns
+        // 4fr..4fr+3: one 8-byte (bf16) / 16-byte (f32) store, 16 consecutive lanes = one contiguous row segment.
         const int vrows = min(BM, p.M - ctm * BM);
-        auto mk = [&](const void* base, long ld) {
-            return __builtin_amdgcn_make_buffer_rsrc((void*)((char*)base + (long)ctm * BM * ld * csz), (short)0,
-                                                     (int)min((long)0x7fffffff, (long)vrows * ld * csz), 0x00020000);
+        auto mk = [&](const void* base, long ld, int es) {
+            return __builtin_amdgcn_make_buffer_rsrc((void*)((char*)base + (long)ctm * BM * ld * es), (short)0,
+                                                     (int)min((long)0x7fffffff, (long)vrows * ld * es), 0x00020000);
         };
-        const __amdgpu_buffer_rsrc_t crs = mk(Cb, p.ldc);
-        const __amdgpu_buffer_rsrc_t prs = mk(PREACT ? p.preact : Cb, PREACT ? p.ldp : p.ldc);
-        const __amdgpu_buffer_rsrc_t srs = mk(pre ? (const void*)side_src : (const void*)Cb, pre ? side_ld : p.ldc);
-        const unsigned biasaddr = lds_off(smem + BIAS_OFF) + cslot * BN * 4 + (wn * 64 + g * 8) * 4;
-        f32x4 b0, b1;
-        int rloc = wm * WMT * 16 + fr, cbase = ctn * BN + wn * 64 + g * 8;
-        asm volatile("" : "+v"(rloc), "+v"(cbase));   // keep the 48 per-item byte offsets out of the main loop's live range (LICM)
+        const __amdgpu_buffer_rsrc_t crs = mk(Cb, p.ldc, csz);
+        const __amdgpu_buffer_rsrc_t prs = mk(PREACT ? p.preact : Cb, PREACT ? p.ldp : p.ldc, csz);
+        const __amdgpu_buffer_rsrc_t srs = mk(pre ? (const void*)side_src : (const void*)Cb, pre ? side_ld : p.ldc, pre ? 2 : csz);
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+            const unsigned biasaddr = lds_off(smem + BIAS_OFF) + cslot * BN * 4 + (wn * 64 + fr * 4) * 4;
+            GD_DSR128(bv, biasaddr, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bv));
+        }
+        int rloc = wm * WMT * 16 + g * 4, col0 = ctn * BN + wn * 64 + fr * 4;
+        asm volatile("" : "+v"(rloc), "+v"(col0));   // keep the per-item byte offsets out of the main loop's live range (LICM)
         const int OOB = 0x7ffffff0;   // beyond every num_records: the hardware drops the access
-        gd_u32x4 sd[SDEP] = {};
-        auto side_load = [&](int idx) {   // idx = u * WMT + i
-            const int col0 = cbase + (idx / WMT) * 32;
-            const int off = col0 < p.N ? (int)((long)(rloc + (idx % WMT) * 16) * side_ld * 2 + col0 * 2) : OOB;
-            sd[idx % SDEP] = __builtin_amdgcn_raw_buffer_load_b128(srs, off, 0, GD_PERSIST_SIDE_AUX);
+        const int ldc_i = (int)p.ldc, ldp_i = (int)p.ldp, lds_i = (int)side_ld;   // (host: 256 * ld * size < 2^31)
+        const bool cok = col0 < p.N;
+        constexpr int NITEM = 4 * WMT;   // idx = 4 i + r
+        gd_u32x2 sd[SDEP] = {};
+        auto side_load = [&](int idx) {
+            const int off = cok ? ((rloc + (idx >> 2) * 16 + (idx & 3)) * lds_i + col0) * 2 : OOB;
+            sd[idx % SDEP] = __builtin_amdgcn_raw_buffer_load_b64(srs, off, 0, GD_PERSIST_SIDE_AUX);
         };
         if (pre) {
 #pragma unroll
@@ -304,15 +306,15 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
         }
         // ---- the ring is free: the next tile's pipeline starts before (SIDE 0) or in the middle of (SIDE 1/2) this
         // tile's epilogue.  VMEM retires in issue order, so a side load younger than the DMA could only be consumed once the
-        // whole prefetch has landed: with a side tensor all 2*WMT side loads go out first (SDEP up front, the rest
-        // while items 0..DMA_AT-1 are processed) and the DMA follows at item DMA_AT.
-        constexpr int DMA_AT = pre ? 2 * WMT - SDEP : 0;
+        // whole prefetch has landed: with a side tensor ALL side loads go out first (SDEP up front, the rest while items
+        // 0..DMA_AT-1 are processed) and the DMA follows at item DMA_AT.
+        constexpr int DMA_AT = pre ? NITEM - SDEP : 0;
         t += gridDim.x;
         const bool more = t < ntiles;
-        after = (2 * WMT - DMA_AT) * (cper + (PREACT ? cper : 0));   // epilogue VMEM instructions younger than the stage-1 DMA
+        after = (NITEM - DMA_AT) * (1 + (PREACT ? 1 : 0));   // epilogue VMEM instructions younger than the stage-1 DMA
 #pragma unroll
-        for (int idx = 0; idx < 2 * WMT; ++idx) {
-            const int i = idx % WMT, u = idx / WMT;
+        for (int idx = 0; idx < NITEM; ++idx) {
+            const int i = idx >> 2, r = idx & 3;
             if (idx == DMA_AT) {
                 if (more) {
                     wg = xcd_remap(t, ntiles);
@@ -325,41 +327,30 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
                 asm volatile("" ::: "memory");   // nothing younger may be hoisted above the DMA: `after` counts on it
                 if (p.probe) { const unsigned long long c = __builtin_amdgcn_s_memtime(); pd += c - pc0; pc0 = c; }
             }
-            const int rl = rloc + i * 16, row = ctm * BM + rl, col0 = cbase + u * 32;
-            if (i == 0) {
-                b0 = f32x4{0.f, 0.f, 0.f, 0.f}; b1 = b0;
-                if (p.bias) {
-                    if (u == 0) { GD_DSR128(b0, biasaddr, 0); GD_DSR128(b1, biasaddr, 16); }
-                    else { GD_DSR128(b0, biasaddr, 128); GD_DSR128(b1, biasaddr, 144); }
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b0), "+v"(b1));
-                }
-            }
-            float v[8];
+            const int rl = rloc + i * 16 + r;
+            float v[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                v[k] = fmaf(p.alpha, acc[i][2 * u][k], b0[k]);
-                v[4 + k] = fmaf(p.alpha, acc[i][2 * u + 1][k], b1[k]);
-            }
-            if (PREACT) bst8_aux<GD_PERSIST_STORE_AUX>(prs, col0 < p.N ? (int)((long)rl * p.ldp * csz + (long)col0 * csz) : OOB, cdt, v);
+            for (int j = 0; j < 4; ++j) v[j] = fmaf(p.alpha, acc[i][j][r], bv[j]);
+            if (PREACT) bst4_aux<GD_PERSIST_STORE_AUX>(prs, cok ? (rl * ldp_i + col0) * csz : OOB, cdt, v);
             if (ACT == 1) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = CF32 ? gelu_f(v[k]) : gelu_fast(v[k]);
+                for (int j = 0; j < 4; ++j) v[j] = CF32 ? gelu_f(v[j]) : gelu_fast(v[j]);
             } else if (ACT == 2) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+                for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
             }
             if (SIDE == 1) {
-                const bf16x8 x = __builtin_bit_cast(bf16x8, sd[idx % SDEP]);
+                const bf16x4 x = __builtin_bit_cast(bf16x4, sd[idx % SDEP]);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] *= dgelu_fast((float)x[k]);
+                for (int j = 0; j < 4; ++j) v[j] *= dgelu_fast((float)x[j]);
             }
             if (SIDE == 2) {
-                const bf16x8 x = __builtin_bit_cast(bf16x8, sd[idx % SDEP]);
+                const bf16x4 x = __builtin_bit_cast(bf16x4, sd[idx % SDEP]);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] += (float)x[k];
+                for (int j = 0; j < 4; ++j) v[j] += (float)x[j];
             }
-            bst8_aux<GD_PERSIST_STORE_AUX>(crs, col0 < p.N ? (int)((long)rl * p.ldc * csz + (long)col0 * csz) : OOB, cdt, v);
-            if (pre && idx + SDEP < 2 * WMT) side_load(idx + SDEP);
+            bst4_aux<GD_PERSIST_STORE_AUX>(crs, cok ? (rl * ldc_i + col0) * csz : OOB, cdt, v);
+            if (pre && idx + SDEP < NITEM) side_load(idx + SDEP);
         }
         if (p.probe) { const unsigned long long c = __builtin_amdgcn_s_memtime(); pe += c - pc0; pn += 1; }
         if (!more) break;
