@@ -23,7 +23,8 @@ struct GemmNtParams {
     const float* lora_t; const float* lora_b; int lora_rt;   // v += sum_r t[m,r] * b[r,n]
     void* preact; long ldp;          // store v before the activation
     int act;                         // 0 none, 1 GELU(erf), 2 ReLU
-    const void* dact_src; long ldd; int dact;                 // v *= act'(src): 1 dGELU(pre), 2 (src > 0)
+    int act_deriv;                   // preact receives GELU'(v) instead of v (C-ABI act = 3): the backward then gates with dact = 3
+    const void* dact_src; long ldd; int dact;                 // v *= act'(src): 1 dGELU(pre), 2 (src > 0), 3 v *= src (stored derivative)
     const void* residual; long ldr;  // v += residual
     int accumulate;                  // v += C
     int vec_epilogue;                // every epilogue tensor is 16-byte aligned with 16-byte-multiple row strides
@@ -80,11 +81,12 @@ __global__ __launch_bounds__(256) void gemm_nt_regstage_kernel(GemmNtParams p) {
                     for (int q = 0; q < 8; ++q)
                         if (q < p.lora_rt) v += lt[q] * p.lora_b[(long)q * p.N + col];
                 }
-                if (p.preact) st_rt(p.preact, (long)row * p.ldp + col, cdt, v);
+                if (p.preact) st_rt(p.preact, (long)row * p.ldp + col, cdt, p.act_deriv ? dgelu_f(v) : v);
                 if (p.act == 1) v = gelu_f(v);
                 else if (p.act == 2) v = fmaxf(v, 0.f);
                 if (p.dact == 1) v *= dgelu_f(ld_rt(p.dact_src, (long)row * p.ldd + col, cdt));
                 else if (p.dact == 2) v = ld_rt(p.dact_src, (long)row * p.ldd + col, cdt) > 0.f ? v : 0.f;
+                else if (p.dact == 3) v *= ld_rt(p.dact_src, (long)row * p.ldd + col, cdt);
                 if (p.residual) v += ld_rt(p.residual, (long)row * p.ldr + col, cdt);
                 if (p.accumulate) v += ld_rt(Cb, (long)row * p.ldc + col, cdt);
                 st_rt(Cb, (long)row * p.ldc + col, cdt, v);
@@ -295,7 +297,14 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(GemmNtParams p)
                         for (int k = 0; k < 4; ++k) { v[k] += tq * b0[k]; v[4 + k] += tq * b1[k]; }
                     }
                 }
-                if (p.preact) st8_rt(p.preact, (long)row * p.ldp + col0, cdt, v);
+                if (p.preact) {
+                    if (p.act_deriv) {
+                        float dv[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) dv[k] = cdt == GD_BF16 ? dgelu_fast(v[k]) : dgelu_f(v[k]);
+                        st8_rt(p.preact, (long)row * p.ldp + col0, cdt, dv);
+                    } else st8_rt(p.preact, (long)row * p.ldp + col0, cdt, v);
+                }
                 if (p.act == 1) {
                     if (cdt == GD_BF16) {
 #pragma unroll
@@ -315,7 +324,10 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(GemmNtParams p)
 #pragma unroll
                         for (int k = 0; k < 8; ++k) s[k] = (float)t[k];
                     } else ld8_rt(p.dact_src, (long)row * p.ldd + col0, cdt, s);
-                    if (p.dact == 1 && cdt == GD_BF16) {
+                    if (p.dact == 3) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] *= s[k];
+                    } else if (p.dact == 1 && cdt == GD_BF16) {
 #pragma unroll
                         for (int k = 0; k < 8; ++k) v[k] *= dgelu_fast(s[k]);
                     } else {
@@ -349,11 +361,12 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(GemmNtParams p)
                     if (p.bias) x += p.bias[col];
                     if (p.lora_t && !lora_mma)   // (otherwise already in acc via the MFMA rank update)
                         for (int qq = 0; qq < p.lora_rt; ++qq) x += p.lora_t[(long)row * p.lora_rt + qq] * p.lora_b[(long)qq * p.N + col];
-                    if (p.preact) st_rt(p.preact, (long)row * p.ldp + col, cdt, x);
+                    if (p.preact) st_rt(p.preact, (long)row * p.ldp + col, cdt, p.act_deriv ? dgelu_f(x) : x);
                     if (p.act == 1) x = gelu_f(x);
                     else if (p.act == 2) x = fmaxf(x, 0.f);
                     if (p.dact == 1) x *= dgelu_f(ld_rt(p.dact_src, (long)row * p.ldd + col, cdt));
                     else if (p.dact == 2) x = ld_rt(p.dact_src, (long)row * p.ldd + col, cdt) > 0.f ? x : 0.f;
+                    else if (p.dact == 3) x *= ld_rt(p.dact_src, (long)row * p.ldd + col, cdt);
                     if (p.residual) x += ld_rt(p.residual, (long)row * p.ldr + col, cdt);
                     if (p.accumulate) x += ld_rt(Cb, (long)row * p.ldc + col, cdt);
                     st_rt(Cb, (long)row * p.ldc + col, cdt, x);
@@ -668,7 +681,7 @@ extern "C" int gd_gemm_nt(const void* A, const void* W, void* C, int M, int N, i
     GemmNtParams p;
     p.A = A; p.W = W; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc;
     p.sA = sA; p.sW = sW; p.sC = sC; p.c_dtype = c_dtype; p.alpha = alpha; p.bias = bias;
-    p.lora_t = lora_t; p.lora_b = lora_b; p.lora_rt = lora_rt; p.preact = preact; p.ldp = ldp; p.act = act;
+    p.lora_t = lora_t; p.lora_b = lora_b; p.lora_rt = lora_rt; p.preact = preact; p.ldp = ldp; p.act = act == 3 ? 1 : act; p.act_deriv = act == 3;
     p.dact_src = dact_src; p.ldd = ldd; p.dact = dact_src ? dact : 0; p.residual = residual; p.ldr = ldr;
     p.accumulate = accumulate;
     const int cs = gd_dtype_size(c_dtype);
@@ -699,11 +712,13 @@ extern "C" int gd_gemm_nt(const void* A, const void* W, void* C, int M, int N, i
     if (ab_dtype == GD_BF16 && !accumulate && !(dact_src && residual)) {
         const bool cb = c_dtype == GD_BF16;
         if (!dact_src && !residual) {
-            if (act == 0 && !preact) pk = cb ? gemm_nt_persist_kernel<bf16, 0, 0, false, false> : gemm_nt_persist_kernel<bf16, 0, 0, false, true>;
-            else if (act == 1 && !preact && cb) pk = gemm_nt_persist_kernel<bf16, 0, 1, false, false>;
-            else if (act == 1 && preact && cb) pk = gemm_nt_persist_kernel<bf16, 0, 1, true, false>;
-        } else if (dact_src && dact == 1 && act == 0 && !preact && cb) pk = gemm_nt_persist_kernel<bf16, 1, 0, false, false>;
-        else if (residual && act == 0 && !preact && cb) pk = gemm_nt_persist_kernel<bf16, 2, 0, false, false>;
+            if (act == 0 && !preact) pk = cb ? gemm_nt_persist_kernel<bf16, 0, 0, 0, false> : gemm_nt_persist_kernel<bf16, 0, 0, 0, true>;
+            else if ((act == 1 || act == 3) && !preact && cb) pk = gemm_nt_persist_kernel<bf16, 0, 1, 0, false>;
+            else if (act == 1 && preact && cb) pk = gemm_nt_persist_kernel<bf16, 0, 1, 1, false>;
+            else if (act == 3 && preact && cb) pk = gemm_nt_persist_kernel<bf16, 0, 1, 2, false>;
+        } else if (dact_src && dact == 1 && act == 0 && !preact && cb) pk = gemm_nt_persist_kernel<bf16, 1, 0, 0, false>;
+        else if (dact_src && dact == 3 && act == 0 && !preact && cb) pk = gemm_nt_persist_kernel<bf16, 3, 0, 0, false>;
+        else if (residual && act == 0 && !preact && cb) pk = gemm_nt_persist_kernel<bf16, 2, 0, 0, false>;
     }
     if (big && persist && pk && p.vec_epilogue && N % 8 == 0 && (!lora_t || lora_rt == 8) && 256 * ldmax * cs < 0x7fffffffL) {
         // Tile quantisation: T tiles on C CUs take ceil(T / C) rounds, e.g. 1029 tiles of the N = 768 GEMMs = 4.02 -> 5 rounds.

@@ -108,11 +108,13 @@ __device__ __forceinline__ void bst4_aux(__amdgpu_buffer_rsrc_t rs, int off, int
 #define GD_PERSIST_SIDE_AUX 2     // side tensors are read once: stream them past the L2's operand panels
 #endif
 
-// Compile-time epilogue: SIDE 0 none | 1 v *= dGELU(dact_src) | 2 v += residual (bf16 side tensor, prefetched);
-// ACT 0 none | 1 GELU | 2 ReLU; PREACT store v before the activation; CF32 C / preact are f32 (else bf16).
+// Compile-time epilogue: SIDE 0 none | 1 v *= dGELU(dact_src) | 2 v += residual | 3 v *= dact_src (bf16 side tensor,
+// prefetched); ACT 0 none | 1 GELU | 2 ReLU; PREACT 0 none | 1 store v before the activation | 2 store GELU'(v) (the
+// backward then only multiplies: SIDE 3 — recomputing dGELU from the stored pre-activation cost 20 k cycles per tile of
+// the fc1 backward GEMM); CF32 C / preact are f32 (else bf16).
 // (With these as run-time flags the 16-item unrolled epilogue was ~160 scalar branches per tile: 4 k cycles of a
 // 45 k-cycle tile with nothing to do.)  Other combinations stay on gemm_nt_kernel.
-template <typename T, int SIDE, int ACT, bool PREACT, bool CF32>
+template <typename T, int SIDE, int ACT, int PREACT, bool CF32>
 __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
     constexpr int NWN = 4, WMT = 8, NW = 8, BM = 256, BN = 256;
     constexpr int ABYTES = BM * 128, STAGE = (BM + BN) * 128, APW = BM / 8 / NW, BPW = BN / 8 / NW;
@@ -193,8 +195,8 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
     const int sa = swz(fr);
     const unsigned lds0 = lds_off(smem);
     constexpr bool pre = SIDE != 0;
-    const bf16* side_src = (const bf16*)(SIDE == 1 ? p.dact_src : p.residual);
-    const long side_ld = SIDE == 1 ? p.ldd : p.ldr;
+    const bf16* side_src = (const bf16*)(SIDE == 2 ? p.residual : p.dact_src);
+    const long side_ld = SIDE == 2 ? p.ldr : p.ldd;
 
     int t = blockIdx.x, slot = 0;
     if (t >= ntiles) return;
@@ -331,8 +333,18 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
             float v[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = fmaf(p.alpha, acc[i][j][r], bv[j]);
-            if (PREACT) bst4_aux<GD_PERSIST_STORE_AUX>(prs, cok ? (rl * ldp_i + col0) * csz : OOB, cdt, v);
-            if (ACT == 1) {
+            if (PREACT == 1) bst4_aux<GD_PERSIST_STORE_AUX>(prs, cok ? (rl * ldp_i + col0) * csz : OOB, cdt, v);
+            if (ACT == 1 && PREACT == 2) {   // GELU and its derivative from one shared exponential; the derivative is what is stored
+                float dv[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float Phi, ex;
+                    gelu_parts(v[j], Phi, ex);
+                    dv[j] = Phi + v[j] * ex * 0.39894228040143268f;
+                    v[j] *= Phi;
+                }
+                bst4_aux<GD_PERSIST_STORE_AUX>(prs, cok ? (rl * ldp_i + col0) * csz : OOB, cdt, dv);
+            } else if (ACT == 1) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = CF32 ? gelu_f(v[j]) : gelu_fast(v[j]);
             } else if (ACT == 2) {
@@ -348,6 +360,11 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
                 const bf16x4 x = __builtin_bit_cast(bf16x4, sd[idx % SDEP]);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] += (float)x[j];
+            }
+            if (SIDE == 3) {
+                const bf16x4 x = __builtin_bit_cast(bf16x4, sd[idx % SDEP]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] *= (float)x[j];
             }
             bst4_aux<GD_PERSIST_STORE_AUX>(crs, cok ? (rl * ldc_i + col0) * csz : OOB, cdt, v);
             if (pre && idx + SDEP < NITEM) side_load(idx + SDEP);

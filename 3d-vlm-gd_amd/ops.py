@@ -58,8 +58,9 @@ def gemm_nt(a, w, out=None, *, out_dtype=None, alpha=1.0, bias=None, lora_t=None
             act=0, dact_src=None, dact=0, residual=None, accumulate=False):
     """out[M,N] = epilogue(alpha * a[M,K] @ w[N,K]^T).  a, w: same dtype (f32 | bf16), last dim contiguous.
     Batched when a is 3-D ([B,M,K] x [B,N,K] -> [B,M,N], no epilogue tensors).
-    Epilogue order: +bias[N] (f32) -> +lora_t[M,r] @ lora_b[r,N] (f32) -> store preact -> act (1 GELU, 2 ReLU)
-    -> *act'(dact_src) (1 dGELU(pre), 2 src>0) -> +residual -> +out (accumulate)."""
+    Epilogue order: +bias[N] (f32) -> +lora_t[M,r] @ lora_b[r,N] (f32) -> store preact -> act (1 GELU, 2 ReLU,
+    3 GELU with `preact` receiving GELU'(v)) -> *act'(dact_src) (1 dGELU(pre), 2 src>0, 3 v *= src) -> +residual
+    -> +out (accumulate)."""
     _req(a.is_cuda and w.is_cuda and a.dtype == w.dtype, "gemm_nt: a and w must be CUDA tensors of one dtype")
     _req(a.stride(-1) == 1 and w.stride(-1) == 1, "gemm_nt: a and w must be contiguous along K")
     batched = a.dim() == 3

@@ -144,7 +144,7 @@ class _BlockFn(torch.autograd.Function):
         x1 = ops.gemm_nt(o, plan["wproj"], bias=plan["bproj"], residual=x)
         y2, mean2, rstd2 = ops.layernorm_fwd(x1, plan["ln2_w"], plan["ln2_b"], plan["eps2"], save_stats=need)
         pre = torch.empty(M, plan["w1"].shape[0], dtype=T, device=x.device) if need else None
-        h = ops.gemm_nt(y2, plan["w1"], bias=plan["b1"], act=1, preact=pre)
+        h = ops.gemm_nt(y2, plan["w1"], bias=plan["b1"], act=3, preact=pre)   # pre <- GELU'(fc1 output): all the backward needs
         x2 = ops.gemm_nt(h, plan["w2"], bias=plan["b2"], residual=x1)
         out, hd = x2, None
         if down is not None:
@@ -170,7 +170,7 @@ class _BlockFn(torch.autograd.Function):
             g_up = ops.gemm_tn(dout, hd)                                                          # [D, 64]
             g_down = ops.gemm_tn(dhp, x2)                                                         # [64, D]
             dx2 = ops.gemm_nt(dhp, down.detach().t().to(T).contiguous(), residual=dout)
-        dpre = ops.gemm_nt(dx2, plan["w2_t"], dact_src=pre, dact=1)                               # [M, 4D]
+        dpre = ops.gemm_nt(dx2, plan["w2_t"], dact_src=pre, dact=3)                               # [M, 4D] (x stored GELU')
         dy2 = ops.gemm_nt(dpre, plan["w1_t"])
         del dpre
         dx1 = ops.layernorm_bwd(dy2, x1, plan["ln2_w"], mean2, rstd2, dres=dx2)

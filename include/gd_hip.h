@@ -31,8 +31,9 @@ int gd_gemm_phase_probe(int enable, unsigned long long* out5);
 
 /* C[M,N] = epilogue(alpha * A[M,K] . W[N,K]^T); replaces torch nn.Linear / torch.bmm on the student path
  * (timm VisionTransformer qkv/proj/fc1/fc2, utils/model.py:57-71 LoRA, :7-25 Adapter; src/finetune_timm_vggt.py:516-517).
- * Epilogue order: +bias[N](f32) -> +lora_t[M,rt].lora_b[rt,N](f32, rt<=8) -> store preact -> act(1 GELU erf,2 ReLU)
- * -> *act'(dact_src) (1 dGELU(src), 2 src>0) -> +residual -> +C (accumulate).  batch>1: grid over batch strides. */
+ * Epilogue order: +bias[N](f32) -> +lora_t[M,rt].lora_b[rt,N](f32, rt<=8) -> store preact -> act(1 GELU erf,2 ReLU,
+ * 3 GELU with preact receiving GELU'(v) instead of v) -> *act'(dact_src) (1 dGELU(src), 2 src>0, 3 v*=src: the stored
+ * derivative of act 3) -> +residual -> +C (accumulate).  batch>1: grid over batch strides. */
 int gd_gemm_nt(const void* A, const void* W, void* C, int M, int N, int K, long lda, long ldw, long ldc,
                int batch, long sA, long sW, long sC, int ab_dtype, int c_dtype, float alpha,
                const float* bias, const float* lora_t, const float* lora_b, int lora_rt, void* preact, long ldp,

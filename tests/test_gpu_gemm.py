@@ -45,6 +45,13 @@ def test_gemm_nt_epilogues(dtype, tol):
     plain = a.double() @ w.double().t()
     assert rel_err(ops.gemm_nt(a, w, dact_src=src, dact=1), plain * x.grad) < tol
     assert rel_err(ops.gemm_nt(a, w, dact_src=src, dact=2), plain * (src.double() > 0)) < tol
+    assert rel_err(ops.gemm_nt(a, w, dact_src=src, dact=3), plain * src.double()) < tol
+    yy = (plain + bias.double()).requires_grad_(True)
+    torch.nn.functional.gelu(yy).sum().backward()
+    dgs = torch.empty(M, N, dtype=dtype, device="cuda")
+    o3 = ops.gemm_nt(a, w, bias=bias, preact=dgs, act=3)
+    assert rel_err(o3, torch.nn.functional.gelu(yy.detach())) < tol
+    assert rel_err(dgs, yy.grad) < max(tol, 2e-5)   # GELU' goes through __expf in the f32 path
     acc = _mk((M, N), torch.float32, 10)
     want = acc.double() + plain
     ops.gemm_nt(a, w, out=acc, accumulate=True)
@@ -78,6 +85,13 @@ def test_gemm_nt_persistent_epilogues(M, N, K):
     assert rel_err(ops.gemm_nt(a, w, dact_src=src, dact=1), plain * x.grad) < tol
     assert rel_err(ops.gemm_nt(a, w, bias=bias, residual=res), plain + bias.double() + res.double()) < tol
     assert rel_err(ops.gemm_nt(a, w, residual=res), plain + res.double()) < tol
+    # act = 3: GELU forward that stores GELU'(v); dact = 3: gate by the stored derivative
+    y = (plain + bias.double()).requires_grad_(True)
+    gelu(y).sum().backward()
+    dg = torch.empty(M, N, dtype=dt, device="cuda")
+    out = ops.gemm_nt(a, w, bias=bias, preact=dg, act=3)
+    assert rel_err(out, gelu(y.detach())) < tol and rel_err(dg, y.grad) < tol
+    assert rel_err(ops.gemm_nt(a, w, dact_src=src, dact=3), plain * src.double()) < tol
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 1e-2)])
