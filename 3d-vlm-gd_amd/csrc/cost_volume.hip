@@ -28,17 +28,33 @@ extern "C" int gd_gemm_nt(const void* A, const void* W, void* C, int M, int N, i
 #define CV_EPS 1e-8f
 
 
-// stats layout: [P][2][hw][4] = {inv_norm, teacher_rowsum(clamped), logZ, W}
-// one wave per (pair, view, row): 16-byte feature loads; teacher row (4-byte aligned only: hw is odd) read as a
-// scalar head + aligned float4 body + scalar tail.
+// stats layout: [P][2][hw][4] = {inv_norm, teacher_rowsum(clamped), logZ, W};  wa: [P][2][hw][2] = {W, A}.
+// One wave per (pair, view, row).  The teacher row is read ONCE into registers (coalesced 4-byte loads: rows are only
+// 4-byte aligned, hw is odd), summed, and — now that 1/rowsum is known — swept again from the registers for the two
+// row statistics that do not involve the student at all:  W = sum_j t,  A = sum_j t log t,  t = max(T / rowsum, 1e-8).
+// (They used to be accumulated per 128 x 128 tile next to the S-dependent terms: one v_log per element per direction.)
+#define CV_TROW_MAX 24   // registers per lane for a teacher row: hw <= 1536; longer rows take a second pass over memory
 __global__ __launch_bounds__(256) void cv_prep_kernel(const void* f1, const void* f2, const float* t1,
-                                                      const float* t2, float* stats, int hw, int C, int dtype) {
+                                                      const float* t2, float* stats, float* wa, int hw, int C, int dtype) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave, which = blockIdx.y, p = blockIdx.z;
     if (row >= hw) return;
     const void* f = which ? f2 : f1;
     const float* t = (which ? t2 : t1) + ((long)p * hw + row) * hw;
     const long fo = ((long)p * hw + row) * C;
+    const bool inreg = hw <= 64 * CV_TROW_MAX;
+    float tv[CV_TROW_MAX];
+    float rs = 0.f;
+    if (inreg) {
+#pragma unroll
+        for (int k = 0; k < CV_TROW_MAX; ++k) {
+            const int j = lane + 64 * k;
+            tv[k] = j < hw ? t[j] : 0.f;
+            rs += tv[k];
+        }
+    } else {
+        for (int j = lane; j < hw; j += 64) rs += t[j];
+    }
     float ss = 0.f;
     if (dtype == GD_BF16) {
         const bf16x8* fv = (const bf16x8*)((const bf16*)f + fo);
@@ -54,23 +70,31 @@ __global__ __launch_bounds__(256) void cv_prep_kernel(const void* f1, const void
             ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
         }
     }
-    const int head = (4 - (int)(((uintptr_t)t >> 2) & 3)) & 3;   // floats until 16-byte alignment
-    float rs = 0.f;
-    if (lane < head && lane < hw) rs += t[lane];
-    const int nvec = hw > head ? (hw - head) >> 2 : 0;
-    const f32x4* tv = (const f32x4*)(t + head);
-    for (int j = lane; j < nvec; j += 64) {
-        const f32x4 v = tv[j];
-        rs += (v[0] + v[1]) + (v[2] + v[3]);
-    }
-    const int tail0 = head + nvec * 4;
-    if (tail0 + lane < hw) rs += t[tail0 + lane];
     ss = wave_sum(ss);
-    rs = wave_sum(rs);
+    rs = fmaxf(wave_sum(rs), CV_EPS);
+    const float ir = 1.0f / rs;
+    float W = 0.f, A = 0.f;
+    if (inreg) {
+#pragma unroll
+        for (int k = 0; k < CV_TROW_MAX; ++k) {
+            if (lane + 64 * k < hw) {
+                const float x = fmaxf(tv[k] * ir, CV_EPS);
+                W += x; A += x * __logf(x);
+            }
+        }
+    } else {
+        for (int j = lane; j < hw; j += 64) {
+            const float x = fmaxf(t[j] * ir, CV_EPS);
+            W += x; A += x * __logf(x);
+        }
+    }
+    W = wave_sum(W); A = wave_sum(A);
     if (lane == 0) {
         float* o = stats + (((long)p * 2 + which) * hw + row) * 4;
         o[0] = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
-        o[1] = fmaxf(rs, CV_EPS);
+        o[1] = rs;
+        float* w2 = wa + (((long)p * 2 + which) * hw + row) * 2;
+        w2[0] = W; w2[1] = A;
     }
 }
 
@@ -128,13 +152,32 @@ __device__ __forceinline__ void cv_s_tile(const CvTileParams& q, int p, int tm, 
         }
 }
 
-// Teacher tiles are PRELOADED into registers before the MFMA main loop (128 independent 4-byte loads per lane,
-// in flight under the contraction), because the sweeps below are otherwise one exposed HBM latency per row.
-// Sweep shape: a wave instruction covers 4 tile rows x 16 columns (64-byte row segments); each lane accumulates
-// its 8 column groups locally, so a row statistic costs a 4-step reduction inside 16 lanes.
+// Forward tile kernel.  What is left per element once W and A come from cv_prep:
+//   Z partials (sum of e^s over the tile's rows / columns): taken straight from the accumulators, ONE v_exp per element
+//   for both directions, reduced with DPP / two cross-row shuffles, the two wave halves combined through LDS;
+//   B partials (sum of t * s): two sweeps, S tile (then its transpose) parked in LDS, teacher tile in registers,
+//   per element one multiply, one max, one FMA — no transcendentals.
+// Teacher loads are 16 bytes per lane (rows are only 4-byte aligned: `f32x4_u`), 16 lanes = one contiguous 256-byte
+// row segment, issued before the MFMA main loop (direction 1) / before the first sweep (direction 2).
+// LDS images: S row-major (the b128 row reads of 4 rows x 256 B are conflict-free by the hardware's lane grouping);
+// S^T with the 16-byte chunk index XOR-ed by (row & 15) — the transposing b128 writes of 16 lanes hit 16 different rows
+// at one column offset — and the teacher columns of direction 2 permuted the same way (a sum does not care).
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ f32x4 cv_ld4(const float* T, long rowoff, int col, int hw, bool rok) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (rok) {
+        if (col + 4 <= hw) { const f32x4_u u = *(const f32x4_u*)(T + rowoff + col); v = f32x4{u[0], u[1], u[2], u[3]}; }
+        else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (col + k < hw) v[k] = T[rowoff + col + k];
+        }
+    }
+    return v;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256, 2) void cv_fwd_tile_kernel(CvTileParams q) {
-    __shared__ __attribute__((aligned(16))) char smem[CV_RING + 4096];   // ONE LDS object: ring | tile statistics
+    __shared__ __attribute__((aligned(16))) char smem[CV_RING + 4096 + 2048];   // ring / S tile | tile statistics | Z partials
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, g = lane >> 4, c = lane & 15;
     const int p = blockIdx.y, hw = q.hw;
@@ -143,87 +186,110 @@ __global__ __launch_bounds__(256, 2) void cv_fwd_tile_kernel(CvTileParams q) {
     const float* T1 = q.t1 + (long)p * hw * hw;
     const float* T2 = q.t2 + (long)p * hw * hw;
     f32x4* sSt = (f32x4*)(smem + CV_RING);
+    float* sZr = (float*)(smem + CV_RING + 4096);   // [2 (wn)][128 rows]
+    float* sZc = sZr + 256;                          // [2 (wm)][128 columns]
     cv_stage_stats(q, p, tm, tn, sSt);
-    // direction-1 teacher tile: in flight under the main loop.  (Both tiles at once would cost 128 VGPRs and halve
-    // the occupancy; with one block per CU every K-step of the 2-deep DMA ring exposes a full memory latency.)
-    float t1v[8][8], t2v[8][8];   // [4-row step][16-column group]
+    // direction-1 teacher tile (tile row = teacher row), in flight under the main loop
+    f32x4 t1v[8][2], t2v[8][2];
 #pragma unroll
     for (int st = 0; st < 8; ++st) {
-        const int row = tm * 128 + wave * 32 + st * 4 + g;     // dir 1: teacher row = tile row
+        const int row = tm * 128 + wave * 32 + st * 4 + g;
 #pragma unroll
-        for (int cg = 0; cg < 8; ++cg) {
-            const int col = tn * 128 + cg * 16 + c;
-            t1v[st][cg] = (row < hw && col < hw) ? T1[(long)row * hw + col] : 0.f;
-        }
+        for (int h = 0; h < 2; ++h) t1v[st][h] = cv_ld4(T1, (long)row * hw, tn * 128 + h * 64 + 4 * c, hw, row < hw);
     }
+    f32x4 acc[4][4];
+    cv_s_tile<T>(q, p, tm, tn, smem, sSt, acc);     // ends with a barrier: the ring is free
+    float* sS = (float*)smem;                        // [128][128] row-major
+    // ---- Z partials from the accumulators (e^s of in-range elements) + S into LDS ----
     {
-        f32x4 acc[4][4];
-        cv_s_tile<T>(q, p, tm, tn, smem, sSt, acc);
-        float* sS_ = (float*)smem;
+        float zc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int r = 0; r < 4; ++r) {
+                const int rl = wm * 64 + i * 16 + g * 4 + r;
+                const bool rok = tm * 128 + rl < hw;
+                float zr = 0.f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    sS_[sidx(wm * 64 + i * 16 + g * 4 + r, wn * 64 + j * 16 + c, 128)] = acc[i][j][r];
-    }
-    float* sS = (float*)smem;   // [128][128] swizzled
-    // direction-2 teacher tile: issued now, lands under the direction-1 sweep
+                for (int j = 0; j < 4; ++j) {
+                    const int cl = wn * 64 + j * 16 + c;
+                    const float s = acc[i][j][r];
+                    const float e = (rok && tn * 128 + cl < hw) ? __expf(s) : 0.f;
+                    zr += e; zc[j] += e;
+                    sS[rl * 128 + cl] = s;
+                }
+                zr = row16_sum(zr);
+                if (c == 0) sZr[wn * 128 + rl] = zr;
+            }
 #pragma unroll
-    for (int st = 0; st < 8; ++st) {
-        const int trow = tn * 128 + wave * 32 + st * 4 + g;    // dir 2: teacher row = tile column
-#pragma unroll
-        for (int cg = 0; cg < 8; ++cg) {
-            const int ti = tm * 128 + cg * 16 + c;
-            t2v[st][cg] = (trow < hw && ti < hw) ? T2[(long)trow * hw + ti] : 0.f;
+        for (int j = 0; j < 4; ++j) {
+            float v = zc[j];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (g == 0) sZc[wm * 128 + wn * 64 + j * 16 + c] = v;
         }
     }
+    // direction-2 teacher tile (tile column = teacher row); columns permuted like the S^T image
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+        const int jl = wave * 32 + st * 4 + g, trow = tn * 128 + jl;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            t2v[st][h] = cv_ld4(T2, (long)trow * hw, tm * 128 + h * 64 + 4 * (c ^ (jl & 15)), hw, trow < hw);
+    }
     __syncthreads();
-
-    // ---- direction 1: rows of S against teacher rows T1[i, :] ----
+    // ---- direction 1: B = sum_j t s over the tile's columns, rows wave*32 .. +32 ----
 #pragma unroll
     for (int st = 0; st < 8; ++st) {
         const int rl = wave * 32 + st * 4 + g, row = tm * 128 + rl;
-        const bool rok = row < hw;
         const float ir1 = sSt[rl][1];
-        float Z = 0.f, Wt = 0.f, A = 0.f, B = 0.f;
+        float B = 0.f;
 #pragma unroll
-        for (int cg = 0; cg < 8; ++cg) {
-            const int cl = cg * 16 + c;
-            if (rok && tn * 128 + cl < hw) {
-                const float s = sS[sidx(rl, cl, 128)];
-                const float t = fmaxf(t1v[st][cg] * ir1, CV_EPS);
-                Z += __expf(s); Wt += t; A += t * __logf(t); B += t * s;
-            }
+        for (int h = 0; h < 2; ++h) {
+            const f32x4 sv = *(const f32x4*)(sS + rl * 128 + h * 64 + 4 * c);
+            const int col = tn * 128 + h * 64 + 4 * c;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (col + k < hw) B = fmaf(fmaxf(t1v[st][h][k] * ir1, CV_EPS), sv[k], B);
         }
-        Z = row16_sum(Z); Wt = row16_sum(Wt); A = row16_sum(A); B = row16_sum(B);
-        if (c == 0 && rok) *(f32x4*)(q.part1 + (((long)p * q.nslab + tn) * hw + row) * 4) = f32x4{Z, Wt, A, B};
+        B = row16_sum(B);
+        if (c == 0 && row < hw)
+            *(f32x4*)(q.part1 + (((long)p * q.nslab + tn) * hw + row) * 4) = f32x4{sZr[rl] + sZr[128 + rl], 0.f, 0.f, B};
     }
-    // ---- direction 2: columns of S against teacher rows T2[j, :] ----
+    __syncthreads();
+    // ---- S^T into the same LDS: lane (g, c) owns rows 4g..4g+3 of m-tile i for its column: one b128 per (i, j) ----
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int cl = wn * 64 + j * 16 + c;                 // S^T row
+            const int L = i * 4 + g;                             // 16-byte chunk inside the wm half
+            *(f32x4*)(sS + cl * 128 + wm * 64 + 4 * (L ^ (cl & 15))) = acc[i][j];
+        }
+    __syncthreads();
+    // ---- direction 2: B = sum_i t s over the tile's rows, columns wave*32 .. +32 ----
 #pragma unroll
     for (int st = 0; st < 8; ++st) {
         const int jl = wave * 32 + st * 4 + g, col = tn * 128 + jl;
-        const bool cok = col < hw;
         const float ir2 = sSt[128 + jl][1];
-        float Z = 0.f, Wt = 0.f, A = 0.f, B = 0.f;
+        float B = 0.f;
 #pragma unroll
-        for (int ig = 0; ig < 8; ++ig) {
-            const int il = ig * 16 + c;
-            if (cok && tm * 128 + il < hw) {
-                const float s = sS[sidx(il, jl, 128)];
-                const float t = fmaxf(t2v[st][ig] * ir2, CV_EPS);
-                Z += __expf(s); Wt += t; A += t * __logf(t); B += t * s;
-            }
+        for (int h = 0; h < 2; ++h) {
+            const f32x4 sv = *(const f32x4*)(sS + jl * 128 + h * 64 + 4 * c);      // physical chunk c = logical c ^ (jl & 15)
+            const int ti = tm * 128 + h * 64 + 4 * (c ^ (jl & 15));
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (ti + k < hw) B = fmaf(fmaxf(t2v[st][h][k] * ir2, CV_EPS), sv[k], B);
         }
-        Z = row16_sum(Z); Wt = row16_sum(Wt); A = row16_sum(A); B = row16_sum(B);
-        if (c == 0 && cok) *(f32x4*)(q.part2 + (((long)p * q.nslab + tm) * hw + col) * 4) = f32x4{Z, Wt, A, B};
+        B = row16_sum(B);
+        if (c == 0 && col < hw)
+            *(f32x4*)(q.part2 + (((long)p * q.nslab + tm) * hw + col) * 4) = f32x4{sZc[jl] + sZc[128 + jl], 0.f, 0.f, B};
     }
 }
 
 // reduce the slabs, save logZ and W for the backward, emit per-chunk partial losses (CV_FCH chunks per pair), then sum
 #define CV_FCH 8
-__global__ __launch_bounds__(256) void cv_finalize_kernel(const float* part1, const float* part2,
+__global__ __launch_bounds__(256) void cv_finalize_kernel(const float* part1, const float* part2, const float* wa,
                                                           const unsigned char* m1, const unsigned char* m2,
                                                           float* stats, double* chunk_loss, int hw, int nslab, int variant) {
     const int p = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
@@ -233,11 +299,12 @@ __global__ __launch_bounds__(256) void cv_finalize_kernel(const float* part1, co
     for (int idx = ch * per + tid; idx < min(2 * hw, (ch + 1) * per); idx += 256) {
         const int d = idx >= hw, row = d ? idx - hw : idx;
         const float* part = d ? part2 : part1;
-        float Z = 0.f, Wt = 0.f, A = 0.f, B = 0.f;
+        float Z = 0.f, B = 0.f;
         for (int s = 0; s < nslab; ++s) {
             const f32x4 v = *(const f32x4*)(part + (((long)p * nslab + s) * hw + row) * 4);
-            Z += v[0]; Wt += v[1]; A += v[2]; B += v[3];
+            Z += v[0]; B += v[3];
         }
+        const float Wt = wa[(((long)p * 2 + d) * hw + row) * 2], A = wa[(((long)p * 2 + d) * hw + row) * 2 + 1];
         const float logZ = logf(Z);
         float* st = stats + (((long)p * 2 + d) * hw + row) * 4;
         st[2] = logZ;
@@ -398,7 +465,8 @@ static inline int cv_hwp(int hw) { return (hw + 63) & ~63; }   // K of the two b
 
 extern "C" size_t gd_cost_volume_kl_workspace_bytes(int P, int hw, int C, int dtype, int backward) {
     const size_t es = (size_t)gd_dtype_size(dtype);
-    if (!backward) return 2 * align256((size_t)P * 2 * cv_tiles(hw) * hw * 4 * sizeof(float)) + align256((size_t)P * CV_FCH * sizeof(double));
+    if (!backward) return 2 * align256((size_t)P * 2 * cv_tiles(hw) * hw * 4 * sizeof(float)) + align256((size_t)P * CV_FCH * sizeof(double)) +
+                          align256((size_t)P * 2 * hw * 2 * sizeof(float));
     const size_t hwp = (size_t)cv_hwp(hw);
     return 2 * align256((size_t)P * hw * hwp * es) + 2 * align256((size_t)P * C * hwp * es) +
            2 * align256((size_t)P * hw * C * sizeof(float));
@@ -421,7 +489,8 @@ extern "C" int gd_cost_volume_kl_fwd(const void* f1, const void* f2, const float
     float* part1 = (float*)workspace;
     float* part2 = (float*)((char*)workspace + align256((size_t)P * nslab * hw * 4 * sizeof(float)));
     double* chunk_loss = (double*)((char*)workspace + 2 * align256((size_t)P * 2 * tiles * hw * 4 * sizeof(float)));
-    hipLaunchKernelGGL(cv_prep_kernel, dim3(gd_cdiv(hw, 4), 2, P), dim3(256), 0, s, f1, f2, t1, t2, stats, hw, C,
+    float* wa = (float*)((char*)chunk_loss + align256((size_t)P * CV_FCH * sizeof(double)));
+    hipLaunchKernelGGL(cv_prep_kernel, dim3(gd_cdiv(hw, 4), 2, P), dim3(256), 0, s, f1, f2, t1, t2, stats, wa, hw, C,
                        dtype);
     GD_LAUNCH_OK();
     CvTileParams q = {};
@@ -432,7 +501,7 @@ extern "C" int gd_cost_volume_kl_fwd(const void* f1, const void* f2, const float
     else
         hipLaunchKernelGGL(cv_fwd_tile_kernel<float>, dim3(tiles * tiles, P), dim3(256), 0, s, q);
     GD_LAUNCH_OK();
-    hipLaunchKernelGGL(cv_finalize_kernel, dim3(P, CV_FCH), dim3(256), 0, s, part1, part2, m1, m2, stats, chunk_loss, hw,
+    hipLaunchKernelGGL(cv_finalize_kernel, dim3(P, CV_FCH), dim3(256), 0, s, part1, part2, wa, m1, m2, stats, chunk_loss, hw,
                        nslab, variant);
     hipLaunchKernelGGL(cv_loss_kernel, dim3(gd_cdiv(P, 64)), dim3(64), 0, s, chunk_loss, loss, P, hw);
     GD_LAUNCH_OK();
