@@ -310,10 +310,12 @@ class _TapMean(torch.autograd.Function):
     def backward(ctx, dout):
         prefix, ng, B, Nt, D = ctx.meta
         dout = dout.contiguous()
-        dg = [torch.empty(B, Nt, D, dtype=dout.dtype, device=dout.device) for _ in range(ng)]
-        check(lib().gd_tap_mean_bwd(_ptr_array(dg), ng, prefix, ptr(dout), B, Nt - prefix, D, dtype_code(dout),
+        # the ng gradients are identical (dout / ng): one buffer, handed to every grid
+        dg = torch.empty(B, Nt, D, dtype=dout.dtype, device=dout.device)
+        scaled = dout * (1.0 / ng)
+        check(lib().gd_tap_mean_bwd(_ptr_array([dg]), 1, prefix, ptr(scaled), B, Nt - prefix, D, dtype_code(dout),
                                     stream()), "gd_tap_mean_bwd")
-        return (None,) + tuple(dg)
+        return (None,) + (dg,) * ng
 
 
 def tap_mean(grids, prefix=1):

@@ -441,8 +441,12 @@ class _GatherFn(torch.autograd.Function):
     def backward(ctx, dout):
         (kp,) = ctx.saved_tensors
         (gh, gw, sx, sy, img_h, img_w, patch), B, Ng, D, prefix, ng, T = ctx.meta
-        dg = ops.kp_gather_bwd(ng, kp, dout, B, kp.shape[1], gh, gw, D, sx, sy, img_h, img_w, patch, prefix=prefix)
-        return (None, None) + tuple(dg)     # fp32 gradients; LN / conv backward accept them
+        # every grid of the mean receives the SAME gradient (w * dout / ng): scatter it once and hand the one buffer, cast
+        # once to the grids' dtype, to all of them (four zero-filled fp32 grids + four scatters + four casts otherwise)
+        dg = ops.kp_gather_bwd(1, kp, dout * (1.0 / ng), B, kp.shape[1], gh, gw, D, sx, sy, img_h, img_w, patch, prefix=prefix)[0]
+        if dg.dtype != T:
+            dg = dg.to(T)
+        return (None, None) + (dg,) * ng
 
 
 def kp_gather(grids, kp, gh, gw, sx, sy, img_h, img_w, patch):

@@ -83,9 +83,8 @@ def main():
     batches = [synthetic_batch(P, img, img, N, hw, dev, seed=1234 + 1000 * rank + i, teacher_patch=patch) for i in range(2)]
 
     def step(i):
-        eng.zero_grad_flat()
         loss, terms = eng.training_step(batches[i % len(batches)])
-        loss.backward()
+        eng.backward(loss)          # gradients land in the flat buffer through one multi-tensor copy
         reducer.start()
         scale = reducer.finish()
         eng.optimizer_step(grad_scale=scale)
