@@ -20,6 +20,16 @@
 
 #define HD 64
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // bare v_exp_f32
+// max over the 4 lanes {l, l^16, l^32, l^48} with the gfx950 row-swap instructions (VALU; a ds_bpermute pair costs two
+// dependent LDS round trips in the middle of the softmax)
+__device__ __forceinline__ float quad_rows_max(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = fmaxf(__builtin_bit_cast(float, a[0]), __builtin_bit_cast(float, a[1]));
+    const unsigned w = __builtin_bit_cast(unsigned, v);
+    const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return fmaxf(__builtin_bit_cast(float, b[0]), __builtin_bit_cast(float, b[1]));
+}
 
 template <typename T> struct AT;
 template <> struct AT<bf16> {
@@ -196,8 +206,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* qkv, T* o, fl
                     if (tail && k0 + kt * 16 + g * 4 + r >= N) s[qt][kt][r] = -1e30f;
                     tmax = fmaxf(tmax, s[qt][kt][r]);
                 }
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            tmax = quad_rows_max(tmax);
             const float mn = fmaxf(m[qt], tmax * c2);      // c2 > 0: max commutes with the scaling
             const float alpha = fast_exp2(m[qt] - mn);
             float ps = 0.f;
@@ -209,9 +218,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* qkv, T* o, fl
                     s[qt][kt][r] = p;
                     ps += p;
                 }
-            ps += __shfl_xor(ps, 16, 64);
-            ps += __shfl_xor(ps, 32, 64);
-            l[qt] = l[qt] * alpha + ps;
+            l[qt] = l[qt] * alpha + ps;                     // per-LANE partial (this lane's 16 keys of every tile): the
+                                                            // four lanes of a query are summed once, after the loop
             const bool moved = mn != m[qt];
             m[qt] = mn;
             if (__any(moved)) {
@@ -238,6 +246,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* qkv, T* o, fl
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         const int q = q0 + qt * 16 + c;
+        l[qt] += __shfl_xor(l[qt], 16, 64);
+        l[qt] += __shfl_xor(l[qt], 32, 64);
         if (q >= N) continue;
         const float inv = 1.0f / l[qt];
         T* orow = o + ((long)b * N + q) * H * HD + h * HD;
