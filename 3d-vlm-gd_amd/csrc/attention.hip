@@ -504,6 +504,189 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const T* qkv, con
     }
 }
 
+// ------------------------------------------------------------------------------------------ teacher cross-view maps
+// VGGT teacher -> distillation target.  The reference's global blocks return, per head, the two
+// cross-view softmax maps  softmax(q[prefix:N/2] k[N/2+prefix:]^T * scale / temperature)  and the mirrored one
+// (vggt/layers/attention.py:51-85), i.e. [2B, H, n, n] fp32 per block (480 MB per pair at n = 1369, H = 16), which are then
+// averaged over heads (src/finetune_timm_vggt.py:390-392) and over the selected blocks (vggt/models/aggregator.py:273).
+// Here only the averaged [2B, n, n] map ever exists: pass 1 = flash-style row statistics per (direction, head, query)
+// (log2 domain), pass 2 = one block per (128 queries x 64 keys) output tile loops over the heads, recomputes the
+// S^T tile on the MFMA and accumulates exp2(s - lse) in registers; `weight` (= 1 / (H * blocks)) and `accumulate`
+// fold the layer mean into the same buffer.  q, k: [B, H, N, 64] (after q/k-norm and RoPE).
+template <typename T>
+__global__ __launch_bounds__(256, 2) void cva_stats_kernel(const T* q, const T* k, float* lse2, int B, int H, int N, int prefix,
+                                                           float c2) {
+    constexpr int NF = AT<T>::NF, ROWB = AT<T>::ROWB;
+    typedef typename Mma<T>::Frag Frag;
+    __shared__ __attribute__((aligned(16))) char sK[64 * ROWB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+    const int n = N / 2 - prefix, dir = blockIdx.z / B, b = blockIdx.z % B, h = blockIdx.y;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const long ld_b = (long)HD * sizeof(T);
+    const char* qb = (const char*)q + (((long)b * H + h) * N + (dir ? N / 2 + prefix : prefix)) * ld_b;
+    const char* kb = (const char*)k + (((long)b * H + h) * N + (dir ? prefix : N / 2 + prefix)) * ld_b;
+    Frag qf[2][NF];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int qi = q0 + qt * 16 + c;
+#pragma unroll
+        for (int u = 0; u < NF; ++u) {
+            Frag z = {};
+            qf[qt][u] = qi < n ? load_nfrag<T>(qb + (long)qi * ld_b, u, g) : z;
+        }
+    }
+    float m[2] = {-1e30f, -1e30f}, l[2] = {0.f, 0.f};
+    TileRegs<T> rk;
+    tile_load<T>(rk, kb, ld_b, 0, n);
+    for (int k0 = 0; k0 < n; k0 += 64) {
+        __syncthreads();
+        tile_store<T, true, false>(rk, sK, nullptr);
+        __syncthreads();
+        if (k0 + 64 < n) tile_load<T>(rk, kb, ld_b, k0 + 64, n);
+        f32x4 s[2][4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            Frag kf[NF];
+#pragma unroll
+            for (int u = 0; u < NF; ++u) kf[u] = load_nfrag<T>(sK + (kt * 16 + c) * ROWB, u, g);
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < NF; ++u) a = Mma<T>::mma(kf[u], qf[qt][u], a);
+                s[qt][kt] = a;
+            }
+        }
+        const bool tail = k0 + 64 > n;
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            float tmax = -1e30f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (tail && k0 + kt * 16 + g * 4 + r >= n) s[qt][kt][r] = -1e30f;
+                    tmax = fmaxf(tmax, s[qt][kt][r]);
+                }
+            tmax = quad_rows_max(tmax);
+            const float mn = fmaxf(m[qt], tmax * c2);
+            float ps = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ps += fast_exp2(fmaf(s[qt][kt][r], c2, -mn));
+            l[qt] = l[qt] * fast_exp2(m[qt] - mn) + ps;
+            m[qt] = mn;
+        }
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int qi = q0 + qt * 16 + c;
+        l[qt] += __shfl_xor(l[qt], 16, 64);
+        l[qt] += __shfl_xor(l[qt], 32, 64);
+        if (qi < n && g == 0) lse2[(((long)dir * B + b) * H + h) * n + qi] = m[qt] + log2f(l[qt]);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void cva_emit_kernel(const T* q, const T* k, const float* lse2, float* out, int B, int H, int N,
+                                                          int prefix, float c2, float weight, int accumulate) {
+    constexpr int NF = AT<T>::NF, ROWB = AT<T>::ROWB;
+    typedef typename Mma<T>::Frag Frag;
+    __shared__ __attribute__((aligned(16))) char sK[64 * ROWB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+    const int n = N / 2 - prefix, dir = blockIdx.z / B, b = blockIdx.z % B;
+    const int q0 = blockIdx.x * 128 + wave * 32, k0 = blockIdx.y * 64;
+    const long ld_b = (long)HD * sizeof(T);
+    const long head_b = (long)N * ld_b;
+    const char* qb = (const char*)q + (((long)b * H) * N + (dir ? N / 2 + prefix : prefix)) * ld_b;
+    const char* kb = (const char*)k + (((long)b * H) * N + (dir ? prefix : N / 2 + prefix)) * ld_b;
+    const float* lb = lse2 + (((long)dir * B + b) * H) * n;
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) acc[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    TileRegs<T> rk;
+    tile_load<T>(rk, kb, ld_b, k0, n);
+    for (int h = 0; h < H; ++h) {
+        __syncthreads();
+        tile_store<T, true, false>(rk, sK, nullptr);
+        __syncthreads();
+        if (h + 1 < H) tile_load<T>(rk, kb + (long)(h + 1) * head_b, ld_b, k0, n);
+        Frag qf[2][NF];
+        float ls[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const int qi = q0 + qt * 16 + c;
+            ls[qt] = qi < n ? lb[(long)h * n + qi] : 0.f;
+#pragma unroll
+            for (int u = 0; u < NF; ++u) {
+                Frag z = {};
+                qf[qt][u] = qi < n ? load_nfrag<T>(qb + (long)h * head_b + (long)qi * ld_b, u, g) : z;
+            }
+        }
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            Frag kf[NF];
+#pragma unroll
+            for (int u = 0; u < NF; ++u) kf[u] = load_nfrag<T>(sK + (kt * 16 + c) * ROWB, u, g);
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < NF; ++u) a = Mma<T>::mma(kf[u], qf[qt][u], a);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[qt][kt][r] += fast_exp2(fmaf(a[r], c2, -ls[qt]));
+            }
+        }
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int qi = q0 + qt * 16 + c;
+        if (qi >= n) continue;
+        float* orow = out + (((long)dir * B + b) * n + qi) * n;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kj = k0 + kt * 16 + g * 4 + r;
+                if (kj < n) orow[kj] = weight * acc[qt][kt][r] + (accumulate ? orow[kj] : 0.f);
+            }
+    }
+}
+
+extern "C" size_t gd_cross_view_attn_workspace_bytes(int B, int H, int N, int prefix) {
+    const int n = N / 2 - prefix;
+    return n > 0 ? (size_t)2 * B * H * n * sizeof(float) : 0;
+}
+
+extern "C" int gd_cross_view_attn(const void* q, const void* k, float* out, int B, int H, int N, int prefix, int head_dim,
+                                  float scale, float temperature, float weight, int accumulate, int dtype, void* workspace,
+                                  void* stream) {
+    GD_REQUIRE(B > 0 && H > 0 && N > 0 && N % 2 == 0 && prefix >= 0 && N / 2 - prefix > 0,
+               "gd_cross_view_attn: bad shape B=%d H=%d N=%d prefix=%d", B, H, N, prefix);
+    GD_REQUIRE(head_dim == HD, "gd_cross_view_attn: head_dim must be 64 (got %d)", head_dim);
+    GD_REQUIRE(dtype == GD_F32 || dtype == GD_BF16, "gd_cross_view_attn: bad dtype %d", dtype);
+    GD_REQUIRE(temperature > 0.f, "gd_cross_view_attn: temperature must be positive");
+    GD_REQUIRE(((uintptr_t)q & 15) == 0 && ((uintptr_t)k & 15) == 0 && workspace != nullptr,
+               "gd_cross_view_attn: q, k must be 16-byte aligned, workspace non-null");
+    const int n = N / 2 - prefix;
+    const float c2 = scale / temperature * 1.4426950408889634f;
+    float* lse2 = (float*)workspace;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 g1(gd_cdiv(n, 128), H, 2 * B), g2(gd_cdiv(n, 128), gd_cdiv(n, 64), 2 * B);
+    if (dtype == GD_BF16) {
+        hipLaunchKernelGGL(cva_stats_kernel<bf16>, g1, dim3(256), 0, s, (const bf16*)q, (const bf16*)k, lse2, B, H, N, prefix, c2);
+        hipLaunchKernelGGL(cva_emit_kernel<bf16>, g2, dim3(256), 0, s, (const bf16*)q, (const bf16*)k, lse2, out, B, H, N, prefix, c2, weight, accumulate);
+    } else {
+        hipLaunchKernelGGL(cva_stats_kernel<float>, g1, dim3(256), 0, s, (const float*)q, (const float*)k, lse2, B, H, N, prefix, c2);
+        hipLaunchKernelGGL(cva_emit_kernel<float>, g2, dim3(256), 0, s, (const float*)q, (const float*)k, lse2, out, B, H, N, prefix, c2, weight, accumulate);
+    }
+    GD_LAUNCH_OK();
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------ C ABI
 extern "C" int gd_attention_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, int head_dim, float scale,
                                 int dtype, void* stream) {

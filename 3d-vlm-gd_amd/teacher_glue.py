@@ -133,3 +133,26 @@ def point_cloud_to_depth(points, K, w, h, device=None):
     check(lib().gd_point_cloud_to_depth(ptr(pts), ptr(k), ptr(depth), ptr(cnt), 1, pts.shape[1], w, h, stream()),
           "gd_point_cloud_to_depth")
     return depth.view(1, 1, h, w)
+
+
+def cross_view_attention_maps(q, k, scale, temperature=1.0, prefix=5, out=None, weight=None, accumulate=False):
+    """Head-averaged cross-view attention maps of one VGGT global block (vggt/layers/attention.py:51-85, `return_attn`,
+    followed by `.mean(dim=1)` of src/finetune_timm_vggt.py:390-392) without the [2B, H, n, n] intermediate.
+    q, k: [B, H, N, 64] (f32 | bf16) -> [2B, n, n] fp32, n = N/2 - prefix.  Averaging over several blocks
+    (vggt/models/aggregator.py:273): call once per block with the same `out`, weight = 1 / (H * n_blocks) and
+    accumulate=True from the second block on."""
+    if not (q.is_cuda and k.is_cuda and q.dtype == k.dtype and q.shape == k.shape and q.dim() == 4):
+        raise GdHipError("cross_view_attention_maps: q, k must be CUDA tensors [B, H, N, 64] of one dtype")
+    B, H, N, d = q.shape
+    q, k = q.contiguous(), k.contiguous()
+    n = N // 2 - prefix
+    if out is None:
+        out = torch.empty(2 * B, max(n, 0), max(n, 0), dtype=torch.float32, device=q.device)
+    ws = torch.empty(max(1, lib().gd_cross_view_attn_workspace_bytes(B, H, N, prefix)), dtype=torch.uint8, device=q.device)
+    dt = 1 if q.dtype == torch.bfloat16 else 0
+    if q.dtype not in (torch.float32, torch.bfloat16):
+        raise GdHipError("cross_view_attention_maps: dtype must be float32 or bfloat16")
+    w = (1.0 / H) if weight is None else float(weight)
+    check(lib().gd_cross_view_attn(ptr(q), ptr(k), ptr(out), B, H, N, int(prefix), d, float(scale), float(temperature), w,
+                                   1 if accumulate else 0, dt, ptr(ws), stream()), "gd_cross_view_attn")
+    return out

@@ -158,6 +158,17 @@ int gd_point_cloud_to_depth(const float* points, const float* K, float* depth, f
 int gd_rope_2d(void* tokens, const long* positions, int B, int N, int H, int D, long ld_tok, float base, float fwd,
                int dtype, void* stream);
 
+/* VGGT teacher -> distillation target: head- (and, through weight / accumulate, block-) averaged cross-view attention maps.
+ * Replaces the `return_attn` branch of vggt/layers/attention.py:51-85 (two [B,H,n,n] softmax blocks per global block,
+ * torch.cat on dim 0) + the head mean of src/finetune_timm_vggt.py:390-392 + the block mean of vggt/models/aggregator.py:273,
+ * without ever materialising a per-head map.  q, k: [B, H, N, 64] (f32 | bf16, after q/k-norm and RoPE), N even;
+ * n = N/2 - prefix; out [2B, n, n] fp32: rows 0..B-1 = softmax(q[prefix:N/2] k[N/2+prefix:]^T scale / temperature),
+ * rows B..2B-1 the mirrored block; out = (accumulate ? out : 0) + weight * sum_h softmax_h.  workspace: row statistics. */
+size_t gd_cross_view_attn_workspace_bytes(int B, int H, int N, int prefix);
+int gd_cross_view_attn(const void* q, const void* k, float* out, int B, int H, int N, int prefix, int head_dim,
+                       float scale, float temperature, float weight, int accumulate, int dtype, void* workspace,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -596,3 +596,16 @@ def mast3r_keypoint_filter(kp1, kp2, conf1, conf2, min_conf_thr=10):
     _, i2 = filter_kp_by_conf(b, conf2 >= th2)
     keep = torch.unique(torch.cat([i1, i2], 0))
     return a[:, keep], b[:, keep]
+
+
+def cross_view_attention_maps(q, k, scale, temperature=1.0, prefix=5):
+    """VGGT teacher -> distillation target: the cross-view attention maps of one global block,
+    vggt/layers/attention.py:51-85 (`return_attn` branch: q scaled by head_dim^-0.5, the two cross blocks
+    q[prefix:N/2].k[N/2+prefix:]^T and q[N/2+prefix:].k[prefix:N/2]^T, softmax(scores / temperature) over keys,
+    torch.cat on dim 0), followed by the head mean of src/finetune_timm_vggt.py:390-392.
+    q, k [B, H, N, d] -> [2B, n, n] with n = N/2 - prefix; rows 0..B-1 are view-1 queries, B..2B-1 view-2 queries."""
+    N = q.shape[2]
+    qs = q * scale
+    a1 = torch.softmax(qs[..., prefix:N // 2, :] @ k[..., N // 2 + prefix:, :].transpose(-2, -1) / temperature, dim=-1)
+    a2 = torch.softmax(qs[..., N // 2 + prefix:, :] @ k[..., prefix:N // 2, :].transpose(-2, -1) / temperature, dim=-1)
+    return torch.cat([a1, a2], dim=0).mean(dim=1)

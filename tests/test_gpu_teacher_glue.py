@@ -56,3 +56,29 @@ def test_nn_argmax_and_nms_at_teacher_scale():
     assert sub.shape == (300, 2)
     lin = set((want[:, 0] * W + want[:, 1]).tolist())
     assert all(int(r) * W + int(c) in lin for r, c in sub.cpu())
+
+
+def test_cross_view_attention_maps_golden_and_full_size():
+    """gd_cross_view_attn against the reference fixture (f32), and at the teacher's real size against the oracle (bf16 / f32),
+    including the block mean folded in through weight / accumulate."""
+    from gd_amd import teacher_glue as TG
+    import gd_oracle as O
+    g = load_golden("g14_cross_view_attn")
+    q, k = g["q"].cuda(), g["k"].cuda()
+    out = TG.cross_view_attention_maps(q, k, float(g["scale"]), float(g["temperature"]), int(g["prefix"]))
+    assert out.shape == g["maps"].shape
+    assert float((out.cpu() - g["maps"]).abs().max()) < 2e-6
+    # real size: 2 views x (5 + 37*37) tokens, 16 heads; two "blocks" averaged
+    B, H, n, prefix = 1, 16, 1369, 5
+    N = 2 * (n + prefix)
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    qs = [torch.randn(B, H, N, 64, device="cuda", generator=gen) for _ in range(2)]
+    ks = [torch.randn(B, H, N, 64, device="cuda", generator=gen) for _ in range(2)]
+    for dt, tol in ((torch.float32, 2e-6), (torch.bfloat16, 2e-3)):
+        acc = None
+        for i in range(2):
+            acc = TG.cross_view_attention_maps(qs[i].to(dt), ks[i].to(dt), 0.125, 0.7, prefix, out=acc, weight=1.0 / (2 * H),
+                                               accumulate=i > 0)
+        ref = sum(O.cross_view_attention_maps(qs[i].to(dt).double(), ks[i].to(dt).double(), 0.125, 0.7, prefix) for i in range(2)) / 2
+        assert float((acc.double() - ref).abs().max()) < tol * float(ref.abs().max()) + 1e-9, dt
+        assert float((acc.sum(-1) - 1).abs().max()) < 1e-3

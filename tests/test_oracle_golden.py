@@ -161,3 +161,12 @@ def test_reciprocal_nns():
     assert torch.equal(xy1, g["xy1"].long()) and torch.equal(xy2, g["xy2"].long())
     k1, k2 = O.mast3r_keypoint_filter(xy1, xy2, g["conf1"], g["conf2"])
     assert torch.equal(k1[0], g["kp1_filtered"]) and torch.equal(k2[0], g["kp2_filtered"])
+
+
+def test_g14_cross_view_attention_maps():
+    """VGGT teacher cross-view maps (vggt/layers/attention.py:51-85 + head mean): oracle vs the reference's output."""
+    g = load_golden("g14_cross_view_attn")
+    got = O.cross_view_attention_maps(g["q"], g["k"], float(g["scale"]), float(g["temperature"]), int(g["prefix"]))
+    assert got.shape == g["maps"].shape
+    assert float((got - g["maps"]).abs().max()) < 1e-6
+    assert float((got.sum(-1) - 1).abs().max()) < 1e-5      # every row is a mean of softmax rows

@@ -110,6 +110,26 @@ def bench_attn():
     print(f"attn bwd  {t*1e6:8.1f} us  {2.5*fl/t/1e12:7.1f} TF/s (algorithmic 5 products)")
 
 
+def bench_cva():
+    """teacher cross-view attention maps (gd_cross_view_attn) vs the reference formulation in torch (per-head maps materialised)."""
+    from gd_amd import teacher_glue as TG
+    B, H, n, prefix = 4, 16, 1369, 5
+    N = 2 * (n + prefix)
+    q = torch.randn(B, H, N, 64, device="cuda").bfloat16()
+    k = torch.randn(B, H, N, 64, device="cuda").bfloat16()
+    out = torch.empty(2 * B, n, n, device="cuda")
+    t = timeit(lambda: TG.cross_view_attention_maps(q, k, 0.125, 0.7, prefix, out=out))
+
+    def ref():
+        qs = q.float() * 0.125
+        a1 = torch.softmax(qs[..., prefix:N // 2, :] @ k.float()[..., N // 2 + prefix:, :].transpose(-2, -1) / 0.7, -1)
+        a2 = torch.softmax(qs[..., N // 2 + prefix:, :] @ k.float()[..., prefix:N // 2, :].transpose(-2, -1) / 0.7, -1)
+        return torch.cat([a1, a2], 0).mean(1)
+    t2 = timeit(ref, warm=1, it=3)
+    by = 2 * B * n * n * 4 + 2 * q.numel() * 2
+    print(f"cross_view_attn B={B} H={H} n={n}: {t*1e6:8.1f} us ({t*1e6/B:.1f} us/pair, {by/t/1e9:.0f} GB/s of output+inputs) | torch per-head maps {t2*1e6:8.1f} us")
+
+
 def bench_tn():
     M = 87680
     for (N, K, ydt, xdt) in [(8, 2304, torch.float32, torch.bfloat16), (8, 768, torch.float32, torch.bfloat16),
@@ -203,6 +223,8 @@ if __name__ == "__main__":
         pmc_cv()
     if "attn" in which:
         bench_attn()
+    if "cva" in which:
+        bench_cva()
     if "tn" in which:
         bench_tn()
     if "rank" in which:
