@@ -47,6 +47,8 @@ SIGNATURES = {
     "gd_patch_mask": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "gd_smooth_ap": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float,
                              c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gd_smooth_ap_me": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_void_p,
+                                c_void_p, c_void_p, c_void_p]),
     "gd_pair_rank_workspace_bytes": (c_size_t, [c_int]),
     "gd_pair_rank": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p,
                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

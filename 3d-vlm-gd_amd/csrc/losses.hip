@@ -86,6 +86,85 @@ __global__ __launch_bounds__(256) void smooth_ap_kernel(const float* sim, const 
     if (threadIdx.x == 0) row_loss[(long)p * Nmax + i] = (1.0f - 0.5f * (ap1 + ap2)) / (float)n;
 }
 
+// ---- "ME" variant of the matching loss (src/finetune_timm_me.py:191-220): the positives are EVERY (i, j) whose 3-D points
+// are closer than thres3d_pos (a dynamic count, none or several per row), the negatives those farther than thres3d_neg;
+//   per positive (i, jp):  ap1 = r1 / (r1 + sum_neg sig(s_ij - 1)),  r1 = sig(s_pos - 1) + 1
+//                          ap2 = r2 / (r2 + sum_neg sig(s_ij - s_pos)),  r2 = sig(1 - s_pos) + 1;   loss = mean_pos (1 - (ap1+ap2)/2)
+// One block per row i walks the row's positives in index order (deterministic); the row of dsim is accumulated in place,
+// UN-normalised (the number of positives of the pair is only known once every row is done): smooth_ap_me_finalize
+// divides.  row_ws: [P][Nmax][2] = {sum over the row's positives of (1 - ap), number of positives}.
+#define AP_ME_NMAX 4096
+__global__ __launch_bounds__(256) void smooth_ap_me_kernel(const float* sim, const float* pts1, const float* pts2, const int* counts,
+                                                           float* row_ws, float* dsim, int Nmax, float thr_pos, float thr_neg,
+                                                           float inv_temp) {
+    __shared__ float red[4];
+    __shared__ unsigned char flag[AP_ME_NMAX];   // bit 0: negative, bit 1: positive
+    const int p = blockIdx.y, i = blockIdx.x, n = counts ? counts[p] : Nmax;
+    const float* srow = sim + ((long)p * Nmax + i) * Nmax;
+    float* drow = dsim + ((long)p * Nmax + i) * Nmax;
+    for (int j = threadIdx.x; j < Nmax; j += 256) drow[j] = 0.f;
+    if (i >= n) {
+        if (threadIdx.x == 0) { row_ws[((long)p * Nmax + i) * 2] = 0.f; row_ws[((long)p * Nmax + i) * 2 + 1] = 0.f; }
+        return;
+    }
+    const float ax = pts1[((long)p * Nmax + i) * 3 + 0], ay = pts1[((long)p * Nmax + i) * 3 + 1], az = pts1[((long)p * Nmax + i) * 3 + 2];
+    float A1 = 0.f;
+    for (int j = threadIdx.x; j < n; j += 256) {
+        const float* q = pts2 + ((long)p * Nmax + j) * 3;
+        const float dx = ax - q[0], dy = ay - q[1], dz = az - q[2];
+        const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+        const unsigned char f = (dist > thr_neg ? 1 : 0) | (dist < thr_pos ? 2 : 0);
+        flag[j] = f;
+        if (f & 1) { float d1; A1 += sig_t(srow[j] - 1.0f, inv_temp, d1); }
+    }
+    A1 = block_sum(A1, red);          // (its barriers also publish flag[])
+    float lsum = 0.f;
+    int npos = 0;
+    for (int jp = 0; jp < n; ++jp) {
+        if (!(flag[jp] & 2)) continue;                 // block-uniform
+        const float pos = srow[jp];
+        float A2 = 0.f, D2 = 0.f;
+        for (int j = threadIdx.x; j < n; j += 256)
+            if (flag[j] & 1) { float d2; A2 += sig_t(srow[j] - pos, inv_temp, d2); D2 += d2; }
+        A2 = block_sum(A2, red);
+        D2 = block_sum(D2, red);
+        float dr1, dr2;
+        const float r1 = sig_t(pos - 1.0f, inv_temp, dr1) + 1.0f, r2 = sig_t(1.0f - pos, inv_temp, dr2) + 1.0f;
+        const float den1 = r1 + A1, den2 = r2 + A2;
+        const float ap1 = r1 / den1, ap2 = r2 / den2;
+        const float dap1_dA = -r1 / (den1 * den1), dap2_dA = -r2 / (den2 * den2);
+        const float dap1_dr = A1 / (den1 * den1), dap2_dr = A2 / (den2 * den2);
+        lsum += 1.0f - 0.5f * (ap1 + ap2);
+        ++npos;
+        for (int j = threadIdx.x; j < n; j += 256) {
+            float gj = 0.f;
+            if (flag[j] & 1) {
+                float d1, d2;
+                sig_t(srow[j] - 1.0f, inv_temp, d1);
+                sig_t(srow[j] - pos, inv_temp, d2);
+                gj = -0.5f * (dap1_dA * d1 + dap2_dA * d2);
+            }
+            if (j == jp) gj += -0.5f * (dap1_dr * dr1 - dap2_dr * dr2 - dap2_dA * D2);
+            if (gj != 0.f) drow[j] += gj;               // this block owns the row
+        }
+    }
+    if (threadIdx.x == 0) { row_ws[((long)p * Nmax + i) * 2] = lsum; row_ws[((long)p * Nmax + i) * 2 + 1] = (float)npos; }
+}
+
+// loss[p] = sum_rows / M_p, dsim[p] /= M_p   (M_p = positives of the pair; 0 -> loss 0, zero gradient)
+__global__ __launch_bounds__(256) void smooth_ap_me_finalize_kernel(const float* row_ws, float* loss, float* dsim, int Nmax) {
+    __shared__ float red[4];
+    const int p = blockIdx.y;
+    float ls = 0.f, cnt = 0.f;
+    for (int i = threadIdx.x; i < Nmax; i += 256) { ls += row_ws[((long)p * Nmax + i) * 2]; cnt += row_ws[((long)p * Nmax + i) * 2 + 1]; }
+    ls = block_sum(ls, red);
+    cnt = block_sum(cnt, red);
+    const float inv = cnt > 0.f ? 1.0f / cnt : 0.f;
+    if (blockIdx.x == 0 && threadIdx.x == 0) loss[p] = ls * inv;
+    const long total = (long)Nmax * Nmax;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) dsim[(long)p * total + idx] *= inv;
+}
+
 // out[p] = sum_i rows[p, i]   (deterministic)
 __global__ __launch_bounds__(256) void row_sum_kernel(const float* rows, float* out, int n) {
     __shared__ float red[4];
@@ -465,6 +544,21 @@ extern "C" int gd_smooth_ap(const float* sim, const float* pts3d_1, const float*
     hipLaunchKernelGGL(smooth_ap_kernel, dim3(Nmax, P), dim3(256), 0, s, sim, pts3d_1, pts3d_2, counts, row_ws, dsim,
                        Nmax, variant, thres3d_neg, 1.0f / temp);
     hipLaunchKernelGGL(row_sum_kernel, dim3(P), dim3(256), 0, s, row_ws, loss, Nmax);
+    GD_LAUNCH_OK();
+    return 0;
+}
+
+extern "C" int gd_smooth_ap_me(const float* sim, const float* pts3d_1, const float* pts3d_2, const int* counts, int P,
+                               int Nmax, float thres3d_pos, float thres3d_neg, float temp, float* loss, float* dsim,
+                               float* row_ws, void* stream) {
+    GD_REQUIRE(P > 0 && Nmax > 0 && temp > 0.f, "gd_smooth_ap_me: bad arguments");
+    GD_REQUIRE(Nmax <= AP_ME_NMAX, "gd_smooth_ap_me: at most %d keypoints per view (got %d)", AP_ME_NMAX, Nmax);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(smooth_ap_me_kernel, dim3(Nmax, P), dim3(256), 0, s, sim, pts3d_1, pts3d_2, counts, row_ws, dsim, Nmax,
+                       thres3d_pos, thres3d_neg, 1.0f / temp);
+    int fb = (int)(((long)Nmax * Nmax + 255) / 256);
+    if (fb > 1024) fb = 1024;
+    hipLaunchKernelGGL(smooth_ap_me_finalize_kernel, dim3(fb, P), dim3(256), 0, s, row_ws, loss, dsim, Nmax);
     GD_LAUNCH_OK();
     return 0;
 }

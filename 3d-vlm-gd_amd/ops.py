@@ -362,10 +362,15 @@ class _SmoothAP(torch.autograd.Function):
         sim = gemm_nt(d1, d2)                                     # [P,N,N] fp32, exact-f32 MFMA
         loss = torch.empty(P, dtype=torch.float32, device=dev)
         dsim = torch.empty_like(sim)
-        rows = torch.empty(P, N, dtype=torch.float32, device=dev)
-        rc = lib().gd_smooth_ap(ptr(sim), ptr(p1), ptr(p2), ptr(counts), P, N, VARIANTS[variant], float(thr),
-                                float(temp), ptr(loss), ptr(dsim), ptr(rows), stream())
-        check(rc, "gd_smooth_ap")
+        rows = torch.empty(P, N, 2, dtype=torch.float32, device=dev)
+        if variant == "me":      # every pair closer than thr[0] is a positive (src/finetune_timm_me.py:191-220)
+            rc = lib().gd_smooth_ap_me(ptr(sim), ptr(p1), ptr(p2), ptr(counts), P, N, float(thr[0]), float(thr[1]),
+                                       float(temp), ptr(loss), ptr(dsim), ptr(rows), stream())
+            check(rc, "gd_smooth_ap_me")
+        else:
+            rc = lib().gd_smooth_ap(ptr(sim), ptr(p1), ptr(p2), ptr(counts), P, N, VARIANTS[variant], float(thr),
+                                    float(temp), ptr(loss), ptr(dsim), ptr(rows), stream())
+            check(rc, "gd_smooth_ap")
         ctx.save_for_backward(d1, d2, dsim)
         ctx.n0 = N0
         return loss
@@ -379,9 +384,11 @@ class _SmoothAP(torch.autograd.Function):
         return dd1[:, :ctx.n0], dd2[:, :ctx.n0], None, None, None, None, None, None
 
 
-def smooth_ap(desc1, desc2, pts3d_1, pts3d_2, counts=None, variant="vggt", thres3d_neg=0.1, temp=0.01):
-    """desc [P,N,C] unit descriptors, pts3d [P,N,3], counts int32 [P] (valid keypoints per pair) -> loss [P]."""
-    return _SmoothAP.apply(desc1, desc2, pts3d_1, pts3d_2, counts, variant, thres3d_neg, temp)
+def smooth_ap(desc1, desc2, pts3d_1, pts3d_2, counts=None, variant="vggt", thres3d_neg=0.1, temp=0.01, thres3d_pos=5e-3):
+    """desc [P,N,C] unit descriptors, pts3d [P,N,3], counts int32 [P] (valid keypoints per pair) -> loss [P].
+    variant "vggt" | "mast3r": positives on the diagonal; "me": every pair closer than thres3d_pos (finetune_timm_me.py)."""
+    thr = (thres3d_pos, thres3d_neg) if variant == "me" else thres3d_neg
+    return _SmoothAP.apply(desc1, desc2, pts3d_1, pts3d_2, counts, variant, thr, temp)
 
 
 HEAD_KEYS = ("w1", "b1", "ln_w", "ln_b", "w2", "b2")

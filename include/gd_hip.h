@@ -111,6 +111,13 @@ int gd_tap_mean_bwd(void* const* dgrids, int ngrid, int prefix, const void* dout
  * src/finetune_timm_mast3r.py:560-589 variant 1): sim [P,Nmax,Nmax] -> loss [P] and dsim = dloss/dsim (fused). */
 int gd_smooth_ap(const float* sim, const float* pts3d_1, const float* pts3d_2, const int* counts, int P, int Nmax,
                  int variant, float thres3d_neg, float temp, float* loss, float* dsim, float* row_ws, void* stream);
+
+/* "ME" variant of the matching loss (src/finetune_timm_me.py:191-220): positives = every (i,j) with |p1_i - p2_j| <
+ * thres3d_pos (dynamic count), negatives = distance > thres3d_neg; loss[p] = mean over the pair's positives of
+ * 1 - (ap1 + ap2)/2 (0 when there is none); dsim = d loss[p] / d sim.  row_ws: P*Nmax*2 floats.  Nmax <= 4096. */
+int gd_smooth_ap_me(const float* sim, const float* pts3d_1, const float* pts3d_2, const int* counts, int P, int Nmax,
+                    float thres3d_pos, float thres3d_neg, float temp, float* loss, float* dsim, float* row_ws,
+                    void* stream);
 /* pairwise_logistic_ranking_loss (utils/losses.py:18-41) with DepthAwareFeatureFusion (utils/model.py:100-127) on
  * pre-projected u = W1 f [S,Nmax,128]: loss [S], du (scaled by gscale/count), head_grad[516] += {b1,ln_w,ln_b,w2,b2} (nullable),
  * head_grad_sets [S,516] = the same per set (nullable). */

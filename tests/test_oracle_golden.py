@@ -170,3 +170,14 @@ def test_g14_cross_view_attention_maps():
     assert got.shape == g["maps"].shape
     assert float((got - g["maps"]).abs().max()) < 1e-6
     assert float((got.sum(-1) - 1).abs().max()) < 1e-5      # every row is a mean of softmax rows
+
+
+def test_g08_matching_loss_me_variant():
+    """ME variant (src/finetune_timm_me.py:191-220, dynamic positives): oracle vs the reference's loss and gradients."""
+    g = load_golden("g08_match_me")
+    d1 = g["desc1"].clone().requires_grad_(True)
+    d2 = g["desc2"].clone().requires_grad_(True)
+    loss = O.smooth_ap_loss_me(d1, d2, g["pts3d_1"], g["pts3d_2"])
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 1e-6
+    assert float((d1.grad - g["gdesc1"]).abs().max()) < 1e-6 and float((d2.grad - g["gdesc2"]).abs().max()) < 1e-6
