@@ -187,3 +187,89 @@ extern "C" int gd_point_cloud_to_depth(const float* points, const float* K, floa
     GD_LAUNCH_OK();
     return 0;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// MASt3R teacher -> distillation target `tgt_attn_map` (dust3r/dust3r/model.py:346-366), after the head mean and the
+// reciprocity average:  R_l = (mean_h tgt_l + (mean_h src_l)^T) / 2  per decoder layer l (raw scaled scores; as GEMMs:
+// R_l = scale/(2H) (Q1 K2^T + K1 Q2^T) over the concatenated heads, see teacher_glue.mast3r_tgt_attn_map_from_qk).
+//   P_l = softmax(R_l / temperature) over keys;  P_l[:, :, 0] := min(P_l) (one scalar per layer, over the whole batch);
+//   out = mean_l P_l.
+// Kernel 1: one wave per (b, i) row walks all layers, accumulates the row of `out` in registers and records the row
+// minimum of every layer; kernel 2 turns the row minima into the per-layer minima and overwrites column 0.
+// ---------------------------------------------------------------------------------------------------------------------
+#define TG_ROW_MAX 32   // 64 * 32 = 2048 keys per row in registers
+__global__ __launch_bounds__(256) void mast3r_target_rows_kernel(const float* R, float* out, float* rowmin, int L, long rows, int N2,
+                                                                 float inv_temp) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long row = (long)blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    float acc[TG_ROW_MAX];
+#pragma unroll
+    for (int k = 0; k < TG_ROW_MAX; ++k) acc[k] = 0.f;
+    const float c2 = inv_temp * 1.4426950408889634f;
+    for (int l = 0; l < L; ++l) {
+        const float* r = R + ((long)l * rows + row) * N2;
+        float v[TG_ROW_MAX], mx = -3.0e38f;
+#pragma unroll
+        for (int k = 0; k < TG_ROW_MAX; ++k) {
+            const int j = lane + 64 * k;
+            v[k] = j < N2 ? r[j] : -3.0e38f;
+            mx = fmaxf(mx, v[k]);
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < TG_ROW_MAX; ++k) {
+            v[k] = lane + 64 * k < N2 ? exp2f((v[k] - mx) * c2) : 0.f;
+            sum += v[k];
+        }
+        sum = wave_sum(sum);
+        const float inv = 1.0f / sum;
+        float mn = 3.0e38f;
+#pragma unroll
+        for (int k = 0; k < TG_ROW_MAX; ++k) {
+            if (lane + 64 * k < N2) { const float pr = v[k] * inv; acc[k] += pr; mn = fminf(mn, pr); }
+        }
+        mn = -wave_max(-mn);
+        if (lane == 0) rowmin[(long)l * rows + row] = mn;
+    }
+    const float w = 1.0f / (float)L;
+#pragma unroll
+    for (int k = 0; k < TG_ROW_MAX; ++k) {
+        const int j = lane + 64 * k;
+        if (j < N2) out[row * N2 + j] = acc[k] * w;
+    }
+}
+
+__global__ __launch_bounds__(256) void mast3r_target_col0_kernel(const float* rowmin, float* out, int L, long rows, int N2) {
+    __shared__ float red[4];
+    __shared__ float fill;
+    float total = 0.f;
+    for (int l = 0; l < L; ++l) {
+        float mn = 3.0e38f;
+        for (long r = threadIdx.x; r < rows; r += 256) mn = fminf(mn, rowmin[(long)l * rows + r]);
+        mn = -wave_max(-mn);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mn;
+        __syncthreads();
+        total += fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
+    }
+    if (threadIdx.x == 0) fill = total / (float)L;
+    __syncthreads();
+    for (long r = threadIdx.x; r < rows; r += 256) out[r * N2] = fill;
+}
+
+extern "C" int gd_mast3r_attn_target(const float* recip_scores, int L, int B, int N1, int N2, float temperature, float* out,
+                                     float* workspace, void* stream) {
+    GD_REQUIRE(L > 0 && B > 0 && N1 > 0 && N2 > 0 && temperature > 0.f, "gd_mast3r_attn_target: bad arguments");
+    GD_REQUIRE(N2 <= 64 * TG_ROW_MAX, "gd_mast3r_attn_target: at most %d keys per row (got %d)", 64 * TG_ROW_MAX, N2);
+    GD_REQUIRE(workspace != nullptr, "gd_mast3r_attn_target: workspace of L*B*N1 floats required");
+    const long rows = (long)B * N1;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(mast3r_target_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, recip_scores, out, workspace, L, rows,
+                       N2, 1.0f / temperature);
+    hipLaunchKernelGGL(mast3r_target_col0_kernel, dim3(1), dim3(256), 0, s, workspace, out, L, rows, N2);
+    GD_LAUNCH_OK();
+    return 0;
+}

@@ -156,3 +156,40 @@ def cross_view_attention_maps(q, k, scale, temperature=1.0, prefix=5, out=None, 
     check(lib().gd_cross_view_attn(ptr(q), ptr(k), ptr(out), B, H, N, int(prefix), d, float(scale), float(temperature), w,
                                    1 if accumulate else 0, dt, ptr(ws), stream()), "gd_cross_view_attn")
     return out
+
+
+def _mast3r_target(recip, temperature):
+    L, B, N1, N2 = recip.shape
+    out = torch.empty(B, N1, N2, dtype=torch.float32, device=recip.device)
+    ws = torch.empty(L * B * N1, dtype=torch.float32, device=recip.device)
+    check(lib().gd_mast3r_attn_target(ptr(recip), L, B, N1, N2, float(temperature), ptr(out), ptr(ws), stream()),
+          "gd_mast3r_attn_target")
+    return out
+
+
+def mast3r_tgt_attn_map(tgt_camaps, src_camaps, temperature=3.0):
+    """`tgt_attn_map` of dust3r/dust3r/model.py:346-366 (reciprocity on) from the decoder's per-layer raw cross-attention
+    score maps, tgt [B,H,N1,N2] / src [B,H,N2,N1] (CrossAttention's `attn_map`): head mean and reciprocity average in
+    torch (two reductions per layer), softmax / min-fill / layer mean in one HIP pass.  -> [B, N1, N2] fp32."""
+    recip = torch.stack([(t.float().mean(dim=1) + s.float().mean(dim=1).transpose(-1, -2)) * 0.5
+                         for t, s in zip(tgt_camaps, src_camaps)]).contiguous()
+    return _mast3r_target(recip, temperature)
+
+
+def mast3r_tgt_attn_map_from_qk(q1s, k2s, q2s, k1s, scale, temperature=3.0):
+    """Same target without ever forming a per-head map: the head MEAN of raw scores is linear, so per layer
+    mean_h(q_h k_h^T) * scale = scale / H * Q K^T over the concatenated heads, and the reciprocity average is
+    scale / (2H) * (Q1 K2^T + K1 Q2^T) — two accumulating MFMA GEMMs.  q*/k*: per-layer lists of [B, H, N, 64]
+    (after RoPE, dust3r/croco/models/blocks.py:150-172).  -> [B, N1, N2] fp32."""
+    from . import ops
+    L = len(q1s)
+    B, H, N1, d = q1s[0].shape
+    N2 = k2s[0].shape[2]
+    flat = lambda t: t.permute(0, 2, 1, 3).reshape(t.shape[0], t.shape[2], H * d).contiguous()
+    recip = torch.empty(L, B, N1, N2, dtype=torch.float32, device=q1s[0].device)
+    a = float(scale) / (2.0 * H)
+    for l in range(L):
+        for b in range(B):
+            ops.gemm_nt(flat(q1s[l])[b], flat(k2s[l])[b], out=recip[l, b], alpha=a)
+            ops.gemm_nt(flat(k1s[l])[b], flat(q2s[l])[b], out=recip[l, b], alpha=a, accumulate=True)
+    return _mast3r_target(recip, temperature)

@@ -176,6 +176,13 @@ int gd_cross_view_attn(const void* q, const void* k, float* out, int B, int H, i
                        float scale, float temperature, float weight, int accumulate, int dtype, void* workspace,
                        void* stream);
 
+/* MASt3R teacher -> distillation target `tgt_attn_map` (dust3r/dust3r/model.py:346-366) from the per-layer reciprocity
+ * averages recip_scores[L][B][N1][N2] = (mean_h tgt_l + (mean_h src_l)^T) / 2 of the decoder's raw cross-attention scores:
+ * softmax(. / temperature) over keys, column 0 := min of the layer's map, mean over layers -> out [B][N1][N2].
+ * workspace: L*B*N1 floats.  N2 <= 2048. */
+int gd_mast3r_attn_target(const float* recip_scores, int L, int B, int N1, int N2, float temperature, float* out,
+                          float* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -609,3 +609,20 @@ def cross_view_attention_maps(q, k, scale, temperature=1.0, prefix=5):
     a1 = torch.softmax(qs[..., prefix:N // 2, :] @ k[..., N // 2 + prefix:, :].transpose(-2, -1) / temperature, dim=-1)
     a2 = torch.softmax(qs[..., N // 2 + prefix:, :] @ k[..., prefix:N // 2, :].transpose(-2, -1) / temperature, dim=-1)
     return torch.cat([a1, a2], dim=0).mean(dim=1)
+
+
+def mast3r_tgt_attn_map(tgt_camaps, src_camaps, temperature=3.0, reciprocity=True):
+    """MASt3R teacher -> distillation target, dust3r/dust3r/model.py:346-366.  tgt_camaps / src_camaps: per decoder layer
+    the CrossAttention `attn_map` = raw scaled scores [B, H, N1, N2] / [B, H, N2, N1]
+    (dust3r/croco/models/blocks.py:150-172).  Head mean -> (tgt + src^T) / 2 -> softmax(. / temperature) over keys ->
+    column 0 := min of the whole layer map -> mean over layers.  -> [B, N1, N2]."""
+    t = [a.mean(dim=1) for a in tgt_camaps]
+    if reciprocity:
+        s = [a.mean(dim=1) for a in src_camaps]
+        t = [((ct + cs.transpose(-1, -2)) / 2 / temperature).softmax(dim=-1) for ct, cs in zip(t, s)]
+    out = []
+    for m in t:
+        m = m.clone()
+        m[:, :, 0] = m.min()
+        out.append(m)
+    return torch.stack(out, dim=1).mean(dim=1)

@@ -82,3 +82,21 @@ def test_cross_view_attention_maps_golden_and_full_size():
         ref = sum(O.cross_view_attention_maps(qs[i].to(dt).double(), ks[i].to(dt).double(), 0.125, 0.7, prefix) for i in range(2)) / 2
         assert float((acc.double() - ref).abs().max()) < tol * float(ref.abs().max()) + 1e-9, dt
         assert float((acc.sum(-1) - 1).abs().max()) < 1e-3
+
+
+def test_mast3r_tgt_attn_map_golden_and_from_qk():
+    from gd_amd import teacher_glue as TG
+    g = load_golden("g17_mast3r_tgt_attn_map")
+    out = TG.mast3r_tgt_attn_map([t.cuda() for t in g["tgt"]], [t.cuda() for t in g["src"]], float(g["temperature"]))
+    assert float((out.cpu() - g["out"]).abs().max()) < 2e-6
+    # from q / k (12 heads x 64, 768 tokens = the 24 x 32 MASt3R grid), 3 layers: never forms a per-head map
+    B, H, N, L, scale = 2, 12, 768, 3, 0.125
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    mk = lambda: [torch.randn(B, H, N, 64, device="cuda", generator=gen) for _ in range(L)]
+    q1, k2, q2, k1 = mk(), mk(), mk(), mk()
+    got = TG.mast3r_tgt_attn_map_from_qk(q1, k2, q2, k1, scale, 3.0)
+    tgt = [(a.double() @ b.double().transpose(-1, -2)) * scale for a, b in zip(q1, k2)]
+    src = [(a.double() @ b.double().transpose(-1, -2)) * scale for a, b in zip(q2, k1)]
+    ref = O.mast3r_tgt_attn_map(tgt, src, 3.0)
+    assert float((got.double() - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+    assert float((got[:, :, 1:].sum(-1) - ref[:, :, 1:].sum(-1).float()).abs().max()) < 1e-4

@@ -181,3 +181,10 @@ def test_g08_matching_loss_me_variant():
     loss.backward()
     assert abs(loss.item() - float(g["loss"])) < 1e-6
     assert float((d1.grad - g["gdesc1"]).abs().max()) < 1e-6 and float((d2.grad - g["gdesc2"]).abs().max()) < 1e-6
+
+
+def test_g17_mast3r_tgt_attn_map():
+    """MASt3R teacher target map (dust3r/dust3r/model.py:346-366): oracle vs the reference's forward."""
+    g = load_golden("g17_mast3r_tgt_attn_map")
+    got = O.mast3r_tgt_attn_map(list(g["tgt"]), list(g["src"]), float(g["temperature"]))
+    assert float((got - g["out"]).abs().max()) < 1e-6
