@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--img", type=int, default=518)
     ap.add_argument("--keypoints", type=int, default=300)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--geometry", default="shared", choices=["shared", "reference"],
+                    help="shared: one 37x37-token forward per image feeds all extractors (BASELINE headline); reference: the "
+                         "reference's geometry (80x80-token forwards for the keypoint features + the teacher-grid forward)")
     ap.add_argument("--gemm-shapes", action="store_true", help="per-shape gemm_nt breakdown on stderr")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); 'gloo' lets two "
@@ -75,7 +78,7 @@ def main():
     hw = (img // patch) ** 2
 
     eng = FinetuneGD(r=4, backbone=args.backbone, patch_size=patch, img_size=img, variant=args.variant,
-                     geometry="shared", dtype=args.dtype, teacher_patch=patch, lora_b_std=1e-3,
+                     geometry=args.geometry, dtype=args.dtype, teacher_patch=patch, lora_b_std=1e-3,
                      vit_kwargs=dict(init_values=1.0)).to(dev)
     flat = eng.configure_optimizers()
     reducer = dp.FlatGradReducer(flat["g"], world)
@@ -117,12 +120,15 @@ def main():
         Nt = hw + 1
         fwd, bwd = vit_flops_per_image(D, L, Nt, patch, L - 4)
         flop_pair = 2 * (fwd + bwd)
+        if args.geometry == "reference":   # + the two 80x80-token forwards / backwards per image
+            f2, b2 = vit_flops_per_image(D, L, (eng.target_res // eng.downsample_factor) ** 2 + 1, patch, L - 4)
+            flop_pair += 2 * 2 * (f2 + b2)
         out = {"metric": "image-pairs/sec (518^2, ViT-B/14 LoRA) student distillation step", "value": round(pairs_per_s, 3),
                "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": f"finetune_timm_{args.variant}_objaverse: {args.backbone}/14 + LoRA(r=4,q,v)+adapters "
-                                      f"blocks 4-11, {img}^2 pairs, shared-518 geometry, {args.variant} losses "
+                                      f"blocks 4-11, {img}^2 pairs, {'shared-518' if args.geometry == 'shared' else 'reference (80x80-token)'} geometry, {args.variant} losses "
                                       f"(AP+depth+intra+cost-KL), {P} pairs/GPU, {N} keypoints/pair, hw={hw}",
                           "pairs_per_gpu": P, "global_pairs": P * world, "parallelism": f"dp{world}"},
                "loss": round(float(loss.detach()), 6),
