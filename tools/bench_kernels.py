@@ -99,13 +99,17 @@ def pmc_cv():
 
 
 def bench_attn():
-    B, N, H = 64, 1370, 12
+    for (B, N, H) in ((64, 1370, 12), (8, 6401, 12)):
+        _bench_attn(B, N, H)
+
+
+def _bench_attn(B, N, H):
     qkv = torch.randn(B * N, 3 * H * 64, device="cuda").bfloat16()
     dout = torch.randn(B * N, H * 64, device="cuda").bfloat16()
     o, lse = ops.attention_fwd(qkv, B, N, H)
     fl = 4.0 * B * H * N * N * 64
     t = timeit(lambda: ops.attention_fwd(qkv, B, N, H))
-    print(f"attn fwd  {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TF/s")
+    print(f"attn fwd  B={B} N={N}: {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TF/s")
     t = timeit(lambda: ops.attention_bwd(qkv, o, dout, lse, B, N, H))
     print(f"attn bwd  {t*1e6:8.1f} us  {2.5*fl/t/1e12:7.1f} TF/s (algorithmic 5 products)")
 
