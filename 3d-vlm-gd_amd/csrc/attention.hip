@@ -17,6 +17,7 @@
 // qkv is the packed [B, N, 3, H, 64] output of the QKV GEMM; o is [B, N, H*64]; lse is [B, H, N] (natural log).
 #include "gd_common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 #define HD 64
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // bare v_exp_f32
@@ -254,6 +255,172 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* qkv, T* o, fl
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) store4<T>(orow + dt * 16 + g * 4, oacc[dt][qt] * inv);
         if (g == 0) lse[((long)b * H + h) * N + q] = (m[qt] + log2f(l[qt])) * 0.6931471805599453f;   // natural log
+    }
+}
+
+// ------------------------------------------------------------------------------------------ forward, bf16, LDS-DMA
+// Same mathematics and register layout as attn_fwd_kernel, but K / V tiles travel global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4) into a THREE-slot ring, two tiles ahead, with no staging registers: at N = 1370 one tile of
+// prefetch distance (~0.9 us) is shorter than a loaded memory round trip and 31 % of the wave cycles sat in s_waitcnt
+// vmcnt.  Rows are 128 bytes unpadded (a DMA piece is 8 rows x 128 B, lane-linear in LDS); the 16-byte chunk index is
+// XOR-swizzled with (row >> 1) & 7 on the SOURCE address, as in the GEMM, so the K fragment reads (ds_read_b128) and the
+// V transpose reads (ds_read_b64_tr_b16) stay conflict-free.  All LDS reads are inline asm (a ds_read the compiler can see
+// gets an `s_waitcnt vmcnt` to the most recent LDS-DMA in front of it); one counted vmcnt wait + one barrier per tile.
+// Key rows past N are clamped to row N-1: their scores are masked in the (compile-time) tail tile, so p = 0 for them.
+#define ADS_R128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
+#define ADS_TR64(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
+typedef __attribute__((ext_vector_type(2))) unsigned a_u32x2;
+__global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const bf16* qkv, bf16* o, float* lse, int N, int H, float scale) {
+    typedef bf16x8 Frag;
+    constexpr int TILE = 64 * 128;                       // one K or V tile: 64 rows x 128 B
+    __shared__ __attribute__((aligned(16))) char smem[6 * TILE];   // K slots 0..2 | V slots 0..2
+    const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128 + wave * 32;
+    const long ld_b = (long)3 * H * HD * 2;
+    const char* base = (const char*)qkv + (long)b * N * ld_b;
+    const char* qb = base + (long)(0 * H + h) * HD * 2;
+    const char* kb = base + (long)(1 * H + h) * HD * 2;
+    const char* vb = base + (long)(2 * H + h) * HD * 2;
+
+    Frag qf[2][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int q = q0 + qt * 16 + c;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (q < N) qf[qt][u] = load_nfrag<bf16>(qb + (long)q * ld_b, u, g);
+            else { Frag z = {}; qf[qt][u] = z; }
+        }
+    }
+    // DMA: wave w moves pieces 2w, 2w+1 (8 rows each) of the K tile and of the V tile
+    const int prow = lane >> 3, pchunk = lane & 7;
+    auto issue = [&](int k0, int slot) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (wave * 2 + i) * 8 + prow;
+            const long off = (long)min(k0 + row, N - 1) * ld_b + ((pchunk ^ ((row >> 1) & 7)) * 16);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kb + off),
+                                             (__attribute__((address_space(3))) void*)(smem + slot * TILE + (wave * 2 + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vb + off),
+                                             (__attribute__((address_space(3))) void*)(smem + (3 + slot) * TILE + (wave * 2 + i) * 1024), 16, 0, 0);
+        }
+    };
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)smem;
+    // K fragment (kt, u): row kt*16 + c, logical chunk 4u + g
+    const int swk = (c >> 1) & 7;
+    const unsigned ka0 = c * 128 + ((0 + g) ^ swk) * 16, ka1 = c * 128 + ((4 + g) ^ swk) * 16;
+    // V transpose fragment (dt, u): rows 32u + 4g + q (+16), logical chunk 2dt + (p>>1), 8-byte half p&1
+    const int vq = c >> 2, vp = c & 3, swv = (2 * g + (vq >> 1)) & 7;
+    unsigned va[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) va[dt] = (4 * g + vq) * 128 + (((2 * dt + (vp >> 1)) ^ swv) * 16) + 8 * (vp & 1);
+
+    f32x4 oacc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) oacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m[2] = {-1e30f, -1e30f}, l[2] = {0.f, 0.f};   // m in log2 units
+    const float c2 = scale * 1.4426950408889634f;
+    const int ntile = (N + 63) / 64;
+    issue(0, 0);
+    if (ntile > 1) issue(64, 1);
+    auto key_tile = [&](int t, auto tail_tag) {
+        constexpr bool tail = decltype(tail_tag)::value;
+        const int k0 = t * 64, slot = t % 3;
+        if (t + 1 < ntile) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // tile t landed; tile t+1 may still fly
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();            // everyone's pieces of tile t landed; everyone is done with tile t-1's slot
+        asm volatile("" ::: "memory");
+        if (t + 2 < ntile) issue(k0 + 128, (t + 2) % 3);
+        const unsigned kbase = lds0 + slot * TILE, vbase = lds0 + (3 + slot) * TILE;
+        f32x4 kr[4][2];
+        ADS_R128(kr[0][0], kbase + ka0, 0);    ADS_R128(kr[0][1], kbase + ka1, 0);
+        ADS_R128(kr[1][0], kbase + ka0, 2048); ADS_R128(kr[1][1], kbase + ka1, 2048);
+        ADS_R128(kr[2][0], kbase + ka0, 4096); ADS_R128(kr[2][1], kbase + ka1, 4096);
+        ADS_R128(kr[3][0], kbase + ka0, 6144); ADS_R128(kr[3][1], kbase + ka1, 6144);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kr[0][0]), "+v"(kr[0][1]), "+v"(kr[1][0]), "+v"(kr[1][1]), "+v"(kr[2][0]), "+v"(kr[2][1]),
+                     "+v"(kr[3][0]), "+v"(kr[3][1]));
+        f32x4 s[2][4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < 2; ++u) a = Mma<bf16>::mma(__builtin_bit_cast(Frag, kr[kt][u]), qf[qt][u], a);
+                s[qt][kt] = a;
+            }
+        // V fragments: issued now, consumed after the softmax
+        a_u32x2 vr[4][2][2];   // [dt][u][row half]
+#define ADS_V(dt)                                                                                   \
+        ADS_TR64(vr[dt][0][0], vbase + va[dt], 0);    ADS_TR64(vr[dt][0][1], vbase + va[dt], 2048);     \
+        ADS_TR64(vr[dt][1][0], vbase + va[dt], 4096); ADS_TR64(vr[dt][1][1], vbase + va[dt], 6144);
+        ADS_V(0) ADS_V(1) ADS_V(2) ADS_V(3)
+#undef ADS_V
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            float tmax = -1e30f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (tail && k0 + kt * 16 + g * 4 + r >= N) s[qt][kt][r] = -1e30f;
+                    tmax = fmaxf(tmax, s[qt][kt][r]);
+                }
+            tmax = quad_rows_max(tmax);
+            const float mn = fmaxf(m[qt], tmax * c2);
+            const float alpha = fast_exp2(m[qt] - mn);
+            float ps = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = fast_exp2(fmaf(s[qt][kt][r], c2, -mn));
+                    s[qt][kt][r] = p;
+                    ps += p;
+                }
+            l[qt] = l[qt] * alpha + ps;
+            const bool moved = mn != m[qt];
+            m[qt] = mn;
+            if (__any(moved)) {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) oacc[dt][qt] *= alpha;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vr[0][0][0]), "+v"(vr[0][0][1]), "+v"(vr[0][1][0]), "+v"(vr[0][1][1]), "+v"(vr[1][0][0]),
+                     "+v"(vr[1][0][1]), "+v"(vr[1][1][0]), "+v"(vr[1][1][1]), "+v"(vr[2][0][0]), "+v"(vr[2][0][1]), "+v"(vr[2][1][0]),
+                     "+v"(vr[2][1][1]), "+v"(vr[3][0][0]), "+v"(vr[3][0][1]), "+v"(vr[3][1][0]), "+v"(vr[3][1][1]));
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            Frag pf[2];
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) pf[qt] = acc_to_bfrag<bf16>(s[qt], u);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                typedef __attribute__((ext_vector_type(4))) unsigned a_u32x4;
+                const a_u32x4 z = {vr[dt][u][0][0], vr[dt][u][0][1], vr[dt][u][1][0], vr[dt][u][1][1]};
+                const Frag vf = __builtin_bit_cast(Frag, z);
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) oacc[dt][qt] = Mma<bf16>::mma(vf, pf[qt], oacc[dt][qt]);
+            }
+        }
+    };
+    int t = 0;
+    for (; (t + 1) * 64 <= N; ++t) key_tile(t, std::false_type{});
+    if (t * 64 < N) key_tile(t, std::true_type{});
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int q = q0 + qt * 16 + c;
+        l[qt] += __shfl_xor(l[qt], 16, 64);
+        l[qt] += __shfl_xor(l[qt], 32, 64);
+        if (q >= N) continue;
+        const float inv = 1.0f / l[qt];
+        bf16* orow = o + ((long)b * N + q) * H * HD + h * HD;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) store4<bf16>(orow + dt * 16 + g * 4, oacc[dt][qt] * inv);
+        if (g == 0) lse[((long)b * H + h) * N + q] = (m[qt] + log2f(l[qt])) * 0.6931471805599453f;
     }
 }
 
@@ -695,7 +862,11 @@ extern "C" int gd_attention_fwd(const void* qkv, void* o, float* lse, int B, int
     GD_REQUIRE(dtype == GD_F32 || dtype == GD_BF16, "gd_attention_fwd: bad dtype %d", dtype);
     GD_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)o & 15) == 0, "gd_attention_fwd: pointers must be 16-byte aligned");
     dim3 grid(gd_cdiv(N, 128), H, B);
-    if (dtype == GD_BF16)
+    static int dma = -1;   // GD_ATTN_DMA=0: the register-staged forward kernel (A/B testing)
+    if (dma < 0) { const char* e = getenv("GD_ATTN_DMA"); dma = e ? atoi(e) : 1; }
+    if (dtype == GD_BF16 && dma)
+        hipLaunchKernelGGL(attn_fwd_dma_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale);
+    else if (dtype == GD_BF16)
         hipLaunchKernelGGL(attn_fwd_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale);
     else
         hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)qkv, (float*)o, lse, N, H, scale);
