@@ -334,6 +334,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const bf16* qkv, b
         __builtin_amdgcn_s_barrier();            // everyone's pieces of tile t landed; everyone is done with tile t-1's slot
         asm volatile("" ::: "memory");
         if (t + 2 < ntile) issue(k0 + 128, (t + 2) % 3);
+        if (q0 >= N) return;      // (lambda) a wave whose 32 queries are all past N only moves its DMA pieces
         const unsigned kbase = lds0 + slot * TILE, vbase = lds0 + (3 + slot) * TILE;
         f32x4 kr[4][2];
         ADS_R128(kr[0][0], kbase + ka0, 0);    ADS_R128(kr[0][1], kbase + ka1, 0);
@@ -501,6 +502,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const T* qkv, const
             tile_load<T>(rk, kb, ld_b, k0 + 64, N);
             tile_load<T>(rv, vb, ld_b, k0 + 64, N);
         }
+        if (q0 >= N) continue;   // a wave whose 32 queries are all past N only helps staging
         f32x4 ds[2][4];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
@@ -583,6 +585,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const T* qkv, con
         }
     }
     const float c2 = scale * 1.4426950408889634f;
+    const bool wave_live = key0 < N;
     f32x4 dk[4][2], dv[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -614,6 +617,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const T* qkv, con
             rdl = q < N ? delta[((long)b * H + h) * N + q] : 0.f;
         }
         __syncthreads();
+        if (!wave_live) continue;   // (this wave's 32 keys are all past N: it only helps staging the tiles — 5 of the 48 waves of an
+                                    //  (image, head) at N = 1370)
         f32x4 pp[2][4], dsv[2][4];  // [key tile][query tile]
 #pragma unroll
         for (int qt = 0; qt < 4; ++qt) {
