@@ -245,6 +245,7 @@ class FinetuneGD(nn.Module):
         pts3d_1, pts3d_2 [P,N,3]; depth_1, depth_2 [P,h,w]; cost_1, cost_2 [P,hw,hw];
         mask_1, mask_2 [P,h,w] bool (vggt)."""
         self.clear_cache()
+        self.model.prepare_trainables()      # per-step pack of the LoRA / adapter weights (dropped again below: never stale)
         rgbs = torch.cat([batch["rgb_1"], batch["rgb_2"]], 0).contiguous()
         counts = batch.get("counts")
         depth_loss, intra = self.calculate_depth_loss(batch["depth_1"], batch["depth_2"], rgbs, batch["kp_1"],
@@ -255,6 +256,7 @@ class FinetuneGD(nn.Module):
         per_pair = (self.ap_loss_weight * ap + self.depth_loss_weight * depth_loss
                     + self.intra_depth_loss_weight * intra + self.kl_loss_weight * kl)
         self.clear_cache()
+        self.model.release_trainables()
         terms = {"ap_loss": ap.detach(), "depth_loss": depth_loss.detach(), "intra_depth_loss": intra.detach(),
                  "kl_loss": kl.detach()}
         return per_pair.mean(), terms

@@ -132,13 +132,18 @@ class _BlockFn(torch.autograd.Function):
         need = x.requires_grad or any(t is not None and t.requires_grad for t in (a_q, b_q, a_v, b_v, down, up))
         y1, mean1, rstd1 = ops.layernorm_fwd(x, plan["ln1_w"], plan["ln1_b"], plan["eps1"], save_stats=need)
         t = at = bt = None
+        tw = plan.get("tw")           # per-step pack of the trainable weights (GDViT.prepare_trainables), or None
         if a_q is not None:
             r = a_q.shape[0]
-            at = torch.cat([a_q, a_v], 0).detach()                              # [2r, D] fp32
-            bt = torch.zeros(2 * r, 3 * D, dtype=torch.float32, device=x.device)
-            bt[:r, :D] = b_q.detach().t()
-            bt[r:, 2 * D:] = b_v.detach().t()
-            t = ops.gemm_nt(y1, at.to(T).contiguous(), out_dtype=torch.float32)  # [M, 2r]
+            if tw is not None:
+                at, bt, at_T = tw["at"], tw["bt"], tw["at_T"]
+            else:
+                at = torch.cat([a_q, a_v], 0).detach()                              # [2r, D] fp32
+                bt = torch.zeros(2 * r, 3 * D, dtype=torch.float32, device=x.device)
+                bt[:r, :D] = b_q.detach().t()
+                bt[r:, 2 * D:] = b_v.detach().t()
+                at_T = at.to(T).contiguous()
+            t = ops.gemm_nt(y1, at_T, out_dtype=torch.float32)  # [M, 2r]
         qkv = ops.gemm_nt(y1, plan["wqkv"], bias=plan["bqkv"], lora_t=t, lora_b=bt)
         o, lse = ops.attention_fwd(qkv, B, Nt, H)
         x1 = ops.gemm_nt(o, plan["wproj"], bias=plan["bproj"], residual=x)
@@ -148,10 +153,10 @@ class _BlockFn(torch.autograd.Function):
         x2 = ops.gemm_nt(h, plan["w2"], bias=plan["b2"], residual=x1)
         out, hd = x2, None
         if down is not None:
-            hd = ops.gemm_nt(x2, down.detach().to(T).contiguous(), act=2)
-            out = ops.gemm_nt(hd, up.detach().to(T).contiguous(), residual=x2)
+            hd = ops.gemm_nt(x2, tw["down_T"] if tw is not None else down.detach().to(T).contiguous(), act=2)
+            out = ops.gemm_nt(hd, tw["up_T"] if tw is not None else up.detach().to(T).contiguous(), residual=x2)
         if need:
-            ctx.plan, ctx.dims = plan, (B, Nt)
+            ctx.plan, ctx.dims, ctx.tw = plan, (B, Nt), tw
             ctx.has_lora, ctx.has_ad = a_q is not None, down is not None
             ctx.save_for_backward(x, mean1, rstd1, y1, t, at, bt, qkv, o, lse, x1, mean2, rstd2, pre, x2, hd,
                                   down, up)
@@ -165,11 +170,21 @@ class _BlockFn(torch.autograd.Function):
         dout = dout.contiguous().to(T)
         g_down = g_up = g_aq = g_bq = g_av = g_bv = None
         dx2 = dout
+        tw = ctx.tw
+        # the four weight-gradient accumulators of the block come out of ONE zero-filled buffer
+        bott = down.shape[0] if ctx.has_ad else 0
+        r2 = at.shape[0] if ctx.has_lora else 0
+        zb = torch.zeros(2 * bott * D + r2 * 4 * D, dtype=torch.float32, device=dout.device)
+        z_up, z_down = zb[:D * bott].view(D, bott), zb[D * bott:2 * D * bott].view(bott, D)
+        z_bt = zb[2 * D * bott:2 * D * bott + r2 * 3 * D].view(r2, 3 * D)
+        z_at = zb[2 * D * bott + r2 * 3 * D:].view(r2, D)
         if ctx.has_ad:
-            dhp = ops.gemm_nt(dout, up.detach().t().to(T).contiguous(), dact_src=hd, dact=2)       # [M, 64]
-            g_up = ops.gemm_tn(dout, hd)                                                          # [D, 64]
-            g_down = ops.gemm_tn(dhp, x2)                                                         # [64, D]
-            dx2 = ops.gemm_nt(dhp, down.detach().t().to(T).contiguous(), residual=dout)
+            up_tT = tw["up_tT"] if tw is not None else up.detach().t().to(T).contiguous()
+            down_tT = tw["down_tT"] if tw is not None else down.detach().t().to(T).contiguous()
+            dhp = ops.gemm_nt(dout, up_tT, dact_src=hd, dact=2)                                   # [M, 64]
+            g_up = ops.gemm_tn(dout, hd, out=z_up)                                                # [D, 64]
+            g_down = ops.gemm_tn(dhp, x2, out=z_down)                                             # [64, D]
+            dx2 = ops.gemm_nt(dhp, down_tT, residual=dout)
         dpre = ops.gemm_nt(dx2, plan["w2_t"], dact_src=pre, dact=3)                               # [M, 4D] (x stored GELU')
         dy2 = ops.gemm_nt(dpre, plan["w1_t"])
         del dpre
@@ -178,11 +193,12 @@ class _BlockFn(torch.autograd.Function):
         dqkv = ops.attention_bwd(qkv, o, do, lse, B, Nt, H)
         if ctx.has_lora:
             r = at.shape[0] // 2
-            dt = ops.gemm_nt(dqkv, bt.to(T).contiguous(), out_dtype=torch.float32)                 # [M, 2r]
-            gbt = ops.gemm_tn(t, dqkv)                                                            # [2r, 3D]
-            gat = ops.gemm_tn(dt, y1)                                                             # [2r, D]
-            g_bq, g_bv = gbt[:r, :D].t().contiguous(), gbt[r:, 2 * D:].t().contiguous()
-            g_aq, g_av = gat[:r].contiguous(), gat[r:].contiguous()
+            bt_T = tw["bt_T"] if tw is not None else bt.to(T).contiguous()
+            dt = ops.gemm_nt(dqkv, bt_T, out_dtype=torch.float32)                                  # [M, 2r]
+            gbt = ops.gemm_tn(t, dqkv, out=z_bt)                                                  # [2r, 3D]
+            gat = ops.gemm_tn(dt, y1, out=z_at)                                                   # [2r, D]
+            g_bq, g_bv = gbt[:r, :D].t(), gbt[r:, 2 * D:].t()      # strided views: the gradient gather copies them anyway
+            g_aq, g_av = gat[:r], gat[r:]
         if not ctx.needs_input_grad[0]:   # first trainable block: nothing below it learns, skip dX (one GEMM + one LN backward)
             return None, None, None, None, g_aq, g_bq, g_av, g_bv, g_down, g_up
         if ctx.has_lora:
@@ -208,6 +224,9 @@ def run_block(blk, x):
             raise ops._lib.GdHipError("LoRA rank > 4 not supported by the fused epilogue")
     if adapter is not None:
         down, up = adapter.down.weight, adapter.up.weight
+    tw = getattr(inner, "_tw", None)
+    if tw is not None and tw.get("dtype") == x.dtype:
+        plan = dict(plan, tw=tw)
     out = _BlockFn.apply(x.reshape(B * Nt, D), plan, B, Nt, a_q, b_q, a_v, b_v, down, up)
     return out.view(B, Nt, D)
 
@@ -294,6 +313,39 @@ class GDViT(nn.Module):
             w.copy_(torch.nn.init.trunc_normal_(torch.empty_like(w), std=0.02, generator=g))
             if self.patch_embed.proj.bias is not None:
                 self.patch_embed.proj.bias.zero_()
+
+    def prepare_trainables(self):
+        """Per-step pack of every adapted block's trainable weights in the engine's layouts (LoRA A stacked [2r, D] and its
+        cast, LoRA B scattered into the [2r, 3D] epilogue operand and its cast, adapter weights and their transposes
+        cast): a dozen batched torch kernels per step instead of ~14 tiny ones per block and pass.  Valid until the
+        weights change: FinetuneGD.training_step builds it and `release_trainables` drops it after the backward."""
+        T = self.dtype
+        lo, ad = [], []
+        for blk in self.blocks:
+            inner, lora, adapter = _unwrap(blk)
+            inner._tw = None
+            if lora is not None and lora.linear_a_k is None and lora.linear_a_v is not None and adapter is not None:
+                lo.append((inner, lora, adapter))
+        if not lo:
+            return
+        with torch.no_grad():
+            r = lo[0][1].linear_a_q.weight.shape[0]
+            D = lo[0][1].linear_a_q.weight.shape[1]
+            at = torch.stack([torch.cat([l.linear_a_q.weight, l.linear_a_v.weight], 0) for _, l, _ in lo]).float()   # [L, 2r, D]
+            bt = torch.zeros(len(lo), 2 * r, 3 * D, dtype=torch.float32, device=at.device)
+            bt[:, :r, :D] = torch.stack([l.linear_b_q.weight for _, l, _ in lo]).transpose(1, 2)
+            bt[:, r:, 2 * D:] = torch.stack([l.linear_b_v.weight for _, l, _ in lo]).transpose(1, 2)
+            down = torch.stack([a.down.weight for _, _, a in lo])        # [L, 64, D]
+            up = torch.stack([a.up.weight for _, _, a in lo])            # [L, D, 64]
+            at_T, bt_T, down_T, up_T = at.to(T), bt.to(T), down.to(T), up.to(T)
+            down_tT, up_tT = down_T.transpose(1, 2).contiguous(), up_T.transpose(1, 2).contiguous()
+        for i, (inner, _, _) in enumerate(lo):
+            inner._tw = {"dtype": T, "at": at[i], "bt": bt[i], "at_T": at_T[i], "bt_T": bt_T[i], "down_T": down_T[i],
+                         "up_T": up_T[i], "down_tT": down_tT[i], "up_tT": up_tT[i]}
+
+    def release_trainables(self):
+        for blk in self.blocks:
+            _unwrap(blk)[0]._tw = None
 
     def invalidate_plans(self):
         self._pos_cache, self._pe_plan = {}, None
