@@ -155,6 +155,28 @@ def test_full_step_f32_matches_oracle(variant, geometry):
             assert float(diff[solid].max()) < 0.02 * lr, (i, float(diff[solid].max()))
 
 
+@pytest.mark.parametrize("backbone", ["vit_small", "vit_large"])
+def test_full_step_other_widths(backbone):
+    """BASELINE configs 1 / 3 / 5 use ViT-S (D = 384, 6 heads) and ViT-L (D = 1024, 16 heads, 24 blocks): the same step at
+    56 x 70 pixels, f32 engine against the fp64 oracle (loss, every loss term, gradient norm)."""
+    from gd_amd.finetune import FinetuneGD
+    torch.manual_seed(0)
+    eng = FinetuneGD(r=4, variant="mast3r", geometry="shared", dtype="f32", adapter_start_idx=4, bottleneck_dim=64,
+                     lora_b_std=0.05, vit_kwargs=dict(init_values=1.0), backbone=backbone, patch_size=14, img_size=56,
+                     teacher_patch=14).cuda()
+    P, h, w, N = 1, 56, 70, 10
+    batch = synthetic_batch(P, h, w, N, (h // 14) * (w // 14), "cuda", seed=6)
+    ref_loss, ref_terms, ref_grads, _, ref_norm = _oracle_step(eng, batch, P)
+    eng.configure_optimizers()
+    loss, terms = eng.training_step(batch)
+    eng.backward(loss)
+    assert abs(loss.item() - ref_loss) < 1e-3 * abs(ref_loss), (loss.item(), ref_loss)
+    for a, b in (("ap_loss", "ap"), ("intra_depth_loss", "intra"), ("kl_loss", "kl")):
+        assert abs(terms[a][0].item() - ref_terms[0][b]) < 1e-3 * max(1e-3, abs(ref_terms[0][b])), a
+    norm = eng.optimizer_step()
+    assert abs(norm.item() - ref_norm.item()) < 5e-3 * ref_norm.item()
+
+
 def test_full_step_bf16_loss_parity():
     """bf16 engine vs fp64 oracle on the same weights: the north_star's 1e-3 rel bar is stated for the loss."""
     P, h, w, N = 2, 56, 70, 12
