@@ -32,9 +32,6 @@ struct GemmNtParams {
     int deep_ring;                   // 256x256 config: 4-slot ring of 64-byte K stages with counted waits (GD_GEMM_DEEP=1; measured 10 % SLOWER than the 2-deep ring: twice the barriers)
     unsigned long long* probe;       // gd_gemm_phase_probe accumulators (device), or null
     int stagger;                     // persistent kernel experiment (GD_GEMM_STAGGER): start-up skew between CUs, units of ~0.85 us
-    int tile_hi;                     // persistent kernel: process big tiles [0, tile_hi) (row-major ids); 0 = all
-    int sub_base;                    // 128x128 kernel, sub-tile mode (> 0 or sub_mode): block b is quarter b&3 of big tile sub_base + b/4
-    int sub_mode;
     int tile_order;                  // experiment knob (GD_GEMM_ORDER): 0 XCD chunks, tn fastest; 1 no remap; 2 XCD chunks, 4-wide tn bands
 };
 
@@ -152,12 +149,6 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(GemmNtParams p)
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
     const int wg = p.tile_order == 1 ? (int)blockIdx.x : xcd_remap(blockIdx.x, tiles_m * tiles_n);
     int tm = wg / tiles_n, tn = wg % tiles_n;
-    if (p.sub_mode) {   // the tail of a persistent launch: quarters of the 256 x 256 tiles the full rounds left over
-        const int big = p.sub_base + ((int)blockIdx.x >> 2), q = (int)blockIdx.x & 3, big_n = (p.N + 255) / 256;
-        tm = 2 * (big / big_n) + (q >> 1);
-        tn = 2 * (big % big_n) + (q & 1);
-        if (tm * BM >= p.M || tn * BN >= p.N) return;
-    }
     if (p.tile_order == 2) {   // bands of 4 column tiles, row tiles fastest inside a band
         const int band = 4, full = (tiles_n / band) * band;
         const int per_band = band * tiles_m;
@@ -693,7 +684,7 @@ extern "C" int gd_gemm_nt(const void* A, const void* W, void* C, int M, int N, i
     { static int cp = -1; if (cp < 0) { const char* e = getenv("GD_GEMM_CSTORE"); cp = e ? atoi(e) : 1; }
       p.c_policy = (cp && (long)256 * ldc * gd_dtype_size(c_dtype) < 0x7fffffffL && !accumulate) ? cp : 0; }
     { static int dr = -1; if (dr < 0) { const char* e = getenv("GD_GEMM_DEEP"); dr = e ? atoi(e) : 0; } p.deep_ring = dr; }
-    p.probe = g_probe; p.tile_hi = 0; p.sub_base = 0; p.sub_mode = 0;
+    p.probe = g_probe;
     { static int sg = -1; if (sg < 0) { const char* e = getenv("GD_GEMM_STAGGER"); sg = e ? atoi(e) : 0; } p.stagger = sg; }
     { static int ord = -1; if (ord < 0) { const char* e = getenv("GD_GEMM_ORDER"); ord = e ? atoi(e) : 0; } p.tile_order = ord; }
     const bool big = dma && N >= 256 && M >= 1024 && !gd_force_small_tiles();
@@ -721,21 +712,12 @@ extern "C" int gd_gemm_nt(const void* A, const void* W, void* C, int M, int N, i
         else if (residual && act == 0 && !preact && cb) pk = gemm_nt_persist_kernel<bf16, 2, 0, 0, false>;
     }
     if (big && persist && pk && p.vec_epilogue && N % 8 == 0 && (!lora_t || lora_rt == 8) && 256 * ldmax * cs < 0x7fffffffL) {
-        // Tile quantisation: T tiles on C CUs take ceil(T / C) rounds, e.g. 1029 tiles of the N = 768 GEMMs = 4.02 -> 5 rounds.
-        // When the last round would be less than half full, the persistent kernel stops at the last full round and the
-        // left-over tiles run as 128 x 128 quarters (2 blocks / CU, all CUs busy for ~1/3 of a round).
+        // (Tile quantisation — e.g. 1029 tiles of the N = 768 GEMMs on 256 CUs — costs far less than a round: the left-over
+        // tiles run alone on an idle chip.  Handing them to the 128 x 128 kernel or cutting them into K slices was measured
+        // slower / equal: DESIGN.md section 5.)
         const int ntiles = gd_cdiv(M, 256) * gd_cdiv(N, 256);
-        static int split = -1;
-        if (split < 0) { const char* e = getenv("GD_GEMM_TAIL_SPLIT"); split = e ? atoi(e) : 0; }   // measured SLOWER (N=768,K=3072: 939 vs 1004 TF/s): 4*rem small blocks alone on the chip are latency-bound
-        const int rem = ntiles % ncu;
-        const bool tail = split && batch == 1 && ntiles > ncu && rem > 0 && 2 * rem <= ncu;
-        p.tile_hi = tail ? ntiles - rem : ntiles;
         dim3 gridp(ntiles < ncu ? ntiles : ncu, batch);
         hipLaunchKernelGGL(pk, gridp, dim3(512), 0, st, p);
-        if (tail) {
-            p.sub_mode = 1; p.sub_base = ntiles - rem;
-            hipLaunchKernelGGL((gemm_nt_kernel<bf16, 2, 2, 4>), dim3(4 * rem, 1), dim3(256), 0, st, p);
-        }
         GD_LAUNCH_OK();
         return 0;
     }

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
     const int wm = wave / NWN, wn = wave % NWN;
     const int fr = lane & 15, g = lane >> 4;
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-    const int ntiles = p.tile_hi > 0 ? p.tile_hi : tiles_m * tiles_n;   // (the host may keep the last partial round for the 128 x 128 kernel)
+    const int ntiles = tiles_m * tiles_n;
     const long batch = blockIdx.y;
     const char* Ab = (const char*)p.A + batch * p.sA * (long)sizeof(T);
     const char* Wb = (const char*)p.W + batch * p.sW * (long)sizeof(T);
