@@ -110,7 +110,7 @@ class FinetuneGD(nn.Module):
     def zero_grad_flat(self):
         self._flat["g"].zero_()
 
-    def backward(self, loss):
+    def backward(self, loss, pre_gather=None):
         """loss.backward() with the gradients gathered into the flat buffer by ONE multi-tensor copy.  With `p.grad`
         pre-set to views of the flat buffer autograd accumulates into each of the ~60 trainable tensors separately
         (an add and a copy kernel per tensor, ~6 us each on an otherwise busy GPU); with `p.grad = None` it just hands the
@@ -120,6 +120,8 @@ class FinetuneGD(nn.Module):
         for p in ps:
             p.grad = None
         loss.backward()
+        if pre_gather is not None:       # e.g. OverlappedGradReducer.wait_early: hook-launched all-reduces of some p.grad
+            pre_gather()
         self._flat["g"].zero_()
         dst = [v for p, v in zip(ps, views) if p.grad is not None]
         src = [p.grad for p in ps if p.grad is not None]

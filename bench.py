@@ -81,13 +81,16 @@ def main():
                      geometry=args.geometry, dtype=args.dtype, teacher_patch=patch, lora_b_std=1e-3,
                      vit_kwargs=dict(init_values=1.0)).to(dev)
     flat = eng.configure_optimizers()
-    reducer = dp.FlatGradReducer(flat["g"], world)
+    # gradient exchange in two chunks: refine_conv + depth head from grad hooks (under the ViT backward), the rest after it
+    early = list(eng.refine_conv.parameters()) + list(eng.depth_diff_head.parameters())
+    reducer = dp.OverlappedGradReducer(eng.trainable_parameters(), flat["views"], flat["g"], early, world)
+    reducer.attach()
     # a few distinct synthetic batches per rank (seed 1234 + 1000*rank + i), resident on the device
     batches = [synthetic_batch(P, img, img, N, hw, dev, seed=1234 + 1000 * rank + i, teacher_patch=patch) for i in range(2)]
 
     def step(i):
         loss, terms = eng.training_step(batches[i % len(batches)])
-        eng.backward(loss)          # gradients land in the flat buffer through one multi-tensor copy
+        eng.backward(loss, pre_gather=reducer.wait_early)   # gradients land in the flat buffer through one multi-tensor copy
         reducer.start()
         scale = reducer.finish()
         eng.optimizer_step(grad_scale=scale)

@@ -35,3 +35,52 @@ def test_flat_grad_allreduce_world2():
     assert out[0][:2] == (0, 4) and out[1][:2] == (4, 8)
     assert out[0][2] == want and out[1][2] == want
     assert out[0][3] == 2.0 and out[1][3] == 2.0
+
+
+def _worker_overlap(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import gd_amd  # noqa: F401
+    from gd_amd import dp
+    dp.init_from_env(backend="gloo")
+    # five "parameters" as views of one flat buffer (16-byte aligned slices with pads, like FinetuneGD.configure_optimizers)
+    shapes = [(3, 4), (5,), (2, 6), (7,), (4, 4)]
+    al = lambda k: (k + 3) // 4 * 4
+    n = sum(al(torch.Size(s).numel()) for s in shapes)
+    flat_p, flat_g = torch.zeros(n), torch.zeros(n)
+    params, views, off = [], [], 0
+    for s in shapes:
+        k = torch.Size(s).numel()
+        p = torch.nn.Parameter(torch.zeros(s))
+        p.data = flat_p[off:off + k].view(s)
+        params.append(p)
+        views.append(flat_g[off:off + k].view(s))
+        off += al(k)
+    early = [params[2], params[3]]                                 # reduced from hooks while "the backward" is still running
+    red = dp.OverlappedGradReducer(params, views, flat_g, early, world)
+    red.attach()
+    x = torch.arange(1, 6, dtype=torch.float32) * (rank + 1)
+    loss = sum((p * x[i]).sum() for i, p in enumerate(params))     # d loss / d p_i = x[i] everywhere
+    for p in params:
+        p.grad = None
+    loss.backward()
+    red.wait_early()
+    flat_g.zero_()
+    torch._foreach_copy_(views, [p.grad for p in params])
+    red.start()
+    scale = red.finish()
+    out[rank] = [float((v * scale).mean()) for v in views] + [red.late]
+    torch.distributed.destroy_process_group()
+
+
+def test_overlapped_grad_reducer_world2():
+    """early chunk from post-accumulate-grad hooks + late ranges of the flat buffer == one mean all-reduce of everything"""
+    world, port = 2, 29613
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_overlap, args=(world, port, out), nprocs=world, join=True)
+    want = [1.5 * i for i in range(1, 6)]                            # mean over ranks of x[i] * (rank + 1)
+    for r in range(world):
+        assert out[r][:5] == want, out[r]
+        assert out[r][5] == [(0, 20), (39, 56)]      # flat layout 12 | 5+3 pad | [12 | 7] +1 pad | 16; the late ranges are the complement
