@@ -83,6 +83,8 @@ class OverlappedGradReducer:
 
     def _hook(self, p):
         if p.grad is not None:
+            if not p.grad.is_contiguous():      # collectives need dense buffers (a gradient may arrive as a strided view)
+                p.grad = p.grad.contiguous()
             self.works.append(dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=True))
 
     def wait_early(self):
