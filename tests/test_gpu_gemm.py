@@ -94,6 +94,24 @@ def test_gemm_nt_persistent_epilogues(M, N, K):
     assert rel_err(ops.gemm_nt(a, w, dact_src=src, dact=3), plain * src.double()) < tol
 
 
+def test_gemm_nt_persistent_ragged_n_and_batched():
+    """persistent kernel with a half-empty last column tile (N = 320), and batched with fp32 output (the cost-volume
+    backward's G.b products: grid.y = batch)."""
+    from gd_amd import ops
+    dt = torch.bfloat16
+    M, N, K = 1300, 320, 128
+    a, w = _mk((M, K), dt, 41), _mk((N, K), dt, 42)
+    bias, res = _mk((N,), torch.float32, 43), _mk((M, N), dt, 44)
+    lt, lb = _mk((M, 8), torch.float32, 45), _mk((8, N), torch.float32, 46)
+    plain = a.double() @ w.double().t()
+    assert rel_err(ops.gemm_nt(a, w, bias=bias, residual=res), plain + bias.double() + res.double()) < 2e-2
+    assert rel_err(ops.gemm_nt(a, w, bias=bias, lora_t=lt, lora_b=lb), plain + bias.double() + lt.double() @ lb.double()) < 2e-2
+    assert rel_err(ops.gemm_nt(a, w, bias=bias, act=1), torch.nn.functional.gelu(plain + bias.double())) < 2e-2
+    ab, wb = _mk((3, 1100, 192), dt, 47), _mk((3, 320, 192), dt, 48)
+    out = ops.gemm_nt(ab, wb, out_dtype=torch.float32)
+    assert out.dtype == torch.float32 and rel_err(out, ab.double() @ wb.double().transpose(1, 2)) < 1e-5
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 1e-2)])
 def test_gemm_nt_batched_strided(dtype, tol):
     from gd_amd import ops
