@@ -1,0 +1,355 @@
+// Bottleneck adapter (a3 — utils/model.py:7-25: out + up(relu(down(out))), D -> 64 -> D, no bias), fused for gfx950.
+//
+// As two GEMMs the adapter is pure HBM traffic: read x (down), write h, read h + x again (up + residual), write out —
+// four passes over [M, D] for 2 * 2 * M * D * 64 FLOP.  Here a block keeps its 32 x D slice of x in LDS (one LDS-DMA
+// fill, 16-byte chunks XOR-swizzled by row so the MFMA fragment reads are conflict-free), contracts it against the down
+// weight (each wave owns 16 of the 64 bottleneck columns; its 16 x D weight slab is prefetched into registers while the
+// tile is in flight), gates, parks the 32 x 64 hidden tile in LDS, and runs the up projection + residual straight out
+// of LDS: x is read from HBM once and out written once.  Three blocks fit a CU, so one block's fill overlaps its
+// neighbours' MFMA / store phases.
+//
+// The same kernel is the backward-to-input:  dX = dOut + ((dOut . up) * [h > 0]) . down  — first weight = up^T [64, D],
+// gate taken from the saved forward hidden tile instead of the value's own sign, second weight = down^T [D, 64].
+// The gated hidden tile (forward: h, backward: dh) is written out because the weight gradients contract it (gd_gemm_tn).
+#include "gd_common.h"
+#include <utility>
+
+// compile-time index loop: array indices are constants when the IR is built, so per-thread arrays that live across the
+// persistent kernel's (not unrolled) tile loop are promoted to registers instead of scratch
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+#define AD_BM 32
+#define AD_BOT 64
+
+// phase 2 of one wave: out[32, D/4] = hidden . w2^T + x.  Weight row n0 + 4*fr + j feeds tile j, so a lane ends up with 4
+// consecutive columns and 16 lanes cover 128 contiguous bytes of an output row.  The next column group's weight
+// fragments are requested before the current group's MFMAs (L2 latency under the stores of the previous group).
+template <int D, bool FULL>
+__device__ __forceinline__ void ad_phase2(const char* sX, const char* sH, const bf16* __restrict__ w2, bf16* __restrict__ out,
+                                          int wave, int g, int c, int row0, int M) {
+    constexpr int CPR = D / 8, NG = D / 256;
+    auto load_b2 = [&](int gq, bf16x8 (&b2)[4][2]) {
+        const char* wr = (const char*)w2 + (long)(wave * (D / 4) + 64 * gq + 4 * c) * (AD_BOT * 2) + 16 * g;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) b2[j][ks] = *(const bf16x8*)(wr + j * (AD_BOT * 2) + 64 * ks);
+    };
+    bf16x8 b2[2][4][2];
+    load_b2(0, b2[0]);
+    bf16x8 ah[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) ah[i][ks] = *(const bf16x8*)(sH + (16 * i + c) * (AD_BOT * 2) + 64 * ks + 16 * g);
+#pragma unroll
+    for (int gq = 0; gq < NG; ++gq) {
+        if (gq + 1 < NG) load_b2(gq + 1, b2[(gq + 1) & 1]);
+        const int off = 2 * (wave * (D / 4) + 64 * gq + 4 * c);   // byte offset of this lane's 4 columns inside a row
+        bf16x4 xr[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * i + 4 * g + r;
+                xr[i][r] = *(const bf16x4*)(sX + ((row * CPR + ((off >> 4) ^ (row & 15))) * 16) + (off & 8));
+            }
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = Mma<bf16>::mma(ah[i][ks], b2[gq & 1][j][ks], acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * i + 4 * g + r;
+                bf16x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (bf16)(acc[i][j][r] + (float)xr[i][r][j]);
+                if (FULL || row0 + row < M) *(bf16x4*)((char*)out + (long)(row0 + row) * (D * 2) + off) = o;
+            }
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256, D <= 768 ? 3 : 2) void adapter_fused_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w1,
+                                                            const bf16* __restrict__ w2, const bf16* __restrict__ gate,
+                                                            bf16* __restrict__ hout, bf16* __restrict__ out, int M) {
+    constexpr int CPR = D / 8;                  // 16-byte chunks per row
+    constexpr int KS = D / 32;                  // MFMA K-steps of phase 1
+    constexpr int PIECES = AD_BM * D * 2 / 1024, PPW = PIECES / 4;
+    static_assert(D % 256 == 0, "D must split into 64-column groups over 4 waves");
+    __shared__ __attribute__((aligned(16))) char sX[AD_BM * D * 2];
+    __shared__ __attribute__((aligned(16))) char sH[AD_BM * AD_BOT * 2];
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // ---- this wave's 16 rows of the first weight, all K-steps (L2-resident; requested before the tile fill) ----
+    bf16x8 b1[KS];
+    {
+        const char* w1r = (const char*)w1 + (long)(16 * wave + c) * (D * 2) + 16 * g;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) b1[ks] = *(const bf16x8*)(w1r + ks * 64);
+    }
+    const int row0 = blockIdx.x * AD_BM;
+    // ---- the x tile: LDS position (row, p) holds source chunk p ^ (row & 15) ----
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int piece = wave * PPW + i;
+        const int lin = piece * 64 + lane, row = lin / CPR, p = lin % CPR;
+        const char* src = (const char*)x + (long)min(row0 + row, M - 1) * (D * 2) + ((p ^ (row & 15)) * 16);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(sX + piece * 1024), 16, 0, 0);
+    }
+    // gate values in the accumulator layout: unconditional loads from a clamped address (a conditional load costs a full
+    // memory round trip each inside its exec-masked block)
+    const bool gated = gate != nullptr;
+    bf16 gt[2][4];
+    {
+        const bf16* gp = gated ? gate : w1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = min(row0 + 16 * i + 4 * g + r, M - 1);
+                gt[i][r] = gp[gated ? (long)row * AD_BOT + 16 * wave + c : 0];
+            }
+    }
+    __syncthreads();
+
+    // ---- phase 1: hidden[32, 16 of 64] = x_tile . w1^T  (two independent accumulation chains per row tile) ----
+    f32x4 acc1[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) acc1[i][0] = acc1[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // fragment reads in batches of 8 (4 K-steps x 2 row tiles) ahead of their MFMAs: the block is latency-bound, not
+    // LDS-bandwidth-bound (every wave sweeps the whole tile once: 4 x 48 KB of reads per block)
+    constexpr int KB = 4;
+    static_assert(KS % KB == 0, "K-steps must split into read batches");
+#pragma unroll
+    for (int k0 = 0; k0 < KS; k0 += KB) {
+        bf16x8 a[KB][2];
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                a[kk][i] = *(const bf16x8*)(sX + (((16 * i + c) * CPR + ((4 * (k0 + kk) + g) ^ c)) * 16));
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc1[i][kk & 1] = Mma<bf16>::mma(a[kk][i], b1[k0 + kk], acc1[i][kk & 1]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = acc1[i][0][r] + acc1[i][1][r];
+            v = gated ? ((float)gt[i][r] > 0.f ? v : 0.f) : fmaxf(v, 0.f);
+            ((bf16*)sH)[(16 * i + 4 * g + r) * AD_BOT + 16 * wave + c] = (bf16)v;
+        }
+    __syncthreads();
+    if (hout != nullptr && row0 + (tid >> 3) < M)
+        *(uint4*)((char*)hout + (long)row0 * (AD_BOT * 2) + tid * 16) = *(const uint4*)(sH + tid * 16);
+
+    if (row0 + AD_BM <= M) ad_phase2<D, true>(sX, sH, w2, out, wave, g, c, row0, M);
+    else ad_phase2<D, false>(sX, sH, w2, out, wave, g, c, row0, M);
+}
+
+// Persistent form (one 4-wave block per CU, M >= a few thousand rows): in the kernel above every block re-reads both
+// weights (192 KB at D = 768) through the vector-memory path for a 48 KB tile — four times the tile's own bytes, and
+// that, not HBM, is what it is bound by.  Here a wave keeps its slab of BOTH weights in registers for the whole launch
+// (one wave per SIMD: 512 registers), walks tiles blockIdx.x, blockIdx.x + gridDim.x, ..., and has the next tile's 48 KB
+// in flight into registers (12 x 16 B per thread) while it works on the current one out of LDS.
+template <int D>
+__global__ __launch_bounds__(256, 1) void adapter_persist_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w1,
+                                                                 const bf16* __restrict__ w2, const bf16* __restrict__ gate,
+                                                                 bf16* __restrict__ hout, bf16* __restrict__ out, int M) {
+    constexpr int CPR = D / 8, KS = D / 32, NG = D / 256;
+    constexpr int PPT = AD_BM * CPR / 256;      // 16-byte chunks of a tile per thread
+    __shared__ __attribute__((aligned(16))) char sX[AD_BM * D * 2];
+    __shared__ __attribute__((aligned(16))) char sH[AD_BM * AD_BOT * 2];
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntiles = (M + AD_BM - 1) / AD_BM;
+    const bool gated = gate != nullptr;
+
+    // (the launch keeps gridDim.x <= ntiles, so every block owns at least one tile)
+    int tile = blockIdx.x;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 pre[PPT];
+    static_for<PPT>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = ic;
+        const int lin = i * 256 + tid, row = lin / CPR, p = lin % CPR;
+        pre[i] = *(const u32x4*)((const char*)x + (long)min(tile * AD_BM + row, M - 1) * (D * 2) + p * 16);
+    });
+    constexpr bool B2REG = D <= 768;            // D = 1024: both weights + the prefetched tile do not fit 512 registers
+    bf16x8 b1[KS], b2[B2REG ? NG : 1][4][2];
+    {
+        const char* w1r = (const char*)w1 + (long)(16 * wave + c) * (D * 2) + 16 * g;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) b1[ks] = *(const bf16x8*)(w1r + ks * 64);
+#pragma unroll
+        for (int gq = 0; gq < (B2REG ? NG : 0); ++gq)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    b2[gq][j][ks] = *(const bf16x8*)((const char*)w2 + (long)(wave * (D / 4) + 64 * gq + 4 * c + j) * (AD_BOT * 2) +
+                                                     64 * ks + 16 * g);
+    }
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * AD_BM;
+        __syncthreads();                        // the previous tile's readers are done with sX and sH
+        static_for<PPT>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = ic;
+            const int lin = i * 256 + tid, row = lin / CPR, p = lin % CPR;
+            *(u32x4*)(sX + (row * CPR + (p ^ (row & 15))) * 16) = pre[i];
+        });
+        unsigned short gt[8];
+        {
+            const bf16* gp = gated ? gate : w1;
+            static_for<8>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = ic / 4, r = ic % 4;
+                const int row = min(row0 + 16 * i + 4 * g + r, M - 1);
+                gt[ic] = ((const unsigned short*)gp)[gated ? (long)row * AD_BOT + 16 * wave + c : 0];
+            });
+        }
+        __syncthreads();
+        {   // next tile into registers (the last iteration re-reads its own tile: harmless, keeps the loads unconditional)
+            const int nt = tile + (int)gridDim.x < ntiles ? tile + (int)gridDim.x : tile;
+            static_for<PPT>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = ic;
+                const int lin = i * 256 + tid, row = lin / CPR, p = lin % CPR;
+                pre[i] = *(const u32x4*)((const char*)x + (long)min(nt * AD_BM + row, M - 1) * (D * 2) + p * 16);
+            });
+        }
+
+        // ---- phase 1 ----
+        f32x4 acc1[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc1[i][0] = acc1[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        constexpr int KB = 4;
+#pragma unroll
+        for (int k0 = 0; k0 < KS; k0 += KB) {
+            bf16x8 a[KB][2];
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    a[kk][i] = *(const bf16x8*)(sX + (((16 * i + c) * CPR + ((4 * (k0 + kk) + g) ^ c)) * 16));
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc1[i][kk & 1] = Mma<bf16>::mma(a[kk][i], b1[k0 + kk], acc1[i][kk & 1]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc1[i][0][r] + acc1[i][1][r];
+                v = gated ? ((short)gt[4 * i + r] > 0 ? v : 0.f) : fmaxf(v, 0.f);   // bf16 > 0 <=> its bits, as int16, > 0
+                ((bf16*)sH)[(16 * i + 4 * g + r) * AD_BOT + 16 * wave + c] = (bf16)v;
+            }
+        __syncthreads();
+        if (hout != nullptr && row0 + (tid >> 3) < M)
+            *(uint4*)((char*)hout + (long)row0 * (AD_BOT * 2) + tid * 16) = *(const uint4*)(sH + tid * 16);
+
+        // ---- phase 2 ----
+        if constexpr (!B2REG) {   // second weight streamed from L2 per tile, as in the one-tile kernel
+            if (row0 + AD_BM <= M) ad_phase2<D, true>(sX, sH, w2, out, wave, g, c, row0, M);
+            else ad_phase2<D, false>(sX, sH, w2, out, wave, g, c, row0, M);
+            continue;
+        }
+        bf16x8 ah[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) ah[i][ks] = *(const bf16x8*)(sH + (16 * i + c) * (AD_BOT * 2) + 64 * ks + 16 * g);
+        const bool full = row0 + AD_BM <= M;
+#pragma unroll
+        for (int gq = 0; gq < NG; ++gq) {
+            const int off = 2 * (wave * (D / 4) + 64 * gq + 4 * c);
+            uint2 xr[2][4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * i + 4 * g + r;
+                    xr[i][r] = *(const uint2*)(sX + ((row * CPR + ((off >> 4) ^ (row & 15))) * 16) + (off & 8));
+                }
+            f32x4 acc[2][4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = Mma<bf16>::mma(ah[i][ks], b2[B2REG ? gq : 0][j][ks], acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * i + 4 * g + r;
+                    const uint2 xv = xr[i][r];   // 4 bf16: widen by shifting into the high half
+                    const float x0 = __builtin_bit_cast(float, xv.x << 16), x1 = __builtin_bit_cast(float, xv.x & 0xffff0000u);
+                    const float x2 = __builtin_bit_cast(float, xv.y << 16), x3 = __builtin_bit_cast(float, xv.y & 0xffff0000u);
+                    bf16x4 o;
+                    o[0] = (bf16)(acc[i][0][r] + x0); o[1] = (bf16)(acc[i][1][r] + x1);
+                    o[2] = (bf16)(acc[i][2][r] + x2); o[3] = (bf16)(acc[i][3][r] + x3);
+                    if (full || row0 + row < M) *(bf16x4*)((char*)out + (long)(row0 + row) * (D * 2) + off) = o;
+                }
+        }
+    }
+}
+
+template <int D>
+static void adapter_launch(const void* x, const void* w1, const void* w2, const void* gate, void* hout, void* out, int M,
+                           hipStream_t s) {
+    static const int persist = getenv("GD_ADAPTER_PERSIST") ? atoi(getenv("GD_ADAPTER_PERSIST")) : 1;
+    if (persist && M >= 256 * AD_BM * 4) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        hipLaunchKernelGGL(adapter_persist_kernel<D>, dim3(min(cus * persist, gd_cdiv(M, AD_BM))), dim3(256), 0, s, (const bf16*)x, (const bf16*)w1,
+                           (const bf16*)w2, (const bf16*)gate, (bf16*)hout, (bf16*)out, M);
+        return;
+    }
+    hipLaunchKernelGGL(adapter_fused_kernel<D>, dim3(gd_cdiv(M, AD_BM)), dim3(256), 0, s, (const bf16*)x, (const bf16*)w1,
+                       (const bf16*)w2, (const bf16*)gate, (bf16*)hout, (bf16*)out, M);
+}
+
+// out[M, D] = x + gate(x . w1^T) . w2^T ;  hidden[M, 64] = gate(x . w1^T)  (bf16, may be null)
+//   gate_src == null : ReLU (forward; w1 = down [64, D], w2 = up [D, 64])
+//   gate_src [M, 64] : keep where gate_src > 0 (backward-to-input; x = dOut, w1 = up^T [64, D], w2 = down^T [D, 64])
+extern "C" int gd_adapter_fused_supported(int D, int bottleneck, int dtype) {
+    return dtype == GD_BF16 && bottleneck == AD_BOT && (D == 256 || D == 512 || D == 768 || D == 1024);
+}
+
+extern "C" int gd_adapter_fused(const void* x, const void* w1, const void* w2, const void* gate_src, void* hidden,
+                                void* out, int M, int D, int bottleneck, int dtype, void* stream) {
+    GD_REQUIRE(M > 0, "gd_adapter_fused: M = %d", M);
+    GD_REQUIRE(gd_adapter_fused_supported(D, bottleneck, dtype),
+               "gd_adapter_fused: unsupported configuration D=%d bottleneck=%d dtype=%d (bf16, bottleneck 64, D in {256,512,768,1024}); "
+               "use two gd_gemm_nt calls", D, bottleneck, dtype);
+    GD_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w1 & 15) == 0 && ((uintptr_t)w2 & 15) == 0 &&
+                   ((uintptr_t)out & 15) == 0 && ((uintptr_t)hidden & 15) == 0 && ((uintptr_t)gate_src & 1) == 0,
+               "gd_adapter_fused: x, w1, w2, out, hidden must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    switch (D) {
+        case 256: adapter_launch<256>(x, w1, w2, gate_src, hidden, out, M, s); break;
+        case 512: adapter_launch<512>(x, w1, w2, gate_src, hidden, out, M, s); break;
+        case 768: adapter_launch<768>(x, w1, w2, gate_src, hidden, out, M, s); break;
+        default: adapter_launch<1024>(x, w1, w2, gate_src, hidden, out, M, s); break;
+    }
+    GD_LAUNCH_OK();
+    return 0;
+}

@@ -186,6 +186,31 @@ def attention_bwd(qkv, o, dout, lse, B, N, H):
 
 
 # ----------------------------------------------------------------------------------------------
+# bottleneck adapter (utils/model.py:7-25), one fused pass
+# ----------------------------------------------------------------------------------------------
+def adapter_fused_supported(x, bottleneck):
+    return bool(lib().gd_adapter_fused_supported(int(x.shape[-1]), int(bottleneck), dtype_code(x)))
+
+
+def adapter_fused(x, w1, w2, gate_src=None, save_hidden=True):
+    """out = x + gate(x @ w1.T) @ w2.T, hidden = gate(x @ w1.T)   (x [M,D] bf16, w1 [64,D], w2 [D,64], same dtype).
+    gate_src None: ReLU (the forward, w1 = down, w2 = up); gate_src [M,64]: keep where gate_src > 0 (the backward-to-input
+    with x = dOut, w1 = up^T, w2 = down^T, gate_src = the forward's hidden).  -> (out, hidden or None)."""
+    M, D = x.shape
+    bott = w1.shape[0]
+    _req(x.is_contiguous() and w1.is_contiguous() and w2.is_contiguous() and w1.shape == (bott, D) and
+         w2.shape == (D, bott) and w1.dtype == x.dtype and w2.dtype == x.dtype, "adapter_fused: layout")
+    _req(gate_src is None or (gate_src.is_contiguous() and gate_src.shape == (M, bott) and gate_src.dtype == x.dtype),
+         "adapter_fused: gate_src layout")
+    out = torch.empty_like(x)
+    hidden = torch.empty(M, bott, dtype=x.dtype, device=x.device) if save_hidden else None
+    rc = lib().gd_adapter_fused(ptr(x), ptr(w1), ptr(w2), ptr(gate_src), ptr(hidden), ptr(out), M, D, bott,
+                                dtype_code(x), stream())
+    check(rc, "gd_adapter_fused")
+    return out, hidden
+
+
+# ----------------------------------------------------------------------------------------------
 # normalisation
 # ----------------------------------------------------------------------------------------------
 def layernorm_fwd(x, gamma, beta, eps, *, save_stats=True, out_dtype=None):

@@ -153,8 +153,13 @@ class _BlockFn(torch.autograd.Function):
         x2 = ops.gemm_nt(h, plan["w2"], bias=plan["b2"], residual=x1)
         out, hd = x2, None
         if down is not None:
-            hd = ops.gemm_nt(x2, tw["down_T"] if tw is not None else down.detach().to(T).contiguous(), act=2)
-            out = ops.gemm_nt(hd, tw["up_T"] if tw is not None else up.detach().to(T).contiguous(), residual=x2)
+            down_T = tw["down_T"] if tw is not None else down.detach().to(T).contiguous()
+            up_T = tw["up_T"] if tw is not None else up.detach().to(T).contiguous()
+            if ops.adapter_fused_supported(x2, down.shape[0]):
+                out, hd = ops.adapter_fused(x2, down_T, up_T, save_hidden=need)
+            else:
+                hd = ops.gemm_nt(x2, down_T, act=2)
+                out = ops.gemm_nt(hd, up_T, residual=x2)
         if need:
             ctx.plan, ctx.dims, ctx.tw = plan, (B, Nt), tw
             ctx.has_lora, ctx.has_ad = a_q is not None, down is not None
@@ -181,10 +186,13 @@ class _BlockFn(torch.autograd.Function):
         if ctx.has_ad:
             up_tT = tw["up_tT"] if tw is not None else up.detach().t().to(T).contiguous()
             down_tT = tw["down_tT"] if tw is not None else down.detach().t().to(T).contiguous()
-            dhp = ops.gemm_nt(dout, up_tT, dact_src=hd, dact=2)                                   # [M, 64]
+            if ops.adapter_fused_supported(dout, bott):
+                dx2, dhp = ops.adapter_fused(dout, up_tT, down_tT, gate_src=hd)                   # dX and d(hidden) [M, 64]
+            else:
+                dhp = ops.gemm_nt(dout, up_tT, dact_src=hd, dact=2)                               # [M, 64]
+                dx2 = ops.gemm_nt(dhp, down_tT, residual=dout)
             g_up = ops.gemm_tn(dout, hd, out=z_up)                                                # [D, 64]
             g_down = ops.gemm_tn(dhp, x2, out=z_down)                                             # [64, D]
-            dx2 = ops.gemm_nt(dhp, down_tT, residual=dout)
         dpre = ops.gemm_nt(dx2, plan["w2_t"], dact_src=pre, dact=3)                               # [M, 4D] (x stored GELU')
         dy2 = ops.gemm_nt(dpre, plan["w1_t"])
         del dpre

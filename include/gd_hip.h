@@ -74,6 +74,15 @@ int gd_layernorm_fwd(const void* x, const float* gamma, const float* beta, void*
 int gd_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                      const void* dres, void* dx, int M, int D, long ldd, long ldx, float dyscale, int dtype,
                      int dy_dtype, void* stream);
+/* Adapter / BlockWithAdapter (utils/model.py:7-25): out = x + up(relu(down(x))), D -> 64 -> D, no bias — one fused pass
+ * (x read once, out written once; the 64-wide hidden tile never leaves the CU except as the saved copy `hidden`).
+ *   forward : gate_src = NULL (ReLU), w1 = down.weight [64, D], w2 = up.weight [D, 64]
+ *   backward: x = dOut, gate_src = saved forward hidden [M, 64] (keep where > 0), w1 = up.weight^T [64, D],
+ *             w2 = down.weight^T [D, 64]; `hidden` then receives d(hidden) for the weight gradients (gd_gemm_tn).
+ * bf16, bottleneck 64, D in {256, 512, 768, 1024} (gd_adapter_fused_supported); other shapes: two gd_gemm_nt calls. */
+int gd_adapter_fused_supported(int D, int bottleneck, int dtype);
+int gd_adapter_fused(const void* x, const void* w1, const void* w2, const void* gate_src, void* hidden, void* out, int M,
+                     int D, int bottleneck, int dtype, void* stream);
 /* F.normalize(p=2, dim=-1) on fp32 rows (src/finetune_timm_vggt.py:328) and its backward. */
 int gd_l2norm_fwd(const float* x, float* y, float* inv, int M, int D, float eps, void* stream);
 int gd_l2norm_bwd(const float* y, const float* dy, const float* inv, float* dx, int M, int D, void* stream);

@@ -139,3 +139,41 @@ def test_gemm_rejects_bad_arguments():
     a = torch.randn(16, 10, device="cuda")   # K*4 = 40 bytes: not a multiple of 16
     with pytest.raises(_lib.GdHipError):
         ops.gemm_nt(a, torch.randn(8, 10, device="cuda"))
+
+
+@pytest.mark.parametrize("M,D", [(1000, 768), (87, 256), (4100, 1024), (32, 512), (33007, 768), (32800, 1024)])
+def test_adapter_fused(M, D):
+    """fused bottleneck adapter (utils/model.py:7-25) against fp64 torch: forward (ReLU gate) and the backward-to-input
+    form (gate from the saved hidden tile); ragged last 32-row tile; M >= 32768 takes the persistent kernel (weights in
+    registers, one block per CU walking tiles)."""
+    from gd_amd import ops
+    dt = torch.bfloat16
+    x = _mk((M, D), dt, 51)
+    down, up = _mk((64, D), dt, 52) * 0.05, _mk((D, 64), dt, 53) * 0.05
+    assert ops.adapter_fused_supported(x, 64)
+    out, hid = ops.adapter_fused(x, down, up)
+    h_ref = torch.relu(x.double() @ down.double().t())
+    assert rel_err(hid, h_ref) < 1e-2
+    assert rel_err(out, x.double() + hid.double() @ up.double().t()) < 1e-2     # the kernel contracts the bf16 hidden tile
+    assert rel_err(out - x, h_ref @ up.double().t()) < 5e-2                        # the adapter branch itself
+    out2, none = ops.adapter_fused(x, down, up, save_hidden=False)
+    assert none is None and torch.equal(out2, out)
+    # backward-to-input: dX = dOut + ((dOut @ up) * [h > 0]) @ down
+    dout = _mk((M, D), dt, 54)
+    up_t, down_t = up.t().contiguous(), down.t().contiguous()
+    dx, dh = ops.adapter_fused(dout, up_t, down_t, gate_src=hid)
+    dh_ref = (dout.double() @ up.double()) * (hid.double() > 0)
+    assert rel_err(dh, dh_ref) < 1e-2
+    assert rel_err(dx, dout.double() + dh.double() @ down.double()) < 1e-2
+    # same numbers as the two-GEMM formulation it replaces
+    hd2 = ops.gemm_nt(x, down, act=2)
+    o2 = ops.gemm_nt(hd2, up, residual=x)
+    assert rel_err(hid, hd2.double()) < 1e-2 and rel_err(out, o2.double()) < 1e-2
+
+
+def test_adapter_fused_rejects_unsupported():
+    from gd_amd import ops, _lib
+    x = torch.randn(64, 384, device="cuda").bfloat16()
+    assert not ops.adapter_fused_supported(x, 64)
+    with pytest.raises(_lib.GdHipError):
+        ops.adapter_fused(x, torch.randn(64, 384, device="cuda").bfloat16(), torch.randn(384, 64, device="cuda").bfloat16())

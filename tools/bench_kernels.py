@@ -83,6 +83,26 @@ def bench_cv():
                   f"fwd+bwd {tfb*1e6/P:8.1f} us/pair {(fwd_bytes+bwd_bytes)/tfb/1e9:8.1f} GB/s")
 
 
+def bench_adapter():
+    """fused adapter kernel against the two-GEMM formulation (M = 87680 rows of the P = 32 step)."""
+    for D in (768, 1024):
+        M = 87680
+        x = torch.randn(M, D, device="cuda").bfloat16()
+        down = (torch.randn(64, D, device="cuda") * 0.05).bfloat16()
+        up = (torch.randn(D, 64, device="cuda") * 0.05).bfloat16()
+        by = 2 * M * D * 2 + M * 64 * 2
+        t = timeit(lambda: ops.adapter_fused(x, down, up))
+
+        def two():
+            h = ops.gemm_nt(x, down, act=2)
+            return ops.gemm_nt(h, up, residual=x)
+        t2 = timeit(two)
+        _, hid = ops.adapter_fused(x, down, up)
+        ut, dn = up.t().contiguous(), down.t().contiguous()
+        tb = timeit(lambda: ops.adapter_fused(x, ut, dn, gate_src=hid))
+        print(f"adapter D={D}: fused fwd {t*1e6:7.1f} us ({by/t/1e9:6.0f} GB/s)  bwd-to-input {tb*1e6:7.1f} us | two GEMMs {t2*1e6:7.1f} us")
+
+
 def pmc_cv():
     """one configuration, few launches: the target of `rocprofv3 --pmc ...` runs (profiles/README.md)."""
     P, hw, C = 32, 1369, 768
@@ -216,8 +236,20 @@ def pmc_gemm():
     torch.cuda.synchronize()
 
 
+def pmc_adapter():
+    M, D = 87680, 768
+    x = torch.randn(M, D, device="cuda").bfloat16()
+    down = (torch.randn(64, D, device="cuda") * 0.05).bfloat16()
+    up = (torch.randn(D, 64, device="cuda") * 0.05).bfloat16()
+    for _ in range(3):
+        ops.adapter_fused(x, down, up)
+    torch.cuda.synchronize()
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gemm", "cv"]
+    if "pmc_adapter" in which:
+        pmc_adapter()
     if "gemm" in which:
         bench_gemm()
     if "cv" in which:
@@ -236,6 +268,8 @@ if __name__ == "__main__":
         bench_rank()
     if "probe" in which:
         probe_gemm()
+    if "adapter" in which:
+        bench_adapter()
     if "pmc_attn" in which:
         pmc_attn()
     if "pmc_gemm" in which:
