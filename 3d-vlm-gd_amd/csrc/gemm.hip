@@ -652,6 +652,70 @@ static bool gd_force_small_tiles() {   // GD_GEMM_SMALL_TILES=1: A/B switch for 
     return v == 1;
 }
 
+// Skinny NT GEMM, N <= 8 (the rank-2r LoRA projections t = LN(x) A^T and dt = dqkv B: M = 87 680, K = 768 / 2304): pure
+// streaming of A.  The 128 x 128 tile kernel spends a full tile of MFMA and W traffic on 8 useful columns (28 TFLOP/s);
+// here a wave owns 16 rows, streams them as MFMA A fragments straight from global memory (two batches of four K-steps in
+// flight), W lives in LDS as [K-step][8 rows][64 B] (conflict-free linear fragment reads; columns 8..15 of the MFMA tile
+// are fed zeros) and the 16 x 8 result leaves as two 16-byte stores per row.
+#define SK_ROWS 8
+template <typename TC>
+__global__ __launch_bounds__(512) void gemm_nt_skinny_kernel(GemmNtParams p) {
+    extern __shared__ __attribute__((aligned(16))) char sW[];       // K/32 x 512 B
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nks = p.K >> 5;
+    // W -> LDS: 16-byte chunk j of row r goes to K-step j/4, row r, sub-chunk j%4
+    for (int q = tid; q < SK_ROWS * (p.K >> 3); q += 512) {
+        const int r = q / (p.K >> 3), j = q % (p.K >> 3);
+        uint4 v = {0u, 0u, 0u, 0u};
+        if (r < p.N) v = *(const uint4*)((const bf16*)p.W + (long)r * p.ldw + j * 8);
+        *(uint4*)(sW + (j >> 2) * 512 + r * 64 + (j & 3) * 16) = v;
+    }
+    __syncthreads();
+    const int row0 = (blockIdx.x * 8 + wave) * 16;
+    if (row0 >= p.M) return;
+    const char* ar = (const char*)p.A + (long)min(row0 + c, p.M - 1) * p.lda * 2 + 16 * g;
+    const char* wr = sW + (c & 7) * 64 + 16 * g;
+    const bool wlive = c < SK_ROWS;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    bf16x8 a0[4], a1[4];
+    const int nb = nks >> 2;                                        // batches of four K-steps (K % 128 == 0)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a0[k] = *(const bf16x8*)(ar + k * 64);
+    for (int b = 0; b < nb; b += 2) {
+        if (b + 1 < nb) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a1[k] = *(const bf16x8*)(ar + (b + 1) * 256 + k * 64);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            bf16x8 w = {};
+            if (wlive) w = *(const bf16x8*)(wr + (b * 4 + k) * 512);
+            if (k & 1) acc1 = Mma<bf16>::mma(a0[k], w, acc1); else acc0 = Mma<bf16>::mma(a0[k], w, acc0);
+        }
+        if (b + 2 < nb) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a0[k] = *(const bf16x8*)(ar + (b + 2) * 256 + k * 64);
+        }
+        if (b + 1 < nb) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                bf16x8 w = {};
+                if (wlive) w = *(const bf16x8*)(wr + ((b + 1) * 4 + k) * 512);
+                if (k & 1) acc1 = Mma<bf16>::mma(a1[k], w, acc1); else acc0 = Mma<bf16>::mma(a1[k], w, acc0);
+            }
+        }
+    }
+    // lane (g, c) holds rows 4g + r, column c
+    if (c < p.N) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = row0 + 4 * g + r;
+            if (row < p.M) ((TC*)p.C)[(long)row * p.ldc + c] = from_f32<TC>((acc0[r] + acc1[r]) * p.alpha);
+        }
+    }
+}
+
 extern "C" int gd_gemm_nt(const void* A, const void* W, void* C, int M, int N, int K, long lda, long ldw, long ldc,
                           int batch, long sA, long sW, long sC, int ab_dtype, int c_dtype, float alpha,
                           const float* bias, const float* lora_t, const float* lora_b, int lora_rt, void* preact,
@@ -696,6 +760,14 @@ extern "C" int gd_gemm_nt(const void* A, const void* W, void* C, int M, int N, i
         persist = e ? atoi(e) : 1;
         int dev = 0; hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+    }
+    if (ab_dtype == GD_BF16 && N <= SK_ROWS && M >= 4096 && batch == 1 && K % 128 == 0 && K <= 4096 && !bias && !lora_t && !preact &&
+        act == 0 && !dact_src && !residual && !accumulate) {
+        const size_t lds = (size_t)(K / 32) * 512;
+        if (c_dtype == GD_F32) hipLaunchKernelGGL(gemm_nt_skinny_kernel<float>, dim3(gd_cdiv(M, 128)), dim3(512), lds, st, p);
+        else hipLaunchKernelGGL(gemm_nt_skinny_kernel<bf16>, dim3(gd_cdiv(M, 128)), dim3(512), lds, st, p);
+        GD_LAUNCH_OK();
+        return 0;
     }
     const long ldmax = (ldc > ldp ? ldc : ldp) > (ldd > ldr ? ldd : ldr) ? (ldc > ldp ? ldc : ldp) : (ldd > ldr ? ldd : ldr);
     // persistent kernel (bf16 operands): the epilogue combinations of the student step, each its own instantiation

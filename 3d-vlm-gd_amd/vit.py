@@ -202,7 +202,11 @@ class _BlockFn(torch.autograd.Function):
         if ctx.has_lora:
             r = at.shape[0] // 2
             bt_T = tw["bt_T"] if tw is not None else bt.to(T).contiguous()
-            dt = ops.gemm_nt(dqkv, bt_T, out_dtype=torch.float32)                                  # [M, 2r]
+            # dt = dqkv @ bt^T [M, 2r]: bt is zero outside its q rows x q columns and v rows x v columns, so only those two
+            # thirds of dqkv are streamed (two skinny launches into the halves of dt)
+            dt = torch.empty(dqkv.shape[0], 2 * r, dtype=torch.float32, device=dqkv.device)
+            ops.gemm_nt(dqkv[:, :D], bt_T[:r, :D], out=dt[:, :r])
+            ops.gemm_nt(dqkv[:, 2 * D:], bt_T[r:, 2 * D:], out=dt[:, r:])
             gbt = ops.gemm_tn(t, dqkv, out=z_bt)                                                  # [2r, 3D]
             gat = ops.gemm_tn(dt, y1, out=z_at)                                                   # [2r, D]
             g_bq, g_bv = gbt[:r, :D].t(), gbt[r:, 2 * D:].t()      # strided views: the gradient gather copies them anyway

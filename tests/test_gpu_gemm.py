@@ -177,3 +177,20 @@ def test_adapter_fused_rejects_unsupported():
     assert not ops.adapter_fused_supported(x, 64)
     with pytest.raises(_lib.GdHipError):
         ops.adapter_fused(x, torch.randn(64, 384, device="cuda").bfloat16(), torch.randn(384, 64, device="cuda").bfloat16())
+
+
+@pytest.mark.parametrize("M,N,K", [(5000, 8, 2304), (4100, 4, 768), (8192, 8, 128), (4097, 7, 1536)])
+def test_gemm_nt_skinny(M, N, K):
+    """streaming kernel for N <= 8, M >= 4096 (the LoRA rank projections): fp32 and bf16 outputs, alpha, a strided A view
+    (q / v thirds of a packed qkv gradient) and a strided output slice."""
+    from gd_amd import ops
+    dt = torch.bfloat16
+    a, w = _mk((M, K), dt, 61), _mk((N, K), dt, 62)
+    ref = a.double() @ w.double().t()
+    assert rel_err(ops.gemm_nt(a, w, out_dtype=torch.float32), ref) < 1e-5
+    assert rel_err(ops.gemm_nt(a, w, alpha=0.5), 0.5 * ref) < 1e-2
+    big = _mk((M, 3 * K), dt, 63)
+    sl = big[:, 2 * K:]
+    out = torch.zeros(M, 2 * N, dtype=torch.float32, device="cuda")
+    ops.gemm_nt(sl, w, out=out[:, N:])
+    assert rel_err(out[:, N:], sl.double() @ w.double().t()) < 1e-5 and float(out[:, :N].abs().max()) == 0.0
