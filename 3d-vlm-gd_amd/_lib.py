@@ -26,7 +26,7 @@ SIGNATURES = {
                            c_int, c_long, c_long, c_long, c_int, c_int, c_float, c_void_p]),
     "gd_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_long,
                                  c_long, c_float, c_int, c_int, c_void_p]),
-    "gd_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+    "gd_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                  c_long, c_long, c_float, c_int, c_int, c_void_p]),
     "gd_adapter_fused_supported": (c_int, [c_int, c_int, c_int]),
     "gd_adapter_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

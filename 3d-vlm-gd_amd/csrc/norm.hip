@@ -64,8 +64,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* x, const float* ga
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;  dx += dres when given
 template <typename T, typename TD, int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* dy, const T* x, const float* gamma, const float* mean,
-                                                     const float* rstd, const T* dres, T* dx, int M, int D, long ldd,
-                                                     long ldx, float dyscale) {
+                                                     const float* rstd, const T* dres, const T* dres2, T* dx, int M, int D,
+                                                     long ldd, long ldx, float dyscale) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const float mu = mean[row], rs = rstd[row];
@@ -99,6 +99,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* dy, const T* x, c
             for (int k = 0; k < 4; ++k) o[k] = rs * (g[i][k] - s1 - xh[i][k] * s2);
             if (dres) {
                 const f32x4 r = load4<T>(dres + (long)row * ldx + c);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] += r[k];
+            }
+            if (dres2) {
+                const f32x4 r = load4<T>(dres2 + (long)row * ldx + c);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) o[k] += r[k];
             }
@@ -163,15 +168,15 @@ extern "C" int gd_layernorm_fwd(const void* x, const float* gamma, const float* 
 }
 
 extern "C" int gd_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
-                                const float* rstd, const void* dres, void* dx, int M, int D, long ldd, long ldx,
-                                float dyscale, int dtype, int dy_dtype, void* stream) {
+                                const float* rstd, const void* dres, const void* dres2, void* dx, int M, int D, long ldd,
+                                long ldx, float dyscale, int dtype, int dy_dtype, void* stream) {
     GD_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * LN_MAXV, "gd_layernorm_bwd: D=%d must be a multiple of 4 and <= 2048", D);
     GD_REQUIRE(ldx % 4 == 0 && ldd % 4 == 0, "gd_layernorm_bwd: row strides must be multiples of 4 elements");
     dim3 grid(gd_cdiv(M, 4)), blk(256);
     hipStream_t s = (hipStream_t)stream;
-#define B_BB(NV) hipLaunchKernelGGL((ln_bwd_kernel<bf16, bf16, NV>), grid, blk, 0, s, (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx, M, D, ldd, ldx, dyscale)
-#define B_BF(NV) hipLaunchKernelGGL((ln_bwd_kernel<bf16, float, NV>), grid, blk, 0, s, (const float*)dy, (const bf16*)x, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx, M, D, ldd, ldx, dyscale)
-#define B_FF(NV) hipLaunchKernelGGL((ln_bwd_kernel<float, float, NV>), grid, blk, 0, s, (const float*)dy, (const float*)x, gamma, mean, rstd, (const float*)dres, (float*)dx, M, D, ldd, ldx, dyscale)
+#define B_BB(NV) hipLaunchKernelGGL((ln_bwd_kernel<bf16, bf16, NV>), grid, blk, 0, s, (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (const bf16*)dres, (const bf16*)dres2, (bf16*)dx, M, D, ldd, ldx, dyscale)
+#define B_BF(NV) hipLaunchKernelGGL((ln_bwd_kernel<bf16, float, NV>), grid, blk, 0, s, (const float*)dy, (const bf16*)x, gamma, mean, rstd, (const bf16*)dres, (const bf16*)dres2, (bf16*)dx, M, D, ldd, ldx, dyscale)
+#define B_FF(NV) hipLaunchKernelGGL((ln_bwd_kernel<float, float, NV>), grid, blk, 0, s, (const float*)dy, (const float*)x, gamma, mean, rstd, (const float*)dres, (const float*)dres2, (float*)dx, M, D, ldd, ldx, dyscale)
     if (dtype == GD_BF16 && dy_dtype == GD_BF16) LN_DISPATCH_NV(D, B_BB);
     else if (dtype == GD_BF16 && dy_dtype == GD_F32) LN_DISPATCH_NV(D, B_BF);
     else if (dtype == GD_F32 && dy_dtype == GD_F32) LN_DISPATCH_NV(D, B_FF);

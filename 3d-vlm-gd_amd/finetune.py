@@ -65,7 +65,7 @@ class FinetuneGD(nn.Module):
         self.target_res = 640
         self.depth_diff_head = DepthAwareFeatureFusion(input_dim=self.embedding_dim, use_tanh=True)
         self.resize_patch_size = teacher_patch or (14 if variant == "vggt" else self.patch_size)
-        self._fwd_cache = {}
+        self._fwd_cache, self._norm_cache, self._fuse_taps = {}, {}, False
         self._flat = None
 
     def reset_parameters(self, lora_b_std=0.0, generator=None):
@@ -173,12 +173,16 @@ class FinetuneGD(nn.Module):
         key = (rgbs.data_ptr(), rgbs._version, tuple(rgbs.shape), gh, gw)
         if key not in self._fwd_cache:
             P = self.patch_size
-            taps, x = self.model.forward_all(rgbs, (4, 5, 6, 7), size=(gh * P, gw * P))
+            if getattr(self, "_fuse_taps", False):   # training_step: every tap is also wanted final-normed
+                taps, x, normed = self.model.forward_all(rgbs, (4, 5, 6, 7), size=(gh * P, gw * P), norm_taps=True)
+                self._norm_cache[key] = normed
+            else:
+                taps, x = self.model.forward_all(rgbs, (4, 5, 6, 7), size=(gh * P, gw * P))
             self._fwd_cache[key] = (taps, x)
         return self._fwd_cache[key]
 
     def clear_cache(self):
-        self._fwd_cache = {}
+        self._fwd_cache, self._norm_cache = {}, {}
 
     def get_intermediate_feature(self, rgbs, pts=None, n=(4, 5, 6, 7), normalize=True):
         """src/finetune_timm_vggt.py:256-302 (reshape=True path): mean over taps of bilinear samples of the
@@ -187,8 +191,14 @@ class FinetuneGD(nn.Module):
         gh, gw = self._kp_grid(h, w)
         P = self.patch_size
         taps, _ = self._forward(rgbs, gh, gw)
-        sel = [taps[(4, 5, 6, 7).index(i)] for i in n]
-        grids = [self.model.norm(t) for t in sel] if normalize else sel
+        idx = [(4, 5, 6, 7).index(i) for i in n]
+        normed = self._norm_cache.get((rgbs.data_ptr(), rgbs._version, tuple(rgbs.shape), gh, gw))
+        if not normalize:
+            grids = [taps[j] for j in idx]
+        elif normed is not None:
+            grids = [normed[j] for j in idx]
+        else:
+            grids = [self.model.norm(taps[j]) for j in idx]
         return kp_gather(grids, pts, gh, gw, (gw * P) / w, (gh * P) / h, gh * P, gw * P, P)
 
     def get_feature(self, rgbs, pts, normalize=True):
@@ -248,6 +258,7 @@ class FinetuneGD(nn.Module):
         mask_1, mask_2 [P,h,w] bool (vggt)."""
         self.clear_cache()
         self.model.prepare_trainables()      # per-step pack of the LoRA / adapter weights (dropped again below: never stale)
+        self._fuse_taps = self.geometry == "shared"   # one forward feeds keypoint AND cost features: norm the taps on the way
         rgbs = torch.cat([batch["rgb_1"], batch["rgb_2"]], 0).contiguous()
         counts = batch.get("counts")
         depth_loss, intra = self.calculate_depth_loss(batch["depth_1"], batch["depth_2"], rgbs, batch["kp_1"],
@@ -258,6 +269,7 @@ class FinetuneGD(nn.Module):
         per_pair = (self.ap_loss_weight * ap + self.depth_loss_weight * depth_loss
                     + self.intra_depth_loss_weight * intra + self.kl_loss_weight * kl)
         self.clear_cache()
+        self._fuse_taps = False
         self.model.release_trainables()
         terms = {"ap_loss": ap.detach(), "depth_loss": depth_loss.detach(), "intra_depth_loss": intra.detach(),
                  "kl_loss": kl.detach()}

@@ -225,12 +225,14 @@ def layernorm_fwd(x, gamma, beta, eps, *, save_stats=True, out_dtype=None):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, dyscale=1.0):
-    """dx [M,D] (dtype of x) = LN'(dy * dyscale) (+ dres)."""
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, dyscale=1.0, dres2=None):
+    """dx [M,D] (dtype of x) = LN'(dy * dyscale) (+ dres) (+ dres2)."""
     M, D = x.shape
-    _req(x.is_contiguous() and dy.stride(-1) == 1 and (dres is None or dres.is_contiguous()), "layernorm_bwd: layout")
+    _req(x.is_contiguous() and dy.stride(-1) == 1 and all(t is None or (t.is_contiguous() and t.dtype == x.dtype and
+                                                                        t.numel() == x.numel()) for t in (dres, dres2)),
+         "layernorm_bwd: layout")
     dx = torch.empty_like(x)
-    rc = lib().gd_layernorm_bwd(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), M, D,
+    rc = lib().gd_layernorm_bwd(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dres2), ptr(dx), M, D,
                                 dy.stride(0), x.stride(0), float(dyscale), dtype_code(x), dtype_code(dy), stream())
     check(rc, "gd_layernorm_bwd")
     return dx

@@ -266,6 +266,38 @@ class _LNFn(torch.autograd.Function):
         return ops.layernorm_bwd(dy2, x2, wf, mean, rstd).view(ctx.shp), None, None, None
 
 
+class _TapFn(torch.autograd.Function):
+    """A tapped block output x feeds three consumers in the distillation step: the next block, `model.norm` (keypoint
+    features) and the un-normed tap mean (cost-volume features).  Left to autograd, the three gradients are summed with
+    two extra full-tensor passes per tap; here x goes out as two aliases + its norm, and the backward folds the two
+    pass-through gradients into the LayerNorm backward kernel as residuals (one pass)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1]).contiguous()
+        wf, bf = w.detach().float().contiguous(), b.detach().float().contiguous()
+        y, mean, rstd = ops.layernorm_fwd(x2, wf, bf, eps, save_stats=x.requires_grad)
+        if x.requires_grad:
+            ctx.save_for_backward(x2, wf, mean, rstd)
+            ctx.shp = shp
+        return x.view_as(x), x.view_as(x), y.view(shp)
+
+    @staticmethod
+    def backward(ctx, g_next, g_raw, g_norm):
+        x2, wf, mean, rstd = ctx.saved_tensors
+        res = [g.reshape(x2.shape).contiguous().to(x2.dtype) for g in (g_next, g_raw) if g is not None]
+        if g_norm is None:
+            dx = None if not res else (res[0] if len(res) == 1 else res[0] + res[1])
+        else:
+            dy = g_norm.reshape(x2.shape).contiguous()
+            if dy.dtype not in (torch.float32, x2.dtype) or (x2.dtype == torch.float32 and dy.dtype != torch.float32):
+                dy = dy.float()
+            dx = ops.layernorm_bwd(dy, x2, wf, mean, rstd, dres=res[0] if res else None,
+                                   dres2=res[1] if len(res) > 1 else None)
+        return (dx.view(ctx.shp) if dx is not None else None), None, None, None
+
+
 class GDLayerNorm(nn.LayerNorm):
     """`model.norm` / `norm_pre`: frozen affine, HIP forward and backward-to-input."""
 
@@ -430,14 +462,23 @@ class GDViT(nn.Module):
             x = blk(x)
         return self.norm(x)
 
-    def forward_all(self, x, taps, size=None):
-        """One pass: (tap outputs in `taps` order, last block output) — the shared-forward mode."""
+    def forward_all(self, x, taps, size=None, norm_taps=False):
+        """One pass: (tap outputs in `taps` order, last block output) — the shared-forward mode.  With norm_taps the
+        final norm of every tap is taken on the way (`_TapFn`: one fused gradient sum per tap in the backward) and the
+        result is (taps, last, normed taps)."""
         x = self.embed(x, size)
-        outs = {}
+        outs, normed = {}, {}
         for i, blk in enumerate(self.blocks):
             x = blk(x)
             if i in taps:
-                outs[i] = x
+                if norm_taps and i + 1 < len(self.blocks):
+                    x, outs[i], normed[i] = _TapFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps)
+                else:
+                    outs[i] = x
+                    if norm_taps:
+                        normed[i] = self.norm(x)
+        if norm_taps:
+            return [outs[i] for i in taps], x, [normed[i] for i in taps]
         return [outs[i] for i in taps], x
 
     def forward(self, x):

@@ -67,13 +67,15 @@ int gd_cost_volume_kl_bwd(const void* f1, const void* f2, const float* t1, const
                           const unsigned char* m2, int P, int hw, int C, int dtype, const float* gloss,
                           const float* stats, void* df1, void* df2, void* workspace, void* stream);
 
-/* nn.LayerNorm forward / backward-to-input (timm Block.norm1/norm2, model.norm; frozen affine).  dres (optional)
- * is added to dx (residual-stream gradient).  dy may be f32 while x is bf16 (dy_dtype). */
+/* nn.LayerNorm forward / backward-to-input (timm Block.norm1/norm2, model.norm; frozen affine).  dres and dres2
+ * (optional, dtype of x, row stride ldx) are added to dx: the residual-stream gradient, and — for a tapped block output,
+ * which feeds the next block, the tap's norm and the un-normed tap mean — the third consumer's gradient, so that the
+ * sum autograd would form with two extra passes comes out of this one kernel.  dy may be f32 while x is bf16 (dy_dtype). */
 int gd_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int M,
                      int D, long ldx, long ldy, float eps, int dtype, int y_dtype, void* stream);
 int gd_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
-                     const void* dres, void* dx, int M, int D, long ldd, long ldx, float dyscale, int dtype,
-                     int dy_dtype, void* stream);
+                     const void* dres, const void* dres2, void* dx, int M, int D, long ldd, long ldx, float dyscale,
+                     int dtype, int dy_dtype, void* stream);
 /* Adapter / BlockWithAdapter (utils/model.py:7-25): out = x + up(relu(down(x))), D -> 64 -> D, no bias — one fused pass
  * (x read once, out written once; the 64-wide hidden tile never leaves the CU except as the saved copy `hidden`).
  *   forward : gate_src = NULL (ReLU), w1 = down.weight [64, D], w2 = up.weight [D, 64]
