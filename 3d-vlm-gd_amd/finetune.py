@@ -23,6 +23,16 @@ from .model import Adapter, BlockWithAdapter, DepthAwareFeatureFusion, _LoRA_qkv
 from .vit import conv3x3_tokens, create_vit, kp_gather
 
 
+def _pair_batch(a, b):
+    """cat([a, b], 0) — free when the loader already collated the two views as the halves of one buffer."""
+    base = a._base
+    if (base is not None and base is b._base and base.is_contiguous() and base.shape[0] == a.shape[0] + b.shape[0]
+            and base.shape[1:] == a.shape[1:] and a.is_contiguous() and b.is_contiguous()
+            and a.data_ptr() == base.data_ptr() and b.data_ptr() == base.data_ptr() + a.numel() * a.element_size()):
+        return base
+    return torch.cat([a, b], 0).contiguous()
+
+
 class FinetuneGD(nn.Module):
     def __init__(self, r=4, backbone="vit_base", patch_size=14, img_size=518, variant="vggt", geometry="shared",
                  dtype="bf16", ap_loss_weight=1.0, depth_loss_weight=None, intra_depth_loss_weight=1.0,
@@ -226,9 +236,8 @@ class FinetuneGD(nn.Module):
         P = kp_1.shape[0]
         kp = torch.cat([kp_1, kp_2], 0)
         feat = self.get_intermediate_feature(rgbs, pts=kp, n=indices, normalize=True)       # [2P,N,D]
-        feats = torch.stack([feat[:P], feat[P:]], 1)                                         # [P,2,N,D]
         d1, d2 = ops.kp_depth(depth_1, kp_1), ops.kp_depth(depth_2, kp_2)
-        return ops.depth_losses(feats, d1, d2, self.depth_diff_head.head_params(), counts=counts, depth_threshold=0.05)
+        return ops.depth_losses(feat, d1, d2, self.depth_diff_head.head_params(), counts=counts, depth_threshold=0.05)   # view-major [2P,N,D]
 
     def calculate_cost_loss(self, rgbs, cost_1, cost_2, kp_1=None, kp_2=None, mask_1=None, mask_2=None):
         """src/finetune_timm_vggt.py:488-533 / src/finetune_timm_mast3r.py:504-540."""
@@ -242,14 +251,16 @@ class FinetuneGD(nn.Module):
         else:
             m1 = F.interpolate(mask_1[:, None].float(), size=(ph, pw), mode="nearest").reshape(P, -1) > 0
             m2 = F.interpolate(mask_2[:, None].float(), size=(ph, pw), mode="nearest").reshape(P, -1) > 0
-        return ops.cost_volume_kl(f[:P], f[P:], cost_1, cost_2, m1, m2, self.variant)
+        f1, f2 = ops.split_pairs(f, P)
+        return ops.cost_volume_kl(f1, f2, cost_1, cost_2, m1, m2, self.variant)
 
     def calculate_matching_loss(self, rgbs, kp_1, kp_2, pts3d_1, pts3d_2, counts=None):
         """src/finetune_timm_vggt.py:536-574 / src/finetune_timm_mast3r.py:543-589.  pts3d_k [P,N,3] are the
         teacher's 3-D points already gathered at the keypoints."""
         P = kp_1.shape[0]
         desc = self.get_feature(rgbs, torch.cat([kp_1, kp_2], 0), normalize=True)
-        return ops.smooth_ap(desc[:P], desc[P:], pts3d_1, pts3d_2, counts, self.variant, self.thres3d_neg, 0.01)
+        d1, d2 = ops.split_pairs(desc, P)
+        return ops.smooth_ap(d1, d2, pts3d_1, pts3d_2, counts, self.variant, self.thres3d_neg, 0.01)
 
     def training_step(self, batch):
         """Loss of P pairs = mean over pairs of the reference's per-pair loss (src/finetune_timm_vggt.py:599-616).
@@ -259,7 +270,7 @@ class FinetuneGD(nn.Module):
         self.clear_cache()
         self.model.prepare_trainables()      # per-step pack of the LoRA / adapter weights (dropped again below: never stale)
         self._fuse_taps = self.geometry == "shared"   # one forward feeds keypoint AND cost features: norm the taps on the way
-        rgbs = torch.cat([batch["rgb_1"], batch["rgb_2"]], 0).contiguous()
+        rgbs = _pair_batch(batch["rgb_1"], batch["rgb_2"])
         counts = batch.get("counts")
         depth_loss, intra = self.calculate_depth_loss(batch["depth_1"], batch["depth_2"], rgbs, batch["kp_1"],
                                                       batch["kp_2"], counts)

@@ -186,6 +186,35 @@ def attention_bwd(qkv, o, dout, lse, B, N, H):
 
 
 # ----------------------------------------------------------------------------------------------
+# views of the two halves of a [2P, ...] batch (view 1 / view 2 of P pairs)
+# ----------------------------------------------------------------------------------------------
+class _SplitPairs(torch.autograd.Function):
+    """x[:P], x[P:] whose backward is ONE concatenation (autograd's own slice backward zero-fills a full-size tensor per
+    half, copies, then adds the two)."""
+
+    @staticmethod
+    def forward(ctx, x, P):
+        ctx.P, ctx.shape, ctx.dt = P, x.shape, x.dtype
+        return x[:P], x[P:]
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        P, shp = ctx.P, ctx.shape
+        if g1 is None and g2 is None:
+            return None, None
+        dev = (g1 if g1 is not None else g2).device
+        if g1 is None:
+            g1 = torch.zeros((P,) + tuple(shp[1:]), dtype=g2.dtype, device=dev)
+        if g2 is None:
+            g2 = torch.zeros((shp[0] - P,) + tuple(shp[1:]), dtype=g1.dtype, device=dev)
+        return torch.cat([g1, g2], 0), None
+
+
+def split_pairs(x, P):
+    return _SplitPairs.apply(x, P)
+
+
+# ----------------------------------------------------------------------------------------------
 # bottleneck adapter (utils/model.py:7-25), one fused pass
 # ----------------------------------------------------------------------------------------------
 def adapter_fused_supported(x, bottleneck):
@@ -293,9 +322,13 @@ def im2col3x3(x, bstride, B, gh, gw, D):
     return col
 
 
-def col2im3x3(dcol, B, gh, gw, D):
-    dx = torch.empty(B * gh * gw, D, dtype=dcol.dtype, device=dcol.device)
-    check(lib().gd_col2im3x3(ptr(dcol), ptr(dx), gh * gw * D, B, gh, gw, D, dtype_code(dcol), stream()), "gd_col2im3x3")
+def col2im3x3(dcol, B, gh, gw, D, prefix=0):
+    """-> [B, prefix + gh*gw, D]: gradient of the token grid the 3x3 conv read, prefix-token rows zero."""
+    dx = torch.empty(B, prefix + gh * gw, D, dtype=dcol.dtype, device=dcol.device)
+    if prefix:
+        dx[:, :prefix].zero_()
+    check(lib().gd_col2im3x3(ptr(dcol), dx[:, prefix:].data_ptr(), (prefix + gh * gw) * D, B, gh, gw, D, dtype_code(dcol),
+                             stream()), "gd_col2im3x3")
     return dx
 
 
@@ -428,10 +461,15 @@ class _DepthLosses(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, feats, d1, d2, counts, thr, w1, b1, ln_w, ln_b, w2, b2):
-        P, _, N, D = feats.shape
-        dev = feats.device
+        vm = feats.dim() == 3                  # [2P,N,D] view-major (view 1 of all pairs, then view 2): no big transpose —
+        dev = feats.device                     # the head's first layer is row-wise, so only its 128-wide output is re-ordered
         f = feats.contiguous().float()
-        u = gemm_nt(f.view(P * 2 * N, D), w1.contiguous())         # [P*2*N,128] = W1 f
+        if vm:
+            P, N, D = feats.shape[0] // 2, feats.shape[1], feats.shape[2]
+            u = gemm_nt(f.view(2 * P * N, D), w1.contiguous()).view(2, P, N, 128).transpose(0, 1).contiguous()
+        else:
+            P, _, N, D = feats.shape
+            u = gemm_nt(f.view(P * 2 * N, D), w1.contiguous())         # [P*2*N,128] = W1 f
         depth = torch.stack([d1, d2], 1).contiguous().float()      # [P,2,N]
         dv1, dv2 = depth[:, 0].contiguous(), depth[:, 1].contiguous()
         cnt2 = counts.repeat_interleave(2).contiguous() if counts is not None else None
@@ -449,27 +487,28 @@ class _DepthLosses(torch.autograd.Function):
         check(lib().gd_depth_l1(ptr(u), ptr(dv1), ptr(dv2), ptr(counts), ptr(ones), P, N, *[ptr(t) for t in hp],
                                 ptr(l1), ptr(du_l), None, ptr(hg_l), None, stream()), "gd_depth_l1")
         ctx.save_for_backward(f, w1, du_r, du_l, hg_r, hg_l)
-        ctx.dims = (P, N, D)
+        ctx.dims = (P, N, D, vm)
         intra = 0.5 * (rank.view(P, 2)[:, 0] + rank.view(P, 2)[:, 1])
         return l1, intra
 
     @staticmethod
     def backward(ctx, g_l1, g_intra):
         f, w1, du_r, du_l, hg_r, hg_l = ctx.saved_tensors
-        P, N, D = ctx.dims
+        P, N, D, vm = ctx.dims
         gi = (0.5 * g_intra.float()).repeat_interleave(2)                       # per keypoint set
         gl = g_l1.float()
-        du = (du_r.view(P, 2, N, 128) * gi.view(P, 2, 1, 1) + du_l * gl.view(P, 1, 1, 1)).view(P * 2 * N, 128)
+        du = du_r.view(P, 2, N, 128) * gi.view(P, 2, 1, 1) + du_l * gl.view(P, 1, 1, 1)
         hg = (hg_r * gi[:, None]).sum(0) + (hg_l * gl[:, None]).sum(0)
-        df = gemm_nt(du, w1.t().contiguous()).view(P, 2, N, D)     # du . W1
+        du = (du.transpose(0, 1).contiguous() if vm else du).view(P * 2 * N, 128)     # rows in the order of f
+        df = gemm_nt(du, w1.t().contiguous()).view(f.shape)        # du . W1
         dw1 = gemm_tn(du, f.view(P * 2 * N, D))                    # du^T f  [128, D]
         return (df, None, None, None, None, dw1, hg[0:128].clone(), hg[128:256].clone(), hg[256:384].clone(),
                 hg[384:512].view(1, 128).clone(), hg[512:513].clone())
 
 
 def depth_losses(feats, depth_1, depth_2, head, counts=None, depth_threshold=0.05):
-    """feats [P,2,N,D] keypoint features of both views, depth_k [P,N]; head: dict w1,b1,ln_w,ln_b,w2,b2.
-    -> (depth_l1 [P], intra_rank [P])  (calculate_depth_loss tail)."""
+    """feats [P,2,N,D] keypoint features of both views — or [2P,N,D] view-major as the extractor returns them —, depth_k
+    [P,N]; head: dict w1,b1,ln_w,ln_b,w2,b2.  -> (depth_l1 [P], intra_rank [P])  (calculate_depth_loss tail)."""
     return _DepthLosses.apply(feats, depth_1, depth_2, counts, depth_threshold, head["w1"], head["b1"], head["ln_w"],
                               head["ln_b"], head["w2"], head["b2"])
 

@@ -518,9 +518,7 @@ class _Conv3x3Fn(torch.autograd.Function):
         gweight = gw_.view(D, 3, 3, D).permute(0, 3, 1, 2).contiguous()
         gbias = dyf.sum(0)
         dcol = ops.gemm_nt(dyt, wk.t().contiguous())                        # [M, 9D]
-        dxg = ops.col2im3x3(dcol, B, gh, gw, D).view(B, gh * gw, D)
-        dtok = torch.zeros(B, Nt, D, dtype=T, device=dy.device)
-        dtok[:, Nt - gh * gw:] = dxg
+        dtok = ops.col2im3x3(dcol, B, gh, gw, D, prefix=Nt - gh * gw)     # straight into the [B, Nt, D] token gradient
         return dtok, gweight, gbias, None, None
 
 

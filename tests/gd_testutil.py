@@ -80,4 +80,7 @@ def synthetic_batch(P, h, w, N, hw, device, seed=0, teacher_patch=14, counts=Non
         for p, n in enumerate(counts):
             b["kp_1"][p, n:] = -1.0
             b["kp_2"][p, n:] = -1.0
-    return {k: v.to(device) for k, v in b.items()}
+    b = {k: v.to(device) for k, v in b.items()}
+    rgb = torch.cat([b["rgb_1"], b["rgb_2"]], 0)          # collated as the two halves of one buffer, as a loader would hand them:
+    b["rgb_1"], b["rgb_2"] = rgb[:P], rgb[P:]             # the step then needs no concatenation copy (finetune._pair_batch)
+    return b
