@@ -316,66 +316,80 @@ __device__ __forceinline__ float oct_sum(float v) {   // sum over the lane's 8-l
     return v;
 }
 
-struct Head8 { float yh[16], dg[16], a[16], rstd, s; };
+// EPL head channels per lane: 16 -> 8 lanes per pair (8 pairs per wave-instruction), 8 -> 16 lanes per pair (4 pairs).
+// The 16-channel form needs 332 registers (one wave per SIMD: every VALU dependency and LDS read stalls the SIMD); the
+// 8-channel form fits three waves per SIMD for 2x the replicated per-pair scalar tail (tanh / exp / log1p).
+template <int EPL> __device__ __forceinline__ float grp_sum(float v);
+template <> __device__ __forceinline__ float grp_sum<16>(float v) { return oct_sum(v); }
+template <> __device__ __forceinline__ float grp_sum<8>(float v) { return row16_sum(v); }
+
+// Cached per evaluation: yh = LN-normalised z, q = w2 * GELU'(y), a = GELU(y) and the two group sums the LayerNorm
+// backward needs, P1 = sum q ln_w and P2 = sum q ln_w yh — they do not depend on the upstream gradient, so the backward is
+// one pass over the lane's channels with no reduction of its own.
+template <int EPL> struct Head8 { float yh[EPL], q[EPL], a[EPL], rstd, s, P1, P2; };
 
 // z = sign * d + b1 ; returns s = tanh(w2 . GELU(LN(z)) + b2) and caches what the backward needs
-__device__ __forceinline__ float head8_eval(const float (&d)[16], float sign, const float (*sh)[128], int k0, float hb2, Head8& c) {
-    float z[16], sum = 0.f;
+template <int EPL>
+__device__ __forceinline__ float head8_eval(const float (&d)[EPL], float sign, const float (*sh)[128], int k0, float hb2, Head8<EPL>& c) {
+    float z[EPL], sum = 0.f;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) { z[e] = fmaf(sign, d[e], sh[0][k0 + e]); sum += z[e]; }
-    const float mu = oct_sum(sum) * (1.0f / 128.0f);
+    for (int e = 0; e < EPL; ++e) { z[e] = fmaf(sign, d[e], sh[0][k0 + e]); sum += z[e]; }
+    const float mu = grp_sum<EPL>(sum) * (1.0f / 128.0f);
     float var = 0.f;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) { z[e] -= mu; var = fmaf(z[e], z[e], var); }
-    c.rstd = rsqrtf(oct_sum(var) * (1.0f / 128.0f) + 1e-5f);
-    float o = 0.f;
+    for (int e = 0; e < EPL; ++e) { z[e] -= mu; var = fmaf(z[e], z[e], var); }
+    c.rstd = rsqrtf(grp_sum<EPL>(var) * (1.0f / 128.0f) + 1e-5f);
+    float o = 0.f, p1 = 0.f, p2 = 0.f;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
+    for (int e = 0; e < EPL; ++e) {
         c.yh[e] = z[e] * c.rstd;
         const float y = fmaf(c.yh[e], sh[1][k0 + e], sh[2][k0 + e]);
         float Phi, ex;
         gelu_parts(y, Phi, ex);
         c.a[e] = y * Phi;
-        c.dg[e] = Phi + y * ex * 0.39894228040143268f;
+        c.q[e] = sh[3][k0 + e] * fmaf(y * ex, 0.39894228040143268f, Phi);
+        const float ql = c.q[e] * sh[1][k0 + e];
+        p1 += ql;
+        p2 = fmaf(ql, c.yh[e], p2);
         o = fmaf(c.a[e], sh[3][k0 + e], o);
     }
-    c.s = tanhf(oct_sum(o) + hb2);
+    c.P1 = grp_sum<EPL>(p1) * (1.0f / 128.0f);
+    c.P2 = grp_sum<EPL>(p2) * (1.0f / 128.0f);
+    // tanh(x) = 1 - 2 / (1 + e^2x): the per-pair scalar tail runs replicated in every lane of the group, so it is kept to a
+    // handful of instructions (v_exp / v_rcp; |error| ~1e-7, inf -> +-1 without a clamp)
+    c.s = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * (grp_sum<EPL>(o) + hb2)));
     return c.s;
 }
 
-template <bool ACC>
-__device__ __forceinline__ void head8_back(float dLds, const float (*sh)[128], int k0, const Head8& c, float (&dz)[16],
-                                           float (*acc)[16], float& acc_b2) {
+template <int EPL, bool ACC>
+__device__ __forceinline__ void head8_back(float dLds, const float (*sh)[128], int k0, const Head8<EPL>& c, float (&dz)[EPL],
+                                           float (*acc)[EPL], float& acc_b2) {
     const float dof = dLds * (1.0f - c.s * c.s);
-    float dyh[16], m1 = 0.f, m2 = 0.f;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const float dy = dof * sh[3][k0 + e] * c.dg[e];
-        dyh[e] = dy * sh[1][k0 + e];
-        m1 += dyh[e];
-        m2 = fmaf(dyh[e], c.yh[e], m2);
-        if (ACC) { acc[1][e] = fmaf(dy, c.yh[e], acc[1][e]); acc[2][e] += dy; acc[3][e] = fmaf(dof, c.a[e], acc[3][e]); }
-    }
+    const float rd = c.rstd * dof;
     if (ACC) acc_b2 += dof;
-    m1 = oct_sum(m1) * (1.0f / 128.0f);
-    m2 = oct_sum(m2) * (1.0f / 128.0f);
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        dz[e] = c.rstd * (dyh[e] - m1 - c.yh[e] * m2);
-        if (ACC) acc[0][e] += dz[e];
+    for (int e = 0; e < EPL; ++e) {
+        // dz = rstd * (dyh - mean(dyh) - yh * mean(dyh yh)),  dyh = dof q ln_w
+        dz[e] = rd * (fmaf(c.q[e], sh[1][k0 + e], -c.P1) - c.yh[e] * c.P2);
+        if (ACC) {
+            const float dy = dof * c.q[e];
+            acc[0][e] += dz[e]; acc[1][e] = fmaf(dy, c.yh[e], acc[1][e]); acc[2][e] += dy; acc[3][e] = fmaf(dof, c.a[e], acc[3][e]);
+        }
     }
 }
 
-__global__ __launch_bounds__(256) void pair_rank8_kernel(const float* u, const float* depth, const int* counts,
+template <int EPL>
+__global__ __launch_bounds__(256, EPL == 8 ? 3 : 1) void pair_rank8_kernel(const float* u, const float* depth, const int* counts,
                                                          const float* b1, const float* lw, const float* lb,
                                                          const float* w2, const float* b2, float* du, float* hg,
                                                          float* loss_sum, int* pair_cnt, int Nmax, float thr) {
+    constexpr int LPP = 128 / EPL, PPW = 64 / LPP;              // lanes per pair, pairs per wave
     __shared__ __attribute__((aligned(16))) float sh[4][128];   // b1, ln_w, ln_b, w2
     __shared__ float sacc[4][5][128];
     __shared__ float sred[4][2];
     __shared__ int scnt[4];
     const int set = blockIdx.y, i = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int sub = lane & 7, ps = lane >> 3, k0 = sub * 16;
+    const int sub = lane % LPP, ps = lane / LPP, k0 = sub * EPL;
     const int n = counts ? counts[set] : Nmax;
     float* dui = du + ((long)set * Nmax + i) * 128;
     if (i >= n) {
@@ -389,54 +403,55 @@ __global__ __launch_bounds__(256) void pair_rank8_kernel(const float* u, const f
     __syncthreads();
     const float hb2 = b2[0];
     const float* ub = u + (long)set * Nmax * 128;
-    float ui[16];
+    float ui[EPL];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < EPL / 4; ++q) {
         const f32x4 v = *(const f32x4*)(ub + (long)i * 128 + k0 + 4 * q);
 #pragma unroll
         for (int k = 0; k < 4; ++k) ui[4 * q + k] = v[k];
     }
     const float di = depth[(long)set * Nmax + i];
-    float acc[4][16], dacc[16];
+    float acc[4][EPL], dacc[EPL];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) { acc[0][e] = acc[1][e] = acc[2][e] = acc[3][e] = 0.f; dacc[e] = 0.f; }
+    for (int e = 0; e < EPL; ++e) { acc[0][e] = acc[1][e] = acc[2][e] = acc[3][e] = 0.f; dacc[e] = 0.f; }
     float acc_b2 = 0.f, lsum = 0.f;
     int cnt = 0;
-    for (int jb = wave * 8; jb < n; jb += 32) {
+    for (int jb = wave * PPW; jb < n; jb += 4 * PPW) {
         const int j = jb + ps;
         const bool inr = j < n;
         const float dd = inr ? depth[(long)set * Nmax + j] - di : 0.f;   // d_j - d_i
         const bool valid = inr && fabsf(dd) > thr;
         if (!__any(valid)) continue;
         const float alpha = dd > 0.f ? 1.f : -1.f, vf = valid ? 1.f : 0.f;
-        float d[16];
+        float d[EPL];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < EPL / 4; ++q) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (inr) v = *(const f32x4*)(ub + (long)j * 128 + k0 + 4 * q);
 #pragma unroll
             for (int k = 0; k < 4; ++k) d[4 * q + k] = v[k] - ui[4 * q + k];
         }
-        Head8 c;
-        float dz[16];
+        Head8<EPL> c;
+        float dz[EPL];
         // pair (i, j): z = u_j - u_i + b1, alpha_ij = sign(d_j - d_i)
-        float s = head8_eval(d, 1.0f, sh, k0, hb2, c);
-        lsum += vf * log1pf(expf(-alpha * s));
-        head8_back<true>(vf * (-alpha / (1.0f + expf(alpha * s))), sh, k0, c, dz, acc, acc_b2);
+        float s = head8_eval<EPL>(d, 1.0f, sh, k0, hb2, c);
+        const float em = __expf(-alpha * s);                       // |s| < 1: e^-as in (0.36, 2.72)
+        lsum += vf * __logf(1.0f + em);
+        head8_back<EPL, true>(vf * -alpha * em * __builtin_amdgcn_rcpf(1.0f + em), sh, k0, c, dz, acc, acc_b2);   // -a / (1 + e^as)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) dacc[e] -= dz[e];
+        for (int e = 0; e < EPL; ++e) dacc[e] -= dz[e];
         cnt += valid ? 1 : 0;
         // mirrored pair (j, i): z' = u_i - u_j + b1, alpha_ji = -alpha; only its dz reaches du_i
-        s = head8_eval(d, -1.0f, sh, k0, hb2, c);
-        head8_back<false>(vf * (alpha / (1.0f + expf(-alpha * s))), sh, k0, c, dz, nullptr, acc_b2);
+        s = head8_eval<EPL>(d, -1.0f, sh, k0, hb2, c);
+        head8_back<EPL, false>(vf * alpha * __builtin_amdgcn_rcpf(1.0f + __expf(-alpha * s)), sh, k0, c, dz, nullptr, acc_b2);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) dacc[e] += dz[e];
+        for (int e = 0; e < EPL; ++e) dacc[e] += dz[e];
     }
-    // sum the 8 pair slots of the wave (lanes with equal sub), then the 4 waves through LDS
+    // sum the pair slots of the wave (lanes with equal sub), then the 4 waves through LDS
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
+    for (int e = 0; e < EPL; ++e) {
 #pragma unroll
-        for (int o = 8; o < 64; o <<= 1) {
+        for (int o = LPP; o < 64; o <<= 1) {
             dacc[e] += __shfl_xor(dacc[e], o, 64);
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[t][e] += __shfl_xor(acc[t][e], o, 64);
@@ -444,13 +459,13 @@ __global__ __launch_bounds__(256) void pair_rank8_kernel(const float* u, const f
     }
     if (ps == 0) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
+        for (int e = 0; e < EPL; ++e) {
             sacc[wave][0][k0 + e] = dacc[e];
 #pragma unroll
             for (int t = 0; t < 4; ++t) sacc[wave][1 + t][k0 + e] = acc[t][e];
         }
     }
-    // per-pair scalars live replicated in the 8 lanes of a group: count them once
+    // per-pair scalars live replicated in the lanes of a group: count them once
     const float b2s = wave_sum(sub == 0 ? acc_b2 : 0.f), ls = wave_sum(sub == 0 ? lsum : 0.f);
     const float cs = wave_sum(sub == 0 ? (float)cnt : 0.f);
     if (lane == 0) { sred[wave][0] = b2s; sred[wave][1] = ls; scnt[wave] = (int)(cs + 0.5f); }
@@ -578,9 +593,11 @@ extern "C" int gd_pair_rank(const float* u, const float* depth, const int* count
     hipMemsetAsync(workspace, 0, gd_pair_rank_workspace_bytes(S), s);
     static int wide = -1;   // GD_PAIR_RANK_WAVE=1 selects the older one-wave-per-pair kernel (A/B testing)
     if (wide < 0) { const char* e = getenv("GD_PAIR_RANK_WAVE"); wide = e ? atoi(e) : 0; }
-    if (wide) hipLaunchKernelGGL(pair_rank_kernel, dim3(Nmax, S), dim3(256), 0, s, u, depth, counts, b1, ln_w, ln_b, w2, b2, du,
+    if (wide == 1) hipLaunchKernelGGL(pair_rank_kernel, dim3(Nmax, S), dim3(256), 0, s, u, depth, counts, b1, ln_w, ln_b, w2, b2, du,
                                  hg, lsum, cnt, Nmax, depth_threshold);
-    else hipLaunchKernelGGL(pair_rank8_kernel, dim3(Nmax, S), dim3(256), 0, s, u, depth, counts, b1, ln_w, ln_b, w2, b2, du,
+    else if (wide == 2) hipLaunchKernelGGL(pair_rank8_kernel<16>, dim3(Nmax, S), dim3(256), 0, s, u, depth, counts, b1, ln_w, ln_b, w2,
+                                           b2, du, hg, lsum, cnt, Nmax, depth_threshold);   // GD_PAIR_RANK_WAVE=2: 8 lanes per pair
+    else hipLaunchKernelGGL(pair_rank8_kernel<8>, dim3(Nmax, S), dim3(256), 0, s, u, depth, counts, b1, ln_w, ln_b, w2, b2, du,
                             hg, lsum, cnt, Nmax, depth_threshold);
     hipLaunchKernelGGL(pair_rank_finalize_kernel, dim3(S), dim3(256), 0, s, du, hg, lsum, cnt, gscale, head_grad,
                        head_grad_sets, loss, Nmax);
