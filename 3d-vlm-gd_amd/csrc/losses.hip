@@ -483,6 +483,130 @@ __global__ __launch_bounds__(256, EPL == 8 ? 3 : 1) void pair_rank8_kernel(const
     }
 }
 
+// ---- tiled form: every UNORDERED pair {i, j} is evaluated once.  The kernel above gives each row i its own block and,
+// to keep du_i local, evaluates (i, j) and the mirror (j, i) for every j — each head evaluation is done twice across the
+// grid.  Here a block owns a 16 x 32 tile of the strict upper triangle (i < j): the four pair slots of a wave hold four
+// rows i, the block sweeps the tile's 32 columns j (each wave starting at a different column), and for a pair both ordered
+// terms are taken at once:  g = dz(i,j) - dz(j,i);  du_i -= g stays in registers, du_j += g is summed over the wave's four
+// slots by two lane shuffles and over the four waves by LDS atomic adds; the tile's 16 + 32 partial rows then go to du with
+// no-return global atomic adds (du is zero-filled first; fp32 summation order is not fixed, as for the head gradients).
+#define RT_I 16
+#define RT_J 32
+__global__ __launch_bounds__(256, 2) void pair_rank_tile_kernel(const float* u, const float* depth, const int* counts,
+                                                               const float* b1, const float* lw, const float* lb,
+                                                               const float* w2, const float* b2, float* du, float* hg,
+                                                               float* loss_sum, int* pair_cnt, int Nmax, float thr, int nti) {
+    constexpr int EPL = 8;
+    __shared__ __attribute__((aligned(16))) float sh[4][128];   // b1, ln_w, ln_b, w2
+    __shared__ float sJ[RT_J][128];
+    __shared__ float sacc[4][4][128];
+    __shared__ float sred[4][2];
+    __shared__ int scnt[4];
+    const int set = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane & 15, ps = lane >> 4, k0 = sub * EPL;
+    const int ti = blockIdx.x % nti, tj = blockIdx.x / nti;
+    const int n = counts ? counts[set] : Nmax;
+    const int i0 = ti * RT_I, j0 = tj * RT_J;
+    if (j0 + RT_J - 1 <= i0 || i0 >= n || j0 >= n) return;      // tile entirely on / below the diagonal, or past the set
+    if (threadIdx.x < 128) {
+        sh[0][threadIdx.x] = b1[threadIdx.x]; sh[1][threadIdx.x] = lw[threadIdx.x];
+        sh[2][threadIdx.x] = lb[threadIdx.x]; sh[3][threadIdx.x] = w2[threadIdx.x];
+    }
+    for (int q = threadIdx.x; q < RT_J * 128; q += 256) (&sJ[0][0])[q] = 0.f;
+    __syncthreads();
+    const float hb2 = b2[0];
+    const float* ub = u + (long)set * Nmax * 128;
+    const int i = i0 + wave * 4 + ps;
+    const bool iok = i < n;
+    float ui[EPL];
+#pragma unroll
+    for (int q = 0; q < EPL / 4; ++q) {
+        const f32x4 v = *(const f32x4*)(ub + (long)min(i, Nmax - 1) * 128 + k0 + 4 * q);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ui[4 * q + k] = v[k];
+    }
+    const float di = depth[(long)set * Nmax + min(i, Nmax - 1)];
+    float acc[4][EPL], dacc[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) { acc[0][e] = acc[1][e] = acc[2][e] = acc[3][e] = 0.f; dacc[e] = 0.f; }
+    float acc_b2 = 0.f, lsum = 0.f;
+    int cnt = 0;
+    for (int it = 0; it < RT_J; ++it) {
+        const int jj = (it + 8 * wave) & (RT_J - 1), j = j0 + jj;   // uniform over the wave
+        if (j >= n) continue;
+        const float dd = depth[(long)set * Nmax + j] - di;         // d_j - d_i
+        const bool valid = iok && i < j && fabsf(dd) > thr;
+        if (!__any(valid)) continue;
+        const float alpha = dd > 0.f ? 1.f : -1.f, vf = valid ? 1.f : 0.f;
+        float d[EPL];
+#pragma unroll
+        for (int q = 0; q < EPL / 4; ++q) {
+            const f32x4 v = *(const f32x4*)(ub + (long)j * 128 + k0 + 4 * q);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d[4 * q + k] = v[k] - ui[4 * q + k];
+        }
+        Head8<EPL> c;
+        float dz[EPL], g[EPL];
+        // ordered pair (i, j): z = u_j - u_i + b1, alpha_ij = sign(d_j - d_i)
+        float s = head8_eval<EPL>(d, 1.0f, sh, k0, hb2, c);
+        float em = __expf(-alpha * s);
+        lsum += vf * __logf(1.0f + em);
+        head8_back<EPL, true>(vf * -alpha * em * __builtin_amdgcn_rcpf(1.0f + em), sh, k0, c, dz, acc, acc_b2);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) g[e] = dz[e];
+        // ordered pair (j, i): z' = u_i - u_j + b1, alpha_ji = -alpha
+        s = head8_eval<EPL>(d, -1.0f, sh, k0, hb2, c);
+        em = __expf(alpha * s);
+        lsum += vf * __logf(1.0f + em);
+        head8_back<EPL, true>(vf * alpha * em * __builtin_amdgcn_rcpf(1.0f + em), sh, k0, c, dz, acc, acc_b2);
+        cnt += valid ? 2 : 0;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            g[e] -= dz[e];                       // d loss / d(u_j - u_i)
+            dacc[e] -= g[e];
+            float t = g[e];
+            t += __shfl_xor(t, 16, 64);
+            t += __shfl_xor(t, 32, 64);
+            if (ps == 0) atomicAdd(&sJ[jj][k0 + e], t);
+        }
+    }
+    // head-parameter gradients: sum the 4 slots of the wave, then the 4 waves through LDS
+#pragma unroll
+    for (int e = 0; e < EPL; ++e)
+#pragma unroll
+        for (int o = 16; o < 64; o <<= 1)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t][e] += __shfl_xor(acc[t][e], o, 64);
+    if (ps == 0) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) sacc[wave][t][k0 + e] = acc[t][e];
+    }
+    if (iok) {
+        float* dui = du + ((long)set * Nmax + i) * 128 + k0;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) unsafeAtomicAdd(dui + e, dacc[e]);
+    }
+    const float b2s = wave_sum(sub == 0 ? acc_b2 : 0.f), ls = wave_sum(sub == 0 ? lsum : 0.f);
+    const float cs = wave_sum(sub == 0 ? (float)cnt : 0.f);
+    if (lane == 0) { sred[wave][0] = b2s; sred[wave][1] = ls; scnt[wave] = (int)(cs + 0.5f); }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < RT_J * 128; idx += 256) {
+        const int jj = idx >> 7, k = idx & 127;
+        if (j0 + jj < n) unsafeAtomicAdd(du + ((long)set * Nmax + j0 + jj) * 128 + k, sJ[jj][k]);
+    }
+    for (int idx = threadIdx.x; idx < 4 * 128; idx += 256) {
+        const int t = idx >> 7, k = idx & 127;
+        unsafeAtomicAdd(hg + (long)set * HG_SIZE + t * 128 + k, sacc[0][t][k] + sacc[1][t][k] + sacc[2][t][k] + sacc[3][t][k]);
+    }
+    if (threadIdx.x == 0) {
+        unsafeAtomicAdd(hg + (long)set * HG_SIZE + 512, sred[0][0] + sred[1][0] + sred[2][0] + sred[3][0]);
+        unsafeAtomicAdd(loss_sum + set, sred[0][1] + sred[1][1] + sred[2][1] + sred[3][1]);
+        atomicAdd(pair_cnt + set, scnt[0] + scnt[1] + scnt[2] + scnt[3]);
+    }
+}
+
 // L1(head(f1 - f2), tanh(d1 - d2)) rows (src/finetune_timm_vggt.py:475-479): one wave per keypoint.
 // u holds [P][2][Nmax][128]; writes du for both views (du1 = +dz, du2 = -dz, scaled by gscale[p]/n),
 // head grads (scaled) into hg[p], loss_sum[p] += |s - t| / n.
@@ -597,8 +721,14 @@ extern "C" int gd_pair_rank(const float* u, const float* depth, const int* count
                                  hg, lsum, cnt, Nmax, depth_threshold);
     else if (wide == 2) hipLaunchKernelGGL(pair_rank8_kernel<16>, dim3(Nmax, S), dim3(256), 0, s, u, depth, counts, b1, ln_w, ln_b, w2,
                                            b2, du, hg, lsum, cnt, Nmax, depth_threshold);   // GD_PAIR_RANK_WAVE=2: 8 lanes per pair
-    else hipLaunchKernelGGL(pair_rank8_kernel<8>, dim3(Nmax, S), dim3(256), 0, s, u, depth, counts, b1, ln_w, ln_b, w2, b2, du,
-                            hg, lsum, cnt, Nmax, depth_threshold);
+    else if (wide == 3) hipLaunchKernelGGL(pair_rank8_kernel<8>, dim3(Nmax, S), dim3(256), 0, s, u, depth, counts, b1, ln_w, ln_b, w2, b2, du,
+                                           hg, lsum, cnt, Nmax, depth_threshold);           // GD_PAIR_RANK_WAVE=3: one block per row i
+    else {
+        hipMemsetAsync(du, 0, (size_t)S * Nmax * 128 * sizeof(float), s);
+        const int nti = gd_cdiv(Nmax, RT_I), ntj = gd_cdiv(Nmax, RT_J);
+        hipLaunchKernelGGL(pair_rank_tile_kernel, dim3(nti * ntj, S), dim3(256), 0, s, u, depth, counts, b1, ln_w, ln_b, w2, b2,
+                           du, hg, lsum, cnt, Nmax, depth_threshold, nti);
+    }
     hipLaunchKernelGGL(pair_rank_finalize_kernel, dim3(S), dim3(256), 0, s, du, hg, lsum, cnt, gscale, head_grad,
                        head_grad_sets, loss, Nmax);
     GD_LAUNCH_OK();
