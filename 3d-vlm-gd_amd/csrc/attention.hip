@@ -425,34 +425,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const bf16* qkv, b
     }
 }
 
-// delta[b,h,q] = sum_d dO[b,q,h,d] * O[b,q,h,d]
-template <typename T>
-__global__ __launch_bounds__(256) void attn_delta_kernel(const T* o, const T* dout, float* delta, int N, int H, long total) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;  // over B*N*H*16 : 16 lanes x 4 elements per (b,q,h)
-    const long item = idx >> 4;
-    const int part = idx & 15;
-    float acc = 0.f;
-    if (item < total) {
-        const T* po = o + item * HD + part * 4;
-        const T* pd = dout + item * HD + part * 4;
+// dot of two operand fragments (the 16 bytes a lane holds of a row), fp32
+__device__ __forceinline__ float frag_dot(bf16x8 a, bf16x8 b) {
+    float s = 0.f;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) acc += to_f32<T>(po[k]) * to_f32<T>(pd[k]);
-    }
-#pragma unroll
-    for (int ofs = 1; ofs < 16; ofs <<= 1) acc += __shfl_xor(acc, ofs, 64);
-    if (item < total && part == 0) {
-        const long bq = item / H;
-        const int h = item % H;
-        const long bb = bq / N;
-        const int q = bq % N;
-        delta[(bb * H + h) * N + q] = acc;
-    }
+    for (int k = 0; k < 8; ++k) s = fmaf((float)a[k], (float)b[k], s);
+    return s;
 }
+__device__ __forceinline__ float frag_dot(f32x4 a, f32x4 b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
 
 // ------------------------------------------------------------------------------------------ backward: dQ
 template <typename T>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const T* qkv, const T* dout, const float* lse,
-                                                          const float* delta, T* dqkv, int N, int H, float scale) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const T* qkv, const T* o, const T* dout, const float* lse,
+                                                          float* delta, T* dqkv, int N, int H, float scale) {
     constexpr int NF = AT<T>::NF, ROWB = AT<T>::ROWB;
     typedef typename Mma<T>::Frag Frag;
     __shared__ __attribute__((aligned(16))) char sK[64 * ROWB];
@@ -467,21 +452,30 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const T* qkv, const
     const char* vb = base + (long)(2 * H + h) * HD * sizeof(T);
     const long ldo_b = (long)H * HD * sizeof(T);
     const char* dob = (const char*)dout + (long)b * N * ldo_b + (long)h * HD * sizeof(T);
+    const char* ob = (const char*)o + (long)b * N * ldo_b + (long)h * HD * sizeof(T);
 
+    // delta = rowsum(dO * O) is taken here, from the dO fragments this wave loads anyway (+ the matching O fragments), and
+    // written for the dK/dV kernel that runs next on the stream — it used to be its own pass over O and dO.
     Frag qf[2][NF], dof[2][NF];
     float lq[2], dl[2];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         const int q = q0 + qt * 16 + c;
         const bool ok = q < N;
+        float dsum = 0.f;
 #pragma unroll
         for (int u = 0; u < NF; ++u) {
             Frag z = {};
             qf[qt][u] = ok ? load_nfrag<T>(qb + (long)q * ld_b, u, g) : z;
             dof[qt][u] = ok ? load_nfrag<T>(dob + (long)q * ldo_b, u, g) : z;
+            const Frag of_ = ok ? load_nfrag<T>(ob + (long)q * ldo_b, u, g) : z;
+            dsum += frag_dot(dof[qt][u], of_);
         }
+        dsum += __shfl_xor(dsum, 16, 64);      // the four lane groups g hold the four 16-byte pieces of each K-chunk
+        dsum += __shfl_xor(dsum, 32, 64);
         lq[qt] = ok ? lse[((long)b * H + h) * N + q] * 1.4426950408889634f : 0.f;   // log2 units
-        dl[qt] = ok ? delta[((long)b * H + h) * N + q] : 0.f;
+        dl[qt] = dsum;
+        if (ok && g == 0) delta[((long)b * H + h) * N + q] = dsum;
     }
     f32x4 dq[4][2];
 #pragma unroll
@@ -888,15 +882,13 @@ extern "C" int gd_attention_bwd(const void* qkv, const void* o, const void* dout
     GD_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)dout & 15) == 0 && ((uintptr_t)dqkv & 15) == 0,
                "gd_attention_bwd: pointers must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    const long total = (long)B * N * H;
+    GD_REQUIRE(((uintptr_t)o & 15) == 0, "gd_attention_bwd: o must be 16-byte aligned");
     dim3 grid(gd_cdiv(N, 128), H, B);
     if (dtype == GD_BF16) {
-        hipLaunchKernelGGL(attn_delta_kernel<bf16>, dim3(gd_cdiv(total * 16, 256)), dim3(256), 0, s, (const bf16*)o, (const bf16*)dout, delta_ws, N, H, total);
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)qkv, (const bf16*)dout, lse, delta_ws, (bf16*)dqkv, N, H, scale);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)qkv, (const bf16*)o, (const bf16*)dout, lse, delta_ws, (bf16*)dqkv, N, H, scale);
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<bf16, 8>), dim3(gd_cdiv(N, 256), H, B), dim3(512), 0, s, (const bf16*)qkv, (const bf16*)dout, lse, delta_ws, (bf16*)dqkv, N, H, scale);
     } else {
-        hipLaunchKernelGGL(attn_delta_kernel<float>, dim3(gd_cdiv(total * 16, 256)), dim3(256), 0, s, (const float*)o, (const float*)dout, delta_ws, N, H, total);
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<float>, grid, dim3(256), 0, s, (const float*)qkv, (const float*)dout, lse, delta_ws, (float*)dqkv, N, H, scale);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<float>, grid, dim3(256), 0, s, (const float*)qkv, (const float*)o, (const float*)dout, lse, delta_ws, (float*)dqkv, N, H, scale);
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<float, 8>), dim3(gd_cdiv(N, 256), H, B), dim3(512), 0, s, (const float*)qkv, (const float*)dout, lse, delta_ws, (float*)dqkv, N, H, scale);
     }
     GD_LAUNCH_OK();
