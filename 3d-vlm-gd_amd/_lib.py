@@ -44,7 +44,7 @@ SIGNATURES = {
                                  c_int, c_float, c_float, c_int, c_int, c_int, c_int, c_void_p]),
     "gd_tap_mean_fwd": (c_int, [ctypes.POINTER(c_void_p), c_int, c_long, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                 c_void_p]),
-    "gd_tap_mean_bwd": (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, c_void_p, c_int, c_int, c_int, c_int,
+    "gd_tap_mean_bwd": (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_int,
                                 c_void_p]),
     "gd_kp_depth": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "gd_patch_mask": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),

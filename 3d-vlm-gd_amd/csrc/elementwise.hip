@@ -46,13 +46,28 @@ __global__ __launch_bounds__(256) void patch_im2col_kernel(const float* img, T* 
 template <typename T>
 __global__ __launch_bounds__(256) void assemble_tokens_kernel(const T* patch, const float* cls, const float* pos,
                                                               T* out, int B, int Np, int D) {
-    const long total = (long)B * (Np + 1) * D;
+    constexpr int V = 16 / sizeof(T);           // 16 bytes of tokens per thread (D is a multiple of 8)
+    const int dv = D / V;
+    const long total = (long)B * (Np + 1) * dv;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const int d = idx % D;
-        const int n = (idx / D) % (Np + 1);
-        const long b = idx / ((long)D * (Np + 1));
-        const float v = n == 0 ? cls[d] : to_f32<T>(patch[(b * Np + (n - 1)) * D + d]);
-        out[idx] = from_f32<T>(v + pos[(long)n * D + d]);
+        const int d = (int)(idx % dv) * V;
+        const int n = (idx / dv) % (Np + 1);
+        const long b = idx / ((long)dv * (Np + 1));
+        float v[V];
+        if (n == 0) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) v[k] = cls[d + k];
+        } else {
+            const uint4 raw = *(const uint4*)(patch + (b * Np + (n - 1)) * D + d);
+            const T* e = (const T*)&raw;
+#pragma unroll
+            for (int k = 0; k < V; ++k) v[k] = to_f32<T>(e[k]);
+        }
+        uint4 o;
+        T* oe = (T*)&o;
+#pragma unroll
+        for (int k = 0; k < V; ++k) oe[k] = from_f32<T>(v[k] + pos[(long)n * D + d + k]);
+        *(uint4*)(out + (b * (Np + 1) + n) * D + d) = o;
     }
 }
 
@@ -281,27 +296,46 @@ __global__ __launch_bounds__(256) void cast_kernel(const TI* in, TO* out, long n
 // get_feature_cost (src/finetune_timm_mast3r.py:321-337, src/finetune_timm_vggt.py:342-353): mean of the tap
 // outputs with the prefix token dropped -> contiguous [B, hw, D];  backward scatters dout/ngrid back.
 struct TapMeanParams { const void* grid[4]; void* dgrid[4]; int ngrid; long bstride; int prefix; };
+// 16 bytes per thread (8 bf16 / 4 f32): D is a multiple of the vector width, so a vector never straddles the prefix rows
 template <typename T>
 __global__ __launch_bounds__(256) void tap_mean_fwd_kernel(TapMeanParams p, T* out, int B, int hw, int D) {
-    const long total = (long)B * hw * D;
+    constexpr int V = 16 / sizeof(T);
+    const long rowv = (long)hw * D / V, total = (long)B * rowv;
     const float inv = 1.0f / (float)p.ngrid;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const long b = idx / ((long)hw * D), rem = idx % ((long)hw * D);
+        const long b = idx / rowv, rem = (idx - b * rowv) * V;
         const long src = b * p.bstride + (long)p.prefix * D + rem;
-        float acc = 0.f;
-        for (int t = 0; t < p.ngrid; ++t) acc += to_f32<T>(((const T*)p.grid[t])[src]);
-        out[idx] = from_f32<T>(acc * inv);
+        float acc[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc[k] = 0.f;
+        for (int t = 0; t < p.ngrid; ++t) {
+            const uint4 raw = *(const uint4*)((const T*)p.grid[t] + src);
+            const T* e = (const T*)&raw;
+#pragma unroll
+            for (int k = 0; k < V; ++k) acc[k] += to_f32<T>(e[k]);
+        }
+        uint4 o;
+        T* oe = (T*)&o;
+#pragma unroll
+        for (int k = 0; k < V; ++k) oe[k] = from_f32<T>(acc[k] * inv);
+        *(uint4*)(out + b * (long)hw * D + rem) = o;
     }
 }
 template <typename T>
-__global__ __launch_bounds__(256) void tap_mean_bwd_kernel(TapMeanParams p, const T* dout, int B, int hw, int D) {
-    const long total = (long)B * p.bstride;   // bstride = (prefix + hw) * D
-    const float inv = 1.0f / (float)p.ngrid;
+__global__ __launch_bounds__(256) void tap_mean_bwd_kernel(TapMeanParams p, const T* dout, int B, int hw, int D, float scale) {
+    constexpr int V = 16 / sizeof(T);
+    const long rowv = p.bstride / V, total = (long)B * rowv;   // bstride = (prefix + hw) * D
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const long b = idx / p.bstride, rem = idx % p.bstride;
-        float v = 0.f;
-        if (rem >= (long)p.prefix * D) v = to_f32<T>(dout[b * (long)hw * D + rem - (long)p.prefix * D]) * inv;
-        for (int t = 0; t < p.ngrid; ++t) ((T*)p.dgrid[t])[idx] = from_f32<T>(v);
+        const long b = idx / rowv, rem = (idx - b * rowv) * V;
+        uint4 o = {0u, 0u, 0u, 0u};
+        if (rem >= (long)p.prefix * D) {
+            const uint4 raw = *(const uint4*)(dout + b * (long)hw * D + rem - (long)p.prefix * D);
+            const T* e = (const T*)&raw;
+            T* oe = (T*)&o;
+#pragma unroll
+            for (int k = 0; k < V; ++k) oe[k] = from_f32<T>(to_f32<T>(e[k]) * scale);
+        }
+        for (int t = 0; t < p.ngrid; ++t) *(uint4*)((T*)p.dgrid[t] + b * p.bstride + rem) = o;
     }
 }
 
@@ -322,8 +356,9 @@ extern "C" int gd_patch_im2col(const float* img, void* col, int B, int h, int w,
 
 extern "C" int gd_assemble_tokens(const void* patch, const float* cls, const float* pos, void* out, int B, int Np,
                                   int D, int dtype, void* stream) {
-    GD_REQUIRE(B > 0 && Np > 0 && D > 0, "gd_assemble_tokens: bad shape");
-    const long total = (long)B * (Np + 1) * D;
+    GD_REQUIRE(B > 0 && Np > 0 && D > 0 && D % 8 == 0, "gd_assemble_tokens: bad shape (D must be a multiple of 8)");
+    GD_REQUIRE(((uintptr_t)patch & 15) == 0 && ((uintptr_t)out & 15) == 0, "gd_assemble_tokens: patch and out must be 16-byte aligned");
+    const long total = (long)B * (Np + 1) * D / (16 / gd_dtype_size(dtype));
     if (dtype == GD_BF16)
         hipLaunchKernelGGL(assemble_tokens_kernel<bf16>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, (const bf16*)patch, cls, pos, (bf16*)out, B, Np, D);
     else
@@ -458,7 +493,8 @@ extern "C" int gd_tap_mean_fwd(const void* const* grids, int ngrid, long bstride
     TapMeanParams p = {};
     for (int t = 0; t < ngrid; ++t) p.grid[t] = grids[t];
     p.ngrid = ngrid; p.bstride = bstride; p.prefix = prefix;
-    const long total = (long)B * hw * D;
+    GD_REQUIRE(D % 8 == 0, "gd_tap_mean_fwd: D must be a multiple of 8");
+    const long total = (long)B * hw * D / (dtype == GD_BF16 ? 8 : 4);
     if (dtype == GD_BF16) hipLaunchKernelGGL(tap_mean_fwd_kernel<bf16>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, p, (bf16*)out, B, hw, D);
     else hipLaunchKernelGGL(tap_mean_fwd_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, p, (float*)out, B, hw, D);
     GD_LAUNCH_OK();
@@ -466,14 +502,14 @@ extern "C" int gd_tap_mean_fwd(const void* const* grids, int ngrid, long bstride
 }
 
 extern "C" int gd_tap_mean_bwd(void* const* dgrids, int ngrid, int prefix, const void* dout, int B, int hw, int D,
-                               int dtype, void* stream) {
-    GD_REQUIRE(ngrid >= 1 && ngrid <= 4 && B > 0 && hw > 0 && D > 0, "gd_tap_mean_bwd: bad arguments");
+                               float scale, int dtype, void* stream) {
+    GD_REQUIRE(ngrid >= 1 && ngrid <= 4 && B > 0 && hw > 0 && D > 0 && D % 8 == 0, "gd_tap_mean_bwd: bad arguments");
     TapMeanParams p = {};
     for (int t = 0; t < ngrid; ++t) p.dgrid[t] = dgrids[t];
     p.ngrid = ngrid; p.bstride = (long)(prefix + hw) * D; p.prefix = prefix;
-    const long total = (long)B * p.bstride;
-    if (dtype == GD_BF16) hipLaunchKernelGGL(tap_mean_bwd_kernel<bf16>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, p, (const bf16*)dout, B, hw, D);
-    else hipLaunchKernelGGL(tap_mean_bwd_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, p, (const float*)dout, B, hw, D);
+    const long total = (long)B * p.bstride / (dtype == GD_BF16 ? 8 : 4);
+    if (dtype == GD_BF16) hipLaunchKernelGGL(tap_mean_bwd_kernel<bf16>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, p, (const bf16*)dout, B, hw, D, scale);
+    else hipLaunchKernelGGL(tap_mean_bwd_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, p, (const float*)dout, B, hw, D, scale);
     GD_LAUNCH_OK();
     return 0;
 }

@@ -372,8 +372,7 @@ class _TapMean(torch.autograd.Function):
         dout = dout.contiguous()
         # the ng gradients are identical (dout / ng): one buffer, handed to every grid
         dg = torch.empty(B, Nt, D, dtype=dout.dtype, device=dout.device)
-        scaled = dout * (1.0 / ng)
-        check(lib().gd_tap_mean_bwd(_ptr_array([dg]), 1, prefix, ptr(scaled), B, Nt - prefix, D, dtype_code(dout),
+        check(lib().gd_tap_mean_bwd(_ptr_array([dg]), 1, prefix, ptr(dout), B, Nt - prefix, D, 1.0 / ng, dtype_code(dout),
                                     stream()), "gd_tap_mean_bwd")
         return (None,) + (dg,) * ng
 

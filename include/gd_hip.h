@@ -112,11 +112,13 @@ int gd_kp_depth(const float* depth, const float* kp, float* out, int B, int Nk, 
 int gd_patch_mask(const float* kp, unsigned char* mask, int B, int Nk, int H, int W, int P, void* stream);
 
 /* get_feature_cost tail (src/finetune_timm_mast3r.py:321-337, src/finetune_timm_vggt.py:342-353): mean of 1..4 tap
- * outputs [B, prefix+hw, D] with the prefix token dropped -> [B,hw,D]; backward fills dgrids [B, prefix+hw, D]. */
+ * outputs [B, prefix+hw, D] with the prefix token dropped -> [B,hw,D]; backward fills each of the ngrid buffers
+ * dgrids[t] [B, prefix+hw, D] with scale * dout (prefix rows zero) — scale = 1 / (number of taps averaged); the taps all
+ * receive the same gradient, so one buffer (ngrid = 1) can be handed to every tap.  D must be a multiple of 8. */
 int gd_tap_mean_fwd(const void* const* grids, int ngrid, long bstride, int prefix, void* out, int B, int hw, int D,
                     int dtype, void* stream);
-int gd_tap_mean_bwd(void* const* dgrids, int ngrid, int prefix, const void* dout, int B, int hw, int D, int dtype,
-                    void* stream);
+int gd_tap_mean_bwd(void* const* dgrids, int ngrid, int prefix, const void* dout, int B, int hw, int D, float scale,
+                    int dtype, void* stream);
 
 /* calculate_matching_loss after the descriptor GEMM (src/finetune_timm_vggt.py:543-572 variant 0,
  * src/finetune_timm_mast3r.py:560-589 variant 1): sim [P,Nmax,Nmax] -> loss [P] and dsim = dloss/dsim (fused). */
