@@ -8,37 +8,43 @@
 // antialias; src/finetune_timm_vggt.py:270,340) -> Normalize(mean,std) (:153) -> im2col for the PxP/stride-P
 // patch conv.  col[(b,gy,gx), c*P*P + py*P + px], zero padded to Kp columns.
 // ---------------------------------------------------------------------------------------------------
-template <typename T>
+// PC: compile-time patch size (14 / 16: the index arithmetic is ~10 integer divisions per element, by constants they
+// become multiplies), 0 = run-time P.
+template <typename T, int PC>
 __global__ __launch_bounds__(256) void patch_im2col_kernel(const float* img, T* col, int B, int h, int w, int H,
-                                                           int W, int P, int Kp, float m0, float m1, float m2,
+                                                           int W, int Prt, int Kp, float m0, float m1, float m2,
                                                            float s0, float s1, float s2) {
+    const int P = PC ? PC : Prt;
     const int gw = W / P, gh = H / P;
-    const long total = (long)B * gh * gw * Kp;
+    const long rows = (long)B * gh * gw;
     const float sy = (float)h / (float)H, sx = (float)w / (float)W;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const int k = idx % Kp;
-        const long row = idx / Kp;
-        float v = 0.f;
-        if (k < 3 * P * P) {
-            const int c = k / (P * P), py = (k / P) % P, px = k % P;
-            const int gx = row % gw, gy = (row / gw) % gh, b = row / ((long)gw * gh);
-            const int Y = gy * P + py, X = gx * P + px;
-            const float* src = img + ((long)b * 3 + c) * h * w;
-            float pix;
-            if (h == H && w == W) {
-                pix = src[(long)Y * w + X];
-            } else {
-                float fy = fmaxf(((float)Y + 0.5f) * sy - 0.5f, 0.f), fx = fmaxf(((float)X + 0.5f) * sx - 0.5f, 0.f);
-                const int y0 = min((int)fy, h - 1), x0 = min((int)fx, w - 1);
-                const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
-                const float wy = fy - (float)y0, wx = fx - (float)x0;
-                pix = (1.f - wy) * ((1.f - wx) * src[(long)y0 * w + x0] + wx * src[(long)y0 * w + x1]) +
-                      wy * ((1.f - wx) * src[(long)y1 * w + x0] + wx * src[(long)y1 * w + x1]);
+    const bool same = h == H && w == W;
+    // one block per output row (patch): the patch coordinates are wave-uniform, a thread only splits its column index
+    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int gx = row % gw, gy = (row / gw) % gh;
+        const long b = row / ((long)gw * gh);
+        for (int k = threadIdx.x; k < Kp; k += 256) {
+            float v = 0.f;
+            if (k < 3 * P * P) {
+                const int c = k / (P * P), py = (k / P) % P, px = k % P;
+                const int Y = gy * P + py, X = gx * P + px;
+                const float* src = img + (b * 3 + c) * h * w;
+                float pix;
+                if (same) {
+                    pix = src[(long)Y * w + X];
+                } else {
+                    float fy = fmaxf(((float)Y + 0.5f) * sy - 0.5f, 0.f), fx = fmaxf(((float)X + 0.5f) * sx - 0.5f, 0.f);
+                    const int y0 = min((int)fy, h - 1), x0 = min((int)fx, w - 1);
+                    const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+                    const float wy = fy - (float)y0, wx = fx - (float)x0;
+                    pix = (1.f - wy) * ((1.f - wx) * src[(long)y0 * w + x0] + wx * src[(long)y0 * w + x1]) +
+                          wy * ((1.f - wx) * src[(long)y1 * w + x0] + wx * src[(long)y1 * w + x1]);
+                }
+                const float mu = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+                v = (pix - mu) / sd;
             }
-            const float mu = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
-            v = (pix - mu) / sd;
+            col[row * Kp + k] = from_f32<T>(v);
         }
-        col[idx] = from_f32<T>(v);
     }
 }
 
@@ -345,11 +351,11 @@ static inline int ew_blocks(long total) { long b = (total + 255) / 256; return (
 extern "C" int gd_patch_im2col(const float* img, void* col, int B, int h, int w, int H, int W, int P, int Kp,
                                const float* mean3, const float* std3, int dtype, void* stream) {
     GD_REQUIRE(B > 0 && H % P == 0 && W % P == 0 && Kp >= 3 * P * P, "gd_patch_im2col: bad geometry H=%d W=%d P=%d Kp=%d", H, W, P, Kp);
-    const long total = (long)B * (H / P) * (W / P) * Kp;
-    if (dtype == GD_BF16)
-        hipLaunchKernelGGL(patch_im2col_kernel<bf16>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, img, (bf16*)col, B, h, w, H, W, P, Kp, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
-    else
-        hipLaunchKernelGGL(patch_im2col_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, img, (float*)col, B, h, w, H, W, P, Kp, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+    const long rows = (long)B * (H / P) * (W / P);
+#define GD_PI2C(TT, PCV) hipLaunchKernelGGL((patch_im2col_kernel<TT, PCV>), dim3((unsigned)(rows < 65536 * 4 ? rows : 65536 * 4)), dim3(256), 0, (hipStream_t)stream, img, (TT*)col, B, h, w, H, W, P, Kp, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2])
+    if (dtype == GD_BF16) { if (P == 14) GD_PI2C(bf16, 14); else if (P == 16) GD_PI2C(bf16, 16); else GD_PI2C(bf16, 0); }
+    else { if (P == 14) GD_PI2C(float, 14); else if (P == 16) GD_PI2C(float, 16); else GD_PI2C(float, 0); }
+#undef GD_PI2C
     GD_LAUNCH_OK();
     return 0;
 }
