@@ -32,6 +32,7 @@ struct GemmNtParams {
     int deep_ring;                   // 256x256 config: 4-slot ring of 64-byte K stages with counted waits (GD_GEMM_DEEP=1; measured 10 % SLOWER than the 2-deep ring: twice the barriers)
     unsigned long long* probe;       // gd_gemm_phase_probe accumulators (device), or null
     int stagger;                     // persistent kernel experiment (GD_GEMM_STAGGER): start-up skew between CUs, units of ~0.85 us
+    int k_rot;                       // persistent kernel: per-tile rotation of the K-step order, krot = (tn * k_rot + tm) % nk (GD_GEMM_KROT, default 1, 0 = off: +1.3 % on the step, in-step A/B 525.6 vs 518.8 pairs/s)
     int tile_order;                  // experiment knob (GD_GEMM_ORDER): 0 XCD chunks, tn fastest; 1 no remap; 2 XCD chunks, 4-wide tn bands
 };
 
@@ -750,6 +751,7 @@ extern "C" int gd_gemm_nt(const void* A, const void* W, void* C, int M, int N, i
     { static int dr = -1; if (dr < 0) { const char* e = getenv("GD_GEMM_DEEP"); dr = e ? atoi(e) : 0; } p.deep_ring = dr; }
     p.probe = g_probe;
     { static int sg = -1; if (sg < 0) { const char* e = getenv("GD_GEMM_STAGGER"); sg = e ? atoi(e) : 0; } p.stagger = sg; }
+    { static int kr = -1; if (kr < 0) { const char* e = getenv("GD_GEMM_KROT"); kr = e ? atoi(e) : 1; } p.k_rot = kr; }
     { static int ord = -1; if (ord < 0) { const char* e = getenv("GD_GEMM_ORDER"); ord = e ? atoi(e) : 0; } p.tile_order = ord; }
     const bool big = dma && N >= 256 && M >= 1024 && !gd_force_small_tiles();
     dim3 gridb(gd_cdiv(M, 256) * gd_cdiv(N, 256), batch);

@@ -144,7 +144,12 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
     const char* abase_t;
     const char* wbase_t;
     unsigned aoff[APW], woff[BPW];
+    // K-steps are walked in a per-tile ROTATED order (p.k_rot): the tiles that share an A row panel (same tm) or a W panel
+    // (same tn) run at the same time on one XCD; in lockstep they all miss the L2 on the same 128-byte K slice at the same
+    // moment, rotated one tile fetches a slice and the others hit it.
+    int krot = 0;
     auto set_tile = [&](int tm, int tn) {
+        krot = p.k_rot ? (tn * p.k_rot + tm) % nk : 0;
         abase_t = Ab + (long)tm * BM * lda_b;
         wbase_t = Wb + (long)tn * BN * ldw_b;
         const int av = min(BM, p.M - tm * BM) - 1, wv = min(BN, p.N - tn * BN) - 1;
@@ -159,7 +164,8 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
             woff[i] = (unsigned)(min(nperm64(row), wv) * (int)ldw_b + ((lane & 7) ^ swz(row)) * 16);
         }
     };
-    auto issue = [&](int kt, int buf) {
+    auto issue = [&](int kt0, int buf) {
+        const int kt = kt0 + krot >= nk ? kt0 + krot - nk : kt0 + krot;
         char* sA = smem + buf * STAGE;
         char* sB = sA + ABYTES;
 #pragma unroll
