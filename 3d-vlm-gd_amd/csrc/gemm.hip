@@ -507,9 +507,13 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmTnParams p) {
     __shared__ __attribute__((aligned(16))) char sX[64 * ROWB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wy = wave >> 1, wx = wave & 1;
-    const int tiles_k = (p.K + 127) / 128;
-    const int tn = blockIdx.x / tiles_k, tk = blockIdx.x % tiles_k;
-    const int m_begin = blockIdx.y * p.mchunk, m_end = min(p.M, m_begin + p.mchunk);
+    const int tiles_k = (p.K + 127) / 128, tiles_n = (p.N + 127) / 128;
+    // the (tn, tk) blocks of one M-chunk re-read its Y column blocks (tiles_k times) and X column blocks (tiles_n times):
+    // each XCD gets a contiguous run of tiles, tn fastest, so an X block is fetched by one L2 and the Y blocks by few
+    const int t = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+    const int tile = t % (int)gridDim.x, mc = t / (int)gridDim.x;
+    const int tn = tile % tiles_n, tk = tile / tiles_n;
+    const int m_begin = mc * p.mchunk, m_end = min(p.M, m_begin + p.mchunk);
     const bf16* Y = (const bf16*)p.Y + (long)blockIdx.z * p.sY;
     const bf16* X = (const bf16*)p.X + (long)blockIdx.z * p.sX;
     float* G = p.G + (long)blockIdx.z * p.sG;
