@@ -145,6 +145,15 @@ def main():
                                "frac": round(ach / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
                                "launches": n, "avg_launch_us": round(ms / max(n, 1) * 1e3, 2),
                                "share_of_step": round(ms / (dt * 1e3), 3)}
+            # memory-side bytes per launch: PMC counters cannot be read from inside the timed run, so this is the committed
+            # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE measurement of this same command (profiles/README.md), default workload only
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemm_traffic.json")
+            if (os.path.exists(pmc) and args.dtype == "bf16" and args.backbone == "vit_base" and P == 32
+                    and args.geometry == "shared" and args.variant == "mast3r"):
+                with open(pmc) as fh:
+                    t = json.load(fh)
+                out["roofline"]["traffic"] = round(t["hbm_side_mb_per_launch"] * 1e6)
+                out["roofline"]["traffic_source"] = "profiles/r01_pmc_gemm_traffic.json (2 x FETCH_SIZE + WRITE_SIZE per persistent-kernel launch, separate --pmc passes)"
             if args.gemm_shapes:
                 for k, (cnt, sms, tf) in sorted(prof.by_shape().items(), key=lambda kv: -kv[1][1]):
                     print(f"gemm_nt {str(k):58s} x{cnt:4d} {sms / args.steps:8.3f} ms/step {tf:7.1f} TF/s", file=sys.stderr)
