@@ -17,11 +17,15 @@ class GemmProfiler:
     def __init__(self):
         self.records = []
 
-    def totals(self):
+    def totals(self, keep=None):
+        """(FLOPs, ms, launches) over the recorded launches; keep(tag) with tag = (M, N, K, B, epilogue, out dtype, operand
+        dtype) selects a subset (e.g. the launches that run on the persistent MFMA kernel, leaving out the HBM-bound N <= 8
+        streaming launches)."""
         torch.cuda.synchronize()
-        flops = sum(r[2] for r in self.records)
-        ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
-        return flops, ms, len(self.records)
+        recs = [r for r in self.records if keep is None or keep(r[3])]
+        flops = sum(r[2] for r in recs)
+        ms = sum(r[0].elapsed_time(r[1]) for r in recs)
+        return flops, ms, len(recs)
 
     def by_shape(self):
         """{(M, N, K, B, epilogue tag): (launches, ms, TFLOP/s)} — where the step's GEMM time goes."""
@@ -100,7 +104,7 @@ def gemm_nt(a, w, out=None, *, out_dtype=None, alpha=1.0, bias=None, lora_t=None
     if _PROFILER is not None:
         e1.record()
         tag = "".join(c for c, t in (("b", bias), ("l", lora_t), ("p", preact), ("d", dact_src), ("r", residual)) if t is not None)
-        _PROFILER.records.append((e0, e1, 2.0 * M * N * K * B, (M, N, K, B, f"{tag}a{act}{'+' if accumulate else ''}", str(out.dtype)[6:])))
+        _PROFILER.records.append((e0, e1, 2.0 * M * N * K * B, (M, N, K, B, f"{tag}a{act}{'+' if accumulate else ''}", str(out.dtype)[6:], str(a.dtype)[6:])))
     check(rc, "gd_gemm_nt")
     return out
 
