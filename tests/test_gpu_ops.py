@@ -286,3 +286,35 @@ def test_smooth_ap_me_variant_golden_and_ragged():
         assert float(ar.grad.abs().max()) > 1e-4      # the comparison below is informative
         assert rel_err(ag.grad[q, :n], ar.grad[0]) < 2e-3 and rel_err(bg.grad[q, :n], br.grad[0]) < 2e-3, q
         assert float(ag.grad[q, n:].abs().max()) == 0.0 if n < N else True
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+def test_tap_fn_and_split_pairs_gradients(dtype, tol):
+    """vit._TapFn (a tapped block output handed to three consumers, their gradients folded into one LayerNorm-backward
+    launch through dres / dres2) and ops.split_pairs (one-cat backward) against plain autograd on the same graph."""
+    from gd_amd import ops
+    from gd_amd.vit import _TapFn
+    B, Nt, D = 4, 37, 128
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(B, Nt, D, device="cuda", generator=g).to(dtype).requires_grad_(True)
+    w = (1 + 0.1 * torch.randn(D, device="cuda", generator=g)).requires_grad_(False)
+    b = (0.1 * torch.randn(D, device="cuda", generator=g)).requires_grad_(False)
+    c1, c2, c3 = (torch.randn(B, Nt, D, device="cuda", generator=g).to(dtype) for _ in range(3))
+    nxt, raw, normed = _TapFn.apply(x, w, b, 1e-6)
+    assert torch.equal(nxt, x) and torch.equal(raw, x)
+    a1, a2 = ops.split_pairs(raw, B // 2)
+    loss = (nxt.float() * c1.float()).sum() + (normed.float() * c2.float()).sum() + \
+           (a1.float() * c3[:B // 2].float()).sum() + 2.0 * (a2.float() * c3[B // 2:].float()).sum()
+    loss.backward()
+    got = x.grad.double()
+    xr = x.detach().double().requires_grad_(True)
+    nr = torch.nn.functional.layer_norm(xr, (D,), w.double(), b.double(), 1e-6)
+    ref = (xr * c1.double()).sum() + (nr * c2.double()).sum() + (xr[:B // 2] * c3[:B // 2].double()).sum() + \
+          2.0 * (xr[B // 2:] * c3[B // 2:].double()).sum()
+    ref.backward()
+    assert rel_err(normed, nr.detach()) < tol and rel_err(got, xr.grad) < tol
+    # only some consumers used: the missing gradients are None inside the backward
+    x2 = x.detach().clone().requires_grad_(True)
+    n2, r2, m2 = _TapFn.apply(x2, w, b, 1e-6)
+    (n2.float() * c1.float()).sum().backward()
+    assert rel_err(x2.grad, c1.double()) < tol
