@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* qkv, T* o, fl
 #define ADS_R128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
 #define ADS_TR64(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
 typedef __attribute__((ext_vector_type(2))) unsigned a_u32x2;
-__global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const bf16* qkv, bf16* o, float* lse, int N, int H, float scale) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const bf16* qkv, bf16* o, float* lse, int N, int H, float scale, int rot_on) {
     typedef bf16x8 Frag;
     constexpr int TILE = 64 * 128;                       // one K or V tile: 64 rows x 128 B
     __shared__ __attribute__((aligned(16))) char smem[6 * TILE];   // K slots 0..2 | V slots 0..2
@@ -340,17 +340,23 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const bf16* qkv, b
         for (int j = 0; j < 2; ++j) oacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m[2] = {-1e30f, -1e30f}, l[2] = {0.f, 0.f};   // m in log2 units
     const float c2 = scale * 1.4426950408889634f;
-    const int ntile = (N + 63) / 64;
-    issue(0, 0);
-    if (ntile > 1) issue(64, 1);
+    const int ntile = (N + 63) / 64, nfull = N / 64;
+    // The x-blocks of an (image, head) start together on one XCD and sweep the same K / V tiles at the same pace: in
+    // lockstep they all ask one L2 channel for the same lines at the same moment.  Softmax accumulation does not care about
+    // the key order, so block xb starts at full tile (2 xb) mod nfull and wraps; the partial tail tile stays last (its
+    // mask is the compile-time variant of the tile body).
+    const int rot = (nfull > 0 && rot_on) ? (2 * xb_) % nfull : 0;
+    auto pk0 = [&](int t) { return (t < nfull ? (t + rot >= nfull ? t + rot - nfull : t + rot) : t) * 64; };
+    issue(pk0(0), 0);
+    if (ntile > 1) issue(pk0(1), 1);
     auto key_tile = [&](int t, auto tail_tag) {
         constexpr bool tail = decltype(tail_tag)::value;
-        const int k0 = t * 64, slot = t % 3;
+        const int k0 = pk0(t), slot = t % 3;
         if (t + 1 < ntile) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // tile t landed; tile t+1 may still fly
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();            // everyone's pieces of tile t landed; everyone is done with tile t-1's slot
         asm volatile("" ::: "memory");
-        if (t + 2 < ntile) issue(k0 + 128, (t + 2) % 3);
+        if (t + 2 < ntile) issue(pk0(t + 2), (t + 2) % 3);
         if (q0 >= N) return;      // (lambda) a wave whose 32 queries are all past N only moves its DMA pieces
         const unsigned kbase = lds0 + slot * TILE, vbase = lds0 + (3 + slot) * TILE;
         f32x4 kr[4][2];
@@ -503,17 +509,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const T* qkv, const
         for (int j = 0; j < 2; ++j) dq[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float c2 = scale * 1.4426950408889634f;
 
+    // (key tiles in plain order: a per-block rotated order, which helps the forward kernel a little, measured 4 % SLOWER here —
+    //  the blocks of an (image, head) trail each other through the L2 and the rotation takes that away)
+    const int ntile = (N + 63) / 64;
+    auto pk0 = [&](int t) { return t * 64; };
     TileRegs<T> rk, rv;
-    tile_load<T>(rk, kb, ld_b, 0, N);
-    tile_load<T>(rv, vb, ld_b, 0, N);
-    for (int k0 = 0; k0 < N; k0 += 64) {
+    tile_load<T>(rk, kb, ld_b, pk0(0), N);
+    tile_load<T>(rv, vb, ld_b, pk0(0), N);
+    for (int t = 0; t < ntile; ++t) {
         __syncthreads();
         tile_store<T, true, TOp<T>::kNeedT>(rk, sK, sKt);
         tile_store<T, true, false>(rv, sV, nullptr);
         __syncthreads();
-        if (k0 + 64 < N) {
-            tile_load<T>(rk, kb, ld_b, k0 + 64, N);
-            tile_load<T>(rv, vb, ld_b, k0 + 64, N);
+        if (t + 1 < ntile) {
+            tile_load<T>(rk, kb, ld_b, pk0(t + 1), N);
+            tile_load<T>(rv, vb, ld_b, pk0(t + 1), N);
         }
         if (q0 >= N) continue;   // a wave whose 32 queries are all past N only helps staging
         f32x4 ds[2][4];
@@ -607,27 +617,30 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const T* qkv, con
 #pragma unroll
         for (int j = 0; j < 2; ++j) { dk[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
+    const int ntile = (N + 63) / 64;
+    auto pq0 = [&](int t) { return t * 64; };
     TileRegs<T, NT> rq, rd;
-    tile_load<T, NT>(rq, qb, ld_b, 0, N);
-    tile_load<T, NT>(rd, dob, ldo_b, 0, N);
+    tile_load<T, NT>(rq, qb, ld_b, pq0(0), N);
+    tile_load<T, NT>(rd, dob, ldo_b, pq0(0), N);
     float rl = 0.f, rdl = 0.f;   // next tile's lse / delta rows, prefetched with the tile
     // queries >= N: lse = +1e30 makes p = 2^(0 - 1e30) = 0 (their Q / dO rows are staged as zeros) — no mask in the loop
     const float LSE_PAD = 1e30f;
     if (threadIdx.x < 64) {
-        rl = threadIdx.x < N ? lse[((long)b * H + h) * N + threadIdx.x] : LSE_PAD;
-        rdl = threadIdx.x < N ? delta[((long)b * H + h) * N + threadIdx.x] : 0.f;
+        const int q = pq0(0) + threadIdx.x;
+        rl = q < N ? lse[((long)b * H + h) * N + q] : LSE_PAD;
+        rdl = q < N ? delta[((long)b * H + h) * N + q] : 0.f;
     }
-    for (int q0 = 0; q0 < N; q0 += 64) {
+    for (int t = 0; t < ntile; ++t) {
         __syncthreads();
         tile_store<T, true, TOp<T>::kNeedT, NT>(rq, sQ, sQt);
         tile_store<T, true, TOp<T>::kNeedT, NT>(rd, sD, sDt);
-        if (q0 + 64 < N) {
-            tile_load<T, NT>(rq, qb, ld_b, q0 + 64, N);
-            tile_load<T, NT>(rd, dob, ldo_b, q0 + 64, N);
+        if (t + 1 < ntile) {
+            tile_load<T, NT>(rq, qb, ld_b, pq0(t + 1), N);
+            tile_load<T, NT>(rd, dob, ldo_b, pq0(t + 1), N);
         }
         if (threadIdx.x < 64) { sL[threadIdx.x] = rl * 1.4426950408889634f; sDl[threadIdx.x] = rdl; }   // lse in log2 units
-        if (q0 + 64 < N && threadIdx.x < 64) {
-            const int q = q0 + 64 + threadIdx.x;
+        if (t + 1 < ntile && threadIdx.x < 64) {
+            const int q = pq0(t + 1) + threadIdx.x;
             rl = q < N ? lse[((long)b * H + h) * N + q] : LSE_PAD;
             rdl = q < N ? delta[((long)b * H + h) * N + q] : 0.f;
         }
@@ -885,7 +898,8 @@ extern "C" int gd_attention_fwd(const void* qkv, void* o, float* lse, int B, int
     static int dma = -1;   // GD_ATTN_DMA=0: the register-staged forward kernel (A/B testing)
     if (dma < 0) { const char* e = getenv("GD_ATTN_DMA"); dma = e ? atoi(e) : 1; }
     if (dtype == GD_BF16 && dma)
-        hipLaunchKernelGGL(attn_fwd_dma_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale);
+        { static int ro = -1; if (ro < 0) { const char* e = getenv("GD_ATTN_ROT"); ro = e ? atoi(e) : 1; }
+          hipLaunchKernelGGL(attn_fwd_dma_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, ro); }
     else if (dtype == GD_BF16)
         hipLaunchKernelGGL(attn_fwd_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale);
     else
