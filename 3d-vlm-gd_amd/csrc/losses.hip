@@ -610,41 +610,58 @@ __global__ __launch_bounds__(256, 2) void pair_rank_tile_kernel(const float* u, 
 // L1(head(f1 - f2), tanh(d1 - d2)) rows (src/finetune_timm_vggt.py:475-479): one wave per keypoint.
 // u holds [P][2][Nmax][128]; writes du for both views (du1 = +dz, du2 = -dz, scaled by gscale[p]/n),
 // head grads (scaled) into hg[p], loss_sum[p] += |s - t| / n.
+#define DL1_KPW 4   // keypoints per wave: the head-gradient partials of 16 keypoints meet in LDS before ONE set of atomics per block
 __global__ __launch_bounds__(256) void depth_l1_kernel(const float* u, const float* d1, const float* d2,
                                                        const int* counts, const float* gscale, const float* b1,
                                                        const float* lw, const float* lb, const float* w2,
                                                        const float* b2, float* du, float* hg, float* loss_sum,
                                                        int Nmax) {
+    __shared__ float sacc[4][4][128];
+    __shared__ float sred[4][2];
     const int p = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int k = blockIdx.x * 4 + wave, n = counts ? counts[p] : Nmax;
-    if (k >= Nmax) return;
-    float* du1 = du + (((long)p * 2 + 0) * Nmax + k) * 128;
-    float* du2 = du + (((long)p * 2 + 1) * Nmax + k) * 128;
-    if (k >= n) {
-        du1[lane] = du1[lane + 64] = du2[lane] = du2[lane + 64] = 0.f;
-        return;
-    }
+    const int n = counts ? counts[p] : Nmax;
     const HeadW h = load_head(b1, lw, lb, w2, b2, lane);
-    const float* u1 = u + (((long)p * 2 + 0) * Nmax + k) * 128;
-    const float* u2 = u + (((long)p * 2 + 1) * Nmax + k) * 128;
-    float z[2] = {u1[lane] - u2[lane] + h.b1[0], u1[lane + 64] - u2[lane + 64] + h.b1[1]};
-    HeadCache c;
-    const float s = head_eval(z, h, c);
-    const float t = tanhf(d1[(long)p * Nmax + k] - d2[(long)p * Nmax + k]);
-    const float diff = s - t, w = gscale[p] / (float)n;
     float acc[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-    float acc_b2 = 0.f, dz[2];
-    head_back((diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f)) * w, h, c, dz, acc, acc_b2);
+    float acc_b2 = 0.f, lsum = 0.f;
+    for (int kk = 0; kk < DL1_KPW; ++kk) {
+        const int k = (blockIdx.x * 4 + wave) * DL1_KPW + kk;
+        if (k >= Nmax) break;
+        float* du1 = du + (((long)p * 2 + 0) * Nmax + k) * 128;
+        float* du2 = du + (((long)p * 2 + 1) * Nmax + k) * 128;
+        if (k >= n) {
+            du1[lane] = du1[lane + 64] = du2[lane] = du2[lane + 64] = 0.f;
+            continue;
+        }
+        const float* u1 = u + (((long)p * 2 + 0) * Nmax + k) * 128;
+        const float* u2 = u + (((long)p * 2 + 1) * Nmax + k) * 128;
+        float z[2] = {u1[lane] - u2[lane] + h.b1[0], u1[lane + 64] - u2[lane + 64] + h.b1[1]};
+        HeadCache c;
+        const float s = head_eval(z, h, c);
+        const float t = tanhf(d1[(long)p * Nmax + k] - d2[(long)p * Nmax + k]);
+        const float diff = s - t, w = gscale[p] / (float)n;
+        float dz[2];
+        head_back((diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f)) * w, h, c, dz, acc, acc_b2);
+        lsum += fabsf(diff) / (float)n;
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        du1[lane + 64 * e] = dz[e];
-        du2[lane + 64 * e] = -dz[e];
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) atomicAdd(hg + (long)p * HG_SIZE + tt * 128 + lane + 64 * e, acc[tt][e]);
+        for (int e = 0; e < 2; ++e) {
+            du1[lane + 64 * e] = dz[e];
+            du2[lane + 64 * e] = -dz[e];
+        }
     }
-    if (lane == 0) {
-        atomicAdd(hg + (long)p * HG_SIZE + 512, acc_b2);
-        atomicAdd(loss_sum + p, fabsf(diff) / (float)n);
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) sacc[wave][tt][lane + 64 * e] = acc[tt][e];
+    if (lane == 0) { sred[wave][0] = acc_b2; sred[wave][1] = lsum; }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 4 * 128; idx += 256) {
+        const int tt = idx >> 7, kx = idx & 127;
+        const float v = sacc[0][tt][kx] + sacc[1][tt][kx] + sacc[2][tt][kx] + sacc[3][tt][kx];
+        if (v != 0.f) atomicAdd(hg + (long)p * HG_SIZE + tt * 128 + kx, v);
+    }
+    if (threadIdx.x == 0) {
+        atomicAdd(hg + (long)p * HG_SIZE + 512, sred[0][0] + sred[1][0] + sred[2][0] + sred[3][0]);
+        atomicAdd(loss_sum + p, sred[0][1] + sred[1][1] + sred[2][1] + sred[3][1]);
     }
 }
 
@@ -743,7 +760,7 @@ extern "C" int gd_depth_l1(const float* u, const float* d1, const float* d2, con
     float* hg = (float*)workspace;   // [P, 516] scratch
     hipMemsetAsync(hg, 0, (size_t)P * HG_SIZE * sizeof(float), s);
     hipMemsetAsync(loss, 0, (size_t)P * sizeof(float), s);
-    hipLaunchKernelGGL(depth_l1_kernel, dim3(gd_cdiv(Nmax, 4), P), dim3(256), 0, s, u, d1, d2, counts, gscale, b1, ln_w,
+    hipLaunchKernelGGL(depth_l1_kernel, dim3(gd_cdiv(Nmax, 4 * DL1_KPW), P), dim3(256), 0, s, u, d1, d2, counts, gscale, b1, ln_w,
                        ln_b, w2, b2, du, hg, loss, Nmax);
     if (head_grad) hipLaunchKernelGGL(row_sum_cols_kernel, dim3(gd_cdiv(HG_SIZE, 256)), dim3(256), 0, s, hg, head_grad, P, HG_SIZE);
     GD_LAUNCH_OK();
