@@ -577,7 +577,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const T* qkv, const
 // ------------------------------------------------------------------------------------------ backward: dK, dV
 template <typename T, int NW>
 __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const T* qkv, const T* dout, const float* lse,
-                                                           const float* delta, T* dqkv, int N, int H, float scale) {
+                                                           const float* delta, T* dqkv, int N, int H, float scale, int vfirst) {
     constexpr int NF = AT<T>::NF, ROWB = AT<T>::ROWB;
     typedef typename Mma<T>::Frag Frag;
     __shared__ __attribute__((aligned(16))) char sQ[64 * ROWB];
@@ -694,8 +694,9 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const T* qkv, con
     for (int kt = 0; kt < 2; ++kt) {
         const int key = key0 + kt * 16 + c;
         if (key >= N) continue;
-        T* rk = dqkv + ((long)b * N + key) * 3 * H * HD + (long)(1 * H + h) * HD;
-        T* rv = dqkv + ((long)b * N + key) * 3 * H * HD + (long)(2 * H + h) * HD;
+        // column block of dK / dV inside the packed gradient row: (dq, dk, dv) or, with vfirst, (dq, dv, dk)
+        T* rk = dqkv + ((long)b * N + key) * 3 * H * HD + (long)((vfirst ? 2 : 1) * H + h) * HD;
+        T* rv = dqkv + ((long)b * N + key) * 3 * H * HD + (long)((vfirst ? 1 : 2) * H + h) * HD;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             store4<T>(rk + dt * 16 + g * 4, dk[dt][kt] * scale);
@@ -910,7 +911,8 @@ extern "C" int gd_attention_fwd(const void* qkv, void* o, float* lse, int B, int
 
 extern "C" int gd_attention_bwd(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv,
                                 float* delta_ws, int B, int N, int H, int head_dim, float scale, int dtype,
-                                void* stream) {
+                                int grad_order, void* stream) {
+    GD_REQUIRE(grad_order == 0 || grad_order == 1, "gd_attention_bwd: grad_order must be 0 (dq, dk, dv) or 1 (dq, dv, dk)");
     GD_REQUIRE(B > 0 && N > 0 && H > 0, "gd_attention_bwd: bad shape B=%d N=%d H=%d", B, N, H);
     GD_REQUIRE(head_dim == HD, "gd_attention_bwd: head_dim must be 64 (got %d)", head_dim);
     GD_REQUIRE(dtype == GD_F32 || dtype == GD_BF16, "gd_attention_bwd: bad dtype %d", dtype);
@@ -921,10 +923,10 @@ extern "C" int gd_attention_bwd(const void* qkv, const void* o, const void* dout
     dim3 grid(gd_cdiv(N, 128), H, B);
     if (dtype == GD_BF16) {
         hipLaunchKernelGGL(attn_bwd_dq_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)qkv, (const bf16*)o, (const bf16*)dout, lse, delta_ws, (bf16*)dqkv, N, H, scale);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<bf16, 8>), dim3(gd_cdiv(N, 256), H, B), dim3(512), 0, s, (const bf16*)qkv, (const bf16*)dout, lse, delta_ws, (bf16*)dqkv, N, H, scale);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<bf16, 8>), dim3(gd_cdiv(N, 256), H, B), dim3(512), 0, s, (const bf16*)qkv, (const bf16*)dout, lse, delta_ws, (bf16*)dqkv, N, H, scale, grad_order);
     } else {
         hipLaunchKernelGGL(attn_bwd_dq_kernel<float>, grid, dim3(256), 0, s, (const float*)qkv, (const float*)o, (const float*)dout, lse, delta_ws, (float*)dqkv, N, H, scale);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<float, 8>), dim3(gd_cdiv(N, 256), H, B), dim3(512), 0, s, (const float*)qkv, (const float*)dout, lse, delta_ws, (float*)dqkv, N, H, scale);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<float, 8>), dim3(gd_cdiv(N, 256), H, B), dim3(512), 0, s, (const float*)qkv, (const float*)dout, lse, delta_ws, (float*)dqkv, N, H, scale, grad_order);
     }
     GD_LAUNCH_OK();
     return 0;

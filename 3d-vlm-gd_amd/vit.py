@@ -104,6 +104,8 @@ class GDBlock(nn.Module):
              "b1": f32(self.mlp.fc1.bias) if self.mlp.fc1.bias is not None else zeros(w1.shape[0]),
              "b2": bfc2.contiguous()}
         p["wqkv"], p["wqkv_t"] = both(wqkv)
+        # the attention backward hands back (dq, dv, dk): W^T with its K blocks in that order for dX = dqkv . W
+        p["wqkv_t_qvk"] = torch.cat([wqkv[:D], wqkv[2 * D:], wqkv[D:2 * D]], 0).t().to(dtype).contiguous()
         p["wproj"], p["wproj_t"] = both(wproj)
         p["w1"], p["w1_t"] = both(w1)
         p["w2"], p["w2_t"] = both(wfc2)
@@ -179,10 +181,10 @@ class _BlockFn(torch.autograd.Function):
         # the four weight-gradient accumulators of the block come out of ONE zero-filled buffer
         bott = down.shape[0] if ctx.has_ad else 0
         r2 = at.shape[0] if ctx.has_lora else 0
-        zb = torch.zeros(2 * bott * D + r2 * 4 * D, dtype=torch.float32, device=dout.device)
+        zb = torch.zeros(2 * bott * D + r2 * 3 * D, dtype=torch.float32, device=dout.device)
         z_up, z_down = zb[:D * bott].view(D, bott), zb[D * bott:2 * D * bott].view(bott, D)
-        z_bt = zb[2 * D * bott:2 * D * bott + r2 * 3 * D].view(r2, 3 * D)
-        z_at = zb[2 * D * bott + r2 * 3 * D:].view(r2, D)
+        z_bt = zb[2 * D * bott:2 * D * bott + r2 * 2 * D].view(r2, 2 * D)     # t^T [dq | dv]
+        z_at = zb[2 * D * bott + r2 * 2 * D:].view(r2, D)
         if ctx.has_ad:
             up_tT = tw["up_tT"] if tw is not None else up.detach().t().to(T).contiguous()
             down_tT = tw["down_tT"] if tw is not None else down.detach().t().to(T).contiguous()
@@ -198,25 +200,24 @@ class _BlockFn(torch.autograd.Function):
         del dpre
         dx1 = ops.layernorm_bwd(dy2, x1, plan["ln2_w"], mean2, rstd2, dres=dx2)
         do = ops.gemm_nt(dx1, plan["wproj_t"])
-        dqkv = ops.attention_bwd(qkv, o, do, lse, B, Nt, H)
+        # gradient columns come back as (dq, dv, dk): the q / v LoRA factors only ever touch the first two thirds
+        dqkv = ops.attention_bwd(qkv, o, do, lse, B, Nt, H, vfirst=True)
         if ctx.has_lora:
             r = at.shape[0] // 2
             bt_T = tw["bt_T"] if tw is not None else bt.to(T).contiguous()
-            # dt = dqkv @ bt^T [M, 2r]: bt is zero outside its q rows x q columns and v rows x v columns, so only those two
-            # thirds of dqkv are streamed (two skinny launches into the halves of dt)
-            dt = torch.empty(dqkv.shape[0], 2 * r, dtype=torch.float32, device=dqkv.device)
-            ops.gemm_nt(dqkv[:, :D], bt_T[:r, :D], out=dt[:, :r])
-            ops.gemm_nt(dqkv[:, 2 * D:], bt_T[r:, 2 * D:], out=dt[:, r:])
-            gbt = ops.gemm_tn(t, dqkv, out=z_bt)                                                  # [2r, 3D]
+            bt_qv = tw["bt_qv"] if tw is not None else torch.cat([bt_T[:, :D], bt_T[:, 2 * D:]], 1).contiguous()   # [2r, 2D]
+            dqv = dqkv[:, :2 * D]
+            dt = ops.gemm_nt(dqv, bt_qv, out_dtype=torch.float32)                                 # [M, 2r], streams 2/3 of dqkv
+            gbt = ops.gemm_tn(t, dqv, out=z_bt)                                                   # [2r, 2D]
             gat = ops.gemm_tn(dt, y1, out=z_at)                                                   # [2r, D]
-            g_bq, g_bv = gbt[:r, :D].t(), gbt[r:, 2 * D:].t()      # strided views: the gradient gather copies them anyway
+            g_bq, g_bv = gbt[:r, :D].t(), gbt[r:, D:].t()          # strided views: the gradient gather copies them anyway
             g_aq, g_av = gat[:r], gat[r:]
         if not ctx.needs_input_grad[0]:   # first trainable block: nothing below it learns, skip dX (one GEMM + one LN backward)
             return None, None, None, None, g_aq, g_bq, g_av, g_bv, g_down, g_up
         if ctx.has_lora:
-            dy1 = ops.gemm_nt(dqkv, plan["wqkv_t"], lora_t=dt, lora_b=at.contiguous())            # dqkv.W + dt.At
+            dy1 = ops.gemm_nt(dqkv, plan["wqkv_t_qvk"], lora_t=dt, lora_b=at.contiguous())        # dqkv.W + dt.At
         else:
-            dy1 = ops.gemm_nt(dqkv, plan["wqkv_t"])
+            dy1 = ops.gemm_nt(dqkv, plan["wqkv_t_qvk"])
         dx = ops.layernorm_bwd(dy1, x, plan["ln1_w"], mean1, rstd1, dres=dx1)
         return dx, None, None, None, g_aq, g_bq, g_av, g_bv, g_down, g_up
 
@@ -382,9 +383,10 @@ class GDViT(nn.Module):
             down = torch.stack([a.down.weight for _, _, a in lo])        # [L, 64, D]
             up = torch.stack([a.up.weight for _, _, a in lo])            # [L, D, 64]
             at_T, bt_T, down_T, up_T = at.to(T), bt.to(T), down.to(T), up.to(T)
+            bt_qv = torch.cat([bt_T[:, :, :D], bt_T[:, :, 2 * D:]], 2).contiguous()      # [L, 2r, 2D]: the (dq, dv) column order
             down_tT, up_tT = down_T.transpose(1, 2).contiguous(), up_T.transpose(1, 2).contiguous()
         for i, (inner, _, _) in enumerate(lo):
-            inner._tw = {"dtype": T, "at": at[i], "bt": bt[i], "at_T": at_T[i], "bt_T": bt_T[i], "down_T": down_T[i],
+            inner._tw = {"dtype": T, "at": at[i], "bt": bt[i], "at_T": at_T[i], "bt_T": bt_T[i], "bt_qv": bt_qv[i], "down_T": down_T[i],
                          "up_T": up_T[i], "down_tT": down_tT[i], "up_tT": up_tT[i]}
 
     def release_trainables(self):

@@ -47,12 +47,13 @@ int gd_gemm_tn(const void* Y, const void* X, float* G, int M, int N, int K, long
 
 /* Multi-head self-attention, head_dim 64, flash-style (no N x N matrix): replaces F.scaled_dot_product_attention in
  * timm Attention.forward (same arithmetic as vggt/layers/attention.py:51-71).  qkv [B,N,3,H,64] packed
- * QKV-GEMM output, o [B,N,H*64], lse [B,H,N] f32 (natural log); backward writes dqkv [B,N,3,H,64];
- * delta_ws [B,H,N] f32 scratch. */
+ * QKV-GEMM output, o [B,N,H*64], lse [B,H,N] f32 (natural log); backward writes dqkv [B,N,3,H,64] as (dq, dk, dv)
+ * (grad_order 0) or (dq, dv, dk) (grad_order 1: the q and v gradients, the only ones the q/v LoRA factors contract, become
+ * one contiguous 2*H*64-column block); delta_ws [B,H,N] f32 scratch. */
 int gd_attention_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, int head_dim, float scale, int dtype,
                      void* stream);
 int gd_attention_bwd(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, float* delta_ws,
-                     int B, int N, int H, int head_dim, float scale, int dtype, void* stream);
+                     int B, int N, int H, int head_dim, float scale, int dtype, int grad_order, void* stream);
 
 /* Dense cost-volume KL for P pairs, fused: calculate_cost_loss (src/finetune_timm_vggt.py:488-533 variant 0,
  * src/finetune_timm_mast3r.py:504-540 variant 1) = F.normalize + bmm x2 + softmax + get_masked_patch_cost

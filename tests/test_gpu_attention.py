@@ -30,3 +30,8 @@ def test_attention(dtype, tol, gtol, B, N, H):
     assert rel_err(o, ro) < tol
     assert rel_err(lse, rl) < 1e-5 if dtype == torch.float32 else rel_err(lse, rl) < 1e-2
     assert rel_err(dqkv, rg) < gtol
+    # grad_order 1: the same gradients with the dK and dV column blocks exchanged -> (dq, dv, dk)
+    d2 = ops.attention_bwd(qkv, o, dout, lse, B, N, H, vfirst=True)
+    D = H * 64
+    assert torch.equal(d2[:, :D], dqkv[:, :D]) and torch.equal(d2[:, D:2 * D], dqkv[:, 2 * D:]) and \
+        torch.equal(d2[:, 2 * D:], dqkv[:, D:2 * D])
