@@ -11,8 +11,8 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
-#define GD_F32 0
-#define GD_BF16 1
+// the public C ABI: every TU sees the prototypes, so a definition that drifts from the header fails to compile
+#include "gd_hip.h"
 
 // ---- host-side error plumbing (definitions in cabi.hip) ----
 void gd_set_error(const char* fmt, ...);

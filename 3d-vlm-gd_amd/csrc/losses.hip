@@ -754,10 +754,12 @@ extern "C" int gd_pair_rank(const float* u, const float* depth, const int* count
 
 extern "C" int gd_depth_l1(const float* u, const float* d1, const float* d2, const int* counts, const float* gscale,
                            int P, int Nmax, const float* b1, const float* ln_w, const float* ln_b, const float* w2,
-                           const float* b2, float* loss, float* du, float* head_grad, void* workspace, void* stream) {
+                           const float* b2, float* loss, float* du, float* head_grad, float* head_grad_sets,
+                           void* workspace, void* stream) {
     GD_REQUIRE(P > 0 && Nmax > 0, "gd_depth_l1: bad shape");
+    GD_REQUIRE(head_grad_sets || workspace, "gd_depth_l1: head_grad_sets [P,516] or a workspace of that size is required");
     hipStream_t s = (hipStream_t)stream;
-    float* hg = (float*)workspace;   // [P, 516] scratch
+    float* hg = head_grad_sets ? head_grad_sets : (float*)workspace;   // per-pair head gradients [P, 516]
     hipMemsetAsync(hg, 0, (size_t)P * HG_SIZE * sizeof(float), s);
     hipMemsetAsync(loss, 0, (size_t)P * sizeof(float), s);
     hipLaunchKernelGGL(depth_l1_kernel, dim3(gd_cdiv(Nmax, 4 * DL1_KPW), P), dim3(256), 0, s, u, d1, d2, counts, gscale, b1, ln_w,

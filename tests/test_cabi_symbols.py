@@ -27,3 +27,44 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), f"{name} declared in include/ but not exported"
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
     assert _lib.lib().gd_abi_version() >= 1
+
+
+def _header_prototypes():
+    """name -> (return kind, [argument kinds]) parsed from include/*.h; kinds: int, long, float, size_t, ptr."""
+    protos = {}
+    inc = os.path.join(ROOT, "include")
+    for fn in os.listdir(inc):
+        if not fn.endswith(".h"):
+            continue
+        txt = re.sub(r"/\*.*?\*/", " ", open(os.path.join(inc, fn)).read(), flags=re.S)
+        txt = "\n".join(l for l in txt.splitlines() if not l.lstrip().startswith("#"))
+
+        def kind(decl):
+            decl = decl.strip()
+            if "*" in decl:
+                return "ptr"
+            toks = [t for t in re.findall(r"[A-Za-z_][A-Za-z0-9_]*", decl) if t not in ("const", "unsigned")]
+            return toks[0]          # the type word; a parameter name (if any) follows it
+        for ret, name, args in re.findall(r"([A-Za-z_][A-Za-z0-9_ \*]*?)\b(gd_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", txt):
+            a = [] if args.strip() in ("", "void") else [kind(x) for x in args.split(",")]
+            protos[name] = (kind(ret), a)
+    return protos
+
+
+def _ctype_kind(t):
+    if t in (ctypes.c_void_p, ctypes.c_char_p) or (isinstance(t, type) and issubclass(t, ctypes._Pointer)):
+        return "ptr"
+    return {ctypes.c_int: "int", ctypes.c_long: "long", ctypes.c_float: "float", ctypes.c_size_t: "size_t"}[t]
+
+
+def test_ctypes_signatures_match_the_header():
+    """Arity and argument kinds of every entry point agree between include/gd_hip.h and _lib.SIGNATURES (the .hip
+    definitions are checked against the same header by the compiler: gd_common.h includes it)."""
+    import gd_amd
+    from gd_amd import _lib
+    protos = _header_prototypes()
+    assert set(protos) == set(_lib.SIGNATURES)
+    for name, (res, args) in _lib.SIGNATURES.items():
+        hret, hargs = protos[name]
+        assert [_ctype_kind(a) for a in args] == hargs, (name, [_ctype_kind(a) for a in args], hargs)
+        assert _ctype_kind(res) == hret, (name, res, hret)

@@ -183,6 +183,30 @@ def test_depth_losses_golden():
     assert rel_err(head["ln_w"].grad, g["g_ln_w"]) < 1e-3
 
 
+def test_depth_losses_on_a_side_stream():
+    """The C ABI takes the caller's stream: the same op on a non-default stream (producers and consumers of u / du on that
+    stream only) gives the same numbers — gd_depth_l1 once dropped its stream argument and ran on stream 0."""
+    from gd_amd import ops
+    g = load_golden("g11_depth_loss")
+    N, D = g["kf1"].shape[1], g["kf1"].shape[2]
+    s = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        head = _head(g)
+        big = torch.randn(4096, 4096, device="cuda")
+        for _ in range(4):
+            big = big @ big * 1e-2                 # keeps the side stream busy ahead of the op's inputs
+        scale = (big.sum() * 0).nan_to_num() + 1.0       # = 1, but only once the matmuls are done
+        feats = (torch.stack([g["kf1"][0], g["kf2"][0]], 0)[None].cuda() * scale).requires_grad_(True)
+        d1 = ops.kp_depth(g["depth_1"][None].cuda(), g["kp_1"].cuda())
+        d2 = ops.kp_depth(g["depth_2"][None].cuda(), g["kp_2"].cuda())
+        l1, intra = ops.depth_losses(feats, d1, d2, head)
+        (l1 + intra).sum().backward()
+    s.synchronize()
+    assert abs(l1.item() - g["depth_loss"]) < 1e-5 and abs(intra.item() - g["intra_loss"]) < 1e-5
+    assert rel_err(feats.grad[0, 0], g["g_kf1"][0]) < 1e-3 and rel_err(head["w2"].grad, g["g_w2"]) < 1e-3
+
+
 def test_ranking_golden_and_batched():
     from gd_amd import ops
     g = load_golden("g07_ranking")
