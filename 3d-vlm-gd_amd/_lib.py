@@ -57,9 +57,21 @@ SIGNATURES = {
                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gd_depth_l1": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gd_depth_head_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gd_depth_head_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_void_p]),
+    "gd_sigmoid_temp": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_float, c_void_p]),
+    "gd_masked_patch_cost_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_float,
+                                         c_void_p]),
+    "gd_masked_patch_cost_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                         c_float, c_int, c_float, c_void_p]),
+    "gd_kl_divergence_map_fwd": (c_int, [c_void_p, c_void_p, c_long, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "gd_kl_divergence_map_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "gd_adamw_workspace_bytes": (c_size_t, []),
     "gd_clip_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_float, c_float, c_float,
                                    c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    "gd_clip_adamw_ranges": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_float, c_float, c_float,
+                                     c_float, c_float, c_float, c_float, c_void_p, c_void_p, ctypes.POINTER(c_long), c_int, c_void_p]),
     "gd_unproject_depth": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "gd_coview_masks": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_void_p]),
     "gd_nms_keypoints": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

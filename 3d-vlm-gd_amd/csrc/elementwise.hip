@@ -481,6 +481,29 @@ extern "C" int gd_clip_adamw_step(float* params, const float* grads, float* exp_
     return 0;
 }
 
+extern "C" int gd_clip_adamw_ranges(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, int step,
+                                    float lr, float weight_decay, float beta1, float beta2, float eps, float max_norm,
+                                    float grad_scale, float* grad_norm_out, void* workspace, const long* ranges, int n_ranges,
+                                    void* stream) {
+    GD_REQUIRE(n > 0 && step >= 1 && n_ranges >= 1 && ranges, "gd_clip_adamw_ranges: bad arguments");
+    for (int r = 0; r < n_ranges; ++r)
+        GD_REQUIRE(ranges[2 * r] >= 0 && ranges[2 * r] < ranges[2 * r + 1] && ranges[2 * r + 1] <= n && ranges[2 * r] % 4 == 0,
+                   "gd_clip_adamw_ranges: range %d = [%ld, %ld) is not a 16-byte aligned sub-range of [0, %ld)", r, ranges[2 * r],
+                   ranges[2 * r + 1], n);
+    hipStream_t s = (hipStream_t)stream;
+    double* partial = (double*)workspace;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(GD_SUMSQ_BLOCKS), dim3(256), 0, s, grads, n, partial);     // the norm is global
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    for (int r = 0; r < n_ranges; ++r) {
+        const long a = ranges[2 * r], m = ranges[2 * r + 1] - a;
+        hipLaunchKernelGGL(adamw_kernel, dim3(ew_blocks(m)), dim3(256), 0, s, params + a, grads + a, exp_avg + a, exp_avg_sq + a, m,
+                           partial, GD_SUMSQ_BLOCKS, max_norm, lr, weight_decay, beta1, beta2, eps, bc1, bc2, grad_scale,
+                           grad_norm_out);
+    }
+    GD_LAUNCH_OK();
+    return 0;
+}
+
 extern "C" int gd_cast(const void* in, void* out, long n, float scale, int in_dtype, int out_dtype, void* stream) {
     GD_REQUIRE(n > 0, "gd_cast: n must be positive");
     hipStream_t s = (hipStream_t)stream;

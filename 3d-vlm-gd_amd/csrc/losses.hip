@@ -690,6 +690,58 @@ __global__ __launch_bounds__(256) void row_sum_cols_kernel(const float* in, floa
     out[c] += s;
 }
 
+// Eager DepthAwareFeatureFusion.forward (utils/model.py:101-127, depths = None branch) on pre-projected rows
+// u = W1 f [M,128]: out[m] = tanh(w2 . GELU(LN(u[m] + b1)) + b2); one wave per row.  The backward recomputes the row,
+// writes du[m] and accumulates the head-parameter gradients (block partials through LDS, one set of atomics per block).
+#define DH_RPW 8   // rows per wave
+__global__ __launch_bounds__(256) void depth_head_fwd_kernel(const float* u, const float* b1, const float* lw, const float* lb,
+                                                             const float* w2, const float* b2, float* out, int M) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const HeadW h = load_head(b1, lw, lb, w2, b2, lane);
+    for (int kk = 0; kk < DH_RPW; ++kk) {
+        const long m = ((long)blockIdx.x * 4 + wave) * DH_RPW + kk;
+        if (m >= M) break;
+        const float z[2] = {u[m * 128 + lane] + h.b1[0], u[m * 128 + lane + 64] + h.b1[1]};
+        HeadCache c;
+        const float s = head_eval(z, h, c);
+        if (lane == 0) out[m] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void depth_head_bwd_kernel(const float* u, const float* dout, const float* b1, const float* lw,
+                                                             const float* lb, const float* w2, const float* b2, float* du,
+                                                             float* hg, int M) {
+    __shared__ float sacc[4][4][128];
+    __shared__ float sred[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const HeadW h = load_head(b1, lw, lb, w2, b2, lane);
+    float acc[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+    float acc_b2 = 0.f;
+    for (int kk = 0; kk < DH_RPW; ++kk) {
+        const long m = ((long)blockIdx.x * 4 + wave) * DH_RPW + kk;
+        if (m >= M) break;
+        const float z[2] = {u[m * 128 + lane] + h.b1[0], u[m * 128 + lane + 64] + h.b1[1]};
+        HeadCache c;
+        head_eval(z, h, c);
+        float dz[2];
+        head_back(dout[m], h, c, dz, acc, acc_b2);
+        du[m * 128 + lane] = dz[0];
+        du[m * 128 + lane + 64] = dz[1];
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) sacc[wave][tt][lane + 64 * e] = acc[tt][e];
+    if (lane == 0) sred[wave] = acc_b2;
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 4 * 128; idx += 256) {
+        const int tt = idx >> 7, kx = idx & 127;
+        const float v = sacc[0][tt][kx] + sacc[1][tt][kx] + sacc[2][tt][kx] + sacc[3][tt][kx];
+        if (v != 0.f) atomicAdd(hg + tt * 128 + kx, v);
+    }
+    if (threadIdx.x == 0) atomicAdd(hg + 512, sred[0] + sred[1] + sred[2] + sred[3]);
+}
+
 // ---------------------------------------------------------------------------------------------------
 extern "C" int gd_smooth_ap(const float* sim, const float* pts3d_1, const float* pts3d_2, const int* counts, int P,
                             int Nmax, int variant, float thres3d_neg, float temp, float* loss, float* dsim,
@@ -765,6 +817,25 @@ extern "C" int gd_depth_l1(const float* u, const float* d1, const float* d2, con
     hipLaunchKernelGGL(depth_l1_kernel, dim3(gd_cdiv(Nmax, 4 * DL1_KPW), P), dim3(256), 0, s, u, d1, d2, counts, gscale, b1, ln_w,
                        ln_b, w2, b2, du, hg, loss, Nmax);
     if (head_grad) hipLaunchKernelGGL(row_sum_cols_kernel, dim3(gd_cdiv(HG_SIZE, 256)), dim3(256), 0, s, hg, head_grad, P, HG_SIZE);
+    GD_LAUNCH_OK();
+    return 0;
+}
+
+extern "C" int gd_depth_head_fwd(const float* u, int M, const float* b1, const float* ln_w, const float* ln_b,
+                                 const float* w2, const float* b2, float* out, void* stream) {
+    GD_REQUIRE(M > 0, "gd_depth_head_fwd: bad shape");
+    hipLaunchKernelGGL(depth_head_fwd_kernel, dim3(gd_cdiv(M, 4 * DH_RPW)), dim3(256), 0, (hipStream_t)stream, u, b1, ln_w, ln_b,
+                       w2, b2, out, M);
+    GD_LAUNCH_OK();
+    return 0;
+}
+
+extern "C" int gd_depth_head_bwd(const float* u, const float* dout, int M, const float* b1, const float* ln_w,
+                                 const float* ln_b, const float* w2, const float* b2, float* du, float* head_grad,
+                                 void* stream) {
+    GD_REQUIRE(M > 0 && head_grad, "gd_depth_head_bwd: bad arguments");
+    hipLaunchKernelGGL(depth_head_bwd_kernel, dim3(gd_cdiv(M, 4 * DH_RPW)), dim3(256), 0, (hipStream_t)stream, u, dout, b1, ln_w,
+                       ln_b, w2, b2, du, head_grad, M);
     GD_LAUNCH_OK();
     return 0;
 }

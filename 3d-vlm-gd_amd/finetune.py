@@ -35,17 +35,24 @@ def _pair_batch(a, b):
 
 class FinetuneGD(nn.Module):
     def __init__(self, r=4, backbone="vit_base", patch_size=14, img_size=518, variant="vggt", geometry="shared",
-                 dtype="bf16", ap_loss_weight=1.0, depth_loss_weight=None, intra_depth_loss_weight=1.0,
-                 kl_loss_weight=1.0, teacher_patch=None, adapter_start_idx=4, bottleneck_dim=64, vit_kwargs=None,
-                 lora_b_std=0.0, seed=0):
+                 dtype="bf16", ap_loss_weight=1.0, depth_loss_weight=None, intra_depth_loss_weight=None,
+                 kl_loss_weight=None, teacher_patch=None, adapter_start_idx=4, bottleneck_dim=64, vit_kwargs=None,
+                 lora_b_std=0.0, seed=0, init_temperature=1.0, final_temperature=None, max_epochs=500):
         super().__init__()
-        assert r > 0 and variant in ("vggt", "mast3r") and geometry in ("shared", "reference")
+        assert r > 0 and variant in ("vggt", "mast3r", "me") and geometry in ("shared", "reference")
         self.variant, self.geometry = variant, geometry
+        me = variant == "me"     # FinetuneTIMM (src/finetune_timm_me.py:30-89): LoRA on the last 4 blocks, AP loss only
         self.ap_loss_weight = ap_loss_weight
         # reference defaults: MASt3R depth_loss_weight=0.0 (finetune_timm_mast3r.py:79-82), VGGT 1.0 (:86-89)
-        self.depth_loss_weight = (0.0 if variant == "mast3r" else 1.0) if depth_loss_weight is None else depth_loss_weight
-        self.intra_depth_loss_weight = intra_depth_loss_weight
-        self.kl_loss_weight = kl_loss_weight
+        self.depth_loss_weight = (1.0 if variant == "vggt" else 0.0) if depth_loss_weight is None else depth_loss_weight
+        self.intra_depth_loss_weight = (0.0 if me else 1.0) if intra_depth_loss_weight is None else intra_depth_loss_weight
+        self.kl_loss_weight = (0.0 if me else 1.0) if kl_loss_weight is None else kl_loss_weight
+        # teacher softmax temperature schedule: MASt3R 1.0 -> 0.5 over max_epochs (finetune_timm_mast3r.py:83-84,217-227),
+        # VGGT constant 1.0 (finetune_timm_vggt.py:92-93,187-188).  The teacher runner reads `teacher_temperature`.
+        self.init_temperature = init_temperature
+        self.final_temperature = (0.5 if variant == "mast3r" else init_temperature) if final_temperature is None else final_temperature
+        self.teacher_temperature = self.init_temperature
+        self.max_epochs, self.current_epoch = max_epochs, 0
         model = create_vit(backbone, patch_size=patch_size, img_size=img_size, dtype=dtype, **(vit_kwargs or {}))
         self.embedding_dim = model.embed_dim
         for p in model.parameters():
@@ -54,6 +61,8 @@ class FinetuneGD(nn.Module):
         self.w_As, self.w_Bs = [], []
         self.adapters = nn.ModuleList()
         g = torch.Generator().manual_seed(seed + 1)
+        if me:
+            adapter_start_idx = len(model.blocks) - 4         # `model.blocks[-4:]`, no adapters (finetune_timm_me.py:51-70)
         for blk_idx in range(adapter_start_idx, len(model.blocks)):
             blk = model.blocks[blk_idx]
             w_qkv_linear = blk.attn.qkv
@@ -63,6 +72,8 @@ class FinetuneGD(nn.Module):
             self.w_As += [w_a_q, w_a_v]
             self.w_Bs += [w_b_q, w_b_v]
             blk.attn.qkv = _LoRA_qkv(w_qkv_linear, w_a_q, w_b_q, w_a_v, w_b_v)
+            if me:
+                continue
             adapter = Adapter(dim=self.embedding_dim, bottleneck_dim=bottleneck_dim)
             model.blocks[blk_idx] = BlockWithAdapter(blk, adapter)
             self.adapters.append(adapter)
@@ -71,9 +82,10 @@ class FinetuneGD(nn.Module):
         self.downsample_factor = 8
         self.refine_conv = nn.Conv2d(self.embedding_dim, self.embedding_dim, kernel_size=3, stride=1, padding=1)
         self.thres3d_neg = 0.1
+        self.thresh3d_pos = 5e-3                               # ME positives (finetune_timm_me.py:76)
         self.patch_size = model.patch_embed.patch_size[0]
         self.target_res = 640
-        self.depth_diff_head = DepthAwareFeatureFusion(input_dim=self.embedding_dim, use_tanh=True)
+        self.depth_diff_head = None if me else DepthAwareFeatureFusion(input_dim=self.embedding_dim, use_tanh=True)
         self.resize_patch_size = teacher_patch or (14 if variant == "vggt" else self.patch_size)
         self._fwd_cache, self._norm_cache, self._fuse_taps = {}, {}, False
         self._flat = None
@@ -92,8 +104,9 @@ class FinetuneGD(nn.Module):
     # ------------------------------------------------------------------ optimiser state (flat buffers)
     def trainable_parameters(self):
         """Order of configure_optimizers (src/finetune_timm_vggt.py:642-648)."""
+        head = list(self.depth_diff_head.parameters()) if self.depth_diff_head is not None else []
         return ([l.weight for l in self.w_As] + [l.weight for l in self.w_Bs] + list(self.refine_conv.parameters())
-                + list(self.depth_diff_head.parameters()) + list(self.adapters.parameters()))
+                + head + list(self.adapters.parameters()))
 
     def configure_optimizers(self, lr=1e-5, weight_decay=1e-4, max_norm=1.0):
         """Re-seat every trainable tensor as a view of ONE flat fp32 buffer (params / grads / Adam moments):
@@ -104,17 +117,31 @@ class FinetuneGD(nn.Module):
         dev = ps[0].device
         flat_p = torch.zeros(n, dtype=torch.float32, device=dev)
         flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
+        # parameters that never receive a gradient (depth_attention: utils/model.py:92-97 builds it, no loss evaluates it):
+        # torch.optim.AdamW skips a parameter whose .grad is None — no moment update AND no weight decay.  They sit in ONE
+        # contiguous span of the flat buffer (depth_diff_head.parameters() lists depth_attention first); the optimiser
+        # step runs on the two ranges around it.
+        unused = {id(q) for q in self.depth_diff_head.depth_attention.parameters()} if self.depth_diff_head is not None else set()
         off = 0
-        views = []
+        views, skip = [], []
         for p in ps:
             k = p.numel()
             flat_p[off:off + k] = p.detach().reshape(-1)
             p.data = flat_p[off:off + k].view(p.shape)
             p.grad = flat_g[off:off + k].view(p.shape)
             views.append(p.grad)
+            if id(p) in unused:
+                skip.append((off, off + al(k)))
             off += al(k)
+        live, pos = [], 0
+        for a, b in skip:                     # complement of the (adjacent) skipped spans
+            if a > pos:
+                live.append((pos, a))
+            pos = max(pos, b)
+        if pos < n:
+            live.append((pos, n))
         self._flat = {"p": flat_p, "g": flat_g, "views": views, "m": torch.zeros_like(flat_p), "v": torch.zeros_like(flat_p),
-                      "step": 0, "lr": lr, "wd": weight_decay, "max_norm": max_norm}
+                      "step": 0, "lr": lr, "wd": weight_decay, "max_norm": max_norm, "live": live}
         return self._flat
 
     def zero_grad_flat(self):
@@ -144,7 +171,36 @@ class FinetuneGD(nn.Module):
         f = self._flat
         f["step"] += 1
         return ops.clip_adamw_step(f["p"], f["g"], f["m"], f["v"], f["step"], lr=f["lr"], weight_decay=f["wd"],
-                                   max_norm=f["max_norm"], grad_scale=grad_scale)
+                                   max_norm=f["max_norm"], grad_scale=grad_scale, ranges=f["live"])
+
+    # ------------------------------------------------------------------ teacher temperature schedule
+    def update_temperature(self, current_epoch=None, total_epochs=None):
+        """src/finetune_timm_mast3r.py:217-224: linear init -> final over the run's epochs; the result is what the
+        teacher's target softmax uses (`self.matcher.temperature` there, `teacher_temperature` here)."""
+        if current_epoch is not None:
+            self.current_epoch = current_epoch
+        total = total_epochs if total_epochs is not None else (self.max_epochs if self.max_epochs and self.max_epochs > 0 else 100)
+        ratio = min(self.current_epoch / total, 1.0)
+        self.teacher_temperature = self.init_temperature * (1 - ratio) + self.final_temperature * ratio
+        return self.teacher_temperature
+
+    def on_train_batch_end(self, *args, **kwargs):
+        """src/finetune_timm_mast3r.py:226-227"""
+        self.update_temperature()
+
+    def fit_step(self, batch, reducer=None):
+        """One optimisation step of the minimal loop that stands in for Lightning's (src/main.py:153-161): forward +
+        losses, backward, gradient exchange (dp.OverlappedGradReducer; None = single rank), clip + AdamW.
+        -> (loss, terms, pre-clip gradient norm)."""
+        loss, terms = self.training_step(batch)
+        if reducer is None:
+            self.backward(loss)
+            scale = 1.0
+        else:
+            self.backward(loss, pre_gather=reducer.wait_early)
+            reducer.start()
+            scale = reducer.finish()
+        return loss, terms, self.optimizer_step(grad_scale=scale)
 
     # ------------------------------------------------------------------ checkpoint layout (SURVEY 3.4)
     def on_save_checkpoint(self, checkpoint):
@@ -153,9 +209,19 @@ class FinetuneGD(nn.Module):
             checkpoint[f"w_a_{i:03d}"] = l.weight
         for i, l in enumerate(self.w_Bs):
             checkpoint[f"w_b_{i:03d}"] = l.weight
-        checkpoint["depth_diff_head"] = self.depth_diff_head.state_dict()
+        if self.depth_diff_head is not None:
+            checkpoint["depth_diff_head"] = self.depth_diff_head.state_dict()
         for i, a in enumerate(self.adapters):
             checkpoint[f"adapter_{i:03d}"] = a.state_dict()
+        # Lightning stores `optimizer_states` beside these keys; here the AdamW state is the flat moment buffers
+        if self._flat is not None:
+            f = self._flat
+            checkpoint["gd_optimizer_state"] = {"exp_avg": f["m"].detach().clone(), "exp_avg_sq": f["v"].detach().clone(),
+                                                "step": f["step"], "numel": f["p"].numel()}
+        for k, v in list(checkpoint.items()):       # views of the flat parameter buffer: save the tensors, not the whole storage
+            if isinstance(v, torch.Tensor):
+                checkpoint[k] = v.detach().clone()
+        checkpoint["epoch"] = self.current_epoch
         return checkpoint
 
     def on_load_checkpoint(self, checkpoint):
@@ -165,9 +231,17 @@ class FinetuneGD(nn.Module):
                 l.weight.copy_(checkpoint[f"w_a_{i:03d}"])
             for i, l in enumerate(self.w_Bs):
                 l.weight.copy_(checkpoint[f"w_b_{i:03d}"])
-            self.depth_diff_head.load_state_dict(checkpoint["depth_diff_head"])
+            if self.depth_diff_head is not None:
+                self.depth_diff_head.load_state_dict(checkpoint["depth_diff_head"])
             for i, a in enumerate(self.adapters):
                 a.load_state_dict(checkpoint[f"adapter_{i:03d}"])
+            st = checkpoint.get("gd_optimizer_state")
+            if st is not None and self._flat is not None and st["numel"] == self._flat["p"].numel():
+                self._flat["m"].copy_(st["exp_avg"])
+                self._flat["v"].copy_(st["exp_avg_sq"])
+                self._flat["step"] = int(st["step"])
+            self.current_epoch = int(checkpoint.get("epoch", self.current_epoch))
+            self.update_temperature()
 
     # ------------------------------------------------------------------ student forwards
     def _kp_grid(self, h, w):
@@ -218,7 +292,10 @@ class FinetuneGD(nn.Module):
         P = self.patch_size
         _, x = self._forward(rgbs, gh, gw)
         fmap = conv3x3_tokens(self.model.norm(x), self.refine_conv.weight, self.refine_conv.bias, gh, gw)
-        feat = kp_gather([fmap], pts, gh, gw, (gw * P) / w, (gh * P) / h, gh * P, gw * P, P)
+        # the ME trainer passes h = patch_h * 14 and the default patch_size = stride = 14 whatever the model's patch is
+        # (src/finetune_timm_me.py:155); the two teacher-driven trainers pass the model's patch (finetune_timm_vggt.py:325-327)
+        Pi = 14 if self.variant == "me" else P
+        feat = kp_gather([fmap], pts, gh, gw, (gw * P) / w, (gh * P) / h, gh * Pi, gw * Pi, Pi)
         return ops.l2_normalize(feat) if normalize else feat
 
     def get_feature_cost(self, rgbs):
@@ -260,7 +337,8 @@ class FinetuneGD(nn.Module):
         P = kp_1.shape[0]
         desc = self.get_feature(rgbs, torch.cat([kp_1, kp_2], 0), normalize=True)
         d1, d2 = ops.split_pairs(desc, P)
-        return ops.smooth_ap(d1, d2, pts3d_1, pts3d_2, counts, self.variant, self.thres3d_neg, 0.01)
+        return ops.smooth_ap(d1, d2, pts3d_1, pts3d_2, counts, self.variant, self.thres3d_neg, 0.01,
+                             thres3d_pos=self.thresh3d_pos)
 
     def training_step(self, batch):
         """Loss of P pairs = mean over pairs of the reference's per-pair loss (src/finetune_timm_vggt.py:599-616).
@@ -272,6 +350,14 @@ class FinetuneGD(nn.Module):
         self._fuse_taps = self.geometry == "shared"   # one forward feeds keypoint AND cost features: norm the taps on the way
         rgbs = _pair_batch(batch["rgb_1"], batch["rgb_2"])
         counts = batch.get("counts")
+        if self.variant == "me":          # src/finetune_timm_me.py:191-220: the correspondence AP loss alone
+            ap = self.calculate_matching_loss(rgbs, batch["kp_1"], batch["kp_2"], batch["pts3d_1"], batch["pts3d_2"], counts)
+            self.clear_cache()
+            self._fuse_taps = False
+            self.model.release_trainables()
+            zero = torch.zeros_like(ap.detach())
+            return (self.ap_loss_weight * ap).mean(), {"ap_loss": ap.detach(), "depth_loss": zero, "intra_depth_loss": zero,
+                                                       "kl_loss": zero}
         depth_loss, intra = self.calculate_depth_loss(batch["depth_1"], batch["depth_2"], rgbs, batch["kp_1"],
                                                       batch["kp_2"], counts)
         kl = self.calculate_cost_loss(rgbs, batch["cost_1"], batch["cost_2"], batch["kp_1"], batch["kp_2"],
@@ -279,6 +365,10 @@ class FinetuneGD(nn.Module):
         ap = self.calculate_matching_loss(rgbs, batch["kp_1"], batch["kp_2"], batch["pts3d_1"], batch["pts3d_2"], counts)
         per_pair = (self.ap_loss_weight * ap + self.depth_loss_weight * depth_loss
                     + self.intra_depth_loss_weight * intra + self.kl_loss_weight * kl)
+        if counts is not None:
+            # a pair whose keypoint filter left nothing: the reference returns a constant zero loss for that step
+            # (src/finetune_timm_mast3r.py:604-607, src/finetune_timm_vggt.py:585-597) — zero loss, zero gradient here too
+            per_pair = torch.where(counts.to(per_pair.device) > 0, per_pair, torch.zeros_like(per_pair))
         self.clear_cache()
         self._fuse_taps = False
         self.model.release_trainables()

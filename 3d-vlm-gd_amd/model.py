@@ -3,9 +3,9 @@ arguments, attribute names and state_dict keys, so the reference's wrapping code
 (src/finetune_timm_vggt.py:134-162) and checkpoints apply unchanged.
 
 These modules are parameter containers + markers.  The fused engine (vit.py) discovers them on the block
-list and folds them into HIP kernels (LoRA as a rank-r epilogue of the QKV GEMM, the adapter as two skinny
-GEMMs with fused ReLU / residual); calling them directly on CUDA tensors also routes through the HIP GEMMs.
-There is no eager fallback.
+list and folds them into HIP kernels (LoRA as a rank-r epilogue of the QKV GEMM, the adapter as one fused
+pass); calling them directly ("eager") on CUDA tensors also routes through the HIP kernels.
+There is no CPU fallback.
 """
 import torch
 import torch.nn as nn
@@ -108,9 +108,9 @@ class _LoRA_qkv(nn.Module):
 
 
 class DepthAwareFeatureFusion(nn.Module):
-    """utils/model.py:88-127 — parameter container with the reference's layout (depth_attention is never used
-    by the losses but is part of the checkpoint).  The losses evaluate fusion_layer inside gd_pair_rank /
-    gd_depth_l1; `head_params()` hands them the tensors."""
+    """utils/model.py:88-127 — the reference's layout (depth_attention is never used by the losses but is part of the
+    checkpoint).  The fused losses evaluate fusion_layer inside gd_pair_rank / gd_depth_l1 (`head_params()` hands them
+    the tensors); `forward` is the eager form on the same HIP head kernels."""
 
     def __init__(self, input_dim, hidden_dim=128, use_tanh=True):
         super().__init__()
@@ -127,5 +127,11 @@ class DepthAwareFeatureFusion(nn.Module):
                 "w2": fl[3].weight, "b2": fl[3].bias}
 
     def forward(self, features, depths=None):
-        raise RuntimeError("DepthAwareFeatureFusion is evaluated inside the fused HIP losses "
-                           "(gd_amd.ops.depth_losses); it has no eager forward")
+        """utils/model.py:101-127, eager: features [..., D] (+ depths [...]) -> tanh(fusion_layer(.)) [...].  The first
+        Linear runs on gd_gemm_nt, LayerNorm + GELU + the 128 -> 1 Linear + tanh in gd_depth_head_{fwd,bwd}.  The
+        `depths` branch (never taken by the reference's losses) modulates the features by depth_attention first."""
+        if depths is not None:
+            da = self.depth_attention
+            e = torch.nn.functional.gelu(depths.unsqueeze(-1).float() * da[0].weight[:, 0] + da[0].bias)   # Linear(1, 128): outer product
+            features = features.float() * torch.sigmoid(hip_linear(e, da[2].weight, da[2].bias))
+        return ops.depth_head(features, self.head_params())

@@ -341,21 +341,21 @@ def _ptr_array(tensors):
     return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
-def kp_gather_fwd(grids, bstride, kp, B, Nk, gh, gw, D, sx, sy, img_h, img_w, patch):
+def kp_gather_fwd(grids, bstride, kp, B, Nk, gh, gw, D, sx, sy, img_h, img_w, patch, stride=None):
     """grids: list (1..4) of tensors whose data_ptr is the (b=0, token 0 of the grid) element."""
     out = torch.empty(B, Nk, D, dtype=torch.float32, device=kp.device)
     check(lib().gd_kp_gather_fwd(_ptr_array(grids), len(grids), bstride, dtype_code(grids[0]), ptr(kp), ptr(out), B,
-                                 Nk, gh, gw, D, float(sx), float(sy), img_h, img_w, patch, patch, stream()),
-          "gd_kp_gather_fwd")
+                                 Nk, gh, gw, D, float(sx), float(sy), img_h, img_w, patch, patch if stride is None else stride,
+                                 stream()), "gd_kp_gather_fwd")
     return out
 
 
-def kp_gather_bwd(ngrid, kp, dout, B, Nk, gh, gw, D, sx, sy, img_h, img_w, patch, prefix=0):
+def kp_gather_bwd(ngrid, kp, dout, B, Nk, gh, gw, D, sx, sy, img_h, img_w, patch, prefix=0, stride=None):
     """-> list of ngrid fp32 gradient buffers [B, prefix + gh*gw, D] (prefix-token rows stay zero)."""
     dg = [torch.zeros(B, prefix + gh * gw, D, dtype=torch.float32, device=kp.device) for _ in range(ngrid)]
     dout = dout.contiguous().float()
     check(lib().gd_kp_gather_bwd(_ptr_array([t[:, prefix:] for t in dg]), ngrid, (prefix + gh * gw) * D, ptr(kp), ptr(dout), B, Nk, gh, gw, D, float(sx), float(sy),
-                                 img_h, img_w, patch, patch, stream()), "gd_kp_gather_bwd")
+                                 img_h, img_w, patch, patch if stride is None else stride, stream()), "gd_kp_gather_bwd")
     return dg
 
 
@@ -516,18 +516,205 @@ def depth_losses(feats, depth_1, depth_2, head, counts=None, depth_threshold=0.0
                               head["ln_b"], head["w2"], head["b2"])
 
 
+class _DepthHead(torch.autograd.Function):
+    """Eager DepthAwareFeatureFusion rows: tanh(fusion_layer(f)) for f [M, D] -> [M] (utils/model.py:101-127)."""
+
+    @staticmethod
+    def forward(ctx, feats, w1, b1, ln_w, ln_b, w2, b2):
+        shp = feats.shape
+        f = feats.reshape(-1, shp[-1]).contiguous().float()
+        M = f.shape[0]
+        w1c = w1.detach().float().contiguous()
+        u = gemm_nt(f, w1c)                                                   # [M, 128]
+        hp = [t.detach().contiguous().float() for t in (b1, ln_w, ln_b, w2.reshape(-1), b2)]
+        out = torch.empty(M, dtype=torch.float32, device=f.device)
+        check(lib().gd_depth_head_fwd(ptr(u), M, *[ptr(t) for t in hp], ptr(out), stream()), "gd_depth_head_fwd")
+        ctx.save_for_backward(f, w1c, u, *hp)
+        ctx.shp = shp
+        return out.view(shp[:-1])
+
+    @staticmethod
+    def backward(ctx, dout):
+        f, w1c, u, *hp = ctx.saved_tensors
+        M = f.shape[0]
+        dz = dout.reshape(-1).contiguous().float()
+        du = torch.empty_like(u)
+        hg = torch.zeros(516, dtype=torch.float32, device=f.device)
+        check(lib().gd_depth_head_bwd(ptr(u), ptr(dz), M, *[ptr(t) for t in hp], ptr(du), ptr(hg), stream()), "gd_depth_head_bwd")
+        df = gemm_nt(du, w1c.t().contiguous()).view(ctx.shp)
+        dw1 = gemm_tn(du, f)
+        return (df, dw1, hg[0:128].clone(), hg[128:256].clone(), hg[256:384].clone(), hg[384:512].view(1, 128).clone(),
+                hg[512:513].clone())
+
+
+def depth_head(feats, head):
+    """feats [..., D] -> tanh(w2 . GELU(LN(W1 f + b1)) + b2) [...]; head: dict w1,b1,ln_w,ln_b,w2,b2."""
+    return _DepthHead.apply(feats, head["w1"], head["b1"], head["ln_w"], head["ln_b"], head["w2"], head["b2"])
+
+
+class _PairRank(torch.autograd.Function):
+    """pairwise_logistic_ranking_loss over B keypoint sets, the reference's GLOBAL mean over the valid pairs of all sets
+    (utils/losses.py:36-40): per-set means from gd_pair_rank, re-weighted by the per-set valid-pair counts."""
+
+    @staticmethod
+    def forward(ctx, feats, depths, thr, w1, b1, ln_w, ln_b, w2, b2):
+        B, N, D = feats.shape
+        dev = feats.device
+        f = feats.contiguous().float()
+        w1c = w1.detach().float().contiguous()
+        u = gemm_nt(f.view(B * N, D), w1c).view(B, N, 128)
+        hp = [t.detach().contiguous().float() for t in (b1, ln_w, ln_b, w2.reshape(-1), b2)]
+        ones = torch.ones(B, dtype=torch.float32, device=dev)
+        loss = torch.empty(B, dtype=torch.float32, device=dev)
+        du = torch.empty(B, N, 128, dtype=torch.float32, device=dev)
+        hg = torch.empty(B, 516, dtype=torch.float32, device=dev)
+        nbytes = lib().gd_pair_rank_workspace_bytes(B)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        dd = depths.contiguous().float()
+        check(lib().gd_pair_rank(ptr(u), ptr(dd), None, ptr(ones), B, N, float(thr), *[ptr(t) for t in hp], ptr(loss),
+                                 ptr(du), None, ptr(hg), ptr(ws), stream()), "gd_pair_rank")
+        cnt = ws[(B * 517) * 4:(B * 518) * 4].view(torch.int32).float()         # workspace layout: hg [B,516] | loss_sum [B] | pair_cnt [B]
+        wgt = cnt / cnt.sum().clamp_min(1.0)
+        ctx.save_for_backward(f, w1c, du, hg, wgt)
+        return (loss * wgt).sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        f, w1c, du, hg, wgt = ctx.saved_tensors
+        B, N, D = f.shape
+        sc = (g.float() * wgt)
+        du = (du * sc.view(B, 1, 1)).view(B * N, 128)
+        hgs = (hg * sc[:, None]).sum(0)
+        df = gemm_nt(du, w1c.t().contiguous()).view(B, N, D)
+        dw1 = gemm_tn(du, f.view(B * N, D))
+        return (df, None, None, dw1, hgs[0:128].clone(), hgs[128:256].clone(), hgs[256:384].clone(),
+                hgs[384:512].view(1, 128).clone(), hgs[512:513].clone())
+
+
+def pair_rank_loss(feats, depths, head, depth_threshold=0.0):
+    """feats [B,N,D], depths [B,N] -> scalar: mean of log(1 + exp(-sign(d_j - d_i) head(f_j - f_i))) over the pairs with
+    |d_j - d_i| > depth_threshold (0 when there is none)."""
+    return _PairRank.apply(feats, depths, depth_threshold, head["w1"], head["b1"], head["ln_w"], head["ln_b"], head["w2"],
+                           head["b2"])
+
+
+# ----------------------------------------------------------------------------------------------
+# stand-alone forms of the reference's loss helpers (compat.py); the step uses the fused ops above
+# ----------------------------------------------------------------------------------------------
+class _SigmoidTemp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, temp):
+        xc = x.contiguous().float()
+        y = torch.empty_like(xc)
+        check(lib().gd_sigmoid_temp(ptr(xc), None, ptr(y), xc.numel(), float(temp), stream()), "gd_sigmoid_temp")
+        ctx.save_for_backward(xc)
+        ctx.temp = float(temp)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (xc,) = ctx.saved_tensors
+        dyc = dy.contiguous().float()
+        dx = torch.empty_like(xc)
+        check(lib().gd_sigmoid_temp(ptr(xc), ptr(dyc), ptr(dx), xc.numel(), ctx.temp, stream()), "gd_sigmoid_temp")
+        return dx, None
+
+
+def sigmoid_temp(x, temp=1.0):
+    return _SigmoidTemp.apply(x, temp)
+
+
+class _MaskedPatchCost(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cost, m1, m2, eps, use_softmax, temperature):
+        B, R, C = cost.shape
+        c = cost.contiguous().float()
+        m1c = m1.contiguous().to(torch.uint8)
+        m2c = m2.contiguous().to(torch.uint8) if m2 is not None else None
+        _req(m1c.numel() == R and (m2c is None or m2c.numel() == C), "masked_patch_cost: mask sizes")
+        y = torch.empty_like(c)
+        check(lib().gd_masked_patch_cost_fwd(ptr(c), ptr(m1c), ptr(m2c), ptr(y), B, R, C, float(eps), int(bool(use_softmax)),
+                                             float(temperature), stream()), "gd_masked_patch_cost_fwd")
+        ctx.save_for_backward(c, y, m1c, m2c)
+        ctx.cfg = (float(eps), int(bool(use_softmax)), float(temperature))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        c, y, m1c, m2c = ctx.saved_tensors
+        B, R, C = c.shape
+        dyc = dy.contiguous().float()
+        dc = torch.empty_like(c)
+        eps, sm, temp = ctx.cfg
+        check(lib().gd_masked_patch_cost_bwd(ptr(c), ptr(y), ptr(dyc), ptr(m1c), ptr(m2c), ptr(dc), B, R, C, eps, sm, temp,
+                                             stream()), "gd_masked_patch_cost_bwd")
+        return dc, None, None, None, None, None
+
+
+def masked_patch_cost(cost, m1, m2=None, eps=1e-8, use_softmax=False, temperature=1.0):
+    return _MaskedPatchCost.apply(cost, m1, m2, eps, use_softmax, temperature)
+
+
+class _KLMap(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, p, eps):
+        _req(t.shape == p.shape, "kl_divergence_map: shapes differ")
+        tc, pc = t.contiguous().float(), p.contiguous().float()
+        cols = tc.shape[-1]
+        rows = tc.numel() // cols
+        loss = torch.empty(1, dtype=torch.float32, device=tc.device)
+        ws = torch.empty(rows, dtype=torch.float32, device=tc.device)
+        check(lib().gd_kl_divergence_map_fwd(ptr(tc), ptr(pc), rows, cols, float(eps), ptr(loss), ptr(ws), stream()),
+              "gd_kl_divergence_map_fwd")
+        ctx.save_for_backward(tc, pc)
+        ctx.eps = float(eps)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        tc, pc = ctx.saved_tensors
+        cols = tc.shape[-1]
+        rows = tc.numel() // cols
+        gt, gp = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dt = torch.empty_like(tc) if gt else None
+        dp = torch.empty_like(pc) if gp else None
+        gg = g.reshape(1).contiguous().float()
+        check(lib().gd_kl_divergence_map_bwd(ptr(tc), ptr(pc), ptr(gg), rows, cols, ctx.eps, ptr(dt), ptr(dp), stream()),
+              "gd_kl_divergence_map_bwd")
+        return dt, dp, None
+
+
+def kl_divergence_map(t, p, eps=1e-8):
+    return _KLMap.apply(t, p, eps)
+
+
 # ----------------------------------------------------------------------------------------------
 # optimiser
 # ----------------------------------------------------------------------------------------------
 def clip_adamw_step(params, grads, exp_avg, exp_avg_sq, step, lr=1e-5, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8,
-                    max_norm=1.0, grad_scale=1.0):
-    """In place on the flat fp32 buffers; returns the pre-clip global grad norm (device scalar)."""
+                    max_norm=1.0, grad_scale=1.0, ranges=None):
+    """In place on the flat fp32 buffers; returns the pre-clip global grad norm (device scalar).  `ranges` = [(a, b), ...]
+    restricts the UPDATE (moments, decay, step) to those element ranges — parameters outside them are left untouched, as
+    torch.optim.AdamW leaves a parameter whose .grad is None; the norm is always taken over the whole buffer (their
+    gradient slice is zero)."""
     norm = torch.empty(1, dtype=torch.float32, device=params.device)
     ws = torch.empty(lib().gd_adamw_workspace_bytes(), dtype=torch.uint8, device=params.device)
-    check(lib().gd_clip_adamw_step(ptr(params), ptr(grads), ptr(exp_avg), ptr(exp_avg_sq), params.numel(), int(step),
-                                   lr, weight_decay, betas[0], betas[1], eps, max_norm, grad_scale, ptr(norm), ptr(ws),
-                                   stream()), "gd_clip_adamw_step")
+    n = params.numel()
+    if not ranges or (len(ranges) == 1 and tuple(ranges[0]) == (0, n)):
+        check(lib().gd_clip_adamw_step(ptr(params), ptr(grads), ptr(exp_avg), ptr(exp_avg_sq), n, int(step),
+                                       lr, weight_decay, betas[0], betas[1], eps, max_norm, grad_scale, ptr(norm), ptr(ws),
+                                       stream()), "gd_clip_adamw_step")
+        return norm
+    check(lib().gd_clip_adamw_ranges(ptr(params), ptr(grads), ptr(exp_avg), ptr(exp_avg_sq), n, int(step), lr, weight_decay,
+                                     betas[0], betas[1], eps, max_norm, grad_scale, ptr(norm), ptr(ws),
+                                     (ctypes_long_array([x for ab in ranges for x in ab])), len(ranges), stream()),
+          "gd_clip_adamw_ranges")
     return norm
+
+
+def ctypes_long_array(vals):
+    import ctypes
+    return (ctypes.c_long * len(vals))(*[int(v) for v in vals])
 
 
 def cast(x, dtype, scale=1.0):

@@ -343,6 +343,14 @@ class GDViT(nn.Module):
         self._pos_cache = {}
         self._pe_plan = None
         self.init_weights()
+        # the per-dtype plans cache cast / folded / transposed copies of the frozen weights: drop them whenever the weights
+        # can have changed under them (load_state_dict; .to() / .float() / .cuda() go through _apply below)
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_plans())
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self.invalidate_plans()
+        return out
 
     def init_weights(self, seed=0):
         g = torch.Generator().manual_seed(seed)
@@ -395,8 +403,11 @@ class GDViT(nn.Module):
 
     def invalidate_plans(self):
         self._pos_cache, self._pe_plan = {}, None
-        for b in self.blocks:
-            _unwrap(b)[0]._plan = None
+        for b in getattr(self, "blocks", ()):
+            inner = b.block if hasattr(b, "block") and hasattr(b, "adapter") else b
+            if isinstance(inner, GDBlock):
+                inner._plan = None
+                inner._tw = None
 
     # ---- frozen prologue pieces ----
     def _pos(self, gh, gw):
@@ -433,6 +444,11 @@ class GDViT(nn.Module):
         """img [B,3,h,w] fp32 in [0,1] (NOT normalised: Normalize and the optional bilinear resize to `size`
         are fused into the im2col kernel) -> tokens [B, 1+gh*gw, D]."""
         P = self.patch_embed.patch_size[0]
+        st = self.patch_embed.proj.stride
+        st = (st, st) if isinstance(st, int) else tuple(st)
+        if st != (P, P):     # src/evaluate_timm.py:266-279 overrides the stride for dense features: not implemented by the fused kernel
+            raise ops._lib.GdHipError(f"patch_embed.proj.stride = {st}: the fused patch-embed kernel implements stride == patch "
+                                      f"size ({P}) only (overlapping-patch evaluation mode is not supported)")
         B, _, h, w = img.shape
         H, W = size if size is not None else (h, w)
         assert H % P == 0 and W % P == 0, f"image size {(H, W)} not a multiple of patch {P}"
@@ -531,13 +547,13 @@ def conv3x3_tokens(tok, weight, bias, gh, gw):
 class _GatherFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, kp, geom, *grids):
-        gh, gw, sx, sy, img_h, img_w, patch = geom
+        gh, gw, sx, sy, img_h, img_w, patch, stride = geom
         B, Ng, D = grids[0].shape
         prefix = Ng - gh * gw
         gs = [g.contiguous() for g in grids]
         kp = kp.contiguous().float()
         out = ops.kp_gather_fwd([g[:, prefix:] for g in gs], Ng * D, kp, B, kp.shape[1], gh, gw, D, sx, sy, img_h,
-                                img_w, patch)
+                                img_w, patch, stride=stride)
         ctx.save_for_backward(kp)
         ctx.meta = (geom, B, Ng, D, prefix, len(gs), gs[0].dtype)
         return out
@@ -545,15 +561,17 @@ class _GatherFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         (kp,) = ctx.saved_tensors
-        (gh, gw, sx, sy, img_h, img_w, patch), B, Ng, D, prefix, ng, T = ctx.meta
+        (gh, gw, sx, sy, img_h, img_w, patch, stride), B, Ng, D, prefix, ng, T = ctx.meta
         # every grid of the mean receives the SAME gradient (w * dout / ng): scatter it once and hand the one buffer, cast
         # once to the grids' dtype, to all of them (four zero-filled fp32 grids + four scatters + four casts otherwise)
-        dg = ops.kp_gather_bwd(1, kp, dout * (1.0 / ng), B, kp.shape[1], gh, gw, D, sx, sy, img_h, img_w, patch, prefix=prefix)[0]
+        dg = ops.kp_gather_bwd(1, kp, dout * (1.0 / ng), B, kp.shape[1], gh, gw, D, sx, sy, img_h, img_w, patch, prefix=prefix,
+                               stride=stride)[0]
         if dg.dtype != T:
             dg = dg.to(T)
         return (None, None) + (dg,) * ng
 
 
-def kp_gather(grids, kp, gh, gw, sx, sy, img_h, img_w, patch):
+def kp_gather(grids, kp, gh, gw, sx, sy, img_h, img_w, patch, stride=None):
     """interpolate_features on token-major grids [B, prefix+gh*gw, D] (mean over the list) -> [B, Nk, D] fp32."""
-    return _GatherFn.apply(kp, (gh, gw, float(sx), float(sy), int(img_h), int(img_w), int(patch)), *grids)
+    return _GatherFn.apply(kp, (gh, gw, float(sx), float(sy), int(img_h), int(img_w), int(patch),
+                                int(patch if stride is None else stride)), *grids)

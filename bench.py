@@ -2,16 +2,25 @@
 """Benchmark of the geometric-distillation student step (BASELINE.json metric: image-pairs/s at 518^2,
 ViT-B/14 + LoRA) on N MI355X GPUs of one node.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, 1 rank/GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 without WORLD_SIZE in the environment: this process only LAUNCHES `python -m torch.distributed.run --nproc-per-node N
+bench.py ...` as a child (before any GPU call) and exits with its code — one rank per GPU over RCCL; under torchrun
+(WORLD_SIZE set) it is a rank.  The reference's counterpart is Lightning DDP with devices=-1 (src/main.py:147-151).
 
 A "step" = one pass of the hot path over one batch of synthetic pairs per GPU: student ViT forward (one
 shared 37x37-token forward per image, taps 4-7 + final), the three distillation losses against synthetic
 teacher targets, backward through LoRA/adapters/refine_conv/depth head, flat-gradient all-reduce (N>1), global-norm
 clip + AdamW.  Inputs are resident in HBM before the timed region.  Prints ONE JSON line (rank 0).
 
-Extra objects on the line: `roofline` for the dominant kernel (gemm_nt, MFMA-bound) from HIP events recorded
-around every launch inside the timed region; `roofline_cost_volume` (HBM-bound fused cost-volume KL, timed on
-its own after the run); `cpu_baseline` = the CPU oracle (oracle/gd_oracle.py) on a bounded sample, rank 0 / N=1 only.
+Extra objects on the line:
+  roofline              the dominant kernel (persistent gemm_nt, MFMA-bound) from HIP events around every launch in the timed region
+  roofline_cost_volume  the HBM-bound fused cost-volume KL, timed on its own after the run
+  parity                engine loss vs the CPU oracle (oracle/gd_oracle.py, fp32) on the same weights and the same pairs
+  f32                   the same workload on the f32 engine (the reference's arithmetic precision), measured in the same run
+  other_configs         short runs of BASELINE configs 3 / 5-like and of the reference's own token geometry
+  comm                  N > 1: all-reduce time of the two gradient chunks and the exposed fraction of the step
+  cpu_baseline          the CPU oracle on a bounded sample of the same workload, rank 0 / N=1 only
 """
 import argparse
 import json
@@ -26,6 +35,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+PATCH = 14
 
 
 def parse():
@@ -33,13 +43,16 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default=None, help="a reference yaml (config/finetune_timm_*.yaml): variant and loss "
+                    "weights are taken from it (gd_amd.config); explicit flags below win")
     ap.add_argument("--pairs-per-gpu", type=int, default=32)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--variant", default="mast3r", choices=["mast3r", "vggt"])
-    ap.add_argument("--backbone", default="vit_base")
+    ap.add_argument("--variant", default=None, choices=["mast3r", "vggt"])
+    ap.add_argument("--backbone", default=None)
     ap.add_argument("--img", type=int, default=518)
     ap.add_argument("--keypoints", type=int, default=300)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle legs (parity + cpu_baseline)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the f32 / other_configs companion measurements")
     ap.add_argument("--geometry", default="shared", choices=["shared", "reference"],
                     help="shared: one 37x37-token forward per image feeds all extractors (BASELINE headline); reference: the "
                          "reference's geometry (80x80-token forwards for the keypoint features + the teacher-grid forward)")
@@ -50,6 +63,19 @@ def parse():
     return ap.parse_args()
 
 
+def launch_ranks(args):
+    """--gpus N from a plain shell: start the N ranks as a child job and relay its exit code.  Nothing in this process has
+    touched the GPU yet (and it never will): a process that initialised HIP must not be re-exec'ed."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
 def vit_flops_per_image(D, L, Nt, P, La, r=4, bott=64):
     """Algorithmic FLOPs: forward all L blocks + patch embed; backward dX only through the La adapted blocks."""
     fwd = L * (24 * Nt * D * D + 4 * Nt * Nt * D) + 2 * (Nt - 1) * D * 3 * P * P + La * 4 * Nt * D * bott + La * 8 * Nt * D * r
@@ -57,166 +83,272 @@ def vit_flops_per_image(D, L, Nt, P, La, r=4, bott=64):
     return fwd, bwd
 
 
+def flops_per_pair(eng, hw, geometry):
+    D, L = eng.embedding_dim, len(eng.model.blocks)
+    fwd, bwd = vit_flops_per_image(D, L, hw + 1, PATCH, L - 4)
+    fl = 2 * (fwd + bwd)
+    if geometry == "reference":   # + the two 80x80-token forwards / backwards per image
+        f2, b2 = vit_flops_per_image(D, L, (eng.target_res // eng.downsample_factor) ** 2 + 1, PATCH, L - 4)
+        fl += 2 * 2 * (f2 + b2)
+    return fl
+
+
+def barrier(world):
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+
+
+class Job:
+    """One engine + its resident synthetic batches + the gradient exchange: `step(i)` is the timed unit."""
+
+    def __init__(self, backbone, variant, dtype, geometry, P, img, N, dev, rank, world, vit_kwargs=None, weights=None):
+        from gd_amd import dp
+        from gd_amd.finetune import FinetuneGD
+        from gd_testutil import synthetic_batch
+        self.hw = (img // PATCH) ** 2
+        self.P, self.world, self.geometry, self.dtype = P, world, geometry, dtype
+        self.eng = FinetuneGD(r=4, backbone=backbone, patch_size=PATCH, img_size=img, variant=variant, geometry=geometry,
+                              dtype=dtype, teacher_patch=PATCH, lora_b_std=1e-3,
+                              vit_kwargs=dict(init_values=1.0) if vit_kwargs is None else vit_kwargs, **(weights or {})).to(dev)
+        flat = self.eng.configure_optimizers()
+        # gradient exchange in two chunks: refine_conv + depth head from grad hooks (under the ViT backward), the rest after it
+        early = list(self.eng.refine_conv.parameters()) + list(self.eng.depth_diff_head.parameters())
+        self.reducer = dp.OverlappedGradReducer(self.eng.trainable_parameters(), flat["views"], flat["g"], early, world)
+        self.reducer.attach()
+        self.flat = flat
+        # a few distinct synthetic batches per rank (seed 1234 + 1000*rank + i), resident on the device
+        self.batches = [synthetic_batch(P, img, img, N, self.hw, dev, seed=1234 + 1000 * rank + i, teacher_patch=PATCH)
+                        for i in range(2)]
+
+    def step(self, i):
+        return self.eng.fit_step(self.batches[i % len(self.batches)], self.reducer)[0]
+
+    def timed(self, steps, warmup, dev, prof=None):
+        """-> (seconds for `steps` steps = max over ranks, last loss); barrier + synchronize on both sides."""
+        from gd_amd import dp, ops
+        for i in range(warmup):
+            self.step(i)
+        barrier(self.world)
+        if prof is not None:
+            ops.set_gemm_profiler(prof)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            loss = self.step(i)
+        barrier(self.world)
+        dt = time.perf_counter() - t0
+        ops.set_gemm_profiler(None)
+        return dp.max_over_ranks(dt, dev), loss
+
+
+def gemm_roofline(prof, dtype, dt, steps):
+    # the dominant kernel: the 256x256 persistent MFMA kernel (bf16: every gd_gemm_nt launch with M >= 1024, N >= 256);
+    # the N <= 8 LoRA projections run on an HBM-bound streaming kernel and are not part of this figure
+    big = (lambda t: t[0] >= 1024 and t[1] >= 256 and t[6] == "bfloat16" and "+" not in t[4]) if dtype == "bf16" else None
+    fl, ms, n = prof.totals(big)
+    ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    kname = "gemm_nt_persist_kernel<bf16> (256x256 persistent tile kernel, all epilogue instantiations)" if dtype == "bf16" \
+        else "gemm_nt_kernel<float> (128x128 tiles, exact-f32 MFMA v_mfma_f32_16x16x4_f32)"
+    return {"kernel": kname, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_TFLOPS[dtype], 4), "traffic": None, "launches": n,
+            "avg_launch_us": round(ms / max(n, 1) * 1e3, 2), "share_of_step": round(ms / (dt * 1e3), 3)}
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     import gd_amd  # noqa: F401
+    from gd_amd import config as gd_config
     from gd_amd import dp, ops
-    from gd_amd.finetune import FinetuneGD
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from gd_testutil import synthetic_batch
+
+    cfg = gd_config.load(args.config) if args.config else gd_config.preset("finetune_timm_mast3r_objaverse")
+    variant = args.variant or cfg["variant"]
+    backbone = args.backbone or "vit_base"
+    weights = {k: cfg[k] for k in ("ap_loss_weight", "depth_loss_weight", "intra_depth_loss_weight", "kl_loss_weight") if k in cfg}
+    if args.variant and args.variant != cfg["variant"]:   # a different trainer: its own default weights, not the yaml's
+        weights = {}
 
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     ndev = torch.cuda.device_count()
     if args.backend == "gloo":      # functional check only: every rank may share device 0
         os.environ["LOCAL_RANK"] = str(int(os.environ.get("LOCAL_RANK", "0")) % ndev)
     rank, local, world = dp.init_from_env(backend=args.backend)
+    assert world == args.gpus, f"--gpus {args.gpus} but the launcher started {world} ranks"
     local = local % ndev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     P, img, N = args.pairs_per_gpu, args.img, args.keypoints
-    patch = 14
-    hw = (img // patch) ** 2
 
-    eng = FinetuneGD(r=4, backbone=args.backbone, patch_size=patch, img_size=img, variant=args.variant,
-                     geometry=args.geometry, dtype=args.dtype, teacher_patch=patch, lora_b_std=1e-3,
-                     vit_kwargs=dict(init_values=1.0)).to(dev)
-    flat = eng.configure_optimizers()
-    # gradient exchange in two chunks: refine_conv + depth head from grad hooks (under the ViT backward), the rest after it
-    early = list(eng.refine_conv.parameters()) + list(eng.depth_diff_head.parameters())
-    reducer = dp.OverlappedGradReducer(eng.trainable_parameters(), flat["views"], flat["g"], early, world)
-    reducer.attach()
-    # a few distinct synthetic batches per rank (seed 1234 + 1000*rank + i), resident on the device
-    batches = [synthetic_batch(P, img, img, N, hw, dev, seed=1234 + 1000 * rank + i, teacher_patch=patch) for i in range(2)]
-
-    def step(i):
-        loss, terms = eng.training_step(batches[i % len(batches)])
-        eng.backward(loss, pre_gather=reducer.wait_early)   # gradients land in the flat buffer through one multi-tensor copy
-        reducer.start()
-        scale = reducer.finish()
-        eng.optimizer_step(grad_scale=scale)
-        return loss
-
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    for i in range(args.warmup):
-        step(i)
+    job = Job(backbone, variant, args.dtype, args.geometry, P, img, N, dev, rank, world, weights=weights)
+    eng, hw = job.eng, job.hw
     prof = None if args.no_kernel_events else ops.GemmProfiler()
-    barrier()
-    if prof:
-        ops.set_gemm_profiler(prof)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = step(i)
-    barrier()
-    dt = time.perf_counter() - t0
-    ops.set_gemm_profiler(None)
-    dt = dp.max_over_ranks(dt, dev)
+    dt, loss = job.timed(args.steps, args.warmup, dev, prof)
     pairs_per_s = P * world * args.steps / dt
+
+    comm = comm_report(job, args, dev, dt) if world > 1 else None
 
     out = None
     if rank == 0:
-        D = eng.embedding_dim
-        L = len(eng.model.blocks)
-        Nt = hw + 1
-        fwd, bwd = vit_flops_per_image(D, L, Nt, patch, L - 4)
-        flop_pair = 2 * (fwd + bwd)
-        if args.geometry == "reference":   # + the two 80x80-token forwards / backwards per image
-            f2, b2 = vit_flops_per_image(D, L, (eng.target_res // eng.downsample_factor) ** 2 + 1, patch, L - 4)
-            flop_pair += 2 * 2 * (f2 + b2)
+        flop_pair = flops_per_pair(eng, hw, args.geometry)
         out = {"metric": "image-pairs/sec (518^2, ViT-B/14 LoRA) student distillation step", "value": round(pairs_per_s, 3),
                "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-               "config": {"workload": f"finetune_timm_{args.variant}_objaverse: {args.backbone}/14 + LoRA(r=4,q,v)+adapters "
-                                      f"blocks 4-11, {img}^2 pairs, {'shared-518' if args.geometry == 'shared' else 'reference (80x80-token)'} geometry, {args.variant} losses "
+               "config": {"workload": f"{cfg['name']}: {backbone}/14 + LoRA(r=4,q,v)+adapters "
+                                      f"blocks 4-11, {img}^2 pairs, {'shared-518' if args.geometry == 'shared' else 'reference (80x80-token)'} geometry, {variant} losses "
                                       f"(AP+depth+intra+cost-KL), {P} pairs/GPU, {N} keypoints/pair, hw={hw}",
-                          "pairs_per_gpu": P, "global_pairs": P * world, "parallelism": f"dp{world}"},
+                          "pairs_per_gpu": P, "global_pairs": P * world, "parallelism": f"dp{world}",
+                          "world_size_seen": world, "backend": args.backend or "nccl (RCCL)"},
                "loss": round(float(loss.detach()), 6),
                "vit_algorithmic_tflops": round(pairs_per_s / world * flop_pair / 1e12, 2),
                "vit_frac_of_mfma_peak": round(pairs_per_s / world * flop_pair / 1e12 / PEAK_TFLOPS[args.dtype], 4)}
         if prof:
-            # the dominant kernel: the 256x256 persistent MFMA kernel (bf16: every gd_gemm_nt launch with M >= 1024, N >= 256);
-            # the N <= 8 LoRA projections run on an HBM-bound streaming kernel and are not part of this figure
-            big = (lambda t: t[0] >= 1024 and t[1] >= 256 and t[6] == "bfloat16" and "+" not in t[4]) if args.dtype == "bf16" else None
-            fl, ms, n = prof.totals(big)
-            ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            kname = "gemm_nt_persist_kernel<bf16> (256x256 persistent tile kernel, all epilogue instantiations)" if args.dtype == "bf16" \
-                else f"gd_gemm_nt<{args.dtype}> (gemm_nt_kernel)"
-            out["roofline"] = {"kernel": kname, "bound": "mfma", "achieved": round(ach, 2),
-                               "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
-                               "frac": round(ach / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
-                               "launches": n, "avg_launch_us": round(ms / max(n, 1) * 1e3, 2),
-                               "share_of_step": round(ms / (dt * 1e3), 3)}
-            # memory-side bytes per launch: PMC counters cannot be read from inside the timed run, so this is the committed
+            out["roofline"] = gemm_roofline(prof, args.dtype, dt, args.steps)
+            # memory-side bytes per launch: PMC counters cannot be read from inside the timed run, so this REPLAYS the committed
             # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE measurement of this same command (profiles/README.md), default workload only
             pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemm_traffic.json")
-            if (os.path.exists(pmc) and args.dtype == "bf16" and args.backbone == "vit_base" and P == 32
-                    and args.geometry == "shared" and args.variant == "mast3r"):
+            if (os.path.exists(pmc) and args.dtype == "bf16" and backbone == "vit_base" and P == 32
+                    and args.geometry == "shared" and variant == "mast3r"):
                 with open(pmc) as fh:
                     t = json.load(fh)
                 out["roofline"]["traffic"] = round(t["hbm_side_mb_per_launch"] * 1e6)
-                out["roofline"]["traffic_source"] = "profiles/r01_pmc_gemm_traffic.json (2 x FETCH_SIZE + WRITE_SIZE per persistent-kernel launch, separate --pmc passes)"
+                out["roofline"]["traffic_replayed_from"] = ("profiles/r01_pmc_gemm_traffic.json (2 x FETCH_SIZE + WRITE_SIZE per "
+                                                            "persistent-kernel launch, separate --pmc passes; NOT measured in this run)")
             if args.gemm_shapes:
                 for k, (cnt, sms, tf) in sorted(prof.by_shape().items(), key=lambda kv: -kv[1][1]):
                     print(f"gemm_nt {str(k):58s} x{cnt:4d} {sms / args.steps:8.3f} ms/step {tf:7.1f} TF/s", file=sys.stderr)
-        # ---- cost-volume kernel on its own (HBM-bound; algorithmic bytes per SURVEY 8d) ----
-        es = 2 if args.dtype == "bf16" else 4
-        b = batches[0]
-        Tt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-        f1 = torch.randn(P, hw, D, device=dev).to(Tt).requires_grad_(True)
-        f2 = torch.randn(P, hw, D, device=dev).to(Tt).requires_grad_(True)
-        m1 = torch.rand(P, hw, device=dev) > 0.3
-        m2 = torch.rand(P, hw, device=dev) > 0.3
-
-        def cv_fwd():
-            with torch.no_grad():
-                return ops.cost_volume_kl(f1, f2, b["cost_1"], b["cost_2"], m1, m2, args.variant)
-
-        def cv_fb():
-            f1.grad = f2.grad = None
-            ops.cost_volume_kl(f1, f2, b["cost_1"], b["cost_2"], m1, m2, args.variant).sum().backward()
-        tf = ops.time_on_stream(cv_fwd, 2, 5)
-        tfb = ops.time_on_stream(cv_fb, 2, 5)
-        fwd_bytes = P * (2 * hw * D * es + 2 * hw * hw * 4 + 2 * hw)
-        bwd_bytes = fwd_bytes + P * 2 * hw * D * es
-        out["roofline_cost_volume"] = {"kernel": "cost_volume_kl fwd (cv_prep + cv_fwd_tile + cv_finalize)", "bound": "hbm",
-                                       "achieved": round(fwd_bytes / tf / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                       "frac": round(fwd_bytes / tf / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
-                                       "us_per_pair_fwd": round(tf / P * 1e6, 2),
-                                       "fwd_bwd_GBps": round((fwd_bytes + bwd_bytes) / tfb / 1e9, 1),
-                                       "us_per_pair_fwd_bwd": round(tfb / P * 1e6, 2)}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(eng, batches[0], args)
+        out["roofline_cost_volume"] = cost_volume_roofline(job, args, dev, variant)
+        if comm:
+            out["comm"] = comm
+        if not args.no_cpu_baseline:
+            par, base = parity_and_cpu_baseline(job, args)
+            out["parity"] = par
+            if world == 1:
+                out["cpu_baseline"] = base
+    del job, eng
+    torch.cuda.empty_cache()
+    if not args.no_extras:
+        extras = companion_runs(args, variant, backbone, weights, dev, rank, world)
+        if rank == 0:
+            out.update(extras)
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
 
-def cpu_baseline(eng, batch, args):
-    """The CPU oracle (a port of the reference arithmetic) on ONE pair of the same workload, fp32, all host cores:
-    forward + backward of the three losses through the oracle ViT (checker code, timed beside — never inside — the product path)."""
+def cost_volume_roofline(job, args, dev, variant):
+    """The cost-volume kernel on its own (HBM-bound; algorithmic bytes per SURVEY 8d)."""
+    from gd_amd import ops
+    P, hw, D = job.P, job.hw, job.eng.embedding_dim
+    es = 2 if args.dtype == "bf16" else 4
+    b = job.batches[0]
+    Tt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    f1 = torch.randn(P, hw, D, device=dev).to(Tt).requires_grad_(True)
+    f2 = torch.randn(P, hw, D, device=dev).to(Tt).requires_grad_(True)
+    m1 = torch.rand(P, hw, device=dev) > 0.3
+    m2 = torch.rand(P, hw, device=dev) > 0.3
+
+    def cv_fwd():
+        with torch.no_grad():
+            return ops.cost_volume_kl(f1, f2, b["cost_1"], b["cost_2"], m1, m2, variant)
+
+    def cv_fb():
+        f1.grad = f2.grad = None
+        ops.cost_volume_kl(f1, f2, b["cost_1"], b["cost_2"], m1, m2, variant).sum().backward()
+    tf = ops.time_on_stream(cv_fwd, 2, 5)
+    tfb = ops.time_on_stream(cv_fb, 2, 5)
+    fwd_bytes = P * (2 * hw * D * es + 2 * hw * hw * 4 + 2 * hw)
+    bwd_bytes = fwd_bytes + P * 2 * hw * D * es
+    return {"kernel": "cost_volume_kl fwd", "bound": "hbm",
+            "achieved": round(fwd_bytes / tf / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": round(fwd_bytes / tf / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
+            "algorithmic_bytes_per_launch": fwd_bytes,
+            "us_per_pair_fwd": round(tf / P * 1e6, 2),
+            "fwd_bwd_GBps": round((fwd_bytes + bwd_bytes) / tfb / 1e9, 1),
+            "us_per_pair_fwd_bwd": round(tfb / P * 1e6, 2)}
+
+
+def comm_report(job, args, dev, dt):
+    """N > 1: stand-alone all-reduce time of the two gradient chunks and the share of the step the exchange exposes
+    (step time with the exchange switched off, same ranks, same inputs, measured right after the timed region)."""
+    import torch.distributed as dist
+    from gd_amd import dp
+    flat_g = job.flat["g"]
+    n_late = sum(b - a for a, b in job.reducer.late)
+    n_early = flat_g.numel() - n_late
+
+    def ar_ms(n):
+        buf = torch.zeros(n, dtype=torch.float32, device=dev)
+        for _ in range(2):
+            dist.all_reduce(buf)
+        barrier(job.world)
+        t0 = time.perf_counter()
+        for _ in range(10):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        return dp.max_over_ranks((time.perf_counter() - t0) / 10 * 1e3, dev)
+    early_ms, late_ms = ar_ms(n_early), ar_ms(n_late)
+    world = job.reducer.world
+    job.reducer.world = 1            # no collective is issued; the 1/world scale goes with it (timing only)
+    job.reducer.detach()
+    dt0, _ = job.timed(args.steps, 1, dev)
+    job.reducer.world = world
+    job.reducer.attach()
+    return {"allreduce_ms_early_chunk": round(early_ms, 3), "early_chunk_MB": round(n_early * 4 / 1e6, 2),
+            "allreduce_ms_late_chunk": round(late_ms, 3), "late_chunk_MB": round(n_late * 4 / 1e6, 2),
+            "ms_per_step_without_exchange": round(dt0 / args.steps * 1e3, 3),
+            "exposed_comm_frac": round(max(0.0, (dt - dt0) / dt), 4)}
+
+
+def physical_cores():
+    try:
+        seen = set()
+        phys = core = None
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("physical id"):
+                    phys = line.split(":")[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":")[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        seen.add((phys, core))
+                    phys = core = None
+        return len(seen) or None
+    except OSError:
+        return None
+
+
+def parity_and_cpu_baseline(job, args):
+    """The CPU oracle (a port of the reference arithmetic, fp32, host cores) on the first NS pairs of batch 0 with the
+    engine's CURRENT weights: (a) parity — the engine's per-pair loss terms on the same pairs and weights (checker only,
+    outside every timed region); (b) cpu_baseline — the oracle's forward + backward time per pair."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import gd_oracle as O
     import torch.nn.functional as F
     from gd_testutil import oracle_params
+    eng, batch = job.eng, job.batches[0]
+    with torch.no_grad():
+        _, terms = eng.training_step(batch)
+    terms = {k: v.float().cpu() for k, v in terms.items()}
     cores = min(os.cpu_count(), 32)       # torch CPU ops stop scaling (and oversubscribe) well before 256 threads
     torch.set_num_threads(cores)
     p, tr, refine, head, cfg = oracle_params(eng)
-    leaves = []
     for d in tr.values():
         for blk in d.values():
             for k in blk:
                 blk[k] = blk[k].requires_grad_(True)
-                leaves.append(blk[k])
     refine = {k: v.requires_grad_(True) for k, v in refine.items()}
     head = {k: v.requires_grad_(True) for k, v in head.items()}
     NS = min(4, batch["rgb_1"].shape[0])                      # bounded sample: NS pairs, ~10-15 s of host work
     weights = {"ap": eng.ap_loss_weight, "depth": eng.depth_loss_weight, "intra": eng.intra_depth_loss_weight,
                "kl": eng.kl_loss_weight}
+    names = (("ap_loss", "ap"), ("depth_loss", "depth"), ("intra_depth_loss", "intra"), ("kl_loss", "kl"))
+    worst_term, tot_hip, tot_ref = 0.0, 0.0, 0.0
     t0 = time.perf_counter()
     for q in range(NS):
         cb = {k: v[q:q + 1].detach().cpu() for k, v in batch.items()}
@@ -227,12 +359,58 @@ def cpu_baseline(eng, batch, args):
                "pts3d_1": cb["pts3d_1"], "pts3d_2": cb["pts3d_2"],
                "mask_patch_1": F.interpolate(cb["mask_1"][:, None].float(), size=(h // tp, w // tp), mode="nearest").bool().view(-1),
                "mask_patch_2": F.interpolate(cb["mask_2"][:, None].float(), size=(h // tp, w // tp), mode="nearest").bool().view(-1)}
-        terms = O.pair_losses(one, p, cfg, tr, refine, head)
-        (O.total_loss(terms, weights) / NS).backward()
+        ot = O.pair_losses(one, p, cfg, tr, refine, head)
+        ref = O.total_loss(ot, weights)
+        (ref / NS).backward()
+        tot_ref += ref.item()
+        tot_hip += sum(weights[b] * terms[a][q].item() for a, b in names)
+        for a, b in names:
+            if weights[b] != 0:
+                worst_term = max(worst_term, abs(terms[a][q].item() - ot[b].item()) / max(1e-3, abs(ot[b].item())))
     dt = (time.perf_counter() - t0) / NS
-    return {"value": round(1.0 / dt, 4), "unit": "image-pairs/s", "cores": cores, "kind": "port",
-            "sample": f"{NS} pairs of the same workload (fwd+bwd, fp32, oracle/gd_oracle.py, {cores} threads): "
-                      f"{dt:.1f} s per pair"}
+    rel = abs(tot_hip - tot_ref) / abs(tot_ref)
+    par = {"rel_err": float(f"{rel:.3e}"), "tol": 1e-3, "ok": bool(rel < 1e-3), "worst_term_rel_err": float(f"{worst_term:.3e}"),
+           "loss_hip": round(tot_hip / NS, 6), "loss_oracle": round(tot_ref / NS, 6), "engine_dtype": job.dtype,
+           "what": f"mean loss of {NS} pairs of the benched batch, engine (HIP, {job.dtype}) vs oracle/gd_oracle.py (CPU fp32), same weights"}
+    base = {"value": round(1.0 / dt, 4), "unit": "image-pairs/s", "cores": cores, "host_logical_cpus": os.cpu_count(),
+            "host_physical_cores": physical_cores(), "kind": "port",
+            "sample": f"{NS} pairs of the same workload (fwd+bwd, fp32, oracle/gd_oracle.py, {cores} threads): {dt:.1f} s per pair"}
+    return par, base
+
+
+def companion_runs(args, variant, backbone, weights, dev, rank, world):
+    """Short driver-observed runs beside the headline (same process, after it): the f32 engine on the SAME workload (the
+    reference's arithmetic precision), and — N = 1 only — ViT-L/14 with the VGGT losses (BASELINE config 3), a CLIP-style
+    pre-norm ViT-L/14 (config 5) and the reference's own token geometry."""
+    from gd_amd import ops
+    out = {}
+    P, img, N = args.pairs_per_gpu, args.img, args.keypoints
+
+    def run(bb, var, dtype, geometry, pairs, vit_kwargs=None, steps=2, prof=False, wts=None):
+        job = Job(bb, var, dtype, geometry, pairs, img, N, dev, rank, world, vit_kwargs=vit_kwargs, weights=wts)
+        pr = ops.GemmProfiler() if prof else None
+        dt, loss = job.timed(steps, 1, dev, pr)
+        fl = flops_per_pair(job.eng, job.hw, geometry)
+        pps = pairs * world * steps / dt
+        rec = {"value": round(pps, 3), "unit": "image-pairs/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+               "warmup": 1, "dtype": dtype, "pairs_per_gpu": pairs, "backbone": bb, "variant": var, "geometry": geometry,
+               "loss": round(float(loss.detach()), 6),
+               "vit_frac_of_mfma_peak": round(pps / world * fl / 1e12 / PEAK_TFLOPS[dtype], 4)}
+        if pr is not None:
+            rec["roofline"] = gemm_roofline(pr, dtype, dt, steps)
+        del job
+        torch.cuda.empty_cache()
+        return rec
+
+    if args.dtype != "f32":
+        out["f32"] = run(backbone, variant, "f32", args.geometry, P, prof=not args.no_kernel_events, wts=weights)
+    if world == 1 and args.geometry == "shared" and backbone == "vit_base":
+        out["other_configs"] = {
+            "vit_large_vggt": run("vit_large", "vggt", args.dtype, "shared", 16),
+            "prenorm_vit_large_all_losses": run("vit_large", "vggt", args.dtype, "shared", 16,
+                                                vit_kwargs=dict(pre_norm=True, ln_eps=1e-5, pos_interp="timm")),
+            "reference_geometry": run(backbone, variant, args.dtype, "reference", 8, wts=weights)}
+    return out
 
 
 if __name__ == "__main__":

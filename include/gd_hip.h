@@ -145,12 +145,45 @@ int gd_depth_l1(const float* u, const float* d1, const float* d2, const int* cou
                 int Nmax, const float* b1, const float* ln_w, const float* ln_b, const float* w2, const float* b2,
                 float* loss, float* du, float* head_grad, float* head_grad_sets, void* workspace, void* stream);
 
+/* Eager DepthAwareFeatureFusion.forward (utils/model.py:101-127, `depths=None` branch: fusion_layer + tanh) on rows already
+ * projected by its first Linear, u = W1 f [M,128] (gd_gemm_nt): out[m] = tanh(w2 . GELU(LayerNorm_128(u[m] + b1)) + b2).
+ * Backward: du [M,128] and head_grad[516] += {b1, ln_w, ln_b, w2, b2} gradients for the upstream dout [M]. */
+int gd_depth_head_fwd(const float* u, int M, const float* b1, const float* ln_w, const float* ln_b, const float* w2,
+                      const float* b2, float* out, void* stream);
+int gd_depth_head_bwd(const float* u, const float* dout, int M, const float* b1, const float* ln_w, const float* ln_b,
+                      const float* w2, const float* b2, float* du, float* head_grad, void* stream);
+
+/* Stand-alone forms of the reference's loss helpers, for callers that bind the reference's function names
+ * (gd_amd/compat.py); the training step uses the fused kernels above instead and never materialises these maps.
+ * gd_sigmoid_temp: utils/functions.py:24-33 sigmoid(tensor, temp): exponent = clamp(-x / temp, -50, 50), y = 1 / (1 + exp(.));
+ *   dy == NULL: out = y; dy != NULL: out = dy * dy/dx (zero where the clamp is active).
+ * gd_masked_patch_cost_{fwd,bwd}: utils/functions.py:402-422 get_masked_patch_cost(cost [B,rows,cols], mask_patch_1 [rows],
+ *   mask_patch_2 [cols] or NULL, eps, use_softmax, temperature); bwd takes the forward's output y.
+ * gd_kl_divergence_map_{fwd,bwd}: utils/losses.py:5-15 kl_divergence_map(t, p, eps) over `rows` rows of `cols` entries ->
+ *   loss[1]; row_ws: rows floats; bwd writes dt and / or dp (nullable) for the upstream scalar gloss[1]. */
+int gd_sigmoid_temp(const float* x, const float* dy, float* out, long n, float temp, void* stream);
+int gd_masked_patch_cost_fwd(const float* cost, const unsigned char* m1, const unsigned char* m2, float* out, int B,
+                             int rows, int cols, float eps, int use_softmax, float temperature, void* stream);
+int gd_masked_patch_cost_bwd(const float* cost, const float* y, const float* dy, const unsigned char* m1,
+                             const unsigned char* m2, float* dcost, int B, int rows, int cols, float eps,
+                             int use_softmax, float temperature, void* stream);
+int gd_kl_divergence_map_fwd(const float* t, const float* p, long rows, int cols, float eps, float* loss,
+                             float* row_ws, void* stream);
+int gd_kl_divergence_map_bwd(const float* t, const float* p, const float* gloss, long rows, int cols, float eps,
+                             float* dt, float* dp, void* stream);
+
 /* Lightning gradient_clip_val=1.0 (src/main.py:153) + torch.optim.AdamW (src/finetune_timm_vggt.py:642-648) on the
  * flat fp32 trainable buffer; grads are multiplied by grad_scale first. */
 size_t gd_adamw_workspace_bytes(void);
 int gd_clip_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, int step,
                        float lr, float weight_decay, float beta1, float beta2, float eps, float max_norm,
                        float grad_scale, float* grad_norm_out, void* workspace, void* stream);
+/* The same step restricted to n_ranges element ranges [ranges[2r], ranges[2r+1]) of the flat buffer (host array, range starts
+ * multiples of 4): elements outside them are left untouched — torch.optim.AdamW skips parameters whose .grad is None
+ * (depth_attention, utils/model.py:92-97: no moments, no weight decay); the clip norm is taken over the whole buffer. */
+int gd_clip_adamw_ranges(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, int step, float lr,
+                         float weight_decay, float beta1, float beta2, float eps, float max_norm, float grad_scale,
+                         float* grad_norm_out, void* workspace, const long* ranges, int n_ranges, void* stream);
 int gd_cast(const void* in, void* out, long n, float scale, int in_dtype, int out_dtype, void* stream);
 
 /* Teacher -> target glue on the device.

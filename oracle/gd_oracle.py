@@ -390,7 +390,10 @@ def student_features(img, kp, p, cfg, trainable, refine):
     samp = [interpolate_features(grid(final_norm(t, p, cfg)), pts, gh * P, gw * P, False, P, P) for t in taps]
     kp_feat = torch.stack(samp, 0).mean(0).permute(0, 2, 1)
     fmap = F.conv2d(grid(final_norm(x, p, cfg)), refine["weight"], refine["bias"], padding=1)
-    desc = F.normalize(interpolate_features(fmap, pts, gh * P, gw * P, False, P, P).permute(0, 2, 1), dim=-1)
+    # the ME trainer calls interpolate_features(feature, pts, h=patch_h * 14, w=patch_w * 14) with the default
+    # patch_size = stride = 14 (src/finetune_timm_me.py:155); the other two pass the model's patch size
+    Pi = 14 if cfg["variant"] == "me" else P
+    desc = F.normalize(interpolate_features(fmap, pts, gh * Pi, gw * Pi, False, Pi, Pi).permute(0, 2, 1), dim=-1)
 
     tp = cfg["teacher_patch"]
     ch, cw = h // tp, w // tp
@@ -424,6 +427,14 @@ def pair_losses(batch, p, cfg, trainable, refine, hp):
     kl = cost_volume_kl(f1[2], f2[2], batch["cost_1"], batch["cost_2"], m1, m2, cfg["variant"])
     ap = smooth_ap_loss(f1[1], f2[1], batch["pts3d_1"], batch["pts3d_2"], cfg["variant"])
     return {"ap": ap, "depth": depth_l1, "intra": intra, "kl": kl}
+
+
+def me_pair_loss(batch, p, cfg, trainable, refine, thres3d_pos=5e-3, thres3d_neg=0.1):
+    """FinetuneTIMM.training_step (src/finetune_timm_me.py:191-220): get_feature on both views, then the smooth-AP loss
+    with dynamic positives (every keypoint pair closer than thres3d_pos in 3-D)."""
+    d1 = student_features(batch["rgb_1"], batch["kp_1"], p, cfg, trainable, refine)[1]
+    d2 = student_features(batch["rgb_2"], batch["kp_2"], p, cfg, trainable, refine)[1]
+    return smooth_ap_loss_me(d1, d2, batch["pts3d_1"], batch["pts3d_2"], thres3d_pos, thres3d_neg)
 
 
 def total_loss(terms, weights):
