@@ -88,9 +88,10 @@ SIGNATURES = {
     "gd_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                  c_int, c_float, c_int, c_int, c_void_p]),
     "gd_cost_volume_kl_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
-    "gd_cost_volume_kl_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
-                                      c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "gd_cost_volume_kl_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+    "gd_cost_volume_teacher_stats": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "gd_cost_volume_kl_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                      c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gd_cost_volume_kl_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
                                       c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 

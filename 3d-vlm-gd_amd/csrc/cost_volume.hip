@@ -18,6 +18,7 @@
 // NT GEMMs (G b and G^T a), then cv_norm_bwd pulls the gradient through the L2 normalisation.
 #include "gd_common.h"
 #include "gemm_tile.h"
+#include <stdlib.h>
 
 extern "C" int gd_gemm_nt(const void* A, const void* W, void* C, int M, int N, int K, long lda, long ldw, long ldc,
                           int batch, long sA, long sW, long sC, int ab_dtype, int c_dtype, float alpha,
@@ -28,20 +29,20 @@ extern "C" int gd_gemm_nt(const void* A, const void* W, void* C, int M, int N, i
 #define CV_EPS 1e-8f
 
 
-// stats layout: [P][2][hw][4] = {inv_norm, teacher_rowsum(clamped), logZ, W};  wa: [P][2][hw][2] = {W, A}.
-// One wave per (pair, view, row).  The teacher row is read ONCE into registers (coalesced 4-byte loads: rows are only
-// 4-byte aligned, hw is odd), summed, and — now that 1/rowsum is known — swept again from the registers for the two
-// row statistics that do not involve the student at all:  W = sum_j t,  A = sum_j t log t,  t = max(T / rowsum, 1e-8).
-// (They used to be accumulated per 128 x 128 tile next to the S-dependent terms: one v_log per element per direction.)
+// stats layout: [P][2][hw][4] = {inv_norm, teacher_rowsum(clamped), logZ, W};  tstats: [P][2][hw][4] = {rowsum(clamped), W, A, 0}.
+// Teacher maps are [P][hw][ldt] (row stride ldt >= hw elements; ldt % 4 == 0 makes every row 16-byte aligned).
+//
+// cv_tstats: everything about a teacher row that does not involve the student — it depends on the teacher data only, so
+// a caller that caches the targets of a pair computes it ONCE (gd_cost_volume_teacher_stats) and the step then reads each
+// teacher map a single time.  One wave per (pair, view, row): the row is read ONCE into registers (coalesced dword loads),
+// summed, and — now that 1/rowsum is known — swept again from the registers for  W = sum_j t,  A = sum_j t log t,
+// t = max(T / rowsum, 1e-8).
 #define CV_TROW_MAX 24   // registers per lane for a teacher row: hw <= 1536; longer rows take a second pass over memory
-__global__ __launch_bounds__(256) void cv_prep_kernel(const void* f1, const void* f2, const float* t1,
-                                                      const float* t2, float* stats, float* wa, int hw, int C, int dtype) {
+__global__ __launch_bounds__(256) void cv_tstats_kernel(const float* t1, const float* t2, float* tstats, int hw, int ldt) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave, which = blockIdx.y, p = blockIdx.z;
     if (row >= hw) return;
-    const void* f = which ? f2 : f1;
-    const float* t = (which ? t2 : t1) + ((long)p * hw + row) * hw;
-    const long fo = ((long)p * hw + row) * C;
+    const float* t = (which ? t2 : t1) + ((long)p * hw + row) * ldt;
     const bool inreg = hw <= 64 * CV_TROW_MAX;
     float tv[CV_TROW_MAX];
     float rs = 0.f;
@@ -55,22 +56,6 @@ __global__ __launch_bounds__(256) void cv_prep_kernel(const void* f1, const void
     } else {
         for (int j = lane; j < hw; j += 64) rs += t[j];
     }
-    float ss = 0.f;
-    if (dtype == GD_BF16) {
-        const bf16x8* fv = (const bf16x8*)((const bf16*)f + fo);
-        for (int c = lane; c < C / 8; c += 64) {
-            const bf16x8 v = fv[c];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) ss += (float)v[k] * (float)v[k];
-        }
-    } else {
-        const f32x4* fv = (const f32x4*)((const float*)f + fo);
-        for (int c = lane; c < C / 4; c += 64) {
-            const f32x4 v = fv[c];
-            ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
-        }
-    }
-    ss = wave_sum(ss);
     rs = fmaxf(wave_sum(rs), CV_EPS);
     const float ir = 1.0f / rs;
     float W = 0.f, A = 0.f;
@@ -89,19 +74,45 @@ __global__ __launch_bounds__(256) void cv_prep_kernel(const void* f1, const void
         }
     }
     W = wave_sum(W); A = wave_sum(A);
+    if (lane == 0) *(f32x4*)(tstats + (((long)p * 2 + which) * hw + row) * 4) = f32x4{rs, W, A, 0.f};
+}
+
+// inverse L2 norms of the student feature rows (+ the teacher row sum copied next to them: the tile kernels read one
+// float4 per row / column).  One wave per (pair, view, row).
+__global__ __launch_bounds__(256) void cv_norm_kernel(const void* f1, const void* f2, const float* tstats, float* stats, int hw,
+                                                      int C, int dtype) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave, which = blockIdx.y, p = blockIdx.z;
+    if (row >= hw) return;
+    const void* f = which ? f2 : f1;
+    const long fo = ((long)p * hw + row) * C;
+    float ss = 0.f;
+    if (dtype == GD_BF16) {
+        const bf16x8* fv = (const bf16x8*)((const bf16*)f + fo);
+        for (int c = lane; c < C / 8; c += 64) {
+            const bf16x8 v = fv[c];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) ss += (float)v[k] * (float)v[k];
+        }
+    } else {
+        const f32x4* fv = (const f32x4*)((const float*)f + fo);
+        for (int c = lane; c < C / 4; c += 64) {
+            const f32x4 v = fv[c];
+            ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        }
+    }
+    ss = wave_sum(ss);
     if (lane == 0) {
-        float* o = stats + (((long)p * 2 + which) * hw + row) * 4;
-        o[0] = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
-        o[1] = rs;
-        float* w2 = wa + (((long)p * 2 + which) * hw + row) * 2;
-        w2[0] = W; w2[1] = A;
+        const long o = (((long)p * 2 + which) * hw + row) * 4;
+        stats[o] = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+        stats[o + 1] = tstats[o];
     }
 }
 
 struct CvTileParams {
     const void* f1; const void* f2; const float* t1; const float* t2;
     float* stats; float* part1; float* part2;
-    int hw, C, tiles, nslab;
+    int hw, C, tiles, nslab, ldt, P;
     // backward only
     const unsigned char* m1; const unsigned char* m2; const float* gloss;
     void* G1; void* G2; int hwp;
@@ -183,8 +194,9 @@ __global__ __launch_bounds__(256, 2) void cv_fwd_tile_kernel(CvTileParams q) {
     const int p = blockIdx.y, hw = q.hw;
     const int wg = xcd_remap(blockIdx.x, q.tiles * q.tiles);
     const int tm = wg / q.tiles, tn = wg % q.tiles;
-    const float* T1 = q.t1 + (long)p * hw * hw;
-    const float* T2 = q.t2 + (long)p * hw * hw;
+    const int ldt = q.ldt;
+    const float* T1 = q.t1 + (long)p * hw * ldt;
+    const float* T2 = q.t2 + (long)p * hw * ldt;
     f32x4* sSt = (f32x4*)(smem + CV_RING);
     float* sZr = (float*)(smem + CV_RING + 4096);   // [2 (wn)][128 rows]
     float* sZc = sZr + 256;                          // [2 (wm)][128 columns]
@@ -195,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void cv_fwd_tile_kernel(CvTileParams q) {
     for (int st = 0; st < 8; ++st) {
         const int row = tm * 128 + wave * 32 + st * 4 + g;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) t1v[st][h] = cv_ld4(T1, (long)row * hw, tn * 128 + h * 64 + 4 * c, hw, row < hw);
+        for (int h = 0; h < 2; ++h) t1v[st][h] = cv_ld4(T1, (long)row * ldt, tn * 128 + h * 64 + 4 * c, hw, row < hw);
     }
     f32x4 acc[4][4];
     cv_s_tile<T>(q, p, tm, tn, smem, sSt, acc);     // ends with a barrier: the ring is free
@@ -235,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void cv_fwd_tile_kernel(CvTileParams q) {
         const int jl = wave * 32 + st * 4 + g, trow = tn * 128 + jl;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
-            t2v[st][h] = cv_ld4(T2, (long)trow * hw, tm * 128 + h * 64 + 4 * (c ^ (jl & 15)), hw, trow < hw);
+            t2v[st][h] = cv_ld4(T2, (long)trow * ldt, tm * 128 + h * 64 + 4 * (c ^ (jl & 15)), hw, trow < hw);
     }
     __syncthreads();
     // ---- direction 1: B = sum_j t s over the tile's columns, rows wave*32 .. +32 ----
@@ -254,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void cv_fwd_tile_kernel(CvTileParams q) {
         }
         B = row16_sum(B);
         if (c == 0 && row < hw)
-            *(f32x4*)(q.part1 + (((long)p * q.nslab + tn) * hw + row) * 4) = f32x4{sZr[rl] + sZr[128 + rl], 0.f, 0.f, B};
+            *(f32x2*)(q.part1 + (((long)p * q.nslab + tn) * hw + row) * 2) = f32x2{sZr[rl] + sZr[128 + rl], B};
     }
     __syncthreads();
     // ---- S^T into the same LDS: lane (g, c) owns rows 4g..4g+3 of m-tile i for its column: one b128 per (i, j) ----
@@ -283,13 +295,255 @@ __global__ __launch_bounds__(256, 2) void cv_fwd_tile_kernel(CvTileParams q) {
         }
         B = row16_sum(B);
         if (c == 0 && col < hw)
-            *(f32x4*)(q.part2 + (((long)p * q.nslab + tm) * hw + col) * 4) = f32x4{sZc[jl] + sZc[128 + jl], 0.f, 0.f, B};
+            *(f32x2*)(q.part2 + (((long)p * q.nslab + tm) * hw + col) * 2) = f32x2{sZc[jl] + sZc[128 + jl], B};
     }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// PERSISTENT forward (the default for K rows that are a multiple of 128 bytes).  The tile kernel above serialises its
+// three resources — teacher loads, LDS-DMA feature stages and the epilogue sweeps sit in ONE in-order vector-memory
+// queue per wave, and the S tile is parked in LDS twice.  Here the roles are split over the waves of one 768-thread
+// block per CU that walks its XCD's share of the (pair, tile) space:
+//   * 4 LOADER waves own the LDS-DMA: a 4-slot ring of 128-byte K-steps (A 128 rows + B 128 rows = 32 KB per slot) keeps
+//     three steps in flight ACROSS tile boundaries (the next tile's first steps are already landing during the current
+//     epilogue), the tile's row / column statistics ride along as one more DMA piece, and the loaders also carry the
+//     previous tile's partial sums from LDS to the slabs — they issue nothing but DMA and stores, so counted
+//     `s_waitcnt vmcnt(16)` is all their synchronisation with memory;
+//   * 8 COMPUTE waves (4 x 2, wave tile 32 x 64) run the MFMAs and then the whole epilogue FROM THE ACCUMULATORS: the
+//     teacher tiles are loaded straight into the accumulator layout — direction 2 (tile column = teacher row) as one
+//     16-byte load per 16x16 block (four consecutive rows of S are four consecutive entries of the teacher row), direction 1
+//     as dword loads whose 16 lanes cover a 64-byte row segment — one tile AHEAD: a wave re-issues its teacher loads
+//     right after the epilogue that consumed the registers, and they land under the next main loop.  Nothing but
+//     teacher loads is in a compute wave's vector-memory queue, so they never sit in front of a feature stage.
+//     S never touches LDS; per element: one v_exp (both directions' Z), and max + fma per direction.
+//   One s_barrier per K-step joins all 12 waves (step n landed / slot n-1 free); the epilogue has none.
+// ---------------------------------------------------------------------------------------------------
+#define CVP_SLOTS 4
+#define CVP_STAGE 32768
+#define CVP_STAT_OFF (CVP_SLOTS * CVP_STAGE)            // 2 x 256 float4 (tile parity)
+#define CVP_PART_OFF (CVP_STAT_OFF + 2 * 4096)          // 2 x 1536 floats: rowsZ[2][128] rowsB[2][128] colsZ[4][128] colsB[4][128]
+#define CVP_SMEM (CVP_PART_OFF + 2 * 6144)
+
+__device__ __forceinline__ void cvp_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ float cvp_lds_f32(unsigned addr) {
+    float v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+
+struct CvpTile { int p, tm, tn; };
+__device__ __forceinline__ CvpTile cvp_tile(int l, int tiles) {
+    const int t2 = tiles * tiles;
+    CvpTile t;
+    t.p = l / t2;
+    const int r = l - t.p * t2;
+    t.tm = r / tiles;
+    t.tn = r - t.tm * tiles;
+    return t;
+}
+
+template <typename T>
+__global__ __launch_bounds__(768) void cv_fwd_persist_kernel(CvTileParams q) {
+    __shared__ __attribute__((aligned(16))) char smem[CVP_SMEM];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hw = q.hw, tiles = q.tiles, ldt = q.ldt;
+    const long rowb = (long)q.C * sizeof(T);
+    const int nk = (int)(rowb / 128);
+    // this block's share: XCD x (blocks b and b + 8 share one) takes a contiguous range of the pair-major tile list, its
+    // blocks stride through it — the ~32 tiles in flight on an XCD belong to one or two pairs: their features stay in its L2
+    const int total = q.P * tiles * tiles, nbx = gridDim.x >> 3, xc = blockIdx.x & 7, kb = blockIdx.x >> 3;
+    const int qT = total >> 3, rT = total & 7;
+    const int beg = xc < rT ? xc * (qT + 1) : rT * (qT + 1) + (xc - rT) * qT;
+    const int cnt = qT + (xc < rT ? 1 : 0);
+    const int n_tiles = cnt > kb ? (cnt - kb + nbx - 1) / nbx : 0;
+    if (n_tiles == 0) return;
+    const int n_total = n_tiles * nk;
+    const unsigned smem_base = (unsigned)(uintptr_t)smem;      // LDS byte address of the block's array (generic -> LDS offset)
+
+    if (wave >= 8) {
+        // ======================================= LOADER waves =======================================
+        const int lw = wave - 8;
+        const char* asrc[4];
+        const char* wsrc[4];
+        const char* ssrc = nullptr;
+        int it_i = 0, k_i = 0;                 // (tile, K-step) of the next step to issue
+        auto issue = [&](int n) {
+            char* sA = smem + (n & (CVP_SLOTS - 1)) * CVP_STAGE;
+            char* sB = sA + 128 * 128;
+            if (k_i == 0) {
+                const CvpTile t = cvp_tile(beg + kb + it_i * nbx, tiles);
+                const char* Ab = (const char*)q.f1 + (long)t.p * hw * rowb;
+                const char* Wb = (const char*)q.f2 + (long)t.p * hw * rowb;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = (lw * 4 + i) * 8 + (lane >> 3);
+                    asrc[i] = Ab + (long)min(t.tm * 128 + row, hw - 1) * rowb + (((lane & 7) ^ swz(row)) * 16);
+                    wsrc[i] = Wb + (long)min(t.tn * 128 + row, hw - 1) * rowb + (((lane & 7) ^ swz(row)) * 16);
+                }
+                const int e = lw * 64 + lane, which = e >> 7;
+                const int idx = min((which ? t.tn : t.tm) * 128 + (e & 127), hw - 1);
+                ssrc = (const char*)(q.stats + (((long)t.p * 2 + which) * hw + idx) * 4);
+                // the tile's 256 row / column statistics: first (oldest) piece of the step, parity buffer of the tile
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ssrc,
+                                                 (__attribute__((address_space(3))) void*)(smem + CVP_STAT_OFF + (it_i & 1) * 4096 + lw * 1024),
+                                                 16, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + (long)k_i * 128),
+                                                 (__attribute__((address_space(3))) void*)(sA + (lw * 4 + i) * 1024), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + (long)k_i * 128),
+                                                 (__attribute__((address_space(3))) void*)(sB + (lw * 4 + i) * 1024), 16, 0, 0);
+            if (++k_i == nk) { k_i = 0; ++it_i; }
+        };
+        // previous tile's partial sums: LDS (written by the compute waves before the barrier just passed) -> slabs
+        const uintptr_t p1 = (uintptr_t)q.part1, p2 = (uintptr_t)q.part2;
+        auto flush = [&](int it) {
+            const CvpTile t = cvp_tile(beg + kb + it * nbx, tiles);
+            const unsigned pb = smem_base + CVP_PART_OFF + (it & 1) * 6144;
+            const int e = lw * 64 + lane;          // 0..127 rows, 128..255 columns
+            // one code path for both halves (a pointer picked by a per-lane branch became a vector load from the kernel
+            // argument block + s_waitcnt vmcnt(0): it drained the loader's DMA ring once per tile)
+            const bool isrow = e < 128;
+            const int c = e & 127;
+            const unsigned zo = isrow ? c : 512 + c, bo = isrow ? 256 + c : 1024 + c;
+            float Z = cvp_lds_f32(pb + zo * 4) + cvp_lds_f32(pb + (zo + 128) * 4);
+            float B = cvp_lds_f32(pb + bo * 4) + cvp_lds_f32(pb + (bo + 128) * 4);
+            const float Z2 = cvp_lds_f32(pb + (512 + 256 + c) * 4) + cvp_lds_f32(pb + (512 + 384 + c) * 4);
+            const float B2 = cvp_lds_f32(pb + (1024 + 256 + c) * 4) + cvp_lds_f32(pb + (1024 + 384 + c) * 4);
+            if (!isrow) { Z += Z2; B += B2; }          // columns: four wave rows, fixed order ((w0 + w1) + (w2 + w3)): deterministic
+            const int idx = (isrow ? t.tm : t.tn) * 128 + c, slab = isrow ? t.tn : t.tm;
+            const uintptr_t base = isrow ? p1 : p2;
+            if (idx < hw)       // explicitly a GLOBAL store: a flat store is out of order with respect to vmcnt
+                *(__attribute__((address_space(1))) f32x2*)(base + ((((long)t.p * q.nslab + slab) * hw + idx) * 2) * sizeof(float)) = f32x2{Z, B};
+        };
+        for (int n = 0; n < 3 && n < n_total; ++n) issue(n);
+        int kk = 0, it = 0;
+        for (int n = 0; n < n_total; ++n) {
+            const int rem = n_total - 1 - n;
+            // every operation older than the two youngest steps (8 DMA pieces each) has landed: step n is in LDS
+            if (rem >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (rem == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (n + 3 < n_total) issue(n + 3);
+            if (kk == 0 && it > 0) flush(it - 1);
+            if (++kk == nk) { kk = 0; ++it; }
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        flush(n_tiles - 1);
+        return;
+    }
+
+    // ======================================= COMPUTE waves =======================================
+    const int wm = wave >> 1, wn = wave & 1, g = lane >> 4, c = lane & 15;
+    typedef typename Mma<T>::Frag Frag;
+    const int sa = swz(c);
+    const int abase = (wm * 32 + c) * 128, bbase = 128 * 128 + (wn * 64 + c) * 128;
+    float t1v[2][4][4];      // direction 1: T1[row = tm*128 + wm*32 + ib*16 + 4g + r][col = tn*128 + wn*64 + jb*16 + c]
+    f32x4 t2v[2][4];         // direction 2: T2[row = tn*128 + wn*64 + jb*16 + c][col = tm*128 + wm*32 + ib*16 + 4g .. +3]
+    // branch-free: every address is clamped into the pair's map (rows / columns past hw re-read valid entries; the
+    // epilogue multiplies them by a zeroed s), so the 40 loads of a tile go out back to back with no wait between them
+    auto prefetch = [&](int it) {
+        const CvpTile t = cvp_tile(beg + kb + it * nbx, tiles);
+        const float* T1 = q.t1 + (long)t.p * hw * ldt;
+        const float* T2 = q.t2 + (long)t.p * hw * ldt;
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) {
+                const int col = min(t.tn * 128 + wn * 64 + jb * 16 + c, hw - 1);
+                const int row0 = t.tm * 128 + wm * 32 + ib * 16 + 4 * g;
+                t2v[ib][jb] = *(const f32x4*)(T2 + (long)col * ldt + min(row0, ldt - 4));       // ldt % 4 == 0: aligned, inside the row
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t1v[ib][jb][r] = T1[(long)min(row0 + r, hw - 1) * ldt + col];
+            }
+    };
+    prefetch(0);
+    int n = 0;
+    for (int it = 0; it < n_tiles; ++it) {
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < nk; ++k, ++n) {
+            cvp_barrier();
+            const char* sb = smem + (n & (CVP_SLOTS - 1)) * CVP_STAGE;
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) {
+                const int co = (((kc * 4 + g) ^ sa) * 16);
+                Frag a[2], b[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) b[t] = *(const Frag*)(sb + bbase + t * 2048 + co);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) a[t] = *(const Frag*)(sb + abase + t * 2048 + co);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(a[i], b[j], acc[i][j]);
+            }
+        }
+        // ---------------- epilogue, all from registers ----------------
+        const CvpTile t = cvp_tile(beg + kb + it * nbx, tiles);
+        const f32x4* sSt = (const f32x4*)(smem + CVP_STAT_OFF + (it & 1) * 4096);
+        float* sP = (float*)(smem + CVP_PART_OFF + (it & 1) * 6144);
+        float inv2[4], ir2[4], zc[4], b2[4];
+        bool cok[4];
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+            const int cl = wn * 64 + jb * 16 + c;
+            const f32x4 v = sSt[128 + cl];
+            inv2[jb] = v[0]; ir2[jb] = 1.0f / v[1];
+            cok[jb] = t.tn * 128 + cl < hw;
+            zc[jb] = 0.f; b2[jb] = 0.f;
+        }
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rl = wm * 32 + ib * 16 + 4 * g + r;
+                const f32x4 v = sSt[rl];
+                const float inv1 = v[0], ir1 = 1.0f / v[1];
+                const bool rok = t.tm * 128 + rl < hw;
+                float zr = 0.f, b1 = 0.f;
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb) {
+                    const bool ok = rok && cok[jb];
+                    const float sv = acc[ib][jb][r] * inv1 * inv2[jb];
+                    const float e = ok ? __expf(sv) : 0.f;
+                    const float sm = ok ? sv : 0.f;
+                    zr += e; zc[jb] += e;
+                    b1 = fmaf(fmaxf(t1v[ib][jb][r] * ir1, CV_EPS), sm, b1);
+                    b2[jb] = fmaf(fmaxf(t2v[ib][jb][r] * ir2[jb], CV_EPS), sm, b2[jb]);
+                }
+                zr = row16_sum(zr);
+                b1 = row16_sum(b1);
+                if (c == 0) { sP[wn * 128 + rl] = zr; sP[256 + wn * 128 + rl] = b1; }
+            }
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+            float z = zc[jb], b = b2[jb];
+            z += __shfl_xor(z, 16, 64); z += __shfl_xor(z, 32, 64);
+            b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+            if (g == 0) {
+                const int cl = wn * 64 + jb * 16 + c;
+                sP[512 + wm * 128 + cl] = z; sP[1024 + wm * 128 + cl] = b;
+            }
+        }
+        if (it + 1 < n_tiles) prefetch(it + 1);
+    }
+    cvp_barrier();
 }
 
 // reduce the slabs, save logZ and W for the backward, emit per-chunk partial losses (CV_FCH chunks per pair), then sum
 #define CV_FCH 8
-__global__ __launch_bounds__(256) void cv_finalize_kernel(const float* part1, const float* part2, const float* wa,
+__global__ __launch_bounds__(256) void cv_finalize_kernel(const float* part1, const float* part2, const float* tstats,
                                                           const unsigned char* m1, const unsigned char* m2,
                                                           float* stats, double* chunk_loss, int hw, int nslab, int variant) {
     const int p = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
@@ -301,10 +555,10 @@ __global__ __launch_bounds__(256) void cv_finalize_kernel(const float* part1, co
         const float* part = d ? part2 : part1;
         float Z = 0.f, B = 0.f;
         for (int s = 0; s < nslab; ++s) {
-            const f32x4 v = *(const f32x4*)(part + (((long)p * nslab + s) * hw + row) * 4);
-            Z += v[0]; B += v[3];
+            const f32x2 v = *(const f32x2*)(part + (((long)p * nslab + s) * hw + row) * 2);
+            Z += v[0]; B += v[1];
         }
-        const float Wt = wa[(((long)p * 2 + d) * hw + row) * 2], A = wa[(((long)p * 2 + d) * hw + row) * 2 + 1];
+        const float Wt = tstats[(((long)p * 2 + d) * hw + row) * 4 + 1], A = tstats[(((long)p * 2 + d) * hw + row) * 4 + 2];
         const float logZ = logf(Z);
         float* st = stats + (((long)p * 2 + d) * hw + row) * 4;
         st[2] = logZ;
@@ -340,8 +594,9 @@ __global__ __launch_bounds__(256, 2) void cv_bwd_tile_kernel(CvTileParams q) {
     const int p = blockIdx.y, hw = q.hw, hwp = q.hwp;
     const int wg = xcd_remap(blockIdx.x, q.tiles * q.tiles);
     const int tm = wg / q.tiles, tn = wg % q.tiles;
-    const float* T1 = q.t1 + (long)p * hw * hw;
-    const float* T2 = q.t2 + (long)p * hw * hw;
+    const int ldt = q.ldt;
+    const float* T1 = q.t1 + (long)p * hw * ldt;
+    const float* T2 = q.t2 + (long)p * hw * ldt;
     f32x4* sSt = (f32x4*)(smem + CV_RING);
     cv_stage_stats(q, p, tm, tn, sSt);
     float t1v[2][32];   // pass-A teacher values of both halves: in flight under the main loop
@@ -350,7 +605,7 @@ __global__ __launch_bounds__(256, 2) void cv_bwd_tile_kernel(CvTileParams q) {
 #pragma unroll
         for (int k = 0; k < 32; ++k) {   // pass A: tile row wave+4k, column = 64h + lane
             const int row = tm * 128 + wave + 4 * k, col = tn * 128 + 64 * h + lane;
-            t1v[h][k] = (row < hw && col < hw) ? T1[(long)row * hw + col] : 0.f;
+            t1v[h][k] = (row < hw && col < hw) ? T1[(long)row * ldt + col] : 0.f;
         }
     f32x4 acc[4][4];
     cv_s_tile<T>(q, p, tm, tn, smem, sSt, acc);
@@ -377,7 +632,7 @@ __global__ __launch_bounds__(256, 2) void cv_bwd_tile_kernel(CvTileParams q) {
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int col = col0 + wave + 4 * k, row = tm * 128 + lane + 64 * e;
-                t2v[k][e] = (row < hw && col < hw) ? T2[(long)col * hw + row] : 0.f;
+                t2v[k][e] = (row < hw && col < hw) ? T2[(long)col * ldt + row] : 0.f;
             }
         __syncthreads();
         // pass A: direction-1 term (lane = column)
@@ -465,54 +720,82 @@ static inline int cv_hwp(int hw) { return (hw + 63) & ~63; }   // K of the two b
 
 extern "C" size_t gd_cost_volume_kl_workspace_bytes(int P, int hw, int C, int dtype, int backward) {
     const size_t es = (size_t)gd_dtype_size(dtype);
-    if (!backward) return 2 * align256((size_t)P * 2 * cv_tiles(hw) * hw * 4 * sizeof(float)) + align256((size_t)P * CV_FCH * sizeof(double)) +
-                          align256((size_t)P * 2 * hw * 2 * sizeof(float));
+    if (!backward) return 2 * align256((size_t)P * cv_tiles(hw) * hw * 2 * sizeof(float)) + align256((size_t)P * CV_FCH * sizeof(double)) +
+                          align256((size_t)P * 2 * hw * 4 * sizeof(float));
     const size_t hwp = (size_t)cv_hwp(hw);
     return 2 * align256((size_t)P * hw * hwp * es) + 2 * align256((size_t)P * C * hwp * es) +
            2 * align256((size_t)P * hw * C * sizeof(float));
 }
 
-extern "C" int gd_cost_volume_kl_fwd(const void* f1, const void* f2, const float* t1, const float* t2,
-                                     const unsigned char* m1, const unsigned char* m2, int P, int hw, int C,
-                                     int variant, int dtype, float* loss, float* stats, void* workspace,
+extern "C" int gd_cost_volume_teacher_stats(const float* t1, const float* t2, int P, int hw, int ldt, float* tstats,
+                                            void* stream) {
+    GD_REQUIRE(P > 0 && hw > 0 && ldt >= hw, "gd_cost_volume_teacher_stats: bad shape P=%d hw=%d ldt=%d", P, hw, ldt);
+    GD_REQUIRE(((uintptr_t)tstats & 15) == 0, "gd_cost_volume_teacher_stats: tstats must be 16-byte aligned");
+    hipLaunchKernelGGL(cv_tstats_kernel, dim3(gd_cdiv(hw, 4), 2, P), dim3(256), 0, (hipStream_t)stream, t1, t2, tstats, hw, ldt);
+    GD_LAUNCH_OK();
+    return 0;
+}
+
+extern "C" int gd_cost_volume_kl_fwd(const void* f1, const void* f2, const float* t1, const float* t2, int ldt,
+                                     const float* tstats, const unsigned char* m1, const unsigned char* m2, int P, int hw,
+                                     int C, int variant, int dtype, float* loss, float* stats, void* workspace,
                                      void* stream) {
-    GD_REQUIRE(P > 0 && hw > 0 && C > 0, "gd_cost_volume_kl_fwd: bad shape P=%d hw=%d C=%d", P, hw, C);
+    GD_REQUIRE(P > 0 && hw > 0 && C > 0 && ldt >= hw, "gd_cost_volume_kl_fwd: bad shape P=%d hw=%d C=%d ldt=%d", P, hw, C, ldt);
     GD_REQUIRE(variant == 0 || variant == 1, "gd_cost_volume_kl_fwd: variant must be 0 (vggt) or 1 (mast3r)");
     GD_REQUIRE(dtype == GD_F32 || dtype == GD_BF16, "gd_cost_volume_kl_fwd: bad dtype %d", dtype);
     GD_REQUIRE((C * gd_dtype_size(dtype)) % 16 == 0, "gd_cost_volume_kl_fwd: C*elsize must be a multiple of 16 B");
     GD_REQUIRE((double)hw * 7.3890561 * CV_EPS < 1.0, "gd_cost_volume_kl_fwd: hw too large for the clamp-free softmax");
     GD_REQUIRE(((uintptr_t)f1 & 15) == 0 && ((uintptr_t)f2 & 15) == 0 && ((uintptr_t)stats & 15) == 0 &&
-                   ((uintptr_t)workspace & 15) == 0,
-               "gd_cost_volume_kl_fwd: f1, f2, stats, workspace must be 16-byte aligned");
+                   ((uintptr_t)workspace & 15) == 0 && ((uintptr_t)tstats & 15) == 0,
+               "gd_cost_volume_kl_fwd: f1, f2, stats, tstats, workspace must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const int tiles = cv_tiles(hw), nslab = tiles;
     float* part1 = (float*)workspace;
-    float* part2 = (float*)((char*)workspace + align256((size_t)P * nslab * hw * 4 * sizeof(float)));
-    double* chunk_loss = (double*)((char*)workspace + 2 * align256((size_t)P * 2 * tiles * hw * 4 * sizeof(float)));
-    float* wa = (float*)((char*)chunk_loss + align256((size_t)P * CV_FCH * sizeof(double)));
-    hipLaunchKernelGGL(cv_prep_kernel, dim3(gd_cdiv(hw, 4), 2, P), dim3(256), 0, s, f1, f2, t1, t2, stats, wa, hw, C,
-                       dtype);
+    float* part2 = (float*)((char*)workspace + align256((size_t)P * nslab * hw * 2 * sizeof(float)));
+    double* chunk_loss = (double*)((char*)workspace + 2 * align256((size_t)P * nslab * hw * 2 * sizeof(float)));
+    float* ts_ws = (float*)((char*)chunk_loss + align256((size_t)P * CV_FCH * sizeof(double)));
+    if (!tstats) {     // no cached teacher statistics: one extra pass over the teacher maps
+        hipLaunchKernelGGL(cv_tstats_kernel, dim3(gd_cdiv(hw, 4), 2, P), dim3(256), 0, s, t1, t2, ts_ws, hw, ldt);
+        tstats = ts_ws;
+    }
+    hipLaunchKernelGGL(cv_norm_kernel, dim3(gd_cdiv(hw, 4), 2, P), dim3(256), 0, s, f1, f2, tstats, stats, hw, C, dtype);
     GD_LAUNCH_OK();
     CvTileParams q = {};
     q.f1 = f1; q.f2 = f2; q.t1 = t1; q.t2 = t2; q.stats = stats; q.part1 = part1; q.part2 = part2;
-    q.hw = hw; q.C = C; q.tiles = tiles; q.nslab = nslab;
-    if (dtype == GD_BF16)
+    q.hw = hw; q.C = C; q.tiles = tiles; q.nslab = nslab; q.ldt = ldt; q.P = P;
+    static int persist = -1;     // GD_CV_PERSIST=0: the one-tile-per-block kernel (A/B)
+    if (persist < 0) { const char* e = getenv("GD_CV_PERSIST"); persist = e ? atoi(e) : 1; }
+    const long rowb = (long)C * gd_dtype_size(dtype);
+    if (persist && rowb % 128 == 0 && rowb / 128 >= 3 && ldt % 4 == 0 && ((uintptr_t)t1 & 15) == 0 && ((uintptr_t)t2 & 15) == 0) {
+        int ncu = 256;
+        static int cached_cu = 0;
+        if (!cached_cu) { int dev = 0; hipGetDevice(&dev); hipDeviceGetAttribute(&cached_cu, hipDeviceAttributeMultiprocessorCount, dev); }
+        if (cached_cu >= 8) ncu = cached_cu / 8 * 8;
+        const long total = (long)P * tiles * tiles;
+        int grid = (int)(total < ncu ? (total + 7) / 8 * 8 : ncu);
+        if (const char* e = getenv("GD_CV_GRID")) {      // tests: few blocks, so that every block walks many tiles
+            const int gv = atoi(e) / 8 * 8;
+            if (gv >= 8 && gv < grid) grid = gv;
+        }
+        if (dtype == GD_BF16) hipLaunchKernelGGL(cv_fwd_persist_kernel<bf16>, dim3(grid), dim3(768), 0, s, q);
+        else hipLaunchKernelGGL(cv_fwd_persist_kernel<float>, dim3(grid), dim3(768), 0, s, q);
+    } else if (dtype == GD_BF16)
         hipLaunchKernelGGL(cv_fwd_tile_kernel<bf16>, dim3(tiles * tiles, P), dim3(256), 0, s, q);
     else
         hipLaunchKernelGGL(cv_fwd_tile_kernel<float>, dim3(tiles * tiles, P), dim3(256), 0, s, q);
     GD_LAUNCH_OK();
-    hipLaunchKernelGGL(cv_finalize_kernel, dim3(P, CV_FCH), dim3(256), 0, s, part1, part2, wa, m1, m2, stats, chunk_loss, hw,
+    hipLaunchKernelGGL(cv_finalize_kernel, dim3(P, CV_FCH), dim3(256), 0, s, part1, part2, tstats, m1, m2, stats, chunk_loss, hw,
                        nslab, variant);
     hipLaunchKernelGGL(cv_loss_kernel, dim3(gd_cdiv(P, 64)), dim3(64), 0, s, chunk_loss, loss, P, hw);
     GD_LAUNCH_OK();
     return 0;
 }
 
-extern "C" int gd_cost_volume_kl_bwd(const void* f1, const void* f2, const float* t1, const float* t2,
+extern "C" int gd_cost_volume_kl_bwd(const void* f1, const void* f2, const float* t1, const float* t2, int ldt,
                                      const unsigned char* m1, const unsigned char* m2, int P, int hw, int C,
                                      int dtype, const float* gloss, const float* stats, void* df1, void* df2,
                                      void* workspace, void* stream) {
-    GD_REQUIRE(P > 0 && hw > 0 && C > 0, "gd_cost_volume_kl_bwd: bad shape P=%d hw=%d C=%d", P, hw, C);
+    GD_REQUIRE(P > 0 && hw > 0 && C > 0 && ldt >= hw, "gd_cost_volume_kl_bwd: bad shape P=%d hw=%d C=%d ldt=%d", P, hw, C, ldt);
     GD_REQUIRE(dtype == GD_F32 || dtype == GD_BF16, "gd_cost_volume_kl_bwd: bad dtype %d", dtype);
     GD_REQUIRE((C * gd_dtype_size(dtype)) % 16 == 0, "gd_cost_volume_kl_bwd: C*elsize must be a multiple of 16 B");
     hipStream_t s = (hipStream_t)stream;
@@ -527,7 +810,7 @@ extern "C" int gd_cost_volume_kl_bwd(const void* f1, const void* f2, const float
     float* db = (float*)w;
     CvTileParams q = {};
     q.f1 = f1; q.f2 = f2; q.t1 = t1; q.t2 = t2; q.stats = (float*)stats; q.hw = hw; q.C = C; q.tiles = tiles;
-    q.m1 = m1; q.m2 = m2; q.gloss = gloss; q.G1 = G1; q.G2 = G2; q.hwp = hwp;
+    q.m1 = m1; q.m2 = m2; q.gloss = gloss; q.G1 = G1; q.G2 = G2; q.hwp = hwp; q.ldt = ldt; q.P = P;
     dim3 tgrid(gd_cdiv(hwp, 32), gd_cdiv(C, 32), 2 * P);
     if (dtype == GD_BF16) {
         hipLaunchKernelGGL(cv_bwd_tile_kernel<bf16>, dim3(tiles * tiles, P), dim3(256), 0, s, q);

@@ -316,8 +316,9 @@ class FinetuneGD(nn.Module):
         d1, d2 = ops.kp_depth(depth_1, kp_1), ops.kp_depth(depth_2, kp_2)
         return ops.depth_losses(feat, d1, d2, self.depth_diff_head.head_params(), counts=counts, depth_threshold=0.05)   # view-major [2P,N,D]
 
-    def calculate_cost_loss(self, rgbs, cost_1, cost_2, kp_1=None, kp_2=None, mask_1=None, mask_2=None):
-        """src/finetune_timm_vggt.py:488-533 / src/finetune_timm_mast3r.py:504-540."""
+    def calculate_cost_loss(self, rgbs, cost_1, cost_2, kp_1=None, kp_2=None, mask_1=None, mask_2=None, cost_tstats=None):
+        """src/finetune_timm_vggt.py:488-533 / src/finetune_timm_mast3r.py:504-540.  cost_k [P, hw, hw] — or [P, hw, ldt]
+        padded to 16-byte rows with `cost_tstats` = the cached teacher-row statistics (teacher_cache.TeacherTargetCache)."""
         h, w = rgbs.shape[-2:]
         P = rgbs.shape[0] // 2
         f = self.get_feature_cost(rgbs)
@@ -329,7 +330,7 @@ class FinetuneGD(nn.Module):
             m1 = F.interpolate(mask_1[:, None].float(), size=(ph, pw), mode="nearest").reshape(P, -1) > 0
             m2 = F.interpolate(mask_2[:, None].float(), size=(ph, pw), mode="nearest").reshape(P, -1) > 0
         f1, f2 = ops.split_pairs(f, P)
-        return ops.cost_volume_kl(f1, f2, cost_1, cost_2, m1, m2, self.variant)
+        return ops.cost_volume_kl(f1, f2, cost_1, cost_2, m1, m2, self.variant, tstats=cost_tstats)
 
     def calculate_matching_loss(self, rgbs, kp_1, kp_2, pts3d_1, pts3d_2, counts=None):
         """src/finetune_timm_vggt.py:536-574 / src/finetune_timm_mast3r.py:543-589.  pts3d_k [P,N,3] are the
@@ -361,7 +362,7 @@ class FinetuneGD(nn.Module):
         depth_loss, intra = self.calculate_depth_loss(batch["depth_1"], batch["depth_2"], rgbs, batch["kp_1"],
                                                       batch["kp_2"], counts)
         kl = self.calculate_cost_loss(rgbs, batch["cost_1"], batch["cost_2"], batch["kp_1"], batch["kp_2"],
-                                      batch.get("mask_1"), batch.get("mask_2"))
+                                      batch.get("mask_1"), batch.get("mask_2"), batch.get("cost_tstats"))
         ap = self.calculate_matching_loss(rgbs, batch["kp_1"], batch["kp_2"], batch["pts3d_1"], batch["pts3d_2"], counts)
         per_pair = (self.ap_loss_weight * ap + self.depth_loss_weight * depth_loss
                     + self.intra_depth_loss_weight * intra + self.kl_loss_weight * kl)

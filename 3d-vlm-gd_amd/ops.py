@@ -130,19 +130,45 @@ def gemm_tn(y, x, out=None, *, alpha=1.0):
 VARIANTS = {"vggt": 0, "mast3r": 1}
 
 
+def pad_teacher_maps(t):
+    """[P, hw, hw] -> [P, hw, ldt] view-compatible copy with ldt = hw rounded up to 4 (16-byte aligned rows, zero pad): the
+    layout the fast cost-volume path reads.  Done ONCE per cached pair (TeacherTargetCache), never per step."""
+    P, hw, w = t.shape
+    ldt = (w + 3) // 4 * 4
+    if ldt == w:
+        return t.contiguous().float()
+    out = torch.zeros(P, hw, ldt, dtype=torch.float32, device=t.device)
+    out[:, :, :w] = t
+    return out
+
+
+def cost_volume_teacher_stats(t1, t2):
+    """Per teacher row {max(rowsum, 1e-8), W, A, 0} (see gd_cost_volume_teacher_stats): depends on the teacher maps only —
+    computed once when a pair's targets are cached.  t1, t2 [P, hw, ldt] -> [P, 2, hw, 4] fp32."""
+    P, hw, ldt = t1.shape
+    t1, t2 = t1.contiguous().float(), t2.contiguous().float()
+    out = torch.empty(P, 2, hw, 4, dtype=torch.float32, device=t1.device)
+    check(lib().gd_cost_volume_teacher_stats(ptr(t1), ptr(t2), P, hw, ldt, ptr(out), stream()), "gd_cost_volume_teacher_stats")
+    return out
+
+
 class _CostVolumeKL(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, f1, f2, t1, t2, m1, m2, variant):
+    def forward(ctx, f1, f2, t1, t2, m1, m2, variant, tstats):
         P, hw, C = f1.shape
         f1, f2 = f1.contiguous(), f2.contiguous()
         t1, t2 = t1.contiguous().float(), t2.contiguous().float()
+        ldt = t1.shape[-1]
+        _req(t1.shape == (P, hw, ldt) and t2.shape == (P, hw, ldt) and ldt >= hw, "cost_volume_kl: teacher maps must be [P, hw, ldt >= hw]")
         m1 = m1.contiguous().to(torch.uint8)
         m2 = m2.contiguous().to(torch.uint8)
         dt = dtype_code(f1)
         loss = torch.empty(P, dtype=torch.float32, device=f1.device)
         stats = torch.empty(P, 2, hw, 4, dtype=torch.float32, device=f1.device)
         ws = torch.empty(lib().gd_cost_volume_kl_workspace_bytes(P, hw, C, dt, 0), dtype=torch.uint8, device=f1.device)
-        rc = lib().gd_cost_volume_kl_fwd(ptr(f1), ptr(f2), ptr(t1), ptr(t2), ptr(m1), ptr(m2), P, hw, C,
+        if tstats is not None:
+            _req(tstats.shape == (P, 2, hw, 4) and tstats.dtype == torch.float32 and tstats.is_contiguous(), "cost_volume_kl: bad tstats")
+        rc = lib().gd_cost_volume_kl_fwd(ptr(f1), ptr(f2), ptr(t1), ptr(t2), ldt, ptr(tstats), ptr(m1), ptr(m2), P, hw, C,
                                          VARIANTS[variant], dt, ptr(loss), ptr(stats), ptr(ws), stream())
         check(rc, "gd_cost_volume_kl_fwd")
         ctx.save_for_backward(f1, f2, t1, t2, m1, m2, stats)
@@ -156,16 +182,18 @@ class _CostVolumeKL(torch.autograd.Function):
         df1, df2 = torch.empty_like(f1), torch.empty_like(f2)
         ws = torch.empty(lib().gd_cost_volume_kl_workspace_bytes(P, hw, C, dt, 1), dtype=torch.uint8, device=f1.device)
         g = gloss.contiguous().float()
-        rc = lib().gd_cost_volume_kl_bwd(ptr(f1), ptr(f2), ptr(t1), ptr(t2), ptr(m1), ptr(m2), P, hw, C, dt, ptr(g),
+        rc = lib().gd_cost_volume_kl_bwd(ptr(f1), ptr(f2), ptr(t1), ptr(t2), t1.shape[-1], ptr(m1), ptr(m2), P, hw, C, dt, ptr(g),
                                          ptr(stats), ptr(df1), ptr(df2), ptr(ws), stream())
         check(rc, "gd_cost_volume_kl_bwd")
-        return df1, df2, None, None, None, None, None
+        return df1, df2, None, None, None, None, None, None
 
 
-def cost_volume_kl(f1, f2, t1, t2, m1, m2, variant="vggt"):
-    """Fused dense cost-volume KL for P pairs.  f1,f2 [P,hw,C] raw student features (f32|bf16);
-    t1,t2 [P,hw,hw] teacher maps (f32); m1,m2 [P,hw] bool row masks -> loss [P] (f32)."""
-    return _CostVolumeKL.apply(f1, f2, t1, t2, m1, m2, variant)
+def cost_volume_kl(f1, f2, t1, t2, m1, m2, variant="vggt", tstats=None):
+    """Fused dense cost-volume KL for P pairs.  f1,f2 [P,hw,C] raw student features (f32|bf16); t1,t2 [P,hw,ldt] teacher
+    maps (f32; ldt = hw, or hw padded to a multiple of 4 by `pad_teacher_maps`: the fast path); m1,m2 [P,hw] bool row
+    masks; tstats: `cost_volume_teacher_stats(t1, t2)` computed once per cached pair (None: recomputed here, one more pass
+    over the maps) -> loss [P] (f32)."""
+    return _CostVolumeKL.apply(f1, f2, t1, t2, m1, m2, variant, tstats)
 
 
 def attention_fwd(qkv, B, N, H):

@@ -1,0 +1,94 @@
+"""Per-pair cache of the frozen teacher's distillation targets (north_star: "the frozen teacher runs once per pair
+on-device via cached PyTorch-ROCm inference"; reference call sites src/finetune_timm_vggt.py:357-411,599-603 and
+src/finetune_timm_mast3r.py:345-389,597-633, which re-run the teacher on every step).
+
+A cached entry holds device tensors in the layout the fused student step reads them:
+  cost_1, cost_2   [hw, ldt] fp32 — teacher cost maps, row stride padded to 16 bytes (zero pad)
+  cost_tstats      [2, hw, 4] fp32 — per teacher row {max(rowsum, 1e-8), sum t, sum t log t, 0} (ops.cost_volume_teacher_stats):
+                   everything the KL needs from the teacher side alone, so the step reads each map exactly once
+  kp_1, kp_2 [N, 2], count, pts3d_1, pts3d_2 [N, 3], depth_1, depth_2 [h, w], mask_1, mask_2 [h, w] (VGGT co-view masks)
+`collate` stacks entries into the batch dict of FinetuneGD.training_step (ragged keypoint counts -> `counts` + -1 padding).
+"""
+import torch
+
+from . import ops
+
+_PER_PAIR = ("cost_1", "cost_2", "cost_tstats", "kp_1", "kp_2", "pts3d_1", "pts3d_2", "depth_1", "depth_2", "mask_1", "mask_2")
+
+
+def cache_cost_targets(batch):
+    """In place on a batch dict: pad cost_1 / cost_2 [P, hw, hw] to 16-byte rows and attach `cost_tstats` (idempotent)."""
+    if "cost_tstats" not in batch:
+        batch["cost_1"] = ops.pad_teacher_maps(batch["cost_1"])
+        batch["cost_2"] = ops.pad_teacher_maps(batch["cost_2"])
+        batch["cost_tstats"] = ops.cost_volume_teacher_stats(batch["cost_1"], batch["cost_2"])
+    return batch
+
+
+class TeacherTargetCache:
+    """key (any hashable pair id) -> the pair's targets on `device`.  `get(key, producer)` runs `producer()` — the
+    teacher forward + target extraction (teacher_glue.extract_vggt_targets / extract_mast3r_targets) — only on a miss.
+    The MASt3R targets depend on the teacher softmax temperature (src/finetune_timm_mast3r.py:217-227 anneals it per epoch):
+    entries remember the temperature they were made with and are rebuilt when it has moved by more than `temp_tol`."""
+
+    def __init__(self, device="cuda", max_pairs=None, temp_tol=1e-6):
+        self.device, self.max_pairs, self.temp_tol = device, max_pairs, temp_tol
+        self._d = {}
+        self.hits = self.misses = 0
+
+    def __len__(self):
+        return len(self._d)
+
+    def nbytes(self):
+        return sum(v.numel() * v.element_size() for e in self._d.values() for v in e.values() if isinstance(v, torch.Tensor))
+
+    def put(self, key, targets, temperature=None):
+        e = {}
+        for k, v in targets.items():
+            e[k] = v.to(self.device) if isinstance(v, torch.Tensor) else v
+        if "cost_tstats" not in e:
+            c1, c2 = e["cost_1"], e["cost_2"]
+            c1 = c1[None] if c1.dim() == 2 else c1
+            c2 = c2[None] if c2.dim() == 2 else c2
+            p1, p2 = ops.pad_teacher_maps(c1.float()), ops.pad_teacher_maps(c2.float())
+            e["cost_1"], e["cost_2"], e["cost_tstats"] = p1[0], p2[0], ops.cost_volume_teacher_stats(p1, p2)[0]
+        e["_temperature"] = temperature
+        if self.max_pairs is not None and len(self._d) >= self.max_pairs and key not in self._d:
+            self._d.pop(next(iter(self._d)))           # FIFO eviction: epochs walk the dataset in a fixed order
+        self._d[key] = e
+        return e
+
+    def get(self, key, producer=None, temperature=None):
+        e = self._d.get(key)
+        stale = e is not None and temperature is not None and e["_temperature"] is not None and \
+            abs(e["_temperature"] - temperature) > self.temp_tol
+        if e is None or stale:
+            if producer is None:
+                raise KeyError(key)
+            self.misses += 1
+            return self.put(key, producer(), temperature)
+        self.hits += 1
+        return e
+
+    def collate(self, keys, rgb_1, rgb_2):
+        """-> batch dict for FinetuneGD.training_step: cached targets of `keys` stacked, keypoints padded with -1 to the
+        longest set, `counts` int32 [P]."""
+        es = [self._d[k] for k in keys]
+        n = [int(e["kp_1"].shape[0]) for e in es]
+        N = max(max(n), 1)
+
+        def padkp(t, fill):
+            out = t.new_full((N,) + tuple(t.shape[1:]), fill)
+            out[:t.shape[0]] = t
+            return out
+        b = {"rgb_1": rgb_1, "rgb_2": rgb_2, "counts": torch.tensor(n, dtype=torch.int32, device=self.device)}
+        for k in _PER_PAIR:
+            if k not in es[0]:
+                continue
+            if k in ("kp_1", "kp_2"):
+                b[k] = torch.stack([padkp(e[k].float(), -1.0) for e in es])
+            elif k in ("pts3d_1", "pts3d_2"):
+                b[k] = torch.stack([padkp(e[k].float(), 0.0) for e in es])
+            else:
+                b[k] = torch.stack([e[k] for e in es])
+        return b

@@ -74,7 +74,7 @@ class GDBlock(nn.Module):
     def plan(self, dtype):
         if self._plan is not None and self._plan["dtype"] == dtype:
             return self._plan
-        base = self.attn.qkv.qkv if isinstance(self.attn.qkv, _LoRA_qkv) else self.attn.qkv
+        base = self.attn.qkv.qkv if hasattr(self.attn.qkv, "linear_a_q") else self.attn.qkv      # any _LoRA_qkv-shaped wrapper
         dev = base.weight.device
         D = base.in_features
 
@@ -469,7 +469,7 @@ class GDViT(nn.Module):
         x = self.embed(x, size)
         outs = []
         for i, blk in enumerate(self.blocks):
-            x = blk(x)
+            x = run_block(blk, x)      # not blk(x): a foreign wrapper class (utils/model.py's own) is fused by shape, never called
             if i in take:
                 outs.append(x)
         return outs
@@ -477,7 +477,7 @@ class GDViT(nn.Module):
     def forward_features(self, x, size=None):
         x = self.embed(x, size)
         for blk in self.blocks:
-            x = blk(x)
+            x = run_block(blk, x)      # not blk(x): a foreign wrapper class (utils/model.py's own) is fused by shape, never called
         return self.norm(x)
 
     def forward_all(self, x, taps, size=None, norm_taps=False):
@@ -487,7 +487,7 @@ class GDViT(nn.Module):
         x = self.embed(x, size)
         outs, normed = {}, {}
         for i, blk in enumerate(self.blocks):
-            x = blk(x)
+            x = run_block(blk, x)      # not blk(x): a foreign wrapper class (utils/model.py's own) is fused by shape, never called
             if i in taps:
                 if norm_taps and i + 1 < len(self.blocks):
                     x, outs[i], normed[i] = _TapFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps)

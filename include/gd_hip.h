@@ -58,15 +58,20 @@ int gd_attention_bwd(const void* qkv, const void* o, const void* dout, const flo
 /* Dense cost-volume KL for P pairs, fused: calculate_cost_loss (src/finetune_timm_vggt.py:488-533 variant 0,
  * src/finetune_timm_mast3r.py:504-540 variant 1) = F.normalize + bmm x2 + softmax + get_masked_patch_cost
  * (utils/functions.py:402-422) + kl_divergence_map (utils/losses.py:5-15).
- * f1,f2 [P,hw,C] raw features; t1,t2 [P,hw,hw] f32 teacher maps; m1,m2 [P,hw] uint8 row masks;
- * loss [P] f32; stats [P,2,hw,4] f32 (saved for the backward). */
+ * f1,f2 [P,hw,C] raw features; t1,t2 [P,hw,ldt] f32 teacher maps with row stride ldt >= hw elements (ldt % 4 == 0 gives
+ * 16-byte aligned rows: the fast path; pad entries are never read as data); m1,m2 [P,hw] uint8 row masks;
+ * loss [P] f32; stats [P,2,hw,4] f32 (saved for the backward).
+ * tstats [P,2,hw,4] f32 = per teacher row {max(rowsum, 1e-8), W = sum_j t, A = sum_j t log t, 0} with
+ * t = max(T / rowsum, 1e-8): it depends on the teacher maps only, so a caller that caches a pair's targets computes it once
+ * with gd_cost_volume_teacher_stats and every step then reads each map a single time; tstats == NULL: computed inside. */
 size_t gd_cost_volume_kl_workspace_bytes(int P, int hw, int C, int dtype, int backward);
-int gd_cost_volume_kl_fwd(const void* f1, const void* f2, const float* t1, const float* t2, const unsigned char* m1,
-                          const unsigned char* m2, int P, int hw, int C, int variant, int dtype, float* loss,
-                          float* stats, void* workspace, void* stream);
-int gd_cost_volume_kl_bwd(const void* f1, const void* f2, const float* t1, const float* t2, const unsigned char* m1,
-                          const unsigned char* m2, int P, int hw, int C, int dtype, const float* gloss,
-                          const float* stats, void* df1, void* df2, void* workspace, void* stream);
+int gd_cost_volume_teacher_stats(const float* t1, const float* t2, int P, int hw, int ldt, float* tstats, void* stream);
+int gd_cost_volume_kl_fwd(const void* f1, const void* f2, const float* t1, const float* t2, int ldt, const float* tstats,
+                          const unsigned char* m1, const unsigned char* m2, int P, int hw, int C, int variant, int dtype,
+                          float* loss, float* stats, void* workspace, void* stream);
+int gd_cost_volume_kl_bwd(const void* f1, const void* f2, const float* t1, const float* t2, int ldt,
+                          const unsigned char* m1, const unsigned char* m2, int P, int hw, int C, int dtype,
+                          const float* gloss, const float* stats, void* df1, void* df2, void* workspace, void* stream);
 
 /* nn.LayerNorm forward / backward-to-input (timm Block.norm1/norm2, model.norm; frozen affine).  dres and dres2
  * (optional, dtype of x, row stride ldx) are added to dx: the residual-stream gradient, and — for a tapped block output,

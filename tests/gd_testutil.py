@@ -38,7 +38,7 @@ def oracle_params(engine):
     p = {k: cpu(v) for k, v in p.items()}
     tr = {a: {i: {k: cpu(v) for k, v in d.items()} for i, d in dd.items()} for a, dd in tr.items()}
     refine = {"weight": cpu(engine.refine_conv.weight), "bias": cpu(engine.refine_conv.bias)}
-    head = {k: cpu(v) for k, v in engine.depth_diff_head.head_params().items()}
+    head = {k: cpu(v) for k, v in engine.depth_diff_head.head_params().items()} if engine.depth_diff_head is not None else {}
     inner0 = m.blocks[0].block if hasattr(m.blocks[0], "adapter") else m.blocks[0]
     cfg = dict(patch=engine.patch_size, dim=m.embed_dim, depth=len(m.blocks), heads=inner0.attn.num_heads,
                ln_eps=inner0.norm1.eps, pos_interp=m.pos_interp, pre_norm=hasattr(m.norm_pre, "weight"),

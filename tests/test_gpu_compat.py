@@ -45,7 +45,7 @@ def test_masked_patch_cost_and_kl_golden():
     g = load_golden("g04_masked_cost")
     cost, rm = g["cost"].cuda(), g["row_mask"].cuda().bool()
     a = get_masked_patch_cost(cost, rm)
-    b = get_masked_patch_cost(cost, rm, use_softmax=True, temperature=0.7)
+    b = get_masked_patch_cost(cost * 4 - 2, rm, use_softmax=True, temperature=0.7)      # the fixture's softmax input (tools/make_golden.py)
     assert rel_err(a, g["renorm"]) < 1e-6 and rel_err(b, g["softmax_t07"]) < 1e-6
     kl = kl_divergence_map(g["kl_t"].cuda(), g["kl_p"].cuda())
     assert abs(kl.item() - g["kl"]) < 1e-6 * max(1.0, abs(g["kl"]))

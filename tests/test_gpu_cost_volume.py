@@ -35,20 +35,35 @@ def test_golden_fixture(variant):
     assert rel_err(f1.grad[0], g["g1"]) < 2e-4 and rel_err(f2.grad[0], g["g2"]) < 2e-4
 
 
+def _teacher(layout, t1, t2):
+    """'plain': [P,hw,hw] maps, teacher statistics recomputed inside the op; 'cached': rows padded to 16 bytes + the
+    statistics computed once (what teacher_cache.TeacherTargetCache holds per pair) — the single-pass persistent kernel."""
+    from gd_amd import ops
+    if layout == "plain":
+        return t1, t2, None
+    p1, p2 = ops.pad_teacher_maps(t1), ops.pad_teacher_maps(t2)
+    if p1.shape[-1] != t1.shape[-1]:          # poison the pad entries' neighbours? no: pads must be finite (zero) by contract
+        assert float(p1[..., t1.shape[-1]:].abs().max()) == 0.0
+    return p1, p2, ops.cost_volume_teacher_stats(p1, p2)
+
+
+@pytest.mark.parametrize("layout", ["plain", "cached"])
 @pytest.mark.parametrize("variant", ["vggt", "mast3r"])
-@pytest.mark.parametrize("P,hw,C", [(2, 100, 64), (1, 333, 96), (2, 672, 128)])
-def test_vs_oracle_f32(variant, P, hw, C):
+@pytest.mark.parametrize("P,hw,C", [(2, 100, 64), (1, 333, 96), (2, 672, 128), (3, 257, 160)])
+def test_vs_oracle_f32(variant, P, hw, C, layout):
     from gd_amd import ops
     gen = torch.Generator(device="cuda").manual_seed(hw)
     f1 = torch.randn(P, hw, C, generator=gen, device="cuda").requires_grad_(True)
     f2 = torch.randn(P, hw, C, generator=gen, device="cuda").requires_grad_(True)
     t1 = torch.softmax(3 * torch.randn(P, hw, hw, generator=gen, device="cuda"), -1)
     t2 = torch.softmax(3 * torch.randn(P, hw, hw, generator=gen, device="cuda"), -1)
+    t1[0, 3] = 0.0                                  # a teacher row whose sum hits the 1e-8 clamp
     m1 = torch.rand(P, hw, generator=gen, device="cuda") > 0.3
     m2 = torch.rand(P, hw, generator=gen, device="cuda") > 0.3
     m2[0] = False                                   # a fully masked direction
-    loss = ops.cost_volume_kl(f1, f2, t1, t2, m1, m2, variant)
-    w = torch.tensor([1.0, 0.5][:P], device="cuda")
+    c1, c2, ts = _teacher(layout, t1, t2)
+    loss = ops.cost_volume_kl(f1, f2, c1, c2, m1, m2, variant, tstats=ts)
+    w = torch.tensor([1.0, 0.5, 2.0][:P], device="cuda")
     (loss * w).sum().backward()
     ol, og1, og2 = _oracle(f1.detach(), f2.detach(), t1, t2, m1, m2, variant)
     assert rel_err(loss, ol) < 1e-5
@@ -73,3 +88,34 @@ def test_bf16_full_size():
     ol, og1, og2 = _oracle(f1.detach().float(), f2.detach().float(), t1, t2, m1, m2, "vggt")
     assert rel_err(loss, ol) < 1e-3
     assert rel_err(f1.grad.float(), og1) < 3e-2 and rel_err(f2.grad.float(), og2) < 3e-2
+    # the cached-target layout (padded rows + teacher statistics): the persistent single-pass kernel, same numbers
+    c1, c2, ts = _teacher("cached", t1, t2)
+    loss2 = ops.cost_volume_kl(f1.detach(), f2.detach(), c1, c2, m1, m2, "vggt", tstats=ts)
+    assert rel_err(loss2, ol) < 1e-3 and rel_err(loss2, loss) < 1e-5
+
+
+@pytest.mark.parametrize("variant,dtype,P,hw,C", [("mast3r", torch.float32, 9, 672, 96), ("vggt", torch.bfloat16, 3, 1369, 1024),
+                                                  ("mast3r", torch.bfloat16, 5, 768, 384)])
+def test_persistent_kernel_many_tiles_per_block(variant, dtype, P, hw, C, monkeypatch):
+    """The persistent forward with FEW blocks (GD_CV_GRID=8), so every block walks dozens of tiles: ring slots, the tile-parity
+    statistics / partial-sum buffers and the one-tile-ahead teacher prefetch all wrap around many times.  f32 operands
+    against the fp64 oracle; bf16 (ViT-L width C = 1024 at hw = 1369; ViT-S width at the MASt3R grid hw = 768) against it on the
+    bf16-rounded inputs.  Running twice gives bit-identical losses (fixed summation order)."""
+    from gd_amd import ops
+    gen = torch.Generator(device="cuda").manual_seed(hw + C)
+    f1 = torch.randn(P, hw, C, generator=gen, device="cuda").to(dtype)
+    f2 = torch.randn(P, hw, C, generator=gen, device="cuda").to(dtype)
+    t1 = torch.softmax(3 * torch.randn(P, hw, hw, generator=gen, device="cuda"), -1)
+    t2 = torch.softmax(3 * torch.randn(P, hw, hw, generator=gen, device="cuda"), -1)
+    m1 = torch.rand(P, hw, generator=gen, device="cuda") > 0.3
+    m2 = torch.rand(P, hw, generator=gen, device="cuda") > 0.3
+    c1, c2, ts = _teacher("cached", t1, t2)
+    full = ops.cost_volume_kl(f1, f2, c1, c2, m1, m2, variant, tstats=ts)
+    monkeypatch.setenv("GD_CV_GRID", "8")
+    few = ops.cost_volume_kl(f1, f2, c1, c2, m1, m2, variant, tstats=ts)
+    few2 = ops.cost_volume_kl(f1, f2, c1, c2, m1, m2, variant, tstats=ts)
+    monkeypatch.delenv("GD_CV_GRID")
+    assert torch.equal(few, few2)
+    assert rel_err(few, full) < 1e-6
+    ol, _, _ = _oracle(f1.float(), f2.float(), t1, t2, m1, m2, variant)
+    assert rel_err(few, ol) < (1e-5 if dtype == torch.float32 else 1e-3)

@@ -191,7 +191,7 @@ def test_full_step_bf16_loss_parity():
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/tiny_bf16_parity.txt", "w") as fh:
         fh.write(f"{rel:.3e} loss {loss.item():.6f} ref {ref_loss:.6f}\n")
-    assert rel < 2e-2, (loss.item(), ref_loss)
+    assert rel < 1e-3, (loss.item(), ref_loss)         # north_star tolerance, also on this 64-wide toy ViT
     eng.optimizer_step()
 
 
@@ -296,9 +296,18 @@ def test_checkpoint_carries_optimizer_state_and_unused_params_do_not_decay():
     assert eng2._flat["step"] == 2 and torch.equal(eng2._flat["m"], eng._flat["m"]) and torch.equal(eng2._flat["v"], eng._flat["v"])
     l1 = eng.fit_step(batch)[0]
     l2 = eng2.fit_step(batch)[0]
-    assert l1.item() == l2.item()
+    assert abs(l1.item() - l2.item()) < 1e-6 * abs(l1.item())
+    # the resumed step continues the moments (bias correction of step 3, not of step 1); the float atomics of the scatter /
+    # ranking kernels make two runs differ in the last bits, hence a tolerance instead of bit equality
     for a, b in zip(eng.trainable_parameters(), eng2.trainable_parameters()):
-        assert torch.equal(a, b)
+        assert float((a - b).abs().max()) < 0.05 * eng._flat["lr"]
+    eng3 = _engine("vggt", "shared", "f32", teacher_patch=14)       # same weights, moments NOT restored: a visibly different step
+    eng3.configure_optimizers()
+    ck2 = dict(ck)
+    ck2.pop("gd_optimizer_state")
+    eng3.on_load_checkpoint(ck2)
+    eng3.fit_step(batch)
+    assert max(float((a - b).abs().max()) for a, b in zip(eng.trainable_parameters(), eng3.trainable_parameters())) > 0.2 * eng._flat["lr"]
 
 
 def test_two_ranks_on_one_gpu_equal_one_rank_on_the_whole_batch(tmp_path):
