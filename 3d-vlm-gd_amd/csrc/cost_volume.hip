@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void cv_norm_kernel(const void* f1, const void
 struct CvTileParams {
     const void* f1; const void* f2; const float* t1; const float* t2;
     float* stats; float* part1; float* part2;
-    int hw, C, tiles, nslab, ldt, P;
+    int hw, C, tiles, nslab, ldt, P, dbg;
     // backward only
     const unsigned char* m1; const unsigned char* m2; const float* gloss;
     void* G1; void* G2; int hwp;
@@ -342,7 +342,7 @@ __device__ __forceinline__ CvpTile cvp_tile(int l, int tiles) {
     return t;
 }
 
-template <typename T>
+template <typename T, bool DBG>      // DBG: the GD_CV_DBG anatomy switches (parts of the kernel turned off); never instantiated into the product path
 __global__ __launch_bounds__(768) void cv_fwd_persist_kernel(CvTileParams q) {
     __shared__ __attribute__((aligned(16))) char smem[CVP_SMEM];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -453,18 +453,45 @@ __global__ __launch_bounds__(768) void cv_fwd_persist_kernel(CvTileParams q) {
         const CvpTile t = cvp_tile(beg + kb + it * nbx, tiles);
         const float* T1 = q.t1 + (long)t.p * hw * ldt;
         const float* T2 = q.t2 + (long)t.p * hw * ldt;
+        if (DBG && (q.dbg & 8)) {      // experiment: the same bytes as row-contiguous 16-byte loads (4 rows x 256 B / 8 rows x 128 B per instruction)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int r1 = min(t.tm * 128 + wm * 32 + k * 4 + g, hw - 1), c1 = min(t.tn * 128 + wn * 64 + 4 * c, ldt - 4);
+                const f32x4 v = *(const f32x4*)(T1 + (long)r1 * ldt + c1);
+                t1v[k >> 2][k & 3][0] = v[0]; t1v[k >> 2][k & 3][1] = v[1]; t1v[k >> 2][k & 3][2] = v[2]; t1v[k >> 2][k & 3][3] = v[3];
+                const int r2 = min(t.tn * 128 + wn * 64 + k * 8 + (lane >> 3), hw - 1), c2 = min(t.tm * 128 + wm * 32 + 4 * (lane & 7), ldt - 4);
+                t2v[k >> 2][k & 3] = *(const f32x4*)(T2 + (long)r2 * ldt + c2);
+            }
+            return;
+        }
 #pragma unroll
         for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
             for (int jb = 0; jb < 4; ++jb) {
                 const int col = min(t.tn * 128 + wn * 64 + jb * 16 + c, hw - 1);
                 const int row0 = t.tm * 128 + wm * 32 + ib * 16 + 4 * g;
+                if (DBG && (q.dbg & 16)) {
+                    t2v[ib][jb] = __builtin_nontemporal_load((const f32x4*)(T2 + (long)col * ldt + min(row0, ldt - 4)));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) t1v[ib][jb][r] = __builtin_nontemporal_load(T1 + (long)min(row0 + r, hw - 1) * ldt + col);
+                    continue;
+                }
                 t2v[ib][jb] = *(const f32x4*)(T2 + (long)col * ldt + min(row0, ldt - 4));       // ldt % 4 == 0: aligned, inside the row
 #pragma unroll
                 for (int r = 0; r < 4; ++r) t1v[ib][jb][r] = T1[(long)min(row0 + r, hw - 1) * ldt + col];
             }
     };
-    prefetch(0);
+    const int dbg = DBG ? q.dbg : 0;     // diagnostics (GD_CV_DBG): 1 = no teacher loads, 2 = no epilogue math, 4 = no MFMAs
+    if (dbg & 1) {
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) {
+                t2v[ib][jb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t1v[ib][jb][r] = 0.f;
+            }
+    } else prefetch(0);
     int n = 0;
     for (int it = 0; it < n_tiles; ++it) {
         f32x4 acc[2][4];
@@ -483,11 +510,18 @@ __global__ __launch_bounds__(768) void cv_fwd_persist_kernel(CvTileParams q) {
                 for (int t = 0; t < 4; ++t) b[t] = *(const Frag*)(sb + bbase + t * 2048 + co);
 #pragma unroll
                 for (int t = 0; t < 2; ++t) a[t] = *(const Frag*)(sb + abase + t * 2048 + co);
+                if (!(dbg & 4)) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(a[i], b[j], acc[i][j]);
+                        for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(a[i], b[j], acc[i][j]);
+                } else acc[0][0][0] += (float)a[0][0] + (float)b[0][0] + (float)a[1][0] + (float)b[1][0] + (float)b[2][0] + (float)b[3][0];
             }
+        }
+        if (dbg & 2) {
+            if (it + 1 < n_tiles && !(dbg & 1)) prefetch(it + 1);
+            if (acc[0][0][0] == 12345.678f) ((float*)smem)[tid] = acc[1][1][1] + t1v[0][0][0] + t2v[1][1][1];
+            continue;
         }
         // ---------------- epilogue, all from registers ----------------
         const CvpTile t = cvp_tile(beg + kb + it * nbx, tiles);
@@ -536,7 +570,7 @@ __global__ __launch_bounds__(768) void cv_fwd_persist_kernel(CvTileParams q) {
                 sP[512 + wm * 128 + cl] = z; sP[1024 + wm * 128 + cl] = b;
             }
         }
-        if (it + 1 < n_tiles) prefetch(it + 1);
+        if (it + 1 < n_tiles && !(dbg & 1)) prefetch(it + 1);
     }
     cvp_barrier();
 }
@@ -773,12 +807,14 @@ extern "C" int gd_cost_volume_kl_fwd(const void* f1, const void* f2, const float
         if (cached_cu >= 8) ncu = cached_cu / 8 * 8;
         const long total = (long)P * tiles * tiles;
         int grid = (int)(total < ncu ? (total + 7) / 8 * 8 : ncu);
+        if (const char* e = getenv("GD_CV_DBG")) q.dbg = atoi(e);
         if (const char* e = getenv("GD_CV_GRID")) {      // tests: few blocks, so that every block walks many tiles
             const int gv = atoi(e) / 8 * 8;
             if (gv >= 8 && gv < grid) grid = gv;
         }
-        if (dtype == GD_BF16) hipLaunchKernelGGL(cv_fwd_persist_kernel<bf16>, dim3(grid), dim3(768), 0, s, q);
-        else hipLaunchKernelGGL(cv_fwd_persist_kernel<float>, dim3(grid), dim3(768), 0, s, q);
+        if (q.dbg && dtype == GD_BF16) hipLaunchKernelGGL((cv_fwd_persist_kernel<bf16, true>), dim3(grid), dim3(768), 0, s, q);
+        else if (dtype == GD_BF16) hipLaunchKernelGGL((cv_fwd_persist_kernel<bf16, false>), dim3(grid), dim3(768), 0, s, q);
+        else hipLaunchKernelGGL((cv_fwd_persist_kernel<float, false>), dim3(grid), dim3(768), 0, s, q);
     } else if (dtype == GD_BF16)
         hipLaunchKernelGGL(cv_fwd_tile_kernel<bf16>, dim3(tiles * tiles, P), dim3(256), 0, s, q);
     else

@@ -72,12 +72,14 @@ def bench_cv():
             es = 2 if dt == torch.bfloat16 else 4
             fwd_bytes = P * (2 * hw * C * es + 2 * hw * hw * 4 + 2 * hw)
             bwd_bytes = fwd_bytes + P * 2 * hw * C * es
+            t1, t2 = ops.pad_teacher_maps(t1), ops.pad_teacher_maps(t2)
+            ts = ops.cost_volume_teacher_stats(t1, t2)
             with torch.no_grad():
-                tf = timeit(lambda: ops.cost_volume_kl(f1, f2, t1, t2, m1, m2, "vggt"))
+                tf = timeit(lambda: ops.cost_volume_kl(f1, f2, t1, t2, m1, m2, "vggt", tstats=ts))
 
             def fb():
                 f1.grad = f2.grad = None
-                ops.cost_volume_kl(f1, f2, t1, t2, m1, m2, "vggt").sum().backward()
+                ops.cost_volume_kl(f1, f2, t1, t2, m1, m2, "vggt", tstats=ts).sum().backward()
             tfb = timeit(fb)
             print(f"cost_volume {str(dt)[6:]:9s} P={P:2d}: fwd {tf*1e6/P:8.1f} us/pair {fwd_bytes/tf/1e9:8.1f} GB/s | "
                   f"fwd+bwd {tfb*1e6/P:8.1f} us/pair {(fwd_bytes+bwd_bytes)/tfb/1e9:8.1f} GB/s")
@@ -112,9 +114,11 @@ def pmc_cv():
     t2 = torch.softmax(3 * torch.randn(P, hw, hw, device="cuda"), -1)
     m1 = torch.rand(P, hw, device="cuda") > 0.3
     m2 = torch.rand(P, hw, device="cuda") > 0.3
+    t1, t2 = ops.pad_teacher_maps(t1), ops.pad_teacher_maps(t2)          # the cached-target layout (teacher_cache.py)
+    ts = ops.cost_volume_teacher_stats(t1, t2)
     for _ in range(3):
         f1.grad = f2.grad = None
-        ops.cost_volume_kl(f1, f2, t1, t2, m1, m2, "vggt").sum().backward()
+        ops.cost_volume_kl(f1, f2, t1, t2, m1, m2, "vggt", tstats=ts).sum().backward()
     torch.cuda.synchronize()
 
 
