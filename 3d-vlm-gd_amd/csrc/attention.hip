@@ -32,18 +32,93 @@ __device__ __forceinline__ float quad_rows_max(float v) {
     return fmaxf(__builtin_bit_cast(float, b[0]), __builtin_bit_cast(float, b[1]));
 }
 
+// ---- softmax with a LAGGED reference point (forward) ---------------------------------------------------------------
+// The score accumulators are started from -m (the MFMA's C operand: a persistent register quartet per query tile, no
+// instruction), with q pre-multiplied by scale*log2(e), so a finished accumulator is already  s*c2 - m  and p is ONE
+// v_exp per score — the online softmax's subtract / scale FMA is gone, and so is its running row sum: the row sums come
+// out of the PV product as one more MFMA per k-chunk against an all-ones A fragment (they are then the sums of exactly
+// the bf16-rounded p that multiply V).  m is a reference point, not the exact running maximum: the first tile sets it to
+// the tile's row maximum, later tiles only RAISE it, and only when a score exceeds it by more than ATT_THR (p <= 2^THR
+// otherwise): a wave-uniform branch that is almost never taken after the first tiles.  Any reference point gives the same
+// o = sum p v / sum p and lse = m + log2 sum p; the first-tile rule keeps sum p >= 1, so nothing can underflow to 0 / 0.
+#define ATT_THR 8.0f
+template <typename T> __device__ __forceinline__ typename Mma<T>::Frag frag_scale(typename Mma<T>::Frag f, float a);
+template <> __device__ __forceinline__ bf16x8 frag_scale<bf16>(bf16x8 f, float a) {
+    bf16x8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (bf16)((float)f[k] * a);
+    return o;
+}
+template <> __device__ __forceinline__ f32x4 frag_scale<float>(f32x4 f, float a) { return f * a; }
+template <typename T> __device__ __forceinline__ typename Mma<T>::Frag frag_ones();
+template <> __device__ __forceinline__ bf16x8 frag_ones<bf16>() {
+    const bf16 o = (bf16)1.0f;
+    return bf16x8{o, o, o, o, o, o, o, o};
+}
+template <> __device__ __forceinline__ f32x4 frag_ones<float>() { return f32x4{1.f, 1.f, 1.f, 1.f}; }
+
+// s[qt][kt] hold s*c2 - m of a 64-key tile (TAIL: keys >= N get -1e30).  Updates m / negm (and rescales o, l) when the
+// tile's maximum moved the reference point, then turns the scores into p in place.
+template <bool TAIL>
+__device__ __forceinline__ void softmax_lagged(f32x4 (&s)[2][4], float (&m)[2], f32x4 (&negm)[2], f32x4 (&oacc)[4][2],
+                                               f32x4 (&lacc)[2], bool first, int k0, int g, int N) {
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        float tmax = -1e30f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (TAIL && k0 + kt * 16 + g * 4 + r >= N) s[qt][kt][r] = -1e30f;
+                tmax = fmaxf(tmax, s[qt][kt][r]);
+            }
+        tmax = quad_rows_max(tmax);
+        const bool need = first || tmax > ATT_THR;
+        if (__any(need)) {
+            const float d = need ? tmax : 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[qt][kt][r] -= d;
+            m[qt] += d;
+            negm[qt] = f32x4{-m[qt], -m[qt], -m[qt], -m[qt]};
+            if (!first) {                                  // (first tile: o and l are still zero, and d may be negative)
+                const float alpha = fast_exp2(-d);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) oacc[dt][qt] *= alpha;
+                lacc[qt] *= alpha;
+            }
+        }
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[qt][kt][r] = fast_exp2(s[qt][kt][r]);
+    }
+}
+
 template <typename T> struct AT;
+// LDS tiles of 64 rows.  bf16: rows are 128 bytes UNPADDED and the 16-byte chunk index is XOR-ed with
+// sw(row) = ((row >> 1) & 3) << 1.  One image serves both read patterns conflict-free (PMC before: 33-43 % of the LDS cycles
+// of these kernels were bank-conflict cycles with padded 144-byte rows / the GEMM's (row >> 1) & 7 swizzle):
+//   * ds_read_b128 fragment reads (rows 16 k + c, chunk 4 u + g): the hardware serves lanes {0-3, 12-15, 20-27} together —
+//     rows c in {0..3, 12..15} at chunk q and rows {4..11} at chunk q ^ 1; rows of equal parity share a 128-byte bank
+//     half and get the XOR values {0, 2, 4, 6} resp. {4, 6, 0, 2}: eight distinct chunks per half;
+//   * ds_read_b64_tr_b16 transpose reads (32 lanes = 8 consecutive rows x the chunk PAIR {2 dt, 2 dt + 1}): the four rows of
+//     equal parity need four different pairs — XOR by an even number that differs between them, which an odd XOR ((row >> 1) & 7
+//     has them) does not give.
 template <> struct AT<bf16> {
     static constexpr int NF = 2;        // fragments per 64-wide contraction
-    static constexpr int ROWB = 144;    // LDS row: 64 el * 2 B + 16 pad
+    static constexpr int ROWB = 128;    // LDS row: 64 el * 2 B
     static constexpr int CPR = 8;       // 16-byte chunks per 64-element row
     static constexpr int EPC = 8;       // elements per chunk
+    static __device__ __forceinline__ int sw(int row) { return ((row >> 1) & 3) << 1; }
 };
 template <> struct AT<float> {
     static constexpr int NF = 4;
-    static constexpr int ROWB = 272;
+    static constexpr int ROWB = 272;    // 64 el * 4 B + 16 pad, linear
     static constexpr int CPR = 16;
     static constexpr int EPC = 4;
+    static __device__ __forceinline__ int sw(int) { return 0; }
 };
 
 // four C-layout tiles that span 64 contraction indices (index = 16*tile + 4*g + r) -> B fragment u
@@ -70,6 +145,11 @@ template <typename T> __device__ __forceinline__ typename Mma<T>::Frag load_nfra
     return *(const typename Mma<T>::Frag*)(row + u * 64 + g * 16);
 }
 
+// natural fragment u of row `row` of an LDS tile (chunk 4 u + g, swizzled)
+template <typename T> __device__ __forceinline__ typename Mma<T>::Frag lds_nfrag(const char* tile, int row, int u, int g) {
+    return *(const typename Mma<T>::Frag*)(tile + row * AT<T>::ROWB + (((u * 4 + g) ^ AT<T>::sw(row)) * 16));
+}
+
 // Tile staging, split T14-style: `tile_load` issues the global loads of a 64 x 64-element tile into registers
 // (rows >= nvalid read as zero) and `tile_store` writes them to LDS later — as a natural tile sN[row][64]
 // and/or a transposed tile sT[col][row] — so the next tile's HBM/L2 latency hides under the current tile's MFMAs.
@@ -90,7 +170,7 @@ __device__ __forceinline__ void tile_store(const TileRegs<T, NT>& r, char* sN, c
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int ch = threadIdx.x + NT * i, rr = ch / CPR, cc = ch % CPR;
-        if (NAT) *(uint4*)(sN + rr * ROWB + cc * 16) = r.v[i];
+        if (NAT) *(uint4*)(sN + rr * ROWB + ((cc ^ AT<T>::sw(rr)) * 16)) = r.v[i];
         if (TRN) {
             const T* e = (const T*)&r.v[i];
 #pragma unroll
@@ -109,7 +189,8 @@ template <> struct TOp<bf16> {
     static __device__ __forceinline__ bf16x8 load(const char* sN, const char*, int dt, int u, int g, int lane) {
         typedef __attribute__((ext_vector_type(4))) short s16x4;
         const int i = lane & 15, q = i >> 2, p = i & 3;
-        const char* a0 = sN + (32 * u + 4 * g + q) * AT<bf16>::ROWB + (dt * 16 + 4 * p) * 2;
+        const int row = 32 * u + 4 * g + q;                         // (row + 16 has the same swizzle)
+        const char* a0 = sN + row * AT<bf16>::ROWB + (((2 * dt + (p >> 1)) ^ AT<bf16>::sw(row)) * 16) + 8 * (p & 1);
         const char* a1 = a0 + 16 * AT<bf16>::ROWB;
         const s16x4 x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
         const s16x4 y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1);
@@ -163,13 +244,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* qkv, T* o, fl
     const char* kb = base + (long)(1 * H + h) * HD * sizeof(T);
     const char* vb = base + (long)(2 * H + h) * HD * sizeof(T);
 
-    Frag qf[2][NF];
+    const float c2 = scale * 1.4426950408889634f;
+    Frag qf[2][NF];       // q * scale * log2(e): the scores come out of the MFMA in the exp2 domain
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         const int q = q0 + qt * 16 + c;
 #pragma unroll
         for (int u = 0; u < NF; ++u) {
-            if (q < N) qf[qt][u] = load_nfrag<T>(qb + (long)q * ld_b, u, g);
+            if (q < N) qf[qt][u] = frag_scale<T>(load_nfrag<T>(qb + (long)q * ld_b, u, g), c2);
             else { Frag z = {}; qf[qt][u] = z; }
         }
     }
@@ -178,8 +260,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* qkv, T* o, fl
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) oacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m[2] = {-1e30f, -1e30f}, l[2] = {0.f, 0.f};   // m in log2 units
-    const float c2 = scale * 1.4426950408889634f;
+    float m[2] = {0.f, 0.f};                                  // reference point, log2 units (see softmax_lagged)
+    f32x4 negm[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    f32x4 lacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};   // row sums (every row of the tile = the sum)
+    const Frag ones = frag_ones<T>();
 
     TileRegs<T> rk, rv;
     tile_load<T>(rk, kb, ld_b, 0, N);
@@ -201,53 +285,24 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* qkv, T* o, fl
         for (int kt = 0; kt < 4; ++kt) {
             Frag kf[NF];
 #pragma unroll
-            for (int u = 0; u < NF; ++u) kf[u] = load_nfrag<T>(sK + (kt * 16 + c) * ROWB, u, g);
+            for (int u = 0; u < NF; ++u) kf[u] = lds_nfrag<T>(sK, kt * 16 + c, u, g);
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
-                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                f32x4 a = negm[qt];
 #pragma unroll
                 for (int u = 0; u < NF; ++u) a = Mma<T>::mma(kf[u], qf[qt][u], a);
                 s[qt][kt] = a;
             }
         }
-        // online softmax in the exp2 domain: p = 2^(s*c2 - m2), c2 = scale*log2(e) — one FMA + one v_exp per score;
-        // O is rescaled only when some row maximum moved.
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-            float tmax = -1e30f;
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (tail && k0 + kt * 16 + g * 4 + r >= N) s[qt][kt][r] = -1e30f;
-                    tmax = fmaxf(tmax, s[qt][kt][r]);
-                }
-            tmax = quad_rows_max(tmax);
-            const float mn = fmaxf(m[qt], tmax * c2);      // c2 > 0: max commutes with the scaling
-            const float alpha = fast_exp2(m[qt] - mn);
-            float ps = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = fast_exp2(fmaf(s[qt][kt][r], c2, -mn));
-                    s[qt][kt][r] = p;
-                    ps += p;
-                }
-            l[qt] = l[qt] * alpha + ps;                     // per-LANE partial (this lane's 16 keys of every tile): the
-                                                            // four lanes of a query are summed once, after the loop
-            const bool moved = mn != m[qt];
-            m[qt] = mn;
-            if (__any(moved)) {
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) oacc[dt][qt] *= alpha;
-            }
-        }
+        softmax_lagged<tail>(s, m, negm, oacc, lacc, k0 == 0, k0, g, N);
 #pragma unroll
         for (int u = 0; u < NF; ++u) {
             Frag pf[2];
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) pf[qt] = acc_to_bfrag<T>(s[qt], u);
+            for (int qt = 0; qt < 2; ++qt) {
+                pf[qt] = acc_to_bfrag<T>(s[qt], u);
+                lacc[qt] = Mma<T>::mma(ones, pf[qt], lacc[qt]);
+            }
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const Frag vf = TOp<T>::load(sV, sVt, dt, u, g, lane);
@@ -262,14 +317,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* qkv, T* o, fl
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         const int q = q0 + qt * 16 + c;
-        l[qt] += __shfl_xor(l[qt], 16, 64);
-        l[qt] += __shfl_xor(l[qt], 32, 64);
         if (q >= N) continue;
-        const float inv = 1.0f / l[qt];
+        const float lsum = lacc[qt][0];
+        const float inv = 1.0f / lsum;
         T* orow = o + ((long)b * N + q) * H * HD + h * HD;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) store4<T>(orow + dt * 16 + g * 4, oacc[dt][qt] * inv);
-        if (g == 0) lse[((long)b * H + h) * N + q] = (m[qt] + log2f(l[qt])) * 0.6931471805599453f;   // natural log
+        if (g == 0) lse[((long)b * H + h) * N + q] = (m[qt] + log2f(lsum)) * 0.6931471805599453f;   // natural log
     }
 }
 
@@ -300,13 +354,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const bf16* qkv, b
     const char* kb = base + (long)(1 * H + h) * HD * 2;
     const char* vb = base + (long)(2 * H + h) * HD * 2;
 
-    Frag qf[2][2];
+    const float c2 = scale * 1.4426950408889634f;
+    Frag qf[2][2];        // q * scale * log2(e)
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         const int q = q0 + qt * 16 + c;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            if (q < N) qf[qt][u] = load_nfrag<bf16>(qb + (long)q * ld_b, u, g);
+            if (q < N) qf[qt][u] = frag_scale<bf16>(load_nfrag<bf16>(qb + (long)q * ld_b, u, g), c2);
             else { Frag z = {}; qf[qt][u] = z; }
         }
     }
@@ -316,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const bf16* qkv, b
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = (wave * 2 + i) * 8 + prow;
-            const long off = (long)min(k0 + row, N - 1) * ld_b + ((pchunk ^ ((row >> 1) & 7)) * 16);
+            const long off = (long)min(k0 + row, N - 1) * ld_b + ((pchunk ^ AT<bf16>::sw(row)) * 16);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kb + off),
                                              (__attribute__((address_space(3))) void*)(smem + slot * TILE + (wave * 2 + i) * 1024), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vb + off),
@@ -325,10 +380,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const bf16* qkv, b
     };
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)smem;
     // K fragment (kt, u): row kt*16 + c, logical chunk 4u + g
-    const int swk = (c >> 1) & 7;
+    const int swk = AT<bf16>::sw(c);
     const unsigned ka0 = c * 128 + ((0 + g) ^ swk) * 16, ka1 = c * 128 + ((4 + g) ^ swk) * 16;
     // V transpose fragment (dt, u): rows 32u + 4g + q (+16), logical chunk 2dt + (p>>1), 8-byte half p&1
-    const int vq = c >> 2, vp = c & 3, swv = (2 * g + (vq >> 1)) & 7;
+    const int vq = c >> 2, vp = c & 3, swv = AT<bf16>::sw(4 * g + vq);
     unsigned va[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) va[dt] = (4 * g + vq) * 128 + (((2 * dt + (vp >> 1)) ^ swv) * 16) + 8 * (vp & 1);
@@ -338,8 +393,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const bf16* qkv, b
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) oacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m[2] = {-1e30f, -1e30f}, l[2] = {0.f, 0.f};   // m in log2 units
-    const float c2 = scale * 1.4426950408889634f;
+    float m[2] = {0.f, 0.f};                                  // reference point, log2 units (see softmax_lagged)
+    f32x4 negm[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    f32x4 lacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    const Frag ones = frag_ones<bf16>();
     const int ntile = (N + 63) / 64, nfull = N / 64;
     // The x-blocks of an (image, head) start together on one XCD and sweep the same K / V tiles at the same pace: in
     // lockstep they all ask one L2 channel for the same lines at the same moment.  Softmax accumulation does not care about
@@ -371,7 +428,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const bf16* qkv, b
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
-                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                f32x4 a = negm[qt];
 #pragma unroll
                 for (int u = 0; u < 2; ++u) a = Mma<bf16>::mma(__builtin_bit_cast(Frag, kr[kt][u]), qf[qt][u], a);
                 s[qt][kt] = a;
@@ -383,36 +440,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const bf16* qkv, b
         ADS_TR64(vr[dt][1][0], vbase + va[dt], 4096); ADS_TR64(vr[dt][1][1], vbase + va[dt], 6144);
         ADS_V(0) ADS_V(1) ADS_V(2) ADS_V(3)
 #undef ADS_V
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-            float tmax = -1e30f;
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (tail && k0 + kt * 16 + g * 4 + r >= N) s[qt][kt][r] = -1e30f;
-                    tmax = fmaxf(tmax, s[qt][kt][r]);
-                }
-            tmax = quad_rows_max(tmax);
-            const float mn = fmaxf(m[qt], tmax * c2);
-            const float alpha = fast_exp2(m[qt] - mn);
-            float ps = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = fast_exp2(fmaf(s[qt][kt][r], c2, -mn));
-                    s[qt][kt][r] = p;
-                    ps += p;
-                }
-            l[qt] = l[qt] * alpha + ps;
-            const bool moved = mn != m[qt];
-            m[qt] = mn;
-            if (__any(moved)) {
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) oacc[dt][qt] *= alpha;
-            }
-        }
+        softmax_lagged<tail>(s, m, negm, oacc, lacc, t == 0, k0, g, N);
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vr[0][0][0]), "+v"(vr[0][0][1]), "+v"(vr[0][1][0]), "+v"(vr[0][1][1]), "+v"(vr[1][0][0]),
                      "+v"(vr[1][0][1]), "+v"(vr[1][1][0]), "+v"(vr[1][1][1]), "+v"(vr[2][0][0]), "+v"(vr[2][0][1]), "+v"(vr[2][1][0]),
                      "+v"(vr[2][1][1]), "+v"(vr[3][0][0]), "+v"(vr[3][0][1]), "+v"(vr[3][1][0]), "+v"(vr[3][1][1]));
@@ -420,7 +448,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const bf16* qkv, b
         for (int u = 0; u < 2; ++u) {
             Frag pf[2];
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) pf[qt] = acc_to_bfrag<bf16>(s[qt], u);
+            for (int qt = 0; qt < 2; ++qt) {
+                pf[qt] = acc_to_bfrag<bf16>(s[qt], u);
+                lacc[qt] = Mma<bf16>::mma(ones, pf[qt], lacc[qt]);
+            }
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 typedef __attribute__((ext_vector_type(4))) unsigned a_u32x4;
@@ -437,14 +468,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const bf16* qkv, b
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         const int q = q0 + qt * 16 + c;
-        l[qt] += __shfl_xor(l[qt], 16, 64);
-        l[qt] += __shfl_xor(l[qt], 32, 64);
         if (q >= N) continue;
-        const float inv = 1.0f / l[qt];
+        const float lsum = lacc[qt][0];
+        const float inv = 1.0f / lsum;
         bf16* orow = o + ((long)b * N + q) * H * HD + h * HD;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) store4<bf16>(orow + dt * 16 + g * 4, oacc[dt][qt] * inv);
-        if (g == 0) lse[((long)b * H + h) * N + q] = (m[qt] + log2f(l[qt])) * 0.6931471805599453f;
+        if (g == 0) lse[((long)b * H + h) * N + q] = (m[qt] + log2f(lsum)) * 0.6931471805599453f;
     }
 }
 
@@ -491,7 +521,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const T* qkv, const
 #pragma unroll
         for (int u = 0; u < NF; ++u) {
             Frag z = {};
-            qf[qt][u] = ok ? load_nfrag<T>(qb + (long)q * ld_b, u, g) : z;
+            qf[qt][u] = ok ? frag_scale<T>(load_nfrag<T>(qb + (long)q * ld_b, u, g), scale * 1.4426950408889634f) : z;   // exp2 domain
             dof[qt][u] = ok ? load_nfrag<T>(dob + (long)q * ldo_b, u, g) : z;
             const Frag of_ = ok ? load_nfrag<T>(ob + (long)q * ldo_b, u, g) : z;
             dsum += frag_dot(dof[qt][u], of_);
@@ -507,7 +537,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const T* qkv, const
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) dq[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float c2 = scale * 1.4426950408889634f;
+    // row constants as the initial accumulators (the MFMA's C operand): S' = q k c2 - lse2 and dP' = dO v - delta leave the
+    // chains ready, p = exp2(S') and dS = p * dP' — one v_exp and one multiply per score, no subtract / scale FMA
+    f32x4 nlq[2], ndl[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        nlq[qt] = f32x4{-lq[qt], -lq[qt], -lq[qt], -lq[qt]};
+        ndl[qt] = f32x4{-dl[qt], -dl[qt], -dl[qt], -dl[qt]};
+    }
 
     // (key tiles in plain order: a per-block rotated order, which helps the forward kernel a little, measured 4 % SLOWER here —
     //  the blocks of an (image, head) trail each other through the L2 and the rotation takes that away)
@@ -532,23 +569,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const T* qkv, const
             Frag kf[NF], vf[NF];
 #pragma unroll
             for (int u = 0; u < NF; ++u) {
-                kf[u] = load_nfrag<T>(sK + (kt * 16 + c) * ROWB, u, g);
-                vf[u] = load_nfrag<T>(sV + (kt * 16 + c) * ROWB, u, g);
+                kf[u] = lds_nfrag<T>(sK, kt * 16 + c, u, g);
+                vf[u] = lds_nfrag<T>(sV, kt * 16 + c, u, g);
             }
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
-                f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                f32x4 s = nlq[qt], dp = ndl[qt];
 #pragma unroll
                 for (int u = 0; u < NF; ++u) {
                     s = Mma<T>::mma(kf[u], qf[qt][u], s);
                     dp = Mma<T>::mma(vf[u], dof[qt][u], dp);
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
+                for (int r = 0; r < 4; ++r)
                     // keys >= N need no mask: their K rows are staged as zeros, so whatever dS they get never reaches dQ
-                    const float p = fast_exp2(fmaf(s[r], c2, -lq[qt]));
-                    ds[qt][kt][r] = p * (dp[r] - dl[qt]);          // the 1/sqrt(d) factor is applied once, to dQ
-                }
+                    ds[qt][kt][r] = fast_exp2(s[r]) * dp[r];       // the 1/sqrt(d) factor is applied once, to dQ
             }
         }
 #pragma unroll
@@ -584,7 +619,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const T* qkv, con
     __shared__ __attribute__((aligned(16))) char sQt[TSZ(T)];
     __shared__ __attribute__((aligned(16))) char sD[64 * ROWB];
     __shared__ __attribute__((aligned(16))) char sDt[TSZ(T)];
-    __shared__ float sL[64], sDl[64];
+    __shared__ __attribute__((aligned(16))) float sL[64], sDl[64];   // -lse (log2 units) and -delta of the tile's 64 queries
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
     constexpr int NT = 64 * NW;
     int xb_, h, b;
@@ -605,11 +640,10 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const T* qkv, con
 #pragma unroll
         for (int u = 0; u < NF; ++u) {
             Frag z = {};
-            kf[kt][u] = key < N ? load_nfrag<T>(kb + (long)key * ld_b, u, g) : z;
+            kf[kt][u] = key < N ? frag_scale<T>(load_nfrag<T>(kb + (long)key * ld_b, u, g), scale * 1.4426950408889634f) : z;   // exp2 domain
             vf[kt][u] = key < N ? load_nfrag<T>(vb + (long)key * ld_b, u, g) : z;
         }
     }
-    const float c2 = scale * 1.4426950408889634f;
     const bool wave_live = key0 < N;
     f32x4 dk[4][2], dv[4][2];
 #pragma unroll
@@ -638,7 +672,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const T* qkv, con
             tile_load<T, NT>(rq, qb, ld_b, pq0(t + 1), N);
             tile_load<T, NT>(rd, dob, ldo_b, pq0(t + 1), N);
         }
-        if (threadIdx.x < 64) { sL[threadIdx.x] = rl * 1.4426950408889634f; sDl[threadIdx.x] = rdl; }   // lse in log2 units
+        if (threadIdx.x < 64) { sL[threadIdx.x] = -rl * 1.4426950408889634f; sDl[threadIdx.x] = -rdl; }   // negated: accumulator seeds
         if (t + 1 < ntile && threadIdx.x < 64) {
             const int q = pq0(t + 1) + threadIdx.x;
             rl = q < N ? lse[((long)b * H + h) * N + q] : LSE_PAD;
@@ -653,12 +687,14 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const T* qkv, con
             Frag qf[NF], df[NF];
 #pragma unroll
             for (int u = 0; u < NF; ++u) {
-                qf[u] = load_nfrag<T>(sQ + (qt * 16 + c) * ROWB, u, g);
-                df[u] = load_nfrag<T>(sD + (qt * 16 + c) * ROWB, u, g);
+                qf[u] = lds_nfrag<T>(sQ, qt * 16 + c, u, g);
+                df[u] = lds_nfrag<T>(sD, qt * 16 + c, u, g);
             }
+            // row constants as the initial accumulators: the four queries 16 qt + 4 g + r of this lane's C rows
+            const f32x4 nl = *(const f32x4*)(sL + qt * 16 + g * 4), nd = *(const f32x4*)(sDl + qt * 16 + g * 4);
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
-                f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                f32x4 s = nl, dp = nd;
 #pragma unroll
                 for (int u = 0; u < NF; ++u) {
                     s = Mma<T>::mma(qf[u], kf[kt][u], s);    // rows: queries, cols: keys
@@ -666,10 +702,9 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const T* qkv, con
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int ql = qt * 16 + g * 4 + r;
-                    const float p = fast_exp2(fmaf(s[r], c2, -sL[ql]));
+                    const float p = fast_exp2(s[r]);
                     pp[kt][qt][r] = p;
-                    dsv[kt][qt][r] = p * (dp[r] - sDl[ql]);        // the 1/sqrt(d) factor is applied once, to dK
+                    dsv[kt][qt][r] = p * dp[r];                    // the 1/sqrt(d) factor is applied once, to dK
                 }
             }
         }
@@ -749,7 +784,7 @@ __global__ __launch_bounds__(256, 2) void cva_stats_kernel(const T* q, const T* 
         for (int kt = 0; kt < 4; ++kt) {
             Frag kf[NF];
 #pragma unroll
-            for (int u = 0; u < NF; ++u) kf[u] = load_nfrag<T>(sK + (kt * 16 + c) * ROWB, u, g);
+            for (int u = 0; u < NF; ++u) kf[u] = lds_nfrag<T>(sK, kt * 16 + c, u, g);
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
                 f32x4 a = {0.f, 0.f, 0.f, 0.f};
@@ -831,7 +866,7 @@ __global__ __launch_bounds__(256, 2) void cva_emit_kernel(const T* q, const T* k
         for (int kt = 0; kt < 4; ++kt) {
             Frag kf[NF];
 #pragma unroll
-            for (int u = 0; u < NF; ++u) kf[u] = load_nfrag<T>(sK + (kt * 16 + c) * ROWB, u, g);
+            for (int u = 0; u < NF; ++u) kf[u] = lds_nfrag<T>(sK, kt * 16 + c, u, g);
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
                 f32x4 a = {0.f, 0.f, 0.f, 0.f};
