@@ -78,6 +78,9 @@ SIGNATURES = {
                                  c_void_p]),
     "gd_nn_argmax": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "gd_point_cloud_to_depth": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "gd_post_process_depth_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "gd_post_process_depth": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_int, c_float,
+                                      c_void_p, c_void_p]),
     "gd_rope_2d": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_long, c_float, c_float, c_int, c_void_p]),
     "gd_mast3r_attn_target": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "gd_cross_view_attn_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),

@@ -26,23 +26,28 @@ __global__ void coview_kernel(const float* pm1, const float* pm2, const float* K
     const int p = i / ((long)H * W);
     const float* e1 = E1 + p * 12; const float* e2 = E2 + p * 12;
     const float* k1 = K1 + p * 9;  const float* k2 = K2 + p * 9;
+    // The masks are bool: the arithmetic is pinned to one explicit fp32 operation order (the reference's matmuls restated as
+    // sequential fused multiply-add chains, IEEE division), no compiler contraction or fast division left to chance.
     auto P34 = [](const float* K, const float* E, float (&M)[12]) {
         for (int r = 0; r < 3; ++r)
-            for (int c = 0; c < 4; ++c) M[r * 4 + c] = K[r * 3 + 0] * E[c] + K[r * 3 + 1] * E[4 + c] + K[r * 3 + 2] * E[8 + c];
+            for (int c = 0; c < 4; ++c)
+                M[r * 4 + c] = __builtin_fmaf(K[r * 3 + 2], E[8 + c], __builtin_fmaf(K[r * 3 + 1], E[4 + c], __fmul_rn(K[r * 3 + 0], E[c])));
     };
     float Pa[12], Pb[12];
     P34(k2, e2, Pa);   // view 1 points -> view 2 image
     P34(k1, e1, Pb);   // view 2 points -> view 1 image
     auto test = [&](const float* pm, const float* Pm) -> unsigned char {
-        const float qx = pm[0] - e1[3], qy = pm[1] - e1[7], qz = pm[2] - e1[11];
+        const float qx = __fsub_rn(pm[0], e1[3]), qy = __fsub_rn(pm[1], e1[7]), qz = __fsub_rn(pm[2], e1[11]);
         // torch.matmul(pm - t, R.t()):  w_k = sum_j q_j R[k][j]
-        const float wx = qx * e1[0] + qy * e1[1] + qz * e1[2];
-        const float wy = qx * e1[4] + qy * e1[5] + qz * e1[6];
-        const float wz = qx * e1[8] + qy * e1[9] + qz * e1[10];
-        const float hx = Pm[0] * wx + Pm[1] * wy + Pm[2] * wz + Pm[3];
-        const float hy = Pm[4] * wx + Pm[5] * wy + Pm[6] * wz + Pm[7];
-        const float hz = Pm[8] * wx + Pm[9] * wy + Pm[10] * wz + Pm[11];
-        const float u = hx / (hz + 1e-8f), v = hy / (hz + 1e-8f);
+        const float wx = __builtin_fmaf(qz, e1[2], __builtin_fmaf(qy, e1[1], __fmul_rn(qx, e1[0])));
+        const float wy = __builtin_fmaf(qz, e1[6], __builtin_fmaf(qy, e1[5], __fmul_rn(qx, e1[4])));
+        const float wz = __builtin_fmaf(qz, e1[10], __builtin_fmaf(qy, e1[9], __fmul_rn(qx, e1[8])));
+        // P @ [w; 1]
+        const float hx = __fadd_rn(__builtin_fmaf(Pm[2], wz, __builtin_fmaf(Pm[1], wy, __fmul_rn(Pm[0], wx))), Pm[3]);
+        const float hy = __fadd_rn(__builtin_fmaf(Pm[6], wz, __builtin_fmaf(Pm[5], wy, __fmul_rn(Pm[4], wx))), Pm[7]);
+        const float hz = __fadd_rn(__builtin_fmaf(Pm[10], wz, __builtin_fmaf(Pm[9], wy, __fmul_rn(Pm[8], wx))), Pm[11]);
+        const float den = __fadd_rn(hz, 1e-8f);
+        const float u = __fdiv_rn(hx, den), v = __fdiv_rn(hy, den);
         return (u >= 0.f && u < (float)W && v >= 0.f && v < (float)H) ? 1 : 0;
     };
     m1[i] = test(pm1 + i * 3, Pa);
@@ -270,6 +275,174 @@ extern "C" int gd_mast3r_attn_target(const float* recip_scores, int L, int B, in
     hipLaunchKernelGGL(mast3r_target_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, recip_scores, out, workspace, L, rows,
                        N2, 1.0f / temperature);
     hipLaunchKernelGGL(mast3r_target_col0_kernel, dim3(1), dim3(256), 0, s, workspace, out, L, rows, N2);
+    GD_LAUNCH_OK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// post_process_depth (utils/functions.py:262-345): the rasterised MASt3R depth map -> closed, hole-filled, median /
+// bilateral / guided filtered, outlier-replaced, joint-bilateral filtered map.  Stencils on [P][H][W] maps, one thread
+// per pixel.  SOURCE ABSENT — PARITY UNPINNED for the four kornia filters (restated from their published definitions, see
+// oracle/gd_oracle.py:post_process_depth); the torch parts follow the source.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int ppd_reflect(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+// out = max (sign = +1) / min (sign = -1) over the k x k window, cells outside the image ignored (max_pool2d's -inf padding)
+__global__ void ppd_pool_kernel(const float* in, float* out, int H, int W, int k, float sign) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= H * W) return;
+    const int y = i / W, x = i % W, r = k / 2;
+    const float* m = in + (long)blockIdx.y * H * W;
+    float best = -INFINITY;
+    for (int dy = -r; dy <= r; ++dy)
+        for (int dx = -r; dx <= r; ++dx) {
+            const int yy = y + dy, xx = x + dx;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) best = fmaxf(best, sign * m[yy * W + xx]);
+        }
+    out[(long)blockIdx.y * H * W + i] = sign * best;
+}
+
+// one hole-filling pass (:283-310): valid = in >= thr (first pass, thr = 1e-5) or in > 0 (second pass, strict)
+__global__ void ppd_fill_kernel(const float* in, float* out, int H, int W, int ks, float thr, int strict) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= H * W) return;
+    const int y = i / W, x = i % W, r = ks / 2;
+    const float* m = in + (long)blockIdx.y * H * W;
+    float cnt = 0.f, val = 0.f;
+    for (int dy = -r; dy <= r; ++dy)
+        for (int dx = -r; dx <= r; ++dx) {
+            const int yy = y + dy, xx = x + dx;
+            if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;          // conv2d zero padding
+            const float v = m[yy * W + xx];
+            const bool ok = strict ? v > 0.f : v >= thr;
+            if (ok) { cnt += 1.f; val += v; }
+        }
+    const float c = m[i];
+    const float valid = (strict ? c > 0.f : c >= thr) ? 1.f : 0.f;
+    const float fill = fminf(fmaxf((cnt > 0.f ? 1.f : 0.f) - valid, 0.f), 1.f);
+    out[(long)blockIdx.y * H * W + i] = c * valid + val / (cnt + 1e-8f) * fill;
+}
+
+// kornia median_blur: zero padding, lower median of the k x k window (k in {3, 5})
+__global__ void ppd_median_kernel(const float* in, float* out, int H, int W, int k) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= H * W) return;
+    const int y = i / W, x = i % W, r = k / 2, n = k * k;
+    const float* m = in + (long)blockIdx.y * H * W;
+    float v[25];
+    int c = 0;
+    for (int dy = -r; dy <= r; ++dy)
+        for (int dx = -r; dx <= r; ++dx) {
+            const int yy = y + dy, xx = x + dx;
+            const float t = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? m[yy * W + xx] : 0.f;
+            int j = c++;
+            while (j > 0 && v[j - 1] > t) { v[j] = v[j - 1]; --j; }        // insertion sort
+            v[j] = t;
+        }
+    out[(long)blockIdx.y * H * W + i] = v[(n - 1) / 2];
+}
+
+// kornia (joint_)bilateral_blur, border 'reflect', single channel: w = gauss_space * exp(-0.5 (g_nb - g_c)^2 / sigma_c^2)
+__global__ void ppd_bilateral_kernel(const float* in, const float* guide, float* out, int H, int W, int k, float sigma_color,
+                                     float sigma_space) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= H * W) return;
+    const int y = i / W, x = i % W, r = k / 2;
+    const float* m = in + (long)blockIdx.y * H * W;
+    const float* g = guide + (long)blockIdx.y * H * W;
+    const float gc = g[i], ic = -0.5f / (sigma_color * sigma_color), is = -1.0f / (2.f * sigma_space * sigma_space);
+    float num = 0.f, den = 0.f;
+    for (int dy = -r; dy <= r; ++dy)
+        for (int dx = -r; dx <= r; ++dx) {
+            const int p = ppd_reflect(y + dy, H) * W + ppd_reflect(x + dx, W);
+            const float d = g[p] - gc;
+            const float w = expf(is * (float)(dy * dy + dx * dx)) * expf(ic * d * d);   // (the 1-D normalisations cancel)
+            num += w * m[p]; den += w;
+        }
+    out[(long)blockIdx.y * H * W + i] = num / den;
+}
+
+// guided filter, step 1: a, b from the reflect-padded k x k box means of I, p, I*I, I*p (k may be even: offsets -(k-1)/2 .. k/2)
+__global__ void ppd_guided_ab_kernel(const float* I, const float* p, float* a, float* b, int H, int W, int k, float eps) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= H * W) return;
+    const int y = i / W, x = i % W, fr = (k - 1) / 2;
+    const float* Im = I + (long)blockIdx.y * H * W;
+    const float* pm = p + (long)blockIdx.y * H * W;
+    float sI = 0.f, sp = 0.f, sII = 0.f, sIp = 0.f;
+    for (int dy = -fr; dy < k - fr; ++dy)
+        for (int dx = -fr; dx < k - fr; ++dx) {
+            const int q = ppd_reflect(y + dy, H) * W + ppd_reflect(x + dx, W);
+            const float vi = Im[q], vp = pm[q];
+            sI += vi; sp += vp; sII += vi * vi; sIp += vi * vp;
+        }
+    const float inv = 1.0f / (float)(k * k);
+    const float mI = sI * inv, mp = sp * inv, var = sII * inv - mI * mI, cov = sIp * inv - mI * mp;
+    const float av = cov / (var + eps);
+    a[(long)blockIdx.y * H * W + i] = av;
+    b[(long)blockIdx.y * H * W + i] = mp - av * mI;
+}
+// step 2: q = mean(a) * I + mean(b)
+__global__ void ppd_guided_q_kernel(const float* a, const float* b, const float* I, float* q, int H, int W, int k) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= H * W) return;
+    const int y = i / W, x = i % W, fr = (k - 1) / 2;
+    const long o = (long)blockIdx.y * H * W;
+    float sa = 0.f, sb = 0.f;
+    for (int dy = -fr; dy < k - fr; ++dy)
+        for (int dx = -fr; dx < k - fr; ++dx) {
+            const int p = ppd_reflect(y + dy, H) * W + ppd_reflect(x + dx, W);
+            sa += a[o + p]; sb += b[o + p];
+        }
+    const float inv = 1.0f / (float)(k * k);
+    q[o + i] = sa * inv * I[o + i] + sb * inv;
+}
+
+// 3-sigma outliers of q against its zero-padded k x k local mean / variance are replaced by the median map (:328-335)
+__global__ void ppd_outlier_kernel(const float* q, const float* med, float* out, int H, int W, int k) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= H * W) return;
+    const int y = i / W, x = i % W, r = k / 2;
+    const long o = (long)blockIdx.y * H * W;
+    float s = 0.f, s2 = 0.f;
+    for (int dy = -r; dy <= r; ++dy)
+        for (int dx = -r; dx <= r; ++dx) {
+            const int yy = y + dy, xx = x + dx;
+            if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+            const float v = q[o + yy * W + xx];
+            s += v; s2 += v * v;
+        }
+    const float inv = 1.0f / (float)(k * k);
+    const float lm = s * inv, lv = s2 * inv - lm * lm;
+    const float ls = sqrtf(fmaxf(lv, 1e-6f));
+    const float v = q[o + i];
+    out[o + i] = fabsf(v - lm) > 3.0f * ls ? med[o + i] : v;
+}
+
+extern "C" size_t gd_post_process_depth_workspace_bytes(int P, int H, int W) { return (size_t)6 * P * H * W * sizeof(float); }
+
+extern "C" int gd_post_process_depth(const float* depth, float* out, int P, int H, int W, int kernel_size, int bilateral_d,
+                                     float sigma_color, float sigma_space, int guided_r, float guided_eps, void* workspace,
+                                     void* stream) {
+    GD_REQUIRE(P > 0 && P <= 65535 && H > 1 && W > 1, "gd_post_process_depth: bad shape P=%d H=%d W=%d", P, H, W);
+    GD_REQUIRE((kernel_size == 3 || kernel_size == 5) && bilateral_d % 2 == 1 && bilateral_d >= 1 && bilateral_d / 2 < H &&
+                   bilateral_d / 2 < W && guided_r >= 1 && guided_r <= H && guided_r <= W && sigma_color > 0.f && sigma_space > 0.f,
+               "gd_post_process_depth: kernel_size must be 3 or 5, bilateral_d odd, guided_r <= min(H, W)");
+    GD_REQUIRE(workspace != nullptr, "gd_post_process_depth: workspace required");
+    hipStream_t s = (hipStream_t)stream;
+    const long n = (long)P * H * W;
+    float* w0 = (float*)workspace; float* w1 = w0 + n; float* med = w1 + n; float* bil = med + n; float* a = bil + n; float* b = a + n;
+    const dim3 grid(gd_cdiv((long)H * W, 256), P), blk(256);
+    hipLaunchKernelGGL(ppd_pool_kernel, grid, blk, 0, s, depth, w0, H, W, kernel_size, 1.0f);       // dilate
+    hipLaunchKernelGGL(ppd_pool_kernel, grid, blk, 0, s, w0, w1, H, W, kernel_size, -1.0f);         // erode
+    hipLaunchKernelGGL(ppd_fill_kernel, grid, blk, 0, s, w1, w0, H, W, 5, 1e-5f, 0);
+    hipLaunchKernelGGL(ppd_fill_kernel, grid, blk, 0, s, w0, w1, H, W, 7, 0.f, 1);
+    hipLaunchKernelGGL(ppd_median_kernel, grid, blk, 0, s, w1, med, H, W, kernel_size);
+    hipLaunchKernelGGL(ppd_bilateral_kernel, grid, blk, 0, s, med, med, bil, H, W, bilateral_d, sigma_color, sigma_space);
+    hipLaunchKernelGGL(ppd_guided_ab_kernel, grid, blk, 0, s, bil, med, a, b, H, W, guided_r, guided_eps);   // guidance = bil, input = med
+    hipLaunchKernelGGL(ppd_guided_q_kernel, grid, blk, 0, s, a, b, bil, w0, H, W, guided_r);
+    hipLaunchKernelGGL(ppd_outlier_kernel, grid, blk, 0, s, w0, med, w1, H, W, kernel_size);
+    hipLaunchKernelGGL(ppd_bilateral_kernel, grid, blk, 0, s, w1, med, out, H, W, bilateral_d, sigma_color * 0.5f, sigma_space);
     GD_LAUNCH_OK();
     return 0;
 }

@@ -135,6 +135,22 @@ def point_cloud_to_depth(points, K, w, h, device=None):
     return depth.view(1, 1, h, w)
 
 
+def post_process_depth(depth_img, kernel_size=5, bilateral_d=3, bilateral_sigma_color=0.1, bilateral_sigma_space=1.0, guided_r=8,
+                       guided_eps=1e-2):
+    """utils/functions.py:262-345 on the device: depth [H,W] (or [1,H,W] / [1,1,H,W], or a batch [P,H,W]) -> filtered
+    depth, `.squeeze()`d like the reference's.  kornia's filters are restated (parity unpinned, see include/gd_hip.h)."""
+    d = _f(depth_img)
+    batched = d.dim() == 3 and d.shape[0] > 1
+    d = d.reshape(-1, d.shape[-2], d.shape[-1])
+    P, H, W = d.shape
+    out = torch.empty_like(d)
+    ws = torch.empty(lib().gd_post_process_depth_workspace_bytes(P, H, W), dtype=torch.uint8, device=d.device)
+    check(lib().gd_post_process_depth(ptr(d), ptr(out), P, H, W, int(kernel_size), int(bilateral_d), float(bilateral_sigma_color),
+                                      float(bilateral_sigma_space), int(guided_r), float(guided_eps), ptr(ws), stream()),
+          "gd_post_process_depth")
+    return out if batched else out[0]
+
+
 def cross_view_attention_maps(q, k, scale, temperature=1.0, prefix=5, out=None, weight=None, accumulate=False):
     """Head-averaged cross-view attention maps of one VGGT global block (vggt/layers/attention.py:51-85, `return_attn`,
     followed by `.mean(dim=1)` of src/finetune_timm_vggt.py:390-392) without the [2B, H, n, n] intermediate.
@@ -193,3 +209,66 @@ def mast3r_tgt_attn_map_from_qk(q1s, k2s, q2s, k1s, scale, temperature=3.0):
             ops.gemm_nt(flat(q1s[l])[b], flat(k2s[l])[b], out=recip[l, b], alpha=a)
             ops.gemm_nt(flat(k1s[l])[b], flat(q2s[l])[b], out=recip[l, b], alpha=a, accumulate=True)
     return _mast3r_target(recip, temperature)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Composites: one call per image pair from the frozen teacher's raw outputs to the pair's distillation targets in the layout
+# of teacher_cache.TeacherTargetCache / FinetuneGD.training_step.  The teacher networks themselves (VGGT aggregator + heads,
+# MASt3R encoder / decoder / heads, the VGGT track head) stay PyTorch-ROCm inference and are passed in as tensors / callables.
+# ------------------------------------------------------------------------------------------------------------------
+def _gather_xy(map_hw_c, kp_xy):
+    """map [H, W, C], kp [N, 2] (x, y) -> [N, C]   (`point_map[kp[..., 1].long(), kp[..., 0].long()]`, finetune_timm_vggt.py:540)"""
+    return map_hw_c[kp_xy[:, 1].long(), kp_xy[:, 0].long()]
+
+
+def _border_ok(kp, h, w):
+    return (kp[:, 0] >= 3) & (kp[:, 0] < int(w) - 3) & (kp[:, 1] >= 3) & (kp[:, 1] < int(h) - 3)
+
+
+def extract_vggt_targets(global_qk, depth_map, point_conf, extrinsic, intrinsic, track_fn, scale=64 ** -0.5, temperature=1.0,
+                         prefix=5, num_keypoints=300, min_distance=5, generator=None):
+    """`extract_vggt_features` + `sample_keypoints` (src/finetune_timm_vggt.py:357-449) after the teacher forward.
+    global_qk : list over the selected global-attention blocks of (q, k), each [1, H, N, 64] after q/k-norm and RoPE, N = the
+                two frames' tokens (the aggregator's `return_attn` blocks, vggt/models/aggregator.py:273)
+    depth_map [2, H, W(,1)], point_conf [2, H, W], extrinsic [2, 3, 4], intrinsic [2, 3, 3]: the depth / camera heads' outputs
+    track_fn  : kp_1 int [N, 2] (x, y) -> kp_2 [N, 2] — the teacher's track head (finetune_timm_vggt.py:439-440)
+    -> dict of targets (None when the NMS leaves no keypoint: the reference then skips the step, :585-588)."""
+    out = None
+    nb = len(global_qk)
+    for i, (q, k) in enumerate(global_qk):
+        out = cross_view_attention_maps(q, k, scale, temperature, prefix, out=out, weight=1.0 / (q.shape[1] * nb), accumulate=i > 0)
+    d = depth_map.squeeze(-1) if depth_map.dim() == 4 else depth_map
+    Himg, Wimg = d.shape[-2:]
+    pm = unproject_depth_map_to_point_map(d, extrinsic, intrinsic)                    # [2, H, W, 3]
+    m1, m2 = get_coview_masks(pm[0], pm[1], intrinsic[0], extrinsic[0], intrinsic[1], extrinsic[1], (Himg, Wimg))
+    rc = sample_keypoints_nms(m1, point_conf[0], num_keypoints, min_distance, generator=generator)
+    if rc is None:
+        return None
+    kp1 = rc[:, [1, 0]].int()                                                            # (row, col) -> (x, y)
+    kp2 = track_fn(kp1).int()
+    ok = _border_ok(kp1, Himg, Wimg) & _border_ok(kp2, Himg, Wimg)
+    kp1, kp2 = kp1[ok].float(), kp2[ok].float()
+    return {"cost_1": out[0], "cost_2": out[1], "kp_1": kp1, "kp_2": kp2, "pts3d_1": _gather_xy(pm[0], kp1),
+            "pts3d_2": _gather_xy(pm[1], kp2), "depth_1": _f(d[0]), "depth_2": _f(d[1]), "mask_1": m1, "mask_2": m2}
+
+
+def extract_mast3r_targets(desc_1, desc_2, conf_1, conf_2, pts3d_1, pts3d_2_from_1, pts3d_2, cost_1, cost_2, intrinsic=None,
+                           depth_1=None, depth_2=None, subsample=16, min_conf_thr=10, depth_kernel_size=3):
+    """`extract_mast3r_features` tail + `filter_and_match_keypoints` + the depth branch of `training_step`
+    (src/finetune_timm_mast3r.py:345-469, 617-633) after the teacher forward.
+    desc_k [H, W, 24], conf_k [H, W], pts3d_* [H, W, 3] (view-1 frame), cost_k [hw, hw] = `tgt_attn_map` rows
+    (mast3r_tgt_attn_map / mast3r_tgt_attn_map_from_qk at the trainer's current `teacher_temperature`);
+    depth_k given (the batch's depth maps) or rasterised from the point clouds with `intrinsic` [3, 3] and post-processed.
+    -> dict of targets (None when no keypoint survives, :604-607)."""
+    kp1, kp2 = filter_and_match_keypoints(desc_1, desc_2, conf_1, conf_2, subsample=subsample, min_conf_thr=min_conf_thr)
+    if kp1.shape[1] == 0:
+        return None
+    H, W = conf_1.shape
+    if depth_1 is None:
+        if intrinsic is None:
+            raise GdHipError("extract_mast3r_targets: give depth_1 / depth_2 or the intrinsic matrix to rasterise them")
+        depth_1 = post_process_depth(point_cloud_to_depth(pts3d_1.reshape(-1, 3), intrinsic, W, H)[0, 0], kernel_size=depth_kernel_size)
+        depth_2 = post_process_depth(point_cloud_to_depth(pts3d_2.reshape(-1, 3), intrinsic, W, H)[0, 0], kernel_size=depth_kernel_size)
+    k1, k2 = kp1[0], kp2[0]
+    return {"cost_1": _f(cost_1), "cost_2": _f(cost_2), "kp_1": k1, "kp_2": k2, "pts3d_1": _gather_xy(_f(pts3d_1), k1),
+            "pts3d_2": _gather_xy(_f(pts3d_2_from_1), k2), "depth_1": _f(depth_1), "depth_2": _f(depth_2)}

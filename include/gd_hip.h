@@ -211,6 +211,14 @@ int gd_nn_argmax(const float* queries, const float* database, const unsigned cha
 int gd_point_cloud_to_depth(const float* points, const float* K, float* depth, float* cnt_ws, int P, int Np, int w,
                             int h, void* stream);
 
+/* post_process_depth (utils/functions.py:262-345) on P rasterised depth maps [P,H,W]: max-pool closing, two hole-filling
+ * passes, median (kernel_size in {3, 5}), bilateral, guided filter (guidance = the bilateral map, input = the median map, as the
+ * call site passes them), 3-sigma outlier replacement, joint bilateral.  The four kornia filters are restated from kornia's
+ * published definitions (kornia is not vendored in the reference: parity unpinned).  workspace: 6 P H W floats. */
+size_t gd_post_process_depth_workspace_bytes(int P, int H, int W);
+int gd_post_process_depth(const float* depth, float* out, int P, int H, int W, int kernel_size, int bilateral_d,
+                          float sigma_color, float sigma_space, int guided_r, float guided_eps, void* workspace, void* stream);
+
 /* In-place 2-D RoPE of the frozen MASt3R teacher: replaces curope.rope_2d(tokens, positions, base, fwd)
  * (dust3r/croco/models/curope/curope.cpp:49-69, kernels.cu:17-82).  tokens [B,N,H,D] (token stride ld_tok elements),
  * positions int64 [B,N,2] (y,x); fwd = +F0 forward / -F0 backward. */

@@ -556,6 +556,83 @@ def point_cloud_to_depth(points, K, w, h):
     return out.view(1, 1, h, w)
 
 
+def _reflect_pad(x, front, rear):
+    return F.pad(x, [front, rear, front, rear], mode="reflect")
+
+
+def _box_mean_reflect(x, k):
+    """kornia.filters.box_blur(x, (k, k), border_type='reflect'): mean over a k x k window; an even k pads (k-1)//2 in
+    front and k - 1 - (k-1)//2 behind (window offsets -3..+4 for k = 8)."""
+    fr = (k - 1) // 2
+    return F.avg_pool2d(_reflect_pad(x, fr, k - 1 - fr), k, stride=1)
+
+
+def _gauss1d(k, sigma):
+    x = torch.arange(k, dtype=torch.float64) - k // 2
+    g = torch.exp(-x * x / (2.0 * sigma * sigma))
+    return g / g.sum()
+
+
+def _joint_bilateral(x, guide, k, sigma_color, sigma_space):
+    """kornia.filters.joint_bilateral_blur(x, guide, (k, k), sigma_color, (s, s)), border 'reflect', colour distance 'l1'
+    (single channel: |difference|): weights gaussian_space * exp(-0.5 (guide_nb - guide_c)^2 / sigma_color^2), normalised."""
+    pad = k // 2
+    xp, gp = _reflect_pad(x, pad, pad), _reflect_pad(guide, pad, pad)
+    H, W = x.shape[-2:]
+    g1 = _gauss1d(k, sigma_space).to(x.dtype)
+    num = torch.zeros_like(x)
+    den = torch.zeros_like(x)
+    for dy in range(k):
+        for dx in range(k):
+            nb, gn = xp[..., dy:dy + H, dx:dx + W], gp[..., dy:dy + H, dx:dx + W]
+            wgt = g1[dy] * g1[dx] * torch.exp(-0.5 / (sigma_color * sigma_color) * (gn - guide) ** 2)
+            num = num + wgt * nb
+            den = den + wgt
+    return num / den
+
+
+def post_process_depth(depth_img, kernel_size=5, bilateral_d=3, bilateral_sigma_color=0.1, bilateral_sigma_space=1.0,
+                       guided_r=8, guided_eps=1e-2):
+    """utils/functions.py:262-345.  SOURCE ABSENT — PARITY UNPINNED: the function calls kornia (median_blur, bilateral_blur,
+    guided_blur, joint_bilateral_blur), which is not installed here and not vendored in the reference (requirements.txt pins
+    kornia); those four filters are restated from kornia's published definitions (zero-padded lower median; bilateral /
+    joint bilateral with reflect border, gaussian space kernel, l1 colour distance; He et al.'s guided filter on reflect-padded
+    box means — called as guided_blur(guidance=depth_bilateral, input=depth_median), the argument order of the call site
+    :321), the torch parts (max-pool closing, two hole-filling passes, 3-sigma outlier replacement) follow the source line
+    by line.  depth_img [H, W] -> [H, W]."""
+    x = depth_img.reshape(1, 1, *depth_img.shape[-2:])
+    k = kernel_size
+    pad = k // 2
+    dil = F.max_pool2d(x, k, stride=1, padding=pad)
+    ero = -F.max_pool2d(-dil, k, stride=1, padding=pad)
+    for ks in (5, 7):                                     # :283-310 (the `if empty_mask.sum() > 0` guard changes nothing:
+        valid = (ero >= 1e-5).to(x.dtype) if ks == 5 else (ero > 0).to(x.dtype)    # with no holes fill_mask is zero)
+        ones = torch.ones(1, 1, ks, ks, dtype=x.dtype)
+        cnt = F.conv2d(valid, ones, padding=ks // 2)
+        val = F.conv2d(ero * valid, ones, padding=ks // 2)
+        fill = ((cnt > 0).to(x.dtype) - valid).clamp(0, 1)
+        ero = ero * valid + val / (cnt + 1e-8) * fill
+    # median_blur: zero padding, the (k*k+1)/2-th smallest of the window
+    win = F.unfold(ero, k, padding=pad).reshape(1, k * k, *x.shape[-2:])
+    med = win.sort(dim=1)[0][:, (k * k - 1) // 2][:, None]
+    bil = _joint_bilateral(med, med, bilateral_d, bilateral_sigma_color, bilateral_sigma_space)
+    # guided filter: guidance I = bil, input p = med
+    I, p_ = bil, med
+    mI, mp = _box_mean_reflect(I, guided_r), _box_mean_reflect(p_, guided_r)
+    var = _box_mean_reflect(I * I, guided_r) - mI * mI
+    cov = _box_mean_reflect(I * p_, guided_r) - mI * mp
+    a = cov / (var + guided_eps)
+    b = mp - a * mI
+    q = _box_mean_reflect(a, guided_r) * I + _box_mean_reflect(b, guided_r)
+    kern = torch.ones(1, 1, k, k, dtype=x.dtype) / (k * k)
+    lm = F.conv2d(q, kern, padding=pad)
+    lv = F.conv2d(q * q, kern, padding=pad) - lm * lm
+    out_mask = ((q - lm).abs() > 3.0 * torch.sqrt(lv.clamp(min=1e-6))).to(x.dtype)
+    filt = q * (1 - out_mask) + med * out_mask
+    fin = _joint_bilateral(filt, med, bilateral_d, bilateral_sigma_color / 2, bilateral_sigma_space)
+    return fin[0, 0]
+
+
 def filter_kp_by_conf(kp, conf_mask):
     """utils/functions.py:199-207."""
     k = kp[0]

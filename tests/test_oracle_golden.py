@@ -188,3 +188,12 @@ def test_g17_mast3r_tgt_attn_map():
     g = load_golden("g17_mast3r_tgt_attn_map")
     got = O.mast3r_tgt_attn_map(list(g["tgt"]), list(g["src"]), float(g["temperature"]))
     assert float((got - g["out"]).abs().max()) < 1e-6
+
+
+def test_g16b_filter_and_match_oracle():
+    """The oracle's MASt3R keypoint pipeline equals the reference's filter_and_match_keypoints output (G16b)."""
+    g = load_golden("g16b_filter_and_match")
+    d1, d2, c1, c2 = (g[k].float() for k in ("desc1", "desc2", "conf1", "conf2"))
+    o1, o2 = O.reciprocal_nns(d1, d2, subsample=16)
+    k1, k2 = O.mast3r_keypoint_filter(o1, o2, c1, c2)
+    assert torch.equal(k1[0], g["kp1"]) and torch.equal(k2[0], g["kp2"])
