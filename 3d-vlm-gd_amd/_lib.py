@@ -72,6 +72,10 @@ SIGNATURES = {
                                    c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "gd_clip_adamw_ranges": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_float, c_float, c_float,
                                      c_float, c_float, c_float, c_float, c_void_p, c_void_p, ctypes.POINTER(c_long), c_int, c_void_p]),
+    "gd_comm_unique_id": (c_int, [c_void_p]),
+    "gd_comm_init": (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, c_void_p]),
+    "gd_comm_destroy": (c_int, [c_void_p]),
+    "gd_flat_allreduce": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_void_p]),
     "gd_unproject_depth": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "gd_coview_masks": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_void_p]),
     "gd_nms_keypoints": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

@@ -1,0 +1,92 @@
+// flat_allreduce (SURVEY 8b op list, 8e): the ONE exchange of the data-parallel step — a sum over ranks of the flat fp32
+// gradient buffer (25.6 MB for ViT-B) — directly on RCCL over xGMI, behind the C ABI.  Replaces Lightning DDP's bucketed
+// all-reduce (src/main.py:147-151).  RCCL is bound at run time (dlopen / dlsym of librccl.so: a process that already
+// carries torch's RCCL re-uses that one copy; nothing here links against it), so the library loads on boxes without it and
+// the entry points fail loudly there.
+//   algo 0: one ncclAllReduce (RCCL picks ring / tree / direct for the message size and topology);
+//   algo 1: reduce-scatter + all-gather in place on the rank's 1/nranks slice — on the fully connected 8-GPU xGMI mesh each
+//           of the two phases moves (n / nranks) floats over every one of the 7 links at once (~7x less time on the
+//           wire than a ring for this message size); n must be a multiple of nranks.
+#include "gd_common.h"
+#include <dlfcn.h>
+#include <string.h>
+
+typedef struct { char internal[128]; } gd_nccl_uid;       // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128)
+typedef void* gd_nccl_comm;
+enum { GD_NCCL_FLOAT = 7, GD_NCCL_SUM = 0 };              // ncclFloat32, ncclSum (rccl.h)
+
+static struct {
+    void* h;
+    int (*GetUniqueId)(gd_nccl_uid*);
+    int (*CommInitRank)(gd_nccl_comm*, int, gd_nccl_uid, int);
+    int (*CommDestroy)(gd_nccl_comm);
+    int (*AllReduce)(const void*, void*, size_t, int, int, gd_nccl_comm, hipStream_t);
+    int (*ReduceScatter)(const void*, void*, size_t, int, int, gd_nccl_comm, hipStream_t);
+    int (*AllGather)(const void*, void*, size_t, int, gd_nccl_comm, hipStream_t);
+    const char* (*GetErrorString)(int);
+} R;
+
+static int rccl_bind() {
+    if (R.h) return 0;
+    void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) { gd_set_error("flat_allreduce: cannot load librccl.so (%s)", dlerror()); return -1; }
+#define GD_SYM(field, name)                                                                         \
+    *(void**)(&R.field) = dlsym(h, name);                                                           \
+    if (!R.field) { gd_set_error("flat_allreduce: librccl.so has no symbol %s", name); return -1; }
+    GD_SYM(GetUniqueId, "ncclGetUniqueId") GD_SYM(CommInitRank, "ncclCommInitRank") GD_SYM(CommDestroy, "ncclCommDestroy")
+    GD_SYM(AllReduce, "ncclAllReduce") GD_SYM(ReduceScatter, "ncclReduceScatter") GD_SYM(AllGather, "ncclAllGather")
+    GD_SYM(GetErrorString, "ncclGetErrorString")
+#undef GD_SYM
+    R.h = h;
+    return 0;
+}
+#define GD_NCCL(call, what)                                                                         \
+    do {                                                                                            \
+        const int rc_ = (call);                                                                     \
+        if (rc_ != 0) { gd_set_error("%s: RCCL error %d (%s)", what, rc_, R.GetErrorString(rc_)); return -3; } \
+    } while (0)
+
+extern "C" int gd_comm_unique_id(void* out128) {
+    GD_REQUIRE(out128 != nullptr, "gd_comm_unique_id: null output");
+    if (rccl_bind()) return -1;
+    gd_nccl_uid id;
+    GD_NCCL(R.GetUniqueId(&id), "gd_comm_unique_id");
+    memcpy(out128, id.internal, 128);
+    return 0;
+}
+
+extern "C" int gd_comm_init(void** comm, int nranks, int rank, const void* id128) {
+    GD_REQUIRE(comm && id128 && nranks >= 1 && rank >= 0 && rank < nranks, "gd_comm_init: bad arguments (nranks=%d rank=%d)", nranks, rank);
+    if (rccl_bind()) return -1;
+    gd_nccl_uid id;
+    memcpy(id.internal, id128, 128);
+    gd_nccl_comm c = nullptr;
+    GD_NCCL(R.CommInitRank(&c, nranks, id, rank), "gd_comm_init");
+    *comm = c;
+    return 0;
+}
+
+extern "C" int gd_comm_destroy(void* comm) {
+    if (!comm) return 0;
+    if (rccl_bind()) return -1;
+    GD_NCCL(R.CommDestroy((gd_nccl_comm)comm), "gd_comm_destroy");
+    return 0;
+}
+
+extern "C" int gd_flat_allreduce(void* comm, float* buf, long n, int nranks, int rank, int algo, void* stream) {
+    GD_REQUIRE(comm && buf && n > 0 && nranks >= 1 && rank >= 0 && rank < nranks, "gd_flat_allreduce: bad arguments");
+    GD_REQUIRE(algo == 0 || algo == 1, "gd_flat_allreduce: algo must be 0 (all-reduce) or 1 (reduce-scatter + all-gather)");
+    if (rccl_bind()) return -1;
+    hipStream_t s = (hipStream_t)stream;
+    if (algo == 0) {
+        GD_NCCL(R.AllReduce(buf, buf, (size_t)n, GD_NCCL_FLOAT, GD_NCCL_SUM, (gd_nccl_comm)comm, s), "gd_flat_allreduce");
+        return 0;
+    }
+    GD_REQUIRE(n % nranks == 0, "gd_flat_allreduce: algo 1 needs n (%ld) to be a multiple of nranks (%d)", n, nranks);
+    const size_t per = (size_t)(n / nranks);
+    float* mine = buf + (size_t)rank * per;        // in place: the reduced slice lands where it lives in the full buffer
+    GD_NCCL(R.ReduceScatter(buf, mine, per, GD_NCCL_FLOAT, GD_NCCL_SUM, (gd_nccl_comm)comm, s), "gd_flat_allreduce (reduce-scatter)");
+    GD_NCCL(R.AllGather(mine, buf, per, GD_NCCL_FLOAT, (gd_nccl_comm)comm, s), "gd_flat_allreduce (all-gather)");
+    return 0;
+}

@@ -97,6 +97,21 @@ __device__ __forceinline__ void gelu_parts(float y, float& Phi, float& e) {
 __device__ __forceinline__ float gelu_fast(float y) { float P, e; gelu_parts(y, P, e); return y * P; }
 __device__ __forceinline__ float dgelu_fast(float y) { float P, e; gelu_parts(y, P, e); return P + y * e * 0.39894228040143268f; }
 
+// GELU for bf16 OUTPUTS: Phi(y) ~ sigmoid(y (c1 + c3 y^2 + c5 y^4)) — the 3-coefficient minimax fit of the erf form
+// (max |y Phi| error 2.5e-5, max derivative error 1.1e-4 on the whole line; a bf16 result carries 2^-9 = 2e-3 relative), with
+// the exponent's log2(e) folded into the coefficients: one v_exp, one v_rcp and 5 FMAs for Phi, and the derivative of THIS
+// function costs no second exponential (the erf form needs exp(-y^2/2) on top).  c5 < 0, so the polynomial is evaluated on
+// y clamped to [-8, 8] (u(8) = 27.6: sigmoid = 1 to fp32); the product uses the unclamped y.
+__device__ __forceinline__ void gelu_sig_parts(float y, float& Phi, float& dPhi) {
+    const float yc = __builtin_amdgcn_fmed3f(y, -8.0f, 8.0f), y2 = yc * yc;
+    const float w = fmaf(y2, fmaf(y2, 0.0010142630f, -0.10677572f), -2.3011213f);      // -(c1 + c3 y^2 + c5 y^4) * log2(e)
+    const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(yc * w));
+    const float up = fmaf(y2, fmaf(y2, -0.0035151680f, 0.22203388f), 1.5950158f);       // du/dy
+    Phi = s;
+    dPhi = (s - s * s) * up;                                                             // dPhi/dy
+}
+__device__ __forceinline__ float gelu_sig(float y) { float P, d; gelu_sig_parts(y, P, d); return y * P; }
+
 // ---- 16x16 MFMA tile abstraction ------------------------------------------------
 // One "K-chunk" is 64 bytes of a row: 32 bf16 or 16 f32.  A fragment is the 16 bytes
 // lane l owns: row (or column) l&15, bytes [16*(l>>4), 16*(l>>4)+16) of the chunk.

@@ -344,15 +344,16 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
                 float dv[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    float Phi, ex;
-                    gelu_parts(v[j], Phi, ex);
-                    dv[j] = Phi + v[j] * ex * 0.39894228040143268f;
+                    float Phi, dPhi;
+                    if (CF32) { float ex; gelu_parts(v[j], Phi, ex); dPhi = ex * 0.39894228040143268f; }
+                    else gelu_sig_parts(v[j], Phi, dPhi);       // bf16 outputs: the sigmoid-form fit (gd_common.h)
+                    dv[j] = fmaf(v[j], dPhi, Phi);
                     v[j] *= Phi;
                 }
                 bst4_aux<GD_PERSIST_STORE_AUX>(prs, cok ? (rl * ldp_i + col0) * csz : OOB, cdt, dv);
             } else if (ACT == 1) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = CF32 ? gelu_f(v[j]) : gelu_fast(v[j]);
+                for (int j = 0; j < 4; ++j) v[j] = CF32 ? gelu_f(v[j]) : gelu_sig(v[j]);
             } else if (ACT == 2) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);

@@ -102,6 +102,67 @@ class OverlappedGradReducer:
         return 1.0 / self.world
 
 
+class RcclComm:
+    """The C ABI's own RCCL communicator (gd_comm_init / gd_flat_allreduce in include/gd_hip.h): the flat-buffer exchange
+    without torch.distributed in the data path.  The 128-byte unique id travels over the already-initialised
+    torch.distributed group (any backend) once, at construction."""
+
+    def __init__(self, rank, world):
+        import ctypes
+        from ._lib import check, lib
+        self.rank, self.world = rank, world
+        buf = (ctypes.c_char * 128)()
+        if rank == 0:
+            check(lib().gd_comm_unique_id(buf), "gd_comm_unique_id")
+        ids = [bytes(buf)]
+        if world > 1:
+            dist.broadcast_object_list(ids, src=0)
+        self._id = ctypes.create_string_buffer(ids[0], 128)
+        self._h = ctypes.c_void_p()
+        check(lib().gd_comm_init(ctypes.byref(self._h), world, rank, self._id), "gd_comm_init")
+
+    def all_reduce_(self, flat, algo=None):
+        """In place sum over ranks of a contiguous fp32 CUDA tensor, on the current stream.  algo None: reduce-scatter +
+        all-gather when the length divides by the world size (the direct form for the xGMI mesh), else one all-reduce."""
+        from ._lib import check, lib, stream
+        assert flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous()
+        if algo is None:
+            algo = 1 if flat.numel() % self.world == 0 else 0
+        check(lib().gd_flat_allreduce(self._h, flat.data_ptr(), flat.numel(), self.world, self.rank, int(algo),
+                                      stream()), "gd_flat_allreduce")
+        return flat
+
+    def close(self):
+        from ._lib import lib
+        if self._h:
+            lib().gd_comm_destroy(self._h)
+            self._h = None
+
+
+class DirectGradReducer:
+    """Same contract as OverlappedGradReducer (wait_early / start / finish), one gd_flat_allreduce of the whole flat
+    gradient buffer after the backward, on the compute stream: no bucketing, no hooks, no torch.distributed in the step."""
+
+    def __init__(self, flat_grad, comm):
+        self.flat, self.comm, self.world = flat_grad, comm, comm.world
+
+    def attach(self):
+        pass
+
+    def detach(self):
+        pass
+
+    def wait_early(self):
+        pass
+
+    def start(self):
+        if self.world > 1:
+            self.comm.all_reduce_(self.flat)
+
+    def finish(self):
+        return 1.0 / self.world
+
+
 def shard_pairs(n_pairs, rank, world):
     """Contiguous split of a global batch of pairs."""
     per = n_pairs // world

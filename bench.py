@@ -58,6 +58,9 @@ def parse():
                          "reference's geometry (80x80-token forwards for the keypoint features + the teacher-grid forward)")
     ap.add_argument("--gemm-shapes", action="store_true", help="per-shape gemm_nt breakdown on stderr")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--exchange", default="torch", choices=["torch", "direct"],
+                    help="gradient exchange: torch = torch.distributed all-reduce in two overlapped chunks (default); direct = "
+                         "one gd_flat_allreduce (C ABI, RCCL reduce-scatter + all-gather) after the backward")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); 'gloo' lets two "
                     "ranks share one GPU for a functional check of the N>1 path")
     return ap.parse_args()
@@ -102,7 +105,8 @@ def barrier(world):
 class Job:
     """One engine + its resident synthetic batches + the gradient exchange: `step(i)` is the timed unit."""
 
-    def __init__(self, backbone, variant, dtype, geometry, P, img, N, dev, rank, world, vit_kwargs=None, weights=None):
+    def __init__(self, backbone, variant, dtype, geometry, P, img, N, dev, rank, world, vit_kwargs=None, weights=None,
+                 exchange="torch"):
         from gd_amd import dp
         from gd_amd.finetune import FinetuneGD
         from gd_testutil import synthetic_batch
@@ -114,7 +118,10 @@ class Job:
         flat = self.eng.configure_optimizers()
         # gradient exchange in two chunks: refine_conv + depth head from grad hooks (under the ViT backward), the rest after it
         early = list(self.eng.refine_conv.parameters()) + list(self.eng.depth_diff_head.parameters())
-        self.reducer = dp.OverlappedGradReducer(self.eng.trainable_parameters(), flat["views"], flat["g"], early, world)
+        if exchange == "direct" and world > 1:
+            self.reducer = dp.DirectGradReducer(flat["g"], dp.RcclComm(rank, world))
+        else:
+            self.reducer = dp.OverlappedGradReducer(self.eng.trainable_parameters(), flat["views"], flat["g"], early, world)
         self.reducer.attach()
         self.flat = flat
         # a few distinct synthetic batches per rank (seed 1234 + 1000*rank + i), resident on the device
@@ -183,7 +190,7 @@ def main():
     dev = torch.device("cuda", local)
     P, img, N = args.pairs_per_gpu, args.img, args.keypoints
 
-    job = Job(backbone, variant, args.dtype, args.geometry, P, img, N, dev, rank, world, weights=weights)
+    job = Job(backbone, variant, args.dtype, args.geometry, P, img, N, dev, rank, world, weights=weights, exchange=args.exchange)
     eng, hw = job.eng, job.hw
     prof = None if args.no_kernel_events else ops.GemmProfiler()
     dt, loss = job.timed(args.steps, args.warmup, dev, prof)
@@ -202,7 +209,7 @@ def main():
                                       f"blocks 4-11, {img}^2 pairs, {'shared-518' if args.geometry == 'shared' else 'reference (80x80-token)'} geometry, {variant} losses "
                                       f"(AP+depth+intra+cost-KL), {P} pairs/GPU, {N} keypoints/pair, hw={hw}",
                           "pairs_per_gpu": P, "global_pairs": P * world, "parallelism": f"dp{world}",
-                          "world_size_seen": world, "backend": args.backend or "nccl (RCCL)"},
+                          "world_size_seen": world, "backend": args.backend or "nccl (RCCL)", "exchange": args.exchange},
                "loss": round(float(loss.detach()), 6),
                "vit_algorithmic_tflops": round(pairs_per_s / world * flop_pair / 1e12, 2),
                "vit_frac_of_mfma_peak": round(pairs_per_s / world * flop_pair / 1e12 / PEAK_TFLOPS[args.dtype], 4)}
@@ -280,8 +287,9 @@ def comm_report(job, args, dev, dt):
     import torch.distributed as dist
     from gd_amd import dp
     flat_g = job.flat["g"]
-    n_late = sum(b - a for a, b in job.reducer.late)
-    n_early = flat_g.numel() - n_late
+    late = getattr(job.reducer, "late", [(0, flat_g.numel())])
+    n_late = sum(b - a for a, b in late)
+    n_early = max(flat_g.numel() - n_late, 1)
 
     def ar_ms(n):
         buf = torch.zeros(n, dtype=torch.float32, device=dev)

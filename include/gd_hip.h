@@ -191,6 +191,17 @@ int gd_clip_adamw_ranges(float* params, const float* grads, float* exp_avg, floa
                          float* grad_norm_out, void* workspace, const long* ranges, int n_ranges, void* stream);
 int gd_cast(const void* in, void* out, long n, float scale, int in_dtype, int out_dtype, void* stream);
 
+/* flat_allreduce: the data-parallel step's one exchange — the sum over ranks of the flat fp32 gradient buffer — on RCCL over
+ * xGMI (replaces Lightning DDP's bucketed all-reduce, src/main.py:147-151).  RCCL is bound at run time (dlopen): the calls
+ * fail with a message where librccl.so is absent.  gd_comm_unique_id: rank 0 draws the 128-byte id, the caller hands it to
+ * every rank (any transport); gd_comm_init: collective over the nranks processes (one per GPU, device already selected);
+ * gd_flat_allreduce: in place on buf[n], algo 0 = one all-reduce, algo 1 = reduce-scatter + all-gather on the rank's
+ * n / nranks slice (n % nranks == 0) — the direct form for the fully connected xGMI mesh. */
+int gd_comm_unique_id(void* out128);
+int gd_comm_init(void** comm, int nranks, int rank, const void* id128);
+int gd_comm_destroy(void* comm);
+int gd_flat_allreduce(void* comm, float* buf, long n, int nranks, int rank, int algo, void* stream);
+
 /* Teacher -> target glue on the device.
  * gd_unproject_depth: vggt/utils/geometry.py:12-110 unproject_depth_map_to_point_map (depth [S,H,W], extrinsic [S,3,4],
  *   intrinsic [S,3,3] -> world points [S,H,W,3]).

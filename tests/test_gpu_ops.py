@@ -342,3 +342,23 @@ def test_tap_fn_and_split_pairs_gradients(dtype, tol):
     n2, r2, m2 = _TapFn.apply(x2, w, b, 1e-6)
     (n2.float() * c1.float()).sum().backward()
     assert rel_err(x2.grad, c1.double()) < tol
+
+
+def test_flat_allreduce_cabi_single_rank():
+    """gd_comm_* / gd_flat_allreduce (RCCL bound at run time): a one-rank communicator leaves the buffer unchanged under
+    both algorithms; argument errors are reported through gd_last_error (multi-rank runs need one GPU per rank)."""
+    from gd_amd import dp
+    from gd_amd._lib import GdHipError
+    comm = dp.RcclComm(0, 1)
+    x = torch.arange(1000, dtype=torch.float32, device="cuda")
+    y = x.clone()
+    comm.all_reduce_(y, algo=0)
+    comm.all_reduce_(y, algo=1)
+    torch.cuda.synchronize()
+    assert torch.equal(x, y)
+    with pytest.raises(GdHipError):
+        comm.all_reduce_(y, algo=2)
+    red = dp.DirectGradReducer(y, comm)
+    red.start()
+    assert red.finish() == 1.0
+    comm.close()
