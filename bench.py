@@ -272,9 +272,15 @@ def cost_volume_roofline(job, args, dev, variant):
     tfb = ops.time_on_stream(cv_fb, 2, 5)
     fwd_bytes = P * (2 * hw * D * es + 2 * hw * hw * 4 + 2 * hw)
     bwd_bytes = fwd_bytes + P * 2 * hw * D * es
+    traffic, src = None, None
+    pmc = os.path.join(ROOT, "profiles", "r02_pmc_cost_volume_traffic.json")
+    if os.path.exists(pmc) and (P, hw, D, args.dtype) == (32, 1369, 768, "bf16"):     # the configuration the PMC passes were run on
+        with open(pmc) as fh:
+            traffic = json.load(fh)["fwd_hbm_bytes_per_launch"]
+        src = "profiles/r02_pmc_cost_volume_traffic.json (FETCH_SIZE / WRITE_SIZE, separate --pmc passes, width-corrected; NOT measured in this run)"
     return {"kernel": "cost_volume_kl fwd (cv_norm + cv_fwd_persist + cv_finalize; teacher-row statistics cached per pair)", "bound": "hbm",
             "achieved": round(fwd_bytes / tf / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-            "frac": round(fwd_bytes / tf / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
+            "frac": round(fwd_bytes / tf / 1e9 / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_replayed_from": src,
             "algorithmic_bytes_per_launch": fwd_bytes,
             "us_per_pair_fwd": round(tf / P * 1e6, 2),
             "fwd_bwd_GBps": round((fwd_bytes + bwd_bytes) / tfb / 1e9, 1),
