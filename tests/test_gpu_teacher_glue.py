@@ -200,3 +200,95 @@ def test_target_composites_and_cache_feed_the_step():
     cache.get("m0", lambda: (calls.append(1), t)[1], temperature=1.0)
     cache.get("m0", lambda: (calls.append(1), t)[1], temperature=0.9)
     assert len(calls) == 2
+
+
+def test_vggt_teacher_runner_with_a_fake_teacher():
+    """teacher_runner.VGGTTeacherRunner end to end on the GPU around a FAKE teacher laid out like vggt.models.vggt.VGGT
+    (aggregator.global_blocks[i].attn with qkv / q_norm / k_norm / scale, attn_indices, temperature; camera / depth / point / track
+    heads): q and k are captured by hooks, the blocks' `return_attn` maps are never formed, and the targets equal the composite
+    called on the tensors directly.  (The hooks against the REFERENCE's aggregator: tests/test_teacher_runner_ref.py, CPU.)"""
+    import torch.nn as nn
+    from gd_amd import teacher_glue as tg
+    from gd_amd.teacher_runner import VGGTTeacherRunner
+    torch.manual_seed(3)
+    Himg = Wimg = 56
+    n, prefix, D, Hh = 16, 5, 128, 2
+    g15 = load_golden("g15_teacher_glue")
+    E = torch.stack([g15["E1"], g15["E2"]]).cuda()
+    K = torch.stack([g15["K1"], g15["K2"]]).cuda()
+    K[:, :2, 2] = 28.0
+
+    class Attn(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.num_heads, self.head_dim, self.scale = Hh, D // Hh, (D // Hh) ** -0.5
+            self.qkv, self.proj = nn.Linear(D, 3 * D), nn.Linear(D, D)
+            self.q_norm, self.k_norm, self.rope = nn.LayerNorm(D // Hh), nn.LayerNorm(D // Hh), None
+            self.formed_maps = 0
+
+        def forward(self, x, pos=None, return_attn=False, temperature=1.0):
+            B, N, C = x.shape
+            q, k, v = self.qkv(x).reshape(B, N, 3, Hh, C // Hh).permute(2, 0, 3, 1, 4).unbind(0)
+            q, k = self.q_norm(q), self.k_norm(k)
+            out = self.proj(torch.nn.functional.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, N, C))
+            if return_attn:
+                self.formed_maps += 1
+                return out, torch.zeros(2 * B, Hh, n, n, device=x.device)
+            return out
+
+    class Blk(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.attn = Attn()
+
+        def forward(self, x, pos=None, return_attn=False, temperature=1.0):
+            if return_attn:
+                y, a = self.attn(x, pos=pos, return_attn=True, temperature=temperature)
+                return x + y, a
+            return x + self.attn(x, pos=pos)
+
+    class Agg(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.global_blocks = nn.ModuleList([Blk() for _ in range(3)])
+            self.attn_indices, self.aa_block_size, self.temperature = [0, 2], 1, 0.9
+            self.embed = nn.Linear(3, D)
+
+        def forward(self, images):
+            B, S = images.shape[:2]
+            tok = self.embed(torch.nn.functional.adaptive_avg_pool2d(images.flatten(0, 1), (4, 4)).flatten(2).transpose(1, 2))   # [B*S, 16, D]
+            tok = torch.cat([tok.new_zeros(B * S, prefix, D), tok], 1).reshape(B, S * (prefix + n), D)
+            maps = []
+            for i, blk in enumerate(self.global_blocks):
+                tok, a = blk(tok, pos=None, return_attn=True, temperature=self.temperature)
+                if i in self.attn_indices:
+                    maps.append(a)
+            return [tok], prefix, torch.mean(torch.stack(maps), 0)
+
+    depth = (1.0 + 2 * torch.rand(1, 2, Himg, Wimg, 1)).cuda()
+    conf = (1 + torch.rand(1, 2, Himg, Wimg)).cuda()
+
+    class Fake(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.aggregator = Agg()
+            self.camera_head = lambda toks: [torch.zeros(1, 2, 9, device="cuda")]
+            self.depth_head = lambda toks, img, ps: (depth, conf)
+            self.point_head = lambda toks, img, ps: (None, conf)
+            self.track_head = lambda toks, img, ps, query_points: ([torch.stack([query_points[0], query_points[0] + 1])[None]], None, None)
+    teacher = Fake().cuda().eval()
+    runner = VGGTTeacherRunner(teacher, dtype=torch.float32, prefix=prefix, pose_decoder=lambda pe, hw: (E[None], K[None]))
+    img = torch.rand(1, 2, 3, Himg, Wimg, device="cuda")
+    t = runner.targets(img, num_keypoints=4000, min_distance=3)
+    assert sum(b.attn.formed_maps for b in teacher.aggregator.global_blocks) == 1       # only the unselected block built its maps
+    # the same targets from the tensors directly
+    from gd_amd.teacher_runner import QKCapture
+    sel = [teacher.aggregator.global_blocks[i].attn for i in (0, 2)]
+    with torch.no_grad(), QKCapture(sel) as cap:
+        teacher.aggregator(img)
+    want = tg.extract_vggt_targets(cap.pairs(), depth[0], conf[0], E, K, track_fn=lambda kp: kp + 1, scale=sel[0].scale, temperature=0.9,
+                                   prefix=prefix, num_keypoints=4000, min_distance=3)
+    for k in ("cost_1", "cost_2", "kp_1", "kp_2", "pts3d_1", "depth_2", "mask_1"):
+        assert torch.equal(t[k], want[k]), k
+    ref = sum(O.cross_view_attention_maps(q.cpu().double(), k.cpu().double(), sel[0].scale, 0.9, prefix) for q, k in cap.pairs()) / 2
+    assert rel_err(t["cost_1"], ref[0]) < 1e-4
