@@ -133,6 +133,16 @@ class FinetuneGD(nn.Module):
             if id(p) in unused:
                 skip.append((off, off + al(k)))
             off += al(k)
+        # where the LoRA-A / LoRA-B / adapter tensors start: they sit back to back (all sizes are multiples of 4), in the order the
+        # engine stacks them, so the per-step weight packs and the blocks' weight gradients can use views (vit.prepare_trainables)
+        spans = None
+        nA, nB, nAd = len(self.w_As), len(self.w_Bs), 2 * len(self.adapters)
+        if nA and nAd == nA and all(p.numel() % 4 == 0 for p in ps):
+            offs, o = [], 0
+            for p in ps:
+                offs.append(o)
+                o += al(p.numel())
+            spans = {"A": offs[0], "B": offs[nA], "ad": offs[len(ps) - nAd], "L": nA // 2}
         live, pos = [], 0
         for a, b in skip:                     # complement of the (adjacent) skipped spans
             if a > pos:
@@ -141,7 +151,7 @@ class FinetuneGD(nn.Module):
         if pos < n:
             live.append((pos, n))
         self._flat = {"p": flat_p, "g": flat_g, "views": views, "m": torch.zeros_like(flat_p), "v": torch.zeros_like(flat_p),
-                      "step": 0, "lr": lr, "wd": weight_decay, "max_norm": max_norm, "live": live}
+                      "step": 0, "lr": lr, "wd": weight_decay, "max_norm": max_norm, "live": live, "spans": spans}
         return self._flat
 
     def zero_grad_flat(self):
@@ -156,10 +166,11 @@ class FinetuneGD(nn.Module):
         views = self._flat["views"]
         for p in ps:
             p.grad = None
+        self._flat["g"].zero_()          # BEFORE the backward: blocks prepared with the flat record accumulate straight into it
         loss.backward()
+        self.model.finish_trainable_grads()
         if pre_gather is not None:       # e.g. OverlappedGradReducer.wait_early: hook-launched all-reduces of some p.grad
             pre_gather()
-        self._flat["g"].zero_()
         dst = [v for p, v in zip(ps, views) if p.grad is not None]
         src = [p.grad for p in ps if p.grad is not None]
         if dst:
@@ -192,7 +203,7 @@ class FinetuneGD(nn.Module):
         """One optimisation step of the minimal loop that stands in for Lightning's (src/main.py:153-161): forward +
         losses, backward, gradient exchange (dp.OverlappedGradReducer; None = single rank), clip + AdamW.
         -> (loss, terms, pre-clip gradient norm)."""
-        loss, terms = self.training_step(batch)
+        loss, terms = self.training_step(batch, direct_grads=True)
         if reducer is None:
             self.backward(loss)
             scale = 1.0
@@ -341,13 +352,16 @@ class FinetuneGD(nn.Module):
         return ops.smooth_ap(d1, d2, pts3d_1, pts3d_2, counts, self.variant, self.thres3d_neg, 0.01,
                              thres3d_pos=self.thresh3d_pos)
 
-    def training_step(self, batch):
+    def training_step(self, batch, direct_grads=False):
         """Loss of P pairs = mean over pairs of the reference's per-pair loss (src/finetune_timm_vggt.py:599-616).
         batch: rgb_1, rgb_2 [P,3,h,w] in [0,1]; kp_1, kp_2 [P,N,2] px; counts int32 [P] (optional);
         pts3d_1, pts3d_2 [P,N,3]; depth_1, depth_2 [P,h,w]; cost_1, cost_2 [P,hw,hw];
         mask_1, mask_2 [P,h,w] bool (vggt)."""
         self.clear_cache()
-        self.model.prepare_trainables()      # per-step pack of the LoRA / adapter weights (dropped again below: never stale)
+        # per-step pack of the LoRA / adapter weights (dropped again below: never stale).  direct_grads (fit_step): built from
+        # views of the flat parameter buffer, and the blocks write their weight gradients into the flat gradient buffer — the
+        # caller must then use `self.backward(loss)` (it zeroes that buffer first and finishes the LoRA-B transposes)
+        self.model.prepare_trainables(self._flat if direct_grads and self._flat is not None else None)
         self._fuse_taps = self.geometry == "shared"   # one forward feeds keypoint AND cost features: norm the taps on the way
         rgbs = _pair_batch(batch["rgb_1"], batch["rgb_2"])
         counts = batch.get("counts")

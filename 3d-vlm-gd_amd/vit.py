@@ -181,10 +181,14 @@ class _BlockFn(torch.autograd.Function):
         # the four weight-gradient accumulators of the block come out of ONE zero-filled buffer
         bott = down.shape[0] if ctx.has_ad else 0
         r2 = at.shape[0] if ctx.has_lora else 0
-        zb = torch.zeros(2 * bott * D + r2 * 3 * D, dtype=torch.float32, device=dout.device)
-        z_up, z_down = zb[:D * bott].view(D, bott), zb[D * bott:2 * D * bott].view(bott, D)
-        z_bt = zb[2 * D * bott:2 * D * bott + r2 * 2 * D].view(r2, 2 * D)     # t^T [dq | dv]
-        z_at = zb[2 * D * bott + r2 * 2 * D:].view(r2, D)
+        direct = tw is not None and "g_at" in tw       # weight gradients accumulate straight into the flat gradient buffer
+        if direct:
+            z_up, z_down, z_bt, z_at = tw["g_up"], tw["g_down"], tw["g_bt"], tw["g_at"]
+        else:
+            zb = torch.zeros(2 * bott * D + r2 * 3 * D, dtype=torch.float32, device=dout.device)
+            z_up, z_down = zb[:D * bott].view(D, bott), zb[D * bott:2 * D * bott].view(bott, D)
+            z_bt = zb[2 * D * bott:2 * D * bott + r2 * 2 * D].view(r2, 2 * D)     # t^T [dq | dv]
+            z_at = zb[2 * D * bott + r2 * 2 * D:].view(r2, D)
         if ctx.has_ad:
             up_tT = tw["up_tT"] if tw is not None else up.detach().t().to(T).contiguous()
             down_tT = tw["down_tT"] if tw is not None else down.detach().t().to(T).contiguous()
@@ -212,6 +216,8 @@ class _BlockFn(torch.autograd.Function):
             gat = ops.gemm_tn(dt, y1, out=z_at)                                                   # [2r, D]
             g_bq, g_bv = gbt[:r, :D].t(), gbt[r:, D:].t()          # strided views: the gradient gather copies them anyway
             g_aq, g_av = gat[:r], gat[r:]
+        if direct:       # already in the flat buffer (LoRA-B: GDViT.finish_trainable_grads transposes the stash once per step)
+            g_aq = g_bq = g_av = g_bv = g_down = g_up = None
         if not ctx.needs_input_grad[0]:   # first trainable block: nothing below it learns, skip dX (one GEMM + one LN backward)
             return None, None, None, None, g_aq, g_bq, g_av, g_bv, g_down, g_up
         if ctx.has_lora:
@@ -367,13 +373,18 @@ class GDViT(nn.Module):
             if self.patch_embed.proj.bias is not None:
                 self.patch_embed.proj.bias.zero_()
 
-    def prepare_trainables(self):
+    def prepare_trainables(self, flat=None):
         """Per-step pack of every adapted block's trainable weights in the engine's layouts (LoRA A stacked [2r, D] and its
         cast, LoRA B scattered into the [2r, 3D] epilogue operand and its cast, adapter weights and their transposes
-        cast): a dozen batched torch kernels per step instead of ~14 tiny ones per block and pass.  Valid until the
-        weights change: FinetuneGD.training_step builds it and `release_trainables` drops it after the backward."""
+        cast).  Valid until the weights change: FinetuneGD.training_step builds it and `release_trainables` drops it.
+        flat = FinetuneGD's flat-buffer record (configure_optimizers) with the spans of the LoRA-A / LoRA-B / adapter
+        tensors: the packs are then built from VIEWS of the flat fp32 parameter buffer (the tensors sit there back to back in
+        exactly the stacked order: ~10 kernels per step instead of ~25 stacks / cats), and the blocks' backward accumulates
+        the LoRA / adapter weight gradients straight into the matching views of the flat GRADIENT buffer — no per-block
+        zero-filled scratch, no 48-tensor gather, no strided LoRA-B copies (`finish_trainable_grads` transposes them once)."""
         T = self.dtype
-        lo, ad = [], []
+        lo = []
+        self._direct = None
         for blk in self.blocks:
             inner, lora, adapter = _unwrap(blk)
             inner._tw = None
@@ -381,21 +392,54 @@ class GDViT(nn.Module):
                 lo.append((inner, lora, adapter))
         if not lo:
             return
+        L = len(lo)
+        r, D = lo[0][1].linear_a_q.weight.shape
+        bott = lo[0][2].down.weight.shape[0]
+        use_flat = flat is not None and flat.get("spans") is not None and flat["spans"]["L"] == L
+        extra = [{} for _ in range(L)]
         with torch.no_grad():
-            r = lo[0][1].linear_a_q.weight.shape[0]
-            D = lo[0][1].linear_a_q.weight.shape[1]
-            at = torch.stack([torch.cat([l.linear_a_q.weight, l.linear_a_v.weight], 0) for _, l, _ in lo]).float()   # [L, 2r, D]
-            bt = torch.zeros(len(lo), 2 * r, 3 * D, dtype=torch.float32, device=at.device)
-            bt[:, :r, :D] = torch.stack([l.linear_b_q.weight for _, l, _ in lo]).transpose(1, 2)
-            bt[:, r:, 2 * D:] = torch.stack([l.linear_b_v.weight for _, l, _ in lo]).transpose(1, 2)
-            down = torch.stack([a.down.weight for _, _, a in lo])        # [L, 64, D]
-            up = torch.stack([a.up.weight for _, _, a in lo])            # [L, D, 64]
+            if use_flat:
+                sp, fp, fg = flat["spans"], flat["p"], flat["g"]
+                at = fp[sp["A"]:sp["A"] + L * 2 * r * D].view(L, 2 * r, D)
+                Bv = fp[sp["B"]:sp["B"] + L * 2 * D * r].view(L, 2, D, r)
+                Ad = fp[sp["ad"]:sp["ad"] + L * 2 * bott * D].view(L, 2, bott * D)
+                bt = getattr(self, "_bt_buf", None)
+                if bt is None or bt.shape != (L, 2 * r, 3 * D) or bt.device != fp.device:
+                    bt = self._bt_buf = torch.zeros(L, 2 * r, 3 * D, dtype=torch.float32, device=fp.device)   # the k block stays zero
+                bt[:, :r, :D] = Bv[:, 0].transpose(1, 2)
+                bt[:, r:, 2 * D:] = Bv[:, 1].transpose(1, 2)
+                down, up = Ad[:, 0].view(L, bott, D), Ad[:, 1].view(L, D, bott)
+                gA = fg[sp["A"]:sp["A"] + L * 2 * r * D].view(L, 2 * r, D)
+                gAd = fg[sp["ad"]:sp["ad"] + L * 2 * bott * D].view(L, 2, bott * D)
+                gbt = torch.zeros(L, 2 * r, 2 * D, dtype=torch.float32, device=fp.device)       # t^T [dq | dv] stash
+                for i in range(L):
+                    extra[i] = {"g_at": gA[i], "g_bt": gbt[i], "g_down": gAd[i, 0].view(bott, D), "g_up": gAd[i, 1].view(D, bott)}
+                self._direct = {"gbt": gbt, "gB": fg[sp["B"]:sp["B"] + L * 2 * D * r].view(L, 2, D, r), "r": r, "D": D}
+            else:
+                at = torch.stack([torch.cat([l.linear_a_q.weight, l.linear_a_v.weight], 0) for _, l, _ in lo]).float()   # [L, 2r, D]
+                bt = torch.zeros(L, 2 * r, 3 * D, dtype=torch.float32, device=at.device)
+                bt[:, :r, :D] = torch.stack([l.linear_b_q.weight for _, l, _ in lo]).transpose(1, 2)
+                bt[:, r:, 2 * D:] = torch.stack([l.linear_b_v.weight for _, l, _ in lo]).transpose(1, 2)
+                down = torch.stack([a.down.weight for _, _, a in lo])        # [L, 64, D]
+                up = torch.stack([a.up.weight for _, _, a in lo])            # [L, D, 64]
             at_T, bt_T, down_T, up_T = at.to(T), bt.to(T), down.to(T), up.to(T)
             bt_qv = torch.cat([bt_T[:, :, :D], bt_T[:, :, 2 * D:]], 2).contiguous()      # [L, 2r, 2D]: the (dq, dv) column order
             down_tT, up_tT = down_T.transpose(1, 2).contiguous(), up_T.transpose(1, 2).contiguous()
         for i, (inner, _, _) in enumerate(lo):
             inner._tw = {"dtype": T, "at": at[i], "bt": bt[i], "at_T": at_T[i], "bt_T": bt_T[i], "bt_qv": bt_qv[i], "down_T": down_T[i],
-                         "up_T": up_T[i], "down_tT": down_tT[i], "up_tT": up_tT[i]}
+                         "up_T": up_T[i], "down_tT": down_tT[i], "up_tT": up_tT[i], **extra[i]}
+
+    def finish_trainable_grads(self):
+        """After the backward of a step prepared with `prepare_trainables(flat)`: the LoRA-B gradients were accumulated as
+        t^T [dq | dv] ([2r, 2D] per block); transpose the q and v blocks into the flat buffer's [D, r] tensors (2 kernels)."""
+        d = getattr(self, "_direct", None)
+        if d is None:
+            return
+        r, D = d["r"], d["D"]
+        with torch.no_grad():
+            d["gB"][:, 0] += d["gbt"][:, :r, :D].transpose(1, 2)
+            d["gB"][:, 1] += d["gbt"][:, r:, D:].transpose(1, 2)
+        self._direct = None
 
     def release_trainables(self):
         for blk in self.blocks:
