@@ -341,7 +341,7 @@ def test_two_ranks_on_one_gpu_equal_one_rank_on_the_whole_batch(tmp_path):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-def test_direct_weight_gradients_equal_the_autograd_path(dtype):
+def test_direct_weight_gradients_equal_the_autograd_path(dtype, monkeypatch):
     """fit_step prepares the blocks with the flat-buffer record: weight packs are views of the flat parameter buffer and the
     LoRA / adapter weight gradients accumulate straight into the flat gradient buffer (LoRA-B through one transposing pass).
     The flat gradient equals what autograd + the 48-tensor gather produce; f32 against the fp64 oracle as well."""
@@ -351,7 +351,9 @@ def test_direct_weight_gradients_equal_the_autograd_path(dtype):
     b = _engine("vggt", "shared", dtype, teacher_patch=14)
     fa, fb = a.configure_optimizers(), b.configure_optimizers()
     assert fa["spans"] is not None and fa["spans"]["L"] == 4
+    monkeypatch.setenv("GD_DIRECT_GRADS", "1")
     la, _, na = a.fit_step(batch)                              # direct path
+    monkeypatch.delenv("GD_DIRECT_GRADS")
     lb, _ = b.training_step(batch)                             # autograd returns every gradient, gathered by one multi-tensor copy
     b.backward(lb)
     assert abs(la.item() - lb.item()) < 1e-6 * abs(lb.item())
