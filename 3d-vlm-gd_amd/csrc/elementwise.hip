@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void col2im3x3_kernel(const T* dcol, T* dx, lo
 struct GatherParams {
     const void* grid[4]; int ngrid; long bstride; int grid_dtype;
     const float* kp; float* out; float* dgrid[4]; const float* dout;
-    int B, Nk, gh, gw, D;
+    int B, Nk, gh, gw, D, pitch;     // pitch: tokens per grid line in memory (gw for a dense grid)
     float sx, sy, ax, bx, ay, by;
 };
 
@@ -194,10 +194,10 @@ __global__ __launch_bounds__(256) void kp_gather_fwd_kernel(GatherParams p) {
         float acc = 0.f;
         for (int t = 0; t < p.ngrid; ++t) {
             const long base = b * p.bstride + d;
-            acc += w00 * ld_rt(p.grid[t], base + ((long)y0 * p.gw + x0) * p.D, p.grid_dtype) +
-                   w01 * ld_rt(p.grid[t], base + ((long)y0 * p.gw + x1) * p.D, p.grid_dtype) +
-                   w10 * ld_rt(p.grid[t], base + ((long)y1 * p.gw + x0) * p.D, p.grid_dtype) +
-                   w11 * ld_rt(p.grid[t], base + ((long)y1 * p.gw + x1) * p.D, p.grid_dtype);
+            acc += w00 * ld_rt(p.grid[t], base + ((long)y0 * p.pitch + x0) * p.D, p.grid_dtype) +
+                   w01 * ld_rt(p.grid[t], base + ((long)y0 * p.pitch + x1) * p.D, p.grid_dtype) +
+                   w10 * ld_rt(p.grid[t], base + ((long)y1 * p.pitch + x0) * p.D, p.grid_dtype) +
+                   w11 * ld_rt(p.grid[t], base + ((long)y1 * p.pitch + x1) * p.D, p.grid_dtype);
         }
         p.out[bk * p.D + d] = acc * inv;
     }
@@ -217,10 +217,10 @@ __global__ __launch_bounds__(256) void kp_gather_bwd_kernel(GatherParams p) {
         const float g = p.dout[bk * p.D + d];
         for (int t = 0; t < p.ngrid; ++t) {
             float* dg = p.dgrid[t] + b * gs + d;
-            atomicAdd(dg + ((long)y0 * p.gw + x0) * p.D, w00 * g);
-            atomicAdd(dg + ((long)y0 * p.gw + x1) * p.D, w01 * g);
-            atomicAdd(dg + ((long)y1 * p.gw + x0) * p.D, w10 * g);
-            atomicAdd(dg + ((long)y1 * p.gw + x1) * p.D, w11 * g);
+            atomicAdd(dg + ((long)y0 * p.pitch + x0) * p.D, w00 * g);
+            atomicAdd(dg + ((long)y0 * p.pitch + x1) * p.D, w01 * g);
+            atomicAdd(dg + ((long)y1 * p.pitch + x0) * p.D, w10 * g);
+            atomicAdd(dg + ((long)y1 * p.pitch + x1) * p.D, w11 * g);
         }
     }
 }
@@ -347,6 +347,61 @@ __global__ __launch_bounds__(256) void tap_mean_bwd_kernel(TapMeanParams p, cons
 
 static inline int ew_blocks(long total) { long b = (total + 255) / 256; return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
 
+// ---- refine_conv 3x3 as ONE GEMM over an overlapping-row view (no im2col) ----------------------------------------------
+// Grid lines get one zero SEPARATOR column (pitch = gw + 1) and every grid row r = (b, y, x) is stored with its vertical
+// neighbours: R[r] = (X[r - pitch], X[r], X[r + pitch]) (3 D wide, zeros outside the image / at separators).  With one zero guard
+// row in front, A[r][(dx+1) 3D + (dy+1) D + c] = X[r + dy pitch + dx][c] = Rbuf[r * 3D + k]: an AFFINE view with row stride 3 D and
+// K = 9 D whose rows overlap — the horizontal taps are the neighbouring rows of the buffer itself.  The 3x3 conv, its transpose
+// (on a stacked dY) and its weight gradient are plain GEMMs on that view; the buffer is 3 x the tokens instead of im2col's 9 x.
+// src: token layout (src_pitch = gw, first grid token at src_row0) or a pitched grid (src_pitch = gw + 1); TS f32 | bf16 -> TD.
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void stack3_kernel(const TS* src, TD* dst, int B, int gh, int gw, int D, long src_bstride,
+                                                     long src_row0, int src_pitch) {
+    constexpr int VEC = 16 / sizeof(TD);
+    const int pitch = gw + 1, cpr = D / VEC;                    // chunks per D-wide slot
+    const long rows = (long)B * gh * pitch + 2, total = rows * 3 * cpr;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int ch = (int)(i % cpr);
+        const long t = i / cpr;
+        const int slot = (int)(t % 3);
+        const long R = t / 3, r = R - 1;
+        TD v[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) v[k] = from_f32<TD>(0.f);
+        if (r >= 0 && r < rows - 2) {
+            const int b = (int)(r / ((long)gh * pitch)), rem = (int)(r % ((long)gh * pitch));
+            const int y = rem / pitch, x = rem % pitch, yy = y + slot - 1;
+            if (x < gw && yy >= 0 && yy < gh) {
+                const TS* s = src + (long)b * src_bstride + src_row0 + ((long)yy * src_pitch + x) * D + ch * VEC;
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) v[k] = from_f32<TD>(to_f32<TS>(s[k]));
+            }
+        }
+        TD* d = dst + (R * 3 + slot) * D + ch * VEC;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) d[k] = v[k];
+    }
+}
+
+// pitched grid [B, gh, gw + 1, D] -> token layout [B, prefix + gh*gw, D] (prefix rows zero): the conv's input gradient
+template <typename T>
+__global__ __launch_bounds__(256) void unpitch_kernel(const T* src, T* dst, int B, int gh, int gw, int D, int prefix) {
+    constexpr int VEC = 16 / sizeof(T);
+    const int cpr = D / VEC, Nt = prefix + gh * gw;
+    const long total = (long)B * Nt * cpr;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int ch = (int)(i % cpr);
+        const long t = i / cpr;
+        const int b = (int)(t / Nt), tok = (int)(t % Nt);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (tok >= prefix) {
+            const int g = tok - prefix, y = g / gw, x = g % gw;
+            v = *(const uint4*)(src + (((long)b * gh + y) * (gw + 1) + x) * D + ch * VEC);
+        }
+        *(uint4*)(dst + t * D + ch * VEC) = v;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 extern "C" int gd_patch_im2col(const float* img, void* col, int B, int h, int w, int H, int W, int P, int Kp,
                                const float* mean3, const float* std3, int dtype, void* stream) {
@@ -411,9 +466,10 @@ extern "C" int gd_col2im3x3(const void* dcol, void* dx, long bstride, int B, int
 
 static int fill_gather(GatherParams& p, const void* const* grids, int ngrid, long bstride, int grid_dtype,
                        const float* kp, int B, int Nk, int gh, int gw, int D, float sx, float sy, int img_h,
-                       int img_w, int patch, int stride) {
+                       int img_w, int patch, int stride, int pitch) {
     GD_REQUIRE(ngrid >= 1 && ngrid <= 4, "kp_gather: 1..4 grids (got %d)", ngrid);
-    GD_REQUIRE(B > 0 && Nk > 0 && gh > 0 && gw > 0 && D > 0, "kp_gather: bad shape");
+    GD_REQUIRE(B > 0 && Nk > 0 && gh > 0 && gw > 0 && D > 0 && pitch >= gw, "kp_gather: bad shape (pitch %d < gw %d?)", pitch, gw);
+    p.pitch = pitch;
     for (int t = 0; t < 4; ++t) p.grid[t] = t < ngrid ? grids[t] : nullptr;
     p.ngrid = ngrid; p.bstride = bstride; p.grid_dtype = grid_dtype; p.kp = kp;
     p.B = B; p.Nk = Nk; p.gh = gh; p.gw = gw; p.D = D; p.sx = sx; p.sy = sy;
@@ -427,9 +483,9 @@ static int fill_gather(GatherParams& p, const void* const* grids, int ngrid, lon
 
 extern "C" int gd_kp_gather_fwd(const void* const* grids, int ngrid, long bstride, int grid_dtype, const float* kp,
                                 float* out, int B, int Nk, int gh, int gw, int D, float sx, float sy, int img_h,
-                                int img_w, int patch, int stride, void* stream) {
+                                int img_w, int patch, int stride, int pitch, void* stream) {
     GatherParams p = {};
-    if (fill_gather(p, grids, ngrid, bstride, grid_dtype, kp, B, Nk, gh, gw, D, sx, sy, img_h, img_w, patch, stride)) return -1;
+    if (fill_gather(p, grids, ngrid, bstride, grid_dtype, kp, B, Nk, gh, gw, D, sx, sy, img_h, img_w, patch, stride, pitch)) return -1;
     p.out = out;
     hipLaunchKernelGGL(kp_gather_fwd_kernel, dim3(B * Nk), dim3(256), 0, (hipStream_t)stream, p);
     GD_LAUNCH_OK();
@@ -438,10 +494,10 @@ extern "C" int gd_kp_gather_fwd(const void* const* grids, int ngrid, long bstrid
 
 extern "C" int gd_kp_gather_bwd(float* const* dgrids, int ngrid, long bstride, const float* kp, const float* dout,
                                 int B, int Nk, int gh, int gw, int D, float sx, float sy, int img_h, int img_w,
-                                int patch, int stride, void* stream) {
+                                int patch, int stride, int pitch, void* stream) {
     GatherParams p = {};
     const void* dummy[4] = {dgrids[0], dgrids[0], dgrids[0], dgrids[0]};
-    if (fill_gather(p, dummy, ngrid, bstride, GD_F32, kp, B, Nk, gh, gw, D, sx, sy, img_h, img_w, patch, stride)) return -1;
+    if (fill_gather(p, dummy, ngrid, bstride, GD_F32, kp, B, Nk, gh, gw, D, sx, sy, img_h, img_w, patch, stride, pitch)) return -1;
     for (int t = 0; t < 4; ++t) p.dgrid[t] = t < ngrid ? dgrids[t] : nullptr;
     p.dout = dout;
     hipLaunchKernelGGL(kp_gather_bwd_kernel, dim3(B * Nk), dim3(256), 0, (hipStream_t)stream, p);
@@ -539,6 +595,35 @@ extern "C" int gd_tap_mean_bwd(void* const* dgrids, int ngrid, int prefix, const
     const long total = (long)B * p.bstride / (dtype == GD_BF16 ? 8 : 4);
     if (dtype == GD_BF16) hipLaunchKernelGGL(tap_mean_bwd_kernel<bf16>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, p, (const bf16*)dout, B, hw, D, scale);
     else hipLaunchKernelGGL(tap_mean_bwd_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, p, (const float*)dout, B, hw, D, scale);
+    GD_LAUNCH_OK();
+    return 0;
+}
+
+extern "C" int gd_stack3_rows(const void* src, void* dst, int B, int gh, int gw, int D, long src_bstride, long src_row0,
+                              int src_pitch, int src_dtype, int dst_dtype, void* stream) {
+    GD_REQUIRE(B > 0 && gh > 0 && gw > 0 && D > 0 && (src_pitch == gw || src_pitch == gw + 1), "gd_stack3_rows: bad shape / source pitch");
+    GD_REQUIRE((D * gd_dtype_size(dst_dtype)) % 16 == 0 && ((uintptr_t)dst & 15) == 0, "gd_stack3_rows: D rows must be multiples of 16 bytes, dst aligned");
+    const long total = ((long)B * gh * (gw + 1) + 2) * 3 * (D / (16 / gd_dtype_size(dst_dtype)));
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 g(ew_blocks(total)), b(256);
+    if (src_dtype == GD_BF16 && dst_dtype == GD_BF16)
+        hipLaunchKernelGGL((stack3_kernel<bf16, bf16>), g, b, 0, s, (const bf16*)src, (bf16*)dst, B, gh, gw, D, src_bstride, src_row0, src_pitch);
+    else if (src_dtype == GD_F32 && dst_dtype == GD_BF16)
+        hipLaunchKernelGGL((stack3_kernel<float, bf16>), g, b, 0, s, (const float*)src, (bf16*)dst, B, gh, gw, D, src_bstride, src_row0, src_pitch);
+    else if (src_dtype == GD_F32 && dst_dtype == GD_F32)
+        hipLaunchKernelGGL((stack3_kernel<float, float>), g, b, 0, s, (const float*)src, (float*)dst, B, gh, gw, D, src_bstride, src_row0, src_pitch);
+    else { gd_set_error("gd_stack3_rows: unsupported dtype pair %d -> %d", src_dtype, dst_dtype); return -1; }
+    GD_LAUNCH_OK();
+    return 0;
+}
+
+extern "C" int gd_unpitch_tokens(const void* src, void* dst, int B, int gh, int gw, int D, int prefix, int dtype, void* stream) {
+    GD_REQUIRE(B > 0 && gh > 0 && gw > 0 && D > 0 && prefix >= 0 && (D * gd_dtype_size(dtype)) % 16 == 0 &&
+                   ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "gd_unpitch_tokens: bad shape / alignment");
+    const long total = (long)B * (prefix + gh * gw) * (D / (16 / gd_dtype_size(dtype)));
+    const dim3 g(ew_blocks(total)), b(256);
+    if (dtype == GD_BF16) hipLaunchKernelGGL(unpitch_kernel<bf16>, g, b, 0, (hipStream_t)stream, (const bf16*)src, (bf16*)dst, B, gh, gw, D, prefix);
+    else hipLaunchKernelGGL(unpitch_kernel<float>, g, b, 0, (hipStream_t)stream, (const float*)src, (float*)dst, B, gh, gw, D, prefix);
     GD_LAUNCH_OK();
     return 0;
 }

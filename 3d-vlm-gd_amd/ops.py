@@ -369,22 +369,44 @@ def _ptr_array(tensors):
     return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
-def kp_gather_fwd(grids, bstride, kp, B, Nk, gh, gw, D, sx, sy, img_h, img_w, patch, stride=None):
-    """grids: list (1..4) of tensors whose data_ptr is the (b=0, token 0 of the grid) element."""
+def kp_gather_fwd(grids, bstride, kp, B, Nk, gh, gw, D, sx, sy, img_h, img_w, patch, stride=None, pitch=None):
+    """grids: list (1..4) of tensors whose data_ptr is the (b=0, token 0 of the grid) element; pitch = tokens per grid line in
+    memory (default gw)."""
     out = torch.empty(B, Nk, D, dtype=torch.float32, device=kp.device)
     check(lib().gd_kp_gather_fwd(_ptr_array(grids), len(grids), bstride, dtype_code(grids[0]), ptr(kp), ptr(out), B,
                                  Nk, gh, gw, D, float(sx), float(sy), img_h, img_w, patch, patch if stride is None else stride,
-                                 stream()), "gd_kp_gather_fwd")
+                                 gw if pitch is None else pitch, stream()), "gd_kp_gather_fwd")
     return out
 
 
-def kp_gather_bwd(ngrid, kp, dout, B, Nk, gh, gw, D, sx, sy, img_h, img_w, patch, prefix=0, stride=None):
-    """-> list of ngrid fp32 gradient buffers [B, prefix + gh*gw, D] (prefix-token rows stay zero)."""
-    dg = [torch.zeros(B, prefix + gh * gw, D, dtype=torch.float32, device=kp.device) for _ in range(ngrid)]
+def kp_gather_bwd(ngrid, kp, dout, B, Nk, gh, gw, D, sx, sy, img_h, img_w, patch, prefix=0, stride=None, pitch=None):
+    """-> list of ngrid fp32 gradient buffers [B, prefix + gh*pitch, D] (prefix-token rows / separator columns stay zero)."""
+    pt = gw if pitch is None else pitch
+    dg = [torch.zeros(B, prefix + gh * pt, D, dtype=torch.float32, device=kp.device) for _ in range(ngrid)]
     dout = dout.contiguous().float()
-    check(lib().gd_kp_gather_bwd(_ptr_array([t[:, prefix:] for t in dg]), ngrid, (prefix + gh * gw) * D, ptr(kp), ptr(dout), B, Nk, gh, gw, D, float(sx), float(sy),
-                                 img_h, img_w, patch, patch if stride is None else stride, stream()), "gd_kp_gather_bwd")
+    check(lib().gd_kp_gather_bwd(_ptr_array([t[:, prefix:] for t in dg]), ngrid, (prefix + gh * pt) * D, ptr(kp), ptr(dout), B, Nk, gh, gw, D, float(sx), float(sy),
+                                 img_h, img_w, patch, patch if stride is None else stride, pt, stream()), "gd_kp_gather_bwd")
     return dg
+
+
+def stack3_rows(src, B, gh, gw, D, src_bstride, src_row0, src_pitch, dtype):
+    """-> buf [B*gh*(gw+1) + 2, 3*D] of `dtype` (see gd_stack3_rows); `src` is addressed from its data_ptr."""
+    buf = torch.empty(B * gh * (gw + 1) + 2, 3 * D, dtype=dtype, device=src.device)
+    check(lib().gd_stack3_rows(ptr(src), ptr(buf), B, gh, gw, D, src_bstride, src_row0, src_pitch, dtype_code(src), dtype_code(buf),
+                               stream()), "gd_stack3_rows")
+    return buf
+
+
+def conv_view(buf, rows, D):
+    """The overlapping-row GEMM operand of a stack3 buffer: A[r][k] = buf_flat[r*3D + k], [rows, 9D] with row stride 3D."""
+    return torch.as_strided(buf, (rows, 9 * D), (3 * D, 1))
+
+
+def unpitch_tokens(src, B, gh, gw, D, prefix):
+    """pitched [B*gh*(gw+1), D] -> [B, prefix + gh*gw, D], prefix rows zero."""
+    out = torch.empty(B, prefix + gh * gw, D, dtype=src.dtype, device=src.device)
+    check(lib().gd_unpitch_tokens(ptr(src), ptr(out), B, gh, gw, D, prefix, dtype_code(src), stream()), "gd_unpitch_tokens")
+    return out
 
 
 class _TapMean(torch.autograd.Function):

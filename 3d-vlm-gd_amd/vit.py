@@ -556,6 +556,9 @@ def create_vit(name="vit_base", patch_size=14, img_size=518, **kw):
 # refine_conv on token grids and keypoint sampling (autograd over the C ABI)
 # ------------------------------------------------------------------------------------------------
 class _Conv3x3Fn(torch.autograd.Function):
+    """refine_conv through im2col (the materialising form: a [M, 9D] column buffer each way).  Kept for `GD_CONV_STACKED=0` and
+    as the reference point of tests; the default is _Conv3x3StackedFn."""
+
     @staticmethod
     def forward(ctx, tok, weight, bias, gh, gw):
         """tok [B, 1+gh*gw, D] (prefix token skipped) -> [B, gh*gw, D] fp32."""
@@ -584,20 +587,66 @@ class _Conv3x3Fn(torch.autograd.Function):
         return dtok, gweight, gbias, None, None
 
 
+class _Conv3x3StackedFn(torch.autograd.Function):
+    """refine_conv as ONE GEMM over an overlapping-row view of a 3-row stacked token buffer (gd_stack3_rows): no im2col /
+    col2im, a third of the bytes.  The output lives on the separator-column grid: [B, gh*(gw+1), D] fp32, pitch gw + 1 (the
+    separator positions hold finite garbage and receive zero gradient: kp_gather reads with the pitch and never touches them)."""
+
+    @staticmethod
+    def forward(ctx, tok, weight, bias, gh, gw):
+        B, Nt, D = tok.shape
+        tok = tok.contiguous()
+        T = tok.dtype
+        rows = B * gh * (gw + 1)
+        buf = ops.stack3_rows(tok, B, gh, gw, D, Nt * D, (Nt - gh * gw) * D, gw, T)
+        # K index = (dx, dy, c): weight[n, c, ky, kx] -> [n, kx, ky, c]
+        wk = weight.detach().permute(0, 3, 2, 1).reshape(D, 9 * D).to(T).contiguous()
+        out = ops.gemm_nt(ops.conv_view(buf, rows, D), wk, bias=bias.detach().float().contiguous(), out_dtype=torch.float32)
+        ctx.save_for_backward(buf, weight)
+        ctx.dims = (B, Nt, D, gh, gw)
+        return out.view(B, gh * (gw + 1), D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        buf, weight = ctx.saved_tensors
+        B, Nt, D, gh, gw = ctx.dims
+        T = buf.dtype
+        rows = B * gh * (gw + 1)
+        dyf = dy.reshape(rows, D).contiguous().float()               # zero at the separator positions (nothing reads them)
+        dyt = dyf if T == torch.float32 else ops.cast(dyf, T)
+        gk = ops.gemm_tn(dyt, ops.conv_view(buf, rows, D))            # [Dout, (kx, ky, Din)]
+        gweight = gk.view(D, 3, 3, D).permute(0, 3, 2, 1).contiguous()
+        gbias = dyf.sum(0)
+        # transposed conv = the same view of a stacked dY against the flipped kernel:
+        # dX[r][ci] = sum_{dx, dy, n} dY[r + dy*pitch + dx][n] * W[n, ci, 1 - dy, 1 - dx]
+        sbuf = ops.stack3_rows(dyf, B, gh, gw, D, gh * (gw + 1) * D, 0, gw + 1, T)
+        wt = weight.detach().flip(2, 3).permute(1, 3, 2, 0).reshape(D, 9 * D).to(T).contiguous()      # [ci, (kx, ky, n)]
+        dxp = ops.gemm_nt(ops.conv_view(sbuf, rows, D), wt)            # [rows, D] on the pitched grid
+        dtok = ops.unpitch_tokens(dxp, B, gh, gw, D, Nt - gh * gw)
+        return dtok, gweight, gbias, None, None
+
+
 def conv3x3_tokens(tok, weight, bias, gh, gw):
-    return _Conv3x3Fn.apply(tok, weight, bias, gh, gw)
+    """refine_conv (3x3, padding 1) on the token grid of tok [B, prefix + gh*gw, D].  -> (fmap, pitch): fmap [B, gh*pitch, D] fp32
+    with pitch = gw + 1 (separator-column layout, the default) or gw (im2col path: GD_CONV_STACKED=0, or D rows that are not
+    multiples of 16 bytes)."""
+    import os
+    es = 2 if tok.dtype == torch.bfloat16 else 4
+    if os.environ.get("GD_CONV_STACKED", "1") != "0" and (tok.shape[-1] * es) % 16 == 0:
+        return _Conv3x3StackedFn.apply(tok, weight, bias, gh, gw), gw + 1
+    return _Conv3x3Fn.apply(tok, weight, bias, gh, gw), gw
 
 
 class _GatherFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, kp, geom, *grids):
-        gh, gw, sx, sy, img_h, img_w, patch, stride = geom
+        gh, gw, sx, sy, img_h, img_w, patch, stride, pitch = geom
         B, Ng, D = grids[0].shape
-        prefix = Ng - gh * gw
+        prefix = Ng - gh * pitch
         gs = [g.contiguous() for g in grids]
         kp = kp.contiguous().float()
         out = ops.kp_gather_fwd([g[:, prefix:] for g in gs], Ng * D, kp, B, kp.shape[1], gh, gw, D, sx, sy, img_h,
-                                img_w, patch, stride=stride)
+                                img_w, patch, stride=stride, pitch=pitch)
         ctx.save_for_backward(kp)
         ctx.meta = (geom, B, Ng, D, prefix, len(gs), gs[0].dtype)
         return out
@@ -605,17 +654,18 @@ class _GatherFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         (kp,) = ctx.saved_tensors
-        (gh, gw, sx, sy, img_h, img_w, patch, stride), B, Ng, D, prefix, ng, T = ctx.meta
+        (gh, gw, sx, sy, img_h, img_w, patch, stride, pitch), B, Ng, D, prefix, ng, T = ctx.meta
         # every grid of the mean receives the SAME gradient (w * dout / ng): scatter it once and hand the one buffer, cast
         # once to the grids' dtype, to all of them (four zero-filled fp32 grids + four scatters + four casts otherwise)
         dg = ops.kp_gather_bwd(1, kp, dout * (1.0 / ng), B, kp.shape[1], gh, gw, D, sx, sy, img_h, img_w, patch, prefix=prefix,
-                               stride=stride)[0]
+                               stride=stride, pitch=pitch)[0]
         if dg.dtype != T:
             dg = dg.to(T)
         return (None, None) + (dg,) * ng
 
 
-def kp_gather(grids, kp, gh, gw, sx, sy, img_h, img_w, patch, stride=None):
-    """interpolate_features on token-major grids [B, prefix+gh*gw, D] (mean over the list) -> [B, Nk, D] fp32."""
+def kp_gather(grids, kp, gh, gw, sx, sy, img_h, img_w, patch, stride=None, pitch=None):
+    """interpolate_features on token-major grids [B, prefix+gh*pitch, D] (mean over the list) -> [B, Nk, D] fp32; pitch = tokens
+    per grid line in memory (default gw; gw + 1 for conv3x3_tokens' separator-column output)."""
     return _GatherFn.apply(kp, (gh, gw, float(sx), float(sy), int(img_h), int(img_w), int(patch),
-                                int(patch if stride is None else stride)), *grids)
+                                int(patch if stride is None else stride), int(gw if pitch is None else pitch)), *grids)

@@ -102,16 +102,26 @@ int gd_patch_im2col(const float* img, void* col, int B, int h, int w, int H, int
 /* timm _pos_embed: cls + pos[0] | patch + pos[1:]  ->  tokens [B, Np+1, D]. */
 int gd_assemble_tokens(const void* patch, const float* cls, const float* pos, void* out, int B, int Np, int D,
                        int dtype, void* stream);
-/* refine_conv 3x3/pad 1 (src/finetune_timm_vggt.py:146,325) as im2col / col2im around gd_gemm_nt / gd_gemm_tn. */
+/* refine_conv 3x3/pad 1 (src/finetune_timm_vggt.py:146,325) WITHOUT im2col: gd_stack3_rows writes, for every row r of a grid
+ * whose lines carry one zero separator column (pitch = gw + 1), the three vertically adjacent feature vectors side by side
+ * ([B*gh*pitch + 2, 3D], one zero guard row at each end); the conv, its transpose and its weight gradient are then single
+ * gd_gemm_nt / gd_gemm_tn calls on the OVERLAPPING-row view A[r][k] = buf[r*3D + k], K = 9D, k = (dx+1)*3D + (dy+1)*D + c.
+ * src: token layout (src_pitch = gw, grid starts src_row0 elements into each image of src_bstride elements) or a pitched grid
+ * (src_pitch = gw + 1).  gd_unpitch_tokens: pitched [B, gh, gw+1, D] -> token layout [B, prefix + gh*gw, D], prefix rows zero.
+ * (gd_im2col3x3 / gd_col2im3x3: the materialising form, kept for shapes the view cannot serve.) */
+int gd_stack3_rows(const void* src, void* dst, int B, int gh, int gw, int D, long src_bstride, long src_row0, int src_pitch,
+                   int src_dtype, int dst_dtype, void* stream);
+int gd_unpitch_tokens(const void* src, void* dst, int B, int gh, int gw, int D, int prefix, int dtype, void* stream);
 int gd_im2col3x3(const void* x, long bstride, void* col, int B, int gh, int gw, int D, int dtype, void* stream);
 int gd_col2im3x3(const void* dcol, void* dx, long bstride, int B, int gh, int gw, int D, int dtype, void* stream);
 /* interpolate_features (utils/functions.py:55-76) on 1..4 token-major grids, averaged; backward scatters into fp32
- * gradient grids (batch stride bstride elements, pre-zeroed). */
+ * gradient grids (batch stride bstride elements, pre-zeroed).  pitch = tokens per grid line in memory (gw for a dense grid,
+ * gw + 1 for the separator-column layout of gd_stack3_rows' GEMM output). */
 int gd_kp_gather_fwd(const void* const* grids, int ngrid, long bstride, int grid_dtype, const float* kp, float* out,
                      int B, int Nk, int gh, int gw, int D, float sx, float sy, int img_h, int img_w, int patch,
-                     int stride, void* stream);
+                     int stride, int pitch, void* stream);
 int gd_kp_gather_bwd(float* const* dgrids, int ngrid, long bstride, const float* kp, const float* dout, int B, int Nk,
-                     int gh, int gw, int D, float sx, float sy, int img_h, int img_w, int patch, int stride,
+                     int gh, int gw, int D, float sx, float sy, int img_h, int img_w, int patch, int stride, int pitch,
                      void* stream);
 /* extract_kp_depth (utils/functions.py:348-372) and get_patch_mask_from_kp_tensor (:375-399; mask pre-zeroed). */
 int gd_kp_depth(const float* depth, const float* kp, float* out, int B, int Nk, int H, int W, void* stream);

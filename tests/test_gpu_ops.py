@@ -88,6 +88,41 @@ def test_conv3x3_via_im2col(dtype, tol):
     assert rel_err(dx.view(B, gh, gw, D).permute(0, 3, 1, 2), x.grad) < tol * 2
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("B,gh,gw,D,prefix", [(2, 5, 7, 64, 1), (3, 37, 37, 128, 1), (1, 4, 9, 32, 0)])
+def test_conv3x3_stacked_implicit_gemm(dtype, tol, B, gh, gw, D, prefix):
+    """refine_conv as one GEMM over the overlapping-row view of the 3-row stacked buffer (no im2col): forward, input gradient,
+    weight and bias gradients against F.conv2d in fp64; the output sits on the separator-column grid and is sampled through
+    kp_gather with the pitch.  Also: identical to the im2col path."""
+    from gd_amd.vit import conv3x3_tokens, kp_gather, _Conv3x3Fn
+    tok = torch.randn(B, prefix + gh * gw, D, generator=_g(12), device="cuda").to(dtype).requires_grad_(True)
+    w = (torch.randn(D, D, 3, 3, generator=_g(13), device="cuda") * 0.05).requires_grad_(True)
+    bias = torch.randn(D, generator=_g(14), device="cuda").requires_grad_(True)
+    fmap, pitch = conv3x3_tokens(tok, w, bias, gh, gw)
+    assert pitch == gw + 1 and fmap.shape == (B, gh * pitch, D)
+    grid = fmap.view(B, gh, pitch, D)[:, :, :gw]
+    x = tok.detach().cpu()[:, prefix:].double().reshape(B, gh, gw, D).permute(0, 3, 1, 2).requires_grad_(True)
+    wr, br = w.detach().cpu().double().requires_grad_(True), bias.detach().cpu().double().requires_grad_(True)
+    ref = F.conv2d(x, wr, br, padding=1)
+    assert rel_err(grid.permute(0, 3, 1, 2), ref) < tol
+    old = _Conv3x3Fn.apply(tok.detach(), w.detach(), bias.detach(), gh, gw).view(B, gh, gw, D)
+    assert rel_err(grid, old) < 1e-5      # the same products, summed in another order
+    # gradient: through keypoint sampling on the pitched grid (what the step does) + a dense weight on the real positions
+    P = 14
+    kp = torch.rand(B, 11, 2, generator=_g(15), device="cuda") * torch.tensor([gw * P - 1.0, gh * P - 1.0], device="cuda")
+    samp = kp_gather([fmap], kp, gh, gw, 1.0, 1.0, gh * P, gw * P, P, pitch=pitch)
+    wd = torch.randn(B, gh, gw, D, generator=_g(16), device="cuda")
+    ws = torch.randn(samp.shape, generator=_g(17), device="cuda")
+    ((grid * wd).sum() + (samp * ws).sum()).backward()
+    rs = O.interpolate_features(ref, kp.cpu().double(), gh * P, gw * P, False, P, P).permute(0, 2, 1)
+    assert rel_err(samp, rs) < tol
+    ((ref.permute(0, 2, 3, 1) * wd.cpu().double()).sum() + (rs * ws.cpu().double()).sum()).backward()
+    assert rel_err(tok.grad[:, prefix:].reshape(B, gh, gw, D).permute(0, 3, 1, 2), x.grad) < 2 * tol
+    if prefix:
+        assert float(tok.grad[:, :prefix].abs().max()) == 0.0
+    assert rel_err(w.grad, wr.grad) < 2 * tol and rel_err(bias.grad, br.grad) < 2 * tol
+
+
 @pytest.mark.parametrize("P", [14, 16])
 def test_kp_gather_golden(P):
     from gd_amd import ops
