@@ -365,3 +365,79 @@ def test_direct_weight_gradients_equal_the_autograd_path(dtype, monkeypatch):
         for q, v, g in zip(a.trainable_parameters(), fa["views"], ref_grads):
             assert float((v.cpu().double() - g).abs().max()) < 2e-3 * max(float(g.abs().max()), 1e-3 * max(float(x.abs().max()) for x in ref_grads))
         assert abs(na.item() - ref_norm.item()) < 2e-3 * ref_norm.item()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# G18: the engine against a full optimisation step WRITTEN BY THE REFERENCE (tools/make_golden_g18.py) — no oracle in between
+# ---------------------------------------------------------------------------------------------------------------------
+def _load_reference_student(eng, sd):
+    """DINOv2-ViT state dict of the reference (vggt/layers/vision_transformer.py key layout) -> GDViT, through the wrappers."""
+    m = eng.model
+    with torch.no_grad():
+        m.cls_token.copy_(sd["cls_token"])
+        m.pos_embed.copy_(sd["pos_embed"])
+        m.patch_embed.proj.weight.copy_(sd["patch_embed.proj.weight"])
+        m.patch_embed.proj.bias.copy_(sd["patch_embed.proj.bias"])
+        m.norm.weight.copy_(sd["norm.weight"])
+        m.norm.bias.copy_(sd["norm.bias"])
+        for i, blk in enumerate(m.blocks):
+            inner = blk.block if hasattr(blk, "adapter") else blk
+            q = inner.attn.qkv.qkv if hasattr(inner.attn.qkv, "linear_a_q") else inner.attn.qkv
+            pre = f"blocks.{i}."
+            for mod, name in ((inner.norm1, "norm1"), (inner.norm2, "norm2"), (q, "attn.qkv"), (inner.attn.proj, "attn.proj"),
+                              (inner.mlp.fc1, "mlp.fc1"), (inner.mlp.fc2, "mlp.fc2")):
+                mod.weight.copy_(sd[pre + name + ".weight"])
+                mod.bias.copy_(sd[pre + name + ".bias"])
+            inner.ls1.gamma.copy_(sd[pre + "ls1.gamma"])
+            inner.ls2.gamma.copy_(sd[pre + "ls2.gamma"])
+
+
+@pytest.mark.parametrize("variant", ["vggt", "mast3r"])
+@pytest.mark.parametrize("dtype,tol,utol", [("f32", 1e-4, 5e-3), ("bf16", 1e-2, 0.5)])
+def test_full_step_written_by_the_reference_g18(variant, dtype, tol, utol):
+    from conftest import load_golden
+    from gd_amd.finetune import FinetuneGD
+    from gd_testutil import g18_unpack
+    g = load_golden(f"g18_full_step_{variant}")
+    sd, before, after, grads, pairs = g18_unpack(g)
+    eng = FinetuneGD(r=4, variant=variant, geometry="reference", dtype=dtype, adapter_start_idx=4,
+                     bottleneck_dim=int(g["cfg_bottleneck"]), vit_kwargs=dict(init_values=1.0), teacher_patch=14,
+                     depth_loss_weight=1.0 if variant == "vggt" else 0.0, **TINY)
+    eng.target_res, eng.downsample_factor = int(g["cfg_target_res"]), int(g["cfg_downsample_factor"])
+    _load_reference_student(eng, sd)
+    ps = eng.trainable_parameters()
+    assert len(ps) == len(before)
+    with torch.no_grad():
+        for p_, b_ in zip(ps, before):
+            assert p_.shape == b_.shape
+            p_.copy_(b_)
+    eng = eng.cuda()
+    # the two pairs as one ragged batch
+    P, N = len(pairs), max(t["kp_1"].shape[1] for t in pairs)
+    H, W = pairs[0]["rgb_1"].shape[-2:]
+    kp = lambda k: torch.stack([torch.cat([t[k][0], -torch.ones(N - t[k].shape[1], 2)]) for t in pairs])
+    pts = lambda pm, k: torch.stack([torch.cat([t[pm][t[k][0, :, 1].long(), t[k][0, :, 0].long()],
+                                                torch.zeros(N - t[k].shape[1], 3)]) for t in pairs])
+    batch = {"rgb_1": torch.cat([t["rgb_1"] for t in pairs]), "rgb_2": torch.cat([t["rgb_2"] for t in pairs]),
+             "kp_1": kp("kp_1"), "kp_2": kp("kp_2"), "counts": torch.tensor([t["kp_1"].shape[1] for t in pairs], dtype=torch.int32),
+             "pts3d_1": pts("pm_1", "kp_1"), "pts3d_2": pts("pm_2", "kp_2"),
+             "depth_1": torch.stack([t["depth_1"] for t in pairs]), "depth_2": torch.stack([t["depth_2"] for t in pairs]),
+             "cost_1": torch.cat([t["cost_1"] for t in pairs]), "cost_2": torch.cat([t["cost_2"] for t in pairs]),
+             "mask_1": torch.stack([t["mask_1"] for t in pairs]), "mask_2": torch.stack([t["mask_2"] for t in pairs])}
+    batch = {k: v.cuda() for k, v in batch.items()}
+    eng.configure_optimizers()
+    loss, terms, norm = eng.fit_step(batch)
+    assert abs(loss.item() - float(g["loss"])) < tol * abs(float(g["loss"])), (loss.item(), float(g["loss"]))
+    for q, t in enumerate(pairs):
+        for name, key in (("ap_loss", "term_ap"), ("depth_loss", "term_depth"), ("intra_depth_loss", "term_intra"), ("kl_loss", "term_kl")):
+            ref = float(t[key])
+            assert abs(terms[name][q].item() - ref) < tol * max(abs(ref), 1e-3), (q, name, terms[name][q].item(), ref)
+    assert abs(float(norm) - float(g["clip_norm"])) < max(tol, 1e-3) * float(g["clip_norm"])
+    live = {int(i) for i in g["n_live"]}
+    for i, (p_, a1, b0) in enumerate(zip(eng.trainable_parameters(), after, before)):
+        got = p_.detach().float().cpu()
+        if i not in live:
+            assert torch.equal(got, b0), i            # never-used parameters: untouched, as torch.optim.AdamW leaves them
+            continue
+        da, db = (got - b0).double(), (a1 - b0).double()
+        assert (da - db).norm() <= utol * db.norm() + 1e-12, (i, ((da - db).norm() / db.norm()).item())

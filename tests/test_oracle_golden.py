@@ -197,3 +197,35 @@ def test_g16b_filter_and_match_oracle():
     o1, o2 = O.reciprocal_nns(d1, d2, subsample=16)
     k1, k2 = O.mast3r_keypoint_filter(o1, o2, c1, c2)
     assert torch.equal(k1[0], g["kp1"]) and torch.equal(k2[0], g["kp2"])
+
+
+def test_full_optimisation_step_g18():
+    """G18: the reference's own training_step (both trainers) + clip_grad_norm_ + its configure_optimizers' AdamW on two
+    pairs; the oracle reproduces every loss term, the gradients, the clip norm and the updated weights."""
+    import pytest
+    from gd_testutil import g18_oracle_inputs, g18_pair_batch, g18_unpack
+    for variant in ("vggt", "mast3r"):
+        g = load_golden(f"g18_full_step_{variant}")
+        sd, before, after, grads, pairs = g18_unpack(g)
+        tr, refine, hp, leaves, cfg = g18_oracle_inputs(before, variant, g)
+        w = {"ap": 1.0, "depth": 1.0 if variant == "vggt" else 0.0, "intra": 1.0, "kl": 1.0}
+        total = 0
+        for t in pairs:
+            terms = O.pair_losses(g18_pair_batch(t), sd, cfg, tr, refine, hp)
+            for k in ("ap", "depth", "intra", "kl"):
+                assert terms[k].item() == pytest.approx(float(t[f"term_{k}"]), rel=2e-5), (variant, k)
+            total = total + O.total_loss(terms, w) / len(pairs)
+        assert total.item() == pytest.approx(float(g["loss"]), rel=2e-5)
+        total.backward()
+        og = [x.grad if x.grad is not None else torch.zeros_like(x) for x in leaves]
+        for i, (a, b) in enumerate(zip(og, grads)):
+            if b.abs().max() > 0:
+                assert rel_err(a, b) < 5e-4, (variant, i)
+        live = [int(i) for i in g["n_live"]]
+        params = [x.detach().clone() for x in leaves]
+        state = [(torch.zeros_like(x), torch.zeros_like(x)) for x in params]
+        norm = O.clip_and_adamw([params[i] for i in live], [og[i] for i in live], [state[i] for i in live], 1)
+        assert norm.item() == pytest.approx(float(g["clip_norm"]), rel=2e-5)
+        for i, (p1, a1, b0) in enumerate(zip(params, after, before)):
+            da, db = (p1 - b0).double(), (a1 - b0).double()
+            assert (da - db).norm() <= 2e-3 * db.norm() + 1e-12, (variant, i)
