@@ -102,6 +102,14 @@ SIGNATURES = {
                                       c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gd_cost_volume_kl_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
                                       c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gd_pil_resample_ksize": (c_int, [c_int, c_int]),
+    "gd_pil_resample_coeffs": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "gd_pil_resize_bicubic_u8": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                         c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "gd_u8_to_chw_float": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
+                                   c_void_p]),
+    "gd_color_jitter_u8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gd_gaussian_blur_u8": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
 }
 
 

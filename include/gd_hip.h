@@ -264,6 +264,33 @@ int gd_cross_view_attn(const void* q, const void* k, float* out, int B, int H, i
 int gd_mast3r_attn_target(const float* recip_scores, int L, int B, int N1, int N2, float temperature, float* out,
                           float* workspace, void* stream);
 
+/* ---- input pipeline on device ------------------------------------------------------------------------
+ * vggt/utils/load_fn.py:12-146 `load_and_preprocess_images` after the file decode: PIL Image.resize(..., BICUBIC) on uint8
+ * RGB (:87), ToTensor (:88), centre crop (:91-93) / white padding (:96-111, :121-139).  The resampler is Pillow's
+ * (src/libImaging/Resample.c; third-party, restated): gd_pil_resample_ksize / gd_pil_resample_coeffs compute its
+ * per-output-pixel window start, tap count and 22-bit fixed-point coefficients on the HOST (xmin, count: [out_size];
+ * coeffs: [out_size * ksize]); gd_pil_resize_bicubic_u8 runs the horizontal then the vertical pass on the DEVICE
+ * (src [H,W,C] uint8, tmp [H,new_w,C] uint8, dst [new_h,new_w,C] uint8; the coefficient arrays are device pointers);
+ * bit-exact against Pillow (fixture G20). */
+int gd_pil_resample_ksize(int in_size, int out_size);
+int gd_pil_resample_coeffs(int in_size, int out_size, int* xmin_out, int* count_out, int* coeffs_out);
+int gd_pil_resize_bicubic_u8(const unsigned char* src, unsigned char* tmp, unsigned char* dst, int H, int W, int C,
+                             int new_h, int new_w, const int* xmin_h, const int* count_h, const int* coeffs_h,
+                             int ksize_h, const int* xmin_v, const int* count_v, const int* coeffs_v, int ksize_v,
+                             void* stream);
+/* dst[c][y][x] (float32 CHW canvas H x W) = src[y - pad_top + crop_y0][x - pad_left][c] / 255 inside the crop_h x w window,
+ * `fill` outside (load_fn.py:88-111,121-139). */
+int gd_u8_to_chw_float(const unsigned char* src, float* dst, int h, int w, int C, int crop_y0, int crop_h, int pad_top,
+                       int pad_left, int H, int W, float fill, void* stream);
+/* data_utils/dataset_mast3r_scannetpp.py:185-207 colour augmentation on uint8 RGB [n,H,W,3]: albumentations ColorJitter
+ * (factors [n][4] = brightness, contrast, saturation, hue; order [n][4] = permutation of 0..3, -1 = skip; gray_sum_ws: n
+ * uint64) and GaussianBlur (ksize [n] in {0,3,5,7}; tmp: n*H*W*3 floats).  albumentations / OpenCV are absent: restated from
+ * their published definitions, PARITY UNPINNED. */
+int gd_color_jitter_u8(const unsigned char* src, unsigned char* dst, int n, int H, int W, const float* factors,
+                       const int* order, unsigned long long* gray_sum_ws, void* stream);
+int gd_gaussian_blur_u8(const unsigned char* src, float* tmp, unsigned char* dst, int n, int H, int W, const int* ksize,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

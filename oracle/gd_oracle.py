@@ -714,3 +714,210 @@ def mast3r_tgt_attn_map(tgt_camaps, src_camaps, temperature=3.0, reciprocity=Tru
         m[:, :, 0] = m.min()
         out.append(m)
     return torch.stack(out, dim=1).mean(dim=1)
+
+
+# ----------------------------------------------------------------------------------
+# input pipeline: load_and_preprocess_images after the file decode
+# ----------------------------------------------------------------------------------
+# vggt/utils/load_fn.py:12-146 resizes with PIL's Image.resize(..., BICUBIC) on uint8 RGB.  Pillow is a third-party
+# dependency (requirements.txt pins pillow; 12.2.0 in the build image); its resampler (src/libImaging/Resample.c) is
+# restated here from the published algorithm: separable convolution, horizontal pass then vertical pass with a uint8
+# intermediate, support = 2 * max(scale, 1) (antialiasing when shrinking), Keys cubic a = -0.5, per-output coefficients
+# normalised in double precision, quantised to 22-bit fixed point, integer accumulation from 1 << 21, >> 22, clip to [0,255].
+# Pinned by fixture G20: the reference's load_and_preprocess_images itself, run on synthetic image files.
+_PIL_PRECISION_BITS = 32 - 8 - 2
+
+
+def _pil_bicubic(x):
+    a = -0.5
+    x = abs(x)
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+def pil_resample_coeffs(in_size, out_size):
+    """-> (xmin int32 [out], count int32 [out], coeffs int32 [out, ksize]) of Resample.c precompute_coeffs + normalize_coeffs_8bpc."""
+    import numpy as np
+    scale = filterscale = in_size / out_size
+    if filterscale < 1.0:
+        filterscale = 1.0
+    support = 2.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    xmin_a = np.zeros(out_size, np.int32)
+    cnt_a = np.zeros(out_size, np.int32)
+    kk = np.zeros((out_size, ksize), np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = int(center - support + 0.5)
+        if xmin < 0:
+            xmin = 0
+        xmax = int(center + support + 0.5)
+        if xmax > in_size:
+            xmax = in_size
+        xmax -= xmin
+        w = [_pil_bicubic((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+        ww = 0.0
+        for v in w:
+            ww += v
+        for x in range(xmax):
+            v = w[x] / ww if ww != 0.0 else w[x]
+            kk[xx, x] = int(-0.5 + v * (1 << _PIL_PRECISION_BITS)) if v < 0 else int(0.5 + v * (1 << _PIL_PRECISION_BITS))
+        xmin_a[xx], cnt_a[xx] = xmin, xmax
+    return xmin_a, cnt_a, kk
+
+
+def pil_resize_bicubic_u8(img, new_w, new_h):
+    """img uint8 [H, W, C] (numpy) -> uint8 [new_h, new_w, C]: PIL Image.resize((new_w, new_h), BICUBIC)."""
+    import numpy as np
+    img = np.asarray(img)
+    H, W, C = img.shape
+
+    def one_pass(src, in_size, out_size):          # along axis 1 of src [R, in_size, C]
+        xmin, cnt, kk = pil_resample_coeffs(in_size, out_size)
+        out = np.empty((src.shape[0], out_size, src.shape[2]), np.uint8)
+        s64 = src.astype(np.int64)
+        for xx in range(out_size):
+            acc = np.full((src.shape[0], src.shape[2]), 1 << (_PIL_PRECISION_BITS - 1), np.int64)
+            for x in range(cnt[xx]):
+                acc += s64[:, xmin[xx] + x, :] * int(kk[xx, x])
+            out[:, xx, :] = np.clip(acc >> _PIL_PRECISION_BITS, 0, 255).astype(np.uint8)
+        return out
+    if new_w != W:
+        img = one_pass(img, W, new_w)
+    if new_h != H:
+        img = one_pass(img.transpose(1, 0, 2), H, new_h).transpose(1, 0, 2)
+    return np.ascontiguousarray(img)
+
+
+def load_fn_geometry(width, height, mode="crop", target_size=518):
+    """vggt/utils/load_fn.py:70-84: (new_width, new_height) of the resize."""
+    if mode == "pad":
+        if width >= height:
+            new_width = target_size
+            new_height = round(height * (new_width / width) / 14) * 14
+        else:
+            new_height = target_size
+            new_width = round(width * (new_height / height) / 14) * 14
+    else:
+        new_width = target_size
+        new_height = round(height * (new_width / width) / 14) * 14
+    return new_width, new_height
+
+
+def preprocess_images(images_u8, mode="crop", target_size=518):
+    """vggt/utils/load_fn.py:12-146 after the decode: list of uint8 RGB arrays [H, W, 3] -> float32 [N, 3, H', W'] in [0, 1]
+    (bicubic resize to width 518 / longest side 518 with sides divisible by 14, ToTensor, centre crop of the height (crop mode)
+    or white padding to a square (pad mode), white padding to a common shape)."""
+    import numpy as np
+    if len(images_u8) == 0:
+        raise ValueError("At least 1 image is required")
+    if mode not in ["crop", "pad"]:
+        raise ValueError("Mode must be either 'crop' or 'pad'")
+    out = []
+    for im in images_u8:
+        h, w = im.shape[:2]
+        nw, nh = load_fn_geometry(w, h, mode, target_size)
+        t = torch.from_numpy(pil_resize_bicubic_u8(im, nw, nh)).permute(2, 0, 1).float() / 255.0
+        if mode == "crop" and nh > target_size:
+            sy = (nh - target_size) // 2
+            t = t[:, sy:sy + target_size, :]
+        if mode == "pad":
+            hp, wp = target_size - t.shape[1], target_size - t.shape[2]
+            if hp > 0 or wp > 0:
+                t = torch.nn.functional.pad(t, (wp // 2, wp - wp // 2, hp // 2, hp - hp // 2), value=1.0)
+        out.append(t)
+    mh, mw = max(t.shape[1] for t in out), max(t.shape[2] for t in out)
+    res = []
+    for t in out:
+        hp, wp = mh - t.shape[1], mw - t.shape[2]
+        if hp > 0 or wp > 0:
+            t = torch.nn.functional.pad(t, (wp // 2, wp - wp // 2, hp // 2, hp - hp // 2), value=1.0)
+        res.append(t)
+    return torch.stack(res)
+
+
+# colour augmentation (data_utils/dataset_mast3r_scannetpp.py:185-207).  albumentations (ColorJitter, GaussianBlur) and the
+# OpenCV routines under it are third-party and absent here: restated from their published definitions — PARITY UNPINNED.
+def _cv_gray(r, g, b):
+    return (r * 4899 + g * 9617 + b * 1868 + 8192) >> 14
+
+
+def color_jitter_u8(img, factors, order):
+    """img uint8 [H, W, 3] (numpy); factors (brightness, contrast, saturation, hue); order: permutation of 0..3, -1 = skip.
+    float32 arithmetic in the kernel's operation order (csrc/image_prep.hip jitter_op)."""
+    import numpy as np
+    f32 = np.float32
+    r, g, b = (img[..., c].astype(np.int32) for c in range(3))
+    clip_t = lambda v: np.clip(v, f32(0), f32(255)).astype(np.int32)
+    clip_r = lambda v: np.clip(np.rint(v), f32(0), f32(255)).astype(np.int32)
+    for op in order:
+        if op < 0:
+            continue
+        f = f32(factors[op])
+        if op == 0:
+            r, g, b = (clip_t(c.astype(f32) * f) for c in (r, g, b))
+        elif op == 1:
+            mean = f32(np.float64(_cv_gray(r, g, b).astype(np.uint64).sum()) / np.float64(r.size))
+            o = f32(mean * f32(f32(1) - f))
+            r, g, b = (clip_t(f32(c.astype(f32) * f) + o) for c in (r, g, b))
+        elif op == 2:
+            gy = (_cv_gray(r, g, b).astype(f32) * f32(f32(1) - f)).astype(f32)
+            r, g, b = (clip_r((c.astype(f32) * f).astype(f32) + gy) for c in (r, g, b))
+        else:
+            fr, fg, fb = r.astype(f32), g.astype(f32), b.astype(f32)
+            v = np.maximum(fr, np.maximum(fg, fb))
+            mn = np.minimum(fr, np.minimum(fg, fb))
+            d = (v - mn).astype(f32)
+            ds = np.where(d > 0, d, f32(1))
+            h = np.where(v == fr, (fg - fb) / ds, np.where(v == fg, f32(2) + (fb - fr) / ds, f32(4) + (fr - fg) / ds)).astype(f32)
+            h = (h * f32(30)).astype(f32)
+            h = np.where(h < 0, h + f32(180), h).astype(f32)
+            h = np.where(d > 0, h, f32(0))
+            s = np.where(v > 0, d / np.where(v > 0, v, f32(1)), f32(0)).astype(f32)
+            hi8 = np.rint(h).astype(np.int32)
+            hi8 = np.where(hi8 >= 180, hi8 - 180, hi8)
+            hq = np.fmod(hi8.astype(f32) + f32(f32(180) * f), f32(180)).astype(np.int32)
+            hq = np.where(hq < 0, hq + 180, hq)
+            s8 = (np.rint(s * f32(255)) / f32(255)).astype(f32)
+            hh = (hq.astype(f32) / f32(30)).astype(f32)
+            sector = hh.astype(np.int32) % 6
+            fq = (hh - np.floor(hh)).astype(f32)
+            one = f32(1)
+            p = (v * (one - s8)).astype(f32)
+            q = (v * (one - (s8 * fq).astype(f32))).astype(f32)
+            t = (v * (one - (s8 * (one - fq).astype(f32)).astype(f32))).astype(f32)
+            R = np.choose(sector, [v, q, p, p, t, v])
+            G = np.choose(sector, [t, v, v, q, p, p])
+            B = np.choose(sector, [p, p, t, v, v, q])
+            r, g, b = clip_r(R), clip_r(G), clip_r(B)
+    return np.stack([r, g, b], -1).astype(np.uint8)
+
+
+def gaussian_blur_u8(img, k):
+    """cv2.GaussianBlur(img, (k, k), 0) restated: sigma = 0.3 ((k-1)/2 - 1) + 0.8, normalised, BORDER_REFLECT_101, separable."""
+    import numpy as np
+    if k <= 1:
+        return img.copy()
+    f32 = np.float32
+    sigma = f32(0.3) * (f32(k - 1) * f32(0.5) - f32(1)) + f32(0.8)
+    half = k // 2
+    w = np.exp(-(np.arange(-half, half + 1).astype(f32) ** 2) / (f32(2) * sigma * sigma)).astype(f32)
+
+    def one(a, axis):
+        a = np.moveaxis(a, axis, 0)
+        n = a.shape[0]
+        acc, ws = np.zeros_like(a, dtype=f32), f32(0)
+        for j in range(-half, half + 1):
+            idx = np.arange(n) + j
+            idx = np.where(idx < 0, -idx, idx)
+            idx = np.where(idx >= n, 2 * n - 2 - idx, idx)
+            acc = (acc + w[j + half] * a[idx]).astype(f32)
+            ws = f32(ws + w[j + half])
+        return np.moveaxis((acc / ws).astype(f32), 0, axis)
+    t = one(img.astype(f32), 1)
+    t = one(t, 0)
+    return np.clip(np.rint(t), 0, 255).astype(np.uint8)

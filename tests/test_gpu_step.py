@@ -432,7 +432,8 @@ def test_full_step_written_by_the_reference_g18(variant, dtype, tol, utol):
         for name, key in (("ap_loss", "term_ap"), ("depth_loss", "term_depth"), ("intra_depth_loss", "term_intra"), ("kl_loss", "term_kl")):
             ref = float(t[key])
             assert abs(terms[name][q].item() - ref) < tol * max(abs(ref), 1e-3), (q, name, terms[name][q].item(), ref)
-    assert abs(float(norm) - float(g["clip_norm"])) < max(tol, 1e-3) * float(g["clip_norm"])
+    # bf16 on a 64-wide toy student: the gradient norm carries a few per cent of rounding noise (full-size: tests/test_gpu_fullsize.py)
+    assert abs(float(norm) - float(g["clip_norm"])) < (1e-3 if dtype == "f32" else 5e-2) * float(g["clip_norm"])
     live = {int(i) for i in g["n_live"]}
     for i, (p_, a1, b0) in enumerate(zip(eng.trainable_parameters(), after, before)):
         got = p_.detach().float().cpu()

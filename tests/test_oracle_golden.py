@@ -229,3 +229,13 @@ def test_full_optimisation_step_g18():
         for i, (p1, a1, b0) in enumerate(zip(params, after, before)):
             da, db = (p1 - b0).double(), (a1 - b0).double()
             assert (da - db).norm() <= 2e-3 * db.norm() + 1e-12, (variant, i)
+
+
+def test_load_fn_g20():
+    """G20: the reference's load_and_preprocess_images (PIL bicubic resize, ToTensor, crop / white padding) — the oracle's
+    integer restatement of Pillow's resampler is bit-exact."""
+    g = load_golden("g20_load_fn")
+    for mode in ("crop", "pad"):
+        ins = [g[f"{mode}.in{i}"].numpy() for i in range(2)]
+        out = O.preprocess_images(ins, mode=mode)
+        assert torch.equal(out, g[f"{mode}.out_u8"].float() / 255)

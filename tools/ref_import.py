@@ -106,7 +106,18 @@ def install():
             except Exception:
                 _stub(name)
     tvf = _stub("torchvision.transforms.functional", resize=_tv_resize)
-    tvt = _stub("torchvision.transforms", functional=tvf)
+
+    class _ToTensor:
+        """torchvision.transforms.ToTensor on a PIL RGB image: uint8 HWC -> float32 CHW / 255."""
+
+        def __call__(self, pic):
+            import numpy as np
+            a = np.asarray(pic, dtype=np.uint8)
+            if a.ndim == 2:
+                a = a[:, :, None]
+            return torch.from_numpy(a.copy()).permute(2, 0, 1).contiguous().to(torch.float32).div(255)
+
+    tvt = _stub("torchvision.transforms", functional=tvf, ToTensor=_ToTensor)
     _stub("torchvision", transforms=tvt)
     pl = _stub("pytorch_lightning", LightningModule=_LightningModule, Callback=object)
     pl.loggers = sys.modules["pytorch_lightning.loggers"]
