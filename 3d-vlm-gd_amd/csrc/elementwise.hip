@@ -505,6 +505,71 @@ extern "C" int gd_kp_gather_bwd(float* const* dgrids, int ngrid, long bstride, c
     return 0;
 }
 
+// refine_conv evaluated ONLY where it is sampled.  get_feature (src/finetune_timm_vggt.py:304-332) is
+// interpolate_features(refine_conv(grid))(kp): a 3x3 convolution followed by a bilinear sample — both linear, so
+//   feat[kp] = W . (sum_n w_n patch(pos_n)) + b :   interpolate the 3x3 INPUT patches of the four neighbours, then one GEMM over
+// B*Nk rows instead of B*gh*gw (19 200 against 87 616 at 518^2 / 300 keypoints; 6 400 tokens per image in the reference
+// geometry).  out[bk][(ky, kx, c)] = sum_{a,b} w_ab * tok[b][(y_a + ky - 1) * pitch + x_b + kx - 1][c], zero outside the grid
+// (conv padding 1), neighbours and weights exactly those of kp_gather_fwd (grid_sample, align_corners, border clamp).
+// One thread per 16-byte channel chunk: the 4 x 4 token block around the keypoint is read once, nine taps written.
+template <typename T, typename TO>
+__global__ __launch_bounds__(128) void kp_patch_gather_kernel(GatherParams p, TO* out) {
+    constexpr int V = 16 / sizeof(T);
+    const long bk = blockIdx.x;
+    const long b = bk / p.Nk;
+    int x0, y0, x1, y1; float wx, wy;
+    gather_coords(p, bk, x0, y0, x1, y1, wx, wy);
+    // a clamped neighbour (x1 == x0 or y1 == y0) has weight exactly 0 (wx resp. wy = 0), and the block entry read in its place
+    // is a finite value (a token or the zero padding): the four taps can always be read at offsets {0, 1}
+    const float w00 = (1.f - wx) * (1.f - wy), w01 = wx * (1.f - wy), w10 = (1.f - wx) * wy, w11 = wx * wy;
+    const T* g = (const T*)p.grid[0] + b * p.bstride;
+    for (int ch = threadIdx.x; ch * V < p.D; ch += 128) {
+        float t[4][4][V];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int yy = y0 - 1 + i, xx = x0 - 1 + j;
+                if (yy >= 0 && yy < p.gh && xx >= 0 && xx < p.gw) {
+                    const uint4 v = *(const uint4*)(g + ((long)yy * p.pitch + xx) * p.D + ch * V);
+                    const T* e = (const T*)&v;
+#pragma unroll
+                    for (int k = 0; k < V; ++k) t[i][j][k] = to_f32<T>(e[k]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < V; ++k) t[i][j][k] = 0.f;
+                }
+            }
+        TO* o = out + bk * 9 * p.D + ch * V;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                TO r[V];
+#pragma unroll
+                for (int k = 0; k < V; ++k)
+                    r[k] = from_f32<TO>(w00 * t[ky][kx][k] + w01 * t[ky][kx + 1][k] + w10 * t[ky + 1][kx][k] + w11 * t[ky + 1][kx + 1][k]);
+                *(uint4*)(o + (ky * 3 + kx) * p.D) = *(const uint4*)r;
+            }
+    }
+}
+
+extern "C" int gd_kp_patch_gather(const void* grid, long bstride, int grid_dtype, const float* kp, void* out, int B, int Nk,
+                                  int gh, int gw, int D, float sx, float sy, int img_h, int img_w, int patch, int stride,
+                                  int pitch, void* stream) {
+    GatherParams p = {};
+    const void* one[1] = {grid};
+    if (fill_gather(p, one, 1, bstride, grid_dtype, kp, B, Nk, gh, gw, D, sx, sy, img_h, img_w, patch, stride, pitch)) return -1;
+    GD_REQUIRE((D * gd_dtype_size(grid_dtype)) % 16 == 0 && ((uintptr_t)grid % 16) == 0 && ((uintptr_t)out % 16) == 0,
+               "gd_kp_patch_gather: token rows must be 16-byte multiples and 16-byte aligned");
+    if (grid_dtype == GD_BF16)
+        hipLaunchKernelGGL((kp_patch_gather_kernel<bf16, bf16>), dim3(B * Nk), dim3(128), 0, (hipStream_t)stream, p, (bf16*)out);
+    else
+        hipLaunchKernelGGL((kp_patch_gather_kernel<float, float>), dim3(B * Nk), dim3(128), 0, (hipStream_t)stream, p, (float*)out);
+    GD_LAUNCH_OK();
+    return 0;
+}
+
 extern "C" int gd_kp_depth(const float* depth, const float* kp, float* out, int B, int Nk, int H, int W, void* stream) {
     GD_REQUIRE(B > 0 && Nk > 0 && H > 0 && W > 0, "gd_kp_depth: bad shape");
     hipLaunchKernelGGL(kp_depth_kernel, dim3(gd_cdiv((long)B * Nk, 256)), dim3(256), 0, (hipStream_t)stream, depth, kp, out, B, Nk, H, W);

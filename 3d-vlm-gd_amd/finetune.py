@@ -21,7 +21,7 @@ import torch.nn.functional as F
 
 from . import ops
 from .model import Adapter, BlockWithAdapter, DepthAwareFeatureFusion, _LoRA_qkv
-from .vit import conv3x3_tokens, create_vit, kp_gather
+from .vit import conv3x3_at_keypoints, conv3x3_tokens, create_vit, kp_gather
 
 
 def _pair_batch(a, b):
@@ -307,11 +307,16 @@ class FinetuneGD(nn.Module):
         gh, gw = self._kp_grid(h, w)
         P = self.patch_size
         _, x = self._forward(rgbs, gh, gw)
-        fmap, pitch = conv3x3_tokens(self.model.norm(x), self.refine_conv.weight, self.refine_conv.bias, gh, gw)
         # the ME trainer passes h = patch_h * 14 and the default patch_size = stride = 14 whatever the model's patch is
         # (src/finetune_timm_me.py:155); the two teacher-driven trainers pass the model's patch (finetune_timm_vggt.py:325-327)
         Pi = 14 if self.variant == "me" else P
-        feat = kp_gather([fmap], pts, gh, gw, (gw * P) / w, (gh * P) / h, gh * Pi, gw * Pi, Pi, pitch=pitch)
+        xn = self.model.norm(x)
+        # conv and bilinear sample are both linear: mix the input patches first, convolve B*Nk rows instead of the whole grid
+        feat = conv3x3_at_keypoints(xn, self.refine_conv.weight, self.refine_conv.bias, pts, gh, gw, (gw * P) / w, (gh * P) / h,
+                                    gh * Pi, gw * Pi, Pi)
+        if feat is None:
+            fmap, pitch = conv3x3_tokens(xn, self.refine_conv.weight, self.refine_conv.bias, gh, gw)
+            feat = kp_gather([fmap], pts, gh, gw, (gw * P) / w, (gh * P) / h, gh * Pi, gw * Pi, Pi, pitch=pitch)
         return ops.l2_normalize(feat) if normalize else feat
 
     def get_feature_cost(self, rgbs):

@@ -389,6 +389,16 @@ def kp_gather_bwd(ngrid, kp, dout, B, Nk, gh, gw, D, sx, sy, img_h, img_w, patch
     return dg
 
 
+def kp_patch_gather(grid, bstride, kp, B, Nk, gh, gw, D, sx, sy, img_h, img_w, patch, stride=None, pitch=None):
+    """-> [B*Nk, 9*D] (grid dtype): the bilinear mix of the four neighbours' 3x3 input patches, K order (ky, kx, c) — the GEMM
+    operand of refine_conv evaluated at the keypoints only (gd_kp_patch_gather).  `grid` is addressed from its data_ptr."""
+    out = torch.empty(B * Nk, 9 * D, dtype=grid.dtype, device=grid.device)
+    check(lib().gd_kp_patch_gather(ptr(grid), bstride, dtype_code(grid), ptr(kp), ptr(out), B, Nk, gh, gw, D, float(sx), float(sy),
+                                   img_h, img_w, patch, patch if stride is None else stride, gw if pitch is None else pitch,
+                                   stream()), "gd_kp_patch_gather")
+    return out
+
+
 def stack3_rows(src, B, gh, gw, D, src_bstride, src_row0, src_pitch, dtype):
     """-> buf [B*gh*(gw+1) + 2, 3*D] of `dtype` (see gd_stack3_rows); `src` is addressed from its data_ptr."""
     buf = torch.empty(B * gh * (gw + 1) + 2, 3 * D, dtype=dtype, device=src.device)

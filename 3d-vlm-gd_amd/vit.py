@@ -626,6 +626,61 @@ class _Conv3x3StackedFn(torch.autograd.Function):
         return dtok, gweight, gbias, None, None
 
 
+class _ConvAtKpFn(torch.autograd.Function):
+    """get_feature's `interpolate_features(refine_conv(grid))(kp)` (src/finetune_timm_vggt.py:319-325) with the two linear maps
+    swapped: the 3x3 input patches of a keypoint's four neighbours are mixed with the bilinear weights FIRST
+    (gd_kp_patch_gather -> [B*Nk, 9D]) and the convolution is one GEMM over B*Nk rows instead of B*gh*gw (4.6x fewer at 518^2 with
+    300 keypoints, 21x in the reference geometry); the weight gradient contracts the same B*Nk rows, the bias gradient is the
+    column sum of the keypoint gradient (bilinear weights sum to one).  The input gradient still goes through the dense transposed
+    convolution (scatter to the grid, stacked-row GEMM against the flipped kernel): a 9-tap scatter of [B*Nk, 9D] would be 2 GB of
+    float atomics."""
+
+    @staticmethod
+    def forward(ctx, tok, weight, bias, kp, geom):
+        gh, gw, sx, sy, img_h, img_w, patch = geom
+        B, Nt, D = tok.shape
+        tok = tok.contiguous()
+        kp = kp.contiguous().float()
+        Nk = kp.shape[1]
+        T = tok.dtype
+        colp = ops.kp_patch_gather(tok[:, Nt - gh * gw:], Nt * D, kp, B, Nk, gh, gw, D, sx, sy, img_h, img_w, patch)
+        wk = weight.detach().permute(0, 2, 3, 1).reshape(D, 9 * D).to(T).contiguous()           # [n, (ky, kx, c)]
+        out = ops.gemm_nt(colp, wk, bias=bias.detach().float().contiguous(), out_dtype=torch.float32)
+        ctx.save_for_backward(colp, weight, kp)
+        ctx.meta = (geom, B, Nt, D, Nk)
+        return out.view(B, Nk, D)
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        colp, weight, kp = ctx.saved_tensors
+        (gh, gw, sx, sy, img_h, img_w, patch), B, Nt, D, Nk = ctx.meta
+        T = colp.dtype
+        dfe = dfeat.reshape(B * Nk, D).contiguous().float()
+        dft = dfe if T == torch.float32 else ops.cast(dfe, T)
+        gk = ops.gemm_tn(dft, colp)                                    # [Dout, (ky, kx, Din)]
+        gweight = gk.view(D, 3, 3, D).permute(0, 3, 1, 2).contiguous()
+        gbias = dfe.sum(0)
+        dtok = None
+        if ctx.needs_input_grad[0]:
+            rows = B * gh * (gw + 1)
+            dy = ops.kp_gather_bwd(1, kp, dfe.view(B, Nk, D), B, Nk, gh, gw, D, sx, sy, img_h, img_w, patch, pitch=gw + 1)[0]
+            sbuf = ops.stack3_rows(dy, B, gh, gw, D, gh * (gw + 1) * D, 0, gw + 1, T)
+            wt = weight.detach().flip(2, 3).permute(1, 3, 2, 0).reshape(D, 9 * D).to(T).contiguous()      # [ci, (kx, ky, n)]
+            dxp = ops.gemm_nt(ops.conv_view(sbuf, rows, D), wt)        # [rows, D] on the pitched grid
+            dtok = ops.unpitch_tokens(dxp, B, gh, gw, D, Nt - gh * gw)
+        return dtok, gweight, gbias, None, None
+
+
+def conv3x3_at_keypoints(tok, weight, bias, kp, gh, gw, sx, sy, img_h, img_w, patch):
+    """refine_conv (3x3, padding 1) of the token grid of tok [B, prefix + gh*gw, D], bilinearly sampled at kp [B, Nk, 2] (pixels)
+    -> [B, Nk, D] fp32, or None when the layout does not allow it (rows that are not 16-byte multiples; GD_CONV_AT_KP=0)."""
+    import os
+    es = 2 if tok.dtype == torch.bfloat16 else 4
+    if os.environ.get("GD_CONV_AT_KP", "1") == "0" or (tok.shape[-1] * es) % 16 != 0:
+        return None
+    return _ConvAtKpFn.apply(tok, weight, bias, kp, (gh, gw, float(sx), float(sy), int(img_h), int(img_w), int(patch)))
+
+
 def conv3x3_tokens(tok, weight, bias, gh, gw):
     """refine_conv (3x3, padding 1) on the token grid of tok [B, prefix + gh*gw, D].  -> (fmap, pitch): fmap [B, gh*pitch, D] fp32
     with pitch = gw + 1 (separator-column layout, the default) or gw (im2col path: GD_CONV_STACKED=0, or D rows that are not

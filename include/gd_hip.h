@@ -123,6 +123,13 @@ int gd_kp_gather_fwd(const void* const* grids, int ngrid, long bstride, int grid
 int gd_kp_gather_bwd(float* const* dgrids, int ngrid, long bstride, const float* kp, const float* dout, int B, int Nk,
                      int gh, int gw, int D, float sx, float sy, int img_h, int img_w, int patch, int stride, int pitch,
                      void* stream);
+/* get_feature's refine_conv + interpolate_features (src/finetune_timm_vggt.py:319-325) with the two linear maps swapped:
+ * out[b*Nk + k][(ky, kx, c)] = bilinear mix (the same four neighbours and weights as gd_kp_gather_fwd) of the 3x3 input patches
+ * (zero padding 1) of ONE token grid [gh x pitch, D] -> [B*Nk, 9*D] in the grid's dtype; the conv is then a GEMM over B*Nk rows
+ * against the weight packed as [D_out, (ky, kx, c)].  D*elsize must be a multiple of 16 bytes. */
+int gd_kp_patch_gather(const void* grid, long bstride, int grid_dtype, const float* kp, void* out, int B, int Nk, int gh,
+                       int gw, int D, float sx, float sy, int img_h, int img_w, int patch, int stride, int pitch,
+                       void* stream);
 /* extract_kp_depth (utils/functions.py:348-372) and get_patch_mask_from_kp_tensor (:375-399; mask pre-zeroed). */
 int gd_kp_depth(const float* depth, const float* kp, float* out, int B, int Nk, int H, int W, void* stream);
 int gd_patch_mask(const float* kp, unsigned char* mask, int B, int Nk, int H, int W, int P, void* stream);

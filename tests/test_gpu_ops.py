@@ -123,6 +123,40 @@ def test_conv3x3_stacked_implicit_gemm(dtype, tol, B, gh, gw, D, prefix):
     assert rel_err(w.grad, wr.grad) < 2 * tol and rel_err(bias.grad, br.grad) < 2 * tol
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("B,gh,gw,D,prefix,sxy", [(2, 5, 7, 64, 1, (1.0, 1.0)), (3, 37, 37, 128, 1, (1.0, 1.0)), (1, 4, 9, 32, 0, (1.7, 2.1))])
+def test_conv3x3_at_keypoints(dtype, tol, B, gh, gw, D, prefix, sxy):
+    """get_feature's conv + bilinear sample with the two linear maps swapped (gd_kp_patch_gather + a GEMM over B*Nk rows):
+    forward and all three gradients against F.conv2d + the oracle's interpolate_features in fp64; keypoints on the border, outside
+    the image and the -1 padding of ragged batches included."""
+    from gd_amd.vit import conv3x3_at_keypoints
+    tok = torch.randn(B, prefix + gh * gw, D, generator=_g(12), device="cuda").to(dtype).requires_grad_(True)
+    w = (torch.randn(D, D, 3, 3, generator=_g(13), device="cuda") * 0.05).requires_grad_(True)
+    bias = torch.randn(D, generator=_g(14), device="cuda").requires_grad_(True)
+    P = 14
+    sx, sy = sxy
+    kp = torch.rand(B, 13, 2, generator=_g(15), device="cuda") * torch.tensor([gw * P / sx - 1.0, gh * P / sy - 1.0], device="cuda")
+    kp[:, 0] = 0.0                                                   # corner
+    kp[:, 1] = torch.tensor([gw * P / sx - 1.0, gh * P / sy - 1.0])   # opposite corner (clamped neighbours)
+    kp[:, 2] = torch.tensor([gw * P / sx + 40.0, -25.0])             # outside the image: border clamp
+    kp[:, 3] = -1.0                                                  # ragged-batch padding
+    samp = conv3x3_at_keypoints(tok, w, bias, kp, gh, gw, sx, sy, gh * P, gw * P, P)
+    assert samp is not None and samp.shape == (B, 13, D) and samp.dtype == torch.float32
+    x = tok.detach().cpu()[:, prefix:].double().reshape(B, gh, gw, D).permute(0, 3, 1, 2).requires_grad_(True)
+    wr, br = w.detach().cpu().double().requires_grad_(True), bias.detach().cpu().double().requires_grad_(True)
+    ref = F.conv2d(x, wr, br, padding=1)
+    kps = kp.cpu().double() * torch.tensor([sx, sy], dtype=torch.float64)
+    rs = O.interpolate_features(ref, kps, gh * P, gw * P, False, P, P).permute(0, 2, 1)
+    assert rel_err(samp, rs) < tol
+    ws = torch.randn(samp.shape, generator=_g(17), device="cuda")
+    (samp * ws).sum().backward()
+    (rs * ws.cpu().double()).sum().backward()
+    assert rel_err(tok.grad[:, prefix:].reshape(B, gh, gw, D).permute(0, 3, 1, 2), x.grad) < 2 * tol
+    if prefix:
+        assert float(tok.grad[:, :prefix].abs().max()) == 0.0
+    assert rel_err(w.grad, wr.grad) < 2 * tol and rel_err(bias.grad, br.grad) < 2 * tol
+
+
 @pytest.mark.parametrize("P", [14, 16])
 def test_kp_gather_golden(P):
     from gd_amd import ops
