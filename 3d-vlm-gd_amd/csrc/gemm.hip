@@ -836,8 +836,10 @@ extern "C" int gd_gemm_tn(const void* Y, const void* X, float* G, int M, int N, 
     const bool bf = y_dtype == GD_BF16 && x_dtype == GD_BF16 && N >= 64 && K >= 64;   // bf16 MFMA + transpose reads
     const int tl = bf ? 128 : 64;
     const int tiles = gd_cdiv(N, tl) * gd_cdiv(K, tl);
-    // enough M-chunks to fill the chip without shredding the reduction
-    int splits = ((bf ? 1024 : 2048) + tiles * batch - 1) / (tiles * batch);
+    // enough M-chunks to fill the chip without shredding the reduction (every chunk ends in N x K fp32 atomics: at 87 680 x 768 x 64
+    // 768 blocks measured 40-43 us, 1024: 47-48, 2048: 62, 256: 53)
+    static const int tn_blocks = [] { const char* e = getenv("GD_TN_BLOCKS"); return e ? atoi(e) : 0; }();   // A/B knob: target block count
+    int splits = ((tn_blocks > 0 ? tn_blocks : (bf ? 768 : 2048)) + tiles * batch - 1) / (tiles * batch);
     int mchunk = ((gd_cdiv(M, splits) + 63) / 64) * 64;
     if (mchunk < 256) mchunk = 256;
     p.mchunk = mchunk;

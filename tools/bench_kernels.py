@@ -159,9 +159,9 @@ def bench_cva():
 
 
 def bench_tn():
-    M = 87680
-    for (N, K, ydt, xdt) in [(8, 2304, torch.float32, torch.bfloat16), (8, 768, torch.float32, torch.bfloat16),
-                             (768, 64, torch.bfloat16, torch.bfloat16), (64, 768, torch.bfloat16, torch.bfloat16)]:
+    for (M, N, K, ydt, xdt) in [(87680, 8, 2304, torch.float32, torch.bfloat16), (87680, 8, 768, torch.float32, torch.bfloat16),
+                                (87680, 768, 64, torch.bfloat16, torch.bfloat16), (87680, 64, 768, torch.bfloat16, torch.bfloat16),
+                                (19200, 768, 6912, torch.bfloat16, torch.bfloat16)]:
         y = torch.randn(M, N, device="cuda").to(ydt)
         x = torch.randn(M, K, device="cuda").to(xdt)
         out = torch.zeros(N, K, device="cuda")
@@ -170,7 +170,7 @@ def bench_tn():
         ref = y.double().t() @ x.double()
         got = ops.gemm_tn(y, x)
         err = float((got.double() - ref).norm() / ref.norm())
-        print(f"gemm_tn N={N:4d} K={K:5d}: {t*1e6:8.1f} us  {by/t/1e12:5.2f} TB/s  rel err {err:.2e}")
+        print(f"gemm_tn M={M} N={N:4d} K={K:5d}: {t*1e6:8.1f} us  {by/t/1e12:5.2f} TB/s  rel err {err:.2e}")
 
 
 def bench_rank():
