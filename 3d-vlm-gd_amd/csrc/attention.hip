@@ -611,7 +611,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const T* qkv, const
 
 // ------------------------------------------------------------------------------------------ backward: dK, dV
 template <typename T, int NW>
-__global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const T* qkv, const T* dout, const float* lse,
+__global__ __launch_bounds__(64 * NW, 512 / (64 * NW)) void attn_bwd_dkv_kernel(const T* qkv, const T* dout, const float* lse,
                                                            const float* delta, T* dqkv, int N, int H, float scale, int vfirst) {
     constexpr int NF = AT<T>::NF, ROWB = AT<T>::ROWB;
     typedef typename Mma<T>::Frag Frag;
@@ -958,6 +958,12 @@ extern "C" int gd_attention_bwd(const void* qkv, const void* o, const void* dout
     dim3 grid(gd_cdiv(N, 128), H, B);
     if (dtype == GD_BF16) {
         hipLaunchKernelGGL(attn_bwd_dq_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)qkv, (const bf16*)o, (const bf16*)dout, lse, delta_ws, (bf16*)dqkv, N, H, scale);
+        // GD_ATTN_DKV_NW=4: 128-key blocks of four waves, two blocks per CU (independent barriers, 2.7 % instead of 10.8 % key padding at
+        // N = 1370, Q / dO tiles staged twice as often)
+        static const int dkv_nw = [] { const char* e = getenv("GD_ATTN_DKV_NW"); return e ? atoi(e) : 8; }();
+        if (dkv_nw == 4)
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<bf16, 4>), dim3(gd_cdiv(N, 128), H, B), dim3(256), 0, s, (const bf16*)qkv, (const bf16*)dout, lse, delta_ws, (bf16*)dqkv, N, H, scale, grad_order);
+        else
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<bf16, 8>), dim3(gd_cdiv(N, 256), H, B), dim3(512), 0, s, (const bf16*)qkv, (const bf16*)dout, lse, delta_ws, (bf16*)dqkv, N, H, scale, grad_order);
     } else {
         hipLaunchKernelGGL(attn_bwd_dq_kernel<float>, grid, dim3(256), 0, s, (const float*)qkv, (const float*)o, (const float*)dout, lse, delta_ws, (float*)dqkv, N, H, scale);
