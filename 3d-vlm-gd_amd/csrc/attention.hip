@@ -958,9 +958,13 @@ extern "C" int gd_attention_bwd(const void* qkv, const void* o, const void* dout
     dim3 grid(gd_cdiv(N, 128), H, B);
     if (dtype == GD_BF16) {
         hipLaunchKernelGGL(attn_bwd_dq_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)qkv, (const bf16*)o, (const bf16*)dout, lse, delta_ws, (bf16*)dqkv, N, H, scale);
-        // GD_ATTN_DKV_NW=4: 128-key blocks of four waves, two blocks per CU (independent barriers, 2.7 % instead of 10.8 % key padding at
-        // N = 1370, Q / dO tiles staged twice as often)
-        static const int dkv_nw = [] { const char* e = getenv("GD_ATTN_DKV_NW"); return e ? atoi(e) : 8; }();
+        // 128-key blocks of four waves (two blocks per CU, independent barriers, Q / dO tiles staged twice as often) when the last
+        // 256-key block would be less than half full: N = 1370 pads to 1408 keys instead of 1536 (2.7 % instead of 10.8 %):
+        // backward 1574 -> 1514 us at 64 x 12 x 1370; at N = 6401 (long sweeps, 0.4 % vs 2 % padding) the 8-wave form is 2 % faster.
+        // GD_ATTN_DKV_NW = 4 | 8 forces one form.
+        static const int dkv_env = [] { const char* e = getenv("GD_ATTN_DKV_NW"); return e ? atoi(e) : 0; }();
+        const int tail = N % 256;
+        const int dkv_nw = dkv_env ? dkv_env : ((N < 4096 && tail > 0 && tail <= 128) ? 4 : 8);
         if (dkv_nw == 4)
             hipLaunchKernelGGL((attn_bwd_dkv_kernel<bf16, 4>), dim3(gd_cdiv(N, 128), H, B), dim3(256), 0, s, (const bf16*)qkv, (const bf16*)dout, lse, delta_ws, (bf16*)dqkv, N, H, scale, grad_order);
         else
