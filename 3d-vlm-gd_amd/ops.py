@@ -389,6 +389,22 @@ def kp_gather_bwd(ngrid, kp, dout, B, Nk, gh, gw, D, sx, sy, img_h, img_w, patch
     return dg
 
 
+def kp_gather_bwd_det(kp, dout, scale, out_dtype, B, Nk, gh, gw, D, sx, sy, img_h, img_w, patch, prefix=0, stride=None, pitch=None):
+    """Deterministic interpolate_features backward (no atomics, no zero-fill, no cast pass): -> [B, prefix + gh*pitch, D] of
+    `out_dtype`, every element written (prefix rows / separator columns zero).  None when the shape is outside the kernel's range
+    (Nk > 1024, D % 8, D > 1024) or GD_GATHER_DET=0: the caller then takes the atomic scatter."""
+    import os
+    pt = gw if pitch is None else pitch
+    if os.environ.get("GD_GATHER_DET", "1") == "0" or Nk > 1024 or D % 8 != 0 or D > 1024:
+        return None
+    out = torch.empty(B, prefix + gh * pt, D, dtype=out_dtype, device=kp.device)
+    dout = dout.contiguous().float()
+    check(lib().gd_kp_gather_bwd_det(ptr(out), dtype_code(out), (prefix + gh * pt) * D, prefix, ptr(kp), ptr(dout), float(scale), B, Nk,
+                                     gh, gw, D, float(sx), float(sy), img_h, img_w, patch, patch if stride is None else stride, pt,
+                                     stream()), "gd_kp_gather_bwd_det")
+    return out
+
+
 def kp_patch_gather(grid, bstride, kp, B, Nk, gh, gw, D, sx, sy, img_h, img_w, patch, stride=None, pitch=None):
     """-> [B*Nk, 9*D] (grid dtype): the bilinear mix of the four neighbours' 3x3 input patches, K order (ky, kx, c) — the GEMM
     operand of refine_conv evaluated at the keypoints only (gd_kp_patch_gather).  `grid` is addressed from its data_ptr."""

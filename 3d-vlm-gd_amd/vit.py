@@ -663,7 +663,9 @@ class _ConvAtKpFn(torch.autograd.Function):
         dtok = None
         if ctx.needs_input_grad[0]:
             rows = B * gh * (gw + 1)
-            dy = ops.kp_gather_bwd(1, kp, dfe.view(B, Nk, D), B, Nk, gh, gw, D, sx, sy, img_h, img_w, patch, pitch=gw + 1)[0]
+            dy = ops.kp_gather_bwd_det(kp, dfe.view(B, Nk, D), 1.0, T, B, Nk, gh, gw, D, sx, sy, img_h, img_w, patch, pitch=gw + 1)
+            if dy is None:
+                dy = ops.kp_gather_bwd(1, kp, dfe.view(B, Nk, D), B, Nk, gh, gw, D, sx, sy, img_h, img_w, patch, pitch=gw + 1)[0]
             sbuf = ops.stack3_rows(dy, B, gh, gw, D, gh * (gw + 1) * D, 0, gw + 1, T)
             wt = weight.detach().flip(2, 3).permute(1, 3, 2, 0).reshape(D, 9 * D).to(T).contiguous()      # [ci, (kx, ky, n)]
             dxp = ops.gemm_nt(ops.conv_view(sbuf, rows, D), wt)        # [rows, D] on the pitched grid
@@ -712,10 +714,13 @@ class _GatherFn(torch.autograd.Function):
         (gh, gw, sx, sy, img_h, img_w, patch, stride, pitch), B, Ng, D, prefix, ng, T = ctx.meta
         # every grid of the mean receives the SAME gradient (w * dout / ng): scatter it once and hand the one buffer, cast
         # once to the grids' dtype, to all of them (four zero-filled fp32 grids + four scatters + four casts otherwise)
-        dg = ops.kp_gather_bwd(1, kp, dout * (1.0 / ng), B, kp.shape[1], gh, gw, D, sx, sy, img_h, img_w, patch, prefix=prefix,
-                               stride=stride, pitch=pitch)[0]
-        if dg.dtype != T:
-            dg = dg.to(T)
+        dg = ops.kp_gather_bwd_det(kp, dout, 1.0 / ng, T, B, kp.shape[1], gh, gw, D, sx, sy, img_h, img_w, patch, prefix=prefix,
+                                   stride=stride, pitch=pitch)       # one pass: no zero-fill, no atomics, no cast
+        if dg is None:
+            dg = ops.kp_gather_bwd(1, kp, dout * (1.0 / ng), B, kp.shape[1], gh, gw, D, sx, sy, img_h, img_w, patch, prefix=prefix,
+                                   stride=stride, pitch=pitch)[0]
+            if dg.dtype != T:
+                dg = dg.to(T)
         return (None, None) + (dg,) * ng
 
 

@@ -123,6 +123,12 @@ int gd_kp_gather_fwd(const void* const* grids, int ngrid, long bstride, int grid
 int gd_kp_gather_bwd(float* const* dgrids, int ngrid, long bstride, const float* kp, const float* dout, int B, int Nk,
                      int gh, int gw, int D, float sx, float sy, int img_h, int img_w, int patch, int stride, int pitch,
                      void* stream);
+/* interpolate_features backward without atomics (deterministic): writes EVERY element of dgrid [B][prefix_rows + gh*pitch][D] in
+ * out_dtype (prefix rows and separator columns zero), each position = the fixed-order sum of scale * w * dout[kp] over the
+ * keypoints that touch it.  Nk <= 1024, D % 8 == 0. */
+int gd_kp_gather_bwd_det(void* dgrid, int out_dtype, long bstride, int prefix_rows, const float* kp, const float* dout,
+                         float scale, int B, int Nk, int gh, int gw, int D, float sx, float sy, int img_h, int img_w,
+                         int patch, int stride, int pitch, void* stream);
 /* get_feature's refine_conv + interpolate_features (src/finetune_timm_vggt.py:319-325) with the two linear maps swapped:
  * out[b*Nk + k][(ky, kx, c)] = bilinear mix (the same four neighbours and weights as gd_kp_gather_fwd) of the 3x3 input patches
  * (zero padding 1) of ONE token grid [gh x pitch, D] -> [B*Nk, 9*D] in the grid's dtype; the conv is then a GEMM over B*Nk rows

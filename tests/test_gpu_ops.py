@@ -170,6 +170,35 @@ def test_kp_gather_golden(P):
     dg = ops.kp_gather_bwd(1, kp, g["gout"][0].t().contiguous().cuda()[None], 1, kp.shape[1], ph, pw, C, 1.0, 1.0,
                            g["h"], g["w"], P)[0]
     assert rel_err(dg.view(ph, pw, C).permute(2, 0, 1), g["gdesc"][0]) < 1e-5
+    # the deterministic (no-atomics) backward: same fixture, every element written
+    dd = ops.kp_gather_bwd_det(kp, g["gout"][0].t().contiguous().cuda()[None], 1.0, torch.float32, 1, kp.shape[1], ph, pw, C, 1.0, 1.0,
+                               g["h"], g["w"], P)
+    assert dd is not None and rel_err(dd.view(ph, pw, C).permute(2, 0, 1), g["gdesc"][0]) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,Nk,gh,gw,D,prefix,pitch", [(3, 300, 37, 37, 768, 1, 37), (2, 50, 5, 7, 64, 0, 8), (2, 700, 12, 9, 128, 1, 9)])
+def test_kp_gather_bwd_deterministic(dtype, B, Nk, gh, gw, D, prefix, pitch):
+    """gd_kp_gather_bwd_det against the atomic scatter: same sums (fp32 order differs), prefix rows / separator columns zero,
+    bit-identical from run to run; keypoints on the border, outside, padded with -1, and many on one grid line."""
+    from gd_amd import ops
+    P = 14
+    kp = torch.rand(B, Nk, 2, generator=_g(31), device="cuda") * torch.tensor([gw * P - 1.0, gh * P - 1.0], device="cuda")
+    kp[:, 0] = 0.0
+    kp[:, 1] = torch.tensor([gw * P - 1.0, gh * P - 1.0])
+    kp[:, 2] = torch.tensor([gw * P + 30.0, -12.0])
+    kp[:, 3] = -1.0
+    kp[:, 4:Nk // 2, 1] = 3.0 * P                                   # half of the keypoints on one grid line
+    dout = torch.randn(B, Nk, D, generator=_g(32), device="cuda")
+    ref = ops.kp_gather_bwd(1, kp, dout * 0.25, B, Nk, gh, gw, D, 1.0, 1.0, gh * P, gw * P, P, prefix=prefix, pitch=pitch)[0]
+    a = ops.kp_gather_bwd_det(kp, dout, 0.25, dtype, B, Nk, gh, gw, D, 1.0, 1.0, gh * P, gw * P, P, prefix=prefix, pitch=pitch)
+    b = ops.kp_gather_bwd_det(kp, dout, 0.25, dtype, B, Nk, gh, gw, D, 1.0, 1.0, gh * P, gw * P, P, prefix=prefix, pitch=pitch)
+    assert a.dtype == dtype and a.shape == ref.shape and torch.equal(a, b)
+    assert rel_err(a.float(), ref) < (1e-5 if dtype == torch.float32 else 6e-3)
+    if prefix:
+        assert float(a[:, :prefix].abs().max()) == 0.0
+    if pitch > gw:
+        assert float(a[:, prefix:].view(B, gh, pitch, D)[:, :, gw:].abs().max()) == 0.0
 
 
 def test_kp_gather_multi_grid_mean():
