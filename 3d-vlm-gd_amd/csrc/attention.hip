@@ -611,7 +611,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const T* qkv, const
 
 // ------------------------------------------------------------------------------------------ backward: dK, dV
 template <typename T, int NW>
-__global__ __launch_bounds__(64 * NW, 512 / (64 * NW)) void attn_bwd_dkv_kernel(const T* qkv, const T* dout, const float* lse,
+__global__ __launch_bounds__(64 * NW, NW >= 8 ? 1 : 2) void attn_bwd_dkv_kernel(const T* qkv, const T* dout, const float* lse,
                                                            const float* delta, T* dqkv, int N, int H, float scale, int vfirst) {
     constexpr int NF = AT<T>::NF, ROWB = AT<T>::ROWB;
     typedef typename Mma<T>::Frag Frag;
@@ -965,7 +965,7 @@ extern "C" int gd_attention_bwd(const void* qkv, const void* o, const void* dout
         static const int dkv_env = [] { const char* e = getenv("GD_ATTN_DKV_NW"); return e ? atoi(e) : 0; }();
         const int tail = N % 256;
         const int dkv_nw = dkv_env ? dkv_env : ((N < 4096 && tail > 0 && tail <= 128) ? 4 : 8);
-        if (dkv_nw == 4)
+        if (dkv_nw == 4)       // (two-wave 64-key blocks: 2213 us — the staging registers spill and every block re-stages all of Q / dO)
             hipLaunchKernelGGL((attn_bwd_dkv_kernel<bf16, 4>), dim3(gd_cdiv(N, 128), H, B), dim3(256), 0, s, (const bf16*)qkv, (const bf16*)dout, lse, delta_ws, (bf16*)dqkv, N, H, scale, grad_order);
         else
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<bf16, 8>), dim3(gd_cdiv(N, 256), H, B), dim3(512), 0, s, (const bf16*)qkv, (const bf16*)dout, lse, delta_ws, (bf16*)dqkv, N, H, scale, grad_order);
