@@ -231,14 +231,15 @@ def main():
         out["roofline_cost_volume"] = cost_volume_roofline(job, args, dev, variant)
         if comm:
             out["comm"] = comm
-        if not args.no_cpu_baseline:
+        # the CPU oracle legs (parity of the benched batch, cpu_baseline) and the companion measurements run at N = 1 only: on N > 1
+        # ranks they would only make the other ranks wait (tier contract: "on rank 0 at N=1 only")
+        if not args.no_cpu_baseline and world == 1:
             par, base = parity_and_cpu_baseline(job, args)
             out["parity"] = par
-            if world == 1:
-                out["cpu_baseline"] = base
+            out["cpu_baseline"] = base
     del job, eng
     torch.cuda.empty_cache()
-    if not args.no_extras:
+    if not args.no_extras and world == 1:
         extras = companion_runs(args, variant, backbone, weights, dev, rank, world)
         if rank == 0:
             out.update(extras)
