@@ -276,6 +276,50 @@ def test_me_variant_step_matches_oracle():
     eng.optimizer_step()
 
 
+@pytest.mark.parametrize("dtype,tol,gtol", [("f32", 1e-3, 5e-3), ("bf16", 1e-3, 1e-1)])
+def test_baseline_config1_me_vit_small_224(dtype, tol, gtol):
+    """BASELINE.json configs[0]: finetune_timm_me_objaverse — ViT-S/14, 2 synthetic 224^2 pairs, the ME trainer (LoRA on the last
+    four blocks, smooth-AP with dynamic positives, 3000 keypoints per view: data_utils/dataset.py:71) — loss and LoRA / refine_conv
+    gradients against the fp64 oracle.  3000 keypoints exceed the deterministic gather's 1024: the atomic scatter path runs."""
+    from gd_amd.finetune import FinetuneGD
+    torch.manual_seed(0)
+    eng = FinetuneGD(r=4, variant="me", geometry="shared", dtype=dtype, lora_b_std=0.05, vit_kwargs=dict(init_values=1.0),
+                     teacher_patch=14, backbone="vit_small", patch_size=14, img_size=224).cuda()
+    P, h, w, N = 2, 224, 224, 3000
+    batch = synthetic_batch(P, h, w, N, 256, "cuda", seed=21)
+    g = torch.Generator().manual_seed(22)
+    batch["pts3d_2"] = (batch["pts3d_1"].cpu() + 2e-3 * torch.randn(P, N, 3, generator=g)).cuda()
+    p, tr, refine, head, cfg = oracle_params(eng)
+    p = {k: v.double() for k, v in p.items()}
+    leaves = []
+    for i in sorted(tr["lora"]):
+        for k in ("a_q", "a_v", "b_q", "b_v"):
+            tr["lora"][i][k] = tr["lora"][i][k].double().requires_grad_(True)
+            leaves.append((i, k))
+    refine = {k: v.double().requires_grad_(True) for k, v in refine.items()}
+    cb = {k: v.detach().cpu() for k, v in batch.items()}
+    tot, per = 0, []
+    for q in range(P):
+        one = {"rgb_1": cb["rgb_1"][q:q + 1].double(), "rgb_2": cb["rgb_2"][q:q + 1].double(), "kp_1": cb["kp_1"][q:q + 1],
+               "kp_2": cb["kp_2"][q:q + 1], "pts3d_1": cb["pts3d_1"][q:q + 1].double(), "pts3d_2": cb["pts3d_2"][q:q + 1].double()}
+        l = O.me_pair_loss(one, p, cfg, tr, refine)
+        per.append(l.item())
+        tot = tot + l / P
+    tot.backward()
+    eng.configure_optimizers()
+    loss, terms = eng.training_step(batch)
+    eng.backward(loss)
+    assert abs(loss.item() - tot.item()) < tol * abs(tot.item()), (loss.item(), tot.item())
+    for q in range(P):
+        assert abs(terms["ap_loss"][q].item() - per[q]) < tol * abs(per[q])
+    for i, k in leaves:
+        mod = eng.model.blocks[i].attn.qkv
+        gq = getattr(mod, {"a_q": "linear_a_q", "a_v": "linear_a_v", "b_q": "linear_b_q", "b_v": "linear_b_v"}[k]).weight.grad
+        assert fro_err(gq, tr["lora"][i][k].grad) < gtol, (i, k)
+    assert fro_err(eng.refine_conv.weight.grad, refine["weight"].grad) < gtol
+    eng.optimizer_step()
+
+
 def test_checkpoint_carries_optimizer_state_and_unused_params_do_not_decay():
     """(a) the flat AdamW moments / step are part of the checkpoint; (b) depth_attention never receives a
     gradient — torch.optim.AdamW would skip it entirely (no decay): it must stay bit-identical over a step."""
