@@ -32,12 +32,12 @@ def _record(name, rec):
         json.dump(data, fh, indent=1, sort_keys=True)
 
 
-def _run_case(name, backbone, variant, dtype, img=518, P=2, N=300, vit_kwargs=None, counts=None):
+def _run_case(name, backbone, variant, dtype, img=518, P=2, N=300, vit_kwargs=None, counts=None, eng_kwargs=None):
     from gd_amd.finetune import FinetuneGD
     torch.manual_seed(0)
     vk = dict(init_values=1.0) if vit_kwargs is None else vit_kwargs
     eng = FinetuneGD(r=4, backbone=backbone, patch_size=14, img_size=img, variant=variant, geometry="shared", dtype=dtype,
-                     teacher_patch=14, lora_b_std=1e-3, vit_kwargs=vk).cuda()
+                     teacher_patch=14, lora_b_std=1e-3, vit_kwargs=vk, **(eng_kwargs or {})).cuda()
     hw = (img // 14) ** 2
     batch = synthetic_batch(P, img, img, N, hw, "cuda", seed=1234, teacher_patch=14, counts=counts)
     ref_loss, ref_terms, ref_grads, ref_params, ref_norm = _oracle_step(eng, batch, P)
@@ -100,4 +100,12 @@ def test_vit_large_518_vggt_step_matches_oracle(dtype):
 def test_prenorm_vit_large_bf16_step_matches_oracle():
     rec = _run_case("prenorm_vit_large_336_vggt_bf16", "vit_large", "vggt", "bf16", img=336, P=1, N=200,
                     vit_kwargs=dict(pre_norm=True, ln_eps=1e-5, pos_interp="timm"))
+    _check(rec)
+
+
+# BASELINE config 5 as worded: CLIP-style ViT-L/14 student + MASt3R teacher, "mixed corr + depth + cost losses", bf16 — the MASt3R
+# trainer's loss kernels (masked rows -> softmax KL, keypoint patch masks) with the depth L1 term switched on as well
+def test_prenorm_vit_large_bf16_mast3r_mixed_losses_step_matches_oracle():
+    rec = _run_case("prenorm_vit_large_336_mast3r_all_losses_bf16", "vit_large", "mast3r", "bf16", img=336, P=1, N=200,
+                    vit_kwargs=dict(pre_norm=True, ln_eps=1e-5, pos_interp="timm"), eng_kwargs=dict(depth_loss_weight=1.0))
     _check(rec)
