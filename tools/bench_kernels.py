@@ -173,6 +173,19 @@ def bench_tn():
         print(f"gemm_tn M={M} N={N:4d} K={K:5d}: {t*1e6:8.1f} us  {by/t/1e12:5.2f} TB/s  rel err {err:.2e}")
 
 
+def bench_ln():
+    M, D = 87680, 768
+    x = torch.randn(M, D, device="cuda").bfloat16()
+    dy = torch.randn(M, D, device="cuda").bfloat16()
+    dres = torch.randn(M, D, device="cuda").bfloat16()
+    g, b = torch.randn(D, device="cuda"), torch.randn(D, device="cuda")
+    y, mean, rstd = ops.layernorm_fwd(x, g, b, 1e-6)
+    t = timeit(lambda: ops.layernorm_fwd(x, g, b, 1e-6))
+    print(f"ln fwd {t*1e6:7.1f} us  {2*M*D*2/t/1e12:5.2f} TB/s")
+    t = timeit(lambda: ops.layernorm_bwd(dy, x, g, mean, rstd, dres=dres))
+    print(f"ln bwd (+dres) {t*1e6:7.1f} us  {4*M*D*2/t/1e12:5.2f} TB/s")
+
+
 def bench_rank():
     """depth head losses at the bench shape: 32 pairs x 2 views x 300 keypoints, D = 768."""
     P, N, D = 32, 300, 768
@@ -270,6 +283,8 @@ if __name__ == "__main__":
         bench_tn()
     if "rank" in which:
         bench_rank()
+    if "ln" in which:
+        bench_ln()
     if "probe" in which:
         probe_gemm()
     if "adapter" in which:
