@@ -179,7 +179,9 @@ class _CostVolumeKL(torch.autograd.Function):
         f1, f2, t1, t2, m1, m2, stats = ctx.saved_tensors
         P, hw, C = f1.shape
         dt = dtype_code(f1)
-        df1, df2 = torch.empty_like(f1), torch.empty_like(f2)
+        # the two halves of ONE buffer: split_pairs' backward hands it on without a concatenation pass (134 MB at the step's size)
+        dfull = torch.empty((2 * P, hw, C), dtype=f1.dtype, device=f1.device)
+        df1, df2 = dfull[:P], dfull[P:]
         ws = torch.empty(lib().gd_cost_volume_kl_workspace_bytes(P, hw, C, dt, 1), dtype=torch.uint8, device=f1.device)
         g = gloss.contiguous().float()
         rc = lib().gd_cost_volume_kl_bwd(ptr(f1), ptr(f2), ptr(t1), ptr(t2), t1.shape[-1], ptr(m1), ptr(m2), P, hw, C, dt, ptr(g),
@@ -234,6 +236,12 @@ class _SplitPairs(torch.autograd.Function):
         P, shp = ctx.P, ctx.shape
         if g1 is None and g2 is None:
             return None, None
+        if g1 is not None and g2 is not None:
+            base = g1._base
+            if (base is not None and base is g2._base and base.is_contiguous() and tuple(base.shape) == tuple(shp)
+                    and base.dtype == g1.dtype and g1.is_contiguous() and g2.is_contiguous() and g1.data_ptr() == base.data_ptr()
+                    and g2.data_ptr() == base.data_ptr() + g1.numel() * g1.element_size()):
+                return base, None              # already the halves of one buffer (e.g. cost_volume_kl's backward)
         dev = (g1 if g1 is not None else g2).device
         if g1 is None:
             g1 = torch.zeros((P,) + tuple(shp[1:]), dtype=g2.dtype, device=dev)
