@@ -695,6 +695,33 @@ extern "C" int gd_kp_gather_bwd_det(void* dgrid, int out_dtype, long bstride, in
     return 0;
 }
 
+// refine_conv weight packs for the step, one pass over the fp32 weight W[n][c][ky][kx] (nn.Conv2d layout):
+//   wk[n][(ky, kx, c)]            — the GEMM operand of the forward / weight-gradient at the keypoints,
+//   wt[c][(kx', ky', n)] = W[n][c][2 - ky'][2 - kx']  — the flipped kernel of the transposed convolution on the stacked-row view,
+// both in the engine dtype.  (torch: permute + contiguous + cast, flip + permute + contiguous + cast = six kernels, ~110 us.)
+template <typename T>
+__global__ __launch_bounds__(256) void conv_weight_pack_kernel(const float* w, T* wk, T* wt, int D) {
+    const long total = (long)D * D * 9;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        // i enumerates wk: n, tap = ky*3 + kx, c  (c fastest: coalesced stores of wk; the reads of w gather 9-strided floats)
+        const int c = (int)(i % D), tap = (int)((i / D) % 9);
+        const long n = i / ((long)D * 9);
+        const int ky = tap / 3, kx = tap % 3;
+        const float v = w[((n * D + c) * 3 + ky) * 3 + kx];
+        wk[i] = from_f32<T>(v);
+        // W[n][c][ky][kx] lands in wt[c][(kx', ky', n)] with ky' = 2 - ky, kx' = 2 - kx
+        wt[((long)c * 9 + (2 - kx) * 3 + (2 - ky)) * D + n] = from_f32<T>(v);
+    }
+}
+extern "C" int gd_conv_weight_pack(const float* weight, void* wk, void* wt, int D, int dtype, void* stream) {
+    GD_REQUIRE(D > 0 && weight && wk && wt, "gd_conv_weight_pack: bad arguments");
+    const int blocks = gd_cdiv((long)D * D * 9, 256 * 4);
+    if (dtype == GD_BF16) hipLaunchKernelGGL(conv_weight_pack_kernel<bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, weight, (bf16*)wk, (bf16*)wt, D);
+    else hipLaunchKernelGGL(conv_weight_pack_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, weight, (float*)wk, (float*)wt, D);
+    GD_LAUNCH_OK();
+    return 0;
+}
+
 extern "C" int gd_kp_depth(const float* depth, const float* kp, float* out, int B, int Nk, int H, int W, void* stream) {
     GD_REQUIRE(B > 0 && Nk > 0 && H > 0 && W > 0, "gd_kp_depth: bad shape");
     hipLaunchKernelGGL(kp_depth_kernel, dim3(gd_cdiv((long)B * Nk, 256)), dim3(256), 0, (hipStream_t)stream, depth, kp, out, B, Nk, H, W);

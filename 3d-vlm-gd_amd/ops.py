@@ -397,6 +397,17 @@ def kp_gather_bwd(ngrid, kp, dout, B, Nk, gh, gw, D, sx, sy, img_h, img_w, patch
     return dg
 
 
+def conv_weight_pack(weight, dtype):
+    """refine_conv weight [D, D, 3, 3] fp32 -> (wk [D, 9D] with K order (ky, kx, c), wt [D, 9D] = flipped kernel, K order (kx, ky, n))
+    in `dtype`, one kernel."""
+    D = weight.shape[0]
+    w = weight.detach().float().contiguous()
+    wk = torch.empty(D, 9 * D, dtype=dtype, device=w.device)
+    wt = torch.empty(D, 9 * D, dtype=dtype, device=w.device)
+    check(lib().gd_conv_weight_pack(ptr(w), ptr(wk), ptr(wt), D, dtype_code(wk), stream()), "gd_conv_weight_pack")
+    return wk, wt
+
+
 def kp_gather_bwd_det(kp, dout, scale, out_dtype, B, Nk, gh, gw, D, sx, sy, img_h, img_w, patch, prefix=0, stride=None, pitch=None):
     """Deterministic interpolate_features backward (no atomics, no zero-fill, no cast pass): -> [B, prefix + gh*pitch, D] of
     `out_dtype`, every element written (prefix rows / separator columns zero).  None when the shape is outside the kernel's range

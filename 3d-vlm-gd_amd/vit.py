@@ -644,15 +644,15 @@ class _ConvAtKpFn(torch.autograd.Function):
         Nk = kp.shape[1]
         T = tok.dtype
         colp = ops.kp_patch_gather(tok[:, Nt - gh * gw:], Nt * D, kp, B, Nk, gh, gw, D, sx, sy, img_h, img_w, patch)
-        wk = weight.detach().permute(0, 2, 3, 1).reshape(D, 9 * D).to(T).contiguous()           # [n, (ky, kx, c)]
+        wk, wt = ops.conv_weight_pack(weight, T)            # [n, (ky, kx, c)] and the flipped [ci, (kx, ky, n)] of the backward
         out = ops.gemm_nt(colp, wk, bias=bias.detach().float().contiguous(), out_dtype=torch.float32)
-        ctx.save_for_backward(colp, weight, kp)
+        ctx.save_for_backward(colp, wt, kp)
         ctx.meta = (geom, B, Nt, D, Nk)
         return out.view(B, Nk, D)
 
     @staticmethod
     def backward(ctx, dfeat):
-        colp, weight, kp = ctx.saved_tensors
+        colp, wt, kp = ctx.saved_tensors
         (gh, gw, sx, sy, img_h, img_w, patch), B, Nt, D, Nk = ctx.meta
         T = colp.dtype
         dfe = dfeat.reshape(B * Nk, D).contiguous().float()
@@ -667,7 +667,6 @@ class _ConvAtKpFn(torch.autograd.Function):
             if dy is None:
                 dy = ops.kp_gather_bwd(1, kp, dfe.view(B, Nk, D), B, Nk, gh, gw, D, sx, sy, img_h, img_w, patch, pitch=gw + 1)[0]
             sbuf = ops.stack3_rows(dy, B, gh, gw, D, gh * (gw + 1) * D, 0, gw + 1, T)
-            wt = weight.detach().flip(2, 3).permute(1, 3, 2, 0).reshape(D, 9 * D).to(T).contiguous()      # [ci, (kx, ky, n)]
             dxp = ops.gemm_nt(ops.conv_view(sbuf, rows, D), wt)        # [rows, D] on the pitched grid
             dtok = ops.unpitch_tokens(dxp, B, gh, gw, D, Nt - gh * gw)
         return dtok, gweight, gbias, None, None
