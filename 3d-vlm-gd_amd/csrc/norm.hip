@@ -3,6 +3,7 @@
 // Replaces nn.LayerNorm in timm's Block / model.norm and F.normalize
 // (src/finetune_timm_vggt.py:328).
 #include "gd_common.h"
+#include <stdlib.h>
 
 #define LN_MAXV 8  // 8 x (64 lanes x 4 elements) = 2048 columns
 
@@ -112,6 +113,106 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* dy, const T* x, c
     }
 }
 
+
+// bf16 rows with 16-byte accesses: a lane holds 8 consecutive elements per 512-column slab (D = 768: lanes 0-63 + lanes 0-31)
+template <int NV2>
+__global__ __launch_bounds__(256) void ln_fwd8_kernel(const bf16* x, const float* gamma, const float* beta, bf16* y, float* mean,
+                                                      float* rstd, int M, int D, long ldx, long ldy, float eps) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const bf16* xr = x + (long)row * ldx;
+    float v[NV2][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV2; ++i) {
+        const int c = (lane + 64 * i) * 8;
+        if (c < D) {
+            const bf16x8 t = *(const bf16x8*)(xr + c);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { v[i][k] = (float)t[k]; s += v[i][k]; }
+        }
+    }
+    const float mu = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV2; ++i)
+        if ((lane + 64 * i) * 8 < D) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const float d = v[i][k] - mu; q += d * d; }
+        }
+    const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+    if (lane == 0 && mean) { mean[row] = mu; rstd[row] = rs; }
+    bf16* yr = y + (long)row * ldy;
+#pragma unroll
+    for (int i = 0; i < NV2; ++i) {
+        const int c = (lane + 64 * i) * 8;
+        if (c < D) {
+            const f32x4 g0 = *(const f32x4*)(gamma + c), g1 = *(const f32x4*)(gamma + c + 4);
+            const f32x4 b0 = *(const f32x4*)(beta + c), b1 = *(const f32x4*)(beta + c + 4);
+            bf16x8 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                o[k] = (bf16)((v[i][k] - mu) * rs * g0[k] + b0[k]);
+                o[k + 4] = (bf16)((v[i][k + 4] - mu) * rs * g1[k] + b1[k]);
+            }
+            *(bf16x8*)(yr + c) = o;
+        }
+    }
+}
+template <int NV2>
+__global__ __launch_bounds__(256) void ln_bwd8_kernel(const bf16* dy, const bf16* x, const float* gamma, const float* mean,
+                                                      const float* rstd, const bf16* dres, const bf16* dres2, bf16* dx, int M, int D,
+                                                      long ldd, long ldx, float dyscale) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float mu = mean[row], rs = rstd[row];
+    const bf16* xr = x + (long)row * ldx;
+    const bf16* dr = dy + (long)row * ldd;
+    float xh[NV2][8], g[NV2][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV2; ++i) {
+        const int c = (lane + 64 * i) * 8;
+        if (c < D) {
+            const bf16x8 xv = *(const bf16x8*)(xr + c), dv = *(const bf16x8*)(dr + c);
+            const f32x4 g0 = *(const f32x4*)(gamma + c), g1 = *(const f32x4*)(gamma + c + 4);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                xh[i][k] = ((float)xv[k] - mu) * rs;
+                g[i][k] = (float)dv[k] * dyscale * (k < 4 ? g0[k] : g1[k - 4]);
+                s1 += g[i][k];
+                s2 += g[i][k] * xh[i][k];
+            }
+        }
+    }
+    s1 = wave_sum(s1) / (float)D;
+    s2 = wave_sum(s2) / (float)D;
+    bf16* or_ = dx + (long)row * ldx;
+#pragma unroll
+    for (int i = 0; i < NV2; ++i) {
+        const int c = (lane + 64 * i) * 8;
+        if (c < D) {
+            float o[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = rs * (g[i][k] - s1 - xh[i][k] * s2);
+            if (dres) {
+                const bf16x8 r = *(const bf16x8*)(dres + (long)row * ldx + c);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o[k] += (float)r[k];
+            }
+            if (dres2) {
+                const bf16x8 r = *(const bf16x8*)(dres2 + (long)row * ldx + c);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o[k] += (float)r[k];
+            }
+            bf16x8 ov;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) ov[k] = (bf16)o[k];
+            *(bf16x8*)(or_ + c) = ov;
+        }
+    }
+}
+
 // y = x / max(||x||, eps) on fp32 rows; backward dx = (dy - y (y.dy)) / max(||x||, eps)
 __global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* x, float* y, float* inv, int M, int D, float eps) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -156,7 +257,12 @@ extern "C" int gd_layernorm_fwd(const void* x, const float* gamma, const float* 
 #define F_BB(NV) hipLaunchKernelGGL((ln_fwd_kernel<bf16, bf16, NV>), grid, blk, 0, s, (const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, M, D, ldx, ldy, eps)
 #define F_BF(NV) hipLaunchKernelGGL((ln_fwd_kernel<bf16, float, NV>), grid, blk, 0, s, (const bf16*)x, gamma, beta, (float*)y, mean, rstd, M, D, ldx, ldy, eps)
 #define F_FF(NV) hipLaunchKernelGGL((ln_fwd_kernel<float, float, NV>), grid, blk, 0, s, (const float*)x, gamma, beta, (float*)y, mean, rstd, M, D, ldx, ldy, eps)
-    if (dtype == GD_BF16 && y_dtype == GD_BF16) LN_DISPATCH_NV(D, F_BB);
+    static const int ln16 = [] { const char* e = getenv("GD_LN_16B"); return e ? atoi(e) : 1; }();
+    const bool wide = ln16 && dtype == GD_BF16 && y_dtype == GD_BF16 && D % 8 == 0 && D <= 1024 && ldx % 8 == 0 && ldy % 8 == 0 &&
+                      ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)gamma % 16) == 0 && ((uintptr_t)beta % 16) == 0;
+    if (wide && D <= 512) hipLaunchKernelGGL((ln_fwd8_kernel<1>), grid, blk, 0, s, (const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, M, D, ldx, ldy, eps);
+    else if (wide) hipLaunchKernelGGL((ln_fwd8_kernel<2>), grid, blk, 0, s, (const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, M, D, ldx, ldy, eps);
+    else if (dtype == GD_BF16 && y_dtype == GD_BF16) LN_DISPATCH_NV(D, F_BB);
     else if (dtype == GD_BF16 && y_dtype == GD_F32) LN_DISPATCH_NV(D, F_BF);
     else if (dtype == GD_F32 && y_dtype == GD_F32) LN_DISPATCH_NV(D, F_FF);
     else {
@@ -177,7 +283,13 @@ extern "C" int gd_layernorm_bwd(const void* dy, const void* x, const float* gamm
 #define B_BB(NV) hipLaunchKernelGGL((ln_bwd_kernel<bf16, bf16, NV>), grid, blk, 0, s, (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (const bf16*)dres, (const bf16*)dres2, (bf16*)dx, M, D, ldd, ldx, dyscale)
 #define B_BF(NV) hipLaunchKernelGGL((ln_bwd_kernel<bf16, float, NV>), grid, blk, 0, s, (const float*)dy, (const bf16*)x, gamma, mean, rstd, (const bf16*)dres, (const bf16*)dres2, (bf16*)dx, M, D, ldd, ldx, dyscale)
 #define B_FF(NV) hipLaunchKernelGGL((ln_bwd_kernel<float, float, NV>), grid, blk, 0, s, (const float*)dy, (const float*)x, gamma, mean, rstd, (const float*)dres, (const float*)dres2, (float*)dx, M, D, ldd, ldx, dyscale)
-    if (dtype == GD_BF16 && dy_dtype == GD_BF16) LN_DISPATCH_NV(D, B_BB);
+    static const int ln16 = [] { const char* e = getenv("GD_LN_16B"); return e ? atoi(e) : 1; }();
+    const bool wide = ln16 && dtype == GD_BF16 && dy_dtype == GD_BF16 && D % 8 == 0 && D <= 1024 && ldx % 8 == 0 && ldd % 8 == 0 &&
+                      ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 && ((uintptr_t)dx % 16) == 0 && ((uintptr_t)gamma % 16) == 0 &&
+                      ((uintptr_t)dres % 16) == 0 && ((uintptr_t)dres2 % 16) == 0;
+    if (wide && D <= 512) hipLaunchKernelGGL((ln_bwd8_kernel<1>), grid, blk, 0, s, (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (const bf16*)dres, (const bf16*)dres2, (bf16*)dx, M, D, ldd, ldx, dyscale);
+    else if (wide) hipLaunchKernelGGL((ln_bwd8_kernel<2>), grid, blk, 0, s, (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (const bf16*)dres, (const bf16*)dres2, (bf16*)dx, M, D, ldd, ldx, dyscale);
+    else if (dtype == GD_BF16 && dy_dtype == GD_BF16) LN_DISPATCH_NV(D, B_BB);
     else if (dtype == GD_BF16 && dy_dtype == GD_F32) LN_DISPATCH_NV(D, B_BF);
     else if (dtype == GD_F32 && dy_dtype == GD_F32) LN_DISPATCH_NV(D, B_FF);
     else {
