@@ -695,6 +695,113 @@ extern "C" int gd_kp_gather_bwd_det(void* dgrid, int out_dtype, long bstride, in
     return 0;
 }
 
+// Input gradient of gd_kp_patch_gather (the transposed 3x3 convolution restricted to where it is non-zero), WITHOUT atomics:
+// U[bk][(ky, kx, c)] = dfeat[bk] . W[:, c, ky, kx] comes from ONE GEMM over B*Nk rows; every token (Y, X) then sums
+//   w_ab * U[kp][(Y - y_a + 1, X - x_b + 1, c)]   over the keypoints whose 4 x 4 footprint covers it,
+// in keypoint order (compacted per grid line by wave ballots + a block scan, as in kp_gather_bwd_det_kernel), and is written once in
+// the output dtype — prefix rows zero.  Replaces scatter + stacked-row buffer + a K = 9D GEMM over the whole grid + un-pitching.
+template <typename TU, typename TO>
+__global__ __launch_bounds__(256) void kp_patch_bwd_det_kernel(GatherParams p, const TU* U, TO* dtok, int prefix_rows) {
+    __shared__ int s_kp[KPB_MAXK];
+    __shared__ short s_x0[KPB_MAXK];
+    __shared__ signed char s_dx[KPB_MAXK], s_ky0[KPB_MAXK], s_ky1[KPB_MAXK];
+    __shared__ float s_wx[KPB_MAXK], s_wa0[KPB_MAXK], s_wa1[KPB_MAXK];
+    __shared__ int s_wcnt[4], s_total;
+    const int y = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_total = 0;
+    __syncthreads();
+    for (int base = 0; base < p.Nk; base += 256) {
+        const int k = base + tid;
+        bool m = false;
+        int x0 = 0, y0 = 0, x1 = 0, y1 = 0; float wx = 0.f, wy = 0.f;
+        if (k < p.Nk) {
+            gather_coords(p, (long)b * p.Nk + k, x0, y0, x1, y1, wx, wy);
+            m = y >= y0 - 1 && y <= y0 + 2;            // rows of the 4 x 4 block (the forward reads offsets {0, 1} unconditionally)
+        }
+        const unsigned long long bal = __ballot(m);
+        const int pre = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wcnt[wave] = __popcll(bal);
+        __syncthreads();
+        int off = s_total;
+        for (int w = 0; w < wave; ++w) off += s_wcnt[w];
+        if (m) {
+            const int e = off + pre;
+            const int ky0 = y - y0 + 1, ky1 = y - (y0 + 1) + 1;        // tap row through neighbour a = 0 / a = 1 (rows y0, y0 + 1)
+            s_kp[e] = k; s_x0[e] = (short)x0; s_dx[e] = 1;
+            s_wx[e] = wx;
+            s_wa0[e] = (ky0 >= 0 && ky0 <= 2) ? 1.f - wy : 0.f; s_ky0[e] = (signed char)ky0;
+            s_wa1[e] = (ky1 >= 0 && ky1 <= 2) ? wy : 0.f;       s_ky1[e] = (signed char)ky1;
+        }
+        __syncthreads();
+        if (tid == 0) s_total += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+        __syncthreads();
+    }
+    const int n = s_total;
+    constexpr int V = 8, UV = 16 / sizeof(TU);
+    const int nch = p.D / V;
+    const int slot = tid >> 7, ch = tid & 127;
+    TO* line = dtok + (long)b * p.bstride + ((long)prefix_rows + (long)y * p.gw) * p.D;
+    if (y == 0) {
+        for (long i = tid; i < (long)prefix_rows * p.D; i += 256) dtok[(long)b * p.bstride + i] = from_f32<TO>(0.f);
+    }
+    const long urow = 9L * p.D;
+    for (int x = slot; x < p.gw; x += 2) {
+        if (ch >= nch) continue;
+        float acc[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc[k] = 0.f;
+        for (int e = 0; e < n; ++e) {
+            const int x0 = s_x0[e];
+            if (x < x0 - 1 || x > x0 + 2) continue;                       // (group-uniform)
+            const TU* ub = U + ((long)b * p.Nk + s_kp[e]) * urow + ch * V;
+            const float wx = s_wx[e];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const float wa = a ? s_wa1[e] : s_wa0[e];
+                if (wa == 0.f) continue;
+                const int ky = a ? s_ky1[e] : s_ky0[e];
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb) {
+                    const int kx = x - (x0 + bb) + 1;
+                    const float w = wa * (bb ? wx : 1.f - wx);
+                    if (kx < 0 || kx > 2 || w == 0.f) continue;
+                    const TU* u = ub + (long)(ky * 3 + kx) * p.D;
+#pragma unroll
+                    for (int q = 0; q < V / UV; ++q) {
+                        const uint4 raw = *(const uint4*)(u + q * UV);
+                        const TU* ev = (const TU*)&raw;
+#pragma unroll
+                        for (int k = 0; k < UV; ++k) acc[q * UV + k] += w * to_f32<TU>(ev[k]);
+                    }
+                }
+            }
+        }
+        TO r[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) r[k] = from_f32<TO>(acc[k]);
+        TO* o = line + (long)x * p.D + ch * V;
+        *(uint4*)o = *(const uint4*)r;
+        if (sizeof(TO) == 4) *(uint4*)(o + 4) = *(const uint4*)(r + 4);
+    }
+}
+
+extern "C" int gd_kp_patch_bwd_det(const void* U, void* dtok, int dtype, long bstride, int prefix_rows, const float* kp, int B, int Nk,
+                                   int gh, int gw, int D, float sx, float sy, int img_h, int img_w, int patch, int stride,
+                                   void* stream) {
+    GatherParams p = {};
+    const void* one[1] = {dtok};
+    if (fill_gather(p, one, 1, bstride, GD_F32, kp, B, Nk, gh, gw, D, sx, sy, img_h, img_w, patch, stride, gw)) return -1;
+    GD_REQUIRE(Nk <= KPB_MAXK && D % 8 == 0 && D <= 1024 && prefix_rows >= 0, "gd_kp_patch_bwd_det: needs Nk <= %d, D %% 8 == 0, D <= 1024", KPB_MAXK);
+    GD_REQUIRE(((uintptr_t)dtok % 16) == 0 && ((uintptr_t)U % 16) == 0 && (bstride * gd_dtype_size(dtype)) % 16 == 0,
+               "gd_kp_patch_bwd_det: 16-byte alignment");
+    if (dtype == GD_BF16)
+        hipLaunchKernelGGL((kp_patch_bwd_det_kernel<bf16, bf16>), dim3(gh, B), dim3(256), 0, (hipStream_t)stream, p, (const bf16*)U, (bf16*)dtok, prefix_rows);
+    else
+        hipLaunchKernelGGL((kp_patch_bwd_det_kernel<float, float>), dim3(gh, B), dim3(256), 0, (hipStream_t)stream, p, (const float*)U, (float*)dtok, prefix_rows);
+    GD_LAUNCH_OK();
+    return 0;
+}
+
 // refine_conv weight packs for the step, one pass over the fp32 weight W[n][c][ky][kx] (nn.Conv2d layout):
 //   wk[n][(ky, kx, c)]            — the GEMM operand of the forward / weight-gradient at the keypoints,
 //   wt[c][(kx', ky', n)] = W[n][c][2 - ky'][2 - kx']  — the flipped kernel of the transposed convolution on the stacked-row view,
@@ -713,11 +820,29 @@ __global__ __launch_bounds__(256) void conv_weight_pack_kernel(const float* w, T
         wt[((long)c * 9 + (2 - kx) * 3 + (2 - ky)) * D + n] = from_f32<T>(v);
     }
 }
-extern "C" int gd_conv_weight_pack(const float* weight, void* wk, void* wt, int D, int dtype, void* stream) {
+// wu[(ky, kx, c)][n] = wk[n][(ky, kx, c)]: a plain 2-D transpose of the packed weight through 32 x 32 LDS tiles (both sides coalesced;
+// reading the conv weight with n fastest is a 27 KB stride: that form of the pack took 80 us)
+template <typename T>
+__global__ __launch_bounds__(256) void transpose2d_kernel(const T* src, T* dst, int R, int C) {     // src [R][C] -> dst [C][R]
+    __shared__ T tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8)
+        if (r0 + j < R && c0 + tx < C) tile[j][tx] = src[(long)(r0 + j) * C + c0 + tx];
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+        if (c0 + j < C && r0 + tx < R) dst[(long)(c0 + j) * R + r0 + tx] = tile[tx][j];
+}
+extern "C" int gd_conv_weight_pack(const float* weight, void* wk, void* wt, void* wu, int D, int dtype, void* stream) {
     GD_REQUIRE(D > 0 && weight && wk && wt, "gd_conv_weight_pack: bad arguments");
     const int blocks = gd_cdiv((long)D * D * 9, 256 * 4);
-    if (dtype == GD_BF16) hipLaunchKernelGGL(conv_weight_pack_kernel<bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, weight, (bf16*)wk, (bf16*)wt, D);
-    else hipLaunchKernelGGL(conv_weight_pack_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, weight, (float*)wk, (float*)wt, D);
+    const dim3 tg(gd_cdiv(9 * D, 32), gd_cdiv(D, 32));
+    if (dtype == GD_BF16) {
+        hipLaunchKernelGGL(conv_weight_pack_kernel<bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, weight, (bf16*)wk, (bf16*)wt, D);
+        if (wu) hipLaunchKernelGGL(transpose2d_kernel<bf16>, tg, dim3(256), 0, (hipStream_t)stream, (const bf16*)wk, (bf16*)wu, D, 9 * D);
+    } else {
+        hipLaunchKernelGGL(conv_weight_pack_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, weight, (float*)wk, (float*)wt, D);
+        if (wu) hipLaunchKernelGGL(transpose2d_kernel<float>, tg, dim3(256), 0, (hipStream_t)stream, (const float*)wk, (float*)wu, D, 9 * D);
+    }
     GD_LAUNCH_OK();
     return 0;
 }

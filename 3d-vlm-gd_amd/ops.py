@@ -397,15 +397,24 @@ def kp_gather_bwd(ngrid, kp, dout, B, Nk, gh, gw, D, sx, sy, img_h, img_w, patch
     return dg
 
 
-def conv_weight_pack(weight, dtype):
-    """refine_conv weight [D, D, 3, 3] fp32 -> (wk [D, 9D] with K order (ky, kx, c), wt [D, 9D] = flipped kernel, K order (kx, ky, n))
-    in `dtype`, one kernel."""
+def conv_weight_pack(weight, dtype, with_wu=False):
+    """refine_conv weight [D, D, 3, 3] fp32 -> (wk [D, 9D] with K order (ky, kx, c), wt [D, 9D] = flipped kernel, K order (kx, ky, n),
+    wu [9D, D] = wk transposed or None) in `dtype`, one kernel."""
     D = weight.shape[0]
     w = weight.detach().float().contiguous()
     wk = torch.empty(D, 9 * D, dtype=dtype, device=w.device)
     wt = torch.empty(D, 9 * D, dtype=dtype, device=w.device)
-    check(lib().gd_conv_weight_pack(ptr(w), ptr(wk), ptr(wt), D, dtype_code(wk), stream()), "gd_conv_weight_pack")
-    return wk, wt
+    wu = torch.empty(9 * D, D, dtype=dtype, device=w.device) if with_wu else None
+    check(lib().gd_conv_weight_pack(ptr(w), ptr(wk), ptr(wt), ptr(wu), D, dtype_code(wk), stream()), "gd_conv_weight_pack")
+    return wk, wt, wu
+
+
+def kp_patch_bwd_det(U, kp, out_dtype, B, Nk, Nt, gh, gw, D, sx, sy, img_h, img_w, patch):
+    """U [B*Nk, 9D] (= dfeat . W) -> the token gradient [B, Nt, D] of kp_patch_gather, deterministic, prefix rows zero."""
+    out = torch.empty(B, Nt, D, dtype=out_dtype, device=U.device)
+    check(lib().gd_kp_patch_bwd_det(ptr(U), ptr(out), dtype_code(out), Nt * D, Nt - gh * gw, ptr(kp), B, Nk, gh, gw, D, float(sx), float(sy),
+                                    img_h, img_w, patch, patch, stream()), "gd_kp_patch_bwd_det")
+    return out
 
 
 def kp_gather_bwd_det(kp, dout, scale, out_dtype, B, Nk, gh, gw, D, sx, sy, img_h, img_w, patch, prefix=0, stride=None, pitch=None):

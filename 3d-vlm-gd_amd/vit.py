@@ -644,9 +644,13 @@ class _ConvAtKpFn(torch.autograd.Function):
         Nk = kp.shape[1]
         T = tok.dtype
         colp = ops.kp_patch_gather(tok[:, Nt - gh * gw:], Nt * D, kp, B, Nk, gh, gw, D, sx, sy, img_h, img_w, patch)
-        wk, wt = ops.conv_weight_pack(weight, T)            # [n, (ky, kx, c)] and the flipped [ci, (kx, ky, n)] of the backward
+        import os
+        sparse_dx = tok.requires_grad and Nk <= 1024 and D % 8 == 0 and D <= 1024 and os.environ.get("GD_CONV_DX_AT_KP", "1") != "0"
+        # [n, (ky, kx, c)], the flipped [ci, (kx, ky, n)] of the dense backward, [(ky, kx, c), n] of the backward at the keypoints
+        wk, wt, wu = ops.conv_weight_pack(weight, T, with_wu=sparse_dx)
         out = ops.gemm_nt(colp, wk, bias=bias.detach().float().contiguous(), out_dtype=torch.float32)
-        ctx.save_for_backward(colp, wt, kp)
+        ctx.save_for_backward(colp, wu if sparse_dx else wt, kp)
+        ctx.sparse_dx = sparse_dx
         ctx.meta = (geom, B, Nt, D, Nk)
         return out.view(B, Nk, D)
 
@@ -661,7 +665,11 @@ class _ConvAtKpFn(torch.autograd.Function):
         gweight = gk.view(D, 3, 3, D).permute(0, 3, 1, 2).contiguous()
         gbias = dfe.sum(0)
         dtok = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and ctx.sparse_dx:
+            # dcol = dfeat . W over the B*Nk keypoint rows, then every token gathers its contributions (no atomics, no dense GEMM)
+            U = ops.gemm_nt(dft, wt, out_dtype=T)                  # (`wt` holds wu here) [B*Nk, 9D]
+            dtok = ops.kp_patch_bwd_det(U, kp, T, B, Nk, Nt, gh, gw, D, sx, sy, img_h, img_w, patch)
+        elif ctx.needs_input_grad[0]:
             rows = B * gh * (gw + 1)
             dy = ops.kp_gather_bwd_det(kp, dfe.view(B, Nk, D), 1.0, T, B, Nk, gh, gw, D, sx, sy, img_h, img_w, patch, pitch=gw + 1)
             if dy is None:

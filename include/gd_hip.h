@@ -123,10 +123,15 @@ int gd_kp_gather_fwd(const void* const* grids, int ngrid, long bstride, int grid
 int gd_kp_gather_bwd(float* const* dgrids, int ngrid, long bstride, const float* kp, const float* dout, int B, int Nk,
                      int gh, int gw, int D, float sx, float sy, int img_h, int img_w, int patch, int stride, int pitch,
                      void* stream);
+/* Input gradient of gd_kp_patch_gather without atomics: U [B*Nk, 9*D] = dfeat . W (one GEMM against gd_conv_weight_pack's wu) ->
+ * dtok [B][prefix_rows + gh*gw][D] in `dtype`, every element written once, contributions summed in keypoint order.  Nk <= 1024. */
+int gd_kp_patch_bwd_det(const void* U, void* dtok, int dtype, long bstride, int prefix_rows, const float* kp, int B, int Nk,
+                        int gh, int gw, int D, float sx, float sy, int img_h, int img_w, int patch, int stride, void* stream);
 /* refine_conv (nn.Conv2d weight [D][D][3][3], src/finetune_timm_vggt.py:146) packed for the step in one pass:
  * wk[n][(ky,kx,c)] (forward / weight gradient at the keypoints) and wt[c][(kx',ky',n)] = W[n][c][2-ky'][2-kx'] (the flipped kernel
- * of the transposed convolution on the stacked-row view), both in `dtype`. */
-int gd_conv_weight_pack(const float* weight, void* wk, void* wt, int D, int dtype, void* stream);
+ * of the transposed convolution on the stacked-row view) and, when wu != NULL, wu[(ky,kx,c)][n] (the [9D, D] operand of
+ * dcol = dfeat . wu^T for gd_kp_patch_bwd_det), all in `dtype`. */
+int gd_conv_weight_pack(const float* weight, void* wk, void* wt, void* wu, int D, int dtype, void* stream);
 /* interpolate_features backward without atomics (deterministic): writes EVERY element of dgrid [B][prefix_rows + gh*pitch][D] in
  * out_dtype (prefix rows and separator columns zero), each position = the fixed-order sum of scale * w * dout[kp] over the
  * keypoints that touch it.  Nk <= 1024, D % 8 == 0. */
