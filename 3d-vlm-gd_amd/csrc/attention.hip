@@ -610,7 +610,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const T* qkv, const
 }
 
 // ------------------------------------------------------------------------------------------ backward: dK, dV
-template <typename T, int NW>
+// DK = false: dV only (the first trainable block of the student: nothing below it learns, so dK — and with it dP, dS and the Q^T
+// operand — is never used; half of the kernel's MFMAs)
+template <typename T, int NW, bool DK = true>
 __global__ __launch_bounds__(64 * NW, NW >= 8 ? 1 : 2) void attn_bwd_dkv_kernel(const T* qkv, const T* dout, const float* lse,
                                                            const float* delta, T* dqkv, int N, int H, float scale, int vfirst) {
     constexpr int NF = AT<T>::NF, ROWB = AT<T>::ROWB;
@@ -688,7 +690,7 @@ __global__ __launch_bounds__(64 * NW, NW >= 8 ? 1 : 2) void attn_bwd_dkv_kernel(
 #pragma unroll
             for (int u = 0; u < NF; ++u) {
                 qf[u] = lds_nfrag<T>(sQ, qt * 16 + c, u, g);
-                df[u] = lds_nfrag<T>(sD, qt * 16 + c, u, g);
+                if (DK) df[u] = lds_nfrag<T>(sD, qt * 16 + c, u, g);
             }
             // row constants as the initial accumulators: the four queries 16 qt + 4 g + r of this lane's C rows
             const f32x4 nl = *(const f32x4*)(sL + qt * 16 + g * 4), nd = *(const f32x4*)(sDl + qt * 16 + g * 4);
@@ -698,13 +700,13 @@ __global__ __launch_bounds__(64 * NW, NW >= 8 ? 1 : 2) void attn_bwd_dkv_kernel(
 #pragma unroll
                 for (int u = 0; u < NF; ++u) {
                     s = Mma<T>::mma(qf[u], kf[kt][u], s);    // rows: queries, cols: keys
-                    dp = Mma<T>::mma(df[u], vf[kt][u], dp);
+                    if (DK) dp = Mma<T>::mma(df[u], vf[kt][u], dp);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float p = fast_exp2(s[r]);
                     pp[kt][qt][r] = p;
-                    dsv[kt][qt][r] = p * dp[r];                    // the 1/sqrt(d) factor is applied once, to dK
+                    if (DK) dsv[kt][qt][r] = p * dp[r];            // the 1/sqrt(d) factor is applied once, to dK
                 }
             }
         }
@@ -712,15 +714,16 @@ __global__ __launch_bounds__(64 * NW, NW >= 8 ? 1 : 2) void attn_bwd_dkv_kernel(
         for (int u = 0; u < NF; ++u) {
             Frag pf[2], sf[2];
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt) { pf[kt] = acc_to_bfrag<T>(pp[kt], u); sf[kt] = acc_to_bfrag<T>(dsv[kt], u); }
+            for (int kt = 0; kt < 2; ++kt) { pf[kt] = acc_to_bfrag<T>(pp[kt], u); if (DK) sf[kt] = acc_to_bfrag<T>(dsv[kt], u); }
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const Frag dot = TOp<T>::load(sD, sDt, dt, u, g, lane);
-                const Frag qt_ = TOp<T>::load(sQ, sQt, dt, u, g, lane);
+                Frag qt_ = dot;
+                if (DK) qt_ = TOp<T>::load(sQ, sQt, dt, u, g, lane);
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt) {
                     dv[dt][kt] = Mma<T>::mma(dot, pf[kt], dv[dt][kt]);
-                    dk[dt][kt] = Mma<T>::mma(qt_, sf[kt], dk[dt][kt]);
+                    if (DK) dk[dt][kt] = Mma<T>::mma(qt_, sf[kt], dk[dt][kt]);
                 }
             }
         }
@@ -734,7 +737,7 @@ __global__ __launch_bounds__(64 * NW, NW >= 8 ? 1 : 2) void attn_bwd_dkv_kernel(
         T* rv = dqkv + ((long)b * N + key) * 3 * H * HD + (long)((vfirst ? 1 : 2) * H + h) * HD;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-            store4<T>(rk + dt * 16 + g * 4, dk[dt][kt] * scale);
+            if (DK) store4<T>(rk + dt * 16 + g * 4, dk[dt][kt] * scale);
             store4<T>(rv + dt * 16 + g * 4, dv[dt][kt]);
         }
     }
@@ -947,7 +950,9 @@ extern "C" int gd_attention_fwd(const void* qkv, void* o, float* lse, int B, int
 extern "C" int gd_attention_bwd(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv,
                                 float* delta_ws, int B, int N, int H, int head_dim, float scale, int dtype,
                                 int grad_order, void* stream) {
-    GD_REQUIRE(grad_order == 0 || grad_order == 1, "gd_attention_bwd: grad_order must be 0 (dq, dk, dv) or 1 (dq, dv, dk)");
+    GD_REQUIRE(grad_order >= 0 && grad_order <= 3, "gd_attention_bwd: grad_order bit 0: 0 = (dq, dk, dv), 1 = (dq, dv, dk); bit 1: dK not needed");
+    const bool no_dk = (grad_order & 2) != 0;
+    grad_order &= 1;
     GD_REQUIRE(B > 0 && N > 0 && H > 0, "gd_attention_bwd: bad shape B=%d N=%d H=%d", B, N, H);
     GD_REQUIRE(head_dim == HD, "gd_attention_bwd: head_dim must be 64 (got %d)", head_dim);
     GD_REQUIRE(dtype == GD_F32 || dtype == GD_BF16, "gd_attention_bwd: bad dtype %d", dtype);
@@ -965,7 +970,11 @@ extern "C" int gd_attention_bwd(const void* qkv, const void* o, const void* dout
         static const int dkv_env = [] { const char* e = getenv("GD_ATTN_DKV_NW"); return e ? atoi(e) : 0; }();
         const int tail = N % 256;
         const int dkv_nw = dkv_env ? dkv_env : ((N < 4096 && tail > 0 && tail <= 128) ? 4 : 8);
-        if (dkv_nw == 4)       // (two-wave 64-key blocks: 2213 us — the staging registers spill and every block re-stages all of Q / dO)
+        if (no_dk && dkv_nw == 4)
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<bf16, 4, false>), dim3(gd_cdiv(N, 128), H, B), dim3(256), 0, s, (const bf16*)qkv, (const bf16*)dout, lse, delta_ws, (bf16*)dqkv, N, H, scale, grad_order);
+        else if (no_dk)
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<bf16, 8, false>), dim3(gd_cdiv(N, 256), H, B), dim3(512), 0, s, (const bf16*)qkv, (const bf16*)dout, lse, delta_ws, (bf16*)dqkv, N, H, scale, grad_order);
+        else if (dkv_nw == 4)       // (two-wave 64-key blocks: 2213 us — the staging registers spill and every block re-stages all of Q / dO)
             hipLaunchKernelGGL((attn_bwd_dkv_kernel<bf16, 4>), dim3(gd_cdiv(N, 128), H, B), dim3(256), 0, s, (const bf16*)qkv, (const bf16*)dout, lse, delta_ws, (bf16*)dqkv, N, H, scale, grad_order);
         else
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<bf16, 8>), dim3(gd_cdiv(N, 256), H, B), dim3(512), 0, s, (const bf16*)qkv, (const bf16*)dout, lse, delta_ws, (bf16*)dqkv, N, H, scale, grad_order);

@@ -208,13 +208,14 @@ def attention_fwd(qkv, B, N, H):
     return o, lse
 
 
-def attention_bwd(qkv, o, dout, lse, B, N, H, vfirst=False):
-    """-> dqkv [B*N, 3*H*64] (same dtype as qkv), column blocks (dq, dk, dv) — or (dq, dv, dk) with vfirst."""
+def attention_bwd(qkv, o, dout, lse, B, N, H, vfirst=False, need_dk=True):
+    """-> dqkv [B*N, 3*H*64] (same dtype as qkv), column blocks (dq, dk, dv) — or (dq, dv, dk) with vfirst.  need_dk=False: the dK
+    columns are left unwritten (bf16: the dK/dV kernel then runs its dV half only)."""
     _req(dout.is_contiguous() and dout.shape == o.shape and dout.dtype == qkv.dtype, "attention_bwd: bad dout")
     dqkv = torch.empty_like(qkv)
     delta = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device)
     rc = lib().gd_attention_bwd(ptr(qkv), ptr(o), ptr(dout), ptr(lse), ptr(dqkv), ptr(delta), B, N, H, 64,
-                                64 ** -0.5, dtype_code(qkv), 1 if vfirst else 0, stream())
+                                64 ** -0.5, dtype_code(qkv), (1 if vfirst else 0) | (0 if need_dk else 2), stream())
     check(rc, "gd_attention_bwd")
     return dqkv
 

@@ -205,7 +205,8 @@ class _BlockFn(torch.autograd.Function):
         dx1 = ops.layernorm_bwd(dy2, x1, plan["ln2_w"], mean2, rstd2, dres=dx2)
         do = ops.gemm_nt(dx1, plan["wproj_t"])
         # gradient columns come back as (dq, dv, dk): the q / v LoRA factors only ever touch the first two thirds
-        dqkv = ops.attention_bwd(qkv, o, do, lse, B, Nt, H, vfirst=True)
+        # the first trainable block: no gradient flows below it, dK has no consumer (the LoRA factors contract dq and dv only)
+        dqkv = ops.attention_bwd(qkv, o, do, lse, B, Nt, H, vfirst=True, need_dk=bool(ctx.needs_input_grad[0]))
         if ctx.has_lora:
             r = at.shape[0] // 2
             bt_T = tw["bt_T"] if tw is not None else bt.to(T).contiguous()

@@ -36,6 +36,9 @@ def test_attention(dtype, tol, gtol, B, N, H):
     D = H * 64
     assert torch.equal(d2[:, :D], dqkv[:, :D]) and torch.equal(d2[:, D:2 * D], dqkv[:, 2 * D:]) and \
         torch.equal(d2[:, 2 * D:], dqkv[:, D:2 * D])
+    # need_dk=False (the first trainable block): dq and dv exactly as before, the dK columns are don't-care
+    d3 = ops.attention_bwd(qkv, o, dout, lse, B, N, H, vfirst=True, need_dk=False)
+    assert torch.equal(d3[:, :2 * D], d2[:, :2 * D])
 
 
 @pytest.mark.parametrize("dtype,tol,gtol", [(torch.float32, 2e-5, 1e-4), (torch.bfloat16, 2e-2, 4e-2)])
