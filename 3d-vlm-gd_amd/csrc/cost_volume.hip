@@ -464,6 +464,28 @@ __global__ __launch_bounds__(768) void cv_fwd_persist_kernel(CvTileParams q) {
             }
             return;
         }
+        // Rows / columns that the loss masks out (utils/functions.py:402-422 zeroes them; cv_finalize replaces their term by a
+        // constant) never need their teacher entries: their loads are pointed at the first line of the pair's map instead — still
+        // branch-free and back to back, but an L2 hit instead of HBM traffic.  With the MASt3R trainer's keypoint-patch masks
+        // (~20 % of the patches hold a keypoint) four fifths of both teacher maps are never fetched.
+        bool rk[2][4], ck[4];
+        if (q.m1 && !(DBG && (q.dbg & 32))) {
+            const unsigned char* M1 = q.m1 + (long)t.p * hw;
+            const unsigned char* M2 = q.m2 + (long)t.p * hw;
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rk[ib][r] = M1[min(t.tm * 128 + wm * 32 + ib * 16 + 4 * g + r, hw - 1)] != 0;
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) ck[jb] = M2[min(t.tn * 128 + wn * 64 + jb * 16 + c, hw - 1)] != 0;
+        } else {
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rk[ib][r] = true;
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) ck[jb] = true;
+        }
 #pragma unroll
         for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
@@ -476,9 +498,9 @@ __global__ __launch_bounds__(768) void cv_fwd_persist_kernel(CvTileParams q) {
                     for (int r = 0; r < 4; ++r) t1v[ib][jb][r] = __builtin_nontemporal_load(T1 + (long)min(row0 + r, hw - 1) * ldt + col);
                     continue;
                 }
-                t2v[ib][jb] = *(const f32x4*)(T2 + (long)col * ldt + min(row0, ldt - 4));       // ldt % 4 == 0: aligned, inside the row
+                t2v[ib][jb] = *(const f32x4*)(T2 + (ck[jb] ? (long)col * ldt + min(row0, ldt - 4) : 0L));       // ldt % 4 == 0: aligned, inside the row
 #pragma unroll
-                for (int r = 0; r < 4; ++r) t1v[ib][jb][r] = T1[(long)min(row0 + r, hw - 1) * ldt + col];
+                for (int r = 0; r < 4; ++r) t1v[ib][jb][r] = T1[rk[ib][r] ? (long)min(row0 + r, hw - 1) * ldt + col : 0L];
             }
     };
     const int dbg = DBG ? q.dbg : 0;     // diagnostics (GD_CV_DBG): 1 = no teacher loads, 2 = no epilogue math, 4 = no MFMAs
@@ -797,6 +819,8 @@ extern "C" int gd_cost_volume_kl_fwd(const void* f1, const void* f2, const float
     CvTileParams q = {};
     q.f1 = f1; q.f2 = f2; q.t1 = t1; q.t2 = t2; q.stats = stats; q.part1 = part1; q.part2 = part2;
     q.hw = hw; q.C = C; q.tiles = tiles; q.nslab = nslab; q.ldt = ldt; q.P = P;
+    static const int mask_skip = [] { const char* e = getenv("GD_CV_MASK_SKIP"); return e ? atoi(e) : 1; }();
+    if (mask_skip) { q.m1 = m1; q.m2 = m2; }      // the persistent kernel skips the teacher entries of masked-out rows / columns
     static int persist = -1;     // GD_CV_PERSIST=0: the one-tile-per-block kernel (A/B)
     if (persist < 0) { const char* e = getenv("GD_CV_PERSIST"); persist = e ? atoi(e) : 1; }
     const long rowb = (long)C * gd_dtype_size(dtype);
