@@ -398,6 +398,22 @@ def kp_gather_bwd(ngrid, kp, dout, B, Nk, gh, gw, D, sx, sy, img_h, img_w, patch
     return dg
 
 
+def lora_bwd_fused(dqv, t, bt_qv, gbt):
+    """dqv [M, K] bf16 view (row stride may exceed K), t [M, 8] f32, bt_qv [8, K] bf16, gbt [8, K] f32 (accumulated in place)
+    -> dt [M, 8] f32.  One pass over dqv for both LoRA-backward products (gd_lora_bwd_fused)."""
+    M, K = dqv.shape
+    dt = torch.empty(M, 8, dtype=torch.float32, device=dqv.device)
+    check(lib().gd_lora_bwd_fused(ptr(dqv), dqv.stride(0), ptr(t), ptr(bt_qv), ptr(dt), ptr(gbt), M, K, stream()), "gd_lora_bwd_fused")
+    return dt
+
+
+def lora_bwd_fused_supported(dqv, t, bt_qv, gbt):
+    import os
+    return (os.environ.get("GD_LORA_FUSED", "1") != "0" and dqv.dtype == torch.bfloat16 and bt_qv.dtype == torch.bfloat16
+            and t.dtype == torch.float32 and t.shape[1] == 8 and t.is_contiguous() and bt_qv.is_contiguous() and gbt.is_contiguous()
+            and dqv.stride(1) == 1 and dqv.shape[1] % 256 == 0 and dqv.shape[1] // 256 in (1, 2, 3, 4, 6, 8) and dqv.stride(0) % 8 == 0)
+
+
 def conv_weight_pack(weight, dtype, with_wu=False):
     """refine_conv weight [D, D, 3, 3] fp32 -> (wk [D, 9D] with K order (ky, kx, c), wt [D, 9D] = flipped kernel, K order (kx, ky, n),
     wu [9D, D] = wk transposed or None) in `dtype`, one kernel."""

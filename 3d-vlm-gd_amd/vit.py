@@ -212,8 +212,12 @@ class _BlockFn(torch.autograd.Function):
             bt_T = tw["bt_T"] if tw is not None else bt.to(T).contiguous()
             bt_qv = tw["bt_qv"] if tw is not None else torch.cat([bt_T[:, :D], bt_T[:, 2 * D:]], 1).contiguous()   # [2r, 2D]
             dqv = dqkv[:, :2 * D]
-            dt = ops.gemm_nt(dqv, bt_qv, out_dtype=torch.float32)                                 # [M, 2r], streams 2/3 of dqkv
-            gbt = ops.gemm_tn(t, dqv, out=z_bt)                                                   # [2r, 2D]
+            if ops.lora_bwd_fused_supported(dqv, t, bt_qv, z_bt):
+                dt = ops.lora_bwd_fused(dqv, t, bt_qv, z_bt)                                      # both products, one pass over dqv
+                gbt = z_bt
+            else:
+                dt = ops.gemm_nt(dqv, bt_qv, out_dtype=torch.float32)                             # [M, 2r], streams 2/3 of dqkv
+                gbt = ops.gemm_tn(t, dqv, out=z_bt)                                               # [2r, 2D]
             gat = ops.gemm_tn(dt, y1, out=z_at)                                                   # [2r, D]
             g_bq, g_bv = gbt[:r, :D].t(), gbt[r:, D:].t()          # strided views: the gradient gather copies them anyway
             g_aq, g_av = gat[:r], gat[r:]

@@ -57,6 +57,11 @@ int gd_attention_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, 
 int gd_attention_bwd(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, float* delta_ws,
                      int B, int N, int H, int head_dim, float scale, int dtype, int grad_order, void* stream);
 
+/* LoRA backward of one block in one pass (utils/model.py:57-71): dt [M,8] f32 = dqv [M,K] . bt^T and gbt [8,K] f32 += t^T . dqv for
+ * the bf16 (dq, dv) gradient block dqv (row stride ldx elements), t [M,8] f32 the saved rank projections, bt [8,K] bf16 the B factors
+ * transposed.  K % 256 == 0, K / 256 in {1, 2, 3, 4, 6, 8}. */
+int gd_lora_bwd_fused(const void* dqv, long ldx, const float* t, const void* bt, float* dt, float* gbt, int M, int K, void* stream);
+
 /* Dense cost-volume KL for P pairs, fused: calculate_cost_loss (src/finetune_timm_vggt.py:488-533 variant 0,
  * src/finetune_timm_mast3r.py:504-540 variant 1) = F.normalize + bmm x2 + softmax + get_masked_patch_cost
  * (utils/functions.py:402-422) + kl_divergence_map (utils/losses.py:5-15).

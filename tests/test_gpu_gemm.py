@@ -194,3 +194,25 @@ def test_gemm_nt_skinny(M, N, K):
     out = torch.zeros(M, 2 * N, dtype=torch.float32, device="cuda")
     ops.gemm_nt(sl, w, out=out[:, N:])
     assert rel_err(out[:, N:], sl.double() @ w.double().t()) < 1e-5 and float(out[:, :N].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("M,K,ldx", [(87680, 1536, 2304), (1000, 768, 768), (130, 2048, 3072), (64, 256, 256)])
+def test_lora_bwd_fused(M, K, ldx):
+    """gd_lora_bwd_fused: dt = dqv . bt^T and gbt += t^T . dqv in one pass over the (dq, dv) gradient block, against fp64 and
+    against the two streaming kernels it replaces (ragged last chunk, strided rows, accumulation into a non-zero gbt)."""
+    from gd_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(M + K)
+    buf = torch.randn(M, ldx, generator=g, device="cuda").bfloat16()
+    dqv = buf[:, :K]
+    t = torch.randn(M, 8, generator=g, device="cuda") * 0.3
+    bt = (torch.randn(8, K, generator=g, device="cuda") * 0.05).bfloat16()
+    g0 = torch.randn(8, K, generator=g, device="cuda")
+    gbt = g0.clone()
+    assert ops.lora_bwd_fused_supported(dqv, t, bt, gbt)
+    dt = ops.lora_bwd_fused(dqv, t, bt, gbt)
+    rdt = dqv.double() @ bt.double().t()
+    rg = g0.double() + t.double().t() @ dqv.double()
+    assert rel_err(dt, rdt) < 1e-5
+    assert rel_err(gbt, rg) < 2e-5
+    dt2 = ops.gemm_nt(dqv, bt, out_dtype=torch.float32)
+    assert rel_err(dt, dt2) < 1e-5

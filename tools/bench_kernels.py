@@ -186,6 +186,20 @@ def bench_ln():
     print(f"ln bwd (+dres) {t*1e6:7.1f} us  {4*M*D*2/t/1e12:5.2f} TB/s")
 
 
+def bench_lora():
+    M, D = 87680, 768
+    buf = torch.randn(M, 3 * D, device="cuda").bfloat16()
+    dqv = buf[:, :2 * D]
+    t = torch.randn(M, 8, device="cuda")
+    bt = (torch.randn(8, 2 * D, device="cuda") * 0.05).bfloat16()
+    gbt = torch.zeros(8, 2 * D, device="cuda")
+    tf = timeit(lambda: ops.lora_bwd_fused(dqv, t, bt, gbt))
+    t1 = timeit(lambda: ops.gemm_nt(dqv, bt, out_dtype=torch.float32))
+    t2 = timeit(lambda: ops.gemm_tn(t, dqv, out=gbt))
+    by = M * 2 * D * 2
+    print(f"lora bwd fused {tf*1e6:7.1f} us ({by/tf/1e12:4.2f} TB/s) | separate: dt {t1*1e6:6.1f} + gbt {t2*1e6:6.1f} = {(t1+t2)*1e6:6.1f} us")
+
+
 def bench_rank():
     """depth head losses at the bench shape: 32 pairs x 2 views x 300 keypoints, D = 768."""
     P, N, D = 32, 300, 768
@@ -285,6 +299,8 @@ if __name__ == "__main__":
         bench_rank()
     if "ln" in which:
         bench_ln()
+    if "lora" in which:
+        bench_lora()
     if "probe" in which:
         probe_gemm()
     if "adapter" in which:
