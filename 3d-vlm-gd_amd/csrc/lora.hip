@@ -41,7 +41,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
     const int K = p.K;
     // the B factors stay in LDS for the whole launch
-    for (int i = tid; i < 8 * K / 8; i += 256) *(uint4*)(sBt + i * 8) = *(const uint4*)(p.bt + i * 8);
+    const bool want_dt = p.bt != nullptr;          // bt == NULL: only gbt += t^T . X (e.g. the LoRA-A gradient dt^T . LN(x))
+    if (want_dt)
+        for (int i = tid; i < 8 * K / 8; i += 256) *(uint4*)(sBt + i * 8) = *(const uint4*)(p.bt + i * 8);
 
     f32x4 gacc[NSLAB][4];
 #pragma unroll
@@ -98,6 +100,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     }
             }
             // ---- dt: rows 16w..16w+15 of the chunk, this slab's 256 columns
+            if (want_dt)
 #pragma unroll
             for (int kc = 0; kc < LB_SLAB / 32; ++kc) {
                 const bf16x8 a = *(const bf16x8*)(sX + (16 * wave + c) * LB_ROWB + (32 * kc + 8 * g) * 2);
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
         }
         // dt of the chunk: D[row = 4g + r][col = c = rank]
-        if (c < 8) {
+        if (c < 8 && want_dt) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = chunk * LB_ROWS + 16 * wave + 4 * g + r;
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 extern "C" int gd_lora_bwd_fused(const void* dqv, long ldx, const float* t, const void* bt, float* dt, float* gbt, int M, int K,
                                  void* stream) {
     GD_REQUIRE(M > 0 && K > 0 && K % LB_SLAB == 0 && K / LB_SLAB <= 8 && ldx % 8 == 0, "gd_lora_bwd_fused: K must be a multiple of 256 (<= 2048), ldx of 8");
-    GD_REQUIRE(((uintptr_t)dqv & 15) == 0 && ((uintptr_t)bt & 15) == 0 && t && dt && gbt, "gd_lora_bwd_fused: alignment / null pointers");
+    GD_REQUIRE(((uintptr_t)dqv & 15) == 0 && ((uintptr_t)bt & 15) == 0 && t && gbt && (dt || !bt), "gd_lora_bwd_fused: alignment / null pointers");
     LoraBwdParams p = {(const bf16*)dqv, ldx, t, (const bf16*)bt, dt, gbt, M, K};
     const int nchunk = (M + LB_ROWS - 1) / LB_ROWS;
     const int grid = nchunk < 512 ? nchunk : 512;

@@ -407,10 +407,17 @@ def lora_bwd_fused(dqv, t, bt_qv, gbt):
     return dt
 
 
+def skinny_tn_mfma(t, x, out):
+    """out [8, K] f32 += t [M, 8]^T . x [M, K] (bf16 rows) on the LDS-slab MFMA kernel (gd_lora_bwd_fused with bt = NULL)."""
+    M, K = x.shape
+    check(lib().gd_lora_bwd_fused(ptr(x), x.stride(0), ptr(t), None, None, ptr(out), M, K, stream()), "gd_lora_bwd_fused")
+    return out
+
+
 def lora_bwd_fused_supported(dqv, t, bt_qv, gbt):
     import os
-    return (os.environ.get("GD_LORA_FUSED", "1") != "0" and dqv.dtype == torch.bfloat16 and bt_qv.dtype == torch.bfloat16
-            and t.dtype == torch.float32 and t.shape[1] == 8 and t.is_contiguous() and bt_qv.is_contiguous() and gbt.is_contiguous()
+    return (os.environ.get("GD_LORA_FUSED", "1") != "0" and dqv.dtype == torch.bfloat16 and (bt_qv is None or bt_qv.dtype == torch.bfloat16)
+            and t.dtype == torch.float32 and t.shape[1] == 8 and t.is_contiguous() and (bt_qv is None or bt_qv.is_contiguous()) and gbt.is_contiguous()
             and dqv.stride(1) == 1 and dqv.shape[1] % 256 == 0 and dqv.shape[1] // 256 in (1, 2, 3, 4, 6, 8) and dqv.stride(0) % 8 == 0)
 
 

@@ -218,7 +218,10 @@ class _BlockFn(torch.autograd.Function):
             else:
                 dt = ops.gemm_nt(dqv, bt_qv, out_dtype=torch.float32)                             # [M, 2r], streams 2/3 of dqkv
                 gbt = ops.gemm_tn(t, dqv, out=z_bt)                                               # [2r, 2D]
-            gat = ops.gemm_tn(dt, y1, out=z_at)                                                   # [2r, D]
+            if ops.lora_bwd_fused_supported(y1, dt, None, z_at):
+                gat = ops.skinny_tn_mfma(dt, y1, z_at)                                            # [2r, D] on the same slab kernel
+            else:
+                gat = ops.gemm_tn(dt, y1, out=z_at)                                               # [2r, D]
             g_bq, g_bv = gbt[:r, :D].t(), gbt[r:, D:].t()          # strided views: the gradient gather copies them anyway
             g_aq, g_av = gat[:r], gat[r:]
         if direct:       # already in the flat buffer (LoRA-B: GDViT.finish_trainable_grads transposes the stash once per step)

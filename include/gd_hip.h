@@ -59,7 +59,8 @@ int gd_attention_bwd(const void* qkv, const void* o, const void* dout, const flo
 
 /* LoRA backward of one block in one pass (utils/model.py:57-71): dt [M,8] f32 = dqv [M,K] . bt^T and gbt [8,K] f32 += t^T . dqv for
  * the bf16 (dq, dv) gradient block dqv (row stride ldx elements), t [M,8] f32 the saved rank projections, bt [8,K] bf16 the B factors
- * transposed.  K % 256 == 0, K / 256 in {1, 2, 3, 4, 6, 8}. */
+ * transposed.  bt == NULL: only the second product (dt may be NULL too) — any [8, K] += t^T . X with an [M, 8] f32 left operand, e.g. the
+ * LoRA-A gradient dt^T . LN(x).  K % 256 == 0, K / 256 in {1, 2, 3, 4, 6, 8}. */
 int gd_lora_bwd_fused(const void* dqv, long ldx, const float* t, const void* bt, float* dt, float* gbt, int M, int K, void* stream);
 
 /* Dense cost-volume KL for P pairs, fused: calculate_cost_loss (src/finetune_timm_vggt.py:488-533 variant 0,

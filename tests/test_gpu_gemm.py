@@ -216,3 +216,7 @@ def test_lora_bwd_fused(M, K, ldx):
     assert rel_err(gbt, rg) < 2e-5
     dt2 = ops.gemm_nt(dqv, bt, out_dtype=torch.float32)
     assert rel_err(dt, dt2) < 1e-5
+    # second product alone (bt = NULL): the LoRA-A gradient form
+    g2 = g0.clone()
+    ops.skinny_tn_mfma(t, dqv, g2)
+    assert rel_err(g2, rg) < 2e-5

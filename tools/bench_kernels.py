@@ -197,6 +197,11 @@ def bench_lora():
     t1 = timeit(lambda: ops.gemm_nt(dqv, bt, out_dtype=torch.float32))
     t2 = timeit(lambda: ops.gemm_tn(t, dqv, out=gbt))
     by = M * 2 * D * 2
+    y1 = torch.randn(M, D, device="cuda").bfloat16()
+    ga = torch.zeros(8, D, device="cuda")
+    ta = timeit(lambda: ops.skinny_tn_mfma(t, y1, ga))
+    tb = timeit(lambda: ops.gemm_tn(t, y1, out=ga))
+    print(f"gat (K = {D}): slab MFMA kernel {ta*1e6:6.1f} us | streaming kernel {tb*1e6:6.1f} us")
     print(f"lora bwd fused {tf*1e6:7.1f} us ({by/tf/1e12:4.2f} TB/s) | separate: dt {t1*1e6:6.1f} + gbt {t2*1e6:6.1f} = {(t1+t2)*1e6:6.1f} us")
 
 
