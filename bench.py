@@ -259,8 +259,15 @@ def cost_volume_roofline(job, args, dev, variant):
     Tt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     f1 = torch.randn(P, hw, D, device=dev).to(Tt).requires_grad_(True)
     f2 = torch.randn(P, hw, D, device=dev).to(Tt).requires_grad_(True)
-    m1 = torch.rand(P, hw, device=dev) > 0.3
-    m2 = torch.rand(P, hw, device=dev) > 0.3
+    # the row masks of the benched trainer, from the benched batch: keypoint-patch masks (MASt3R: src/finetune_timm_mast3r.py:515-519)
+    # or the co-view masks down-sampled to the patch grid (VGGT: src/finetune_timm_vggt.py:504-509) — as calculate_cost_loss builds them
+    h = w = args.img
+    if variant == "mast3r":
+        m1, m2 = ops.patch_mask(b["kp_1"], h, w, PATCH), ops.patch_mask(b["kp_2"], h, w, PATCH)
+    else:
+        g = h // PATCH
+        m1 = torch.nn.functional.interpolate(b["mask_1"][:, None].float(), size=(g, g), mode="nearest").reshape(P, -1) > 0
+        m2 = torch.nn.functional.interpolate(b["mask_2"][:, None].float(), size=(g, g), mode="nearest").reshape(P, -1) > 0
 
     def cv_fwd():
         with torch.no_grad():
@@ -271,8 +278,18 @@ def cost_volume_roofline(job, args, dev, variant):
         ops.cost_volume_kl(f1, f2, b["cost_1"], b["cost_2"], m1, m2, variant, tstats=b["cost_tstats"]).sum().backward()
     tf = ops.time_on_stream(cv_fwd, 2, 5)
     tfb = ops.time_on_stream(cv_fb, 2, 5)
+    # the same launch with dense random masks (70 % of the rows kept): nothing to skip, the whole teacher is read
+    d1, d2 = torch.rand(P, hw, device=dev) > 0.3, torch.rand(P, hw, device=dev) > 0.3
+
+    def cv_fwd_dense():
+        with torch.no_grad():
+            return ops.cost_volume_kl(f1, f2, b["cost_1"], b["cost_2"], d1, d2, variant, tstats=b["cost_tstats"])
+    tfd = ops.time_on_stream(cv_fwd_dense, 2, 5)
     fwd_bytes = P * (2 * hw * D * es + 2 * hw * hw * 4 + 2 * hw)
     bwd_bytes = fwd_bytes + P * 2 * hw * D * es
+    # what the kernel has to read once masked teacher rows are skipped (they never enter the loss): features + kept teacher rows + masks
+    kept = int(m1.sum()) + int(m2.sum())
+    needed_bytes = P * (2 * hw * D * es + 2 * hw) + kept * hw * 4
     traffic, src = None, None
     pmc = os.path.join(ROOT, "profiles", "r02_pmc_cost_volume_traffic.json")
     if os.path.exists(pmc) and (P, hw, D, args.dtype) == (32, 1369, 768, "bf16"):     # the configuration the PMC passes were run on
@@ -283,6 +300,11 @@ def cost_volume_roofline(job, args, dev, variant):
             "achieved": round(fwd_bytes / tf / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": round(fwd_bytes / tf / 1e9 / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_replayed_from": src,
             "algorithmic_bytes_per_launch": fwd_bytes,
+            "masks": "keypoint-patch masks of the benched batch" if variant == "mast3r" else "co-view masks of the benched batch",
+            "kept_row_fraction": round(kept / (2 * P * hw), 4), "needed_bytes_per_launch": needed_bytes,
+            "frac_of_needed_bytes": round(needed_bytes / tf / 1e9 / PEAK_HBM_GBS, 4),
+            "dense_masks": {"kept_row_fraction": 0.7, "us_per_pair_fwd": round(tfd / P * 1e6, 2),
+                            "achieved": round(fwd_bytes / tfd / 1e9, 1), "frac": round(fwd_bytes / tfd / 1e9 / PEAK_HBM_GBS, 4)},
             "us_per_pair_fwd": round(tf / P * 1e6, 2),
             "fwd_bwd_GBps": round((fwd_bytes + bwd_bytes) / tfb / 1e9, 1),
             "us_per_pair_fwd_bwd": round(tfb / P * 1e6, 2)}
