@@ -290,12 +290,15 @@ def cost_volume_roofline(job, args, dev, variant):
     # what the kernel has to read once masked teacher rows are skipped (they never enter the loss): features + kept teacher rows + masks
     kept = int(m1.sum()) + int(m2.sum())
     needed_bytes = P * (2 * hw * D * es + 2 * hw) + kept * hw * 4
-    traffic, src = None, None
-    pmc = os.path.join(ROOT, "profiles", "r02_pmc_cost_volume_traffic.json")
-    if os.path.exists(pmc) and (P, hw, D, args.dtype) == (32, 1369, 768, "bf16"):     # the configuration the PMC passes were run on
-        with open(pmc) as fh:
-            traffic = json.load(fh)["fwd_hbm_bytes_per_launch"]
-        src = "profiles/r02_pmc_cost_volume_traffic.json (FETCH_SIZE / WRITE_SIZE, separate --pmc passes, width-corrected; NOT measured in this run)"
+    # HBM traffic: replayed from the committed PMC passes of the same configuration (one file per kind of row mask)
+    def replay(name):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path) and (P, hw, D, args.dtype) == (32, 1369, 768, "bf16"):
+            with open(path) as fh:
+                return json.load(fh)["fwd_hbm_bytes_per_launch"], f"profiles/{name} (FETCH_SIZE / WRITE_SIZE, separate --pmc passes, width-corrected; NOT measured in this run)"
+        return None, None
+    traffic, src = replay("r02_pmc_cost_volume_traffic_kp.json") if variant == "mast3r" else (None, None)
+    traffic_dense, src_dense = replay("r02_pmc_cost_volume_traffic.json")
     return {"kernel": "cost_volume_kl fwd (cv_norm + cv_fwd_persist + cv_finalize; teacher-row statistics cached per pair)", "bound": "hbm",
             "achieved": round(fwd_bytes / tf / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": round(fwd_bytes / tf / 1e9 / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_replayed_from": src,
@@ -304,7 +307,9 @@ def cost_volume_roofline(job, args, dev, variant):
             "kept_row_fraction": round(kept / (2 * P * hw), 4), "needed_bytes_per_launch": needed_bytes,
             "frac_of_needed_bytes": round(needed_bytes / tf / 1e9 / PEAK_HBM_GBS, 4),
             "dense_masks": {"kept_row_fraction": 0.7, "us_per_pair_fwd": round(tfd / P * 1e6, 2),
-                            "achieved": round(fwd_bytes / tfd / 1e9, 1), "frac": round(fwd_bytes / tfd / 1e9 / PEAK_HBM_GBS, 4)},
+                            "achieved": round(fwd_bytes / tfd / 1e9, 1), "frac": round(fwd_bytes / tfd / 1e9 / PEAK_HBM_GBS, 4),
+                            "traffic": traffic_dense,
+                            "traffic_replayed_from": src_dense and src_dense + " — collected before masked teacher rows were skipped: an upper bound"},
             "us_per_pair_fwd": round(tf / P * 1e6, 2),
             "fwd_bwd_GBps": round((fwd_bytes + bwd_bytes) / tfb / 1e9, 1),
             "us_per_pair_fwd_bwd": round(tfb / P * 1e6, 2)}

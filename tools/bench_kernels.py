@@ -122,6 +122,27 @@ def pmc_cv():
     torch.cuda.synchronize()
 
 
+def pmc_cv_kp():
+    """as pmc_cv, with the MASt3R trainer's row masks: patches that hold one of 300 random keypoints (about 20 % of the rows);
+    forward only — what bench.py's `roofline_cost_volume` times."""
+    P, hw, C, img, patch = 32, 1369, 768, 518, 14
+    g = torch.Generator(device="cuda").manual_seed(0)
+    f1 = torch.randn(P, hw, C, device="cuda", generator=g).bfloat16()
+    f2 = torch.randn(P, hw, C, device="cuda", generator=g).bfloat16()
+    t1 = torch.softmax(3 * torch.randn(P, hw, hw, device="cuda", generator=g), -1)
+    t2 = torch.softmax(3 * torch.randn(P, hw, hw, device="cuda", generator=g), -1)
+    kp1 = torch.rand(P, 300, 2, device="cuda", generator=g) * (img - 1)
+    kp2 = torch.rand(P, 300, 2, device="cuda", generator=g) * (img - 1)
+    m1, m2 = ops.patch_mask(kp1, img, img, patch), ops.patch_mask(kp2, img, img, patch)
+    t1, t2 = ops.pad_teacher_maps(t1), ops.pad_teacher_maps(t2)
+    ts = ops.cost_volume_teacher_stats(t1, t2)
+    print("kept rows", int(m1.sum()), int(m2.sum()), "of", P * hw, "each")
+    with torch.no_grad():
+        for _ in range(3):
+            ops.cost_volume_kl(f1, f2, t1, t2, m1, m2, "mast3r", tstats=ts)
+    torch.cuda.synchronize()
+
+
 def bench_attn():
     for (B, N, H) in ((64, 1370, 12), (8, 6401, 12)):
         _bench_attn(B, N, H)
@@ -294,6 +315,8 @@ if __name__ == "__main__":
         bench_gelu()
     if "pmc_cv" in which:
         pmc_cv()
+    if "pmc_cv_kp" in which:
+        pmc_cv_kp()
     if "attn" in which:
         bench_attn()
     if "cva" in which:

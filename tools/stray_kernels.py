@@ -42,7 +42,9 @@ for e in ev:
     for k in e.kernels:
         if not ("at::native" in k.name or "Memcpy" in k.name or "Memset" in k.name or "rocclr" in k.name):
             continue
-        key = (" < ".join(chain[:5]), k.name[:50])
+        st = [f for f in (e.stack or []) if "site-packages" not in f and "dist-packages" not in f and "<built-in" not in f]
+        where = " <- ".join(x.strip().split("/")[-1] for x in st[:3]) if st else " < ".join(chain[:5])
+        key = (where + "   [" + chain[0] + "]", k.name[:50])
         by[key][0] += 1
         by[key][1] += k.duration
 rows = sorted(by.items(), key=lambda kv: -kv[1][1])
