@@ -164,6 +164,33 @@ __device__ __forceinline__ void tile_load(TileRegs<T, NT>& r, const char* gbase,
         r.v[i] = (row0 + rr < nvalid) ? *(const uint4*)(gbase + (long)(row0 + rr) * ld_b + cc * 16) : make_uint4(0, 0, 0, 0);
     }
 }
+// The same through a buffer resource (backward kernels): rows >= nvalid lie past the resource's last record and read as zero
+// in hardware — no per-chunk compare / exec mask / zero-fill and no 64-bit address arithmetic in the tile loop (that was 28 of the
+// dQ loop's 76 non-transcendental VALU instructions); the per-thread byte offsets are loop-invariant, the tile adds row0 * ld.
+template <typename T, int NT = 256> struct TileSrc {
+    __amdgpu_buffer_rsrc_t rs;
+    int off[AT<T>::CPR * 64 / NT];
+    int ld;
+};
+template <typename T, int NT = 256>
+__device__ __forceinline__ void tile_src_init(TileSrc<T, NT>& src, const char* gbase, long ld_b, int nvalid) {
+    constexpr int CPR = AT<T>::CPR, NCH = CPR * 64 / NT;
+    src.rs = __builtin_amdgcn_make_buffer_rsrc((void*)gbase, (short)0, (int)((long)(nvalid - 1) * ld_b + 64 * (long)sizeof(T)), 0x00020000);
+    src.ld = (int)ld_b;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = threadIdx.x + NT * i, rr = ch / CPR, cc = ch % CPR;
+        src.off[i] = rr * (int)ld_b + cc * 16;
+    }
+}
+template <typename T, int NT = 256>
+__device__ __forceinline__ void tile_load(TileRegs<T, NT>& r, const TileSrc<T, NT>& src, int row0) {
+    constexpr int NCH = AT<T>::CPR * 64 / NT;
+    const int base = row0 * src.ld;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+        r.v[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(src.rs, src.off[i] + base, 0, 0));
+}
 template <typename T, bool NAT, bool TRN, int NT = 256>
 __device__ __forceinline__ void tile_store(const TileRegs<T, NT>& r, char* sN, char* sT) {
     constexpr int CPR = AT<T>::CPR, EPC = AT<T>::EPC, ROWB = AT<T>::ROWB, NCH = CPR * 64 / NT;
@@ -551,16 +578,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const T* qkv, const
     const int ntile = (N + 63) / 64;
     auto pk0 = [&](int t) { return t * 64; };
     TileRegs<T> rk, rv;
-    tile_load<T>(rk, kb, ld_b, pk0(0), N);
-    tile_load<T>(rv, vb, ld_b, pk0(0), N);
+    TileSrc<T> ksrc, vsrc;
+    tile_src_init<T>(ksrc, kb, ld_b, N);
+    tile_src_init<T>(vsrc, vb, ld_b, N);
+    tile_load<T>(rk, ksrc, pk0(0));
+    tile_load<T>(rv, vsrc, pk0(0));
     for (int t = 0; t < ntile; ++t) {
         __syncthreads();
         tile_store<T, true, TOp<T>::kNeedT>(rk, sK, sKt);
         tile_store<T, true, false>(rv, sV, nullptr);
         __syncthreads();
         if (t + 1 < ntile) {
-            tile_load<T>(rk, kb, ld_b, pk0(t + 1), N);
-            tile_load<T>(rv, vb, ld_b, pk0(t + 1), N);
+            tile_load<T>(rk, ksrc, pk0(t + 1));
+            tile_load<T>(rv, vsrc, pk0(t + 1));
         }
         if (q0 >= N) continue;   // a wave whose 32 queries are all past N only helps staging
         f32x4 ds[2][4];
@@ -656,8 +686,11 @@ __global__ __launch_bounds__(64 * NW, NW >= 8 ? 1 : 2) void attn_bwd_dkv_kernel(
     const int ntile = (N + 63) / 64;
     auto pq0 = [&](int t) { return t * 64; };
     TileRegs<T, NT> rq, rd;
-    tile_load<T, NT>(rq, qb, ld_b, pq0(0), N);
-    tile_load<T, NT>(rd, dob, ldo_b, pq0(0), N);
+    TileSrc<T, NT> qsrc, dsrc;
+    tile_src_init<T, NT>(qsrc, qb, ld_b, N);
+    tile_src_init<T, NT>(dsrc, dob, ldo_b, N);
+    tile_load<T, NT>(rq, qsrc, pq0(0));
+    tile_load<T, NT>(rd, dsrc, pq0(0));
     float rl = 0.f, rdl = 0.f;   // next tile's lse / delta rows, prefetched with the tile
     // queries >= N: lse = +1e30 makes p = 2^(0 - 1e30) = 0 (their Q / dO rows are staged as zeros) — no mask in the loop
     const float LSE_PAD = 1e30f;
@@ -671,8 +704,8 @@ __global__ __launch_bounds__(64 * NW, NW >= 8 ? 1 : 2) void attn_bwd_dkv_kernel(
         tile_store<T, true, TOp<T>::kNeedT, NT>(rq, sQ, sQt);
         tile_store<T, true, TOp<T>::kNeedT, NT>(rd, sD, sDt);
         if (t + 1 < ntile) {
-            tile_load<T, NT>(rq, qb, ld_b, pq0(t + 1), N);
-            tile_load<T, NT>(rd, dob, ldo_b, pq0(t + 1), N);
+            tile_load<T, NT>(rq, qsrc, pq0(t + 1));
+            tile_load<T, NT>(rd, dsrc, pq0(t + 1));
         }
         if (threadIdx.x < 64) { sL[threadIdx.x] = -rl * 1.4426950408889634f; sDl[threadIdx.x] = -rdl; }   // negated: accumulator seeds
         if (t + 1 < ntile && threadIdx.x < 64) {
