@@ -394,7 +394,29 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const bf16* qkv, b
     }
     // DMA: wave w moves pieces 2w, 2w+1 (8 rows each) of the K tile and of the V tile
     const int prow = lane >> 3, pchunk = lane & 7;
+    // per-piece source pointers of tile 0 (loop-invariant); a full tile adds the scalar k0 * ld_b — the clamped form (one 64-bit
+    // multiply per piece: 10 VALU instructions, two of them quarter-rate) is only needed for the partial last tile
+    const char* kp[2];
+    const char* vp_[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 2 + i) * 8 + prow;
+        const long off = (long)row * ld_b + ((pchunk ^ AT<bf16>::sw(row)) * 16);
+        kp[i] = kb + off;
+        vp_[i] = vb + off;
+    }
     auto issue = [&](int k0, int slot) {
+        if (k0 + 64 <= N) {
+            const unsigned long t0 = (unsigned)k0 * (unsigned)ld_b;     // 32-bit scalar product (an image's qkv rows span < 2^31 bytes)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kp[i] + t0),
+                                                 (__attribute__((address_space(3))) void*)(smem + slot * TILE + (wave * 2 + i) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vp_[i] + t0),
+                                                 (__attribute__((address_space(3))) void*)(smem + (3 + slot) * TILE + (wave * 2 + i) * 1024), 16, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = (wave * 2 + i) * 8 + prow;
@@ -433,14 +455,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const bf16* qkv, b
     auto pk0 = [&](int t) { return (t < nfull ? (t + rot >= nfull ? t + rot - nfull : t + rot) : t) * 64; };
     issue(pk0(0), 0);
     if (ntile > 1) issue(pk0(1), 1);
+    int slot = 0;            // t % 3, kept as a running scalar (the modulo was strength-reduced into per-address VALU fix-ups)
     auto key_tile = [&](int t, auto tail_tag) {
         constexpr bool tail = decltype(tail_tag)::value;
-        const int k0 = pk0(t), slot = t % 3;
+        const int k0 = pk0(t);
         if (t + 1 < ntile) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // tile t landed; tile t+1 may still fly
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();            // everyone's pieces of tile t landed; everyone is done with tile t-1's slot
         asm volatile("" ::: "memory");
-        if (t + 2 < ntile) issue(pk0(t + 2), (t + 2) % 3);
+        if (t + 2 < ntile) issue(pk0(t + 2), slot == 0 ? 2 : slot - 1);
         if (q0 >= N) return;      // (lambda) a wave whose 32 queries are all past N only moves its DMA pieces
         const unsigned kbase = lds0 + slot * TILE, vbase = lds0 + (3 + slot) * TILE;
         f32x4 kr[4][2];
@@ -490,7 +513,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const bf16* qkv, b
         }
     };
     int t = 0;
-    for (; (t + 1) * 64 <= N; ++t) key_tile(t, std::false_type{});
+    for (; (t + 1) * 64 <= N; ++t) {
+        key_tile(t, std::false_type{});
+        slot = slot == 2 ? 0 : slot + 1;
+    }
     if (t * 64 < N) key_tile(t, std::true_type{});
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
