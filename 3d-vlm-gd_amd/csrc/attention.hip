@@ -990,6 +990,7 @@ extern "C" int gd_attention_fwd(const void* qkv, void* o, float* lse, int B, int
                                 int dtype, void* stream) {
     GD_REQUIRE(B > 0 && N > 0 && H > 0, "gd_attention_fwd: bad shape B=%d N=%d H=%d", B, N, H);
     GD_REQUIRE(head_dim == HD, "gd_attention_fwd: head_dim must be 64 (got %d)", head_dim);
+    GD_REQUIRE((long)N * 3 * H * HD * 4 < (1L << 31), "gd_attention_fwd: one image's qkv rows must span < 2^31 bytes (32-bit tile offsets): N=%d H=%d", N, H);
     GD_REQUIRE(dtype == GD_F32 || dtype == GD_BF16, "gd_attention_fwd: bad dtype %d", dtype);
     GD_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)o & 15) == 0, "gd_attention_fwd: pointers must be 16-byte aligned");
     dim3 grid(gd_cdiv(N, 128), H, B);
@@ -1014,6 +1015,7 @@ extern "C" int gd_attention_bwd(const void* qkv, const void* o, const void* dout
     grad_order &= 1;
     GD_REQUIRE(B > 0 && N > 0 && H > 0, "gd_attention_bwd: bad shape B=%d N=%d H=%d", B, N, H);
     GD_REQUIRE(head_dim == HD, "gd_attention_bwd: head_dim must be 64 (got %d)", head_dim);
+    GD_REQUIRE((long)N * 3 * H * HD * 4 < (1L << 31), "gd_attention_bwd: one image's qkv rows must span < 2^31 bytes (32-bit tile offsets): N=%d H=%d", N, H);
     GD_REQUIRE(dtype == GD_F32 || dtype == GD_BF16, "gd_attention_bwd: bad dtype %d", dtype);
     GD_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)dout & 15) == 0 && ((uintptr_t)dqkv & 15) == 0,
                "gd_attention_bwd: pointers must be 16-byte aligned");
