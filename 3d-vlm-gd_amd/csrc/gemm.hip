@@ -374,10 +374,10 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(GemmNtParams p)
 #include "gemm_persist.h"
 
 static unsigned long long* g_probe = nullptr;
-extern "C" int gd_gemm_phase_probe(int enable, unsigned long long* out4) {
-    if (out4 && g_probe) {
+extern "C" int gd_gemm_phase_probe(int enable, unsigned long long* out6) {
+    if (out6 && g_probe) {
         hipDeviceSynchronize();
-        hipMemcpy(out4, g_probe, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        hipMemcpy(out6, g_probe, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost);   // wait, main, epilogue, tiles, dma-issue, stage-barrier wait
     }
     if (enable && !g_probe) {
         GD_REQUIRE(hipMalloc(&g_probe, 8 * sizeof(unsigned long long)) == hipSuccess, "gd_gemm_phase_probe: hipMalloc failed");

@@ -216,7 +216,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
     // VMEM instructions every wave issues unconditionally in one epilogue (buffer ops, range-checked by the hardware)
     int after = 0;   // of those, how many were issued after this tile's stage-1 DMA (0 for the block's first tile)
 
-    unsigned long long pc0 = 0, pw = 0, pm = 0, pe = 0, pn = 0, pd = 0;
+    unsigned long long pc0 = 0, pw = 0, pm = 0, pe = 0, pn = 0, pd = 0, pb = 0;
     for (;;) {
         if (p.probe) pc0 = __builtin_amdgcn_s_memtime();
         f32x4 acc[WMT][4];
@@ -271,10 +271,20 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
             chunk_rows67<T>(P, tl, acc);
             chunk_rows05<T>(Q, tl, sbo + abase + co1, acc);
             // every LDS read of stage kt is done: stage barrier (stage kt+1 landed, slot kt&1 free), then refill the slot
+#ifdef GD_GEMM_STAGE_PROBE
+            unsigned long long pb0 = 0;
+            if (p.probe) pb0 = __builtin_amdgcn_s_memtime();
+#endif
             if (kt == 0) wait_vm_le(after);   // stage 1 is older than the previous epilogue's stores: those may still drain
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+#ifdef GD_GEMM_STAGE_PROBE
+            // -DGD_GEMM_STAGE_PROBE builds only (the two s_memtime reads in the K loop cost 20 % even unarmed): the time this wave
+            // spends between its last LDS read of stage kt and the stage barrier = DMA landing wait + barrier skew.  Measured
+            // 0.40 of the main loop on every shape (87 680 x 3072 x 768: 14.0 k of 35.5 k cycles per tile; 4096^3: 76.7 k of 191.6 k)
+            if (p.probe) pb += __builtin_amdgcn_s_memtime() - pb0;
+#endif
             if (kt + 2 < nk) issue(kt + 2, kt & 1);
             if (kt + 1 < nk) frag_head_issue(P, nsbo + abase + co0, nsbo + bbase + co0);
             chunk_rows67<T>(Q, tl, acc);
@@ -386,6 +396,6 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
         if (!more) break;
     }
     if (p.probe && tid == 0) {
-        atomicAdd(p.probe + 0, pw); atomicAdd(p.probe + 1, pm); atomicAdd(p.probe + 2, pe); atomicAdd(p.probe + 3, pn); atomicAdd(p.probe + 4, pd);
+        atomicAdd(p.probe + 0, pw); atomicAdd(p.probe + 1, pm); atomicAdd(p.probe + 2, pe); atomicAdd(p.probe + 3, pn); atomicAdd(p.probe + 4, pd); atomicAdd(p.probe + 5, pb);
     }
 }

@@ -24,10 +24,11 @@ const char* gd_last_error(void);
 int gd_abi_version(void);
 
 /* Diagnostic (no reference counterpart): per-phase shader-clock cycles of the persistent gemm_nt kernel.
- * enable=1 arms the probe for subsequent gd_gemm_nt calls, enable=0 disarms it; out5 (host, may be NULL) receives the
+ * enable=1 arms the probe for subsequent gd_gemm_nt calls, enable=0 disarms it; out6 (host, SIX values, may be NULL) receives the
  * sums over blocks since arming: [0] waiting for a tile's first K stage, [1] main loop, [2] epilogue items,
- * [3] tiles, [4] epilogue set-up + next-tile DMA issue. */
-int gd_gemm_phase_probe(int enable, unsigned long long* out5);
+ * [3] tiles, [4] epilogue set-up + next-tile DMA issue, [5] the part of [1] spent in the per-K-step `s_waitcnt vmcnt` + barrier
+ * (0 unless the library is built with -DGD_GEMM_STAGE_PROBE). */
+int gd_gemm_phase_probe(int enable, unsigned long long* out6);
 
 /* C[M,N] = epilogue(alpha * A[M,K] . W[N,K]^T); replaces torch nn.Linear / torch.bmm on the student path
  * (timm VisionTransformer qkv/proj/fc1/fc2, utils/model.py:57-71 LoRA, :7-25 Adapter; src/finetune_timm_vggt.py:516-517).

@@ -251,8 +251,8 @@ def probe_gemm():
     import ctypes
     from gd_amd import _lib
     L = _lib.lib()
-    out = (ctypes.c_ulonglong * 5)()
-    cases = [("a0", 87680, 3072, 768, {}), ("a0", 87680, 768, 3072, {}), ("a0", 87680, 768, 768, {}),
+    out = (ctypes.c_ulonglong * 6)()
+    cases = [("a0", 87680, 3072, 768, {}), ("a0", 87680, 768, 3072, {}), ("a0", 87680, 768, 768, {}), ("a0", 4096, 4096, 4096, {}),
              ("ba1", 87680, 3072, 768, dict(bias=True, act=1)), ("bpa1", 87680, 3072, 768, dict(bias=True, act=1, preact=True)),
              ("da0", 87680, 3072, 768, dict(dact=True)), ("bra0", 87680, 768, 3072, dict(bias=True, residual=True))]
     for tag, M, N, K, o in cases:
@@ -271,7 +271,7 @@ def probe_gemm():
         f()
         L.gd_gemm_phase_probe(0, out)
         n = max(out[3], 1)
-        print(f"probe {tag:5s} {M}x{N}x{K}: {t*1e6:7.1f} us {2*M*N*K/t/1e12:7.1f} TF/s | shader-clock cycles per tile: wait {out[0]/n:8.1f}  main {out[1]/n:8.1f}  dma-issue {out[4]/n:8.1f}  epi {out[2]/n:8.1f}  tiles/blk {n/256:5.2f}")
+        print(f"probe {tag:5s} {M}x{N}x{K}: {t*1e6:7.1f} us {2*M*N*K/t/1e12:7.1f} TF/s | shader-clock cycles per tile: wait {out[0]/n:8.1f}  main {out[1]/n:8.1f}  dma-issue {out[4]/n:8.1f}  epi {out[2]/n:8.1f}  tiles/blk {n/256:5.2f} | of main: stage waits (vmcnt + barrier) {out[5]/n:8.1f} = {out[5]/max(out[1],1):.3f}")
 
 
 def pmc_attn():
