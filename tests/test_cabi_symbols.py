@@ -68,3 +68,18 @@ def test_ctypes_signatures_match_the_header():
         hret, hargs = protos[name]
         assert [_ctype_kind(a) for a in args] == hargs, (name, [_ctype_kind(a) for a in args], hargs)
         assert _ctype_kind(res) == hret, (name, res, hret)
+
+
+def test_argument_checks_fail_loudly_without_touching_the_device():
+    """Shape / layout guards run before any HIP call: an entry point handed an unsupported problem returns non-zero and
+    leaves a message in gd_last_error (src/.../curope.cpp:49-69 is the reference's convention: TORCH_CHECK before dispatch)."""
+    import gd_amd
+    from gd_amd import _lib
+    L = _lib.lib()
+    # one image's qkv rows must span < 2^31 bytes (the attention kernels use 32-bit tile offsets): 200 000 tokens x 16 heads
+    rc = L.gd_attention_fwd(None, None, None, 1, 200000, 16, 64, ctypes.c_float(0.125), _lib.BF16, None)
+    assert rc != 0 and b"2^31" in L.gd_last_error()
+    rc = L.gd_attention_bwd(None, None, None, None, None, None, 1, 200000, 16, 64, ctypes.c_float(0.125), _lib.BF16, 0, None)
+    assert rc != 0 and b"2^31" in L.gd_last_error()
+    rc = L.gd_attention_fwd(None, None, None, 1, 16, 2, 32, ctypes.c_float(0.125), _lib.BF16, None)      # head_dim != 64
+    assert rc != 0 and b"head_dim" in L.gd_last_error()
