@@ -158,9 +158,14 @@ def gemm_roofline(prof, dtype, dt, steps):
     ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     kname = "gemm_nt_persist_kernel<bf16> (256x256 persistent tile kernel, all epilogue instantiations)" if dtype == "bf16" \
         else "gemm_nt_kernel<float> (128x128 tiles, exact-f32 MFMA v_mfma_f32_16x16x4_f32)"
-    return {"kernel": kname, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_TFLOPS[dtype], 4), "traffic": None, "launches": n,
-            "avg_launch_us": round(ms / max(n, 1) * 1e3, 2), "share_of_step": round(ms / (dt * 1e3), 3)}
+    out = {"kernel": kname, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
+           "frac": round(ach / PEAK_TFLOPS[dtype], 4), "traffic": None, "launches": n,
+           "avg_launch_us": round(ms / max(n, 1) * 1e3, 2), "share_of_step": round(ms / (dt * 1e3), 3)}
+    if dtype == "bf16":
+        # context, not the yardstick: what back-to-back 16x16x32 bf16 MFMAs (two waves per SIMD, operands in registers, no memory
+        # traffic) sustain on this part under its power limit — tools/micro/mfma_gap.hip, profiles/r02_micro_mfma_gap.txt
+        out["measured_mfma_only_ceiling"] = {"tflops": 2327.6, "frac_of_it": round(ach / 2327.6, 4), "source": "profiles/r02_micro_mfma_gap.txt (NOT measured in this run)"}
+    return out
 
 
 def main():
