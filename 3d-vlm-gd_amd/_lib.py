@@ -17,6 +17,8 @@ c_int, c_long, c_float, c_void_p, c_size_t = ctypes.c_int, ctypes.c_long, ctypes
 SIGNATURES = {
     "gd_last_error": (ctypes.c_char_p, []),
     "gd_abi_version": (c_int, []),
+    "gd_debug_set": (c_int, [ctypes.c_char_p, c_int]),
+    "gd_debug_get": (c_int, [ctypes.c_char_p]),
     "gd_gemm_phase_probe": (c_int, [c_int, c_void_p]),
     "gd_gemm_nt": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_long, c_long,
                            c_int, c_long, c_long, c_long, c_int, c_int, c_float,
@@ -35,6 +37,8 @@ SIGNATURES = {
     "gd_l2norm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "gd_patch_im2col": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                 ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_int, c_void_p]),
+    "gd_patch_im2col_strided": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                        ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_int, c_void_p]),
     "gd_assemble_tokens": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "gd_im2col3x3": (c_int, [c_void_p, c_long, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "gd_col2im3x3": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_void_p]),
@@ -82,6 +86,7 @@ SIGNATURES = {
                                    c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "gd_clip_adamw_ranges": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_float, c_float, c_float,
                                      c_float, c_float, c_float, c_float, c_void_p, c_void_p, ctypes.POINTER(c_long), c_int, c_void_p]),
+    "gd_comm_rccl_version": (c_int, []),
     "gd_comm_unique_id": (c_int, [c_void_p]),
     "gd_comm_init": (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, c_void_p]),
     "gd_comm_destroy": (c_int, [c_void_p]),

@@ -315,10 +315,8 @@ __global__ __launch_bounds__(256, 1) void adapter_persist_kernel(const bf16* __r
 template <int D>
 static void adapter_launch(const void* x, const void* w1, const void* w2, const void* gate, void* hout, void* out, int M,
                            hipStream_t s) {
-    static const int persist = getenv("GD_ADAPTER_PERSIST") ? atoi(getenv("GD_ADAPTER_PERSIST")) : 1;
+    const int persist = gd_knobs().adapter_persist, cus = gd_knobs().ncu;
     if (persist && M >= 256 * AD_BM * 4) {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         hipLaunchKernelGGL(adapter_persist_kernel<D>, dim3(min(cus * persist, gd_cdiv(M, AD_BM))), dim3(256), 0, s, (const bf16*)x, (const bf16*)w1,
                            (const bf16*)w2, (const bf16*)gate, (bf16*)hout, (bf16*)out, M);
         return;

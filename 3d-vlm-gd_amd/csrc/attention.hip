@@ -994,10 +994,9 @@ extern "C" int gd_attention_fwd(const void* qkv, void* o, float* lse, int B, int
     GD_REQUIRE(dtype == GD_F32 || dtype == GD_BF16, "gd_attention_fwd: bad dtype %d", dtype);
     GD_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)o & 15) == 0, "gd_attention_fwd: pointers must be 16-byte aligned");
     dim3 grid(gd_cdiv(N, 128), H, B);
-    static int dma = -1;   // GD_ATTN_DMA=0: the register-staged forward kernel (A/B testing)
-    if (dma < 0) { const char* e = getenv("GD_ATTN_DMA"); dma = e ? atoi(e) : 1; }
+    const int dma = gd_knobs().attn_dma;   // GD_ATTN_DMA=0: the register-staged forward kernel (A/B testing)
     if (dtype == GD_BF16 && dma)
-        { static int ro = -1; if (ro < 0) { const char* e = getenv("GD_ATTN_ROT"); ro = e ? atoi(e) : 1; }
+        { const int ro = gd_knobs().attn_rot;
           hipLaunchKernelGGL(attn_fwd_dma_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, ro); }
     else if (dtype == GD_BF16)
         hipLaunchKernelGGL(attn_fwd_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale);
@@ -1028,7 +1027,7 @@ extern "C" int gd_attention_bwd(const void* qkv, const void* o, const void* dout
         // 256-key block would be less than half full: N = 1370 pads to 1408 keys instead of 1536 (2.7 % instead of 10.8 %):
         // backward 1574 -> 1514 us at 64 x 12 x 1370; at N = 6401 (long sweeps, 0.4 % vs 2 % padding) the 8-wave form is 2 % faster.
         // GD_ATTN_DKV_NW = 4 | 8 forces one form.
-        static const int dkv_env = [] { const char* e = getenv("GD_ATTN_DKV_NW"); return e ? atoi(e) : 0; }();
+        const int dkv_env = gd_knobs().attn_dkv_nw;
         const int tail = N % 256;
         const int dkv_nw = dkv_env ? dkv_env : ((N < 4096 && tail > 0 && tail <= 128) ? 4 : 8);
         if (no_dk && dkv_nw == 4)

@@ -2,6 +2,8 @@
 #include "gd_common.h"
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
 
 static thread_local char g_err[512] = "";
 
@@ -13,4 +15,48 @@ void gd_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* gd_last_error(void) { return g_err; }
+
+// ---- options: one table, read once ----
+struct KnobDef { const char* name; const char* env; int GdKnobs::*field; int def; };
+static const KnobDef KNOBS[] = {
+    {"gemm_persist", "GD_GEMM_PERSIST", &GdKnobs::gemm_persist, 1},       {"gemm_small_tiles", "GD_GEMM_SMALL_TILES", &GdKnobs::gemm_small_tiles, 0},
+    {"gemm_f32_big", "GD_GEMM_F32_BIG", &GdKnobs::gemm_f32_big, 0},       {"gemm_cstore", "GD_GEMM_CSTORE", &GdKnobs::gemm_cstore, 1},
+    {"gemm_krot", "GD_GEMM_KROT", &GdKnobs::gemm_krot, 1},                {"tn_blocks", "GD_TN_BLOCKS", &GdKnobs::tn_blocks, 0},
+    {"attn_dma", "GD_ATTN_DMA", &GdKnobs::attn_dma, 1},                   {"attn_rot", "GD_ATTN_ROT", &GdKnobs::attn_rot, 1},
+    {"attn_dkv_nw", "GD_ATTN_DKV_NW", &GdKnobs::attn_dkv_nw, 0},          {"cv_mask_skip", "GD_CV_MASK_SKIP", &GdKnobs::cv_mask_skip, 1},
+    {"cv_persist", "GD_CV_PERSIST", &GdKnobs::cv_persist, 1},             {"cv_dbg", "GD_CV_DBG", &GdKnobs::cv_dbg, 0},
+    {"cv_grid", "GD_CV_GRID", &GdKnobs::cv_grid, 0},                      {"pair_rank_wave", "GD_PAIR_RANK_WAVE", &GdKnobs::pair_rank_wave, 0},
+    {"ln_16b", "GD_LN_16B", &GdKnobs::ln_16b, 1},                         {"adapter_persist", "GD_ADAPTER_PERSIST", &GdKnobs::adapter_persist, 1},
+};
+
+GdKnobs& gd_knobs_mut() {
+    static GdKnobs k = [] {
+        GdKnobs v = {};
+        for (const KnobDef& d : KNOBS) {
+            const char* e = getenv(d.env);
+            v.*(d.field) = e ? atoi(e) : d.def;
+        }
+        v.ncu = 256;
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            v.ncu = cus;
+        return v;
+    }();
+    return k;
+}
+
+extern "C" int gd_debug_set(const char* name, int value) {
+    GD_REQUIRE(name != nullptr, "gd_debug_set: null name");
+    for (const KnobDef& d : KNOBS)
+        if (strcmp(d.name, name) == 0) { gd_knobs_mut().*(d.field) = value; return 0; }
+    gd_set_error("gd_debug_set: unknown option '%s'", name);
+    return -1;
+}
+extern "C" int gd_debug_get(const char* name) {
+    if (name)
+        for (const KnobDef& d : KNOBS)
+            if (strcmp(d.name, name) == 0) return gd_knobs().*(d.field);
+    gd_set_error("gd_debug_get: unknown option '%s'", name ? name : "(null)");
+    return -1;
+}
 extern "C" int gd_abi_version(void) { return 1; }

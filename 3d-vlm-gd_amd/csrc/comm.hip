@@ -1,12 +1,16 @@
 // flat_allreduce (SURVEY 8b op list, 8e): the ONE exchange of the data-parallel step — a sum over ranks of the flat fp32
-// gradient buffer (25.6 MB for ViT-B) — directly on RCCL over xGMI, behind the C ABI.  Replaces Lightning DDP's bucketed
-// all-reduce (src/main.py:147-151).  RCCL is bound at run time (dlopen / dlsym of librccl.so: a process that already
-// carries torch's RCCL re-uses that one copy; nothing here links against it), so the library loads on boxes without it and
-// the entry points fail loudly there.
-//   algo 0: one ncclAllReduce (RCCL picks ring / tree / direct for the message size and topology);
-//   algo 1: reduce-scatter + all-gather in place on the rank's 1/nranks slice — on the fully connected 8-GPU xGMI mesh each
-//           of the two phases moves (n / nranks) floats over every one of the 7 links at once (~7x less time on the
-//           wire than a ring for this message size); n must be a multiple of nranks.
+// gradient buffer (25.6 MB for ViT-B) — on RCCL over xGMI, behind the C ABI.  Replaces Lightning DDP's bucketed
+// all-reduce (src/main.py:147-151).  RCCL is bound at run time (dlopen / dlsym; nothing here links against it), so the
+// library loads on boxes without it and the entry points fail loudly there.  The copy a process already carries is re-used:
+// loaded libraries are matched by SONAME, torch-ROCm's bundled RCCL is `librccl.so.1`, so that name is tried first with
+// RTLD_NOLOAD, then loaded, and the unversioned development name only as a last resort (a second, different-version RCCL in
+// one process would make the hard-coded enum values and the 128-byte unique id below a guess); ncclGetVersion is checked.
+//   algo 0: one ncclAllReduce;
+//   algo 1: ncclReduceScatter + ncclAllGather in place on the rank's 1/nranks slice (n must be a multiple of nranks).
+// In both forms RCCL chooses the schedule (ring / tree / direct) for the message size and topology: algo 1 is an all-reduce
+// spelled in two calls, NOT the hand-written one-hop exchange over the fully connected xGMI mesh that SURVEY 5 sketches (every
+// rank pushing slice j straight to rank j over its own link).  That form needs peer-mapped buffers (hipIpc) and a multi-GPU
+// node to validate; none was available in rounds 1-3, so it is not built and nothing here claims its wire time.
 #include "gd_common.h"
 #include <dlfcn.h>
 #include <string.h>
@@ -24,20 +28,30 @@ static struct {
     int (*ReduceScatter)(const void*, void*, size_t, int, int, gd_nccl_comm, hipStream_t);
     int (*AllGather)(const void*, void*, size_t, int, gd_nccl_comm, hipStream_t);
     const char* (*GetErrorString)(int);
+    int (*GetVersion)(int*);
+    int version;
 } R;
 
 static int rccl_bind() {
     if (R.h) return 0;
-    void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);      // the copy this process already carries (torch's)
     if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) { gd_set_error("flat_allreduce: cannot load librccl.so (%s)", dlerror()); return -1; }
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) { gd_set_error("flat_allreduce: cannot load librccl.so.1 / librccl.so (%s)", dlerror()); return -1; }
 #define GD_SYM(field, name)                                                                         \
     *(void**)(&R.field) = dlsym(h, name);                                                           \
     if (!R.field) { gd_set_error("flat_allreduce: librccl.so has no symbol %s", name); return -1; }
     GD_SYM(GetUniqueId, "ncclGetUniqueId") GD_SYM(CommInitRank, "ncclCommInitRank") GD_SYM(CommDestroy, "ncclCommDestroy")
     GD_SYM(AllReduce, "ncclAllReduce") GD_SYM(ReduceScatter, "ncclReduceScatter") GD_SYM(AllGather, "ncclAllGather")
-    GD_SYM(GetErrorString, "ncclGetErrorString")
+    GD_SYM(GetErrorString, "ncclGetErrorString") GD_SYM(GetVersion, "ncclGetVersion")
 #undef GD_SYM
+    // ncclFloat32 = 7, ncclSum = 0 and NCCL_UNIQUE_ID_BYTES = 128 hold for every NCCL / RCCL 2.x; anything else is refused
+    int ver = 0;
+    if (R.GetVersion(&ver) != 0 || ver < 20000 || ver >= 30000) {
+        gd_set_error("flat_allreduce: unsupported RCCL version code %d (built against the 2.x ABI)", ver);
+        return -1;
+    }
+    R.version = ver;
     R.h = h;
     return 0;
 }
@@ -54,6 +68,11 @@ extern "C" int gd_comm_unique_id(void* out128) {
     GD_NCCL(R.GetUniqueId(&id), "gd_comm_unique_id");
     memcpy(out128, id.internal, 128);
     return 0;
+}
+
+extern "C" int gd_comm_rccl_version(void) {
+    if (rccl_bind()) return -1;
+    return R.version;
 }
 
 extern "C" int gd_comm_init(void** comm, int nranks, int rank, const void* id128) {

@@ -819,21 +819,17 @@ extern "C" int gd_cost_volume_kl_fwd(const void* f1, const void* f2, const float
     CvTileParams q = {};
     q.f1 = f1; q.f2 = f2; q.t1 = t1; q.t2 = t2; q.stats = stats; q.part1 = part1; q.part2 = part2;
     q.hw = hw; q.C = C; q.tiles = tiles; q.nslab = nslab; q.ldt = ldt; q.P = P;
-    static const int mask_skip = [] { const char* e = getenv("GD_CV_MASK_SKIP"); return e ? atoi(e) : 1; }();
-    if (mask_skip) { q.m1 = m1; q.m2 = m2; }      // the persistent kernel skips the teacher entries of masked-out rows / columns
-    static int persist = -1;     // GD_CV_PERSIST=0: the one-tile-per-block kernel (A/B)
-    if (persist < 0) { const char* e = getenv("GD_CV_PERSIST"); persist = e ? atoi(e) : 1; }
+    if (gd_knobs().cv_mask_skip) { q.m1 = m1; q.m2 = m2; }      // the persistent kernel skips the teacher entries of masked-out rows / columns
+    const int persist = gd_knobs().cv_persist;     // GD_CV_PERSIST=0: the one-tile-per-block kernel (A/B)
     const long rowb = (long)C * gd_dtype_size(dtype);
     if (persist && rowb % 128 == 0 && rowb / 128 >= 3 && ldt % 4 == 0 && ((uintptr_t)t1 & 15) == 0 && ((uintptr_t)t2 & 15) == 0) {
         int ncu = 256;
-        static int cached_cu = 0;
-        if (!cached_cu) { int dev = 0; hipGetDevice(&dev); hipDeviceGetAttribute(&cached_cu, hipDeviceAttributeMultiprocessorCount, dev); }
-        if (cached_cu >= 8) ncu = cached_cu / 8 * 8;
+        if (gd_knobs().ncu >= 8) ncu = gd_knobs().ncu / 8 * 8;
         const long total = (long)P * tiles * tiles;
         int grid = (int)(total < ncu ? (total + 7) / 8 * 8 : ncu);
-        if (const char* e = getenv("GD_CV_DBG")) q.dbg = atoi(e);
-        if (const char* e = getenv("GD_CV_GRID")) {      // tests: few blocks, so that every block walks many tiles
-            const int gv = atoi(e) / 8 * 8;
+        q.dbg = gd_knobs().cv_dbg;
+        if (gd_knobs().cv_grid) {      // tests (gd_debug_set): few blocks, so that every block walks many tiles
+            const int gv = gd_knobs().cv_grid / 8 * 8;
             if (gv >= 8 && gv < grid) grid = gv;
         }
         if (q.dbg && dtype == GD_BF16) hipLaunchKernelGGL((cv_fwd_persist_kernel<bf16, true>), dim3(grid), dim3(768), 0, s, q);

@@ -12,10 +12,12 @@
 // become multiplies), 0 = run-time P.
 template <typename T, int PC>
 __global__ __launch_bounds__(256) void patch_im2col_kernel(const float* img, T* col, int B, int h, int w, int H,
-                                                           int W, int Prt, int Kp, float m0, float m1, float m2,
-                                                           float s0, float s1, float s2) {
+                                                           int W, int Prt, int Kp, int sty, int stx, float m0, float m1,
+                                                           float m2, float s0, float s1, float s2) {
     const int P = PC ? PC : Prt;
-    const int gw = W / P, gh = H / P;
+    // stride == P: the timm PatchEmbed grid; stride < P: overlapping patches (src/evaluate_timm.py:262-266 overrides
+    // patch_embed.proj.stride for dense tracking features) — 1 + (H - P) / stride positions per axis
+    const int gw = 1 + (W - P) / stx, gh = 1 + (H - P) / sty;
     const long rows = (long)B * gh * gw;
     const float sy = (float)h / (float)H, sx = (float)w / (float)W;
     const bool same = h == H && w == W;
@@ -27,7 +29,7 @@ __global__ __launch_bounds__(256) void patch_im2col_kernel(const float* img, T* 
             float v = 0.f;
             if (k < 3 * P * P) {
                 const int c = k / (P * P), py = (k / P) % P, px = k % P;
-                const int Y = gy * P + py, X = gx * P + px;
+                const int Y = gy * sty + py, X = gx * stx + px;
                 const float* src = img + (b * 3 + c) * h * w;
                 float pix;
                 if (same) {
@@ -434,16 +436,23 @@ __global__ __launch_bounds__(256) void unpitch_kernel(const T* src, T* dst, int 
 }
 
 // ---------------------------------------------------------------------------------------------------
-extern "C" int gd_patch_im2col(const float* img, void* col, int B, int h, int w, int H, int W, int P, int Kp,
-                               const float* mean3, const float* std3, int dtype, void* stream) {
-    GD_REQUIRE(B > 0 && H % P == 0 && W % P == 0 && Kp >= 3 * P * P, "gd_patch_im2col: bad geometry H=%d W=%d P=%d Kp=%d", H, W, P, Kp);
-    const long rows = (long)B * (H / P) * (W / P);
-#define GD_PI2C(TT, PCV) hipLaunchKernelGGL((patch_im2col_kernel<TT, PCV>), dim3((unsigned)(rows < 65536 * 4 ? rows : 65536 * 4)), dim3(256), 0, (hipStream_t)stream, img, (TT*)col, B, h, w, H, W, P, Kp, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2])
+extern "C" int gd_patch_im2col_strided(const float* img, void* col, int B, int h, int w, int H, int W, int P, int stride_y,
+                                       int stride_x, int Kp, const float* mean3, const float* std3, int dtype, void* stream) {
+    GD_REQUIRE(B > 0 && P > 0 && H >= P && W >= P && stride_y > 0 && stride_x > 0 && Kp >= 3 * P * P,
+               "gd_patch_im2col: bad geometry H=%d W=%d P=%d stride=(%d,%d) Kp=%d", H, W, P, stride_y, stride_x, Kp);
+    const long rows = (long)B * (1 + (H - P) / stride_y) * (1 + (W - P) / stride_x);
+#define GD_PI2C(TT, PCV) hipLaunchKernelGGL((patch_im2col_kernel<TT, PCV>), dim3((unsigned)(rows < 65536 * 4 ? rows : 65536 * 4)), dim3(256), 0, (hipStream_t)stream, img, (TT*)col, B, h, w, H, W, P, Kp, stride_y, stride_x, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2])
     if (dtype == GD_BF16) { if (P == 14) GD_PI2C(bf16, 14); else if (P == 16) GD_PI2C(bf16, 16); else GD_PI2C(bf16, 0); }
     else { if (P == 14) GD_PI2C(float, 14); else if (P == 16) GD_PI2C(float, 16); else GD_PI2C(float, 0); }
 #undef GD_PI2C
     GD_LAUNCH_OK();
     return 0;
+}
+
+extern "C" int gd_patch_im2col(const float* img, void* col, int B, int h, int w, int H, int W, int P, int Kp,
+                               const float* mean3, const float* std3, int dtype, void* stream) {
+    GD_REQUIRE(P > 0 && H % P == 0 && W % P == 0, "gd_patch_im2col: bad geometry H=%d W=%d P=%d Kp=%d", H, W, P, Kp);
+    return gd_patch_im2col_strided(img, col, B, h, w, H, W, P, P, P, Kp, mean3, std3, dtype, stream);
 }
 
 extern "C" int gd_assemble_tokens(const void* patch, const float* cls, const float* pos, void* out, int B, int Np,

@@ -13,6 +13,7 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 // the public C ABI: every TU sees the prototypes, so a definition that drifts from the header fails to compile
 #include "gd_hip.h"
+#include "gd_knobs.h"
 
 // ---- host-side error plumbing (definitions in cabi.hip) ----
 void gd_set_error(const char* fmt, ...);

@@ -29,11 +29,8 @@ struct GemmNtParams {
     int accumulate;                  // v += C
     int vec_epilogue;                // every epilogue tensor is 16-byte aligned with 16-byte-multiple row strides
     int c_policy;                    // 0 plain C stores, 1 write-through (sc1) C stores (GD_GEMM_CSTORE, default 1)
-    int deep_ring;                   // 256x256 config: 4-slot ring of 64-byte K stages with counted waits (GD_GEMM_DEEP=1; measured 10 % SLOWER than the 2-deep ring: twice the barriers)
-    unsigned long long* probe;       // gd_gemm_phase_probe accumulators (device), or null
-    int stagger;                     // persistent kernel experiment (GD_GEMM_STAGGER): start-up skew between CUs, units of ~0.85 us
+    unsigned long long* probe;       // gd_gemm_phase_probe accumulators (device) in -DGD_GEMM_STAGE_PROBE builds, else null
     int k_rot;                       // persistent kernel: per-tile rotation of the K-step order, krot = (tn * k_rot + tm) % nk (GD_GEMM_KROT, default 1, 0 = off: +1.3 % on the step, in-step A/B 525.6 vs 518.8 pairs/s)
-    int tile_order;                  // experiment knob (GD_GEMM_ORDER): 0 XCD chunks, tn fastest; 1 no remap; 2 XCD chunks, 4-wide tn bands
 };
 
 // Fallback: register-staged main loop (any K with K*elsize % 16 == 0, any alignment of rows), scalar epilogue.
@@ -148,14 +145,8 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(GemmNtParams p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / NWN, wn = wave % NWN;
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-    const int wg = p.tile_order == 1 ? (int)blockIdx.x : xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    int tm = wg / tiles_n, tn = wg % tiles_n;
-    if (p.tile_order == 2) {   // bands of 4 column tiles, row tiles fastest inside a band
-        const int band = 4, full = (tiles_n / band) * band;
-        const int per_band = band * tiles_m;
-        if (wg < (tiles_n / band) * per_band) { const int b = wg / per_band, r = wg % per_band; tn = b * band + r % band; tm = r / band; }
-        else { const int r = wg - (tiles_n / band) * per_band, rem = tiles_n - full; tn = full + r % rem; tm = r / rem; }
-    }
+    const int wg = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tm = wg / tiles_n, tn = wg % tiles_n;
     const long batch = blockIdx.y;
     const char* Ab = (const char*)p.A + batch * p.sA * (long)sizeof(T);
     const char* Wb = (const char*)p.W + batch * p.sW * (long)sizeof(T);
@@ -172,17 +163,8 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(GemmNtParams p)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.lora_b + (long)bk * p.N + bc),
                                          (__attribute__((address_space(3))) void*)(lB + wave * 1024), 16, 0, 0);
     }
-    bool done = false;
-    if constexpr (NWM * NWN == 8) {
-        if (p.deep_ring) {
-            dma_mainloop_deep<T, NWM, NWN, WMT>(Ab, p.lda * (long)sizeof(T), p.M, Wb, p.ldw * (long)sizeof(T), p.N,
-                                                p.K * (int)sizeof(T) / 128, tm, tn, smem, acc);
-            done = true;
-        }
-    }
-    if (!done)
-        dma_mainloop<T, NWM, NWN, WMT>(Ab, p.lda * (long)sizeof(T), p.M, Wb, p.ldw * (long)sizeof(T), p.N,
-                                       p.K * (int)sizeof(T) / 128, tm, tn, smem, acc);
+    dma_mainloop<T, NWM, NWN, WMT>(Ab, p.lda * (long)sizeof(T), p.M, Wb, p.ldw * (long)sizeof(T), p.N,
+                                   p.K * (int)sizeof(T) / 128, tm, tn, smem, acc);
     const int fr = lane & 15, g = lane >> 4;
 
     // ---- LoRA rank update  acc += (T / alpha) . B  as ONE extra MFMA K-chunk per accumulator tile: lane (g, fr) owns
@@ -373,7 +355,12 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(GemmNtParams p)
 
 #include "gemm_persist.h"
 
+// Phase probe of the persistent kernel: exists only in -DGD_GEMM_STAGE_PROBE builds (its s_memtime reads cost 20 % even unarmed,
+// and its accumulator is process-wide state); the shipped library has neither the device code nor the global, and the entry
+// point says so.
+#ifdef GD_GEMM_STAGE_PROBE
 static unsigned long long* g_probe = nullptr;
+static unsigned long long* gd_probe_buffer() { return g_probe; }
 extern "C" int gd_gemm_phase_probe(int enable, unsigned long long* out6) {
     if (out6 && g_probe) {
         hipDeviceSynchronize();
@@ -386,6 +373,15 @@ extern "C" int gd_gemm_phase_probe(int enable, unsigned long long* out6) {
     if (!enable && g_probe) { hipFree(g_probe); g_probe = nullptr; }
     return 0;
 }
+#else
+static unsigned long long* gd_probe_buffer() { return nullptr; }
+extern "C" int gd_gemm_phase_probe(int enable, unsigned long long* out6) {
+    (void)out6;
+    if (!enable) return 0;
+    gd_set_error("gd_gemm_phase_probe: this library was built without -DGD_GEMM_STAGE_PROBE (debug builds only)");
+    return -1;
+}
+#endif
 
 // ------------------------------------------------------------------------------------------
 // gemm_tn: G[N,K] += alpha * sum_m Y[m,n] X[m,k];  64x64 output tile per block, f32 MFMA 16x16x4,
@@ -646,16 +642,8 @@ __global__ __launch_bounds__(320) void gemm_tn_skinny_kernel(GemmTnParams p) {
 // ------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------
-static bool gd_f32_big_tiles() {   // f32: the 128x128 config at 2 blocks/CU measured 125-138 TF/s vs 97-120 for 256x256
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("GD_GEMM_F32_BIG"); v = (e && e[0] == '1') ? 1 : 0; }
-    return v == 1;
-}
-static bool gd_force_small_tiles() {   // GD_GEMM_SMALL_TILES=1: A/B switch for benchmarking the tile configurations
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("GD_GEMM_SMALL_TILES"); v = (e && e[0] == '1') ? 1 : 0; }
-    return v == 1;
-}
+static bool gd_f32_big_tiles() { return gd_knobs().gemm_f32_big == 1; }   // f32: the 128x128 config at 2 blocks/CU measured 125-138 TF/s vs 97-120 for 256x256
+static bool gd_force_small_tiles() { return gd_knobs().gemm_small_tiles == 1; }   // A/B switch for benchmarking the tile configurations
 
 // Skinny NT GEMM, N <= 8 (the rank-2r LoRA projections t = LN(x) A^T and dt = dqkv B: M = 87 680, K = 768 / 2304): pure
 // streaming of A.  The 128 x 128 tile kernel spends a full tile of MFMA and W traffic on 8 useful columns (28 TFLOP/s);
@@ -750,23 +738,14 @@ extern "C" int gd_gemm_nt(const void* A, const void* W, void* C, int M, int N, i
                      (bias == nullptr || ((uintptr_t)bias & 15) == 0) && (lora_b == nullptr || (((uintptr_t)lora_b & 15) == 0 && N % 4 == 0));
     dim3 grid(gd_cdiv(M, 128) * gd_cdiv(N, 128), batch);
     const bool dma = (K * es) % 128 == 0;
-    { static int cp = -1; if (cp < 0) { const char* e = getenv("GD_GEMM_CSTORE"); cp = e ? atoi(e) : 1; }
+    { const int cp = gd_knobs().gemm_cstore;
       p.c_policy = (cp && (long)256 * ldc * gd_dtype_size(c_dtype) < 0x7fffffffL && !accumulate) ? cp : 0; }
-    { static int dr = -1; if (dr < 0) { const char* e = getenv("GD_GEMM_DEEP"); dr = e ? atoi(e) : 0; } p.deep_ring = dr; }
-    p.probe = g_probe;
-    { static int sg = -1; if (sg < 0) { const char* e = getenv("GD_GEMM_STAGGER"); sg = e ? atoi(e) : 0; } p.stagger = sg; }
-    { static int kr = -1; if (kr < 0) { const char* e = getenv("GD_GEMM_KROT"); kr = e ? atoi(e) : 1; } p.k_rot = kr; }
-    { static int ord = -1; if (ord < 0) { const char* e = getenv("GD_GEMM_ORDER"); ord = e ? atoi(e) : 0; } p.tile_order = ord; }
+    p.probe = gd_probe_buffer();
+    p.k_rot = gd_knobs().gemm_krot;
     const bool big = dma && N >= 256 && M >= 1024 && !gd_force_small_tiles();
     dim3 gridb(gd_cdiv(M, 256) * gd_cdiv(N, 256), batch);
     hipStream_t st = (hipStream_t)stream;
-    static int persist = -1, ncu = 256;
-    if (persist < 0) {
-        const char* e = getenv("GD_GEMM_PERSIST");
-        persist = e ? atoi(e) : 1;
-        int dev = 0; hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
-    }
+    const int persist = gd_knobs().gemm_persist, ncu = gd_knobs().ncu;
     if (ab_dtype == GD_BF16 && N <= SK_ROWS && M >= 4096 && batch == 1 && K % 128 == 0 && K <= 4096 && !bias && !lora_t && !preact &&
         act == 0 && !dact_src && !residual && !accumulate) {
         const size_t lds = (size_t)(K / 32) * 512;
@@ -838,7 +817,7 @@ extern "C" int gd_gemm_tn(const void* Y, const void* X, float* G, int M, int N, 
     const int tiles = gd_cdiv(N, tl) * gd_cdiv(K, tl);
     // enough M-chunks to fill the chip without shredding the reduction (every chunk ends in N x K fp32 atomics: at 87 680 x 768 x 64
     // 768 blocks measured 40-43 us, 1024: 47-48, 2048: 62, 256: 53)
-    static const int tn_blocks = [] { const char* e = getenv("GD_TN_BLOCKS"); return e ? atoi(e) : 0; }();   // A/B knob: target block count
+    const int tn_blocks = gd_knobs().tn_blocks;   // A/B knob: target block count
     int splits = ((tn_blocks > 0 ? tn_blocks : (bf ? 768 : 2048)) + tiles * batch - 1) / (tiles * batch);
     int mchunk = ((gd_cdiv(M, splits) + 63) / 64) * 64;
     if (mchunk < 256) mchunk = 256;

@@ -74,34 +74,6 @@ __device__ __forceinline__ void chunk_rows67(const FragHead& h, const FragTail& 
     mma_row<T>(acc[7], t.a7, h.b0, h.b1, h.b2, h.b3);
 }
 
-// The same fragment pipeline on the FOUR-half-stage ring (GD_PERSIST_RING4): a half-stage is one 64-byte K chunk, LDS image
-// [A rows | W rows][64 B], so the 16-row groups are 1024 bytes apart instead of 2048.
-__device__ __forceinline__ void frag_head_issue4(FragHead& h, unsigned aaddr, unsigned baddr) {
-    GD_DSR128(h.b0, baddr, 0); GD_DSR128(h.b1, baddr, 1024); GD_DSR128(h.b2, baddr, 2048); GD_DSR128(h.b3, baddr, 3072);
-    GD_DSR128(h.a0, aaddr, 0);
-}
-template <typename T>
-__device__ __forceinline__ void chunk_rows05_4(FragHead& h, FragTail& t, unsigned aaddr, f32x4 (&acc)[8][4]) {
-    f32x4 a1, a2, a3, a4, a5;
-    GD_DSR128(a1, aaddr, 1024); GD_DSR128(a2, aaddr, 2048); GD_DSR128(a3, aaddr, 3072); GD_DSR128(a4, aaddr, 4096);
-    GD_DSR128(a5, aaddr, 5120); GD_DSR128(t.a6, aaddr, 6144); GD_DSR128(t.a7, aaddr, 7168);
-    asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(h.b0), "+v"(h.b1), "+v"(h.b2), "+v"(h.b3), "+v"(h.a0));
-    mma_row<T>(acc[0], h.a0, h.b0, h.b1, h.b2, h.b3);
-    asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a1));
-    mma_row<T>(acc[1], a1, h.b0, h.b1, h.b2, h.b3);
-    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a2), "+v"(a3));
-    mma_row<T>(acc[2], a2, h.b0, h.b1, h.b2, h.b3);
-    mma_row<T>(acc[3], a3, h.b0, h.b1, h.b2, h.b3);
-    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a4), "+v"(a5));
-    mma_row<T>(acc[4], a4, h.b0, h.b1, h.b2, h.b3);
-    mma_row<T>(acc[5], a5, h.b0, h.b1, h.b2, h.b3);
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t.a6), "+v"(t.a7));
-}
-// 16-byte piece swizzle of the 64-byte-row image: logical piece l of row r sits at position l ^ swz4(r).  With x = (0, 2, 3, 1)
-// over (r >> 2) & 3 the sixteen lanes a ds_read_b128 serves together ({0-3, 12-15, 20-27}, ...) hit sixteen different 16-byte
-// bank groups: rows of equal r & 3 share a 64-byte bank quarter and get four different positions.
-__device__ __forceinline__ int swz4(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
-
 // wait until at most n vector-memory operations of this wave are outstanding (n rounded DOWN to a multiple of 8:
 // conservative).  VMEM operations retire in issue order on gfx9-family parts, so "the S youngest may stay in flight"
 // is how a wave lets its epilogue stores drain under the next tile's main loop while still seeing its DMA land.
@@ -132,11 +104,13 @@ __device__ __forceinline__ void bst4_aux(__amdgpu_buffer_rsrc_t rs, int off, int
 #ifndef GD_PERSIST_STORE_AUX
 #define GD_PERSIST_STORE_AUX 18
 #endif
-// Measured (MI355X, two alternating rounds against the two-stage ring): 87 680 x 2304 x 768 924 -> 797 TFLOP/s, 768 x 768 809 -> 705,
-// 3072 x 768 995-1025 -> 921-934, 768 x 3072 1076 -> 953, 4096^3 1216-1272 -> 1080-1143: the deeper ring does not pay for the second
-// barrier per K step — what a wave waits for at the stage barrier is mostly the other waves, not the DMA.  Kept as a build option.
-#ifndef GD_PERSIST_RING4
-#define GD_PERSIST_RING4 0
+// phase probe (gd_gemm_phase_probe): present in -DGD_GEMM_STAGE_PROBE builds only, armed when p.probe != null
+#ifdef GD_GEMM_STAGE_PROBE
+#define GD_PROBE(...) if (p.probe) { __VA_ARGS__ }
+#define GD_PROBE_DECL(...) __VA_ARGS__
+#else
+#define GD_PROBE(...)
+#define GD_PROBE_DECL(...)
 #endif
 #ifndef GD_PERSIST_SIDE_AUX
 #define GD_PERSIST_SIDE_AUX 2     // side tensors are read once: stream them past the L2's operand panels
@@ -153,10 +127,6 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
     constexpr int NWN = 4, WMT = 8, NW = 8, BM = 256, BN = 256;
     constexpr int ABYTES = BM * 128, STAGE = (BM + BN) * 128, APW = BM / 8 / NW, BPW = BN / 8 / NW;
     constexpr int SDEP = 16;   // side-input prefetch depth (16-byte slots per lane)
-    // GD_PERSIST_RING4: the 128 KB ring as four 32 KB half-stages (one 64-byte K chunk each) instead of two 64 KB stages: three
-    // chunks (96 KB) in flight while one is consumed, a barrier per chunk, counted `vmcnt(8)` waits
-    constexpr bool R4 = GD_PERSIST_RING4 != 0;
-    constexpr int HS = (BM + BN) * 64, AH = BM * 64;
     constexpr int LORA_OFF = 2 * STAGE, BIAS_OFF = LORA_OFF + (BM + BN) * 32;
     __shared__ __attribute__((aligned(16))) char smem[BIAS_OFF + 2 * BN * 4];
     typedef typename Mma<T>::Frag Frag;
@@ -191,16 +161,6 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
         abase_t = Ab + (long)tm * BM * lda_b;
         wbase_t = Wb + (long)tn * BN * ldw_b;
         const int av = min(BM, p.M - tm * BM) - 1, wv = min(BN, p.N - tn * BN) - 1;
-        if (R4) {      // 1-KB pieces of a chunk: 16 rows x 64 bytes; wave w moves pieces 2w, 2w+1 of A and of W
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int row = (wave * 2 + i) * 16 + (lane >> 2);
-                const int pc = ((lane & 3) ^ swz4(row)) * 16;
-                aoff[i] = (unsigned)(min(row, av) * (int)lda_b + pc);
-                woff[i] = (unsigned)(min(nperm64(row), wv) * (int)ldw_b + pc);
-            }
-            return;
-        }
 #pragma unroll
         for (int i = 0; i < APW; ++i) {
             const int row = (wave * APW + i) * 8 + (lane >> 3);
@@ -211,22 +171,6 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
             const int row = (wave * BPW + i) * 8 + (lane >> 3);
             woff[i] = (unsigned)(min(nperm64(row), wv) * (int)ldw_b + ((lane & 7) ^ swz(row)) * 16);
         }
-    };
-    // chunk j (64 bytes of K: half j & 1 of K step j >> 1, rotated like the K steps) into half-stage hs
-    auto issue4 = [&](int j, int hs) {
-        const int k0 = j >> 1;
-        const int kt = k0 + krot >= nk ? k0 + krot - nk : k0 + krot;
-        const int kb = kt * 128 + (j & 1) * 64;
-        char* sA = smem + hs * HS;
-        char* sB = sA + AH;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(abase_t + kb + aoff[i]),
-                                             (__attribute__((address_space(3))) void*)(sA + (wave * 2 + i) * 1024), 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wbase_t + kb + woff[i]),
-                                             (__attribute__((address_space(3))) void*)(sB + (wave * 2 + i) * 1024), 16, 0, 0);
     };
     auto issue = [&](int kt0, int buf) {
         const int kt = kt0 + krot >= nk ? kt0 + krot - nk : kt0 + krot;
@@ -270,42 +214,31 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
 
     int t = blockIdx.x, slot = 0;
     if (t >= ntiles) return;
-    for (int i = 0; i < (int)((blockIdx.x >> 3) & 7) * p.stagger; ++i) __builtin_amdgcn_s_sleep(32);
     int wg = xcd_remap(t, ntiles);
     int tm = wg / tiles_n, tn = wg % tiles_n;
-    const int NC = 2 * nk;           // 64-byte K chunks per tile (ring-4 form)
-    const int npro = min(NC, 4) - 1; // chunks of a tile's prologue issued after chunk 0 (and the side tiles)
     auto prologue = [&](int tm_, int tn_, int slot_) {
         set_tile(tm_, tn_);
-        if (R4) {
-            issue4(0, 0);
-            issue_side(tm_, tn_, slot_);
-            issue4(1, 1);
-            if (NC > 2) { issue4(2, 2); issue4(3, 3); }
-        } else {
-            issue(0, 0);
-            issue_side(tm_, tn_, slot_);
-            if (nk > 1) issue(1, 1);
-        }
+        issue(0, 0);
+        issue_side(tm_, tn_, slot_);
+        if (nk > 1) issue(1, 1);
     };
     prologue(tm, tn, slot);
     // VMEM instructions every wave issues unconditionally in one epilogue (buffer ops, range-checked by the hardware)
     int after = 0;   // of those, how many were issued after this tile's stage-1 DMA (0 for the block's first tile)
 
-    unsigned long long pc0 = 0, pw = 0, pm = 0, pe = 0, pn = 0, pd = 0, pb = 0;
+    GD_PROBE_DECL(unsigned long long pc0 = 0; unsigned long long pw = 0; unsigned long long pm = 0; unsigned long long pe = 0; unsigned long long pn = 0; unsigned long long pd = 0; unsigned long long pb = 0;)
     for (;;) {
-        if (p.probe) pc0 = __builtin_amdgcn_s_memtime();
+        GD_PROBE(pc0 = __builtin_amdgcn_s_memtime();)
         f32x4 acc[WMT][4];
 #pragma unroll
         for (int i = 0; i < WMT; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // stage 0 (ring-4: chunk 0), LoRA tiles and bias of this tile have landed
-        if (R4) wait_vm_le(after + 4 * npro);
-        else wait_vm_le(after + (nk > 1 ? APW + BPW : 0));
+        // stage 0, LoRA tiles and bias of this tile have landed
+        wait_vm_le(after + (nk > 1 ? APW + BPW : 0));
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (p.probe) { const unsigned long long c = __builtin_amdgcn_s_memtime(); pw += c - pc0; pc0 = c; }
+        GD_PROBE({ const unsigned long long c = __builtin_amdgcn_s_memtime(); pw += c - pc0; pc0 = c; })
         if (lora) {
             const bool live = KPL * g < 8;
             // B tile [8][BN] f32: this lane's k rows start at (KPL*g)&7; its columns for the n-tiles j = 0..3 are the four
@@ -341,33 +274,6 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
         const int co0 = ((g ^ sa) * 16), co1 = (((4 + g) ^ sa) * 16);
         FragHead P, Q;
         FragTail tl;
-        if (R4) {
-            const unsigned a4 = lds0 + (wm * WMT * 16 + fr) * 64 + ((g ^ swz4(fr)) * 16);
-            const unsigned b4 = lds0 + AH + (wn * 64 + fr) * 64 + ((g ^ swz4(fr)) * 16);
-            // after this wave's last LDS read of chunk j: chunk j+1 has landed for everyone, half-stage j & 3 is free -> refill it
-            auto stage_sync = [&](int j) {
-                if (j + 1 < NC) {
-                    const int younger = min(2, NC - 2 - j);          // chunk groups (4 DMA instructions each) issued after chunk j+1's
-                    if (j >= 3 && younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                    else wait_vm_le(4 * younger + (j + 1 <= 3 ? after : 0));   // chunks 1-3 are older than the previous epilogue's stores
-                }
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                if (j + 4 < NC) issue4(j + 4, j & 3);
-            };
-            frag_head_issue4(P, a4, b4);
-            for (int j = 0; j < NC; j += 2) {
-                const unsigned h0 = (j & 3) * HS, h1 = ((j + 1) & 3) * HS, h2 = ((j + 2) & 3) * HS;
-                chunk_rows05_4<T>(P, tl, a4 + h0, acc);
-                stage_sync(j);
-                frag_head_issue4(Q, a4 + h1, b4 + h1);
-                chunk_rows67<T>(P, tl, acc);
-                chunk_rows05_4<T>(Q, tl, a4 + h1, acc);
-                stage_sync(j + 1);
-                if (j + 2 < NC) frag_head_issue4(P, a4 + h2, b4 + h2);
-                chunk_rows67<T>(Q, tl, acc);
-            }
-        } else {
         frag_head_issue(P, lds0 + abase + co0, lds0 + bbase + co0);
         for (int kt = 0; kt < nk; ++kt) {
             const unsigned sbo = lds0 + (kt & 1) * STAGE, nsbo = lds0 + ((kt + 1) & 1) * STAGE;
@@ -376,27 +282,21 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
             chunk_rows67<T>(P, tl, acc);
             chunk_rows05<T>(Q, tl, sbo + abase + co1, acc);
             // every LDS read of stage kt is done: stage barrier (stage kt+1 landed, slot kt&1 free), then refill the slot
-#ifdef GD_GEMM_STAGE_PROBE
-            unsigned long long pb0 = 0;
-            if (p.probe) pb0 = __builtin_amdgcn_s_memtime();
-#endif
+            GD_PROBE_DECL(unsigned long long pb0 = 0;) GD_PROBE(pb0 = __builtin_amdgcn_s_memtime();)
             if (kt == 0) wait_vm_le(after);   // stage 1 is older than the previous epilogue's stores: those may still drain
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-#ifdef GD_GEMM_STAGE_PROBE
             // -DGD_GEMM_STAGE_PROBE builds only (the two s_memtime reads in the K loop cost 20 % even unarmed): the time this wave
             // spends between its last LDS read of stage kt and the stage barrier = DMA landing wait + barrier skew.  Measured
             // 0.40 of the main loop on every shape (87 680 x 3072 x 768: 14.0 k of 35.5 k cycles per tile; 4096^3: 76.7 k of 191.6 k)
-            if (p.probe) pb += __builtin_amdgcn_s_memtime() - pb0;
-#endif
+            GD_PROBE(pb += __builtin_amdgcn_s_memtime() - pb0;)
             if (kt + 2 < nk) issue(kt + 2, kt & 1);
             if (kt + 1 < nk) frag_head_issue(P, nsbo + abase + co0, nsbo + bbase + co0);
             chunk_rows67<T>(Q, tl, acc);
         }
-        }
         const int ctm = tm, ctn = tn, cslot = slot;
-        if (p.probe) { const unsigned long long c = __builtin_amdgcn_s_memtime(); pm += c - pc0; pc0 = c; }
+        GD_PROBE({ const unsigned long long c = __builtin_amdgcn_s_memtime(); pm += c - pc0; pc0 = c; })
         // ---- epilogue from the accumulators.  Item (i, r) = row 16i + 4g + r of the wave tile, this lane's four columns
         // 4fr..4fr+3: one 8-byte (bf16) / 16-byte (f32) store, 16 consecutive lanes = one contiguous row segment.
         const int vrows = min(BM, p.M - ctm * BM);
@@ -452,7 +352,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
                     prologue(tm, tn, slot);
                 }
                 asm volatile("" ::: "memory");   // nothing younger may be hoisted above the DMA: `after` counts on it
-                if (p.probe) { const unsigned long long c = __builtin_amdgcn_s_memtime(); pd += c - pc0; pc0 = c; }
+                GD_PROBE({ const unsigned long long c = __builtin_amdgcn_s_memtime(); pd += c - pc0; pc0 = c; })
             }
             const int coff = cbase + (i * 16 + r) * csz * ldc_i, poff = pbase + (i * 16 + r) * csz * ldp_i;
             float v[4];
@@ -495,10 +395,10 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
             bst4_aux<GD_PERSIST_STORE_AUX>(crs, coff, cdt, v);
             if (pre && idx + SDEP < NITEM) side_load(idx + SDEP);
         }
-        if (p.probe) { const unsigned long long c = __builtin_amdgcn_s_memtime(); pe += c - pc0; pn += 1; }
+        GD_PROBE({ const unsigned long long c = __builtin_amdgcn_s_memtime(); pe += c - pc0; pn += 1; })
         if (!more) break;
     }
-    if (p.probe && tid == 0) {
+    GD_PROBE(if (tid == 0) {
         atomicAdd(p.probe + 0, pw); atomicAdd(p.probe + 1, pm); atomicAdd(p.probe + 2, pe); atomicAdd(p.probe + 3, pn); atomicAdd(p.probe + 4, pd); atomicAdd(p.probe + 5, pb);
-    }
+    })
 }

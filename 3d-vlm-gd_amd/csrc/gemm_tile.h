@@ -154,81 +154,3 @@ __device__ __forceinline__ void dma_mainloop(const char* Ab, long lda_b, int Mro
         __syncthreads();
     }
 }
-
-// ------------------------------------------------------------------------------------------------------------
-// Deeper variant for the 256 x 256 / 8-wave tile: stages are 64-byte K slices (one MFMA K-chunk, 32 KB per stage),
-// a 4-slot ring keeps THREE stages in flight (vs one 128-byte step in dma_mainloop) inside the same 128 KB of LDS.
-// Synchronisation: counted `s_waitcnt vmcnt(N)` (this wave's pieces of the stage about to be read have landed; the
-// younger stages stay in flight) followed by a raw s_barrier (everybody's pieces landed, everybody is done reading the
-// slot that is re-filled next).  A DMA piece is 16 rows x 64 B; chunk c of row r is stored at chunk c ^ ((r>>2)&3).
-// ------------------------------------------------------------------------------------------------------------
-template <typename T, int NWM, int NWN, int WMT>
-__device__ __forceinline__ void dma_mainloop_deep(const char* Ab, long lda_b, int Mrows, const char* Wb, long ldw_b,
-                                                  int Nrows, int nk, int tm, int tn, char* smem, f32x4 (&acc)[WMT][4]) {
-    constexpr int NW = NWM * NWN, BM = NWM * WMT * 16, BN = NWN * 64;
-    constexpr int ABYTES = BM * 64, STAGE = (BM + BN) * 64, NSLOT = 4;
-    constexpr int APW = BM / 16 / NW, BPW = BN / 16 / NW;   // 1-KB pieces (16 rows x 64 B) per wave per operand per stage
-    constexpr int G = APW + BPW;                            // DMA instructions per wave per stage
-    static_assert(G == 4, "the counted waits below are written for 4 DMA instructions per wave per stage");
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / NWN, wn = wave % NWN;
-    const int nh = nk * 2;                                  // 64-byte stages
-
-    const char* asrc[APW];
-    const char* wsrc[BPW];
-#pragma unroll
-    for (int i = 0; i < APW; ++i) {
-        const int row = (wave * APW + i) * 16 + (lane >> 2);
-        asrc[i] = Ab + (long)min(tm * BM + row, Mrows - 1) * lda_b + (((lane & 3) ^ ((row >> 2) & 3)) * 16);
-    }
-#pragma unroll
-    for (int i = 0; i < BPW; ++i) {
-        const int row = (wave * BPW + i) * 16 + (lane >> 2);
-        wsrc[i] = Wb + (long)min(tn * BN + row, Nrows - 1) * ldw_b + (((lane & 3) ^ ((row >> 2) & 3)) * 16);
-    }
-    auto issue = [&](int h, int slot) {
-        char* sA = smem + slot * STAGE;
-        char* sB = sA + ABYTES;
-#pragma unroll
-        for (int i = 0; i < APW; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + (long)h * 64),
-                                             (__attribute__((address_space(3))) void*)(sA + (wave * APW + i) * 1024), 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < BPW; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + (long)h * 64),
-                                             (__attribute__((address_space(3))) void*)(sB + (wave * BPW + i) * 1024), 16, 0, 0);
-    };
-#pragma unroll
-    for (int i = 0; i < WMT; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    typedef typename Mma<T>::Frag Frag;
-    const int fr = lane & 15, g = lane >> 4;
-    // rows read by this lane are fr + multiples of 16, so (row>>2)&3 == (fr>>2)&3
-    const int co = ((g ^ ((fr >> 2) & 3)) * 16);
-    const int abase = (wm * WMT * 16 + fr) * 64 + co, bbase = ABYTES + (wn * 64 + fr) * 64 + co;
-
-    issue(0, 0);
-    if (nh > 1) issue(1, 1);
-    if (nh > 2) issue(2, 2);
-    for (int h = 0; h < nh; ++h) {
-        if (h + 2 < nh) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (h + 1 < nh) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (h + 3 < nh) issue(h + 3, (h + 3) & 3);
-        const char* sb = smem + (h & 3) * STAGE;
-        Frag a[WMT], b[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) b[t] = *(const Frag*)(sb + bbase + t * 1024);
-#pragma unroll
-        for (int t = 0; t < WMT; ++t) a[t] = *(const Frag*)(sb + abase + t * 1024);
-#pragma unroll
-        for (int i = 0; i < WMT; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(a[i], b[j], acc[i][j]);
-    }
-    __syncthreads();   // every wave is done with the ring before the caller reuses the LDS
-}

@@ -784,8 +784,7 @@ extern "C" int gd_pair_rank(const float* u, const float* depth, const int* count
     float* lsum = hg + (long)S * HG_SIZE;
     int* cnt = (int*)(lsum + S);
     hipMemsetAsync(workspace, 0, gd_pair_rank_workspace_bytes(S), s);
-    static int wide = -1;   // GD_PAIR_RANK_WAVE=1 selects the older one-wave-per-pair kernel (A/B testing)
-    if (wide < 0) { const char* e = getenv("GD_PAIR_RANK_WAVE"); wide = e ? atoi(e) : 0; }
+    const int wide = gd_knobs().pair_rank_wave;   // GD_PAIR_RANK_WAVE=1 selects the older one-wave-per-pair kernel (A/B testing)
     if (wide == 1) hipLaunchKernelGGL(pair_rank_kernel, dim3(Nmax, S), dim3(256), 0, s, u, depth, counts, b1, ln_w, ln_b, w2, b2, du,
                                  hg, lsum, cnt, Nmax, depth_threshold);
     else if (wide == 2) hipLaunchKernelGGL(pair_rank8_kernel<16>, dim3(Nmax, S), dim3(256), 0, s, u, depth, counts, b1, ln_w, ln_b, w2,

@@ -257,7 +257,7 @@ extern "C" int gd_layernorm_fwd(const void* x, const float* gamma, const float* 
 #define F_BB(NV) hipLaunchKernelGGL((ln_fwd_kernel<bf16, bf16, NV>), grid, blk, 0, s, (const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, M, D, ldx, ldy, eps)
 #define F_BF(NV) hipLaunchKernelGGL((ln_fwd_kernel<bf16, float, NV>), grid, blk, 0, s, (const bf16*)x, gamma, beta, (float*)y, mean, rstd, M, D, ldx, ldy, eps)
 #define F_FF(NV) hipLaunchKernelGGL((ln_fwd_kernel<float, float, NV>), grid, blk, 0, s, (const float*)x, gamma, beta, (float*)y, mean, rstd, M, D, ldx, ldy, eps)
-    static const int ln16 = [] { const char* e = getenv("GD_LN_16B"); return e ? atoi(e) : 1; }();
+    const int ln16 = gd_knobs().ln_16b;
     const bool wide = ln16 && dtype == GD_BF16 && y_dtype == GD_BF16 && D % 8 == 0 && D <= 1024 && ldx % 8 == 0 && ldy % 8 == 0 &&
                       ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)gamma % 16) == 0 && ((uintptr_t)beta % 16) == 0;
     if (wide && D <= 512) hipLaunchKernelGGL((ln_fwd8_kernel<1>), grid, blk, 0, s, (const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, M, D, ldx, ldy, eps);
@@ -283,7 +283,7 @@ extern "C" int gd_layernorm_bwd(const void* dy, const void* x, const float* gamm
 #define B_BB(NV) hipLaunchKernelGGL((ln_bwd_kernel<bf16, bf16, NV>), grid, blk, 0, s, (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (const bf16*)dres, (const bf16*)dres2, (bf16*)dx, M, D, ldd, ldx, dyscale)
 #define B_BF(NV) hipLaunchKernelGGL((ln_bwd_kernel<bf16, float, NV>), grid, blk, 0, s, (const float*)dy, (const bf16*)x, gamma, mean, rstd, (const bf16*)dres, (const bf16*)dres2, (bf16*)dx, M, D, ldd, ldx, dyscale)
 #define B_FF(NV) hipLaunchKernelGGL((ln_bwd_kernel<float, float, NV>), grid, blk, 0, s, (const float*)dy, (const float*)x, gamma, mean, rstd, (const float*)dres, (const float*)dres2, (float*)dx, M, D, ldd, ldx, dyscale)
-    static const int ln16 = [] { const char* e = getenv("GD_LN_16B"); return e ? atoi(e) : 1; }();
+    const int ln16 = gd_knobs().ln_16b;
     const bool wide = ln16 && dtype == GD_BF16 && dy_dtype == GD_BF16 && D % 8 == 0 && D <= 1024 && ldx % 8 == 0 && ldd % 8 == 0 &&
                       ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 && ((uintptr_t)dx % 16) == 0 && ((uintptr_t)gamma % 16) == 0 &&
                       ((uintptr_t)dres % 16) == 0 && ((uintptr_t)dres2 % 16) == 0;

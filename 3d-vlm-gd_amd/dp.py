@@ -122,12 +122,13 @@ class RcclComm:
         check(lib().gd_comm_init(ctypes.byref(self._h), world, rank, self._id), "gd_comm_init")
 
     def all_reduce_(self, flat, algo=None):
-        """In place sum over ranks of a contiguous fp32 CUDA tensor, on the current stream.  algo None: reduce-scatter +
-        all-gather when the length divides by the world size (the direct form for the xGMI mesh), else one all-reduce."""
+        """In place sum over ranks of a contiguous fp32 CUDA tensor, on the current stream.  algo 0 / None: one ncclAllReduce;
+        algo 1: ncclReduceScatter + ncclAllGather on the rank's slice (length must divide by the world size).  RCCL picks the
+        schedule either way; which of the two is faster on an 8-GPU xGMI node is unmeasured (no such node in rounds 1-3)."""
         from ._lib import check, lib, stream
         assert flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous()
         if algo is None:
-            algo = 1 if flat.numel() % self.world == 0 else 0
+            algo = 0
         check(lib().gd_flat_allreduce(self._h, flat.data_ptr(), flat.numel(), self.world, self.rank, int(algo),
                                       stream()), "gd_flat_allreduce")
         return flat
@@ -141,10 +142,12 @@ class RcclComm:
 
 class DirectGradReducer:
     """Same contract as OverlappedGradReducer (wait_early / start / finish), one gd_flat_allreduce of the whole flat
-    gradient buffer after the backward, on the compute stream: no bucketing, no hooks, no torch.distributed in the step."""
+    gradient buffer after the backward, on the compute stream: no bucketing, no hooks, no torch.distributed in the step.
+    EXPERIMENTAL: no N > 1 hardware run exists yet (`bench.py --exchange direct`); `comm` is anything with `.world` and
+    `.all_reduce_(flat)` (RcclComm on GPUs; tests/test_dp_gloo.py drives the contract with a torch.distributed stand-in)."""
 
-    def __init__(self, flat_grad, comm):
-        self.flat, self.comm, self.world = flat_grad, comm, comm.world
+    def __init__(self, flat_grad, comm, algo=None):
+        self.flat, self.comm, self.world, self.algo = flat_grad, comm, comm.world, algo
 
     def attach(self):
         pass
@@ -157,7 +160,7 @@ class DirectGradReducer:
 
     def start(self):
         if self.world > 1:
-            self.comm.all_reduce_(self.flat)
+            self.comm.all_reduce_(self.flat) if self.algo is None else self.comm.all_reduce_(self.flat, self.algo)
 
     def finish(self):
         return 1.0 / self.world

@@ -90,6 +90,7 @@ class FinetuneGD(nn.Module):
         self.resize_patch_size = teacher_patch or (14 if variant == "vggt" else self.patch_size)
         self._fwd_cache, self._norm_cache, self._fuse_taps = {}, {}, False
         self._flat = None
+        self._pending_opt_state = None
 
     def reset_parameters(self, lora_b_std=0.0, generator=None):
         """A: kaiming-uniform(a=sqrt 5), B: zeros (src/finetune_timm_vggt.py:166-170).  lora_b_std > 0 gives the
@@ -154,6 +155,9 @@ class FinetuneGD(nn.Module):
             live.append((pos, n))
         self._flat = {"p": flat_p, "g": flat_g, "views": views, "m": torch.zeros_like(flat_p), "v": torch.zeros_like(flat_p),
                       "step": 0, "lr": lr, "wd": weight_decay, "max_norm": max_norm, "live": live, "spans": spans}
+        st, self._pending_opt_state = getattr(self, "_pending_opt_state", None), None
+        if st is not None:       # a checkpoint was loaded before the optimiser existed: resume its moments and step count
+            self._apply_optimizer_state(st)
         return self._flat
 
     def zero_grad_flat(self):
@@ -234,9 +238,16 @@ class FinetuneGD(nn.Module):
             f = self._flat
             checkpoint["gd_optimizer_state"] = {"exp_avg": f["m"].detach().clone(), "exp_avg_sq": f["v"].detach().clone(),
                                                 "step": f["step"], "numel": f["p"].numel()}
-        for k, v in list(checkpoint.items()):       # views of the flat parameter buffer: save the tensors, not the whole storage
+        # every tensor — the nested state_dicts included — is a view of the flat parameter buffer: save copies, so that torch.save
+        # writes the tensors and not the whole storage, and a later optimiser step cannot change a checkpoint that is still in memory
+        def own(v):
             if isinstance(v, torch.Tensor):
-                checkpoint[k] = v.detach().clone()
+                return v.detach().clone()
+            if isinstance(v, dict):
+                return type(v)((k, own(x)) for k, x in v.items())
+            return v
+        for k in list(checkpoint.keys()):
+            checkpoint[k] = own(checkpoint[k])
         checkpoint["epoch"] = self.current_epoch
         return checkpoint
 
@@ -252,12 +263,24 @@ class FinetuneGD(nn.Module):
             for i, a in enumerate(self.adapters):
                 a.load_state_dict(checkpoint[f"adapter_{i:03d}"])
             st = checkpoint.get("gd_optimizer_state")
-            if st is not None and self._flat is not None and st["numel"] == self._flat["p"].numel():
-                self._flat["m"].copy_(st["exp_avg"])
-                self._flat["v"].copy_(st["exp_avg_sq"])
-                self._flat["step"] = int(st["step"])
+            if st is not None:
+                if self._flat is None:       # the natural resume order: load first, configure_optimizers applies it
+                    self._pending_opt_state = st
+                else:
+                    self._apply_optimizer_state(st)
             self.current_epoch = int(checkpoint.get("epoch", self.current_epoch))
             self.update_temperature()
+
+    def _apply_optimizer_state(self, st):
+        """AdamW moments + step count of a checkpoint into the flat buffers; a layout mismatch is an error, not a silent restart."""
+        n = self._flat["p"].numel()
+        if int(st["numel"]) != n:
+            raise ValueError(f"checkpoint optimizer state has {int(st['numel'])} elements, this engine's trainable buffer has {n} "
+                             "(different backbone / rank / adapter configuration?)")
+        with torch.no_grad():
+            self._flat["m"].copy_(st["exp_avg"])
+            self._flat["v"].copy_(st["exp_avg_sq"])
+        self._flat["step"] = int(st["step"])
 
     # ------------------------------------------------------------------ student forwards
     def _kp_grid(self, h, w):

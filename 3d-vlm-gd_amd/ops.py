@@ -336,15 +336,17 @@ def l2_normalize(x, eps=1e-12):
 # ----------------------------------------------------------------------------------------------
 # image prep / tokens / conv glue
 # ----------------------------------------------------------------------------------------------
-def patch_im2col(img, H, W, P, Kp, mean, std, dtype):
-    """img [B,3,h,w] fp32 in [0,1] -> col [B*(H/P)*(W/P), Kp]: resize to (H,W) + Normalize + im2col, zero padded."""
+def patch_im2col(img, H, W, P, Kp, mean, std, dtype, stride=None):
+    """img [B,3,h,w] fp32 in [0,1] -> col [B*gh*gw, Kp]: resize to (H,W) + Normalize + im2col, zero padded.  stride = (sy, sx)
+    of the patch conv (default = P: gh = H/P; a smaller stride gives overlapping patches, gh = 1 + (H - P) // sy)."""
     import ctypes
     img = img.contiguous().float()
     B, _, h, w = img.shape
-    col = torch.empty(B * (H // P) * (W // P), Kp, dtype=dtype, device=img.device)
+    sy, sx = (P, P) if stride is None else stride
+    col = torch.empty(B * (1 + (H - P) // sy) * (1 + (W - P) // sx), Kp, dtype=dtype, device=img.device)
     m3, s3 = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
-    check(lib().gd_patch_im2col(ptr(img), ptr(col), B, h, w, H, W, P, Kp, m3, s3, dtype_code(col), stream()),
-          "gd_patch_im2col")
+    check(lib().gd_patch_im2col_strided(ptr(img), ptr(col), B, h, w, H, W, P, sy, sx, Kp, m3, s3, dtype_code(col), stream()),
+          "gd_patch_im2col_strided")
     return col
 
 

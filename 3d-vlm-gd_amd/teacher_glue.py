@@ -183,13 +183,20 @@ def _mast3r_target(recip, temperature):
     return out
 
 
+def mast3r_recip_logits(tgt_camaps, src_camaps):
+    """The temperature-INDEPENDENT part of `tgt_attn_map` (dust3r/dust3r/model.py:346-350): per decoder layer the head mean of
+    the raw cross-attention scores, averaged with the transposed other direction.  -> [L, B, N1, N2] fp32; with the symmetrised
+    two-pair batch of the trainer B = 2 and `_mast3r_target(recip, T)[1] / [0]` are cost_1 / cost_2 at temperature T — what
+    teacher_cache.TeacherTargetCache keeps as `cost_recip` so that the annealed temperature never re-runs the teacher."""
+    return torch.stack([(t.float().mean(dim=1) + s.float().mean(dim=1).transpose(-1, -2)) * 0.5
+                        for t, s in zip(tgt_camaps, src_camaps)]).contiguous()
+
+
 def mast3r_tgt_attn_map(tgt_camaps, src_camaps, temperature=3.0):
     """`tgt_attn_map` of dust3r/dust3r/model.py:346-366 (reciprocity on) from the decoder's per-layer raw cross-attention
     score maps, tgt [B,H,N1,N2] / src [B,H,N2,N1] (CrossAttention's `attn_map`): head mean and reciprocity average in
     torch (two reductions per layer), softmax / min-fill / layer mean in one HIP pass.  -> [B, N1, N2] fp32."""
-    recip = torch.stack([(t.float().mean(dim=1) + s.float().mean(dim=1).transpose(-1, -2)) * 0.5
-                         for t, s in zip(tgt_camaps, src_camaps)]).contiguous()
-    return _mast3r_target(recip, temperature)
+    return _mast3r_target(mast3r_recip_logits(tgt_camaps, src_camaps), temperature)
 
 
 def mast3r_tgt_attn_map_from_qk(q1s, k2s, q2s, k1s, scale, temperature=3.0):
@@ -253,7 +260,7 @@ def extract_vggt_targets(global_qk, depth_map, point_conf, extrinsic, intrinsic,
 
 
 def extract_mast3r_targets(desc_1, desc_2, conf_1, conf_2, pts3d_1, pts3d_2_from_1, pts3d_2, cost_1, cost_2, intrinsic=None,
-                           depth_1=None, depth_2=None, subsample=16, min_conf_thr=10, depth_kernel_size=3):
+                           depth_1=None, depth_2=None, subsample=16, min_conf_thr=10, depth_kernel_size=3, cost_recip=None):
     """`extract_mast3r_features` tail + `filter_and_match_keypoints` + the depth branch of `training_step`
     (src/finetune_timm_mast3r.py:345-469, 617-633) after the teacher forward.
     desc_k [H, W, 24], conf_k [H, W], pts3d_* [H, W, 3] (view-1 frame), cost_k [hw, hw] = `tgt_attn_map` rows
@@ -270,5 +277,8 @@ def extract_mast3r_targets(desc_1, desc_2, conf_1, conf_2, pts3d_1, pts3d_2_from
         depth_1 = post_process_depth(point_cloud_to_depth(pts3d_1.reshape(-1, 3), intrinsic, W, H)[0, 0], kernel_size=depth_kernel_size)
         depth_2 = post_process_depth(point_cloud_to_depth(pts3d_2.reshape(-1, 3), intrinsic, W, H)[0, 0], kernel_size=depth_kernel_size)
     k1, k2 = kp1[0], kp2[0]
-    return {"cost_1": _f(cost_1), "cost_2": _f(cost_2), "kp_1": k1, "kp_2": k2, "pts3d_1": _gather_xy(_f(pts3d_1), k1),
-            "pts3d_2": _gather_xy(_f(pts3d_2_from_1), k2), "depth_1": _f(depth_1), "depth_2": _f(depth_2)}
+    out = {"cost_1": _f(cost_1), "cost_2": _f(cost_2), "kp_1": k1, "kp_2": k2, "pts3d_1": _gather_xy(_f(pts3d_1), k1),
+           "pts3d_2": _gather_xy(_f(pts3d_2_from_1), k2), "depth_1": _f(depth_1), "depth_2": _f(depth_2)}
+    if cost_recip is not None:     # [L, 2, N, N] pre-softmax score maps: lets the cache follow the annealed temperature on its own
+        out["cost_recip"] = _f(cost_recip)
+    return out

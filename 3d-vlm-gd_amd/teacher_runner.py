@@ -137,9 +137,9 @@ class MASt3RTeacherRunner:
     """matcher: the user's AsymmetricMASt3R (the reference's fork returns `tgt_attn_map`, dust3r/dust3r/model.py:346-366);
     `inference` / `make_pairs`: dust3r.inference.inference and dust3r.image_pairs.make_pairs of the user's package (lazy import)."""
 
-    def __init__(self, matcher, inference=None, make_pairs=None, min_conf_thr=10, subsample=16):
+    def __init__(self, matcher, inference=None, make_pairs=None, min_conf_thr=10, subsample=16, keep_logits=False):
         self.matcher, self.inference, self.make_pairs = matcher, inference, make_pairs
-        self.min_conf_thr, self.subsample = min_conf_thr, subsample
+        self.min_conf_thr, self.subsample, self.keep_logits = min_conf_thr, subsample, keep_logits
 
     @torch.no_grad()
     def targets(self, rgb_mast3r_1, rgb_mast3r_2, temperature=1.0, intrinsic=None, depth_1=None, depth_2=None, device="cuda"):
@@ -149,12 +149,28 @@ class MASt3RTeacherRunner:
         if mk is None:
             from dust3r.image_pairs import make_pairs as mk
         self.matcher.temperature = temperature          # src/finetune_timm_mast3r.py:215, 224: the annealed target temperature
-        out = inf(mk([rgb_mast3r_1, rgb_mast3r_2], scene_graph="complete", prefilter=None, symmetrize=True), self.matcher, device,
-                  verbose=False)
+        # the decoder's raw cross-attention score maps (dust3r/dust3r/model.py:337, `_decoder` -> dec_feats, tgt_camap, src_camap) are
+        # picked up on the way: their head mean / reciprocity average is the temperature-independent part of `tgt_attn_map`, which
+        # lets TeacherTargetCache(keep_logits=True) follow the annealed temperature without another teacher forward
+        seen, dec = [], getattr(self.matcher, "_decoder", None)
+        if self.keep_logits and dec is not None:
+            def wrapped(*a, **k):
+                r = dec(*a, **k)
+                if isinstance(r, tuple) and len(r) == 3:
+                    seen.append((r[1], r[2]))
+                return r
+            self.matcher._decoder = wrapped
+        try:
+            out = inf(mk([rgb_mast3r_1, rgb_mast3r_2], scene_graph="complete", prefilter=None, symmetrize=True), self.matcher, device,
+                      verbose=False)
+        finally:
+            if self.keep_logits and dec is not None:
+                del self.matcher._decoder           # the instance attribute shadowing the method
         p1, p2 = out["pred1"], out["pred2"]
         dev = torch.device(device)
+        recip = tg.mast3r_recip_logits([t.to(dev) for t in seen[-1][0]], [t.to(dev) for t in seen[-1][1]]) if seen else None
         return tg.extract_mast3r_targets(
             p1["desc"][1].to(dev), p2["desc"][1].to(dev), p1["conf"][1].to(dev), p1["conf"][0].to(dev),
             p1["pts3d"][1].to(dev), p2["pts3d_in_other_view"][1].to(dev), p1["pts3d"][0].to(dev),
             p2["tgt_attn_map"][1].to(dev), p2["tgt_attn_map"][0].to(dev), intrinsic=intrinsic, depth_1=depth_1, depth_2=depth_2,
-            subsample=self.subsample, min_conf_thr=self.min_conf_thr)
+            subsample=self.subsample, min_conf_thr=self.min_conf_thr, cost_recip=recip)

@@ -479,6 +479,24 @@ class GDViT(nn.Module):
             self._pos_cache[key] = pe[0].contiguous()
         return self._pos_cache[key]
 
+    def _pos_strided(self, gh, gw, H, W):
+        """Position table for the overlapping-patch mode.  A foreign `interpolate_pos_encoding` bound onto the model (what
+        src/evaluate_timm.py:268-269 does with `_fix_pos_enc`) is honoured: it is called as the DINO ViT calls it — (tokens,
+        w, h) with w = the image's FIRST spatial extent — on a shape-only stand-in for the token tensor.  Without one the
+        table is the same formula (`_fix_pos_enc` == the dinov2 resampling with the strided grid: bicubic, +0.1 offset)."""
+        fn = getattr(self, "interpolate_pos_encoding", None)
+        if fn is None:
+            return self._pos(gh, gw)
+        key = ("foreign", gh, gw, H, W)
+        if key not in self._pos_cache:
+            with torch.no_grad():
+                stand_in = torch.empty(1, gh * gw + 1, self.embed_dim, device=self.pos_embed.device, dtype=self.pos_embed.dtype)
+                pe = fn(stand_in, H, W)
+            if tuple(pe.shape) != (1, gh * gw + 1, self.embed_dim):
+                raise ops._lib.GdHipError(f"interpolate_pos_encoding returned {tuple(pe.shape)}, expected {(1, gh * gw + 1, self.embed_dim)}")
+            self._pos_cache[key] = pe.detach().float()[0].contiguous()
+        return self._pos_cache[key]
+
     def _patch_plan(self):
         if self._pe_plan is None or self._pe_plan["dtype"] != self.dtype:
             w = self.patch_embed.proj.weight.detach().float()
@@ -497,18 +515,26 @@ class GDViT(nn.Module):
         are fused into the im2col kernel) -> tokens [B, 1+gh*gw, D]."""
         P = self.patch_embed.patch_size[0]
         st = self.patch_embed.proj.stride
-        st = (st, st) if isinstance(st, int) else tuple(st)
-        if st != (P, P):     # src/evaluate_timm.py:266-279 overrides the stride for dense features: not implemented by the fused kernel
-            raise ops._lib.GdHipError(f"patch_embed.proj.stride = {st}: the fused patch-embed kernel implements stride == patch "
-                                      f"size ({P}) only (overlapping-patch evaluation mode is not supported)")
+        st = (st, st) if isinstance(st, int) else tuple(int(v) for v in st)
         B, _, h, w = img.shape
         H, W = size if size is not None else (h, w)
-        assert H % P == 0 and W % P == 0, f"image size {(H, W)} not a multiple of patch {P}"
-        gh, gw = H // P, W // P
         pp = self._patch_plan()
-        col = ops.patch_im2col(img, H, W, P, pp["Kp"], self.mean, self.std, self.dtype)
+        if st == (P, P):
+            assert H % P == 0 and W % P == 0, f"image size {(H, W)} not a multiple of patch {P}"
+            gh, gw = H // P, W // P
+            col = ops.patch_im2col(img, H, W, P, pp["Kp"], self.mean, self.std, self.dtype)
+            pos = self._pos(gh, gw)
+        else:
+            # src/evaluate_timm.py:262-279: the tracking evaluation sets `patch_embed.proj.stride = (s, s)` (s = patch / 2) on the
+            # live model for dense features and swaps in `_fix_pos_enc`'s resampler (utils/functions.py:169-196).  Same conv
+            # weights on overlapping windows, 1 + (H - P) // s positions per axis (the patch conv is frozen: nothing else changes).
+            if st[0] <= 0 or st[1] <= 0 or H < P or W < P:
+                raise ops._lib.GdHipError(f"patch_embed.proj.stride = {st} with image {(H, W)} and patch {P}")
+            gh, gw = 1 + (H - P) // st[0], 1 + (W - P) // st[1]
+            col = ops.patch_im2col(img, H, W, P, pp["Kp"], self.mean, self.std, self.dtype, stride=st)
+            pos = self._pos_strided(gh, gw, H, W)
         tok = ops.gemm_nt(col, pp["w"], bias=pp["b"])
-        x = ops.assemble_tokens(tok, pp["cls"], self._pos(gh, gw), B, gh * gw).view(B, gh * gw + 1, -1)
+        x = ops.assemble_tokens(tok, pp["cls"], pos, B, gh * gw).view(B, gh * gw + 1, -1)
         if not isinstance(self.norm_pre, nn.Identity):
             x = self.norm_pre(x)
         return x

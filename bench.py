@@ -109,7 +109,7 @@ class Job:
                  exchange="torch"):
         from gd_amd import dp
         from gd_amd.finetune import FinetuneGD
-        from gd_testutil import synthetic_batch
+        from gd_amd.synthetic import synthetic_batch
         self.hw = (img // PATCH) ** 2
         self.P, self.world, self.geometry, self.dtype = P, world, geometry, dtype
         self.eng = FinetuneGD(r=4, backbone=backbone, patch_size=PATCH, img_size=img, variant=variant, geometry=geometry,
@@ -175,7 +175,6 @@ def main():
     import gd_amd  # noqa: F401
     from gd_amd import config as gd_config
     from gd_amd import dp, ops
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
 
     cfg = gd_config.load(args.config) if args.config else gd_config.preset("finetune_timm_mast3r_objaverse")
     variant = args.variant or cfg["variant"]
@@ -379,7 +378,7 @@ def parity_and_cpu_baseline(job, args):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import gd_oracle as O
     import torch.nn.functional as F
-    from gd_testutil import oracle_params
+    from gd_amd.synthetic import export_params as oracle_params
     eng, batch = job.eng, job.batches[0]
     with torch.no_grad():
         _, terms = eng.training_step(batch)

@@ -6,7 +6,9 @@
  * point here follows it with plain pointers and sizes:
  *   - returns 0 on success, negative on error; gd_last_error() holds the message (thread-local);
  *   - never allocates: outputs and workspaces are caller-owned (…_workspace_bytes() queries);
- *   - launches on the hipStream_t passed as `stream` (void*), stateless, thread-safe;
+ *   - launches on the hipStream_t passed as `stream` (void*); stateless and thread-safe: the only process-wide state is a
+ *     table of A/B options read ONCE from GD_* environment variables at first use (csrc/gd_knobs.h; thread-safe static
+ *     initialisation) and the dlopen'ed RCCL binding of gd_comm_*; the two debug hooks below are the documented exceptions;
  *   - dtype codes: 0 = float32, 1 = bfloat16; row-major, contiguous last dimension.
  * Each declaration cites the reference interface it replaces (paths relative to the reference root).
  */
@@ -23,11 +25,16 @@ extern "C" {
 const char* gd_last_error(void);
 int gd_abi_version(void);
 
-/* Diagnostic (no reference counterpart): per-phase shader-clock cycles of the persistent gemm_nt kernel.
- * enable=1 arms the probe for subsequent gd_gemm_nt calls, enable=0 disarms it; out6 (host, SIX values, may be NULL) receives the
- * sums over blocks since arming: [0] waiting for a tile's first K stage, [1] main loop, [2] epilogue items,
- * [3] tiles, [4] epilogue set-up + next-tile DMA issue, [5] the part of [1] spent in the per-K-step `s_waitcnt vmcnt` + barrier
- * (0 unless the library is built with -DGD_GEMM_STAGE_PROBE). */
+/* Debug hooks (no reference counterpart; NOT for production use, process-wide, not thread-safe).
+ * gd_debug_set / gd_debug_get: override / read one option of the table above by its name ("cv_grid", "cv_dbg", "gemm_persist",
+ *   ... — csrc/gd_knobs.h) — how tests force few persistent blocks and how the anatomy tools switch kernel parts off.
+ * gd_gemm_phase_probe: per-phase shader-clock cycles of the persistent gemm_nt kernel.  Works ONLY in a library built with
+ *   -DGD_GEMM_STAGE_PROBE (the probe's s_memtime reads cost 20 % even unarmed, so the shipped build has no probe code and this call
+ *   fails with a message when asked to arm).  enable=1 arms it for subsequent gd_gemm_nt calls, enable=0 disarms; out6 (host, SIX
+ *   values, may be NULL) receives the sums over blocks since arming: [0] waiting for a tile's first K stage, [1] main loop,
+ *   [2] epilogue items, [3] tiles, [4] epilogue set-up + next-tile DMA issue, [5] the part of [1] spent in the per-K-step wait + barrier. */
+int gd_debug_set(const char* name, int value);
+int gd_debug_get(const char* name);
 int gd_gemm_phase_probe(int enable, unsigned long long* out6);
 
 /* C[M,N] = epilogue(alpha * A[M,K] . W[N,K]^T); replaces torch nn.Linear / torch.bmm on the student path
@@ -108,6 +115,11 @@ int gd_l2norm_bwd(const float* y, const float* dy, const float* inv, float* dx, 
  * Normalize (:153), im2col for the PxP/stride-P conv of timm PatchEmbed; col [B*(H/P)*(W/P), Kp] zero-padded. */
 int gd_patch_im2col(const float* img, void* col, int B, int h, int w, int H, int W, int P, int Kp,
                     const float* mean3, const float* std3, int dtype, void* stream);
+/* The same with the conv stride decoupled from the patch size: src/evaluate_timm.py:262-266 sets
+ * `model.model.patch_embed.proj.stride = (s, s)` with s = patch/2 for dense tracking features (overlapping patches);
+ * col [B*(1+(H-P)/stride_y)*(1+(W-P)/stride_x), Kp], row (gy, gx) = the PxP window at (gy*stride_y, gx*stride_x). */
+int gd_patch_im2col_strided(const float* img, void* col, int B, int h, int w, int H, int W, int P, int stride_y,
+                            int stride_x, int Kp, const float* mean3, const float* std3, int dtype, void* stream);
 /* timm _pos_embed: cls + pos[0] | patch + pos[1:]  ->  tokens [B, Np+1, D]. */
 int gd_assemble_tokens(const void* patch, const float* cls, const float* pos, void* out, int B, int Np, int D,
                        int dtype, void* stream);
@@ -233,11 +245,13 @@ int gd_clip_adamw_ranges(float* params, const float* grads, float* exp_avg, floa
 int gd_cast(const void* in, void* out, long n, float scale, int in_dtype, int out_dtype, void* stream);
 
 /* flat_allreduce: the data-parallel step's one exchange — the sum over ranks of the flat fp32 gradient buffer — on RCCL over
- * xGMI (replaces Lightning DDP's bucketed all-reduce, src/main.py:147-151).  RCCL is bound at run time (dlopen): the calls
- * fail with a message where librccl.so is absent.  gd_comm_unique_id: rank 0 draws the 128-byte id, the caller hands it to
- * every rank (any transport); gd_comm_init: collective over the nranks processes (one per GPU, device already selected);
- * gd_flat_allreduce: in place on buf[n], algo 0 = one all-reduce, algo 1 = reduce-scatter + all-gather on the rank's
- * n / nranks slice (n % nranks == 0) — the direct form for the fully connected xGMI mesh. */
+ * xGMI (replaces Lightning DDP's bucketed all-reduce, src/main.py:147-151).  RCCL is bound at run time (dlopen, the copy the
+ * process already carries first; 2.x ABI checked through ncclGetVersion): the calls fail with a message where it is absent.
+ * gd_comm_rccl_version: the bound library's version code (or < 0).  gd_comm_unique_id: rank 0 draws the 128-byte id, the
+ * caller hands it to every rank (any transport); gd_comm_init: collective over the nranks processes (one per GPU, device
+ * already selected); gd_flat_allreduce: in place on buf[n], algo 0 = one ncclAllReduce, algo 1 = ncclReduceScatter +
+ * ncclAllGather on the rank's n / nranks slice (n % nranks == 0).  RCCL picks the schedule in both forms. */
+int gd_comm_rccl_version(void);
 int gd_comm_unique_id(void* out128);
 int gd_comm_init(void** comm, int nranks, int rank, const void* id128);
 int gd_comm_destroy(void* comm);

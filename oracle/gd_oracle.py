@@ -306,10 +306,43 @@ def vit_block(x, p, i, cfg, lora=None, ad=None):
     return x
 
 
+def fix_pos_enc(pos_embed, patch_size, stride_hw, npatch, w, h):
+    """The resampler src/evaluate_timm.py:268-269 binds onto the model when it overrides the patch-conv stride
+    (utils/functions.py:169-196, `_fix_pos_enc(patch_size, stride_hw)(self, x, w, h)`): token counts from the STRIDE, bicubic
+    with the +0.1 scale-factor offset.  w / h follow the DINO call convention (`B, nc, w, h = x.shape`: w is the image's
+    first spatial extent).  pos_embed [1, 1+N, D]; npatch = x.shape[1] - 1."""
+    N = pos_embed.shape[1] - 1
+    if npatch == N and w == h:
+        return pos_embed
+    class_pos, patch_pos = pos_embed[:, 0], pos_embed[:, 1:]
+    dim = pos_embed.shape[-1]
+    w0 = 1 + (w - patch_size) // stride_hw[1]
+    h0 = 1 + (h - patch_size) // stride_hw[0]
+    assert w0 * h0 == npatch, (w0, h0, npatch)
+    m = int(math.sqrt(N))
+    w0, h0 = w0 + 0.1, h0 + 0.1
+    grid = F.interpolate(patch_pos.reshape(1, m, m, dim).permute(0, 3, 1, 2),
+                         scale_factor=(w0 / math.sqrt(N), h0 / math.sqrt(N)), mode="bicubic", align_corners=False,
+                         recompute_scale_factor=False)
+    assert int(w0) == grid.shape[-2] and int(h0) == grid.shape[-1]
+    return torch.cat((class_pos.unsqueeze(0), grid.permute(0, 2, 3, 1).reshape(1, -1, dim)), dim=1)
+
+
 def vit_tokens(img, p, cfg):
     """patch-embed conv (PxP stride P) + cls + resampled pos-embed (+ norm_pre when
-    cfg['pre_norm']).  img [B,3,H,W] already normalised."""
+    cfg['pre_norm']).  img [B,3,H,W] already normalised.  cfg['patch_stride'] = (sy, sx): the evaluation-time stride
+    override of src/evaluate_timm.py:262-269 (overlapping patches, position table from `fix_pos_enc`)."""
     P = cfg["patch"]
+    st = cfg.get("patch_stride")
+    if st is not None and tuple(st) != (P, P):
+        x = F.conv2d(img, p["patch_embed.proj.weight"], p.get("patch_embed.proj.bias"), stride=tuple(st))
+        B, D, gh, gw = x.shape
+        x = x.flatten(2).transpose(1, 2)
+        x = torch.cat([p["cls_token"].expand(B, -1, -1), x], dim=1)
+        x = x + fix_pos_enc(p["pos_embed"], P, tuple(st), gh * gw, img.shape[-2], img.shape[-1]).to(x.dtype)
+        if cfg.get("pre_norm", False):
+            x = F.layer_norm(x, (D,), p["norm_pre.weight"], p["norm_pre.bias"], cfg["ln_eps"])
+        return x
     x = F.conv2d(img, p["patch_embed.proj.weight"], p.get("patch_embed.proj.bias"), stride=P)
     B, D, gh, gw = x.shape
     x = x.flatten(2).transpose(1, 2)

@@ -84,3 +84,65 @@ def test_overlapped_grad_reducer_world2():
     for r in range(world):
         assert out[r][:5] == want, out[r]
         assert out[r][5] == [(0, 20), (39, 56)]      # flat layout 12 | 5+3 pad | [12 | 7] +1 pad | 16; the late ranges are the complement
+
+
+class _GlooComm:
+    """Stand-in for dp.RcclComm on CPU: the same two members (`world`, `all_reduce_(flat, algo)`), with algo 1 spelled the way
+    gd_flat_allreduce spells it — reduce-scatter onto the rank's n / world slice, then all-gather in place."""
+
+    def __init__(self, rank, world):
+        self.rank, self.world, self.calls = rank, world, []
+
+    def all_reduce_(self, flat, algo=0):
+        import torch.distributed as dist
+        self.calls.append(int(algo))
+        if algo == 0:
+            dist.all_reduce(flat)
+            return flat
+        assert flat.numel() % self.world == 0
+        per = flat.numel() // self.world
+        mine = torch.empty(per)
+        # gloo has no reduce_scatter: the slice arithmetic of comm.hip (mine = buf + rank * per) on top of all_reduce
+        tmp = flat.clone()
+        dist.all_reduce(tmp)
+        mine.copy_(tmp[self.rank * per:(self.rank + 1) * per])
+        parts = [torch.empty(per) for _ in range(self.world)]
+        dist.all_gather(parts, mine)
+        flat.copy_(torch.cat(parts))
+        return flat
+
+
+def _worker_direct(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import gd_amd  # noqa: F401
+    from gd_amd import dp
+    dp.init_from_env(backend="gloo")
+    res = []
+    for algo in (None, 0, 1):
+        g = torch.arange(12, dtype=torch.float32) * (rank + 1)
+        comm = _GlooComm(rank, world)
+        red = dp.DirectGradReducer(g, comm, algo=algo)
+        red.attach()
+        red.wait_early()               # nothing is in flight before start(): the whole buffer goes in one exchange
+        assert comm.calls == []
+        red.start()
+        scale = red.finish()
+        red.detach()
+        res.append(((g * scale).tolist(), comm.calls))
+    out[rank] = res
+    torch.distributed.destroy_process_group()
+
+
+def test_direct_grad_reducer_contract_world2():
+    """dp.DirectGradReducer (the `--exchange direct` path) against a communicator stand-in: same wait_early / start / finish
+    contract as the overlapped reducer, exactly one exchange per step, the mean of the ranks' buffers for both algorithms."""
+    world, port = 2, 29617
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_direct, args=(world, port, out), nprocs=world, join=True)
+    want = (torch.arange(12, dtype=torch.float32) * 1.5).tolist()
+    for r in range(world):
+        for (vals, calls), algo in zip(out[r], (0, 0, 1)):
+            assert vals == want and calls == [algo]

@@ -1,6 +1,6 @@
 """The reference-signature surface (gd_amd/compat.py) against the reference-generated fixtures G1/G2/G4/G7/G9/G3
 and the oracle, the eager DepthAwareFeatureFusion.forward, duck-typed wrapper discovery with foreign classes, the
-`patch_embed.proj.stride` override, and plan invalidation when frozen weights are reloaded."""
+`patch_embed.proj.stride` override (G21), and plan invalidation when frozen weights are reloaded."""
 import pytest
 import torch
 import torch.nn as nn
@@ -247,15 +247,66 @@ def test_duck_typed_wrapper_discovery_with_foreign_classes():
         assert rel_err(model.blocks[i].adapter.up.weight.grad, tr["adapter"][i]["up"].grad) < 2e-4
 
 
-def test_patch_embed_stride_override_is_refused():
-    """src/evaluate_timm.py:266-279 mutates `patch_embed.proj.stride` for dense tracking features; the fused patch-embed
-    kernel implements stride == patch only, so any other stride must fail loudly instead of being ignored."""
+def _g21_model(dtype):
+    from gd_amd.vit import GDViT
+    g = load_golden("g21_stride_override")
+    model = GDViT(img_size=56, patch_size=14, embed_dim=64, depth=2, num_heads=1, init_values=1.0, dtype=dtype)
+    missing, unexpected = model.load_state_dict({k[3:]: v for k, v in g.items() if k.startswith("sd.")}, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    return g, model.cuda()
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 2e-5), ("bf16", 2e-2)])
+def test_patch_embed_stride_override_g21(dtype, tol):
+    """src/evaluate_timm.py:262-272 mutates `patch_embed.proj.stride` on the live model (overlapping patches for dense
+    tracking features) and binds `_fix_pos_enc`'s resampler as `interpolate_pos_encoding`.  Fixture G21 = that recipe on the
+    reference's in-tree ViT.  The engine must honour the stride (a) with its built-in position resampling and (b) with a
+    foreign `interpolate_pos_encoding` bound onto the model exactly as the reference binds it."""
+    import math
+    import types
+    import torch.nn.functional as F
+    g, model = _g21_model(dtype)
+
+    def foreign_fix_pos_enc(patch_size, stride_hw):       # a `_fix_pos_enc`-shaped override written for this test
+        def interpolate_pos_encoding(self, x, w, h):
+            npatch, N = x.shape[1] - 1, self.pos_embed.shape[1] - 1
+            if npatch == N and w == h:
+                return self.pos_embed
+            w0, h0 = 1 + (w - patch_size) // stride_hw[1], 1 + (h - patch_size) // stride_hw[0]
+            assert w0 * h0 == npatch
+            m, dim = int(math.sqrt(N)), x.shape[-1]
+            pp = F.interpolate(self.pos_embed[:, 1:].reshape(1, m, m, dim).permute(0, 3, 1, 2), mode="bicubic", align_corners=False,
+                               scale_factor=((w0 + 0.1) / m, (h0 + 0.1) / m), recompute_scale_factor=False)
+            return torch.cat((self.pos_embed[:, :1], pp.permute(0, 2, 3, 1).reshape(1, -1, dim)), dim=1)
+        return interpolate_pos_encoding
+
+    for tag in ("sq", "rect"):
+        img = g[f"{tag}.img"].cuda()
+        if hasattr(model, "interpolate_pos_encoding"):
+            del model.interpolate_pos_encoding
+        model.patch_embed.proj.stride = (14, 14)
+        base = model.forward_features(img)
+        assert base.shape[1] == 1 + (img.shape[-2] // 14) * (img.shape[-1] // 14)
+        model.patch_embed.proj.stride = (7, 7)
+        with torch.no_grad():
+            out = model.forward_features(img)
+        assert out.shape == g[f"{tag}.xnorm"].shape
+        assert rel_err(out, g[f"{tag}.xnorm"]) < tol, (tag, "built-in")
+        model.interpolate_pos_encoding = types.MethodType(foreign_fix_pos_enc(14, (7, 7)), model)
+        model.invalidate_plans()
+        with torch.no_grad():
+            out2 = model.forward_features(img)
+        assert rel_err(out2, g[f"{tag}.xnorm"]) < tol, (tag, "foreign override")
+        gh, gw = 1 + (img.shape[-2] - 14) // 7, 1 + (img.shape[-1] - 14) // 7
+        assert rel_err(model._pos_strided(gh, gw, img.shape[-2], img.shape[-1]), g[f"{tag}.pos"][0]) < 1e-6
+
+
+def test_patch_embed_bad_stride_fails_loudly():
     from gd_amd._lib import GdHipError
     from gd_amd.vit import create_vit
     model = create_vit("vit_tiny_test", patch_size=14, img_size=56, dtype="f32").cuda()
     img = torch.rand(1, 3, 56, 56, device="cuda")
-    model.forward_features(img)
-    model.patch_embed.proj.stride = (7, 7)
+    model.patch_embed.proj.stride = (0, 7)
     with pytest.raises(GdHipError):
         model.forward_features(img)
     model.patch_embed.proj.stride = (14, 14)

@@ -96,8 +96,8 @@ def test_bf16_full_size():
 
 @pytest.mark.parametrize("variant,dtype,P,hw,C", [("mast3r", torch.float32, 9, 672, 96), ("vggt", torch.bfloat16, 3, 1369, 1024),
                                                   ("mast3r", torch.bfloat16, 5, 768, 384)])
-def test_persistent_kernel_many_tiles_per_block(variant, dtype, P, hw, C, monkeypatch):
-    """The persistent forward with FEW blocks (GD_CV_GRID=8), so every block walks dozens of tiles: ring slots, the tile-parity
+def test_persistent_kernel_many_tiles_per_block(variant, dtype, P, hw, C):
+    """The persistent forward with FEW blocks (gd_debug_set("cv_grid", 8)), so every block walks dozens of tiles: ring slots, the tile-parity
     statistics / partial-sum buffers and the one-tile-ahead teacher prefetch all wrap around many times.  f32 operands
     against the fp64 oracle; bf16 (ViT-L width C = 1024 at hw = 1369; ViT-S width at the MASt3R grid hw = 768) against it on the
     bf16-rounded inputs.  Running twice gives bit-identical losses (fixed summation order)."""
@@ -111,10 +111,13 @@ def test_persistent_kernel_many_tiles_per_block(variant, dtype, P, hw, C, monkey
     m2 = torch.rand(P, hw, generator=gen, device="cuda") > 0.3
     c1, c2, ts = _teacher("cached", t1, t2)
     full = ops.cost_volume_kl(f1, f2, c1, c2, m1, m2, variant, tstats=ts)
-    monkeypatch.setenv("GD_CV_GRID", "8")
-    few = ops.cost_volume_kl(f1, f2, c1, c2, m1, m2, variant, tstats=ts)
-    few2 = ops.cost_volume_kl(f1, f2, c1, c2, m1, m2, variant, tstats=ts)
-    monkeypatch.delenv("GD_CV_GRID")
+    from gd_amd._lib import check, lib
+    check(lib().gd_debug_set(b"cv_grid", 8), "gd_debug_set")
+    try:
+        few = ops.cost_volume_kl(f1, f2, c1, c2, m1, m2, variant, tstats=ts)
+        few2 = ops.cost_volume_kl(f1, f2, c1, c2, m1, m2, variant, tstats=ts)
+    finally:
+        lib().gd_debug_set(b"cv_grid", 0)
     assert torch.equal(few, few2)
     assert rel_err(few, full) < 1e-6
     ol, _, _ = _oracle(f1.float(), f2.float(), t1, t2, m1, m2, variant)

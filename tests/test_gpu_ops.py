@@ -447,7 +447,9 @@ def test_flat_allreduce_cabi_single_rank():
     both algorithms; argument errors are reported through gd_last_error (multi-rank runs need one GPU per rank)."""
     from gd_amd import dp
     from gd_amd._lib import GdHipError
+    from gd_amd._lib import lib
     comm = dp.RcclComm(0, 1)
+    assert 20000 <= lib().gd_comm_rccl_version() < 30000       # the copy torch carries, 2.x ABI (enum values / id size)
     x = torch.arange(1000, dtype=torch.float32, device="cuda")
     y = x.clone()
     comm.all_reduce_(y, algo=0)

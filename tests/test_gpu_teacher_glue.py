@@ -131,6 +131,11 @@ def test_post_process_depth_vs_oracle(k, H, W, holes):
     assert one.shape == (H, W) and torch.equal(one, out[0])
 
 
+def ops_stats(e):
+    from gd_amd import ops
+    return ops.cost_volume_teacher_stats(e["cost_1"][None], e["cost_2"][None])[0]
+
+
 def test_target_composites_and_cache_feed_the_step():
     """extract_vggt_targets / extract_mast3r_targets -> TeacherTargetCache -> collate -> FinetuneGD.training_step: the
     composites chain the glue kernels exactly as the reference's extract_* / sample_keypoints / filter_and_match_keypoints do
@@ -195,11 +200,41 @@ def test_target_composites_and_cache_feed_the_step():
     assert torch.equal(t["kp_1"].cpu(), g["kp1"]) and torch.equal(t["kp_2"].cpu(), g["kp2"])
     rd = O.post_process_depth(O.point_cloud_to_depth(pts.reshape(-1, 3).cpu(), Km.cpu(), Wm, Hm)[0, 0].double(), kernel_size=3)
     assert float(((t["depth_1"].cpu().double() - rd).abs() > 1e-4 * (1 + rd.abs())).float().mean()) < 5e-3
-    # the MASt3R temperature schedule invalidates cached targets
+    # the MASt3R temperature schedule (src/finetune_timm_mast3r.py:217-227) moves every epoch: without logits or a cost producer
+    # the whole entry is rebuilt ...
     calls.clear()
     cache.get("m0", lambda: (calls.append(1), t)[1], temperature=1.0)
     cache.get("m0", lambda: (calls.append(1), t)[1], temperature=0.9)
     assert len(calls) == 2
+    # ... with a cost producer only the cost maps are, and the keypoints / depth stay the cached tensors
+    kp_before = cache.get("m0", temperature=0.9)["kp_1"]
+    cost9 = torch.softmax(torch.randn(24, 24, generator=gen), -1).cuda()
+    e9 = cache.get("m0", lambda: (calls.append(1), t)[1], temperature=0.8, cost_producer=lambda T: (cost9, cost9))
+    assert len(calls) == 2 and cache.cost_refreshes == 1 and e9["kp_1"] is kp_before
+    assert torch.equal(e9["cost_1"][:, :24], cost9) and e9["_temperature"] == 0.8
+    # ... and with the pre-softmax score maps kept in the entry the cache re-applies the target kernel itself (G17's formula)
+    keep = TeacherTargetCache(keep_logits=True)
+    L_, n_ = 3, 24
+    tgt = [torch.randn(2, 4, n_, n_, generator=gen).cuda() for _ in range(L_)]
+    src = [torch.randn(2, 4, n_, n_, generator=gen).cuda() for _ in range(L_)]
+    recip = tg.mast3r_recip_logits(tgt, src)
+    full = lambda T: dict(t, cost_1=tg.mast3r_tgt_attn_map(tgt, src, T)[1], cost_2=tg.mast3r_tgt_attn_map(tgt, src, T)[0], cost_recip=recip)
+    calls.clear()
+    keep.get("m1", lambda: (calls.append(1), full(1.0))[1], temperature=1.0)
+    e5 = keep.get("m1", lambda: (calls.append(1), full(0.5))[1], temperature=0.5)
+    assert len(calls) == 1 and keep.cost_refreshes == 1
+    want = O.mast3r_tgt_attn_map([x.cpu().double() for x in tgt], [x.cpu().double() for x in src], 0.5)
+    assert rel_err(e5["cost_1"][:, :n_], want[1]) < 1e-5 and rel_err(e5["cost_2"][:, :n_], want[0]) < 1e-5
+    fresh = ops_stats(e5)
+    assert rel_err(e5["cost_tstats"], fresh) < 1e-6
+    assert "cost_recip" not in cache.put("m2", full(1.0), 1.0)            # dropped unless the cache was built with keep_logits
+    # a pair without surviving keypoints: the producers return None (src/finetune_timm_mast3r.py:604-607); remembered, never re-run
+    calls.clear()
+    assert cache.get("empty", lambda: (calls.append(1), None)[1], temperature=1.0) is None
+    assert cache.get("empty", lambda: (calls.append(1), None)[1], temperature=0.7) is None and len(calls) == 1
+    b2 = cache.collate(["pair0", "empty", "pair1"], rgb[:3], rgb[1:4])
+    assert b2["counts"].shape[0] == 2 and torch.equal(b2["rgb_1"], rgb[[0, 2]]) and torch.equal(b2["rgb_2"], rgb[[1, 3]])
+    assert cache.collate(["empty"], rgb[:1], rgb[1:2]) is None
 
 
 def test_vggt_teacher_runner_with_a_fake_teacher():

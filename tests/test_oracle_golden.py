@@ -136,6 +136,22 @@ def test_vit_forward_backward():
                 assert rel_err(tr["adapter"][bi][k].grad, g[f"g_{k}_{bi}"]) < 1e-4, (bi, k)
 
 
+def test_stride_override_tokens_g21():
+    """src/evaluate_timm.py:262-272 on the reference's in-tree ViT (stride 7 on patch 14, `_fix_pos_enc` bound): fixture G21."""
+    g = load_golden("g21_stride_override")
+    sd = {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+    cfg = dict(patch=14, dim=64, depth=2, heads=1, ln_eps=1e-6, pos_interp="dinov2", patch_stride=(7, 7))
+    for tag in ("sq", "rect"):
+        img = g[f"{tag}.img"]
+        h, w = img.shape[-2:]
+        gh, gw = 1 + (h - 14) // 7, 1 + (w - 14) // 7
+        assert rel_err(O.fix_pos_enc(sd["pos_embed"], 14, (7, 7), gh * gw, h, w), g[f"{tag}.pos"]) < 1e-6
+        x = O.vit_tokens(O.normalize_image(img, (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)), sd, cfg)
+        for i in range(2):
+            x = O.vit_block(x, sd, i, cfg, None, None)
+        assert rel_err(O.final_norm(x, sd, cfg), g[f"{tag}.xnorm"]) < 2e-5
+
+
 def test_rope2d():
     g = load_golden("g13_rope2d")
     tok = g["tokens_bhnd"].transpose(1, 2).contiguous()
