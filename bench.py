@@ -15,9 +15,11 @@ clip + AdamW.  Inputs are resident in HBM before the timed region.  Prints ONE J
 
 Extra objects on the line:
   roofline              the dominant kernel (persistent gemm_nt, MFMA-bound) from HIP events around every launch in the timed region
-  roofline_cost_volume  the HBM-bound fused cost-volume KL, timed on its own after the run
+  roofline_cost_volume  the HBM-bound fused cost-volume KL, timed on its own after the run (also as roofline.cost_volume_kl_fwd);
+                        frac = bytes that must move / time / peak, for the benched row masks and for every row kept (`unmasked`)
   parity                engine loss vs the CPU oracle (oracle/gd_oracle.py, fp32) on the same weights and the same pairs
-  f32                   the same workload on the f32 engine (the reference's arithmetic precision), measured in the same run
+  f32                   the same workload on the f32 engine (the reference's arithmetic precision): same --steps / --warmup, own
+                        roofline and parity (also as config.reference_precision_run and roofline.f32_engine)
   other_configs         short runs of BASELINE configs 3 / 5-like and of the reference's own token geometry
   comm                  N > 1: all-reduce time of the two gradient chunks and the exposed fraction of the step
   cpu_baseline          the CPU oracle on a bounded sample of the same workload, rank 0 / N=1 only
@@ -213,7 +215,10 @@ def main():
                                       f"blocks 4-11, {img}^2 pairs, {'shared-518' if args.geometry == 'shared' else 'reference (80x80-token)'} geometry, {variant} losses "
                                       f"(AP+depth+intra+cost-KL), {P} pairs/GPU, {N} keypoints/pair, hw={hw}",
                           "pairs_per_gpu": P, "global_pairs": P * world, "parallelism": f"dp{world}",
-                          "world_size_seen": world, "backend": args.backend or "nccl (RCCL)", "exchange": args.exchange},
+                          "world_size_seen": world, "backend": args.backend or "nccl (RCCL)", "exchange": args.exchange,
+                          "teacher": "excluded from the timed region: targets are synthetic and resident, as a warm TeacherTargetCache "
+                                     "holds them (the frozen teacher runs once per pair, outside the student step)",
+                          "engine_dtype": args.dtype},
                "loss": round(float(loss.detach()), 6),
                "vit_algorithmic_tflops": round(pairs_per_s / world * flop_pair / 1e12, 2),
                "vit_frac_of_mfma_peak": round(pairs_per_s / world * flop_pair / 1e12 / PEAK_TFLOPS[args.dtype], 4)}
@@ -232,7 +237,10 @@ def main():
             if args.gemm_shapes:
                 for k, (cnt, sms, tf) in sorted(prof.by_shape().items(), key=lambda kv: -kv[1][1]):
                     print(f"gemm_nt {str(k):58s} x{cnt:4d} {sms / args.steps:8.3f} ms/step {tf:7.1f} TF/s", file=sys.stderr)
-        out["roofline_cost_volume"] = cost_volume_roofline(job, args, dev, variant)
+        cvr = cost_volume_roofline(job, args, dev, variant)
+        out["roofline_cost_volume"] = cvr
+        if "roofline" in out:       # the driver's parser keeps `roofline` and `config`: the second north-star kernel rides inside
+            out["roofline"]["cost_volume_kl_fwd"] = cvr
         if comm:
             out["comm"] = comm
         # the CPU oracle legs (parity of the benched batch, cpu_baseline) and the companion measurements run at N = 1 only: on N > 1
@@ -247,6 +255,15 @@ def main():
         extras = companion_runs(args, variant, backbone, weights, dev, rank, world)
         if rank == 0:
             out.update(extras)
+            if "f32" in extras:       # first-class beside the headline, where the driver's parser keeps it
+                f = extras["f32"]
+                out["config"]["reference_precision_run"] = {
+                    "dtype": "f32", "value": f["value"], "unit": "image-pairs/s", "ms_per_step": f["ms_per_step"], "steps": f["steps"],
+                    "warmup": f["warmup"], "vit_frac_of_mfma_peak": f["vit_frac_of_mfma_peak"],
+                    "parity_rel_err": f.get("parity", {}).get("rel_err"), "note": "same workload on the f32 engine (exact-f32 MFMA): the "
+                    "reference trains in fp32; gfx950 has no TF32"}
+                if "roofline" in out and "roofline" in f:
+                    out["roofline"]["f32_engine"] = f["roofline"]
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -255,7 +272,10 @@ def main():
 
 
 def cost_volume_roofline(job, args, dev, variant):
-    """The cost-volume kernel on its own (HBM-bound; algorithmic bytes per SURVEY 8d)."""
+    """The cost-volume KL forward on its own (HBM-bound).  `frac` = the bytes the launch MUST move / its time / 8 TB/s — masked
+    teacher rows never enter the loss and are not fetched, so they are not credited: with the benched trainer's row masks the
+    needed bytes are features + kept teacher rows + masks; with every row kept (`unmasked`) they are SURVEY 8d's algorithmic
+    byte count (2 hw D s + 2 hw^2 4 + 2 hw per pair)."""
     from gd_amd import ops
     P, hw, D = job.P, job.hw, job.eng.embedding_dim
     es = 2 if args.dtype == "bf16" else 4
@@ -272,51 +292,50 @@ def cost_volume_roofline(job, args, dev, variant):
         g = h // PATCH
         m1 = torch.nn.functional.interpolate(b["mask_1"][:, None].float(), size=(g, g), mode="nearest").reshape(P, -1) > 0
         m2 = torch.nn.functional.interpolate(b["mask_2"][:, None].float(), size=(g, g), mode="nearest").reshape(P, -1) > 0
-
-    def cv_fwd():
-        with torch.no_grad():
-            return ops.cost_volume_kl(f1, f2, b["cost_1"], b["cost_2"], m1, m2, variant, tstats=b["cost_tstats"])
-
-    def cv_fb():
-        f1.grad = f2.grad = None
-        ops.cost_volume_kl(f1, f2, b["cost_1"], b["cost_2"], m1, m2, variant, tstats=b["cost_tstats"]).sum().backward()
-    tf = ops.time_on_stream(cv_fwd, 2, 5)
-    tfb = ops.time_on_stream(cv_fb, 2, 5)
-    # the same launch with dense random masks (70 % of the rows kept): nothing to skip, the whole teacher is read
-    d1, d2 = torch.rand(P, hw, device=dev) > 0.3, torch.rand(P, hw, device=dev) > 0.3
-
-    def cv_fwd_dense():
-        with torch.no_grad():
-            return ops.cost_volume_kl(f1, f2, b["cost_1"], b["cost_2"], d1, d2, variant, tstats=b["cost_tstats"])
-    tfd = ops.time_on_stream(cv_fwd_dense, 2, 5)
-    fwd_bytes = P * (2 * hw * D * es + 2 * hw * hw * 4 + 2 * hw)
+    feat_bytes = P * (2 * hw * D * es + 2 * hw)
+    fwd_bytes = feat_bytes + P * 2 * hw * hw * 4               # every teacher row
     bwd_bytes = fwd_bytes + P * 2 * hw * D * es
-    # what the kernel has to read once masked teacher rows are skipped (they never enter the loss): features + kept teacher rows + masks
-    kept = int(m1.sum()) + int(m2.sum())
-    needed_bytes = P * (2 * hw * D * es + 2 * hw) + kept * hw * 4
-    # HBM traffic: replayed from the committed PMC passes of the same configuration (one file per kind of row mask)
-    def replay(name):
+
+    def timed(ma, mb, backward=False):
+        def fwd():
+            with torch.no_grad():
+                return ops.cost_volume_kl(f1, f2, b["cost_1"], b["cost_2"], ma, mb, variant, tstats=b["cost_tstats"])
+
+        def fb():
+            f1.grad = f2.grad = None
+            ops.cost_volume_kl(f1, f2, b["cost_1"], b["cost_2"], ma, mb, variant, tstats=b["cost_tstats"]).sum().backward()
+        return ops.time_on_stream(fb if backward else fwd, 2, 5)
+
+    def replay(name):    # HBM traffic per launch: PMC counters cannot be read inside the run; committed passes of this configuration
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path) and (P, hw, D, args.dtype) == (32, 1369, 768, "bf16"):
             with open(path) as fh:
                 return json.load(fh)["fwd_hbm_bytes_per_launch"], f"profiles/{name} (FETCH_SIZE / WRITE_SIZE, separate --pmc passes, width-corrected; NOT measured in this run)"
         return None, None
-    traffic, src = replay("r02_pmc_cost_volume_traffic_kp.json") if variant == "mast3r" else (None, None)
-    traffic_dense, src_dense = replay("r02_pmc_cost_volume_traffic.json")
-    return {"kernel": "cost_volume_kl fwd (cv_norm + cv_fwd_persist + cv_finalize; teacher-row statistics cached per pair)", "bound": "hbm",
-            "achieved": round(fwd_bytes / tf / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-            "frac": round(fwd_bytes / tf / 1e9 / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_replayed_from": src,
-            "algorithmic_bytes_per_launch": fwd_bytes,
-            "masks": "keypoint-patch masks of the benched batch" if variant == "mast3r" else "co-view masks of the benched batch",
-            "kept_row_fraction": round(kept / (2 * P * hw), 4), "needed_bytes_per_launch": needed_bytes,
-            "frac_of_needed_bytes": round(needed_bytes / tf / 1e9 / PEAK_HBM_GBS, 4),
-            "dense_masks": {"kept_row_fraction": 0.7, "us_per_pair_fwd": round(tfd / P * 1e6, 2),
-                            "achieved": round(fwd_bytes / tfd / 1e9, 1), "frac": round(fwd_bytes / tfd / 1e9 / PEAK_HBM_GBS, 4),
-                            "traffic": traffic_dense,
-                            "traffic_replayed_from": src_dense and src_dense + " — collected before masked teacher rows were skipped: an upper bound"},
-            "us_per_pair_fwd": round(tf / P * 1e6, 2),
-            "fwd_bwd_GBps": round((fwd_bytes + bwd_bytes) / tfb / 1e9, 1),
-            "us_per_pair_fwd_bwd": round(tfb / P * 1e6, 2)}
+
+    def leg(ma, mb, pmc_file):
+        t = timed(ma, mb)
+        kept = int(ma.sum()) + int(mb.sum())
+        needed = feat_bytes + kept * hw * 4
+        traffic, src = replay(pmc_file) if pmc_file else (None, None)
+        return {"kept_row_fraction": round(kept / (2 * P * hw), 4), "us_per_pair_fwd": round(t / P * 1e6, 2),
+                "needed_bytes_per_launch": needed, "achieved": round(needed / t / 1e9, 1),
+                "frac": round(needed / t / 1e9 / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_replayed_from": src,
+                "traffic_over_needed": round(traffic / needed, 3) if traffic else None}, t
+    ones = torch.ones(P, hw, dtype=torch.bool, device=dev)
+    bench_masks, tf = leg(m1, m2, "r03_pmc_cost_volume_traffic_kp.json" if variant == "mast3r" else None)
+    unmasked, tfu = leg(ones, ones, "r03_pmc_cost_volume_traffic_full.json")
+    tfb = timed(m1, m2, backward=True)
+    tfbu = timed(ones, ones, backward=True)
+    out = {"kernel": "cost_volume_kl fwd (fused feature norm + contraction + both softmax-KL directions; teacher-row statistics cached per pair)",
+           "bound": "hbm", "peak": PEAK_HBM_GBS, "unit": "GB/s",
+           "masks": "keypoint-patch masks of the benched batch" if variant == "mast3r" else "co-view masks of the benched batch",
+           "frac_definition": "bytes the launch must move (features + KEPT teacher rows + masks) / time / peak: skipped rows earn nothing"}
+    out.update(bench_masks)
+    out["unmasked"] = dict(unmasked, algorithmic_bytes_per_launch_survey_8d=fwd_bytes,
+                           fwd_bwd_GBps=round((fwd_bytes + bwd_bytes) / tfbu / 1e9, 1), us_per_pair_fwd_bwd=round(tfbu / P * 1e6, 2))
+    out["us_per_pair_fwd_bwd"] = round(tfb / P * 1e6, 2)
+    return out
 
 
 def comm_report(job, args, dev, dt):
@@ -428,31 +447,35 @@ def parity_and_cpu_baseline(job, args):
 
 
 def companion_runs(args, variant, backbone, weights, dev, rank, world):
-    """Short driver-observed runs beside the headline (same process, after it): the f32 engine on the SAME workload (the
-    reference's arithmetic precision), and — N = 1 only — ViT-L/14 with the VGGT losses (BASELINE config 3), a CLIP-style
-    pre-norm ViT-L/14 (config 5) and the reference's own token geometry."""
+    """Driver-observed runs beside the headline (same process, after it): the f32 engine — the reference's arithmetic precision —
+    on the SAME workload with the SAME --steps / --warmup, its own GEMM roofline and its own parity check against the CPU oracle;
+    and, short (2 steps), ViT-L/14 with the VGGT losses (BASELINE config 3), a CLIP-style pre-norm ViT-L/14 (config 5) and the
+    reference's own token geometry."""
     from gd_amd import ops
     out = {}
     P, img, N = args.pairs_per_gpu, args.img, args.keypoints
 
-    def run(bb, var, dtype, geometry, pairs, vit_kwargs=None, steps=2, prof=False, wts=None):
+    def run(bb, var, dtype, geometry, pairs, vit_kwargs=None, steps=2, warmup=1, prof=False, wts=None, parity=False):
         job = Job(bb, var, dtype, geometry, pairs, img, N, dev, rank, world, vit_kwargs=vit_kwargs, weights=wts)
         pr = ops.GemmProfiler() if prof else None
-        dt, loss = job.timed(steps, 1, dev, pr)
+        dt, loss = job.timed(steps, warmup, dev, pr)
         fl = flops_per_pair(job.eng, job.hw, geometry)
         pps = pairs * world * steps / dt
         rec = {"value": round(pps, 3), "unit": "image-pairs/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
-               "warmup": 1, "dtype": dtype, "pairs_per_gpu": pairs, "backbone": bb, "variant": var, "geometry": geometry,
+               "warmup": warmup, "dtype": dtype, "pairs_per_gpu": pairs, "backbone": bb, "variant": var, "geometry": geometry,
                "loss": round(float(loss.detach()), 6),
                "vit_frac_of_mfma_peak": round(pps / world * fl / 1e12 / PEAK_TFLOPS[dtype], 4)}
         if pr is not None:
             rec["roofline"] = gemm_roofline(pr, dtype, dt, steps)
+        if parity and not args.no_cpu_baseline:
+            rec["parity"] = parity_and_cpu_baseline(job, args)[0]
         del job
         torch.cuda.empty_cache()
         return rec
 
     if args.dtype != "f32":
-        out["f32"] = run(backbone, variant, "f32", args.geometry, P, prof=not args.no_kernel_events, wts=weights)
+        out["f32"] = run(backbone, variant, "f32", args.geometry, P, steps=args.steps, warmup=args.warmup,
+                         prof=not args.no_kernel_events, wts=weights, parity=world == 1)
     if world == 1 and args.geometry == "shared" and backbone == "vit_base":
         out["other_configs"] = {
             "vit_large_vggt": run("vit_large", "vggt", args.dtype, "shared", 16),

@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from gd_testutil import synthetic_batch
-from test_gpu_step import _oracle_step
+from test_gpu_step import OracleTrainer
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -40,7 +40,8 @@ def _run_case(name, backbone, variant, dtype, img=518, P=2, N=300, vit_kwargs=No
                      teacher_patch=14, lora_b_std=1e-3, vit_kwargs=vk, **(eng_kwargs or {})).cuda()
     hw = (img // 14) ** 2
     batch = synthetic_batch(P, img, img, N, hw, "cuda", seed=1234, teacher_patch=14, counts=counts)
-    ref_loss, ref_terms, ref_grads, ref_params, ref_norm = _oracle_step(eng, batch, P)
+    orc = OracleTrainer(eng)
+    ref_loss, ref_terms, ref_grads, ref_params, ref_norm = orc.step(batch, P)
     flat = eng.configure_optimizers()
     before = [q.detach().clone() for q in eng.trainable_parameters()]
     loss, terms = eng.training_step(batch)
@@ -57,6 +58,7 @@ def _run_case(name, backbone, variant, dtype, img=518, P=2, N=300, vit_kwargs=No
     g_ref = torch.cat([g.reshape(-1) for g in ref_grads])
     rec["grad_rel_fro"] = ((g_hip - g_ref).norm() / g_ref.norm()).item()
     rec["grad_cos"] = (torch.dot(g_hip, g_ref) / (g_hip.norm() * g_ref.norm())).item()
+    rec["groups"] = _group_table(orc.names, [q.grad.detach().double().cpu() for q in ps], ref_grads, float(g_ref.norm()))
     norm = eng.optimizer_step()
     rec["grad_norm"], rec["ref_grad_norm"] = norm.item(), ref_norm.item()
     # updated weights: the step moved every element by <= lr; compare the UPDATE vectors (post - pre), not the weights
@@ -71,12 +73,33 @@ def _run_case(name, backbone, variant, dtype, img=518, P=2, N=300, vit_kwargs=No
     return rec
 
 
+def _group_table(names, g_hip, g_ref, total_norm):
+    """Per parameter group (LoRA-A / LoRA-B / adapter down / up per block, refine_conv, depth head): relative Frobenius error and
+    cosine of the engine's gradient against the oracle's, and the group's share of the whole gradient's norm."""
+    groups = {}
+    for n, a, b in zip(names, g_hip, g_ref):
+        if n.startswith("depth_attention_unused"):
+            continue
+        parts = n.split("/")
+        key = parts[0] if parts[0] in ("refine_conv", "depth_head") else f"{parts[0]}/blk{int(parts[1]):02d}"
+        groups.setdefault(key, []).append((a.reshape(-1), b.reshape(-1)))
+    out = {}
+    for k, lst in groups.items():
+        a, b = torch.cat([x for x, _ in lst]), torch.cat([y for _, y in lst])
+        nb = float(b.norm())
+        out[k] = {"rel_fro": float((a - b).norm() / max(nb, 1e-30)), "cos": float(torch.dot(a, b) / max(float(a.norm()) * nb, 1e-30)),
+                  "share_of_grad_norm": nb / total_norm}
+    return out
+
+
 def _check(rec, tol=TOL, cos=0.99):
     assert rec["rel_err"] < tol, rec
     for k, t in rec["terms"].items():
         assert t["rel_err"] < tol, (k, t)
     assert abs(rec["grad_norm"] - rec["ref_grad_norm"]) < 2e-2 * rec["ref_grad_norm"], rec
     assert rec["grad_cos"] > cos, rec
+    if rec.get("grad_fro_tol") is not None:
+        assert rec["grad_rel_fro"] < rec["grad_fro_tol"], (rec["grad_rel_fro"], rec["groups"])
     assert rec["max_weight_diff_over_lr"] <= 2.1, rec       # AdamW step 1 moves an element by at most lr (sign flips: 2 lr)
     assert rec["weights_rel_fro"] < 1e-3, rec
 
@@ -104,8 +127,58 @@ def test_prenorm_vit_large_bf16_step_matches_oracle():
 
 
 # BASELINE config 5 as worded: CLIP-style ViT-L/14 student + MASt3R teacher, "mixed corr + depth + cost losses", bf16 — the MASt3R
-# trainer's loss kernels (masked rows -> softmax KL, keypoint patch masks) with the depth L1 term switched on as well
+# trainer's loss kernels (masked rows -> softmax KL, keypoint patch masks) with the depth L1 term switched on as well, at the
+# benched resolution (518^2, 1370 tokens, hw = 1369)
 def test_prenorm_vit_large_bf16_mast3r_mixed_losses_step_matches_oracle():
-    rec = _run_case("prenorm_vit_large_336_mast3r_all_losses_bf16", "vit_large", "mast3r", "bf16", img=336, P=1, N=200,
+    rec = _run_case("prenorm_vit_large_518_mast3r_all_losses_bf16", "vit_large", "mast3r", "bf16", img=518, P=1, N=300,
                     vit_kwargs=dict(pre_norm=True, ln_eps=1e-5, pos_interp="timm"), eng_kwargs=dict(depth_loss_weight=1.0))
     _check(rec)
+
+
+# The bf16 engine against the fp32 CPU oracle over a TRAJECTORY: ten optimiser steps from the same weights on the same pair
+# (north_star: "outputs match the reference CPU path (loss values and updated LoRA weights) within stated fp tolerance").
+# Stated tolerances (held below): loss of every step 1e-3 rel; after ten steps the accumulated update dW = W10 - W0 of the whole
+# trainable vector within BF16_TRAJ_DW_FRO relative Frobenius / cosine BF16_TRAJ_DW_COS of the oracle's, per group recorded.
+# AdamW's first steps move every element by ~lr * sign(g): an element whose gradient is smaller than the bf16 noise floor of its
+# group takes a coin-flip direction in ANY reduced-precision run, so dW is compared as a vector, not element-wise.
+BF16_TRAJ_DW_FRO, BF16_TRAJ_DW_COS = 0.35, 0.94
+F32_TRAJ_DW_FRO = 0.02
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_vit_base_518_ten_steps_follow_the_fp32_oracle(dtype):
+    from gd_amd.finetune import FinetuneGD
+    torch.manual_seed(0)
+    P, img, N, steps = 1, 518, 300, 10
+    eng = FinetuneGD(r=4, backbone="vit_base", patch_size=14, img_size=img, variant="mast3r", geometry="shared", dtype=dtype,
+                     teacher_patch=14, lora_b_std=1e-3, vit_kwargs=dict(init_values=1.0)).cuda()
+    batch = synthetic_batch(P, img, img, N, (img // 14) ** 2, "cuda", seed=4321, teacher_patch=14)
+    orc = OracleTrainer(eng, dtype=torch.float32)            # the reference's arithmetic precision
+    eng.configure_optimizers()
+    ps = eng.trainable_parameters()
+    w0 = [q.detach().double().cpu().clone() for q in ps]
+    rec = {"steps": steps, "dtype": dtype, "loss": [], "ref_loss": [], "loss_rel_err": []}
+    for _ in range(steps):
+        loss, _, _ = eng.fit_step(batch)
+        ref_loss, _, _, ref_params, _ = orc.step(batch, P)
+        rec["loss"].append(loss.item())
+        rec["ref_loss"].append(ref_loss)
+        rec["loss_rel_err"].append(abs(loss.item() - ref_loss) / abs(ref_loss))
+    d_hip = [q.detach().double().cpu() - a for q, a in zip(ps, w0)]
+    d_ref = [r.double() - a for r, a in zip(ref_params, w0)]
+    a, b = torch.cat([x.reshape(-1) for x in d_hip]), torch.cat([x.reshape(-1) for x in d_ref])
+    rec["dw_rel_fro"] = float((a - b).norm() / b.norm())
+    rec["dw_cos"] = float(torch.dot(a, b) / (a.norm() * b.norm()))
+    w_hip = torch.cat([q.detach().double().cpu().reshape(-1) for q in ps])
+    w_ref = torch.cat([r.double().reshape(-1) for r in ref_params])
+    rec["weights_rel_fro"] = float((w_hip - w_ref).norm() / w_ref.norm())
+    rec["max_weight_diff_over_lr"] = float((w_hip - w_ref).abs().max() / 1e-5)
+    rec["groups_dw"] = _group_table(orc.names, d_hip, d_ref, float(b.norm()))
+    rec["stated_tolerance"] = {"loss_rel": TOL, "dw_rel_fro": BF16_TRAJ_DW_FRO if dtype == "bf16" else F32_TRAJ_DW_FRO,
+                               "dw_cos": BF16_TRAJ_DW_COS if dtype == "bf16" else 0.999}
+    _record(f"trajectory10_vit_base_518_mast3r_{dtype}", rec)
+    assert max(rec["loss_rel_err"]) < TOL, rec["loss_rel_err"]
+    assert rec["loss"][-1] < rec["loss"][0]                  # and it trains
+    assert rec["dw_rel_fro"] < rec["stated_tolerance"]["dw_rel_fro"], rec
+    assert rec["dw_cos"] > rec["stated_tolerance"]["dw_cos"], rec
+    assert rec["weights_rel_fro"] < 1e-3

@@ -68,54 +68,77 @@ def test_vit_taps_and_grads(dtype, tol, gtol, pre_norm):
         assert err(ad.up.weight.grad, tr["adapter"][i]["up"].grad) < gtol
 
 
+class OracleTrainer:
+    """The CPU oracle as a trainer: same weights as `eng` at construction, `step(batch, P)` = per-pair losses, mean, gradients of
+    every trainable tensor (engine order), one clip + AdamW step on its own copies (moments kept across steps)."""
+
+    def __init__(self, eng, dtype=torch.float64):
+        p, tr, refine, head, cfg = oracle_params(eng)
+        self.dtype, self.cfg = dtype, cfg
+        self.p = {k: v.to(dtype) for k, v in p.items()}
+        self.leaves, self.names = [], []
+
+        def leaf(t, name):
+            t = t.to(dtype).requires_grad_(True)
+            self.leaves.append(t)
+            self.names.append(name)
+            return t
+        blocks = sorted(tr["lora"])
+        for i in blocks:
+            for k in ("a_q", "a_v"):
+                tr["lora"][i][k] = leaf(tr["lora"][i][k], f"lora_A/{i}/{k}")
+        for i in blocks:
+            for k in ("b_q", "b_v"):
+                tr["lora"][i][k] = leaf(tr["lora"][i][k], f"lora_B/{i}/{k}")
+        self.refine = {"weight": leaf(refine["weight"], "refine_conv/weight"), "bias": leaf(refine["bias"], "refine_conv/bias")}
+        # engine order: depth_diff_head.parameters() = depth_attention (unused, 4 tensors) then fusion_layer
+        for j, q in enumerate(eng.depth_diff_head.depth_attention.parameters()):
+            leaf(q.detach().cpu(), f"depth_attention_unused/{j}")
+        self.head = {k: leaf(head[k], f"depth_head/{k}") for k in ("w1", "b1", "ln_w", "ln_b", "w2", "b2")}
+        for i in blocks:
+            for k in ("down", "up"):
+                tr["adapter"][i][k] = leaf(tr["adapter"][i][k], f"adapter_{k}/{i}")
+        self.tr = tr
+        self.weights = {"ap": eng.ap_loss_weight, "depth": eng.depth_loss_weight, "intra": eng.intra_depth_loss_weight,
+                        "kl": eng.kl_loss_weight}
+        self.state = [(torch.zeros_like(t.detach()), torch.zeros_like(t.detach())) for t in self.leaves]
+        self.nstep = 0
+
+    def step(self, batch, P):
+        dt, cfg = self.dtype, self.cfg
+        for t in self.leaves:
+            t.grad = None
+        terms_all, total = [], 0
+        cb = {k: v.detach().cpu() for k, v in batch.items()}
+        for q in range(P):
+            n = int(cb["counts"][q]) if "counts" in cb else cb["kp_1"].shape[1]
+            h, w = cb["rgb_1"].shape[-2:]
+            tp = cfg["teacher_patch"]
+            hw = (h // tp) * (w // tp)
+            one = {"rgb_1": cb["rgb_1"][q:q + 1].to(dt), "rgb_2": cb["rgb_2"][q:q + 1].to(dt),
+                   "kp_1": cb["kp_1"][q:q + 1, :n], "kp_2": cb["kp_2"][q:q + 1, :n],
+                   "depth_1": cb["depth_1"][q].to(dt), "depth_2": cb["depth_2"][q].to(dt),
+                   "cost_1": cb["cost_1"][q:q + 1, :, :hw].to(dt), "cost_2": cb["cost_2"][q:q + 1, :, :hw].to(dt),
+                   "pts3d_1": cb["pts3d_1"][q:q + 1, :n].to(dt), "pts3d_2": cb["pts3d_2"][q:q + 1, :n].to(dt),
+                   "mask_patch_1": F.interpolate(cb["mask_1"][q][None, None].float(), size=(h // tp, w // tp), mode="nearest").bool().view(-1),
+                   "mask_patch_2": F.interpolate(cb["mask_2"][q][None, None].float(), size=(h // tp, w // tp), mode="nearest").bool().view(-1)}
+            terms = O.pair_losses(one, self.p, cfg, self.tr, self.refine, self.head)
+            terms_all.append({k: v.item() for k, v in terms.items()})
+            total = total + O.total_loss(terms, self.weights) / P
+        total.backward()
+        grads = [t.grad.clone() if t.grad is not None else torch.zeros_like(t) for t in self.leaves]
+        params = [t.detach().clone() for t in self.leaves]
+        self.nstep += 1
+        norm = O.clip_and_adamw(params, [g.clone() for g in grads], self.state, self.nstep)
+        with torch.no_grad():
+            for t, q in zip(self.leaves, params):
+                t.copy_(q)
+        return total.item(), terms_all, grads, params, norm
+
+
 def _oracle_step(eng, batch, P):
     """fp64 oracle: per-pair losses, mean, grads of every trainable tensor, one clip+AdamW step."""
-    p, tr, refine, head, cfg = oracle_params(eng)
-    p = {k: v.double() for k, v in p.items()}
-    leaves = []
-
-    def leaf(t):
-        t = t.double().requires_grad_(True)
-        leaves.append(t)
-        return t
-    blocks = sorted(tr["lora"])
-    for i in blocks:
-        for k in ("a_q", "a_v"):
-            tr["lora"][i][k] = leaf(tr["lora"][i][k])
-    for i in blocks:
-        for k in ("b_q", "b_v"):
-            tr["lora"][i][k] = leaf(tr["lora"][i][k])
-    refine = {"weight": leaf(refine["weight"]), "bias": leaf(refine["bias"])}
-    # engine order: depth_diff_head.parameters() = depth_attention (unused, 4 tensors) then fusion_layer
-    da = [leaf(q.detach().cpu()) for q in eng.depth_diff_head.depth_attention.parameters()]
-    head = {k: leaf(head[k]) for k in ("w1", "b1", "ln_w", "ln_b", "w2", "b2")}
-    for i in blocks:
-        for k in ("down", "up"):
-            tr["adapter"][i][k] = leaf(tr["adapter"][i][k])
-    weights = {"ap": eng.ap_loss_weight, "depth": eng.depth_loss_weight, "intra": eng.intra_depth_loss_weight,
-               "kl": eng.kl_loss_weight}
-    terms_all, total = [], 0
-    cb = {k: v.detach().cpu() for k, v in batch.items()}
-    for q in range(P):
-        n = int(cb["counts"][q]) if "counts" in cb else cb["kp_1"].shape[1]
-        h, w = cb["rgb_1"].shape[-2:]
-        tp = cfg["teacher_patch"]
-        one = {"rgb_1": cb["rgb_1"][q:q + 1].double(), "rgb_2": cb["rgb_2"][q:q + 1].double(),
-               "kp_1": cb["kp_1"][q:q + 1, :n], "kp_2": cb["kp_2"][q:q + 1, :n],
-               "depth_1": cb["depth_1"][q].double(), "depth_2": cb["depth_2"][q].double(),
-               "cost_1": cb["cost_1"][q:q + 1].double(), "cost_2": cb["cost_2"][q:q + 1].double(),
-               "pts3d_1": cb["pts3d_1"][q:q + 1, :n].double(), "pts3d_2": cb["pts3d_2"][q:q + 1, :n].double(),
-               "mask_patch_1": F.interpolate(cb["mask_1"][q][None, None].float(), size=(h // tp, w // tp), mode="nearest").bool().view(-1),
-               "mask_patch_2": F.interpolate(cb["mask_2"][q][None, None].float(), size=(h // tp, w // tp), mode="nearest").bool().view(-1)}
-        terms = O.pair_losses(one, p, cfg, tr, refine, head)
-        terms_all.append({k: v.item() for k, v in terms.items()})
-        total = total + O.total_loss(terms, weights) / P
-    total.backward()
-    grads = [t.grad if t.grad is not None else torch.zeros_like(t) for t in leaves]
-    params = [t.detach().clone() for t in leaves]
-    state = [(torch.zeros_like(t), torch.zeros_like(t)) for t in params]
-    norm = O.clip_and_adamw(params, grads, state, 1)
-    return total.item(), terms_all, grads, params, norm
+    return OracleTrainer(eng).step(batch, P)
 
 
 @pytest.mark.parametrize("variant,geometry", [("vggt", "shared"), ("mast3r", "shared"), ("vggt", "reference")])
