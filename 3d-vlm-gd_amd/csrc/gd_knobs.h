@@ -10,6 +10,7 @@ struct GdKnobs {
     int gemm_f32_big;      // GD_GEMM_F32_BIG      1: 256x256 tiles for f32 operands
     int gemm_cstore;       // GD_GEMM_CSTORE       C store policy of the staged kernels (0 LDS-staged, 1 direct)
     int gemm_krot;         // GD_GEMM_KROT         per-tile K-step rotation of the persistent kernel (0 off)
+    int gemm_anat;         // GD_GEMM_ANAT         anatomy instantiations of the persistent main loop (0 = the product kernel)
     int tn_blocks;         // GD_TN_BLOCKS         target block count of the tile TN GEMM (0 auto)
     int attn_dma;          // GD_ATTN_DMA          1: LDS-DMA attention forward; 0: register-staged
     int attn_rot;          // GD_ATTN_ROT          1: forward x-block xb starts at key tile 2 xb

@@ -761,7 +761,15 @@ extern "C" int gd_gemm_nt(const void* A, const void* W, void* C, int M, int N, i
         const bool cb = c_dtype == GD_BF16;
         if (!dact_src && !residual) {
             if (act == 0 && !preact) pk = cb ? gemm_nt_persist_kernel<bf16, 0, 0, 0, false> : gemm_nt_persist_kernel<bf16, 0, 0, 0, true>;
-            else if ((act == 1 || act == 3) && !preact && cb) pk = gemm_nt_persist_kernel<bf16, 0, 1, 0, false>;
+#ifdef GD_GEMM_ANATOMY
+            if (act == 0 && !preact && cb && gd_knobs().gemm_anat) {     // anatomy builds of the main loop (gemm_persist.h, ANAT)
+                const int v = gd_knobs().gemm_anat;
+                pk = v == 1 ? gemm_nt_persist_kernel<bf16, 0, 0, 0, false, 1> : v == 2 ? gemm_nt_persist_kernel<bf16, 0, 0, 0, false, 2>
+                     : v == 3 ? gemm_nt_persist_kernel<bf16, 0, 0, 0, false, 3> : gemm_nt_persist_kernel<bf16, 0, 0, 0, false, 4>;
+            }
+            else
+#endif
+            if ((act == 1 || act == 3) && !preact && cb) pk = gemm_nt_persist_kernel<bf16, 0, 1, 0, false>;
             else if (act == 1 && preact && cb) pk = gemm_nt_persist_kernel<bf16, 0, 1, 1, false>;
             else if (act == 3 && preact && cb) pk = gemm_nt_persist_kernel<bf16, 0, 1, 2, false>;
         } else if (dact_src && dact == 1 && act == 0 && !preact && cb) pk = gemm_nt_persist_kernel<bf16, 1, 0, 0, false>;

@@ -68,6 +68,13 @@ __device__ __forceinline__ void chunk_rows05(FragHead& h, FragTail& t, unsigned 
     mma_row<T>(acc[5], a5, h.b0, h.b1, h.b2, h.b3);
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t.a6), "+v"(t.a7));
 }
+// anatomy: the chunk's LDS reads without its MFMAs
+__device__ __forceinline__ void chunk_reads_only(FragHead& h, FragTail& t, unsigned aaddr) {
+    f32x4 a1, a2, a3, a4, a5;
+    GD_DSR128(a1, aaddr, 2048); GD_DSR128(a2, aaddr, 4096); GD_DSR128(a3, aaddr, 6144); GD_DSR128(a4, aaddr, 8192);
+    GD_DSR128(a5, aaddr, 10240); GD_DSR128(t.a6, aaddr, 12288); GD_DSR128(t.a7, aaddr, 14336);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h.b0), "+v"(h.b1), "+v"(h.b2), "+v"(h.b3), "+v"(h.a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(t.a6), "+v"(t.a7));
+}
 template <typename T>
 __device__ __forceinline__ void chunk_rows67(const FragHead& h, const FragTail& t, f32x4 (&acc)[8][4]) {
     mma_row<T>(acc[6], t.a6, h.b0, h.b1, h.b2, h.b3);
@@ -122,7 +129,15 @@ __device__ __forceinline__ void bst4_aux(__amdgpu_buffer_rsrc_t rs, int off, int
 // the fc1 backward GEMM); CF32 C / preact are f32 (else bf16).
 // (With these as run-time flags the 16-item unrolled epilogue was ~160 scalar branches per tile: 4 k cycles of a
 // 45 k-cycle tile with nothing to do.)  Other combinations stay on gemm_nt_kernel.
-template <typename T, int SIDE, int ACT, int PREACT, bool CF32>
+// Two main-loop schedule experiments of round 3, measured against this kernel in one process (tools/bench_kernels.py gemm_ab,
+// profiles/r03_gemm_variants.txt) and removed: (1) the eight DMA pieces of stage kt+2 issued one by one between the eight MFMAs
+// that follow the stage barrier: -1 % on every shape; (2) waves 4-7 issuing their pieces half a chunk into K step kt+1 (so that the
+// two waves of a SIMD alternate between vector-memory issue and MFMA work): -4...-12 %.  Both move DMA issue LATER: the loop is bound
+// by the landing latency of the one stage in flight (64 KB / ~1.5 us = the 43 GB/s per CU it sustains), not by an issue bubble.
+// ANAT (anatomy builds, tools/bench_kernels.py gemm_anat; never the product path): 1 = no operand DMA in the main loop (the LDS-read +
+// MFMA + barrier loop alone), 2 = no MFMAs (DMA + LDS reads + barriers), 3 = neither LDS reads nor MFMAs (the DMA ring alone), 4 = no C stores (everything else of the epilogue stays).
+// Instantiated only in -DGD_GEMM_ANATOMY builds (gemm.hip); round-3 results: profiles/r03_gemm_anatomy.txt.
+template <typename T, int SIDE, int ACT, int PREACT, bool CF32, int ANAT = 0>
 __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
     constexpr int NWN = 4, WMT = 8, NW = 8, BM = 256, BN = 256;
     constexpr int ABYTES = BM * 128, STAGE = (BM + BN) * 128, APW = BM / 8 / NW, BPW = BN / 8 / NW;
@@ -173,6 +188,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
         }
     };
     auto issue = [&](int kt0, int buf) {
+        if (ANAT == 1) return;
         const int kt = kt0 + krot >= nk ? kt0 + krot - nk : kt0 + krot;
         char* sA = smem + buf * STAGE;
         char* sB = sA + ABYTES;
@@ -274,13 +290,14 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
         const int co0 = ((g ^ sa) * 16), co1 = (((4 + g) ^ sa) * 16);
         FragHead P, Q;
         FragTail tl;
-        frag_head_issue(P, lds0 + abase + co0, lds0 + bbase + co0);
+        constexpr bool AN_MM = ANAT == 0 || ANAT == 1 || ANAT == 4, AN_RD = AN_MM || ANAT == 2;
+        if (AN_RD) frag_head_issue(P, lds0 + abase + co0, lds0 + bbase + co0);
         for (int kt = 0; kt < nk; ++kt) {
             const unsigned sbo = lds0 + (kt & 1) * STAGE, nsbo = lds0 + ((kt + 1) & 1) * STAGE;
-            chunk_rows05<T>(P, tl, sbo + abase + co0, acc);
-            frag_head_issue(Q, sbo + abase + co1, sbo + bbase + co1);
-            chunk_rows67<T>(P, tl, acc);
-            chunk_rows05<T>(Q, tl, sbo + abase + co1, acc);
+            if (AN_MM) chunk_rows05<T>(P, tl, sbo + abase + co0, acc); else if (ANAT == 2) chunk_reads_only(P, tl, sbo + abase + co0);
+            if (AN_RD) frag_head_issue(Q, sbo + abase + co1, sbo + bbase + co1);
+            if (AN_MM) chunk_rows67<T>(P, tl, acc);
+            if (AN_MM) chunk_rows05<T>(Q, tl, sbo + abase + co1, acc); else if (ANAT == 2) chunk_reads_only(Q, tl, sbo + abase + co1);
             // every LDS read of stage kt is done: stage barrier (stage kt+1 landed, slot kt&1 free), then refill the slot
             GD_PROBE_DECL(unsigned long long pb0 = 0;) GD_PROBE(pb0 = __builtin_amdgcn_s_memtime();)
             if (kt == 0) wait_vm_le(after);   // stage 1 is older than the previous epilogue's stores: those may still drain
@@ -292,8 +309,8 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
             // 0.40 of the main loop on every shape (87 680 x 3072 x 768: 14.0 k of 35.5 k cycles per tile; 4096^3: 76.7 k of 191.6 k)
             GD_PROBE(pb += __builtin_amdgcn_s_memtime() - pb0;)
             if (kt + 2 < nk) issue(kt + 2, kt & 1);
-            if (kt + 1 < nk) frag_head_issue(P, nsbo + abase + co0, nsbo + bbase + co0);
-            chunk_rows67<T>(Q, tl, acc);
+            if (kt + 1 < nk && AN_RD) frag_head_issue(P, nsbo + abase + co0, nsbo + bbase + co0);
+            if (AN_MM) chunk_rows67<T>(Q, tl, acc);
         }
         const int ctm = tm, ctn = tn, cslot = slot;
         GD_PROBE({ const unsigned long long c = __builtin_amdgcn_s_memtime(); pm += c - pc0; pc0 = c; })
@@ -392,7 +409,8 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] *= (float)x[j];
             }
-            bst4_aux<GD_PERSIST_STORE_AUX>(crs, coff, cdt, v);
+            if (ANAT != 4) bst4_aux<GD_PERSIST_STORE_AUX>(crs, coff, cdt, v);
+            else asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
             if (pre && idx + SDEP < NITEM) side_load(idx + SDEP);
         }
         GD_PROBE({ const unsigned long long c = __builtin_amdgcn_s_memtime(); pe += c - pc0; pn += 1; })

@@ -288,11 +288,11 @@ class _TapFn(torch.autograd.Function):
     pass-through gradients into the LayerNorm backward kernel as residuals (one pass)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, eps):
+    def forward(ctx, x, w, b, eps, out_dtype=None):
         shp = x.shape
         x2 = x.reshape(-1, shp[-1]).contiguous()
         wf, bf = w.detach().float().contiguous(), b.detach().float().contiguous()
-        y, mean, rstd = ops.layernorm_fwd(x2, wf, bf, eps, save_stats=x.requires_grad)
+        y, mean, rstd = ops.layernorm_fwd(x2, wf, bf, eps, save_stats=x.requires_grad, out_dtype=out_dtype)
         if x.requires_grad:
             ctx.save_for_backward(x2, wf, mean, rstd)
             ctx.shp = shp
@@ -310,7 +310,7 @@ class _TapFn(torch.autograd.Function):
                 dy = dy.float()
             dx = ops.layernorm_bwd(dy, x2, wf, mean, rstd, dres=res[0] if res else None,
                                    dres2=res[1] if len(res) > 1 else None)
-        return (dx.view(ctx.shp) if dx is not None else None), None, None, None
+        return (dx.view(ctx.shp) if dx is not None else None), None, None, None, None
 
 
 class GDLayerNorm(nn.LayerNorm):
@@ -356,6 +356,10 @@ class GDViT(nn.Module):
         self.dtype = _dt(dtype)
         self._pos_cache = {}
         self._pe_plan = None
+        # dtype of the final-normed tap grids that feed the keypoint features (None = the engine dtype).  torch.float32 keeps
+        # LN(tap) unrounded: with near-identical tokens (deep random-init backbones) the depth-ranking gradient is a sum of
+        # feature DIFFERENCES, and a bf16 rounding of the normed values is amplified by |feature| / |difference|
+        self.tap_norm_dtype = None
         self.init_weights()
         # the per-dtype plans cache cast / folded / transposed copies of the frozen weights: drop them whenever the weights
         # can have changed under them (load_state_dict; .to() / .float() / .cuda() go through _apply below)
@@ -568,7 +572,7 @@ class GDViT(nn.Module):
             x = run_block(blk, x)      # not blk(x): a foreign wrapper class (utils/model.py's own) is fused by shape, never called
             if i in taps:
                 if norm_taps and i + 1 < len(self.blocks):
-                    x, outs[i], normed[i] = _TapFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps)
+                    x, outs[i], normed[i] = _TapFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps, self.tap_norm_dtype)
                 else:
                     outs[i] = x
                     if norm_taps:

@@ -164,9 +164,15 @@ def gemm_roofline(prof, dtype, dt, steps):
            "frac": round(ach / PEAK_TFLOPS[dtype], 4), "traffic": None, "launches": n,
            "avg_launch_us": round(ms / max(n, 1) * 1e3, 2), "share_of_step": round(ms / (dt * 1e3), 3)}
     if dtype == "bf16":
-        # context, not the yardstick: what back-to-back 16x16x32 bf16 MFMAs (two waves per SIMD, operands in registers, no memory
-        # traffic) sustain on this part under its power limit — tools/micro/mfma_gap.hip, profiles/r02_micro_mfma_gap.txt
-        out["measured_mfma_only_ceiling"] = {"tflops": 2327.6, "frac_of_it": round(ach / 2327.6, 4), "source": "profiles/r02_micro_mfma_gap.txt (NOT measured in this run)"}
+        # context, not the yardstick (NOT measured in this run; profiles/r03_gemm_anatomy.txt, profiles/r02_micro_mfma_gap.txt):
+        #  * back-to-back 16x16x32 bf16 MFMAs from registers, no memory traffic: 2328 TFLOP/s — the part's power-limited MFMA clock;
+        #  * this kernel's own LDS-read + MFMA + barrier loop with the operand DMA switched off: 1668 TFLOP/s-equivalent at 4096^3
+        #    (1219-1350 on the step's K = 768 shapes, where a tile is 12 K steps + its epilogue): what the chip sustains once
+        #    fragments come from LDS — the four-wave / 512-register form of the same loop reaches the same 1628;
+        #  * with the DMA back on, 1423 at 4096^3 (hipBLASLt's hand-written kernel: 1532), and the C stores cost another 13-17 % at K = 768.
+        out["context_ceilings_tflops"] = {"mfma_only_registers": 2327.6, "lds_fed_mfma_loop_4096": 1667.9, "lds_fed_mfma_loop_k768": 1265.3,
+                                          "frac_of_lds_fed_loop_k768": round(ach / 1265.3, 4),
+                                          "source": "profiles/r03_gemm_anatomy.txt, profiles/r02_micro_mfma_gap.txt (NOT measured in this run)"}
     return out
 
 

@@ -218,11 +218,14 @@ def pairwise_ranking_loss(hp, feats, depths, depth_threshold=0.05):
     return per[valid].mean()
 
 
-def depth_losses(hp, kp_feat_1, kp_feat_2, kp_depth_1, kp_depth_2, depth_threshold=0.05):
+def depth_losses(hp, kp_feat_1, kp_feat_2, kp_depth_1, kp_depth_2, depth_threshold=0.05, aux=None):
     """calculate_depth_loss tail (src/finetune_timm_vggt.py:472-485,
     src/finetune_timm_mast3r.py:487-501): L1(head(f1-f2), tanh(d1-d2)) and the mean of
-    the two intra-view ranking losses."""
+    the two intra-view ranking losses.  aux (dict, optional) receives the L1 residuals pred - target per keypoint: |.| has a kink
+    at zero, and a keypoint whose residual is smaller than an implementation's feature noise takes either sign there."""
     pred = depth_head(kp_feat_1 - kp_feat_2, hp)
+    if aux is not None:
+        aux["l1_residual"] = (pred - torch.tanh(kp_depth_1 - kp_depth_2)).detach().reshape(-1)
     l1 = (pred - torch.tanh(kp_depth_1 - kp_depth_2)).abs().mean()
     r = 0.5 * (pairwise_ranking_loss(hp, kp_feat_1, kp_depth_1, depth_threshold)
                + pairwise_ranking_loss(hp, kp_feat_2, kp_depth_2, depth_threshold))
@@ -443,14 +446,14 @@ def student_features(img, kp, p, cfg, trainable, refine):
     return kp_feat, desc, cost_feat
 
 
-def pair_losses(batch, p, cfg, trainable, refine, hp):
+def pair_losses(batch, p, cfg, trainable, refine, hp, aux=None):
     """Loss terms of one image pair = training_step body after the teacher
     (src/finetune_timm_vggt.py:599-616, src/finetune_timm_mast3r.py:635-653)."""
     f1 = student_features(batch["rgb_1"], batch["kp_1"], p, cfg, trainable, refine)
     f2 = student_features(batch["rgb_2"], batch["kp_2"], p, cfg, trainable, refine)
     d1 = extract_kp_depth(batch["depth_1"], batch["kp_1"])
     d2 = extract_kp_depth(batch["depth_2"], batch["kp_2"])
-    depth_l1, intra = depth_losses(hp, f1[0], f2[0], d1, d2)
+    depth_l1, intra = depth_losses(hp, f1[0], f2[0], d1, d2, aux=aux)
     h, w = batch["rgb_1"].shape[-2:]
     if cfg["variant"] == "vggt":
         m1, m2 = batch["mask_patch_1"], batch["mask_patch_2"]

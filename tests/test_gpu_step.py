@@ -109,6 +109,7 @@ class OracleTrainer:
         for t in self.leaves:
             t.grad = None
         terms_all, total = [], 0
+        self.l1_residuals = []          # per pair: pred - target of the depth-L1 term at every keypoint (the |.| kink, see depth_losses)
         cb = {k: v.detach().cpu() for k, v in batch.items()}
         for q in range(P):
             n = int(cb["counts"][q]) if "counts" in cb else cb["kp_1"].shape[1]
@@ -122,7 +123,9 @@ class OracleTrainer:
                    "pts3d_1": cb["pts3d_1"][q:q + 1, :n].to(dt), "pts3d_2": cb["pts3d_2"][q:q + 1, :n].to(dt),
                    "mask_patch_1": F.interpolate(cb["mask_1"][q][None, None].float(), size=(h // tp, w // tp), mode="nearest").bool().view(-1),
                    "mask_patch_2": F.interpolate(cb["mask_2"][q][None, None].float(), size=(h // tp, w // tp), mode="nearest").bool().view(-1)}
-            terms = O.pair_losses(one, self.p, cfg, self.tr, self.refine, self.head)
+            aux = {}
+            terms = O.pair_losses(one, self.p, cfg, self.tr, self.refine, self.head, aux=aux)
+            self.l1_residuals.append(aux.get("l1_residual"))
             terms_all.append({k: v.item() for k, v in terms.items()})
             total = total + O.total_loss(terms, self.weights) / P
         total.backward()

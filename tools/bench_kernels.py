@@ -36,6 +36,24 @@ def bench_gemm():
             print(f"gemm_nt {str(dt)[6:]:9s} {M}x{N}x{K}: {t*1e3:8.3f} ms  {2*M*N*K/t/1e12:7.1f} TF/s   (torch/hipblaslt {2*M*N*K/t2/1e12:7.1f} TF/s)")
 
 
+def bench_gemm_anat(rounds=3):
+    """Anatomy of the persistent kernel's main loop (gd_debug_set("gemm_anat", v)): 0 everything, 1 no operand DMA, 2 no MFMAs,
+    3 the DMA ring alone (no LDS reads, no MFMAs), 4 no C stores.  Needs a library built with `make FLAGS+=-DGD_GEMM_ANATOMY`.  Interleaved rounds in one process; reported as time and as the TFLOP/s the
+    full FLOP count would be at that time."""
+    L = gd_amd._lib.lib()
+    for (M, N, K) in [(87680, 2304, 768), (87680, 768, 768), (87680, 3072, 768), (87680, 768, 3072), (4096, 4096, 4096), (8192, 8192, 8192)]:
+        a = torch.randn(M, K, device="cuda").bfloat16()
+        w = torch.randn(N, K, device="cuda").bfloat16()
+        out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        res = {v: [] for v in (0, 1, 2, 3, 4)}
+        for r in range(rounds):
+            for v in res:
+                L.gd_debug_set(b"gemm_anat", v)
+                res[v].append(timeit(lambda: ops.gemm_nt(a, w, out=out), warm=2, it=8))
+        L.gd_debug_set(b"gemm_anat", 0)
+        print(f"gemm_anat {M}x{N}x{K}: " + " | ".join(f"v{v} {min(x) * 1e6:8.1f} us ({2 * M * N * K / min(x) / 1e12:7.1f} TF/s-equiv)" for v, x in res.items()), flush=True)
+
+
 def bench_gelu():
     M, N, K = 87680, 3072, 768
     a = torch.randn(M, K, device="cuda").bfloat16()
@@ -309,6 +327,8 @@ if __name__ == "__main__":
         pmc_adapter()
     if "gemm" in which:
         bench_gemm()
+    if "gemm_anat" in which:
+        bench_gemm_anat()
     if "cv" in which:
         bench_cv()
     if "gelu" in which:
