@@ -58,6 +58,8 @@ SIGNATURES = {
     "gd_unpitch_tokens": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "gd_tap_mean_fwd": (c_int, [ctypes.POINTER(c_void_p), c_int, c_long, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                 c_void_p]),
+    "gd_tap_mean_norm_fwd": (c_int, [ctypes.POINTER(c_void_p), c_int, c_long, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                     c_void_p]),
     "gd_tap_mean_bwd": (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_int,
                                 c_void_p]),
     "gd_kp_depth": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
@@ -113,6 +115,8 @@ SIGNATURES = {
     "gd_cost_volume_teacher_stats": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "gd_cost_volume_kl_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                       c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gd_cost_volume_kl_fwd_prenorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                              c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gd_cost_volume_kl_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
                                       c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gd_pil_resample_ksize": (c_int, [c_int, c_int]),

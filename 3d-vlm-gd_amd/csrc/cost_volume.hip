@@ -109,6 +109,18 @@ __global__ __launch_bounds__(256) void cv_norm_kernel(const void* f1, const void
     }
 }
 
+// the same stats rows when the caller already holds the inverse row norms (gd_tap_mean_norm_fwd took them while it wrote the
+// features): 2 P hw threads instead of a pass over the features
+__global__ __launch_bounds__(256) void cv_stats_init_kernel(const float* inv1, const float* inv2, const float* tstats, float* stats, int hw,
+                                                            long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;      // (p, which, row)
+    if (i >= n) return;
+    const long p = i / (2L * hw), rem = i - p * 2L * hw;
+    const int which = (int)(rem / hw), row = (int)(rem - (long)which * hw);
+    stats[i * 4] = (which ? inv2 : inv1)[p * hw + row];
+    stats[i * 4 + 1] = tstats[i * 4];
+}
+
 struct CvTileParams {
     const void* f1; const void* f2; const float* t1; const float* t2;
     float* stats; float* part1; float* part2;
@@ -331,6 +343,11 @@ __device__ __forceinline__ float cvp_lds_f32(unsigned addr) {
     return v;
 }
 
+// LDS row (64 w + 16 jb + c) of the view-2 (column) operand holds tile column 64 w + 4 c + jb: after the MFMAs a lane's four n-tiles
+// are FOUR CONSECUTIVE columns, so a teacher row segment of direction 1 is one aligned 16-byte load per (row, lane) — 16 lanes cover
+// 256 contiguous bytes of the teacher row — instead of four dword loads from four 64-byte segments (the same permutation the
+// persistent GEMM uses for its stores, gemm_persist.h nperm64).
+__device__ __forceinline__ int cv_nperm64(int rho) { return (rho & ~63) | ((rho & 15) << 2) | ((rho >> 4) & 3); }
 struct CvpTile { int p, tm, tn; };
 __device__ __forceinline__ CvpTile cvp_tile(int l, int tiles) {
     const int t2 = tiles * tiles;
@@ -379,7 +396,7 @@ __global__ __launch_bounds__(768) void cv_fwd_persist_kernel(CvTileParams q) {
                 for (int i = 0; i < 4; ++i) {
                     const int row = (lw * 4 + i) * 8 + (lane >> 3);
                     asrc[i] = Ab + (long)min(t.tm * 128 + row, hw - 1) * rowb + (((lane & 7) ^ swz(row)) * 16);
-                    wsrc[i] = Wb + (long)min(t.tn * 128 + row, hw - 1) * rowb + (((lane & 7) ^ swz(row)) * 16);
+                    wsrc[i] = Wb + (long)min(t.tn * 128 + cv_nperm64(row), hw - 1) * rowb + (((lane & 7) ^ swz(row)) * 16);
                 }
                 const int e = lw * 64 + lane, which = e >> 7;
                 const int idx = min((which ? t.tn : t.tm) * 128 + (e & 127), hw - 1);
@@ -445,25 +462,15 @@ __global__ __launch_bounds__(768) void cv_fwd_persist_kernel(CvTileParams q) {
     typedef typename Mma<T>::Frag Frag;
     const int sa = swz(c);
     const int abase = (wm * 32 + c) * 128, bbase = 128 * 128 + (wn * 64 + c) * 128;
-    float t1v[2][4][4];      // direction 1: T1[row = tm*128 + wm*32 + ib*16 + 4g + r][col = tn*128 + wn*64 + jb*16 + c]
-    f32x4 t2v[2][4];         // direction 2: T2[row = tn*128 + wn*64 + jb*16 + c][col = tm*128 + wm*32 + ib*16 + 4g .. +3]
+    // this lane's columns of the tile: cl(jb) = wn*64 + 4c + jb (see cv_nperm64); its rows: wm*32 + ib*16 + 4g + r
+    f32x4 t1v[2][4];         // direction 1: T1[row = tm*128 + wm*32 + ib*16 + 4g + r][col = tn*128 + wn*64 + 4c .. +3]   ([ib][r], element jb)
+    f32x4 t2v[2][4];         // direction 2: T2[row = tn*128 + wn*64 + 4c + jb][col = tm*128 + wm*32 + ib*16 + 4g .. +3]   ([ib][jb], element r)
     // branch-free: every address is clamped into the pair's map (rows / columns past hw re-read valid entries; the
-    // epilogue multiplies them by a zeroed s), so the 40 loads of a tile go out back to back with no wait between them
+    // epilogue multiplies them by a zeroed s), so the 16 loads of a tile go out back to back with no wait between them
     auto prefetch = [&](int it) {
         const CvpTile t = cvp_tile(beg + kb + it * nbx, tiles);
         const float* T1 = q.t1 + (long)t.p * hw * ldt;
         const float* T2 = q.t2 + (long)t.p * hw * ldt;
-        if (DBG && (q.dbg & 8)) {      // experiment: the same bytes as row-contiguous 16-byte loads (4 rows x 256 B / 8 rows x 128 B per instruction)
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int r1 = min(t.tm * 128 + wm * 32 + k * 4 + g, hw - 1), c1 = min(t.tn * 128 + wn * 64 + 4 * c, ldt - 4);
-                const f32x4 v = *(const f32x4*)(T1 + (long)r1 * ldt + c1);
-                t1v[k >> 2][k & 3][0] = v[0]; t1v[k >> 2][k & 3][1] = v[1]; t1v[k >> 2][k & 3][2] = v[2]; t1v[k >> 2][k & 3][3] = v[3];
-                const int r2 = min(t.tn * 128 + wn * 64 + k * 8 + (lane >> 3), hw - 1), c2 = min(t.tm * 128 + wm * 32 + 4 * (lane & 7), ldt - 4);
-                t2v[k >> 2][k & 3] = *(const f32x4*)(T2 + (long)r2 * ldt + c2);
-            }
-            return;
-        }
         // Rows / columns that the loss masks out (utils/functions.py:402-422 zeroes them; cv_finalize replaces their term by a
         // constant) never need their teacher entries: their loads are pointed at the first line of the pair's map instead — still
         // branch-free and back to back, but an L2 hit instead of HBM traffic.  With the MASt3R trainer's keypoint-patch masks
@@ -477,7 +484,7 @@ __global__ __launch_bounds__(768) void cv_fwd_persist_kernel(CvTileParams q) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) rk[ib][r] = M1[min(t.tm * 128 + wm * 32 + ib * 16 + 4 * g + r, hw - 1)] != 0;
 #pragma unroll
-            for (int jb = 0; jb < 4; ++jb) ck[jb] = M2[min(t.tn * 128 + wn * 64 + jb * 16 + c, hw - 1)] != 0;
+            for (int jb = 0; jb < 4; ++jb) ck[jb] = M2[min(t.tn * 128 + wn * 64 + 4 * c + jb, hw - 1)] != 0;
         } else {
 #pragma unroll
             for (int ib = 0; ib < 2; ++ib)
@@ -486,33 +493,25 @@ __global__ __launch_bounds__(768) void cv_fwd_persist_kernel(CvTileParams q) {
 #pragma unroll
             for (int jb = 0; jb < 4; ++jb) ck[jb] = true;
         }
+        const int col0 = min(t.tn * 128 + wn * 64 + 4 * c, ldt - 4);          // ldt % 4 == 0: aligned, inside the row
 #pragma unroll
-        for (int ib = 0; ib < 2; ++ib)
+        for (int ib = 0; ib < 2; ++ib) {
+            const int row0 = t.tm * 128 + wm * 32 + ib * 16 + 4 * g;
 #pragma unroll
             for (int jb = 0; jb < 4; ++jb) {
-                const int col = min(t.tn * 128 + wn * 64 + jb * 16 + c, hw - 1);
-                const int row0 = t.tm * 128 + wm * 32 + ib * 16 + 4 * g;
-                if (DBG && (q.dbg & 16)) {
-                    t2v[ib][jb] = __builtin_nontemporal_load((const f32x4*)(T2 + (long)col * ldt + min(row0, ldt - 4)));
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) t1v[ib][jb][r] = __builtin_nontemporal_load(T1 + (long)min(row0 + r, hw - 1) * ldt + col);
-                    continue;
-                }
-                t2v[ib][jb] = *(const f32x4*)(T2 + (ck[jb] ? (long)col * ldt + min(row0, ldt - 4) : 0L));       // ldt % 4 == 0: aligned, inside the row
-#pragma unroll
-                for (int r = 0; r < 4; ++r) t1v[ib][jb][r] = T1[rk[ib][r] ? (long)min(row0 + r, hw - 1) * ldt + col : 0L];
+                const int col = min(t.tn * 128 + wn * 64 + 4 * c + jb, hw - 1);
+                t2v[ib][jb] = *(const f32x4*)(T2 + (ck[jb] ? (long)col * ldt + min(row0, ldt - 4) : 0L));
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t1v[ib][r] = *(const f32x4*)(T1 + (rk[ib][r] ? (long)min(row0 + r, hw - 1) * ldt + col0 : 0L));
+        }
     };
     const int dbg = DBG ? q.dbg : 0;     // diagnostics (GD_CV_DBG): 1 = no teacher loads, 2 = no epilogue math, 4 = no MFMAs
     if (dbg & 1) {
 #pragma unroll
         for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
-            for (int jb = 0; jb < 4; ++jb) {
-                t2v[ib][jb] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) t1v[ib][jb][r] = 0.f;
-            }
+            for (int jb = 0; jb < 4; ++jb) t2v[ib][jb] = t1v[ib][jb] = f32x4{0.f, 0.f, 0.f, 0.f};
     } else prefetch(0);
     int n = 0;
     for (int it = 0; it < n_tiles; ++it) {
@@ -553,7 +552,7 @@ __global__ __launch_bounds__(768) void cv_fwd_persist_kernel(CvTileParams q) {
         bool cok[4];
 #pragma unroll
         for (int jb = 0; jb < 4; ++jb) {
-            const int cl = wn * 64 + jb * 16 + c;
+            const int cl = wn * 64 + 4 * c + jb;
             const f32x4 v = sSt[128 + cl];
             inv2[jb] = v[0]; ir2[jb] = 1.0f / v[1];
             cok[jb] = t.tn * 128 + cl < hw;
@@ -575,7 +574,7 @@ __global__ __launch_bounds__(768) void cv_fwd_persist_kernel(CvTileParams q) {
                     const float e = ok ? __expf(sv) : 0.f;
                     const float sm = ok ? sv : 0.f;
                     zr += e; zc[jb] += e;
-                    b1 = fmaf(fmaxf(t1v[ib][jb][r] * ir1, CV_EPS), sm, b1);
+                    b1 = fmaf(fmaxf(t1v[ib][r][jb] * ir1, CV_EPS), sm, b1);
                     b2[jb] = fmaf(fmaxf(t2v[ib][jb][r] * ir2[jb], CV_EPS), sm, b2[jb]);
                 }
                 zr = row16_sum(zr);
@@ -588,7 +587,7 @@ __global__ __launch_bounds__(768) void cv_fwd_persist_kernel(CvTileParams q) {
             z += __shfl_xor(z, 16, 64); z += __shfl_xor(z, 32, 64);
             b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
             if (g == 0) {
-                const int cl = wn * 64 + jb * 16 + c;
+                const int cl = wn * 64 + 4 * c + jb;
                 sP[512 + wm * 128 + cl] = z; sP[1024 + wm * 128 + cl] = b;
             }
         }
@@ -792,10 +791,9 @@ extern "C" int gd_cost_volume_teacher_stats(const float* t1, const float* t2, in
     return 0;
 }
 
-extern "C" int gd_cost_volume_kl_fwd(const void* f1, const void* f2, const float* t1, const float* t2, int ldt,
-                                     const float* tstats, const unsigned char* m1, const unsigned char* m2, int P, int hw,
-                                     int C, int variant, int dtype, float* loss, float* stats, void* workspace,
-                                     void* stream) {
+static int cv_fwd_common(const void* f1, const void* f2, const float* inv1, const float* inv2, const float* t1, const float* t2, int ldt,
+                         const float* tstats, const unsigned char* m1, const unsigned char* m2, int P, int hw, int C, int variant,
+                         int dtype, float* loss, float* stats, void* workspace, void* stream) {
     GD_REQUIRE(P > 0 && hw > 0 && C > 0 && ldt >= hw, "gd_cost_volume_kl_fwd: bad shape P=%d hw=%d C=%d ldt=%d", P, hw, C, ldt);
     GD_REQUIRE(variant == 0 || variant == 1, "gd_cost_volume_kl_fwd: variant must be 0 (vggt) or 1 (mast3r)");
     GD_REQUIRE(dtype == GD_F32 || dtype == GD_BF16, "gd_cost_volume_kl_fwd: bad dtype %d", dtype);
@@ -814,7 +812,11 @@ extern "C" int gd_cost_volume_kl_fwd(const void* f1, const void* f2, const float
         hipLaunchKernelGGL(cv_tstats_kernel, dim3(gd_cdiv(hw, 4), 2, P), dim3(256), 0, s, t1, t2, ts_ws, hw, ldt);
         tstats = ts_ws;
     }
-    hipLaunchKernelGGL(cv_norm_kernel, dim3(gd_cdiv(hw, 4), 2, P), dim3(256), 0, s, f1, f2, tstats, stats, hw, C, dtype);
+    if (inv1) {
+        const long n = 2L * P * hw;
+        hipLaunchKernelGGL(cv_stats_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, inv1, inv2, tstats, stats, hw, n);
+    } else
+        hipLaunchKernelGGL(cv_norm_kernel, dim3(gd_cdiv(hw, 4), 2, P), dim3(256), 0, s, f1, f2, tstats, stats, hw, C, dtype);
     GD_LAUNCH_OK();
     CvTileParams q = {};
     q.f1 = f1; q.f2 = f2; q.t1 = t1; q.t2 = t2; q.stats = stats; q.part1 = part1; q.part2 = part2;
@@ -845,6 +847,20 @@ extern "C" int gd_cost_volume_kl_fwd(const void* f1, const void* f2, const float
     hipLaunchKernelGGL(cv_loss_kernel, dim3(gd_cdiv(P, 64)), dim3(64), 0, s, chunk_loss, loss, P, hw);
     GD_LAUNCH_OK();
     return 0;
+}
+
+extern "C" int gd_cost_volume_kl_fwd(const void* f1, const void* f2, const float* t1, const float* t2, int ldt, const float* tstats,
+                                     const unsigned char* m1, const unsigned char* m2, int P, int hw, int C, int variant, int dtype,
+                                     float* loss, float* stats, void* workspace, void* stream) {
+    return cv_fwd_common(f1, f2, nullptr, nullptr, t1, t2, ldt, tstats, m1, m2, P, hw, C, variant, dtype, loss, stats, workspace, stream);
+}
+
+extern "C" int gd_cost_volume_kl_fwd_prenorm(const void* f1, const void* f2, const float* inv_norm1, const float* inv_norm2, const float* t1,
+                                             const float* t2, int ldt, const float* tstats, const unsigned char* m1,
+                                             const unsigned char* m2, int P, int hw, int C, int variant, int dtype, float* loss,
+                                             float* stats, void* workspace, void* stream) {
+    GD_REQUIRE(inv_norm1 != nullptr && inv_norm2 != nullptr, "gd_cost_volume_kl_fwd_prenorm: inverse row norms missing");
+    return cv_fwd_common(f1, f2, inv_norm1, inv_norm2, t1, t2, ldt, tstats, m1, m2, P, hw, C, variant, dtype, loss, stats, workspace, stream);
 }
 
 extern "C" int gd_cost_volume_kl_bwd(const void* f1, const void* f2, const float* t1, const float* t2, int ldt,

@@ -923,6 +923,56 @@ extern "C" int gd_cast(const void* in, void* out, long n, float scale, int in_dt
     return 0;
 }
 
+// The same mean, one WAVE per output row, which also hands out 1 / max(||row||, 1e-12) of the row AS STORED (rounded to T): the
+// cost-volume loss normalises exactly these rows (F.normalize, src/finetune_timm_vggt.py:514-515), and taking the norm here saves
+// its own pass over the features there (gd_cost_volume_kl_fwd_prenorm).  Fixed summation order: bit-reproducible.
+template <typename T>
+__global__ __launch_bounds__(256) void tap_mean_norm_fwd_kernel(TapMeanParams p, T* out, float* inv_norm, int B, int hw, int D) {
+    constexpr int V = 16 / sizeof(T);
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (long)B * hw) return;
+    const long b = row / hw, r = row - b * hw;
+    const long src = b * p.bstride + ((long)p.prefix + r) * D;
+    const float inv = 1.0f / (float)p.ngrid;
+    float ss = 0.f;
+    for (int v = lane; v < D / V; v += 64) {
+        float acc[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc[k] = 0.f;
+        for (int t = 0; t < p.ngrid; ++t) {
+            const uint4 raw = *(const uint4*)((const T*)p.grid[t] + src + (long)v * V);
+            const T* e = (const T*)&raw;
+#pragma unroll
+            for (int k = 0; k < V; ++k) acc[k] += to_f32<T>(e[k]);
+        }
+        uint4 o;
+        T* oe = (T*)&o;
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            oe[k] = from_f32<T>(acc[k] * inv);
+            const float x = to_f32<T>(oe[k]);
+            ss += x * x;
+        }
+        *(uint4*)(out + row * D + (long)v * V) = o;
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) inv_norm[row] = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+}
+
+extern "C" int gd_tap_mean_norm_fwd(const void* const* grids, int ngrid, long bstride, int prefix, void* out, float* inv_norm, int B,
+                                    int hw, int D, int dtype, void* stream) {
+    GD_REQUIRE(ngrid >= 1 && ngrid <= 4 && B > 0 && hw > 0 && D > 0 && D % 8 == 0 && inv_norm != nullptr, "gd_tap_mean_norm_fwd: bad arguments");
+    TapMeanParams p = {};
+    for (int t = 0; t < ngrid; ++t) p.grid[t] = grids[t];
+    p.ngrid = ngrid; p.bstride = bstride; p.prefix = prefix;
+    const unsigned blocks = (unsigned)(((long)B * hw + 3) / 4);
+    if (dtype == GD_BF16) hipLaunchKernelGGL(tap_mean_norm_fwd_kernel<bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, (bf16*)out, inv_norm, B, hw, D);
+    else hipLaunchKernelGGL(tap_mean_norm_fwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, (float*)out, inv_norm, B, hw, D);
+    GD_LAUNCH_OK();
+    return 0;
+}
+
 extern "C" int gd_tap_mean_fwd(const void* const* grids, int ngrid, long bstride, int prefix, void* out, int B, int hw,
                                int D, int dtype, void* stream) {
     GD_REQUIRE(ngrid >= 1 && ngrid <= 4 && B > 0 && hw > 0 && D > 0, "gd_tap_mean_fwd: bad arguments");

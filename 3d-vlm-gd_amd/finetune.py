@@ -342,14 +342,15 @@ class FinetuneGD(nn.Module):
             feat = kp_gather([fmap], pts, gh, gw, (gw * P) / w, (gh * P) / h, gh * Pi, gw * Pi, Pi, pitch=pitch)
         return ops.l2_normalize(feat) if normalize else feat
 
-    def get_feature_cost(self, rgbs):
+    def get_feature_cost(self, rgbs, with_norm=False):
         """src/finetune_timm_vggt.py:335-355 (tap 7) / src/finetune_timm_mast3r.py:321-342 (mean of taps 4-7), no
-        norm, prefix dropped -> [B, hw, D] in the engine dtype."""
+        norm, prefix dropped -> [B, hw, D] in the engine dtype.  with_norm: -> (features, inverse row norms [B, hw]) — the cost
+        loss normalises these rows; their norms are taken while the rows are written."""
         h, w = rgbs.shape[-2:]
         ch, cw = h // self.resize_patch_size, w // self.resize_patch_size
         taps, _ = self._forward(rgbs, ch, cw)
         sel = [taps[3]] if self.variant == "vggt" else list(taps)
-        return ops.tap_mean(sel, prefix=self.model.num_prefix_tokens)
+        return ops.tap_mean(sel, prefix=self.model.num_prefix_tokens, with_norm=with_norm)
 
     # ------------------------------------------------------------------ losses (per-pair vectors [P])
     def calculate_depth_loss(self, depth_1, depth_2, rgbs, kp_1, kp_2, counts=None, indices=(4, 5, 6, 7)):
@@ -365,7 +366,7 @@ class FinetuneGD(nn.Module):
         padded to 16-byte rows with `cost_tstats` = the cached teacher-row statistics (teacher_cache.TeacherTargetCache)."""
         h, w = rgbs.shape[-2:]
         P = rgbs.shape[0] // 2
-        f = self.get_feature_cost(rgbs)
+        f, inv = self.get_feature_cost(rgbs, with_norm=True)
         ph, pw = h // self.resize_patch_size, w // self.resize_patch_size
         if self.variant == "mast3r" or mask_1 is None:
             m1 = ops.patch_mask(kp_1, h, w, self.patch_size)
@@ -374,7 +375,7 @@ class FinetuneGD(nn.Module):
             m1 = F.interpolate(mask_1[:, None].float(), size=(ph, pw), mode="nearest").reshape(P, -1) > 0
             m2 = F.interpolate(mask_2[:, None].float(), size=(ph, pw), mode="nearest").reshape(P, -1) > 0
         f1, f2 = ops.split_pairs(f, P)
-        return ops.cost_volume_kl(f1, f2, cost_1, cost_2, m1, m2, self.variant, tstats=cost_tstats)
+        return ops.cost_volume_kl(f1, f2, cost_1, cost_2, m1, m2, self.variant, tstats=cost_tstats, inv_norms=(inv[:P], inv[P:]))
 
     def calculate_matching_loss(self, rgbs, kp_1, kp_2, pts3d_1, pts3d_2, counts=None):
         """src/finetune_timm_vggt.py:536-574 / src/finetune_timm_mast3r.py:543-589.  pts3d_k [P,N,3] are the

@@ -131,12 +131,14 @@ VARIANTS = {"vggt": 0, "mast3r": 1}
 
 
 def pad_teacher_maps(t):
-    """[P, hw, hw] -> [P, hw, ldt] view-compatible copy with ldt = hw rounded up to 4 (16-byte aligned rows, zero pad): the
-    layout the fast cost-volume path reads.  Done ONCE per cached pair (TeacherTargetCache), never per step."""
+    """[P, hw, hw] -> [P, hw, ldt] view-compatible copy with ldt = hw rounded up to 32 floats (128-byte rows, zero pad): the
+    layout the fast cost-volume path reads (it needs 16-byte rows; whole-line rows keep a tile's 512-byte row segments from
+    straddling cache lines that a neighbouring tile — on another XCD — fetches again: PMC FETCH_SIZE 1.37x -> ~1.0x of the teacher
+    bytes, profiles/README.md round 3).  Done ONCE per cached pair (TeacherTargetCache), never per step."""
     P, hw, w = t.shape
-    ldt = (w + 3) // 4 * 4
-    if ldt == w:
-        return t.contiguous().float()
+    ldt = (w + 31) // 32 * 32
+    if ldt == w and t.dtype == torch.float32 and t.is_contiguous() and t.data_ptr() % 128 == 0:
+        return t
     out = torch.zeros(P, hw, ldt, dtype=torch.float32, device=t.device)
     out[:, :, :w] = t
     return out
@@ -154,7 +156,7 @@ def cost_volume_teacher_stats(t1, t2):
 
 class _CostVolumeKL(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, f1, f2, t1, t2, m1, m2, variant, tstats):
+    def forward(ctx, f1, f2, t1, t2, m1, m2, variant, tstats, inv1=None, inv2=None):
         P, hw, C = f1.shape
         f1, f2 = f1.contiguous(), f2.contiguous()
         t1, t2 = t1.contiguous().float(), t2.contiguous().float()
@@ -168,8 +170,14 @@ class _CostVolumeKL(torch.autograd.Function):
         ws = torch.empty(lib().gd_cost_volume_kl_workspace_bytes(P, hw, C, dt, 0), dtype=torch.uint8, device=f1.device)
         if tstats is not None:
             _req(tstats.shape == (P, 2, hw, 4) and tstats.dtype == torch.float32 and tstats.is_contiguous(), "cost_volume_kl: bad tstats")
-        rc = lib().gd_cost_volume_kl_fwd(ptr(f1), ptr(f2), ptr(t1), ptr(t2), ldt, ptr(tstats), ptr(m1), ptr(m2), P, hw, C,
-                                         VARIANTS[variant], dt, ptr(loss), ptr(stats), ptr(ws), stream())
+        if inv1 is not None:
+            _req(inv1.shape == (P, hw) and inv2.shape == (P, hw) and inv1.dtype == torch.float32 and inv2.dtype == torch.float32 and
+                 inv1.is_contiguous() and inv2.is_contiguous(), "cost_volume_kl: inv_norms must be two contiguous fp32 [P, hw] tensors")
+            rc = lib().gd_cost_volume_kl_fwd_prenorm(ptr(f1), ptr(f2), ptr(inv1), ptr(inv2), ptr(t1), ptr(t2), ldt, ptr(tstats), ptr(m1),
+                                                     ptr(m2), P, hw, C, VARIANTS[variant], dt, ptr(loss), ptr(stats), ptr(ws), stream())
+        else:
+            rc = lib().gd_cost_volume_kl_fwd(ptr(f1), ptr(f2), ptr(t1), ptr(t2), ldt, ptr(tstats), ptr(m1), ptr(m2), P, hw, C,
+                                             VARIANTS[variant], dt, ptr(loss), ptr(stats), ptr(ws), stream())
         check(rc, "gd_cost_volume_kl_fwd")
         ctx.save_for_backward(f1, f2, t1, t2, m1, m2, stats)
         return loss
@@ -187,14 +195,18 @@ class _CostVolumeKL(torch.autograd.Function):
         rc = lib().gd_cost_volume_kl_bwd(ptr(f1), ptr(f2), ptr(t1), ptr(t2), t1.shape[-1], ptr(m1), ptr(m2), P, hw, C, dt, ptr(g),
                                          ptr(stats), ptr(df1), ptr(df2), ptr(ws), stream())
         check(rc, "gd_cost_volume_kl_bwd")
-        return df1, df2, None, None, None, None, None, None
+        return df1, df2, None, None, None, None, None, None, None, None
 
 
-def cost_volume_kl(f1, f2, t1, t2, m1, m2, variant="vggt", tstats=None):
+def cost_volume_kl(f1, f2, t1, t2, m1, m2, variant="vggt", tstats=None, inv_norms=None):
     """Fused dense cost-volume KL for P pairs.  f1,f2 [P,hw,C] raw student features (f32|bf16); t1,t2 [P,hw,ldt] teacher
     maps (f32; ldt = hw, or hw padded to a multiple of 4 by `pad_teacher_maps`: the fast path); m1,m2 [P,hw] bool row
     masks; tstats: `cost_volume_teacher_stats(t1, t2)` computed once per cached pair (None: recomputed here, one more pass
-    over the maps) -> loss [P] (f32)."""
+    over the maps); inv_norms = (inv1, inv2), fp32 [P, hw] each: 1 / max(||row||, 1e-12) of the feature rows as stored, when their
+    producer already took them (`tap_mean(..., with_norm=True)`) — the op then skips its own pass over the features
+    -> loss [P] (f32)."""
+    if inv_norms is not None:
+        return _CostVolumeKL.apply(f1, f2, t1, t2, m1, m2, variant, tstats, inv_norms[0].detach(), inv_norms[1].detach())
     return _CostVolumeKL.apply(f1, f2, t1, t2, m1, m2, variant, tstats)
 
 
@@ -491,29 +503,36 @@ def unpitch_tokens(src, B, gh, gw, D, prefix):
 
 class _TapMean(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, prefix, *grids):
+    def forward(ctx, prefix, with_norm, *grids):
         B, Nt, D = grids[0].shape
         gs = [g.contiguous() for g in grids]
         out = torch.empty(B, Nt - prefix, D, dtype=gs[0].dtype, device=gs[0].device)
+        ctx.meta = (prefix, len(gs), B, Nt, D)
+        if with_norm:
+            inv = torch.empty(B, Nt - prefix, dtype=torch.float32, device=gs[0].device)
+            check(lib().gd_tap_mean_norm_fwd(_ptr_array(gs), len(gs), Nt * D, prefix, ptr(out), ptr(inv), B, Nt - prefix, D,
+                                             dtype_code(out), stream()), "gd_tap_mean_norm_fwd")
+            ctx.mark_non_differentiable(inv)
+            return out, inv
         check(lib().gd_tap_mean_fwd(_ptr_array(gs), len(gs), Nt * D, prefix, ptr(out), B, Nt - prefix, D,
                                     dtype_code(out), stream()), "gd_tap_mean_fwd")
-        ctx.meta = (prefix, len(gs), B, Nt, D)
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, *unused):
         prefix, ng, B, Nt, D = ctx.meta
         dout = dout.contiguous()
         # the ng gradients are identical (dout / ng): one buffer, handed to every grid
         dg = torch.empty(B, Nt, D, dtype=dout.dtype, device=dout.device)
         check(lib().gd_tap_mean_bwd(_ptr_array([dg]), 1, prefix, ptr(dout), B, Nt - prefix, D, 1.0 / ng, dtype_code(dout),
                                     stream()), "gd_tap_mean_bwd")
-        return (None,) + (dg,) * ng
+        return (None, None) + (dg,) * ng
 
 
-def tap_mean(grids, prefix=1):
-    """mean of 1..4 tap outputs [B, prefix+hw, D], prefix tokens dropped -> contiguous [B, hw, D]."""
-    return _TapMean.apply(prefix, *grids)
+def tap_mean(grids, prefix=1, with_norm=False):
+    """mean of 1..4 tap outputs [B, prefix+hw, D], prefix tokens dropped -> contiguous [B, hw, D]; with_norm: -> (mean, inv_norm
+    [B, hw] fp32 = 1 / max(||row||, 1e-12) of the rows as stored, not differentiable: an input of cost_volume_kl(inv_norms=...))."""
+    return _TapMean.apply(prefix, bool(with_norm), *grids)
 
 
 def kp_depth(depth, kp):

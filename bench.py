@@ -302,14 +302,19 @@ def cost_volume_roofline(job, args, dev, variant):
     fwd_bytes = feat_bytes + P * 2 * hw * hw * 4               # every teacher row
     bwd_bytes = fwd_bytes + P * 2 * hw * D * es
 
-    def timed(ma, mb, backward=False):
+    # as the step calls it: the inverse row norms come with the features from their producer (ops.tap_mean(with_norm=True))
+    inv = (1.0 / f1.detach().float().norm(dim=-1).clamp_min(1e-12), 1.0 / f2.detach().float().norm(dim=-1).clamp_min(1e-12))
+
+    def timed(ma, mb, backward=False, own_norm=False):
+        kw = dict(tstats=b["cost_tstats"]) if own_norm else dict(tstats=b["cost_tstats"], inv_norms=inv)
+
         def fwd():
             with torch.no_grad():
-                return ops.cost_volume_kl(f1, f2, b["cost_1"], b["cost_2"], ma, mb, variant, tstats=b["cost_tstats"])
+                return ops.cost_volume_kl(f1, f2, b["cost_1"], b["cost_2"], ma, mb, variant, **kw)
 
         def fb():
             f1.grad = f2.grad = None
-            ops.cost_volume_kl(f1, f2, b["cost_1"], b["cost_2"], ma, mb, variant, tstats=b["cost_tstats"]).sum().backward()
+            ops.cost_volume_kl(f1, f2, b["cost_1"], b["cost_2"], ma, mb, variant, **kw).sum().backward()
         return ops.time_on_stream(fb if backward else fwd, 2, 5)
 
     def replay(name):    # HBM traffic per launch: PMC counters cannot be read inside the run; committed passes of this configuration
@@ -333,7 +338,7 @@ def cost_volume_roofline(job, args, dev, variant):
     unmasked, tfu = leg(ones, ones, "r03_pmc_cost_volume_traffic_full.json")
     tfb = timed(m1, m2, backward=True)
     tfbu = timed(ones, ones, backward=True)
-    out = {"kernel": "cost_volume_kl fwd (fused feature norm + contraction + both softmax-KL directions; teacher-row statistics cached per pair)",
+    out = {"kernel": "cost_volume_kl fwd (contraction + both softmax-KL directions in one persistent kernel; feature row norms from the producer, teacher-row statistics cached per pair)",
            "bound": "hbm", "peak": PEAK_HBM_GBS, "unit": "GB/s",
            "masks": "keypoint-patch masks of the benched batch" if variant == "mast3r" else "co-view masks of the benched batch",
            "frac_definition": "bytes the launch must move (features + KEPT teacher rows + masks) / time / peak: skipped rows earn nothing"}
@@ -341,6 +346,8 @@ def cost_volume_roofline(job, args, dev, variant):
     out["unmasked"] = dict(unmasked, algorithmic_bytes_per_launch_survey_8d=fwd_bytes,
                            fwd_bwd_GBps=round((fwd_bytes + bwd_bytes) / tfbu / 1e9, 1), us_per_pair_fwd_bwd=round(tfbu / P * 1e6, 2))
     out["us_per_pair_fwd_bwd"] = round(tfb / P * 1e6, 2)
+    out["row_norms"] = ("from the feature producer (gd_tap_mean_norm_fwd -> gd_cost_volume_kl_fwd_prenorm), as in the step; with the op's own "
+                        f"norm pass over the features: {timed(ones, ones, own_norm=True) / P * 1e6:.2f} us/pair unmasked")
     return out
 
 

@@ -85,6 +85,13 @@ int gd_cost_volume_teacher_stats(const float* t1, const float* t2, int P, int hw
 int gd_cost_volume_kl_fwd(const void* f1, const void* f2, const float* t1, const float* t2, int ldt, const float* tstats,
                           const unsigned char* m1, const unsigned char* m2, int P, int hw, int C, int variant, int dtype,
                           float* loss, float* stats, void* workspace, void* stream);
+/* The same forward when the caller already holds the inverse L2 norms of the feature rows, inv_norm_k [P, hw] = 1 / max(||f_k row||, 1e-12)
+ * of the rows as stored (gd_tap_mean_norm_fwd hands them out while it writes the features): the kernel's own pass over the
+ * features (135 MB at the step's size) is replaced by a 2 P hw-thread copy. */
+int gd_cost_volume_kl_fwd_prenorm(const void* f1, const void* f2, const float* inv_norm1, const float* inv_norm2, const float* t1,
+                                  const float* t2, int ldt, const float* tstats, const unsigned char* m1, const unsigned char* m2,
+                                  int P, int hw, int C, int variant, int dtype, float* loss, float* stats, void* workspace,
+                                  void* stream);
 int gd_cost_volume_kl_bwd(const void* f1, const void* f2, const float* t1, const float* t2, int ldt,
                           const unsigned char* m1, const unsigned char* m2, int P, int hw, int C, int dtype,
                           const float* gloss, const float* stats, void* df1, void* df2, void* workspace, void* stream);
@@ -176,6 +183,10 @@ int gd_patch_mask(const float* kp, unsigned char* mask, int B, int Nk, int H, in
  * receive the same gradient, so one buffer (ngrid = 1) can be handed to every tap.  D must be a multiple of 8. */
 int gd_tap_mean_fwd(const void* const* grids, int ngrid, long bstride, int prefix, void* out, int B, int hw, int D,
                     int dtype, void* stream);
+/* gd_tap_mean_fwd that also hands out inv_norm [B, hw] = 1 / max(||out row||, 1e-12) of the rows as stored (what F.normalize divides
+ * by, src/finetune_timm_vggt.py:514-515; feeds gd_cost_volume_kl_fwd_prenorm). */
+int gd_tap_mean_norm_fwd(const void* const* grids, int ngrid, long bstride, int prefix, void* out, float* inv_norm, int B, int hw,
+                         int D, int dtype, void* stream);
 int gd_tap_mean_bwd(void* const* dgrids, int ngrid, int prefix, const void* dout, int B, int hw, int D, float scale,
                     int dtype, void* stream);
 

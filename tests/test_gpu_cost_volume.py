@@ -122,3 +122,36 @@ def test_persistent_kernel_many_tiles_per_block(variant, dtype, P, hw, C):
     assert rel_err(few, full) < 1e-6
     ol, _, _ = _oracle(f1.float(), f2.float(), t1, t2, m1, m2, variant)
     assert rel_err(few, ol) < (1e-5 if dtype == torch.float32 else 1e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_producer_side_row_norms(dtype):
+    """ops.tap_mean(with_norm=True) hands out the inverse L2 norms of the rows it writes, and cost_volume_kl(inv_norms=...) uses them
+    instead of its own pass over the features: same features, same norms, bit-identical loss and gradients as the self-contained
+    op (gd_tap_mean_norm_fwd / gd_cost_volume_kl_fwd_prenorm)."""
+    from gd_amd import ops
+    P, hw, C, pre = 3, 672, 256, 1
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    taps = [torch.randn(2 * P, hw + pre, C, generator=gen, device="cuda").to(dtype).requires_grad_(True) for _ in range(4)]
+    t1 = torch.softmax(3 * torch.randn(P, hw, hw, generator=gen, device="cuda"), -1)
+    t2 = torch.softmax(3 * torch.randn(P, hw, hw, generator=gen, device="cuda"), -1)
+    m1 = torch.rand(P, hw, generator=gen, device="cuda") > 0.5
+    m2 = torch.rand(P, hw, generator=gen, device="cuda") > 0.5
+    c1, c2, ts = _teacher("cached", t1, t2)
+    f_plain = ops.tap_mean(taps, prefix=pre)
+    f, inv = ops.tap_mean(taps, prefix=pre, with_norm=True)
+    assert torch.equal(f, f_plain) and inv.shape == (2 * P, hw) and not inv.requires_grad
+    want = 1.0 / f.detach().float().norm(dim=-1).clamp_min(1e-12)
+    assert rel_err(inv, want) < 1e-6
+    la = ops.cost_volume_kl(f_plain[:P], f_plain[P:], c1, c2, m1, m2, "mast3r", tstats=ts)
+    la.sum().backward()
+    ga = [t.grad.clone() for t in taps]
+    for t in taps:
+        t.grad = None
+    lb = ops.cost_volume_kl(f[:P], f[P:], c1, c2, m1, m2, "mast3r", tstats=ts, inv_norms=(inv[:P], inv[P:]))
+    lb.sum().backward()
+    assert torch.equal(la, lb)
+    for a, t in zip(ga, taps):
+        assert torch.equal(a, t.grad)
+    ol, _, _ = _oracle(f[:P].detach().float(), f[P:].detach().float(), t1, t2, m1, m2, "mast3r")
+    assert rel_err(lb, ol) < (1e-5 if dtype == torch.float32 else 1e-3)

@@ -140,7 +140,7 @@ def pmc_cv():
     torch.cuda.synchronize()
 
 
-def pmc_cv_kp():
+def pmc_cv_kp(full=False):
     """as pmc_cv, with the MASt3R trainer's row masks: patches that hold one of 300 random keypoints (about 20 % of the rows);
     forward only — what bench.py's `roofline_cost_volume` times."""
     P, hw, C, img, patch = 32, 1369, 768, 518, 14
@@ -155,9 +155,12 @@ def pmc_cv_kp():
     t1, t2 = ops.pad_teacher_maps(t1), ops.pad_teacher_maps(t2)
     ts = ops.cost_volume_teacher_stats(t1, t2)
     print("kept rows", int(m1.sum()), int(m2.sum()), "of", P * hw, "each")
+    inv = (1.0 / f1.float().norm(dim=-1).clamp_min(1e-12), 1.0 / f2.float().norm(dim=-1).clamp_min(1e-12))     # from the producer in the step
+    if full:
+        m1, m2 = torch.ones_like(m1), torch.ones_like(m2)
     with torch.no_grad():
         for _ in range(3):
-            ops.cost_volume_kl(f1, f2, t1, t2, m1, m2, "mast3r", tstats=ts)
+            ops.cost_volume_kl(f1, f2, t1, t2, m1, m2, "mast3r", tstats=ts, inv_norms=inv)
     torch.cuda.synchronize()
 
 
@@ -337,6 +340,8 @@ if __name__ == "__main__":
         pmc_cv()
     if "pmc_cv_kp" in which:
         pmc_cv_kp()
+    if "pmc_cv_full" in which:
+        pmc_cv_kp(full=True)
     if "attn" in which:
         bench_attn()
     if "cva" in which:
