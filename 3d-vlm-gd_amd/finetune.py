@@ -209,10 +209,11 @@ class FinetuneGD(nn.Module):
         """One optimisation step of the minimal loop that stands in for Lightning's (src/main.py:153-161): forward +
         losses, backward, gradient exchange (dp.OverlappedGradReducer; None = single rank), clip + AdamW.
         -> (loss, terms, pre-clip gradient norm)."""
-        loss, terms = self.training_step(batch, direct_grads=os.environ.get("GD_DIRECT_GRADS", "0") == "1")
-        # GD_DIRECT_GRADS=1: weight packs as views of the flat buffer + weight gradients accumulated straight into it.  Measured
-        # on one box, alternating runs: 539.3 image-pairs/s against 542.9 for the autograd gather — the ~60 tiny kernels it
-        # removes cost less than modelled (the GPU queue never drains), so it stays an option, not the default.
+        # weight packs as views of the flat parameter buffer + LoRA / adapter weight gradients accumulated straight into the flat gradient
+        # buffer (GDViT.prepare_trainables(flat)): ~45 fewer torch-side launches per step (no per-block zero-filled scratch, no
+        # AccumulateGrad copies of the strided LoRA-B views, no 48-tensor gather).  Step time equal within run-to-run noise on one box
+        # (round 2: 539.3 vs 542.9 image-pairs/s); the default since round 3, GD_DIRECT_GRADS=0 restores the autograd gather.
+        loss, terms = self.training_step(batch, direct_grads=os.environ.get("GD_DIRECT_GRADS", "1") != "0")
         if reducer is None:
             self.backward(loss)
             scale = 1.0

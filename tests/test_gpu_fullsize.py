@@ -45,8 +45,11 @@ def _run_case(name, backbone, variant, dtype, img=518, P=2, N=300, vit_kwargs=No
                      teacher_patch=14, lora_b_std=1e-3, vit_kwargs=vk, **(eng_kwargs or {})).cuda()
     hw = (img // 14) ** 2
     batch = synthetic_batch(P, img, img, N, hw, "cuda", seed=1234, teacher_patch=14, counts=counts)
-    orc = OracleTrainer(eng)
-    ref_loss, ref_terms, ref_grads, ref_params, ref_norm = orc.step(batch, P)
+    key = (backbone, variant, img, P, N, str(vk), str(eng_kwargs), str(counts))      # the fp64 oracle does not depend on the engine dtype:
+    if key not in _STEP_ORACLE:                                                       # (same fp32 master weights, same batch) run it once
+        orc = OracleTrainer(eng)
+        _STEP_ORACLE[key] = orc.step(batch, P) + (orc.names, orc.l1_residuals)
+    ref_loss, ref_terms, ref_grads, ref_params, ref_norm, names, l1_residuals = _STEP_ORACLE[key]
     flat = eng.configure_optimizers()
     before = [q.detach().clone() for q in eng.trainable_parameters()]
     loss, terms = eng.training_step(batch)
@@ -63,13 +66,13 @@ def _run_case(name, backbone, variant, dtype, img=518, P=2, N=300, vit_kwargs=No
     g_ref = torch.cat([g.reshape(-1) for g in ref_grads])
     rec["grad_rel_fro"] = ((g_hip - g_ref).norm() / g_ref.norm()).item()
     rec["grad_cos"] = (torch.dot(g_hip, g_ref) / (g_hip.norm() * g_ref.norm())).item()
-    rec["groups"] = _group_table(orc.names, [q.grad.detach().double().cpu() for q in ps], ref_grads, float(g_ref.norm()))
+    rec["groups"] = _group_table(names, [q.grad.detach().double().cpu() for q in ps], ref_grads, float(g_ref.norm()))
     # The depth-L1 term |pred - target| has a kink: a keypoint whose residual is within the engine's feature noise of zero takes
     # either sign, and ONE flipped keypoint turns its whole gradient contribution around — 2 / sqrt(#keypoints) of the depth
     # branch's gradient norm (0.115 at 300 keypoints; tools/diag_bf16_head.py shows the same gradient change in fp64 torch when only
     # the features are swapped).  Count the keypoints inside the noise band and widen the gradient tolerance by that much.
     if eng.depth_loss_weight != 0 and dtype == "bf16":
-        res = torch.cat([r.abs() for r in orc.l1_residuals if r is not None])
+        res = torch.cat([r.abs() for r in l1_residuals if r is not None])
         nkp = int(res.numel())
         rec["l1_kink"] = {"band": KINK_BAND, "keypoints_in_band": int((res < KINK_BAND).sum()), "min_abs_residual": float(res.min()),
                           "keypoints": nkp}
@@ -157,11 +160,13 @@ def test_prenorm_vit_large_bf16_mast3r_mixed_losses_step_matches_oracle():
 # The bf16 engine against the fp32 CPU oracle over a TRAJECTORY: ten optimiser steps from the same weights on the same pair
 # (north_star: "outputs match the reference CPU path (loss values and updated LoRA weights) within stated fp tolerance").
 # Stated tolerances (held below): loss of every step 1e-3 rel; after ten steps the accumulated update dW = W10 - W0 of the whole
-# trainable vector within BF16_TRAJ_DW_FRO relative Frobenius / cosine BF16_TRAJ_DW_COS of the oracle's, per group recorded.
+# trainable vector within BF16_TRAJ_DW_FRO (0.10) relative Frobenius / cosine BF16_TRAJ_DW_COS (0.99) of the oracle's, per group recorded.
 # AdamW's first steps move every element by ~lr * sign(g): an element whose gradient is smaller than the bf16 noise floor of its
 # group takes a coin-flip direction in ANY reduced-precision run, so dW is compared as a vector, not element-wise.
-BF16_TRAJ_DW_FRO, BF16_TRAJ_DW_COS = 0.35, 0.94
-F32_TRAJ_DW_FRO = 0.02
+BF16_TRAJ_DW_FRO, BF16_TRAJ_DW_COS = 0.10, 0.99      # measured (profiles/r03_fullsize_parity.json): 0.049 / 0.9988
+F32_TRAJ_DW_FRO = 0.01                                 # measured: 0.0014
+_STEP_ORACLE = {}
+_TRAJ_ORACLE = {}                                      # the fp32 oracle's trajectory is the same for both engine dtypes: run it once
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f32"])
@@ -172,17 +177,23 @@ def test_vit_base_518_ten_steps_follow_the_fp32_oracle(dtype):
     eng = FinetuneGD(r=4, backbone="vit_base", patch_size=14, img_size=img, variant="mast3r", geometry="shared", dtype=dtype,
                      teacher_patch=14, lora_b_std=1e-3, vit_kwargs=dict(init_values=1.0)).cuda()
     batch = synthetic_batch(P, img, img, N, (img // 14) ** 2, "cuda", seed=4321, teacher_patch=14)
-    orc = OracleTrainer(eng, dtype=torch.float32)            # the reference's arithmetic precision
+    if "traj" not in _TRAJ_ORACLE:                           # same initial weights (fp32 masters, seed 0) and batch for both dtypes
+        orc = OracleTrainer(eng, dtype=torch.float32)        # the reference's arithmetic precision
+        ref_losses = []
+        for _ in range(steps):
+            ref_loss, _, _, ref_params, _ = orc.step(batch, P)
+            ref_losses.append(ref_loss)
+        _TRAJ_ORACLE["traj"] = (ref_losses, ref_params, orc.names)
+    ref_losses, ref_params, names = _TRAJ_ORACLE["traj"]
     eng.configure_optimizers()
     ps = eng.trainable_parameters()
     w0 = [q.detach().double().cpu().clone() for q in ps]
     rec = {"steps": steps, "dtype": dtype, "loss": [], "ref_loss": [], "loss_rel_err": []}
-    for _ in range(steps):
+    for i in range(steps):
         loss, _, _ = eng.fit_step(batch)
-        ref_loss, _, _, ref_params, _ = orc.step(batch, P)
         rec["loss"].append(loss.item())
-        rec["ref_loss"].append(ref_loss)
-        rec["loss_rel_err"].append(abs(loss.item() - ref_loss) / abs(ref_loss))
+        rec["ref_loss"].append(ref_losses[i])
+        rec["loss_rel_err"].append(abs(loss.item() - ref_losses[i]) / abs(ref_losses[i]))
     d_hip = [q.detach().double().cpu() - a for q, a in zip(ps, w0)]
     d_ref = [r.double() - a for r, a in zip(ref_params, w0)]
     a, b = torch.cat([x.reshape(-1) for x in d_hip]), torch.cat([x.reshape(-1) for x in d_ref])
@@ -192,9 +203,9 @@ def test_vit_base_518_ten_steps_follow_the_fp32_oracle(dtype):
     w_ref = torch.cat([r.double().reshape(-1) for r in ref_params])
     rec["weights_rel_fro"] = float((w_hip - w_ref).norm() / w_ref.norm())
     rec["max_weight_diff_over_lr"] = float((w_hip - w_ref).abs().max() / 1e-5)
-    rec["groups_dw"] = _group_table(orc.names, d_hip, d_ref, float(b.norm()))
+    rec["groups_dw"] = _group_table(names, d_hip, d_ref, float(b.norm()))
     rec["stated_tolerance"] = {"loss_rel": TOL, "dw_rel_fro": BF16_TRAJ_DW_FRO if dtype == "bf16" else F32_TRAJ_DW_FRO,
-                               "dw_cos": BF16_TRAJ_DW_COS if dtype == "bf16" else 0.999}
+                               "dw_cos": BF16_TRAJ_DW_COS if dtype == "bf16" else 0.9999}
     _record(f"trajectory10_vit_base_518_mast3r_{dtype}", rec)
     assert max(rec["loss_rel_err"]) < TOL, rec["loss_rel_err"]
     assert rec["loss"][-1] < rec["loss"][0]                  # and it trains
