@@ -232,13 +232,13 @@ def main():
             out["roofline"] = gemm_roofline(prof, args.dtype, dt, args.steps)
             # memory-side bytes per launch: PMC counters cannot be read from inside the timed run, so this REPLAYS the committed
             # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE measurement of this same command (profiles/README.md), default workload only
-            pmc = os.path.join(ROOT, "profiles", "r02_pmc_gemm_traffic.json")
+            pmc = os.path.join(ROOT, "profiles", "r03_pmc_gemm_traffic.json")
             if (os.path.exists(pmc) and args.dtype == "bf16" and backbone == "vit_base" and P == 32
                     and args.geometry == "shared" and variant == "mast3r"):
                 with open(pmc) as fh:
                     t = json.load(fh)
                 out["roofline"]["traffic"] = round(t["hbm_side_mb_per_launch"] * 1e6)
-                out["roofline"]["traffic_replayed_from"] = ("profiles/r02_pmc_gemm_traffic.json (2 x FETCH_SIZE + WRITE_SIZE per "
+                out["roofline"]["traffic_replayed_from"] = ("profiles/r03_pmc_gemm_traffic.json (2 x FETCH_SIZE + WRITE_SIZE per "
                                                             "persistent-kernel launch, separate --pmc passes; NOT measured in this run)")
             if args.gemm_shapes:
                 for k, (cnt, sms, tf) in sorted(prof.by_shape().items(), key=lambda kv: -kv[1][1]):
