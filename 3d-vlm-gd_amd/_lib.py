@@ -107,6 +107,7 @@ SIGNATURES = {
     "gd_cross_view_attn_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "gd_cross_view_attn": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float,
                                    c_int, c_int, c_void_p, c_void_p]),
+    "gd_split3": (c_int, [c_void_p, c_void_p, c_long, c_int, c_long, c_int, c_void_p]),
     "gd_cast": (c_int, [c_void_p, c_void_p, c_long, c_float, c_int, c_int, c_void_p]),
     "gd_attention_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "gd_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,

@@ -20,6 +20,33 @@
 #include <stdlib.h>
 
 #define HD 64
+
+// ---- split-precision path (dtype code GD_F32X3): fp32 tensors in memory, every MFMA operand as a (hi, lo) pair of bf16 fragments,
+// hi = bf16(x), lo = bf16(x - hi), and every product as the three bf16 MFMAs  lo_a hi_b + hi_a lo_b + hi_a hi_b  (all of a . b except
+// lo_a lo_b: ~4e-6 relative, TF32 ~3e-4) — 3 x 16 MFMA cycles per 32-wide chunk against 8 x 32 for the exact-f32 MFMA.  The same
+// kernels, instantiated on the tag type `x3` (a 4-byte element: pointer arithmetic is fp32's); only the traits below differ.
+struct x3 { float v; };
+struct X3Frag { bf16x8 hi, lo; };
+template <typename T> struct IsX3 { static constexpr bool v = false; };
+template <> struct IsX3<x3> { static constexpr bool v = true; };
+template <> struct Mma<x3> {
+    static constexpr int KC = 32;
+    typedef X3Frag Frag;
+    static __device__ __forceinline__ f32x4 mma(const Frag& a, const Frag& b, f32x4 c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.lo, b.hi, c, 0, 0, 0);      // small terms first
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.lo, c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.hi, c, 0, 0, 0);
+    }
+};
+__device__ __forceinline__ X3Frag x3_split(const float (&x)[8]) {
+    X3Frag f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        f.hi[k] = (bf16)x[k];
+        f.lo[k] = (bf16)(x[k] - (float)f.hi[k]);
+    }
+    return f;
+}
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // bare v_exp_f32
 // max over the 4 lanes {l, l^16, l^32, l^48} with the gfx950 row-swap instructions (VALU; a ds_bpermute pair costs two
 // dependent LDS round trips in the middle of the softmax)
@@ -50,12 +77,23 @@ template <> __device__ __forceinline__ bf16x8 frag_scale<bf16>(bf16x8 f, float a
     return o;
 }
 template <> __device__ __forceinline__ f32x4 frag_scale<float>(f32x4 f, float a) { return f * a; }
+template <> __device__ __forceinline__ X3Frag frag_scale<x3>(X3Frag f, float a) {      // scale the fp32 value, split again
+    float x[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = ((float)f.hi[k] + (float)f.lo[k]) * a;
+    return x3_split(x);
+}
 template <typename T> __device__ __forceinline__ typename Mma<T>::Frag frag_ones();
 template <> __device__ __forceinline__ bf16x8 frag_ones<bf16>() {
     const bf16 o = (bf16)1.0f;
     return bf16x8{o, o, o, o, o, o, o, o};
 }
 template <> __device__ __forceinline__ f32x4 frag_ones<float>() { return f32x4{1.f, 1.f, 1.f, 1.f}; }
+template <> __device__ __forceinline__ X3Frag frag_ones<x3>() {
+    X3Frag f = {};
+    f.hi = frag_ones<bf16>();
+    return f;
+}
 
 // s[qt][kt] hold s*c2 - m of a 64-key tile (TAIL: keys >= N get -1e30).  Updates m / negm (and rescales o, l) when the
 // tile's maximum moved the reference point, then turns the scores into p in place.
@@ -121,6 +159,17 @@ template <> struct AT<float> {
     static __device__ __forceinline__ int sw(int) { return 0; }
 };
 
+// x3: an LDS row is 256 bytes = 16 positions of 16 bytes: plane pl (0 hi, 1 lo), chunk q (8 bf16 each) sits at position
+// (8 pl + q) ^ (row & 15) — the sixteen rows 16 k + c that a ds_read_b128 lane group reads at one logical chunk land on sixteen
+// different positions; row and row + 16 share the swizzle (the transpose reads rely on it).
+template <> struct AT<x3> {
+    static constexpr int NF = 2;        // (hi, lo) fragment pairs per 64-wide contraction
+    static constexpr int ROWB = 256;
+    static constexpr int CPR = 16;      // 16-byte chunks per 64-float GLOBAL row
+    static constexpr int EPC = 4;
+    static __device__ __forceinline__ int sw(int row) { return row & 15; }
+};
+
 // four C-layout tiles that span 64 contraction indices (index = 16*tile + 4*g + r) -> B fragment u
 template <typename T> __device__ __forceinline__ typename Mma<T>::Frag acc_to_bfrag(const f32x4 (&t)[4], int u);
 template <> __device__ __forceinline__ bf16x8 acc_to_bfrag<bf16>(const f32x4 (&t)[4], int u) {
@@ -128,6 +177,11 @@ template <> __device__ __forceinline__ bf16x8 acc_to_bfrag<bf16>(const f32x4 (&t
     return bf16x8{(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};
 }
 template <> __device__ __forceinline__ f32x4 acc_to_bfrag<float>(const f32x4 (&t)[4], int u) { return t[u]; }
+template <> __device__ __forceinline__ X3Frag acc_to_bfrag<x3>(const f32x4 (&t)[4], int u) {
+    const f32x4 a = t[2 * u], b = t[2 * u + 1];
+    const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return x3_split(x);
+}
 
 // matching A fragment from a transposed LDS tile row (64 contraction indices contiguous)
 template <typename T> __device__ __forceinline__ typename Mma<T>::Frag load_tfrag(const char* row, int u, int g);
@@ -148,6 +202,19 @@ template <typename T> __device__ __forceinline__ typename Mma<T>::Frag load_nfra
 // natural fragment u of row `row` of an LDS tile (chunk 4 u + g, swizzled)
 template <typename T> __device__ __forceinline__ typename Mma<T>::Frag lds_nfrag(const char* tile, int row, int u, int g) {
     return *(const typename Mma<T>::Frag*)(tile + row * AT<T>::ROWB + (((u * 4 + g) ^ AT<T>::sw(row)) * 16));
+}
+
+template <> __device__ __forceinline__ X3Frag load_nfrag<x3>(const char* row, int u, int g) {      // GLOBAL fp32 row: floats 32 u + 8 g .. + 7
+    const f32x4 a = *(const f32x4*)(row + (32 * u + 8 * g) * 4), b = *(const f32x4*)(row + (32 * u + 8 * g + 4) * 4);
+    const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return x3_split(x);
+}
+template <> __device__ __forceinline__ X3Frag lds_nfrag<x3>(const char* tile, int row, int u, int g) {
+    const char* r = tile + row * AT<x3>::ROWB;
+    X3Frag f;
+    f.hi = *(const bf16x8*)(r + (((u * 4 + g) ^ AT<x3>::sw(row)) * 16));
+    f.lo = *(const bf16x8*)(r + (((8 + u * 4 + g) ^ AT<x3>::sw(row)) * 16));
+    return f;
 }
 
 // Tile staging, split T14-style: `tile_load` issues the global loads of a 64 x 64-element tile into registers
@@ -194,6 +261,20 @@ __device__ __forceinline__ void tile_load(TileRegs<T, NT>& r, const TileSrc<T, N
 template <typename T, bool NAT, bool TRN, int NT = 256>
 __device__ __forceinline__ void tile_store(const TileRegs<T, NT>& r, char* sN, char* sT) {
     constexpr int CPR = AT<T>::CPR, EPC = AT<T>::EPC, ROWB = AT<T>::ROWB, NCH = CPR * 64 / NT;
+    if constexpr (std::is_same<T, x3>::value) {      // four floats -> four hi + four lo bf16 (8 bytes each): half `cc & 1` of bf16 chunk `cc >> 1`
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int ch = threadIdx.x + NT * i, rr = ch / CPR, cc = ch % CPR;
+            const f32x4 x = __builtin_bit_cast(f32x4, r.v[i]);
+            bf16x4 hi, lo;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { hi[k] = (bf16)x[k]; lo[k] = (bf16)(x[k] - (float)hi[k]); }
+            char* row = sN + rr * ROWB + 8 * (cc & 1);
+            *(bf16x4*)(row + (((cc >> 1) ^ AT<x3>::sw(rr)) * 16)) = hi;
+            *(bf16x4*)(row + (((8 + (cc >> 1)) ^ AT<x3>::sw(rr)) * 16)) = lo;
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int ch = threadIdx.x + NT * i, rr = ch / CPR, cc = ch % CPR;
@@ -226,6 +307,27 @@ template <> struct TOp<bf16> {
         return __builtin_bit_cast(bf16x8, z);
     }
 };
+template <> struct TOp<x3> {      // both planes straight from the natural tile, as bf16
+    static constexpr bool kNeedT = false;
+    static __device__ __forceinline__ bf16x8 plane(const char* sN, int pl, int dt, int u, int g, int lane) {
+        typedef __attribute__((ext_vector_type(4))) short s16x4;
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        const int i = lane & 15, q = i >> 2, p = i & 3;
+        const int row = 32 * u + 4 * g + q;                         // (row + 16 has the same swizzle)
+        const char* a0 = sN + row * AT<x3>::ROWB + (((8 * pl + 2 * dt + (p >> 1)) ^ AT<x3>::sw(row)) * 16) + 8 * (p & 1);
+        const char* a1 = a0 + 16 * AT<x3>::ROWB;
+        const s16x4 x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
+        const s16x4 y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1);
+        const s16x8 z = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+        return __builtin_bit_cast(bf16x8, z);
+    }
+    static __device__ __forceinline__ X3Frag load(const char* sN, const char*, int dt, int u, int g, int lane) {
+        X3Frag f;
+        f.hi = plane(sN, 0, dt, u, g, lane);
+        f.lo = plane(sN, 1, dt, u, g, lane);
+        return f;
+    }
+};
 template <> struct TOp<float> {
     static constexpr bool kNeedT = true;
     static __device__ __forceinline__ f32x4 load(const char*, const char* sT, int dt, int u, int g, int lane) {
@@ -236,6 +338,7 @@ template <> struct TOp<float> {
 
 template <typename T> __device__ __forceinline__ void store4(T* p, f32x4 v);
 template <> __device__ __forceinline__ void store4<float>(float* p, f32x4 v) { *(f32x4*)p = v; }
+template <> __device__ __forceinline__ void store4<x3>(x3* p, f32x4 v) { *(f32x4*)p = v; }
 template <> __device__ __forceinline__ void store4<bf16>(bf16* p, f32x4 v) {
     *(bf16x4*)p = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
 }
@@ -539,10 +642,16 @@ __device__ __forceinline__ float frag_dot(bf16x8 a, bf16x8 b) {
     return s;
 }
 __device__ __forceinline__ float frag_dot(f32x4 a, f32x4 b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
+__device__ __forceinline__ float frag_dot(const X3Frag& a, const X3Frag& b) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s = fmaf((float)a.hi[k] + (float)a.lo[k], (float)b.hi[k] + (float)b.lo[k], s);
+    return s;
+}
 
 // ------------------------------------------------------------------------------------------ backward: dQ
 template <typename T>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const T* qkv, const T* o, const T* dout, const float* lse,
+__global__ __launch_bounds__(256, IsX3<T>::v ? 1 : 2) void attn_bwd_dq_kernel(const T* qkv, const T* o, const T* dout, const float* lse,
                                                           float* delta, T* dqkv, int N, int H, float scale) {
     constexpr int NF = AT<T>::NF, ROWB = AT<T>::ROWB;
     typedef typename Mma<T>::Frag Frag;
@@ -669,7 +778,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const T* qkv, const
 // DK = false: dV only (the first trainable block of the student: nothing below it learns, so dK — and with it dP, dS and the Q^T
 // operand — is never used; half of the kernel's MFMAs)
 template <typename T, int NW, bool DK = true>
-__global__ __launch_bounds__(64 * NW, NW >= 8 ? 1 : 2) void attn_bwd_dkv_kernel(const T* qkv, const T* dout, const float* lse,
+__global__ __launch_bounds__(64 * NW, (NW >= 8 || IsX3<T>::v) ? 1 : 2) void attn_bwd_dkv_kernel(const T* qkv, const T* dout, const float* lse,
                                                            const float* delta, T* dqkv, int N, int H, float scale, int vfirst) {
     constexpr int NF = AT<T>::NF, ROWB = AT<T>::ROWB;
     typedef typename Mma<T>::Frag Frag;
@@ -991,7 +1100,7 @@ extern "C" int gd_attention_fwd(const void* qkv, void* o, float* lse, int B, int
     GD_REQUIRE(B > 0 && N > 0 && H > 0, "gd_attention_fwd: bad shape B=%d N=%d H=%d", B, N, H);
     GD_REQUIRE(head_dim == HD, "gd_attention_fwd: head_dim must be 64 (got %d)", head_dim);
     GD_REQUIRE((long)N * 3 * H * HD * 4 < (1L << 31), "gd_attention_fwd: one image's qkv rows must span < 2^31 bytes (32-bit tile offsets): N=%d H=%d", N, H);
-    GD_REQUIRE(dtype == GD_F32 || dtype == GD_BF16, "gd_attention_fwd: bad dtype %d", dtype);
+    GD_REQUIRE(dtype == GD_F32 || dtype == GD_BF16 || dtype == GD_F32X3, "gd_attention_fwd: bad dtype %d", dtype);
     GD_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)o & 15) == 0, "gd_attention_fwd: pointers must be 16-byte aligned");
     dim3 grid(gd_cdiv(N, 128), H, B);
     const int dma = gd_knobs().attn_dma;   // GD_ATTN_DMA=0: the register-staged forward kernel (A/B testing)
@@ -1000,6 +1109,8 @@ extern "C" int gd_attention_fwd(const void* qkv, void* o, float* lse, int B, int
           hipLaunchKernelGGL(attn_fwd_dma_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, ro); }
     else if (dtype == GD_BF16)
         hipLaunchKernelGGL(attn_fwd_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale);
+    else if (dtype == GD_F32X3)
+        hipLaunchKernelGGL(attn_fwd_kernel<x3>, grid, dim3(256), 0, (hipStream_t)stream, (const x3*)qkv, (x3*)o, lse, N, H, scale);
     else
         hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)qkv, (float*)o, lse, N, H, scale);
     GD_LAUNCH_OK();
@@ -1015,7 +1126,7 @@ extern "C" int gd_attention_bwd(const void* qkv, const void* o, const void* dout
     GD_REQUIRE(B > 0 && N > 0 && H > 0, "gd_attention_bwd: bad shape B=%d N=%d H=%d", B, N, H);
     GD_REQUIRE(head_dim == HD, "gd_attention_bwd: head_dim must be 64 (got %d)", head_dim);
     GD_REQUIRE((long)N * 3 * H * HD * 4 < (1L << 31), "gd_attention_bwd: one image's qkv rows must span < 2^31 bytes (32-bit tile offsets): N=%d H=%d", N, H);
-    GD_REQUIRE(dtype == GD_F32 || dtype == GD_BF16, "gd_attention_bwd: bad dtype %d", dtype);
+    GD_REQUIRE(dtype == GD_F32 || dtype == GD_BF16 || dtype == GD_F32X3, "gd_attention_bwd: bad dtype %d", dtype);
     GD_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)dout & 15) == 0 && ((uintptr_t)dqkv & 15) == 0,
                "gd_attention_bwd: pointers must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
@@ -1038,6 +1149,13 @@ extern "C" int gd_attention_bwd(const void* qkv, const void* o, const void* dout
             hipLaunchKernelGGL((attn_bwd_dkv_kernel<bf16, 4>), dim3(gd_cdiv(N, 128), H, B), dim3(256), 0, s, (const bf16*)qkv, (const bf16*)dout, lse, delta_ws, (bf16*)dqkv, N, H, scale, grad_order);
         else
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<bf16, 8>), dim3(gd_cdiv(N, 256), H, B), dim3(512), 0, s, (const bf16*)qkv, (const bf16*)dout, lse, delta_ws, (bf16*)dqkv, N, H, scale, grad_order);
+    } else if (dtype == GD_F32X3) {
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<x3>, grid, dim3(256), 0, s, (const x3*)qkv, (const x3*)o, (const x3*)dout, lse, delta_ws, (x3*)dqkv, N, H, scale);
+        // four-wave 128-key blocks with the whole register file per wave (the (hi, lo) fragments double the operand registers)
+        if (no_dk)
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<x3, 4, false>), dim3(gd_cdiv(N, 128), H, B), dim3(256), 0, s, (const x3*)qkv, (const x3*)dout, lse, delta_ws, (x3*)dqkv, N, H, scale, grad_order);
+        else
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<x3, 4>), dim3(gd_cdiv(N, 128), H, B), dim3(256), 0, s, (const x3*)qkv, (const x3*)dout, lse, delta_ws, (x3*)dqkv, N, H, scale, grad_order);
     } else {
         hipLaunchKernelGGL(attn_bwd_dq_kernel<float>, grid, dim3(256), 0, s, (const float*)qkv, (const float*)o, (const float*)dout, lse, delta_ws, (float*)dqkv, N, H, scale);
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<float, 8>), dim3(gd_cdiv(N, 256), H, B), dim3(512), 0, s, (const float*)qkv, (const float*)dout, lse, delta_ws, (float*)dqkv, N, H, scale, grad_order);

@@ -960,6 +960,39 @@ __global__ __launch_bounds__(256) void tap_mean_norm_fwd_kernel(TapMeanParams p,
     if (lane == 0) inv_norm[row] = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
 }
 
+// f32 -> three bf16 planes per row for the 3-term split product (gd_split3): x = hi + lo + O(2^-17 |x|), hi = bf16(x), lo = bf16(x - hi).
+// which = 0 (left operand):  out row = [hi | lo | hi];  which = 1 (right operand): out row = [hi | hi | lo]
+// so that  out_A . out_W^T = hi_a hi_w + lo_a hi_w + hi_a lo_w  over a contraction of 3 K — everything of a . w except lo_a lo_w.
+__global__ __launch_bounds__(256) void split3_kernel(const float* in, bf16* out, long rows, int K, long ld_in, int which) {
+    const int kv = K / 8;
+    const long total = rows * kv;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long r = idx / kv;
+        const int c = (int)(idx - r * kv) * 8;
+        const f32x4 a = *(const f32x4*)(in + r * ld_in + c), b = *(const f32x4*)(in + r * ld_in + c + 4);
+        const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        bf16x8 hi, lo;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            hi[k] = (bf16)x[k];
+            lo[k] = (bf16)(x[k] - (float)hi[k]);
+        }
+        bf16* o = out + r * 3L * K + c;
+        *(bf16x8*)o = hi;
+        *(bf16x8*)(o + K) = which ? hi : lo;
+        *(bf16x8*)(o + 2L * K) = which ? lo : hi;
+    }
+}
+
+extern "C" int gd_split3(const float* in, void* out, long rows, int K, long ld_in, int which, void* stream) {
+    GD_REQUIRE(in && out && rows > 0 && K > 0 && K % 8 == 0 && ld_in >= K && ld_in % 4 == 0 && (which == 0 || which == 1),
+               "gd_split3: bad arguments (K must be a multiple of 8, ld_in of 4)");
+    GD_REQUIRE(((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 15) == 0, "gd_split3: in / out must be 16-byte aligned");
+    hipLaunchKernelGGL(split3_kernel, dim3(ew_blocks(rows * (K / 8))), dim3(256), 0, (hipStream_t)stream, in, (bf16*)out, rows, K, ld_in, which);
+    GD_LAUNCH_OK();
+    return 0;
+}
+
 extern "C" int gd_tap_mean_norm_fwd(const void* const* grids, int ngrid, long bstride, int prefix, void* out, float* inv_norm, int B,
                                     int hw, int D, int dtype, void* stream) {
     GD_REQUIRE(ngrid >= 1 && ngrid <= 4 && B > 0 && hw > 0 && D > 0 && D % 8 == 0 && inv_norm != nullptr, "gd_tap_mean_norm_fwd: bad arguments");

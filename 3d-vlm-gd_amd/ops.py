@@ -109,6 +109,24 @@ def gemm_nt(a, w, out=None, *, out_dtype=None, alpha=1.0, bias=None, lora_t=None
     return out
 
 
+def split3(x, which):
+    """f32 [rows, K] (rows may be strided) -> bf16 [rows, 3K]: the hi / lo planes of the 3-term split product (gd_split3).  which = "a":
+    left operand [hi | lo | hi]; "w": right operand [hi | hi | lo].  gemm_nt(split3(a, "a"), split3(w, "w"), out_dtype=torch.float32)
+    is a . w^T to ~4e-6 relative (TF32: ~3e-4) on the bf16 matrix cores."""
+    _req(x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1, "split3: a 2-D fp32 CUDA tensor with contiguous rows")
+    rows, K = x.shape
+    out = torch.empty(rows, 3 * K, dtype=torch.bfloat16, device=x.device)
+    check(lib().gd_split3(ptr(x), ptr(out), rows, K, x.stride(0), {"a": 0, "w": 1}[which], stream()), "gd_split3")
+    return out
+
+
+def gemm_nt_x3(a, w3, **kw):
+    """gemm_nt on an fp32 left operand and a PRE-SPLIT right operand w3 = split3(w, "w") (frozen weights are split once): fp32 output and
+    fp32 epilogue tensors, three bf16 MFMA products per term."""
+    kw.setdefault("out_dtype", torch.float32)
+    return gemm_nt(split3(a, "a"), w3, **kw)
+
+
 def gemm_tn(y, x, out=None, *, alpha=1.0):
     """out[N,K] (fp32) += alpha * y[M,N]^T @ x[M,K]   (weight gradients; fp32 accumulation)."""
     _req(y.is_cuda and x.is_cuda and y.stride(-1) == 1 and x.stride(-1) == 1 and y.shape[:-1] == x.shape[:-1],
@@ -210,24 +228,29 @@ def cost_volume_kl(f1, f2, t1, t2, m1, m2, variant="vggt", tstats=None, inv_norm
     return _CostVolumeKL.apply(f1, f2, t1, t2, m1, m2, variant, tstats)
 
 
-def attention_fwd(qkv, B, N, H):
-    """qkv [B*N, 3*H*64] packed (q|k|v, heads inner) -> o [B*N, H*64], lse [B,H,N] (f32)."""
+F32X3 = 2      # gd_attention_* dtype code: fp32 tensors, products as three bf16 MFMAs of (hi, lo) splits (include/gd_hip.h GD_F32X3)
+
+
+def attention_fwd(qkv, B, N, H, x3=False):
+    """qkv [B*N, 3*H*64] packed (q|k|v, heads inner) -> o [B*N, H*64], lse [B,H,N] (f32).  x3 (fp32 tensors only): the TF32-class
+    split-precision kernels instead of the exact-f32 MFMA ones."""
     _req(qkv.is_contiguous() and qkv.shape == (B * N, 3 * H * 64), "attention_fwd: qkv must be [B*N, 3*H*64]")
     o = torch.empty(B * N, H * 64, dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device)
-    rc = lib().gd_attention_fwd(ptr(qkv), ptr(o), ptr(lse), B, N, H, 64, 64 ** -0.5, dtype_code(qkv), stream())
+    _req(not x3 or qkv.dtype == torch.float32, "attention_fwd: x3 needs fp32 tensors")
+    rc = lib().gd_attention_fwd(ptr(qkv), ptr(o), ptr(lse), B, N, H, 64, 64 ** -0.5, F32X3 if x3 else dtype_code(qkv), stream())
     check(rc, "gd_attention_fwd")
     return o, lse
 
 
-def attention_bwd(qkv, o, dout, lse, B, N, H, vfirst=False, need_dk=True):
+def attention_bwd(qkv, o, dout, lse, B, N, H, vfirst=False, need_dk=True, x3=False):
     """-> dqkv [B*N, 3*H*64] (same dtype as qkv), column blocks (dq, dk, dv) — or (dq, dv, dk) with vfirst.  need_dk=False: the dK
     columns are left unwritten (bf16: the dK/dV kernel then runs its dV half only)."""
     _req(dout.is_contiguous() and dout.shape == o.shape and dout.dtype == qkv.dtype, "attention_bwd: bad dout")
     dqkv = torch.empty_like(qkv)
     delta = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device)
     rc = lib().gd_attention_bwd(ptr(qkv), ptr(o), ptr(dout), ptr(lse), ptr(dqkv), ptr(delta), B, N, H, 64,
-                                64 ** -0.5, dtype_code(qkv), (1 if vfirst else 0) | (0 if need_dk else 2), stream())
+                                64 ** -0.5, F32X3 if x3 else dtype_code(qkv), (1 if vfirst else 0) | (0 if need_dk else 2), stream())
     check(rc, "gd_attention_bwd")
     return dqkv
 

@@ -25,8 +25,17 @@ from .model import Adapter, BlockWithAdapter, _LoRA_qkv  # noqa: F401
 
 
 def _dt(name):
-    return {"f32": torch.float32, "bf16": torch.bfloat16, torch.float32: torch.float32,
+    # "tf32x": fp32 storage and arithmetic everywhere except the big frozen-weight GEMMs, which run as 3-term bf16 splits (ops.split3)
+    return {"f32": torch.float32, "bf16": torch.bfloat16, "tf32x": torch.float32, torch.float32: torch.float32,
             torch.bfloat16: torch.bfloat16}[name]
+
+
+def _mm(x, plan, key, **kw):
+    """x . W^T with the plan's frozen weight `key`: one GEMM in the f32 / bf16 engines; in the tf32x engine the weight was split once
+    (plan['x3']) and the activation is split on the way in — three bf16 MFMA products per term, fp32 accumulation / output / epilogue."""
+    if plan.get("x3"):
+        return ops.gemm_nt_x3(x, plan[key], **kw)
+    return ops.gemm_nt(x, plan[key], **kw)
 
 
 class GDAttention(nn.Module):
@@ -66,13 +75,15 @@ class GDBlock(nn.Module):
         self.mlp = GDMlp(dim, int(dim * mlp_ratio))
         self.ls2 = GDLayerScale(dim, init_values) if init_values else nn.Identity()
         self._plan = None
+        self.split3 = False          # tf32x engine (set by GDViT): frozen weights are kept as 3-term bf16 splits
 
     def forward(self, x):
         return run_block(self, x)
 
     # ---- frozen-weight plan: casted / folded / pre-transposed copies, built once per dtype ----
     def plan(self, dtype):
-        if self._plan is not None and self._plan["dtype"] == dtype:
+        x3 = bool(self.split3) and dtype == torch.float32
+        if self._plan is not None and self._plan["dtype"] == dtype and self._plan["x3"] == x3:
             return self._plan
         base = self.attn.qkv.qkv if hasattr(self.attn.qkv, "linear_a_q") else self.attn.qkv      # any _LoRA_qkv-shaped wrapper
         dev = base.weight.device
@@ -95,9 +106,11 @@ class GDBlock(nn.Module):
         wqkv, w1 = f32(base.weight), f32(self.mlp.fc1.weight)
 
         def both(w):
+            if x3:      # [N, 3K] bf16 planes [hi | hi | lo] of W and of W^T (ops.split3)
+                return ops.split3(w.contiguous(), "w"), ops.split3(w.t().contiguous(), "w")
             return w.to(dtype).contiguous(), w.t().to(dtype).contiguous()
 
-        p = {"dtype": dtype, "D": D, "H": self.attn.num_heads, "eps1": self.norm1.eps, "eps2": self.norm2.eps,
+        p = {"dtype": dtype, "x3": x3, "D": D, "H": self.attn.num_heads, "eps1": self.norm1.eps, "eps2": self.norm2.eps,
              "ln1_w": f32(self.norm1.weight), "ln1_b": f32(self.norm1.bias),
              "ln2_w": f32(self.norm2.weight), "ln2_b": f32(self.norm2.bias),
              "bqkv": f32(base.bias) if base.bias is not None else zeros(3 * D), "bproj": bproj.contiguous(),
@@ -105,7 +118,8 @@ class GDBlock(nn.Module):
              "b2": bfc2.contiguous()}
         p["wqkv"], p["wqkv_t"] = both(wqkv)
         # the attention backward hands back (dq, dv, dk): W^T with its K blocks in that order for dX = dqkv . W
-        p["wqkv_t_qvk"] = torch.cat([wqkv[:D], wqkv[2 * D:], wqkv[D:2 * D]], 0).t().to(dtype).contiguous()
+        wqvk_t = torch.cat([wqkv[:D], wqkv[2 * D:], wqkv[D:2 * D]], 0).t().contiguous()
+        p["wqkv_t_qvk"] = ops.split3(wqvk_t, "w") if x3 else wqvk_t.to(dtype).contiguous()
         p["wproj"], p["wproj_t"] = both(wproj)
         p["w1"], p["w1_t"] = both(w1)
         p["w2"], p["w2_t"] = both(wfc2)
@@ -146,13 +160,13 @@ class _BlockFn(torch.autograd.Function):
                 bt[r:, 2 * D:] = b_v.detach().t()
                 at_T = at.to(T).contiguous()
             t = ops.gemm_nt(y1, at_T, out_dtype=torch.float32)  # [M, 2r]
-        qkv = ops.gemm_nt(y1, plan["wqkv"], bias=plan["bqkv"], lora_t=t, lora_b=bt)
-        o, lse = ops.attention_fwd(qkv, B, Nt, H)
-        x1 = ops.gemm_nt(o, plan["wproj"], bias=plan["bproj"], residual=x)
+        qkv = _mm(y1, plan, "wqkv", bias=plan["bqkv"], lora_t=t, lora_b=bt)
+        o, lse = ops.attention_fwd(qkv, B, Nt, H, x3=plan["x3"])
+        x1 = _mm(o, plan, "wproj", bias=plan["bproj"], residual=x)
         y2, mean2, rstd2 = ops.layernorm_fwd(x1, plan["ln2_w"], plan["ln2_b"], plan["eps2"], save_stats=need)
         pre = torch.empty(M, plan["w1"].shape[0], dtype=T, device=x.device) if need else None
-        h = ops.gemm_nt(y2, plan["w1"], bias=plan["b1"], act=3, preact=pre)   # pre <- GELU'(fc1 output): all the backward needs
-        x2 = ops.gemm_nt(h, plan["w2"], bias=plan["b2"], residual=x1)
+        h = _mm(y2, plan, "w1", bias=plan["b1"], act=3, preact=pre)   # pre <- GELU'(fc1 output): all the backward needs
+        x2 = _mm(h, plan, "w2", bias=plan["b2"], residual=x1)
         out, hd = x2, None
         if down is not None:
             down_T = tw["down_T"] if tw is not None else down.detach().to(T).contiguous()
@@ -199,14 +213,14 @@ class _BlockFn(torch.autograd.Function):
                 dx2 = ops.gemm_nt(dhp, down_tT, residual=dout)
             g_up = ops.gemm_tn(dout, hd, out=z_up)                                                # [D, 64]
             g_down = ops.gemm_tn(dhp, x2, out=z_down)                                             # [64, D]
-        dpre = ops.gemm_nt(dx2, plan["w2_t"], dact_src=pre, dact=3)                               # [M, 4D] (x stored GELU')
-        dy2 = ops.gemm_nt(dpre, plan["w1_t"])
+        dpre = _mm(dx2, plan, "w2_t", dact_src=pre, dact=3)                                       # [M, 4D] (x stored GELU')
+        dy2 = _mm(dpre, plan, "w1_t")
         del dpre
         dx1 = ops.layernorm_bwd(dy2, x1, plan["ln2_w"], mean2, rstd2, dres=dx2)
-        do = ops.gemm_nt(dx1, plan["wproj_t"])
+        do = _mm(dx1, plan, "wproj_t")
         # gradient columns come back as (dq, dv, dk): the q / v LoRA factors only ever touch the first two thirds
         # the first trainable block: no gradient flows below it, dK has no consumer (the LoRA factors contract dq and dv only)
-        dqkv = ops.attention_bwd(qkv, o, do, lse, B, Nt, H, vfirst=True, need_dk=bool(ctx.needs_input_grad[0]))
+        dqkv = ops.attention_bwd(qkv, o, do, lse, B, Nt, H, vfirst=True, need_dk=bool(ctx.needs_input_grad[0]), x3=plan["x3"])
         if ctx.has_lora:
             r = at.shape[0] // 2
             bt_T = tw["bt_T"] if tw is not None else bt.to(T).contiguous()
@@ -229,9 +243,9 @@ class _BlockFn(torch.autograd.Function):
         if not ctx.needs_input_grad[0]:   # first trainable block: nothing below it learns, skip dX (one GEMM + one LN backward)
             return None, None, None, None, g_aq, g_bq, g_av, g_bv, g_down, g_up
         if ctx.has_lora:
-            dy1 = ops.gemm_nt(dqkv, plan["wqkv_t_qvk"], lora_t=dt, lora_b=at.contiguous())        # dqkv.W + dt.At
+            dy1 = _mm(dqkv, plan, "wqkv_t_qvk", lora_t=dt, lora_b=at.contiguous())                # dqkv.W + dt.At
         else:
-            dy1 = ops.gemm_nt(dqkv, plan["wqkv_t_qvk"])
+            dy1 = _mm(dqkv, plan, "wqkv_t_qvk")
         dx = ops.layernorm_bwd(dy1, x, plan["ln1_w"], mean1, rstd1, dres=dx1)
         return dx, None, None, None, g_aq, g_bq, g_av, g_bv, g_down, g_up
 
@@ -354,6 +368,11 @@ class GDViT(nn.Module):
         self.pos_interp = pos_interp
         self.mean, self.std = tuple(mean), tuple(std)
         self.dtype = _dt(dtype)
+        # tf32x: TF32-class GEMMs on the bf16 matrix cores (gfx950 has no TF32 MFMA; the reference's MASt3R path computes its matmuls in
+        # TF32, dust3r/croco/models/croco.py:12): fp32 everywhere, the eight big frozen-weight GEMMs of a block as 3-term bf16 splits
+        self.gemm_split3 = dtype == "tf32x"
+        for blk in self.blocks:
+            blk.split3 = self.gemm_split3
         self._pos_cache = {}
         self._pe_plan = None
         # dtype of the final-normed tap grids that feed the keypoint features (None = the engine dtype).  torch.float32 keeps
@@ -674,7 +693,7 @@ class _ConvAtKpFn(torch.autograd.Function):
     float atomics."""
 
     @staticmethod
-    def forward(ctx, tok, weight, bias, kp, geom):
+    def forward(ctx, tok, weight, bias, kp, geom, x3=False):
         gh, gw, sx, sy, img_h, img_w, patch = geom
         B, Nt, D = tok.shape
         tok = tok.contiguous()
@@ -686,9 +705,13 @@ class _ConvAtKpFn(torch.autograd.Function):
         sparse_dx = tok.requires_grad and Nk <= 1024 and D % 8 == 0 and D <= 1024 and os.environ.get("GD_CONV_DX_AT_KP", "1") != "0"
         # [n, (ky, kx, c)], the flipped [ci, (kx, ky, n)] of the dense backward, [(ky, kx, c), n] of the backward at the keypoints
         wk, wt, wu = ops.conv_weight_pack(weight, T, with_wu=sparse_dx)
-        out = ops.gemm_nt(colp, wk, bias=bias.detach().float().contiguous(), out_dtype=torch.float32)
+        x3 = bool(x3) and T == torch.float32 and sparse_dx        # tf32x engine: the two K = 9D GEMMs as 3-term bf16 splits
+        if x3:
+            out = ops.gemm_nt_x3(colp, ops.split3(wk, "w"), bias=bias.detach().float().contiguous())
+        else:
+            out = ops.gemm_nt(colp, wk, bias=bias.detach().float().contiguous(), out_dtype=torch.float32)
         ctx.save_for_backward(colp, wu if sparse_dx else wt, kp)
-        ctx.sparse_dx = sparse_dx
+        ctx.sparse_dx, ctx.x3 = sparse_dx, x3
         ctx.meta = (geom, B, Nt, D, Nk)
         return out.view(B, Nk, D)
 
@@ -705,7 +728,7 @@ class _ConvAtKpFn(torch.autograd.Function):
         dtok = None
         if ctx.needs_input_grad[0] and ctx.sparse_dx:
             # dcol = dfeat . W over the B*Nk keypoint rows, then every token gathers its contributions (no atomics, no dense GEMM)
-            U = ops.gemm_nt(dft, wt, out_dtype=T)                  # (`wt` holds wu here) [B*Nk, 9D]
+            U = ops.gemm_nt_x3(dft, ops.split3(wt, "w")) if ctx.x3 else ops.gemm_nt(dft, wt, out_dtype=T)   # (`wt` holds wu here) [B*Nk, 9D]
             dtok = ops.kp_patch_bwd_det(U, kp, T, B, Nk, Nt, gh, gw, D, sx, sy, img_h, img_w, patch)
         elif ctx.needs_input_grad[0]:
             rows = B * gh * (gw + 1)
@@ -715,17 +738,17 @@ class _ConvAtKpFn(torch.autograd.Function):
             sbuf = ops.stack3_rows(dy, B, gh, gw, D, gh * (gw + 1) * D, 0, gw + 1, T)
             dxp = ops.gemm_nt(ops.conv_view(sbuf, rows, D), wt)        # [rows, D] on the pitched grid
             dtok = ops.unpitch_tokens(dxp, B, gh, gw, D, Nt - gh * gw)
-        return dtok, gweight, gbias, None, None
+        return dtok, gweight, gbias, None, None, None
 
 
-def conv3x3_at_keypoints(tok, weight, bias, kp, gh, gw, sx, sy, img_h, img_w, patch):
+def conv3x3_at_keypoints(tok, weight, bias, kp, gh, gw, sx, sy, img_h, img_w, patch, x3=False):
     """refine_conv (3x3, padding 1) of the token grid of tok [B, prefix + gh*gw, D], bilinearly sampled at kp [B, Nk, 2] (pixels)
     -> [B, Nk, D] fp32, or None when the layout does not allow it (rows that are not 16-byte multiples; GD_CONV_AT_KP=0)."""
     import os
     es = 2 if tok.dtype == torch.bfloat16 else 4
     if os.environ.get("GD_CONV_AT_KP", "1") == "0" or (tok.shape[-1] * es) % 16 != 0:
         return None
-    return _ConvAtKpFn.apply(tok, weight, bias, kp, (gh, gw, float(sx), float(sy), int(img_h), int(img_w), int(patch)))
+    return _ConvAtKpFn.apply(tok, weight, bias, kp, (gh, gw, float(sx), float(sy), int(img_h), int(img_w), int(patch)), bool(x3))
 
 
 def conv3x3_tokens(tok, weight, bias, gh, gw):

@@ -21,6 +21,7 @@ extern "C" {
 
 #define GD_F32 0
 #define GD_BF16 1
+#define GD_F32X3 2   /* gd_attention_{fwd,bwd} only: fp32 tensors, every product as three bf16 MFMAs of (hi, lo) splits (TF32-class; see gd_split3) */
 
 const char* gd_last_error(void);
 int gd_abi_version(void);
@@ -254,6 +255,13 @@ int gd_clip_adamw_ranges(float* params, const float* grads, float* exp_avg, floa
                          float weight_decay, float beta1, float beta2, float eps, float max_norm, float grad_scale,
                          float* grad_norm_out, void* workspace, const long* ranges, int n_ranges, void* stream);
 int gd_cast(const void* in, void* out, long n, float scale, int in_dtype, int out_dtype, void* stream);
+/* TF32-class products on the bf16 matrix cores (gfx950 has no TF32 / xf32 MFMA; the reference's MASt3R path runs its matmuls in TF32:
+ * dust3r/croco/models/croco.py:12 `torch.backends.cuda.matmul.allow_tf32 = True`): an f32 operand is written as three bf16 planes per
+ * row — which = 0, left operand: [hi | lo | hi]; which = 1, right operand: [hi | hi | lo]; hi = bf16(x), lo = bf16(x - hi) — and
+ * gd_gemm_nt on the two 3K-wide bf16 operands (fp32 accumulation, f32 output and epilogue tensors) evaluates
+ * hi_a hi_w + lo_a hi_w + hi_a lo_w: relative error ~4e-6 of the product sum, against ~3e-4 for TF32 and ~2e-3 for plain bf16
+ * (tests/test_gpu_gemm.py::test_split3_product_accuracy).  in [rows, K] f32 (row stride ld_in), out [rows, 3K] bf16. */
+int gd_split3(const float* in, void* out, long rows, int K, long ld_in, int which, void* stream);
 
 /* flat_allreduce: the data-parallel step's one exchange — the sum over ranks of the flat fp32 gradient buffer — on RCCL over
  * xGMI (replaces Lightning DDP's bucketed all-reduce, src/main.py:147-151).  RCCL is bound at run time (dlopen, the copy the

@@ -75,3 +75,24 @@ def test_attention_reference_point_moves(dtype, tol, gtol, case):
     coherent = dtype == torch.bfloat16 and case in ("rising", "all_negative")
     assert float((lse.double().cpu() - rl.cpu()).abs().max()) < (1e-4 if dtype == torch.float32 else 0.15 if coherent else 8e-2)
     assert rel_err(dqkv, rg) < (0.2 if coherent else gtol)
+
+
+@pytest.mark.parametrize("B,N,H", [(1, 17, 1), (2, 64, 2), (1, 257, 3), (2, 1370, 2), (2, 200, 2)])
+def test_attention_split_precision(B, N, H):
+    """The x3 instantiation of the attention kernels (dtype code GD_F32X3: fp32 tensors, every MFMA product as three bf16 MFMAs of
+    (hi, lo) operand splits): output / lse / gradients within 3e-5 of the fp64 reference — TF32-class, 1000x inside plain bf16 —
+    and the same column-order / dV-only contracts as the other dtypes."""
+    from gd_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(N + 1)
+    qkv = torch.randn(B * N, 3 * H * 64, generator=g, device="cuda")
+    dout = torch.randn(B * N, H * 64, generator=g, device="cuda")
+    o, lse = ops.attention_fwd(qkv, B, N, H, x3=True)
+    dqkv = ops.attention_bwd(qkv, o, dout, lse, B, N, H, x3=True)
+    ro, rl, rg = _ref(qkv, B, N, H, dout)
+    fro = lambda a, b: float((a.double().cpu() - b.cpu()).norm() / b.cpu().norm())
+    assert fro(o, ro) < 3e-5 and rel_err(lse, rl) < 1e-5 and fro(dqkv, rg) < 5e-5, (fro(o, ro), rel_err(lse, rl), fro(dqkv, rg))
+    d2 = ops.attention_bwd(qkv, o, dout, lse, B, N, H, vfirst=True, x3=True)
+    D = H * 64
+    assert torch.equal(d2[:, :D], dqkv[:, :D]) and torch.equal(d2[:, D:2 * D], dqkv[:, 2 * D:]) and torch.equal(d2[:, 2 * D:], dqkv[:, D:2 * D])
+    d3 = ops.attention_bwd(qkv, o, dout, lse, B, N, H, vfirst=True, need_dk=False, x3=True)
+    assert torch.equal(d3[:, :2 * D], d2[:, :2 * D])

@@ -220,3 +220,31 @@ def test_lora_bwd_fused(M, K, ldx):
     g2 = g0.clone()
     ops.skinny_tn_mfma(t, dqv, g2)
     assert rel_err(g2, rg) < 2e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(1370, 2304, 768), (5480, 768, 3072), (300, 128, 64)])
+def test_split3_product_accuracy(M, N, K):
+    """ops.split3 + gemm_nt on the 3K-wide bf16 operands (gd_split3: TF32-class products on the bf16 matrix cores): the planes are
+    hi = bf16(x), lo = bf16(x - hi) in the documented order, and the product is within 2e-5 of the fp64 one — well inside TF32's
+    ~3e-4 (operands rounded to 10 mantissa bits) and two orders of magnitude inside plain bf16's ~2e-3; epilogue tensors stay fp32."""
+    from gd_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(M + K)
+    a = torch.randn(M, K, generator=g, device="cuda")
+    w = torch.randn(N, K, generator=g, device="cuda") * 0.05
+    a3, w3 = ops.split3(a, "a"), ops.split3(w, "w")
+    hi = a.bfloat16()
+    lo = (a - hi.float()).bfloat16()
+    assert torch.equal(a3[:, :K], hi) and torch.equal(a3[:, K:2 * K], lo) and torch.equal(a3[:, 2 * K:], hi)
+    wh = w.bfloat16()
+    assert torch.equal(w3[:, :K], wh) and torch.equal(w3[:, K:2 * K], wh) and torch.equal(w3[:, 2 * K:], (w - wh.float()).bfloat16())
+    ref = a.double() @ w.double().t()
+    fro = lambda x: float((x.double() - ref).norm() / ref.norm())
+    got = ops.gemm_nt(a3, w3, out_dtype=torch.float32)
+    assert got.dtype == torch.float32 and fro(got) < 2e-5
+    tf32 = lambda x: ((x.view(torch.int32) + 0x1000) & ~0x1FFF).view(torch.float32)
+    assert fro(got) < 0.2 * fro(tf32(a.clone()).double() @ tf32(w.clone()).double().t())
+    assert fro(got) < 0.02 * fro(ops.gemm_nt(hi, wh, out_dtype=torch.float32))
+    bias = torch.randn(N, generator=g, device="cuda")
+    res = torch.randn(M, N, generator=g, device="cuda")
+    got2 = ops.gemm_nt_x3(a, w3, bias=bias, residual=res)
+    assert float((got2.double() - (ref + bias.double() + res.double())).norm() / ref.norm()) < 2e-5

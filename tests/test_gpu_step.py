@@ -144,6 +144,25 @@ def _oracle_step(eng, batch, P):
     return OracleTrainer(eng).step(batch, P)
 
 
+def test_full_step_tf32x_matches_oracle():
+    """The tf32x engine (fp32 storage, the big frozen-weight GEMMs as 3-term bf16 splits: ops.split3) on the toy student: loss terms
+    1e-5, gradients 1e-3 of the oracle's — between TF32 (what the reference's MASt3R path computes in) and fp32."""
+    P, h, w, N = 2, 56, 70, 12
+    eng = _engine("vggt", "shared", "tf32x", teacher_patch=14)
+    assert eng.model.gemm_split3 and eng.model.dtype == torch.float32
+    batch = synthetic_batch(P, h, w, N, 20, "cuda", seed=3, counts=[12, 9])
+    ref_loss, ref_terms, ref_grads, _, ref_norm = _oracle_step(eng, batch, P)
+    eng.configure_optimizers()
+    loss, terms = eng.training_step(batch)
+    eng.backward(loss)
+    assert abs(loss.item() - ref_loss) < 1e-5 * abs(ref_loss)
+    g_hip = torch.cat([q.grad.detach().double().cpu().reshape(-1) for q in eng.trainable_parameters()])
+    g_ref = torch.cat([g.reshape(-1) for g in ref_grads])
+    assert float((g_hip - g_ref).norm() / g_ref.norm()) < 1e-3
+    plan = eng.model.blocks[5].block.plan(torch.float32)
+    assert plan["x3"] and plan["wqkv"].dtype == torch.bfloat16 and plan["wqkv"].shape == (3 * 64, 3 * 64)
+
+
 @pytest.mark.parametrize("variant,geometry", [("vggt", "shared"), ("mast3r", "shared"), ("vggt", "reference")])
 def test_full_step_f32_matches_oracle(variant, geometry):
     P, h, w, N = 2, 56, 70, 12

@@ -180,6 +180,19 @@ def _bench_attn(B, N, H):
     print(f"attn bwd  {t*1e6:8.1f} us  {2.5*fl/t/1e12:7.1f} TF/s (algorithmic 5 products)")
 
 
+def bench_attn_x3():
+    """fp32 attention: the exact-f32 MFMA kernels against the split-precision (x3) instantiation, 64 x 12 x 1370."""
+    B, N, H = 64, 1370, 12
+    qkv = torch.randn(B * N, 3 * H * 64, device="cuda")
+    dout = torch.randn(B * N, H * 64, device="cuda")
+    fl = 4.0 * B * H * N * N * 64
+    for x3 in (False, True):
+        o, lse = ops.attention_fwd(qkv, B, N, H, x3=x3)
+        tf = timeit(lambda: ops.attention_fwd(qkv, B, N, H, x3=x3), warm=1, it=3)
+        tb = timeit(lambda: ops.attention_bwd(qkv, o, dout, lse, B, N, H, x3=x3), warm=1, it=3)
+        print(f"attn fp32 tensors, {'split-precision x3' if x3 else 'exact-f32 MFMA   '}: fwd {tf*1e6:8.1f} us ({fl/tf/1e12:6.1f} TF/s)  bwd {tb*1e6:8.1f} us ({2.5*fl/tb/1e12:6.1f} TF/s)", flush=True)
+
+
 def bench_cva():
     """teacher cross-view attention maps (gd_cross_view_attn) vs the reference formulation in torch (per-head maps materialised)."""
     from gd_amd import teacher_glue as TG
@@ -344,6 +357,8 @@ if __name__ == "__main__":
         pmc_cv_kp(full=True)
     if "attn" in which:
         bench_attn()
+    if "attn_x3" in which:
+        bench_attn_x3()
     if "cva" in which:
         bench_cva()
     if "tn" in which:
