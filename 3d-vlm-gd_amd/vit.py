@@ -30,11 +30,13 @@ def _dt(name):
             torch.bfloat16: torch.bfloat16}[name]
 
 
-def _mm(x, plan, key, **kw):
+def _mm(x, plan, key, xs=None, **kw):
     """x . W^T with the plan's frozen weight `key`: one GEMM in the f32 / bf16 engines; in the tf32x engine the weight was split once
-    (plan['x3']) and the activation is split on the way in — three bf16 MFMA products per term, fp32 accumulation / output / epilogue."""
+    (plan['x3']) and the activation is split on the way in (xs: its split, when the caller already has it) — three bf16 MFMA products
+    per term, fp32 accumulation / output / epilogue."""
     if plan.get("x3"):
-        return ops.gemm_nt_x3(x, plan[key], **kw)
+        kw.setdefault("out_dtype", torch.float32)
+        return ops.gemm_nt(xs if xs is not None else ops.split3(x, "a"), plan[key], **kw)
     return ops.gemm_nt(x, plan[key], **kw)
 
 
@@ -159,8 +161,13 @@ class _BlockFn(torch.autograd.Function):
                 bt[:r, :D] = b_q.detach().t()
                 bt[r:, 2 * D:] = b_v.detach().t()
                 at_T = at.to(T).contiguous()
-            t = ops.gemm_nt(y1, at_T, out_dtype=torch.float32)  # [M, 2r]
-        qkv = _mm(y1, plan, "wqkv", bias=plan["bqkv"], lora_t=t, lora_b=bt)
+        y1s = ops.split3(y1, "a") if plan["x3"] else None                     # tf32x: ONE split of LN1(x) feeds the LoRA-A and the QKV GEMM
+        if a_q is not None:
+            if plan["x3"]:     # [M, 2r] on the streaming N <= 8 bf16 kernel over the 3K-wide operands (the fp32 tile kernel spends a 128-wide tile on 8 columns)
+                t = ops.gemm_nt(y1s, ops.split3(at.contiguous(), "w"), out_dtype=torch.float32)
+            else:
+                t = ops.gemm_nt(y1, at_T, out_dtype=torch.float32)  # [M, 2r]
+        qkv = _mm(y1, plan, "wqkv", xs=y1s, bias=plan["bqkv"], lora_t=t, lora_b=bt)
         o, lse = ops.attention_fwd(qkv, B, Nt, H, x3=plan["x3"])
         x1 = _mm(o, plan, "wproj", bias=plan["bproj"], residual=x)
         y2, mean2, rstd2 = ops.layernorm_fwd(x1, plan["ln2_w"], plan["ln2_b"], plan["eps2"], save_stats=need)
@@ -226,7 +233,18 @@ class _BlockFn(torch.autograd.Function):
             bt_T = tw["bt_T"] if tw is not None else bt.to(T).contiguous()
             bt_qv = tw["bt_qv"] if tw is not None else torch.cat([bt_T[:, :D], bt_T[:, 2 * D:]], 1).contiguous()   # [2r, 2D]
             dqv = dqkv[:, :2 * D]
-            if ops.lora_bwd_fused_supported(dqv, t, bt_qv, z_bt):
+            if plan["x3"]:
+                if ctx.needs_input_grad[0]:
+                    # tf32x: dt = dqv . Bt^T on the split of the WHOLE dqkv row (the dX GEMM below needs that split anyway) against
+                    # [Bt_q | Bt_v | 0] — the dk third contributes zeros; bf16 tile kernel instead of the fp32 one
+                    dqkv_s = ops.split3(dqkv, "a")
+                    btz = torch.zeros(bt_qv.shape[0], 3 * D, dtype=torch.float32, device=dqkv.device)
+                    btz[:, :2 * D] = bt_qv
+                    dt = ops.gemm_nt(dqkv_s, ops.split3(btz, "w"), out_dtype=torch.float32)      # [M, 2r]
+                else:      # first trainable block: the dk third of dqkv was never written — split the (dq, dv) view only
+                    dt = ops.gemm_nt(ops.split3(dqv, "a"), ops.split3(bt_qv.contiguous(), "w"), out_dtype=torch.float32)
+                gbt = ops.gemm_tn(t, dqv, out=z_bt)                                               # [2r, 2D]
+            elif ops.lora_bwd_fused_supported(dqv, t, bt_qv, z_bt):
                 dt = ops.lora_bwd_fused(dqv, t, bt_qv, z_bt)                                      # both products, one pass over dqv
                 gbt = z_bt
             else:
@@ -243,7 +261,7 @@ class _BlockFn(torch.autograd.Function):
         if not ctx.needs_input_grad[0]:   # first trainable block: nothing below it learns, skip dX (one GEMM + one LN backward)
             return None, None, None, None, g_aq, g_bq, g_av, g_bv, g_down, g_up
         if ctx.has_lora:
-            dy1 = _mm(dqkv, plan, "wqkv_t_qvk", lora_t=dt, lora_b=at.contiguous())                # dqkv.W + dt.At
+            dy1 = _mm(dqkv, plan, "wqkv_t_qvk", xs=dqkv_s if plan["x3"] else None, lora_t=dt, lora_b=at.contiguous())   # dqkv.W + dt.At
         else:
             dy1 = _mm(dqkv, plan, "wqkv_t_qvk")
         dx = ops.layernorm_bwd(dy1, x, plan["ln1_w"], mean1, rstd1, dres=dx1)

@@ -20,6 +20,8 @@ Extra objects on the line:
   parity                engine loss vs the CPU oracle (oracle/gd_oracle.py, fp32) on the same weights and the same pairs
   f32                   the same workload on the f32 engine (the reference's arithmetic precision): same --steps / --warmup, own
                         roofline and parity (also as config.reference_precision_run and roofline.f32_engine)
+  tf32x                 the same workload on the TF32-class engine (fp32 storage, 3-term bf16 split products on the matrix cores): same
+                        --steps / --warmup, own roofline and parity (also as config.tf32_class_run and roofline.tf32x_engine)
   other_configs         short runs of BASELINE configs 3 / 5-like and of the reference's own token geometry
   comm                  N > 1: all-reduce time of the two gradient chunks and the exposed fraction of the step
   cpu_baseline          the CPU oracle on a bounded sample of the same workload, rank 0 / N=1 only
@@ -275,6 +277,16 @@ def main():
                     "reference trains in fp32; gfx950 has no TF32"}
                 if "roofline" in out and "roofline" in f:
                     out["roofline"]["f32_engine"] = f["roofline"]
+            if "tf32x" in extras:
+                f = extras["tf32x"]
+                out["config"]["tf32_class_run"] = {
+                    "dtype": "tf32x", "value": f["value"], "unit": "image-pairs/s", "ms_per_step": f["ms_per_step"], "steps": f["steps"],
+                    "warmup": f["warmup"], "parity_rel_err": f.get("parity", {}).get("rel_err"),
+                    "note": "same workload, fp32 storage, every big GEMM and the attention products as three bf16 MFMAs of (hi, lo) operand splits "
+                            "(gd_split3, GD_F32X3): product error ~4e-6 against ~3e-4 for TF32 — the precision the reference's MASt3R path "
+                            "computes its matmuls in (dust3r/croco/models/croco.py:12, allow_tf32); gradient 3e-4 of the fp64 oracle at full size"}
+                if "roofline" in out and "roofline" in f:
+                    out["roofline"]["tf32x_engine"] = f["roofline"]
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -494,6 +506,9 @@ def companion_runs(args, variant, backbone, weights, dev, rank, world):
     if args.dtype != "f32":
         out["f32"] = run(backbone, variant, "f32", args.geometry, P, steps=args.steps, warmup=args.warmup,
                          prof=not args.no_kernel_events, wts=weights, parity=world == 1)
+    if args.dtype != "tf32x":
+        out["tf32x"] = run(backbone, variant, "tf32x", args.geometry, P, steps=args.steps, warmup=args.warmup,
+                           prof=not args.no_kernel_events, wts=weights, parity=world == 1)
     if world == 1 and args.geometry == "shared" and backbone == "vit_base":
         out["other_configs"] = {
             "vit_large_vggt": run("vit_large", "vggt", args.dtype, "shared", 16),
