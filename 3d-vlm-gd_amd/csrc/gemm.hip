@@ -769,12 +769,13 @@ extern "C" int gd_gemm_nt(const void* A, const void* W, void* C, int M, int N, i
             }
             else
 #endif
-            if ((act == 1 || act == 3) && !preact && cb) pk = gemm_nt_persist_kernel<bf16, 0, 1, 0, false>;
+            if ((act == 1 || act == 3) && !preact) pk = cb ? gemm_nt_persist_kernel<bf16, 0, 1, 0, false> : gemm_nt_persist_kernel<bf16, 0, 1, 0, true>;
             else if (act == 1 && preact && cb) pk = gemm_nt_persist_kernel<bf16, 0, 1, 1, false>;
-            else if (act == 3 && preact && cb) pk = gemm_nt_persist_kernel<bf16, 0, 1, 2, false>;
+            else if (act == 3 && preact) pk = cb ? gemm_nt_persist_kernel<bf16, 0, 1, 2, false> : gemm_nt_persist_kernel<bf16, 0, 1, 2, true>;
         } else if (dact_src && dact == 1 && act == 0 && !preact && cb) pk = gemm_nt_persist_kernel<bf16, 1, 0, 0, false>;
-        else if (dact_src && dact == 3 && act == 0 && !preact && cb) pk = gemm_nt_persist_kernel<bf16, 3, 0, 0, false>;
-        else if (residual && act == 0 && !preact && cb) pk = gemm_nt_persist_kernel<bf16, 2, 0, 0, false>;
+        else if (dact_src && dact == 3 && act == 0 && !preact) pk = cb ? gemm_nt_persist_kernel<bf16, 3, 0, 0, false> : gemm_nt_persist_kernel<bf16, 3, 0, 0, true>;
+        else if (residual && act == 0 && !preact) pk = cb ? gemm_nt_persist_kernel<bf16, 2, 0, 0, false> : gemm_nt_persist_kernel<bf16, 2, 0, 0, true>;
+        // (the f32-output instantiations serve the tf32x engine: bf16 3K-wide split operands, fp32 C / preact / dact_src / residual)
     }
     if (big && persist && pk && p.vec_epilogue && N % 8 == 0 && (!lora_t || lora_rt == 8) && 256 * ldmax * cs < 0x7fffffffL) {
         // (Tile quantisation — e.g. 1029 tiles of the N = 768 GEMMs on 256 CUs — costs far less than a round: the left-over

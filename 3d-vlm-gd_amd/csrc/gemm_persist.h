@@ -13,6 +13,7 @@
 //   * the LoRA rank update is applied at the START of a tile (first MFMA chunk), bias comes from LDS.
 #pragma once
 #include "gemm_tile.h"
+#include <type_traits>
 
 __device__ __forceinline__ int nperm64(int rho) {   // LDS W-row (64w + 16j + fr) -> column 64w + 4fr + j of the 256-wide tile
     return (rho & ~63) | ((rho & 15) << 2) | ((rho >> 4) & 3);
@@ -141,7 +142,8 @@ template <typename T, int SIDE, int ACT, int PREACT, bool CF32, int ANAT = 0>
 __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
     constexpr int NWN = 4, WMT = 8, NW = 8, BM = 256, BN = 256;
     constexpr int ABYTES = BM * 128, STAGE = (BM + BN) * 128, APW = BM / 8 / NW, BPW = BN / 8 / NW;
-    constexpr int SDEP = 16;   // side-input prefetch depth (16-byte slots per lane)
+    constexpr int SDEP = CF32 ? 8 : 16;   // side-input prefetch depth (items per lane in flight: 8 bytes each for bf16 side tensors, 16 for f32)
+    constexpr int ssz = CF32 ? 4 : 2;     // element size of the side tensor (dact_src / residual): the dtype of C
     constexpr int LORA_OFF = 2 * STAGE, BIAS_OFF = LORA_OFF + (BM + BN) * 32;
     __shared__ __attribute__((aligned(16))) char smem[BIAS_OFF + 2 * BN * 4];
     typedef typename Mma<T>::Frag Frag;
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
     const int sa = swz(fr);
     const unsigned lds0 = lds_off(smem);
     constexpr bool pre = SIDE != 0;
-    const bf16* side_src = (const bf16*)(SIDE == 2 ? p.residual : p.dact_src);
+    const void* side_src = SIDE == 2 ? p.residual : p.dact_src;
     const long side_ld = SIDE == 2 ? p.ldr : p.ldd;
 
     int t = blockIdx.x, slot = 0;
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
         };
         const __amdgpu_buffer_rsrc_t crs = mk(Cb, p.ldc, csz);
         const __amdgpu_buffer_rsrc_t prs = mk(PREACT ? p.preact : Cb, PREACT ? p.ldp : p.ldc, csz);
-        const __amdgpu_buffer_rsrc_t srs = mk(pre ? (const void*)side_src : (const void*)Cb, pre ? side_ld : p.ldc, pre ? 2 : csz);
+        const __amdgpu_buffer_rsrc_t srs = mk(pre ? side_src : (const void*)Cb, pre ? side_ld : p.ldc, pre ? ssz : csz);
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
         if (p.bias) {
             const unsigned biasaddr = lds_off(smem + BIAS_OFF) + cslot * BN * 4 + (wn * 64 + fr * 4) * 4;
@@ -340,12 +342,23 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
         // num_records as an unsigned offset.
         const int cbase = cok ? (rloc * ldc_i + col0) * csz : OOB;
         const int pbase = cok ? (rloc * ldp_i + col0) * csz : OOB;
-        const int sbase = cok ? (rloc * lds_i + col0) * 2 : OOB;
+        const int sbase = cok ? (rloc * lds_i + col0) * ssz : OOB;
         constexpr int NITEM = 4 * WMT;   // idx = 4 i + r
-        gd_u32x2 sd[SDEP] = {};
+        typedef typename std::conditional<CF32, gd_u32x4, gd_u32x2>::type SideReg;    // four side values of an item: f32 or bf16
+        SideReg sd[SDEP] = {};
         auto side_load = [&](int idx) {
-            const int off = sbase + ((idx >> 2) * 16 + (idx & 3)) * 2 * lds_i;
-            sd[idx % SDEP] = __builtin_amdgcn_raw_buffer_load_b64(srs, off, 0, GD_PERSIST_SIDE_AUX);
+            const int off = sbase + ((idx >> 2) * 16 + (idx & 3)) * ssz * lds_i;
+            if constexpr (CF32) sd[idx % SDEP] = __builtin_amdgcn_raw_buffer_load_b128(srs, off, 0, GD_PERSIST_SIDE_AUX);
+            else sd[idx % SDEP] = __builtin_amdgcn_raw_buffer_load_b64(srs, off, 0, GD_PERSIST_SIDE_AUX);
+        };
+        auto side_vals = [&](int idx, float (&x)[4]) {
+            if constexpr (CF32) {
+                const f32x4 q = __builtin_bit_cast(f32x4, sd[idx % SDEP]);
+                x[0] = q[0]; x[1] = q[1]; x[2] = q[2]; x[3] = q[3];
+            } else {
+                const bf16x4 q = __builtin_bit_cast(bf16x4, sd[idx % SDEP]);
+                x[0] = (float)q[0]; x[1] = (float)q[1]; x[2] = (float)q[2]; x[3] = (float)q[3];
+            }
         };
         if (pre) {
 #pragma unroll
@@ -394,20 +407,15 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
             }
-            if (SIDE == 1) {
-                const bf16x4 x = __builtin_bit_cast(bf16x4, sd[idx % SDEP]);
+            if (SIDE != 0) {
+                float x[4];
+                side_vals(idx, x);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] *= dgelu_fast((float)x[j]);
-            }
-            if (SIDE == 2) {
-                const bf16x4 x = __builtin_bit_cast(bf16x4, sd[idx % SDEP]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] += (float)x[j];
-            }
-            if (SIDE == 3) {
-                const bf16x4 x = __builtin_bit_cast(bf16x4, sd[idx % SDEP]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] *= (float)x[j];
+                for (int j = 0; j < 4; ++j) {
+                    if (SIDE == 1) v[j] *= CF32 ? dgelu_f(x[j]) : dgelu_fast(x[j]);
+                    if (SIDE == 2) v[j] += x[j];
+                    if (SIDE == 3) v[j] *= x[j];
+                }
             }
             if (ANAT != 4) bst4_aux<GD_PERSIST_STORE_AUX>(crs, coff, cdt, v);
             else asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));

@@ -94,6 +94,29 @@ def test_gemm_nt_persistent_epilogues(M, N, K):
     assert rel_err(ops.gemm_nt(a, w, dact_src=src, dact=3), plain * src.double()) < tol
 
 
+@pytest.mark.parametrize("M,N,K", [(1500, 512, 256), (20000, 768, 192)])
+def test_gemm_nt_persistent_f32_epilogue_tensors(M, N, K):
+    """bf16 operands with fp32 C / preact / dact_src / residual on the persistent kernel (the instantiations the tf32x engine runs its
+    3K-wide split operands on): the epilogue arithmetic is fp32 end to end — compared at 1e-5 against the fp64 result of the same
+    bf16-rounded operands."""
+    from gd_amd import ops
+    dt = torch.bfloat16
+    a, w = _mk((M, K), dt, 31), _mk((N, K), dt, 32)
+    bias = _mk((N,), torch.float32, 33)
+    res, src = _mk((M, N), torch.float32, 36), _mk((M, N), torch.float32, 37)
+    plain = a.double() @ w.double().t()
+    gelu = torch.nn.functional.gelu
+    f32 = torch.float32
+    assert rel_err(ops.gemm_nt(a, w, out_dtype=f32, bias=bias, residual=res), plain + bias.double() + res.double()) < 1e-5
+    assert rel_err(ops.gemm_nt(a, w, out_dtype=f32, dact_src=src, dact=3), plain * src.double()) < 1e-5
+    assert rel_err(ops.gemm_nt(a, w, out_dtype=f32, bias=bias, act=1), gelu(plain + bias.double())) < 1e-5
+    y = (plain + bias.double()).requires_grad_(True)
+    gelu(y).sum().backward()
+    dg = torch.empty(M, N, dtype=f32, device="cuda")
+    out = ops.gemm_nt(a, w, out_dtype=f32, bias=bias, preact=dg, act=3)
+    assert out.dtype == f32 and rel_err(out, gelu(y.detach())) < 1e-5 and rel_err(dg, y.grad) < 1e-5
+
+
 def test_gemm_nt_persistent_ragged_n_and_batched():
     """persistent kernel with a half-empty last column tile (N = 320), and batched with fp32 output (the cost-volume
     backward's G.b products: grid.y = batch)."""
