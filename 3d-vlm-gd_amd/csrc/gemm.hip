@@ -716,7 +716,11 @@ extern "C" int gd_gemm_nt(const void* A, const void* W, void* C, int M, int N, i
                           int accumulate, void* stream) {
     GD_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0, "gd_gemm_nt: bad shape M=%d N=%d K=%d batch=%d", M, N, K, batch);
     GD_REQUIRE(ab_dtype == GD_F32 || ab_dtype == GD_BF16, "gd_gemm_nt: bad ab_dtype %d", ab_dtype);
-    GD_REQUIRE(c_dtype == GD_F32 || c_dtype == GD_BF16, "gd_gemm_nt: bad c_dtype %d", c_dtype);
+    GD_REQUIRE(c_dtype == GD_F32 || c_dtype == GD_BF16 || c_dtype == GD_F32X3, "gd_gemm_nt: bad c_dtype %d", c_dtype);
+    // c_dtype GD_F32X3: C is the [hi | lo | hi] bf16 operand split of the f32 result (row stride ldc >= 3N bf16 elements; the A
+    // operand of the next tf32x GEMM); preact / dact_src / residual are f32.  Persistent-kernel shapes only (checked below).
+    const bool csplit = c_dtype == GD_F32X3;
+    if (csplit) c_dtype = GD_F32;
     const int es = gd_dtype_size(ab_dtype);
     GD_REQUIRE((K * es) % 16 == 0 && (lda * es) % 16 == 0 && (ldw * es) % 16 == 0 && (sA * es) % 16 == 0 &&
                    (sW * es) % 16 == 0,
@@ -732,14 +736,14 @@ extern "C" int gd_gemm_nt(const void* A, const void* W, void* C, int M, int N, i
     p.lora_t = lora_t; p.lora_b = lora_b; p.lora_rt = lora_rt; p.preact = preact; p.ldp = ldp; p.act = act == 3 ? 1 : act; p.act_deriv = act == 3;
     p.dact_src = dact_src; p.ldd = ldd; p.dact = dact_src ? dact : 0; p.residual = residual; p.ldr = ldr;
     p.accumulate = accumulate;
-    const int cs = gd_dtype_size(c_dtype);
+    const int cs = gd_dtype_size(c_dtype), ccs = csplit ? 2 : cs;
     auto al = [&](const void* q, long ld) { return q == nullptr || ((((uintptr_t)q) & 15) == 0 && (ld * cs) % 16 == 0); };
-    p.vec_epilogue = al(C, ldc) && (sC * cs) % 16 == 0 && al(preact, ldp) && al(dact_src, ldd) && al(residual, ldr) &&
+    p.vec_epilogue = ((uintptr_t)C & 15) == 0 && (ldc * ccs) % 16 == 0 && (sC * ccs) % 16 == 0 && al(preact, ldp) && al(dact_src, ldd) && al(residual, ldr) &&
                      (bias == nullptr || ((uintptr_t)bias & 15) == 0) && (lora_b == nullptr || (((uintptr_t)lora_b & 15) == 0 && N % 4 == 0));
     dim3 grid(gd_cdiv(M, 128) * gd_cdiv(N, 128), batch);
     const bool dma = (K * es) % 128 == 0;
     { const int cp = gd_knobs().gemm_cstore;
-      p.c_policy = (cp && (long)256 * ldc * gd_dtype_size(c_dtype) < 0x7fffffffL && !accumulate) ? cp : 0; }
+      p.c_policy = (cp && (long)256 * ldc * ccs < 0x7fffffffL && !accumulate) ? cp : 0; }
     p.probe = gd_probe_buffer();
     p.k_rot = gd_knobs().gemm_krot;
     const bool big = dma && N >= 256 && M >= 1024 && !gd_force_small_tiles();
@@ -775,9 +779,19 @@ extern "C" int gd_gemm_nt(const void* A, const void* W, void* C, int M, int N, i
         } else if (dact_src && dact == 1 && act == 0 && !preact && cb) pk = gemm_nt_persist_kernel<bf16, 1, 0, 0, false>;
         else if (dact_src && dact == 3 && act == 0 && !preact) pk = cb ? gemm_nt_persist_kernel<bf16, 3, 0, 0, false> : gemm_nt_persist_kernel<bf16, 3, 0, 0, true>;
         else if (residual && act == 0 && !preact) pk = cb ? gemm_nt_persist_kernel<bf16, 2, 0, 0, false> : gemm_nt_persist_kernel<bf16, 2, 0, 0, true>;
+        if (csplit) {
+            pk = nullptr;
+            if (!dact_src && !residual && act == 3 && preact) pk = gemm_nt_persist_kernel<bf16, 0, 1, 2, true, 0, true>;
+            else if (!dact_src && !residual && (act == 1 || act == 3) && !preact) pk = gemm_nt_persist_kernel<bf16, 0, 1, 0, true, 0, true>;
+            else if (dact_src && dact == 3 && act == 0 && !preact) pk = gemm_nt_persist_kernel<bf16, 3, 0, 0, true, 0, true>;
+        }
         // (the f32-output instantiations serve the tf32x engine: bf16 3K-wide split operands, fp32 C / preact / dact_src / residual)
     }
-    if (big && persist && pk && p.vec_epilogue && N % 8 == 0 && (!lora_t || lora_rt == 8) && 256 * ldmax * cs < 0x7fffffffL) {
+    const bool persist_ok = big && persist && pk && p.vec_epilogue && N % 8 == 0 && (!lora_t || lora_rt == 8) && 256 * ldmax * cs < 0x7fffffffL;
+    GD_REQUIRE(!csplit || (persist_ok && ldc >= 3L * N && batch == 1),
+               "gd_gemm_nt: split output (c_dtype 2) is served by the persistent kernel only: bf16 operands, M >= 1024, N >= 256, K %% 64 == 0, "
+               "ldc >= 3N, and the GELU(+derivative) or dact 3 epilogues (M=%d N=%d K=%d act=%d dact=%d)", M, N, K, act, dact);
+    if (persist_ok) {
         // (Tile quantisation — e.g. 1029 tiles of the N = 768 GEMMs on 256 CUs — costs far less than a round: the left-over
         // tiles run alone on an idle chip.  Handing them to the 128 x 128 kernel or cutting them into K slices was measured
         // slower / equal: DESIGN.md section 5.)

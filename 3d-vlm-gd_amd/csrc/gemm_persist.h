@@ -138,7 +138,9 @@ __device__ __forceinline__ void bst4_aux(__amdgpu_buffer_rsrc_t rs, int off, int
 // ANAT (anatomy builds, tools/bench_kernels.py gemm_anat; never the product path): 1 = no operand DMA in the main loop (the LDS-read +
 // MFMA + barrier loop alone), 2 = no MFMAs (DMA + LDS reads + barriers), 3 = neither LDS reads nor MFMAs (the DMA ring alone), 4 = no C stores (everything else of the epilogue stays).
 // Instantiated only in -DGD_GEMM_ANATOMY builds (gemm.hip); round-3 results: profiles/r03_gemm_anatomy.txt.
-template <typename T, int SIDE, int ACT, int PREACT, bool CF32, int ANAT = 0>
+// CSPLIT (with CF32): C leaves as the three-plane bf16 operand split of the f32 result — [hi | lo | hi] over 3N columns of row stride
+// ldc (gd_split3 'a' layout), the A operand of the next tf32x GEMM — instead of f32 followed by a gd_split3 pass; side / preact stay f32.
+template <typename T, int SIDE, int ACT, int PREACT, bool CF32, int ANAT = 0, bool CSPLIT = false>
 __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
     constexpr int NWN = 4, WMT = 8, NW = 8, BM = 256, BN = 256;
     constexpr int ABYTES = BM * 128, STAGE = (BM + BN) * 128, APW = BM / 8 / NW, BPW = BN / 8 / NW;
@@ -159,8 +161,10 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
     const char* Wb = (const char*)p.W + batch * p.sW * (long)sizeof(T);
     const long lda_b = p.lda * (long)sizeof(T), ldw_b = p.ldw * (long)sizeof(T);
     const int nk = p.K * (int)sizeof(T) / 128;
+    static_assert(!CSPLIT || CF32, "split output comes from f32 values");
     constexpr int cdt = CF32 ? GD_F32 : GD_BF16, csz = CF32 ? 4 : 2;
-    char* Cb = (char*)p.C + batch * p.sC * (long)csz;
+    constexpr int ccsz = CSPLIT ? 2 : csz;   // element size of C itself (preact / side tensors keep csz / ssz)
+    char* Cb = (char*)p.C + batch * p.sC * (long)ccsz;
     const bool lora = p.lora_t != nullptr;
     const float ia = 1.0f / p.alpha;
 
@@ -323,9 +327,9 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
             return __builtin_amdgcn_make_buffer_rsrc((void*)((char*)base + (long)ctm * BM * ld * es), (short)0,
                                                      (int)min((long)0x7fffffff, (long)vrows * ld * es), 0x00020000);
         };
-        const __amdgpu_buffer_rsrc_t crs = mk(Cb, p.ldc, csz);
-        const __amdgpu_buffer_rsrc_t prs = mk(PREACT ? p.preact : Cb, PREACT ? p.ldp : p.ldc, csz);
-        const __amdgpu_buffer_rsrc_t srs = mk(pre ? side_src : (const void*)Cb, pre ? side_ld : p.ldc, pre ? ssz : csz);
+        const __amdgpu_buffer_rsrc_t crs = mk(Cb, p.ldc, ccsz);
+        const __amdgpu_buffer_rsrc_t prs = mk(PREACT ? p.preact : Cb, PREACT ? p.ldp : p.ldc, PREACT ? csz : ccsz);
+        const __amdgpu_buffer_rsrc_t srs = mk(pre ? side_src : (const void*)Cb, pre ? side_ld : p.ldc, pre ? ssz : ccsz);
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
         if (p.bias) {
             const unsigned biasaddr = lds_off(smem + BIAS_OFF) + cslot * BN * 4 + (wn * 64 + fr * 4) * 4;
@@ -340,7 +344,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
         // byte offsets of item 0; item (i, r) adds the SCALAR (16 i + r) * ld * size — one v_add_u32 per access instead of a
         // per-item 32-bit multiply (quarter rate) + select.  A lane past N keeps OOB as its base: OOB + (< 2^31) stays >= every
         // num_records as an unsigned offset.
-        const int cbase = cok ? (rloc * ldc_i + col0) * csz : OOB;
+        const int cbase = cok ? (rloc * ldc_i + col0) * ccsz : OOB;
         const int pbase = cok ? (rloc * ldp_i + col0) * csz : OOB;
         const int sbase = cok ? (rloc * lds_i + col0) * ssz : OOB;
         constexpr int NITEM = 4 * WMT;   // idx = 4 i + r
@@ -371,7 +375,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
         constexpr int DMA_AT = pre ? NITEM - SDEP : 0;
         t += gridDim.x;
         const bool more = t < ntiles;
-        after = (NITEM - DMA_AT) * (1 + (PREACT ? 1 : 0));   // epilogue VMEM instructions younger than the stage-1 DMA
+        after = (NITEM - DMA_AT) * ((CSPLIT ? 3 : 1) + (PREACT ? 1 : 0));   // epilogue VMEM instructions younger than the stage-1 DMA
 #pragma unroll
         for (int idx = 0; idx < NITEM; ++idx) {
             const int i = idx >> 2, r = idx & 3;
@@ -384,7 +388,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
                 asm volatile("" ::: "memory");   // nothing younger may be hoisted above the DMA: `after` counts on it
                 GD_PROBE({ const unsigned long long c = __builtin_amdgcn_s_memtime(); pd += c - pc0; pc0 = c; })
             }
-            const int coff = cbase + (i * 16 + r) * csz * ldc_i, poff = pbase + (i * 16 + r) * csz * ldp_i;
+            const int coff = cbase + (i * 16 + r) * ccsz * ldc_i, poff = pbase + (i * 16 + r) * csz * ldp_i;
             float v[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = fmaf(p.alpha, acc[i][j][r], bv[j]);
@@ -417,6 +421,15 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
                     if (SIDE == 3) v[j] *= x[j];
                 }
             }
+            if (CSPLIT) {
+                float lo[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) lo[j] = v[j] - (float)(bf16)v[j];
+                const int plane = p.N * 2;
+                bst4_aux<GD_PERSIST_STORE_AUX>(crs, coff, GD_BF16, v);
+                bst4_aux<GD_PERSIST_STORE_AUX>(crs, coff + plane, GD_BF16, lo);
+                bst4_aux<GD_PERSIST_STORE_AUX>(crs, coff + 2 * plane, GD_BF16, v);
+            } else
             if (ANAT != 4) bst4_aux<GD_PERSIST_STORE_AUX>(crs, coff, cdt, v);
             else asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
             if (pre && idx + SDEP < NITEM) side_load(idx + SDEP);

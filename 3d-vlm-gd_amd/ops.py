@@ -59,12 +59,15 @@ def time_on_stream(fn, warm=2, iters=5):
 
 
 def gemm_nt(a, w, out=None, *, out_dtype=None, alpha=1.0, bias=None, lora_t=None, lora_b=None, preact=None,
-            act=0, dact_src=None, dact=0, residual=None, accumulate=False):
+            act=0, dact_src=None, dact=0, residual=None, accumulate=False, out_split=False):
     """out[M,N] = epilogue(alpha * a[M,K] @ w[N,K]^T).  a, w: same dtype (f32 | bf16), last dim contiguous.
     Batched when a is 3-D ([B,M,K] x [B,N,K] -> [B,M,N], no epilogue tensors).
     Epilogue order: +bias[N] (f32) -> +lora_t[M,r] @ lora_b[r,N] (f32) -> store preact -> act (1 GELU, 2 ReLU,
     3 GELU with `preact` receiving GELU'(v)) -> *act'(dact_src) (1 dGELU(pre), 2 src>0, 3 v *= src) -> +residual
-    -> +out (accumulate)."""
+    -> +out (accumulate).
+    out_split: the f32 result leaves as its bf16 operand split [M, 3N] = [hi | lo | hi] (what split3(out, "a") would give: the left
+    operand of the next tf32x GEMM) without the f32 tensor ever reaching memory; preact / dact_src stay f32.  split_out_ok() says
+    whether a shape is served."""
     _req(a.is_cuda and w.is_cuda and a.dtype == w.dtype, "gemm_nt: a and w must be CUDA tensors of one dtype")
     _req(a.stride(-1) == 1 and w.stride(-1) == 1, "gemm_nt: a and w must be contiguous along K")
     batched = a.dim() == 3
@@ -78,14 +81,18 @@ def gemm_nt(a, w, out=None, *, out_dtype=None, alpha=1.0, bias=None, lora_t=None
         _req(w.shape[1] == K, f"gemm_nt: K mismatch {a.shape} x {w.shape}")
         sA = sW = 0
         lda, ldw = a.stride(0), w.stride(0)
+    if out_split:
+        _req(out is None and not batched and a.dtype == torch.bfloat16, "gemm_nt: out_split takes bf16 (split) operands, 2-D, and allocates its output")
+        out = torch.empty(M, 3 * N, dtype=torch.bfloat16, device=a.device)
     if out is None:
         odt = out_dtype or a.dtype
         out = torch.empty((B, M, N) if batched else (M, N), dtype=odt, device=a.device)
     _req(out.stride(-1) == 1, "gemm_nt: out must be contiguous along N")
-    cdt = dtype_code(out)
+    cdt = F32X3 if out_split else dtype_code(out)
+    sdt = torch.float32 if out_split else out.dtype
     for t, name in ((preact, "preact"), (dact_src, "dact_src"), (residual, "residual")):
         if t is not None:
-            _req(t.dtype == out.dtype and t.stride(-1) == 1 and tuple(t.shape) == (M, N), f"gemm_nt: bad {name}")
+            _req(t.dtype == sdt and t.stride(-1) == 1 and tuple(t.shape) == (M, N), f"gemm_nt: bad {name}")
     for t, name in ((bias, "bias"), (lora_t, "lora_t"), (lora_b, "lora_b")):
         if t is not None:
             _req(t.dtype == torch.float32 and t.is_contiguous(), f"gemm_nt: {name} must be contiguous fp32")
@@ -107,6 +114,11 @@ def gemm_nt(a, w, out=None, *, out_dtype=None, alpha=1.0, bias=None, lora_t=None
         _PROFILER.records.append((e0, e1, 2.0 * M * N * K * B, (M, N, K, B, f"{tag}a{act}{'+' if accumulate else ''}", str(out.dtype)[6:], str(a.dtype)[6:])))
     check(rc, "gd_gemm_nt")
     return out
+
+
+def split_out_ok(M, N, K3):
+    """Shapes gemm_nt(..., out_split=True) serves (the persistent kernel's: gd_gemm_nt, c_dtype GD_F32X3)."""
+    return M >= 1024 and N >= 256 and N % 8 == 0 and K3 % 64 == 0
 
 
 def split3(x, which):

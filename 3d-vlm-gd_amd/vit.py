@@ -35,7 +35,8 @@ def _mm(x, plan, key, xs=None, **kw):
     (plan['x3']) and the activation is split on the way in (xs: its split, when the caller already has it) — three bf16 MFMA products
     per term, fp32 accumulation / output / epilogue."""
     if plan.get("x3"):
-        kw.setdefault("out_dtype", torch.float32)
+        if not kw.get("out_split"):
+            kw.setdefault("out_dtype", torch.float32)
         return ops.gemm_nt(xs if xs is not None else ops.split3(x, "a"), plan[key], **kw)
     return ops.gemm_nt(x, plan[key], **kw)
 
@@ -172,8 +173,10 @@ class _BlockFn(torch.autograd.Function):
         x1 = _mm(o, plan, "wproj", bias=plan["bproj"], residual=x)
         y2, mean2, rstd2 = ops.layernorm_fwd(x1, plan["ln2_w"], plan["ln2_b"], plan["eps2"], save_stats=need)
         pre = torch.empty(M, plan["w1"].shape[0], dtype=T, device=x.device) if need else None
-        h = _mm(y2, plan, "w1", bias=plan["b1"], act=3, preact=pre)   # pre <- GELU'(fc1 output): all the backward needs
-        x2 = _mm(h, plan, "w2", bias=plan["b2"], residual=x1)
+        # tf32x: fc1 writes GELU(.) directly as the split left operand of fc2 (no f32 [M, 4D] round trip + split pass)
+        hs = plan["x3"] and ops.split_out_ok(M, plan["w1"].shape[0], plan["w1"].shape[1])
+        h = _mm(y2, plan, "w1", bias=plan["b1"], act=3, preact=pre, out_split=hs)   # pre <- GELU'(fc1 output): all the backward needs
+        x2 = _mm(None if hs else h, plan, "w2", xs=h if hs else None, bias=plan["b2"], residual=x1)
         out, hd = x2, None
         if down is not None:
             down_T = tw["down_T"] if tw is not None else down.detach().to(T).contiguous()
@@ -220,8 +223,9 @@ class _BlockFn(torch.autograd.Function):
                 dx2 = ops.gemm_nt(dhp, down_tT, residual=dout)
             g_up = ops.gemm_tn(dout, hd, out=z_up)                                                # [D, 64]
             g_down = ops.gemm_tn(dhp, x2, out=z_down)                                             # [64, D]
-        dpre = _mm(dx2, plan, "w2_t", dact_src=pre, dact=3)                                       # [M, 4D] (x stored GELU')
-        dy2 = _mm(dpre, plan, "w1_t")
+        hs = plan["x3"] and ops.split_out_ok(dx2.shape[0], plan["w2_t"].shape[0], plan["w2_t"].shape[1])
+        dpre = _mm(dx2, plan, "w2_t", dact_src=pre, dact=3, out_split=hs)                         # [M, 4D] (x stored GELU')
+        dy2 = _mm(None if hs else dpre, plan, "w1_t", xs=dpre if hs else None)
         del dpre
         dx1 = ops.layernorm_bwd(dy2, x1, plan["ln2_w"], mean2, rstd2, dres=dx2)
         do = _mm(dx1, plan, "wproj_t")

@@ -21,7 +21,7 @@ extern "C" {
 
 #define GD_F32 0
 #define GD_BF16 1
-#define GD_F32X3 2   /* gd_attention_{fwd,bwd} only: fp32 tensors, every product as three bf16 MFMAs of (hi, lo) splits (TF32-class; see gd_split3) */
+#define GD_F32X3 2   /* gd_attention_{fwd,bwd}: fp32 tensors, every product as three bf16 MFMAs of (hi, lo) splits (TF32-class; see gd_split3); gd_gemm_nt c_dtype: split output */
 
 const char* gd_last_error(void);
 int gd_abi_version(void);
@@ -42,7 +42,10 @@ int gd_gemm_phase_probe(int enable, unsigned long long* out6);
  * (timm VisionTransformer qkv/proj/fc1/fc2, utils/model.py:57-71 LoRA, :7-25 Adapter; src/finetune_timm_vggt.py:516-517).
  * Epilogue order: +bias[N](f32) -> +lora_t[M,rt].lora_b[rt,N](f32, rt<=8) -> store preact -> act(1 GELU erf,2 ReLU,
  * 3 GELU with preact receiving GELU'(v) instead of v) -> *act'(dact_src) (1 dGELU(src), 2 src>0, 3 v*=src: the stored
- * derivative of act 3) -> +residual -> +C (accumulate).  batch>1: grid over batch strides. */
+ * derivative of act 3) -> +residual -> +C (accumulate).  batch>1: grid over batch strides.
+ * c_dtype GD_F32X3 (tf32x engine): the f32 result leaves as its bf16 operand split C[M, 3N] = [hi | lo | hi] (gd_split3 which 0,
+ * ldc >= 3N bf16 elements) — the left operand of the next split GEMM — with preact / dact_src f32; served for bf16 (split) operands,
+ * M >= 1024, N >= 256, K % 64 == 0 and the act 1|3 (+preact) or dact 3 epilogues; anything else is an error, not a reroute. */
 int gd_gemm_nt(const void* A, const void* W, void* C, int M, int N, int K, long lda, long ldw, long ldc,
                int batch, long sA, long sW, long sC, int ab_dtype, int c_dtype, float alpha,
                const float* bias, const float* lora_t, const float* lora_b, int lora_rt, void* preact, long ldp,

@@ -117,6 +117,48 @@ def test_gemm_nt_persistent_f32_epilogue_tensors(M, N, K):
     assert out.dtype == f32 and rel_err(out, gelu(y.detach())) < 1e-5 and rel_err(dg, y.grad) < 1e-5
 
 
+def _split_matches(got, f):
+    """got [M, 3N] bf16 is the [hi | lo | hi] split of f [M, N] f32: the two hi planes are identical, hi is bf16(f) up to the last-ulp
+    differences two instantiations of one fp32 epilogue may have (packed vs scalar FMA contraction: <= 1 f32 ulp, which moves a bf16
+    rounding on < 1 % of the values), and hi + lo reconstructs f to 2^-16 |f| (a split that lost its lo plane would be at 2^-9)."""
+    N = f.shape[1]
+    hi, lo, hi2 = got[:, :N], got[:, N:2 * N], got[:, 2 * N:]
+    assert torch.equal(hi, hi2)
+    assert float((hi != f.bfloat16()).float().mean()) < 0.01
+    err = (hi.double() + lo.double() - f.double()).abs()
+    assert bool((err <= f.double().abs() * 2.0 ** -16 + 1e-30).all()), float((err / f.double().abs().clamp_min(1e-30)).max())
+
+
+@pytest.mark.parametrize("M,N,K", [(1300, 320, 192), (2048, 512, 384)])
+def test_gemm_nt_split_output_equals_split_of_f32_output(M, N, K):
+    """out_split (c_dtype GD_F32X3): the epilogue writes the [hi | lo | hi] operand split of its f32 result — what gd_split3 of the
+    f32-output call with the same epilogue gives (GELU, GELU + stored derivative, dact 3), ragged last tiles included; shapes the
+    persistent kernel does not serve are refused, never silently rerouted."""
+    from gd_amd import ops
+    from gd_amd._lib import GdHipError
+    dt, f32 = torch.bfloat16, torch.float32
+    a, w = _mk((M, K), dt, 51), _mk((N, K), dt, 52)
+    bias, src = _mk((N,), f32, 53), _mk((M, N), f32, 54)
+    assert ops.split_out_ok(M, N, K)
+    got = ops.gemm_nt(a, w, bias=bias, act=1, out_split=True)
+    assert got.shape == (M, 3 * N) and got.dtype == dt
+    _split_matches(got, ops.gemm_nt(a, w, out_dtype=f32, bias=bias, act=1))
+    d0, d1 = torch.empty(M, N, dtype=f32, device="cuda"), torch.empty(M, N, dtype=f32, device="cuda")
+    f = ops.gemm_nt(a, w, out_dtype=f32, bias=bias, act=3, preact=d0)
+    _split_matches(ops.gemm_nt(a, w, bias=bias, act=3, preact=d1, out_split=True), f)
+    assert rel_err(d1, d0) < 1e-6
+    _split_matches(ops.gemm_nt(a, w, dact_src=src, dact=3, out_split=True), ops.gemm_nt(a, w, out_dtype=f32, dact_src=src, dact=3))
+    # and the product it feeds: split-out . split(w2)^T against the fp64 product of the f32 tensors
+    w2 = _mk((256, N), f32, 55)
+    h3 = ops.gemm_nt(a, w, bias=bias, act=1, out_split=True)
+    hf = ops.gemm_nt(a, w, out_dtype=f32, bias=bias, act=1)
+    assert rel_err(ops.gemm_nt(h3, ops.split3(w2, "w"), out_dtype=f32), hf.double() @ w2.double().t()) < 2e-5
+    with pytest.raises(GdHipError):
+        ops.gemm_nt(a[:512], w, bias=bias, act=1, out_split=True)       # M < 1024: not a persistent-kernel shape
+    with pytest.raises(GdHipError):
+        ops.gemm_nt(a, w, bias=bias, out_split=True)                    # no plain-epilogue split instantiation
+
+
 def test_gemm_nt_persistent_ragged_n_and_batched():
     """persistent kernel with a half-empty last column tile (N = 320), and batched with fp32 output (the cost-volume
     backward's G.b products: grid.y = batch)."""
