@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libgd_hip.so")
 _lib = None
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 3
 
 c_int, c_long, c_float, c_void_p, c_size_t = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
 
@@ -24,6 +24,12 @@ SIGNATURES = {
                            c_int, c_long, c_long, c_long, c_int, c_int, c_float,
                            c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_long, c_int,
                            c_void_p, c_long, c_int, c_void_p, c_long, c_int, c_void_p]),
+    "gd_gemm_nt_scaled": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_long, c_long,
+                                  c_int, c_long, c_long, c_long, c_int, c_int, c_float, c_void_p,
+                                  c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_long, c_int,
+                                  c_void_p, c_long, c_int, c_void_p, c_long, c_int, c_void_p]),
+    "gd_cast_f16": (c_int, [c_void_p, c_void_p, c_long, c_int, c_long, c_float, c_void_p, c_void_p]),
+    "gd_amax_scale": (c_int, [c_void_p, c_long, c_int, c_long, c_float, c_void_p, c_void_p]),
     "gd_gemm_tn": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_long, c_long,
                            c_int, c_long, c_long, c_long, c_int, c_int, c_float, c_void_p]),
     "gd_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_long,
@@ -162,6 +168,8 @@ def dtype_code(t):
         return F32
     if t.dtype == torch.bfloat16:
         return BF16
+    if t.dtype == torch.float16:
+        return F16
     raise GdHipError(f"unsupported dtype {t.dtype}")
 
 

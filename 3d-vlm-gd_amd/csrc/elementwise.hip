@@ -993,6 +993,64 @@ extern "C" int gd_split3(const float* in, void* out, long rows, int K, long ld_i
     return 0;
 }
 
+// ---- fp16 operands of the tf32h engine: x -> f16(sat(x * scale)); the scale of a GRADIENT tensor is a power of two taken from its own
+// maximum on the device (gd_amax_scale), carried to the consuming GEMM as a device scalar (gd_gemm_nt_scaled) — no host round trip.
+__global__ __launch_bounds__(256) void cast_f16_kernel(const float* in, f16* out, long rows, int K, long ld_in, float scale, const float* scale_dev) {
+    const int kv = K / 8;
+    const long total = rows * kv;
+    const float sc = scale_dev ? scale * *scale_dev : scale;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long r = idx / kv;
+        const int c = (int)(idx - r * kv) * 8;
+        const f32x4 a = *(const f32x4*)(in + r * ld_in + c), b = *(const f32x4*)(in + r * ld_in + c + 4);
+        f16x8 h;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { h[k] = from_f32<f16>(a[k] * sc); h[4 + k] = from_f32<f16>(b[k] * sc); }
+        *(f16x8*)(out + r * (long)K + c) = h;
+    }
+}
+__global__ __launch_bounds__(256) void amax_kernel(const float* in, long rows, int K, long ld_in, unsigned* bits) {
+    const int kv = K / 4;
+    const long total = rows * kv;
+    float m = 0.f;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long r = idx / kv;
+        const int c = (int)(idx - r * kv) * 4;
+        const f32x4 a = *(const f32x4*)(in + r * ld_in + c);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(a[0]), fabsf(a[1]))), fmaxf(fabsf(a[2]), fabsf(a[3])));      // fmaxf drops NaNs
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(bits, __builtin_bit_cast(unsigned, m));                  // non-negative floats order like their bit patterns
+}
+// s = the power of two with  target / 2 < amax * s <= target  (1 for an all-zero or non-finite tensor); out = {s, 1 / s}
+__global__ void amax_scale_kernel(const unsigned* bits, float target, float* out) {
+    const float amax = __builtin_bit_cast(float, *bits);
+    float s = 1.0f;
+    if (amax > 0.f && amax < 3.0e38f) s = exp2f(floorf(log2f(target / amax)));
+    s = fminf(fmaxf(s, 1.0f / 16777216.0f / 16777216.0f), 16777216.0f * 16777216.0f * 16777216.0f);  // 2^-48 .. 2^72: s and 1/s stay normal floats
+    out[0] = s;
+    out[1] = 1.0f / s;
+}
+
+extern "C" int gd_cast_f16(const float* in, void* out, long rows, int K, long ld_in, float scale, const float* scale_dev, void* stream) {
+    GD_REQUIRE(in && out && rows > 0 && K > 0 && K % 8 == 0 && ld_in >= K && ld_in % 4 == 0, "gd_cast_f16: bad arguments (K must be a multiple of 8, ld_in of 4)");
+    GD_REQUIRE(((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 15) == 0, "gd_cast_f16: in / out must be 16-byte aligned");
+    hipLaunchKernelGGL(cast_f16_kernel, dim3(ew_blocks(rows * (K / 8))), dim3(256), 0, (hipStream_t)stream, in, (f16*)out, rows, K, ld_in, scale, scale_dev);
+    GD_LAUNCH_OK();
+    return 0;
+}
+
+extern "C" int gd_amax_scale(const float* in, long rows, int K, long ld_in, float target, float* scale3, void* stream) {
+    GD_REQUIRE(in && scale3 && rows > 0 && K > 0 && K % 4 == 0 && ld_in >= K && ld_in % 4 == 0 && target > 0.f, "gd_amax_scale: bad arguments");
+    GD_REQUIRE(((uintptr_t)in & 15) == 0, "gd_amax_scale: in must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(scale3 + 2, 0, 4, st) != hipSuccess) { gd_set_error("gd_amax_scale: memset failed"); return -2; }
+    hipLaunchKernelGGL(amax_kernel, dim3(ew_blocks(rows * (K / 4))), dim3(256), 0, st, in, rows, K, ld_in, (unsigned*)(scale3 + 2));
+    hipLaunchKernelGGL(amax_scale_kernel, dim3(1), dim3(1), 0, st, (const unsigned*)(scale3 + 2), target, scale3);
+    GD_LAUNCH_OK();
+    return 0;
+}
+
 extern "C" int gd_tap_mean_norm_fwd(const void* const* grids, int ngrid, long bstride, int prefix, void* out, float* inv_norm, int B,
                                     int hw, int D, int dtype, void* stream) {
     GD_REQUIRE(ngrid >= 1 && ngrid <= 4 && B > 0 && hw > 0 && D > 0 && D % 8 == 0 && inv_norm != nullptr, "gd_tap_mean_norm_fwd: bad arguments");

@@ -8,6 +8,9 @@
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef _Float16 f16;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
@@ -33,23 +36,27 @@ void gd_set_error(const char* fmt, ...);
         }                                                                                \
     } while (0)
 
-__host__ __device__ static inline int gd_dtype_size(int dt) { return dt == GD_BF16 ? 2 : 4; }
+__host__ __device__ static inline int gd_dtype_size(int dt) { return (dt == GD_BF16 || dt == GD_F16) ? 2 : 4; }
 static inline int gd_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- scalar conversions ----
 template <typename T> __device__ __forceinline__ float to_f32(T v);
 template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ float to_f32<bf16>(bf16 v) { return (float)v; }
+template <> __device__ __forceinline__ float to_f32<f16>(f16 v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf16)v; }
+// fp16 has 5 exponent bits: saturate instead of producing inf (the tf32h engine's operands; see gd_cast_f16)
+__device__ __forceinline__ float f16_sat(float v) { return __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f); }
+template <> __device__ __forceinline__ f16 from_f32<f16>(float v) { return (f16)f16_sat(v); }
 
 // load/store one element of a runtime-typed buffer (dt = GD_F32 / GD_BF16)
 __device__ __forceinline__ float ld_rt(const void* p, long i, int dt) {
-    return dt == GD_BF16 ? (float)((const bf16*)p)[i] : ((const float*)p)[i];
+    return dt == GD_BF16 ? (float)((const bf16*)p)[i] : dt == GD_F16 ? (float)((const f16*)p)[i] : ((const float*)p)[i];
 }
 __device__ __forceinline__ void st_rt(void* p, long i, int dt, float v) {
-    if (dt == GD_BF16) ((bf16*)p)[i] = (bf16)v; else ((float*)p)[i] = v;
+    if (dt == GD_BF16) ((bf16*)p)[i] = (bf16)v; else if (dt == GD_F16) ((f16*)p)[i] = from_f32<f16>(v); else ((float*)p)[i] = v;
 }
 
 // ---- wave-level reductions (64 lanes) on DPP (VALU cross-lane operands; no LDS-crossbar ds_bpermute round trips) ----
@@ -127,6 +134,14 @@ template <> struct Mma<bf16> {
     typedef bf16x8 Frag;
     static __device__ __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+// fp16 operands (11-bit significands = TF32's; 2.5 PFLOP/s dense like bf16): the tf32h engine's matrix products
+template <> struct Mma<f16> {
+    static constexpr int KC = 32;
+    typedef f16x8 Frag;
+    static __device__ __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
     }
 };
 template <> struct Mma<float> {

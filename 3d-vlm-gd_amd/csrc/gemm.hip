@@ -19,6 +19,7 @@ struct GemmNtParams {
     long sA, sW, sC;                 // batch strides in elements (grid.y = batch)
     int c_dtype;                     // dtype of C / preact / dact_src / residual
     float alpha;
+    const float* alpha_dev;          // device scalar multiplied into alpha (gd_gemm_nt_scaled), or null
     const float* bias;               // [N]
     const float* lora_t; const float* lora_b; int lora_rt;   // v += sum_r t[m,r] * b[r,n]
     void* preact; long ldp;          // store v before the activation
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(256) void gemm_nt_regstage_kernel(GemmNtParams p) {
             for (int j = 0; j < 4; ++j) {
                 const int col = tn * BN + wn * 64 + j * 16 + (lane & 15);
                 if (col >= p.N) continue;
-                float v = p.alpha * acc[i][j][r];
+                float v = (p.alpha_dev ? p.alpha * *p.alpha_dev : p.alpha) * acc[i][j][r];
                 if (p.bias) v += p.bias[col];
                 if (p.lora_t) {
 #pragma unroll
@@ -104,6 +105,10 @@ __device__ __forceinline__ void ld8_rt(const void* p, long i, int dt, float (&o)
         const bf16x8 v = *(const bf16x8*)((const bf16*)p + i);
 #pragma unroll
         for (int k = 0; k < 8; ++k) o[k] = (float)v[k];
+    } else if (dt == GD_F16) {
+        const f16x8 v = *(const f16x8*)((const f16*)p + i);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (float)v[k];
     } else {
         const f32x4 a = *(const f32x4*)((const float*)p + i), b = *(const f32x4*)((const float*)p + i + 4);
 #pragma unroll
@@ -113,6 +118,11 @@ __device__ __forceinline__ void ld8_rt(const void* p, long i, int dt, float (&o)
 __device__ __forceinline__ void st8_rt(void* p, long i, int dt, const float (&v)[8]) {
     if (dt == GD_BF16) {
         *(bf16x8*)((bf16*)p + i) = bf16x8{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
+    } else if (dt == GD_F16) {
+        f16x8 h;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) h[k] = from_f32<f16>(v[k]);
+        *(f16x8*)((f16*)p + i) = h;
     } else {
         *(f32x4*)((float*)p + i) = f32x4{v[0], v[1], v[2], v[3]};
         *(f32x4*)((float*)p + i + 4) = f32x4{v[4], v[5], v[6], v[7]};
@@ -128,6 +138,11 @@ __device__ __forceinline__ void st8_wt(__amdgpu_buffer_rsrc_t rs, int byte_off, 
     if (dt == GD_BF16) {
         const bf16x8 b = bf16x8{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, b), rs, byte_off, 0, 16);
+    } else if (dt == GD_F16) {
+        f16x8 h;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) h[k] = from_f32<f16>(v[k]);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h), rs, byte_off, 0, 16);
     } else {
         const f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, a), rs, byte_off, 0, 16);
@@ -176,7 +191,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(GemmNtParams p)
         constexpr int KPL = sizeof(Frag) / sizeof(T);
         const float* lT = (const float*)(smem + 2 * STAGE);
         const float* lB = lT + BM * 8;
-        const float ia = 1.0f / p.alpha;
+        const float ia = 1.0f / (p.alpha_dev ? p.alpha * *p.alpha_dev : p.alpha);
         const bool live = KPL * g < 8;
         Frag bf[4];
 #pragma unroll
@@ -198,6 +213,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(GemmNtParams p)
     }
 
     // ---- epilogue: 64-row passes through LDS (fp32), then 8-column vectors per thread ----
+    const float alpha = p.alpha_dev ? p.alpha * *p.alpha_dev : p.alpha;
     const int cdt = p.c_dtype;
     char* Cb = (char*)p.C + batch * p.sC * (long)gd_dtype_size(cdt);
     float* se = (float*)smem;  // [64][EPLD]
@@ -254,7 +270,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(GemmNtParams p)
             {
                 const f32x4 x0 = *(const f32x4*)(se + lr * EPLD + cc), x1 = *(const f32x4*)(se + lr * EPLD + cc + 4);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { v[k] = p.alpha * x0[k]; v[4 + k] = p.alpha * x1[k]; }
+                for (int k = 0; k < 4; ++k) { v[k] = alpha * x0[k]; v[4 + k] = alpha * x1[k]; }
             }
             if (vec && col0 + 8 <= p.N) {
                 if (p.bias) {
@@ -704,19 +720,24 @@ __global__ __launch_bounds__(512) void gemm_nt_skinny_kernel(GemmNtParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = row0 + 4 * g + r;
-            if (row < p.M) ((TC*)p.C)[(long)row * p.ldc + c] = from_f32<TC>((acc0[r] + acc1[r]) * p.alpha);
+            if (row < p.M) ((TC*)p.C)[(long)row * p.ldc + c] = from_f32<TC>((acc0[r] + acc1[r]) * (p.alpha_dev ? p.alpha * *p.alpha_dev : p.alpha));
         }
     }
 }
 
-extern "C" int gd_gemm_nt(const void* A, const void* W, void* C, int M, int N, int K, long lda, long ldw, long ldc,
-                          int batch, long sA, long sW, long sC, int ab_dtype, int c_dtype, float alpha,
-                          const float* bias, const float* lora_t, const float* lora_b, int lora_rt, void* preact,
-                          long ldp, int act, const void* dact_src, long ldd, int dact, const void* residual, long ldr,
-                          int accumulate, void* stream) {
+static int gemm_nt_impl(const void* A, const void* W, void* C, int M, int N, int K, long lda, long ldw, long ldc,
+                        int batch, long sA, long sW, long sC, int ab_dtype, int c_dtype, float alpha, const float* alpha_dev,
+                        const float* bias, const float* lora_t, const float* lora_b, int lora_rt, void* preact,
+                        long ldp, int act, const void* dact_src, long ldd, int dact, const void* residual, long ldr,
+                        int accumulate, void* stream) {
     GD_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0, "gd_gemm_nt: bad shape M=%d N=%d K=%d batch=%d", M, N, K, batch);
-    GD_REQUIRE(ab_dtype == GD_F32 || ab_dtype == GD_BF16, "gd_gemm_nt: bad ab_dtype %d", ab_dtype);
-    GD_REQUIRE(c_dtype == GD_F32 || c_dtype == GD_BF16 || c_dtype == GD_F32X3, "gd_gemm_nt: bad c_dtype %d", c_dtype);
+    GD_REQUIRE(ab_dtype == GD_F32 || ab_dtype == GD_BF16 || ab_dtype == GD_F16, "gd_gemm_nt: bad ab_dtype %d", ab_dtype);
+    GD_REQUIRE(c_dtype == GD_F32 || c_dtype == GD_BF16 || c_dtype == GD_F32X3 || c_dtype == GD_F16, "gd_gemm_nt: bad c_dtype %d", c_dtype);
+    // fp16 operands (tf32h engine): C / preact / dact_src / residual are f32, or C alone is fp16 (c_dtype GD_F16: the operand of the next
+    // product, saturated at +-65504) with f32 preact / dact_src / residual; bf16 operands never write fp16
+    GD_REQUIRE((c_dtype != GD_F16 && (ab_dtype != GD_F16 || c_dtype == GD_F32)) || (ab_dtype == GD_F16 && c_dtype == GD_F16),
+               "gd_gemm_nt: fp16 operands write f32 or fp16; fp16 results come from fp16 operands only (ab_dtype %d, c_dtype %d)", ab_dtype, c_dtype);
+    GD_REQUIRE(c_dtype != GD_F32X3 || ab_dtype == GD_BF16, "gd_gemm_nt: split output takes bf16 (split) operands");
     // c_dtype GD_F32X3: C is the [hi | lo | hi] bf16 operand split of the f32 result (row stride ldc >= 3N bf16 elements; the A
     // operand of the next tf32x GEMM); preact / dact_src / residual are f32.  Persistent-kernel shapes only (checked below).
     const bool csplit = c_dtype == GD_F32X3;
@@ -732,11 +753,12 @@ extern "C" int gd_gemm_nt(const void* A, const void* W, void* C, int M, int N, i
                "gd_gemm_nt: batched calls take no epilogue tensors");
     GemmNtParams p;
     p.A = A; p.W = W; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc;
-    p.sA = sA; p.sW = sW; p.sC = sC; p.c_dtype = c_dtype; p.alpha = alpha; p.bias = bias;
+    p.sA = sA; p.sW = sW; p.sC = sC; p.c_dtype = c_dtype; p.alpha = alpha; p.alpha_dev = alpha_dev; p.bias = bias;
     p.lora_t = lora_t; p.lora_b = lora_b; p.lora_rt = lora_rt; p.preact = preact; p.ldp = ldp; p.act = act == 3 ? 1 : act; p.act_deriv = act == 3;
     p.dact_src = dact_src; p.ldd = ldd; p.dact = dact_src ? dact : 0; p.residual = residual; p.ldr = ldr;
     p.accumulate = accumulate;
-    const int cs = gd_dtype_size(c_dtype), ccs = csplit ? 2 : cs;
+    const bool chalf = c_dtype == GD_F16;         // fp16 C beside f32 preact / dact_src / residual
+    const int cs = chalf ? 4 : gd_dtype_size(c_dtype), ccs = (csplit || chalf) ? 2 : cs;
     auto al = [&](const void* q, long ld) { return q == nullptr || ((((uintptr_t)q) & 15) == 0 && (ld * cs) % 16 == 0); };
     p.vec_epilogue = ((uintptr_t)C & 15) == 0 && (ldc * ccs) % 16 == 0 && (sC * ccs) % 16 == 0 && al(preact, ldp) && al(dact_src, ldd) && al(residual, ldr) &&
                      (bias == nullptr || ((uintptr_t)bias & 15) == 0) && (lora_b == nullptr || (((uintptr_t)lora_b & 15) == 0 && N % 4 == 0));
@@ -781,16 +803,28 @@ extern "C" int gd_gemm_nt(const void* A, const void* W, void* C, int M, int N, i
         else if (residual && act == 0 && !preact) pk = cb ? gemm_nt_persist_kernel<bf16, 2, 0, 0, false> : gemm_nt_persist_kernel<bf16, 2, 0, 0, true>;
         if (csplit) {
             pk = nullptr;
-            if (!dact_src && !residual && act == 3 && preact) pk = gemm_nt_persist_kernel<bf16, 0, 1, 2, true, 0, true>;
-            else if (!dact_src && !residual && (act == 1 || act == 3) && !preact) pk = gemm_nt_persist_kernel<bf16, 0, 1, 0, true, 0, true>;
-            else if (dact_src && dact == 3 && act == 0 && !preact) pk = gemm_nt_persist_kernel<bf16, 3, 0, 0, true, 0, true>;
+            if (!dact_src && !residual && act == 3 && preact) pk = gemm_nt_persist_kernel<bf16, 0, 1, 2, true, 0, 1>;
+            else if (!dact_src && !residual && (act == 1 || act == 3) && !preact) pk = gemm_nt_persist_kernel<bf16, 0, 1, 0, true, 0, 1>;
+            else if (dact_src && dact == 3 && act == 0 && !preact) pk = gemm_nt_persist_kernel<bf16, 3, 0, 0, true, 0, 1>;
         }
-        // (the f32-output instantiations serve the tf32x engine: bf16 3K-wide split operands, fp32 C / preact / dact_src / residual)
+    } else if (ab_dtype == GD_F16 && !accumulate && !(dact_src && residual)) {
+        // fp16 operands (tf32h engine): f32 results, or an fp16 C beside f32 preact / dact_src
+        const bool ch = c_dtype == GD_F16;
+        if (!dact_src && !residual) {
+            if (act == 0 && !preact) pk = ch ? gemm_nt_persist_kernel<f16, 0, 0, 0, false> : gemm_nt_persist_kernel<f16, 0, 0, 0, true>;
+            else if ((act == 1 || act == 3) && !preact) pk = ch ? gemm_nt_persist_kernel<f16, 0, 1, 0, true, 0, 2> : gemm_nt_persist_kernel<f16, 0, 1, 0, true>;
+            else if (act == 3 && preact) pk = ch ? gemm_nt_persist_kernel<f16, 0, 1, 2, true, 0, 2> : gemm_nt_persist_kernel<f16, 0, 1, 2, true>;
+        } else if (dact_src && dact == 3 && act == 0 && !preact) pk = ch ? gemm_nt_persist_kernel<f16, 3, 0, 0, true, 0, 2> : gemm_nt_persist_kernel<f16, 3, 0, 0, true>;
+        else if (residual && act == 0 && !preact && !ch) pk = gemm_nt_persist_kernel<f16, 2, 0, 0, true>;
     }
+    // (the bf16 f32-output instantiations serve the tf32x engine: 3K-wide split operands, fp32 C / preact / dact_src / residual)
     const bool persist_ok = big && persist && pk && p.vec_epilogue && N % 8 == 0 && (!lora_t || lora_rt == 8) && 256 * ldmax * cs < 0x7fffffffL;
     GD_REQUIRE(!csplit || (persist_ok && ldc >= 3L * N && batch == 1),
                "gd_gemm_nt: split output (c_dtype 2) is served by the persistent kernel only: bf16 operands, M >= 1024, N >= 256, K %% 64 == 0, "
                "ldc >= 3N, and the GELU(+derivative) or dact 3 epilogues (M=%d N=%d K=%d act=%d dact=%d)", M, N, K, act, dact);
+    GD_REQUIRE(!chalf || persist_ok || (!preact && !dact_src && !residual),
+               "gd_gemm_nt: an fp16 C beside f32 epilogue tensors is served by the persistent kernel only (M >= 1024, N >= 256, K %% 64 == 0; "
+               "GELU(+derivative) or dact 3 epilogues): M=%d N=%d K=%d act=%d dact=%d", M, N, K, act, dact);
     if (persist_ok) {
         // (Tile quantisation — e.g. 1029 tiles of the N = 768 GEMMs on 256 CUs — costs far less than a round: the left-over
         // tiles run alone on an idle chip.  Handing them to the 128 x 128 kernel or cutting them into K slices was measured
@@ -801,7 +835,11 @@ extern "C" int gd_gemm_nt(const void* A, const void* W, void* C, int M, int N, i
         GD_LAUNCH_OK();
         return 0;
     }
-    if (ab_dtype == GD_BF16) {
+    if (ab_dtype == GD_F16) {
+        if (big) hipLaunchKernelGGL((gemm_nt_kernel<f16, 2, 4, 8>), gridb, dim3(512), 0, st, p);
+        else if (dma) hipLaunchKernelGGL((gemm_nt_kernel<f16, 2, 2, 4>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(gemm_nt_regstage_kernel<f16>, grid, dim3(256), 0, st, p);
+    } else if (ab_dtype == GD_BF16) {
         if (big) hipLaunchKernelGGL((gemm_nt_kernel<bf16, 2, 4, 8>), gridb, dim3(512), 0, st, p);
         else if (dma) hipLaunchKernelGGL((gemm_nt_kernel<bf16, 2, 2, 4>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL(gemm_nt_regstage_kernel<bf16>, grid, dim3(256), 0, st, p);
@@ -812,6 +850,24 @@ extern "C" int gd_gemm_nt(const void* A, const void* W, void* C, int M, int N, i
     }
     GD_LAUNCH_OK();
     return 0;
+}
+
+extern "C" int gd_gemm_nt(const void* A, const void* W, void* C, int M, int N, int K, long lda, long ldw, long ldc,
+                          int batch, long sA, long sW, long sC, int ab_dtype, int c_dtype, float alpha,
+                          const float* bias, const float* lora_t, const float* lora_b, int lora_rt, void* preact,
+                          long ldp, int act, const void* dact_src, long ldd, int dact, const void* residual, long ldr,
+                          int accumulate, void* stream) {
+    return gemm_nt_impl(A, W, C, M, N, K, lda, ldw, ldc, batch, sA, sW, sC, ab_dtype, c_dtype, alpha, nullptr, bias, lora_t, lora_b, lora_rt,
+                        preact, ldp, act, dact_src, ldd, dact, residual, ldr, accumulate, stream);
+}
+
+extern "C" int gd_gemm_nt_scaled(const void* A, const void* W, void* C, int M, int N, int K, long lda, long ldw, long ldc,
+                                 int batch, long sA, long sW, long sC, int ab_dtype, int c_dtype, float alpha, const float* alpha_dev,
+                                 const float* bias, const float* lora_t, const float* lora_b, int lora_rt, void* preact,
+                                 long ldp, int act, const void* dact_src, long ldd, int dact, const void* residual, long ldr,
+                                 int accumulate, void* stream) {
+    return gemm_nt_impl(A, W, C, M, N, K, lda, ldw, ldc, batch, sA, sW, sC, ab_dtype, c_dtype, alpha, alpha_dev, bias, lora_t, lora_b, lora_rt,
+                        preact, ldp, act, dact_src, ldd, dact, residual, ldr, accumulate, stream);
 }
 
 extern "C" int gd_gemm_tn(const void* Y, const void* X, float* G, int M, int N, int K, long ldy, long ldx, long ldg,

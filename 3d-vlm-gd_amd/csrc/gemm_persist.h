@@ -101,6 +101,9 @@ __device__ __forceinline__ void bst4_aux(__amdgpu_buffer_rsrc_t rs, int off, int
     if (dt == GD_BF16) {
         const bf16x4 b = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(gd_u32x2, b), rs, off, 0, AUX);
+    } else if (dt == GD_F16) {
+        const f16x4 b = f16x4{from_f32<f16>(v[0]), from_f32<f16>(v[1]), from_f32<f16>(v[2]), from_f32<f16>(v[3])};
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(gd_u32x2, b), rs, off, 0, AUX);
     } else {
         const f32x4 a = {v[0], v[1], v[2], v[3]};
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(gd_u32x4, a), rs, off, 0, AUX);
@@ -138,9 +141,10 @@ __device__ __forceinline__ void bst4_aux(__amdgpu_buffer_rsrc_t rs, int off, int
 // ANAT (anatomy builds, tools/bench_kernels.py gemm_anat; never the product path): 1 = no operand DMA in the main loop (the LDS-read +
 // MFMA + barrier loop alone), 2 = no MFMAs (DMA + LDS reads + barriers), 3 = neither LDS reads nor MFMAs (the DMA ring alone), 4 = no C stores (everything else of the epilogue stays).
 // Instantiated only in -DGD_GEMM_ANATOMY builds (gemm.hip); round-3 results: profiles/r03_gemm_anatomy.txt.
-// CSPLIT (with CF32): C leaves as the three-plane bf16 operand split of the f32 result — [hi | lo | hi] over 3N columns of row stride
+// COUT (with CF32; 0 = C has the side tensors' type): 2 = C alone leaves as the 16-bit operand type T (fp16 operands: saturated; the left operand of the next
+// tf32h product) while preact / side stay f32;  1 = C leaves as the three-plane bf16 operand split of the f32 result — [hi | lo | hi] over 3N columns of row stride
 // ldc (gd_split3 'a' layout), the A operand of the next tf32x GEMM — instead of f32 followed by a gd_split3 pass; side / preact stay f32.
-template <typename T, int SIDE, int ACT, int PREACT, bool CF32, int ANAT = 0, bool CSPLIT = false>
+template <typename T, int SIDE, int ACT, int PREACT, bool CF32, int ANAT = 0, int COUT = 0>
 __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
     constexpr int NWN = 4, WMT = 8, NW = 8, BM = 256, BN = 256;
     constexpr int ABYTES = BM * 128, STAGE = (BM + BN) * 128, APW = BM / 8 / NW, BPW = BN / 8 / NW;
@@ -161,12 +165,15 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
     const char* Wb = (const char*)p.W + batch * p.sW * (long)sizeof(T);
     const long lda_b = p.lda * (long)sizeof(T), ldw_b = p.ldw * (long)sizeof(T);
     const int nk = p.K * (int)sizeof(T) / 128;
-    static_assert(!CSPLIT || CF32, "split output comes from f32 values");
-    constexpr int cdt = CF32 ? GD_F32 : GD_BF16, csz = CF32 ? 4 : 2;
-    constexpr int ccsz = CSPLIT ? 2 : csz;   // element size of C itself (preact / side tensors keep csz / ssz)
+    static_assert(COUT == 0 || CF32, "split / 16-bit-beside-f32 output comes from f32 values");
+    constexpr bool CSPLIT = COUT == 1;
+    constexpr int t16 = std::is_same<T, f16>::value ? GD_F16 : GD_BF16;      // dtype code of a 16-bit C
+    constexpr int cdt = CF32 ? GD_F32 : t16, csz = CF32 ? 4 : 2;
+    constexpr int ccsz = COUT ? 2 : csz;   // element size of C itself (preact / side tensors keep csz / ssz)
     char* Cb = (char*)p.C + batch * p.sC * (long)ccsz;
     const bool lora = p.lora_t != nullptr;
-    const float ia = 1.0f / p.alpha;
+    const float alpha = p.alpha_dev ? p.alpha * *p.alpha_dev : p.alpha;      // gd_gemm_nt_scaled: the operands' power-of-two scale, undone here
+    const float ia = 1.0f / alpha;
 
     // DMA sources: wave-uniform tile base (SGPRs) + one 32-bit byte offset per lane and 1-KB piece.  LDS row rho of
     // piece i is (wave*APW + i)*8 + (lane>>3); rows past the matrix edge are clamped (read, never stored).
@@ -262,7 +269,10 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
         asm volatile("" ::: "memory");
         GD_PROBE({ const unsigned long long c = __builtin_amdgcn_s_memtime(); pw += c - pc0; pc0 = c; })
         if (lora) {
-            const bool live = KPL * g < 8;
+            // bf16 operands with f32 results (the tf32x engine): the chunk's 24 spare k slots carry the split-precision terms — lane groups
+            // g = 0, 1, 2 all read the same eight k rows and contribute t_hi b_hi, t_lo b_hi, t_hi b_lo (as gd_split3 does for the main product)
+            constexpr bool L3 = CF32 && std::is_same<T, bf16>::value && KPL == 8;
+            const bool live = L3 ? g < 3 : KPL * g < 8;
             // B tile [8][BN] f32: this lane's k rows start at (KPL*g)&7; its columns for the n-tiles j = 0..3 are the four
             // consecutive floats 64*wn + 4*fr + j: one 16-byte read per k row
             const unsigned baddr = lds_off(smem + LORA_OFF + BM * 32) + 4 * (((KPL * g) & 7) * BN + wn * 64 + 4 * fr);
@@ -277,7 +287,10 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int k = 0; k < KPL; ++k) bf[j][k] = (T)(live ? qs[k][j] : 0.f);
+                    for (int k = 0; k < KPL; ++k) {
+                        const float x = live ? qs[k][j] : 0.f;
+                        bf[j][k] = (L3 && g == 2) ? (T)(x - (float)(T)x) : (T)x;
+                    }
             }
 #define GD_LT(i, IOFF)                                                                                             \
             {                                                                                                          \
@@ -287,7 +300,10 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t0), "+v"(t1));                                             \
                 const float ts[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};                          \
                 Frag af;                                                                                               \
-                _Pragma("unroll") for (int k = 0; k < KPL; ++k) af[k] = (T)(live ? ia * ts[k] : 0.f);                  \
+                _Pragma("unroll") for (int k = 0; k < KPL; ++k) {                                                      \
+                    const float x = live ? ia * ts[k] : 0.f;                                                           \
+                    af[k] = (L3 && g == 1) ? (T)(x - (float)(T)x) : (T)x;                                              \
+                }                                                                                                      \
                 _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(af, bf[j], acc[i][j]);           \
             }
             GD_LT(0, 0) GD_LT(1, 512) GD_LT(2, 1024) GD_LT(3, 1536) GD_LT(4, 2048) GD_LT(5, 2560) GD_LT(6, 3072) GD_LT(7, 3584)
@@ -391,7 +407,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
             const int coff = cbase + (i * 16 + r) * ccsz * ldc_i, poff = pbase + (i * 16 + r) * csz * ldp_i;
             float v[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = fmaf(p.alpha, acc[i][j][r], bv[j]);
+            for (int j = 0; j < 4; ++j) v[j] = fmaf(alpha, acc[i][j][r], bv[j]);
             if (PREACT == 1) bst4_aux<GD_PERSIST_STORE_AUX>(prs, poff, cdt, v);
             if (ACT == 1 && PREACT == 2) {   // GELU and its derivative from one shared exponential; the derivative is what is stored
                 float dv[4];
@@ -430,7 +446,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
                 bst4_aux<GD_PERSIST_STORE_AUX>(crs, coff + plane, GD_BF16, lo);
                 bst4_aux<GD_PERSIST_STORE_AUX>(crs, coff + 2 * plane, GD_BF16, v);
             } else
-            if (ANAT != 4) bst4_aux<GD_PERSIST_STORE_AUX>(crs, coff, cdt, v);
+            if (ANAT != 4) bst4_aux<GD_PERSIST_STORE_AUX>(crs, coff, COUT == 2 ? t16 : cdt, v);
             else asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
             if (pre && idx + SDEP < NITEM) side_load(idx + SDEP);
         }

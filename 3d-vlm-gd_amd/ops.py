@@ -59,7 +59,7 @@ def time_on_stream(fn, warm=2, iters=5):
 
 
 def gemm_nt(a, w, out=None, *, out_dtype=None, alpha=1.0, bias=None, lora_t=None, lora_b=None, preact=None,
-            act=0, dact_src=None, dact=0, residual=None, accumulate=False, out_split=False):
+            act=0, dact_src=None, dact=0, residual=None, accumulate=False, out_split=False, alpha_dev=None):
     """out[M,N] = epilogue(alpha * a[M,K] @ w[N,K]^T).  a, w: same dtype (f32 | bf16), last dim contiguous.
     Batched when a is 3-D ([B,M,K] x [B,N,K] -> [B,M,N], no epilogue tensors).
     Epilogue order: +bias[N] (f32) -> +lora_t[M,r] @ lora_b[r,N] (f32) -> store preact -> act (1 GELU, 2 ReLU,
@@ -67,7 +67,9 @@ def gemm_nt(a, w, out=None, *, out_dtype=None, alpha=1.0, bias=None, lora_t=None
     -> +out (accumulate).
     out_split: the f32 result leaves as its bf16 operand split [M, 3N] = [hi | lo | hi] (what split3(out, "a") would give: the left
     operand of the next tf32x GEMM) without the f32 tensor ever reaching memory; preact / dact_src stay f32.  split_out_ok() says
-    whether a shape is served."""
+    whether a shape is served.
+    fp16 operands (tf32h engine, `cast16`): f32 results, or out_dtype=torch.float16 — an fp16 C (saturated) beside f32 preact / dact_src;
+    alpha_dev: a device scalar multiplied into alpha (the 1/s of an operand scaled by `amax_scale`)."""
     _req(a.is_cuda and w.is_cuda and a.dtype == w.dtype, "gemm_nt: a and w must be CUDA tensors of one dtype")
     _req(a.stride(-1) == 1 and w.stride(-1) == 1, "gemm_nt: a and w must be contiguous along K")
     batched = a.dim() == 3
@@ -89,7 +91,7 @@ def gemm_nt(a, w, out=None, *, out_dtype=None, alpha=1.0, bias=None, lora_t=None
         out = torch.empty((B, M, N) if batched else (M, N), dtype=odt, device=a.device)
     _req(out.stride(-1) == 1, "gemm_nt: out must be contiguous along N")
     cdt = F32X3 if out_split else dtype_code(out)
-    sdt = torch.float32 if out_split else out.dtype
+    sdt = torch.float32 if (out_split or out.dtype == torch.float16) else out.dtype
     for t, name in ((preact, "preact"), (dact_src, "dact_src"), (residual, "residual")):
         if t is not None:
             _req(t.dtype == sdt and t.stride(-1) == 1 and tuple(t.shape) == (M, N), f"gemm_nt: bad {name}")
@@ -103,11 +105,16 @@ def gemm_nt(a, w, out=None, *, out_dtype=None, alpha=1.0, bias=None, lora_t=None
     if _PROFILER is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    rc = lib().gd_gemm_nt(ptr(a), ptr(w), ptr(out), M, N, K, lda, ldw, out.stride(-2), B, sA, sW,
-                          out.stride(0) if batched else 0, dtype_code(a), cdt, float(alpha), ptr(bias), ptr(lora_t),
-                          ptr(lora_b), rt, ptr(preact), preact.stride(0) if preact is not None else 0, int(act),
-                          ptr(dact_src), dact_src.stride(0) if dact_src is not None else 0, int(dact), ptr(residual),
-                          residual.stride(0) if residual is not None else 0, 1 if accumulate else 0, stream())
+    tail = (ptr(bias), ptr(lora_t), ptr(lora_b), rt, ptr(preact), preact.stride(0) if preact is not None else 0, int(act),
+            ptr(dact_src), dact_src.stride(0) if dact_src is not None else 0, int(dact), ptr(residual),
+            residual.stride(0) if residual is not None else 0, 1 if accumulate else 0, stream())
+    head = (ptr(a), ptr(w), ptr(out), M, N, K, lda, ldw, out.stride(-2), B, sA, sW, out.stride(0) if batched else 0, dtype_code(a), cdt,
+            float(alpha))
+    if alpha_dev is not None:
+        _req(alpha_dev.is_cuda and alpha_dev.dtype == torch.float32 and alpha_dev.numel() >= 1, "gemm_nt: alpha_dev must be a CUDA fp32 scalar")
+        rc = lib().gd_gemm_nt_scaled(*head, ptr(alpha_dev), *tail)
+    else:
+        rc = lib().gd_gemm_nt(*head, *tail)
     if _PROFILER is not None:
         e1.record()
         tag = "".join(c for c, t in (("b", bias), ("l", lora_t), ("p", preact), ("d", dact_src), ("r", residual)) if t is not None)
@@ -119,6 +126,25 @@ def gemm_nt(a, w, out=None, *, out_dtype=None, alpha=1.0, bias=None, lora_t=None
 def split_out_ok(M, N, K3):
     """Shapes gemm_nt(..., out_split=True) serves (the persistent kernel's: gd_gemm_nt, c_dtype GD_F32X3)."""
     return M >= 1024 and N >= 256 and N % 8 == 0 and K3 % 64 == 0
+
+
+def cast16(x, scale=1.0, scale_dev=None):
+    """f32 [rows, K] (rows may be strided) -> fp16 [rows, K] = sat(x * scale * scale_dev[0]): an operand of the tf32h engine's products (fp16
+    carries TF32's 11-bit significand).  Forward activations and weights go in unscaled; gradients with the power of two of `amax_scale`."""
+    _req(x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1, "cast16: a 2-D fp32 CUDA tensor with contiguous rows")
+    rows, K = x.shape
+    out = torch.empty(rows, K, dtype=torch.float16, device=x.device)
+    check(lib().gd_cast_f16(ptr(x), ptr(out), rows, K, x.stride(0), float(scale), ptr(scale_dev), stream()), "gd_cast_f16")
+    return out
+
+
+def amax_scale(x, target=64.0):
+    """-> device fp32 [3] = {s, 1/s, scratch}: s the power of two with target/2 < max|x| * s <= target (1 for an all-zero tensor).  No host
+    round trip: s goes to `cast16(scale_dev=r[0:1])`, 1/s to `gemm_nt(alpha_dev=r[1:2])`."""
+    _req(x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1, "amax_scale: a 2-D fp32 CUDA tensor with contiguous rows")
+    out = torch.empty(3, dtype=torch.float32, device=x.device)
+    check(lib().gd_amax_scale(ptr(x), x.shape[0], x.shape[1], x.stride(0), float(target), ptr(out), stream()), "gd_amax_scale")
+    return out
 
 
 def split3(x, which):
@@ -186,7 +212,7 @@ def cost_volume_teacher_stats(t1, t2):
 
 class _CostVolumeKL(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, f1, f2, t1, t2, m1, m2, variant, tstats, inv1=None, inv2=None):
+    def forward(ctx, f1, f2, t1, t2, m1, m2, variant, tstats, inv1=None, inv2=None, x3=False):
         P, hw, C = f1.shape
         f1, f2 = f1.contiguous(), f2.contiguous()
         t1, t2 = t1.contiguous().float(), t2.contiguous().float()
@@ -203,8 +229,17 @@ class _CostVolumeKL(torch.autograd.Function):
         if inv1 is not None:
             _req(inv1.shape == (P, hw) and inv2.shape == (P, hw) and inv1.dtype == torch.float32 and inv2.dtype == torch.float32 and
                  inv1.is_contiguous() and inv2.is_contiguous(), "cost_volume_kl: inv_norms must be two contiguous fp32 [P, hw] tensors")
-            rc = lib().gd_cost_volume_kl_fwd_prenorm(ptr(f1), ptr(f2), ptr(inv1), ptr(inv2), ptr(t1), ptr(t2), ldt, ptr(tstats), ptr(m1),
-                                                     ptr(m2), P, hw, C, VARIANTS[variant], dt, ptr(loss), ptr(stats), ptr(ws), stream())
+            if x3 and f1.dtype == torch.float32 and C % 8 == 0:
+                # tf32x: S = f1 . f2^T as three bf16 MFMA products of the (hi, lo) splits on the bf16 tile kernel (K = 3C) instead of the
+                # exact-f32 MFMA; the row norms stay those of the f32 rows, and the backward (which recomputes S in f32) reads the same
+                # stats layout — logZ from this S agrees with its own to ~1e-6
+                a3, b3 = split3(f1.view(P * hw, C), "a"), split3(f2.view(P * hw, C), "w")
+                ws = torch.empty(lib().gd_cost_volume_kl_workspace_bytes(P, hw, 3 * C, 1, 0), dtype=torch.uint8, device=f1.device)
+                rc = lib().gd_cost_volume_kl_fwd_prenorm(ptr(a3), ptr(b3), ptr(inv1), ptr(inv2), ptr(t1), ptr(t2), ldt, ptr(tstats), ptr(m1),
+                                                         ptr(m2), P, hw, 3 * C, VARIANTS[variant], 1, ptr(loss), ptr(stats), ptr(ws), stream())
+            else:
+                rc = lib().gd_cost_volume_kl_fwd_prenorm(ptr(f1), ptr(f2), ptr(inv1), ptr(inv2), ptr(t1), ptr(t2), ldt, ptr(tstats), ptr(m1),
+                                                         ptr(m2), P, hw, C, VARIANTS[variant], dt, ptr(loss), ptr(stats), ptr(ws), stream())
         else:
             rc = lib().gd_cost_volume_kl_fwd(ptr(f1), ptr(f2), ptr(t1), ptr(t2), ldt, ptr(tstats), ptr(m1), ptr(m2), P, hw, C,
                                              VARIANTS[variant], dt, ptr(loss), ptr(stats), ptr(ws), stream())
@@ -225,18 +260,19 @@ class _CostVolumeKL(torch.autograd.Function):
         rc = lib().gd_cost_volume_kl_bwd(ptr(f1), ptr(f2), ptr(t1), ptr(t2), t1.shape[-1], ptr(m1), ptr(m2), P, hw, C, dt, ptr(g),
                                          ptr(stats), ptr(df1), ptr(df2), ptr(ws), stream())
         check(rc, "gd_cost_volume_kl_bwd")
-        return df1, df2, None, None, None, None, None, None, None, None
+        return df1, df2, None, None, None, None, None, None, None, None, None
 
 
-def cost_volume_kl(f1, f2, t1, t2, m1, m2, variant="vggt", tstats=None, inv_norms=None):
+def cost_volume_kl(f1, f2, t1, t2, m1, m2, variant="vggt", tstats=None, inv_norms=None, x3=False):
     """Fused dense cost-volume KL for P pairs.  f1,f2 [P,hw,C] raw student features (f32|bf16); t1,t2 [P,hw,ldt] teacher
     maps (f32; ldt = hw, or hw padded to a multiple of 4 by `pad_teacher_maps`: the fast path); m1,m2 [P,hw] bool row
     masks; tstats: `cost_volume_teacher_stats(t1, t2)` computed once per cached pair (None: recomputed here, one more pass
     over the maps); inv_norms = (inv1, inv2), fp32 [P, hw] each: 1 / max(||row||, 1e-12) of the feature rows as stored, when their
     producer already took them (`tap_mean(..., with_norm=True)`) — the op then skips its own pass over the features
+    x3 (fp32 features with inv_norms): the forward's similarity matrix as a split-precision bf16 product (tf32x engine)
     -> loss [P] (f32)."""
     if inv_norms is not None:
-        return _CostVolumeKL.apply(f1, f2, t1, t2, m1, m2, variant, tstats, inv_norms[0].detach(), inv_norms[1].detach())
+        return _CostVolumeKL.apply(f1, f2, t1, t2, m1, m2, variant, tstats, inv_norms[0].detach(), inv_norms[1].detach(), x3)
     return _CostVolumeKL.apply(f1, f2, t1, t2, m1, m2, variant, tstats)
 
 

@@ -183,6 +183,11 @@ class _BlockFn(torch.autograd.Function):
             up_T = tw["up_T"] if tw is not None else up.detach().to(T).contiguous()
             if ops.adapter_fused_supported(x2, down.shape[0]):
                 out, hd = ops.adapter_fused(x2, down_T, up_T, save_hidden=need)
+            elif plan["x3"]:        # tf32x: both projections as split-precision products on the bf16 kernels (the fp32 tile kernel: 2 x 370 us)
+                w_dn = tw["down_w3"] if tw is not None and "down_w3" in tw else ops.split3(down_T, "w")
+                w_up = tw["up_w3"] if tw is not None and "up_w3" in tw else ops.split3(up_T, "w")
+                hd = ops.gemm_nt(ops.split3(x2, "a"), w_dn, act=2, out_dtype=torch.float32)
+                out = ops.gemm_nt(ops.split3(hd, "a"), w_up, residual=x2, out_dtype=torch.float32)
             else:
                 hd = ops.gemm_nt(x2, down_T, act=2)
                 out = ops.gemm_nt(hd, up_T, residual=x2)
@@ -218,6 +223,11 @@ class _BlockFn(torch.autograd.Function):
             down_tT = tw["down_tT"] if tw is not None else down.detach().t().to(T).contiguous()
             if ops.adapter_fused_supported(dout, bott):
                 dx2, dhp = ops.adapter_fused(dout, up_tT, down_tT, gate_src=hd)                   # dX and d(hidden) [M, 64]
+            elif plan["x3"]:
+                w_ut = tw["up_tw3"] if tw is not None and "up_tw3" in tw else ops.split3(up_tT, "w")
+                w_dt = tw["down_tw3"] if tw is not None and "down_tw3" in tw else ops.split3(down_tT, "w")
+                dhp = ops.gemm_nt(ops.split3(dout, "a"), w_ut, dact_src=hd, dact=2, out_dtype=torch.float32)
+                dx2 = ops.gemm_nt(ops.split3(dhp, "a"), w_dt, residual=dout, out_dtype=torch.float32)
             else:
                 dhp = ops.gemm_nt(dout, up_tT, dact_src=hd, dact=2)                               # [M, 64]
                 dx2 = ops.gemm_nt(dhp, down_tT, residual=dout)
@@ -478,6 +488,10 @@ class GDViT(nn.Module):
             at_T, bt_T, down_T, up_T = at.to(T), bt.to(T), down.to(T), up.to(T)
             bt_qv = torch.cat([bt_T[:, :, :D], bt_T[:, :, 2 * D:]], 2).contiguous()      # [L, 2r, 2D]: the (dq, dv) column order
             down_tT, up_tT = down_T.transpose(1, 2).contiguous(), up_T.transpose(1, 2).contiguous()
+            if getattr(self, "gemm_split3", False):      # tf32x: the adapter weights as right-hand split operands (four small passes per step)
+                w3 = lambda w: ops.split3(w.reshape(-1, w.shape[-1]).contiguous(), "w").view(L, w.shape[1], 3 * w.shape[2])
+                for i, pack in enumerate(zip(w3(down_T), w3(up_T), w3(down_tT), w3(up_tT))):
+                    extra[i].update(zip(("down_w3", "up_w3", "down_tw3", "up_tw3"), pack))
         for i, (inner, _, _) in enumerate(lo):
             inner._tw = {"dtype": T, "at": at[i], "bt": bt[i], "at_T": at_T[i], "bt_T": bt_T[i], "bt_qv": bt_qv[i], "down_T": down_T[i],
                          "up_T": up_T[i], "down_tT": down_tT[i], "up_tT": up_tT[i], **extra[i]}

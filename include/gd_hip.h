@@ -22,6 +22,7 @@ extern "C" {
 #define GD_F32 0
 #define GD_BF16 1
 #define GD_F32X3 2   /* gd_attention_{fwd,bwd}: fp32 tensors, every product as three bf16 MFMAs of (hi, lo) splits (TF32-class; see gd_split3); gd_gemm_nt c_dtype: split output */
+#define GD_F16 3     /* IEEE half: the operand format of the tf32h engine (gd_cast_f16 -> gd_gemm_nt_scaled, gd_attention_*): 11-bit significands = TF32's */
 
 const char* gd_last_error(void);
 int gd_abi_version(void);
@@ -265,6 +266,21 @@ int gd_cast(const void* in, void* out, long n, float scale, int in_dtype, int ou
  * hi_a hi_w + lo_a hi_w + hi_a lo_w: relative error ~4e-6 of the product sum, against ~3e-4 for TF32 and ~2e-3 for plain bf16
  * (tests/test_gpu_gemm.py::test_split3_product_accuracy).  in [rows, K] f32 (row stride ld_in), out [rows, 3K] bf16. */
 int gd_split3(const float* in, void* out, long rows, int K, long ld_in, int which, void* stream);
+
+/* TF32-class products from ONE fp16 MFMA per term (the tf32h engine): fp16 carries TF32's 11-bit significand, the matrix cores take it at the
+ * bf16 rate, and the missing exponent range is covered by scaling — forward activations and frozen weights go in as they are (saturated at
+ * +-65504, far above anything a ViT produces), a gradient tensor is multiplied by a power of two taken from its own maximum on the device.
+ * gd_cast_f16: out [rows, K] fp16 = sat(in * scale * (scale_dev ? *scale_dev : 1)), in f32 with row stride ld_in.
+ * gd_amax_scale: scale3 (device, 3 floats) <- {s, 1/s, scratch} with s the power of two that puts max|in| into (target/2, target].
+ * gd_gemm_nt_scaled: gd_gemm_nt with alpha multiplied by the device scalar *alpha_dev (the 1/s of a scaled operand) — no host round trip.
+ * gd_gemm_nt itself takes ab_dtype GD_F16 (f32 results, or c_dtype GD_F16: an fp16 C beside f32 preact / dact_src). */
+int gd_cast_f16(const float* in, void* out, long rows, int K, long ld_in, float scale, const float* scale_dev, void* stream);
+int gd_amax_scale(const float* in, long rows, int K, long ld_in, float target, float* scale3, void* stream);
+int gd_gemm_nt_scaled(const void* A, const void* W, void* C, int M, int N, int K, long lda, long ldw, long ldc,
+                      int batch, long sA, long sW, long sC, int ab_dtype, int c_dtype, float alpha, const float* alpha_dev,
+                      const float* bias, const float* lora_t, const float* lora_b, int lora_rt, void* preact, long ldp,
+                      int act, const void* dact_src, long ldd, int dact, const void* residual, long ldr, int accumulate,
+                      void* stream);
 
 /* flat_allreduce: the data-parallel step's one exchange — the sum over ranks of the flat fp32 gradient buffer — on RCCL over
  * xGMI (replaces Lightning DDP's bucketed all-reduce, src/main.py:147-151).  RCCL is bound at run time (dlopen, the copy the

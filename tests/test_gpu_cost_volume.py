@@ -155,3 +155,28 @@ def test_producer_side_row_norms(dtype):
         assert torch.equal(a, t.grad)
     ol, _, _ = _oracle(f[:P].detach().float(), f[P:].detach().float(), t1, t2, m1, m2, "mast3r")
     assert rel_err(lb, ol) < (1e-5 if dtype == torch.float32 else 1e-3)
+
+
+@pytest.mark.parametrize("variant", ["mast3r", "vggt"])
+def test_split_precision_forward(variant):
+    """cost_volume_kl(x3=True) on fp32 features (tf32x engine): the similarity matrix of the FORWARD as a split-precision bf16 product
+    (gd_split3 + the bf16 tile kernel at K = 3C) — loss within 1e-5 of the fp64 oracle (the bf16 kernel on bf16 features: 1e-3), gradients
+    (f32 backward reading the forward's saved logZ) within 1e-4."""
+    from gd_amd import ops
+    P, hw, C = 2, 1369, 768
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    f1 = torch.randn(P, hw, C, generator=gen, device="cuda").requires_grad_(True)
+    f2 = torch.randn(P, hw, C, generator=gen, device="cuda").requires_grad_(True)
+    t1 = torch.softmax(3 * torch.randn(P, hw, hw, generator=gen, device="cuda"), -1)
+    t2 = torch.softmax(3 * torch.randn(P, hw, hw, generator=gen, device="cuda"), -1)
+    m1 = torch.rand(P, hw, generator=gen, device="cuda") > 0.5
+    m2 = torch.rand(P, hw, generator=gen, device="cuda") > 0.5
+    c1, c2, ts = _teacher("cached", t1, t2)
+    inv1 = 1.0 / f1.detach().norm(dim=-1).clamp_min(1e-12)
+    inv2 = 1.0 / f2.detach().norm(dim=-1).clamp_min(1e-12)
+    loss = ops.cost_volume_kl(f1, f2, c1, c2, m1, m2, variant, tstats=ts, inv_norms=(inv1, inv2), x3=True)
+    loss.sum().backward()
+    ol, og1, og2 = _oracle(f1.detach(), f2.detach(), t1, t2, m1, m2, variant)
+    assert rel_err(loss, ol) < 1e-5
+    assert rel_err(f1.grad, og1) < 1e-4 and rel_err(f2.grad, og2) < 1e-4
+

@@ -313,3 +313,58 @@ def test_split3_product_accuracy(M, N, K):
     res = torch.randn(M, N, generator=g, device="cuda")
     got2 = ops.gemm_nt_x3(a, w3, bias=bias, residual=res)
     assert float((got2.double() - (ref + bias.double() + res.double())).norm() / ref.norm()) < 2e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(1300, 320, 192), (2048, 768, 768), (300, 64, 136)])
+def test_fp16_operand_products_are_tf32_class(M, N, K):
+    """The tf32h engine's products: operands rounded to fp16 (11-bit significand = TF32's), fp32 accumulation and epilogue.  The result is the
+    fp64 product of the fp16-rounded operands to fp32 round-off, and its error against the product of the ORIGINAL operands is no larger
+    than that of TF32 emulated on the same operands (10 explicit mantissa bits, round to nearest).  Persistent (first two shapes) and tile
+    kernels (third), with the fp32 epilogue tensors."""
+    from gd_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(M + K)
+    a = torch.randn(M, K, generator=g, device="cuda")
+    w = torch.randn(N, K, generator=g, device="cuda") * 0.05
+    ah, wh = ops.cast16(a), ops.cast16(w)
+    assert ah.dtype == torch.float16 and torch.equal(ah, a.half()) and torch.equal(wh, w.half())
+    ref = a.double() @ w.double().t()
+    fro = lambda x, r=ref: float((x.double() - r).norm() / r.norm())
+    got = ops.gemm_nt(ah, wh, out_dtype=torch.float32)
+    assert got.dtype == torch.float32 and fro(got, ah.double() @ wh.double().t()) < 2e-6
+    tf32 = lambda x: ((x.view(torch.int32) + 0x1000) & ~0x1FFF).view(torch.float32)
+    assert fro(got) < 1.05 * fro(tf32(a.clone()).double() @ tf32(w.clone()).double().t())
+    bias = torch.randn(N, generator=g, device="cuda")
+    res = torch.randn(M, N, generator=g, device="cuda")
+    exact = ah.double() @ wh.double().t()
+    assert fro(ops.gemm_nt(ah, wh, out_dtype=torch.float32, bias=bias, residual=res), exact + bias.double() + res.double()) < 2e-6
+    assert fro(ops.gemm_nt(ah, wh, out_dtype=torch.float32, bias=bias, act=1), torch.nn.functional.gelu(exact + bias.double())) < 1e-5
+
+
+def test_fp16_gradient_operands_carry_a_device_side_scale():
+    """A gradient-sized tensor (values ~1e-7: below fp16's normal range) goes through the fp16 product with the power-of-two scale
+    of gd_amax_scale — taken and undone on the device (cast16(scale_dev=), gemm_nt(alpha_dev=)) — and comes back TF32-class; the same
+    tensor cast without a scale loses everything.  fp16 C output (the next product's operand) saturates instead of overflowing."""
+    from gd_amd import ops
+    M, N, K = 2048, 768, 3072
+    g = torch.Generator(device="cuda").manual_seed(3)
+    d = torch.randn(M, K, generator=g, device="cuda") * 1e-7
+    d[5, 7] = 3e-4                                                          # one outlier sets the scale; the bulk sits 2^-12 below it
+    w = torch.randn(N, K, generator=g, device="cuda") * 0.05
+    sc = ops.amax_scale(d, target=64.0)
+    s, inv = float(sc[0]), float(sc[1])
+    assert s * inv == 1.0 and 32.0 < 3e-4 * s <= 64.0 and abs(round(torch.log2(sc[0]).item()) - torch.log2(sc[0]).item()) < 1e-6
+    dh, wh = ops.cast16(d, scale_dev=sc[0:1]), ops.cast16(w)
+    ref = d.double() @ w.double().t()
+    fro = lambda x: float((x.double() - ref).norm() / ref.norm())
+    got = ops.gemm_nt(dh, wh, out_dtype=torch.float32, alpha_dev=sc[1:2])
+    tf32 = lambda x: ((x.view(torch.int32) + 0x1000) & ~0x1FFF).view(torch.float32)
+    assert fro(got) < 1.05 * fro(tf32(d.clone()).double() @ tf32(w.clone()).double().t())
+    assert fro(ops.gemm_nt(ops.cast16(d), wh, out_dtype=torch.float32)) > 0.05          # unscaled: the operand is mostly subnormal / zero
+    # fp16 C beside f32 epilogue tensors; saturation
+    src = torch.rand(M, N, generator=g, device="cuda")
+    c16 = ops.gemm_nt(dh, wh, out_dtype=torch.float16, dact_src=src, dact=3)
+    want = (dh.double() @ wh.double().t()) * src.double()
+    assert c16.dtype == torch.float16 and float((c16.double() - want).norm() / want.norm()) < 5e-4
+    big = ops.gemm_nt(ops.cast16(torch.full((1024, 64), 60000.0, device="cuda")), ops.cast16(torch.ones(256, 64, device="cuda")),
+                      out_dtype=torch.float16)
+    assert bool(torch.isfinite(big).all()) and float(big.max()) == 65504.0
