@@ -69,13 +69,19 @@ __device__ __forceinline__ float quad_rows_max(float v) {
 // otherwise): a wave-uniform branch that is almost never taken after the first tiles.  Any reference point gives the same
 // o = sum p v / sum p and lse = m + log2 sum p; the first-tile rule keeps sum p >= 1, so nothing can underflow to 0 / 0.
 #define ATT_THR 8.0f
+// the two 16-bit element types share every layout: bf16 (bf16 engine) and fp16 (tf32h engine: TF32's significand; conversions saturate)
+template <typename T> struct V16;
+template <> struct V16<bf16> { typedef bf16x8 T8; typedef bf16x4 T4; };
+template <> struct V16<f16> { typedef f16x8 T8; typedef f16x4 T4; };
 template <typename T> __device__ __forceinline__ typename Mma<T>::Frag frag_scale(typename Mma<T>::Frag f, float a);
-template <> __device__ __forceinline__ bf16x8 frag_scale<bf16>(bf16x8 f, float a) {
-    bf16x8 o;
+template <typename T> __device__ __forceinline__ typename V16<T>::T8 frag_scale16(typename V16<T>::T8 f, float a) {
+    typename V16<T>::T8 o;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) o[k] = (bf16)((float)f[k] * a);
+    for (int k = 0; k < 8; ++k) o[k] = from_f32<T>((float)f[k] * a);
     return o;
 }
+template <> __device__ __forceinline__ bf16x8 frag_scale<bf16>(bf16x8 f, float a) { return frag_scale16<bf16>(f, a); }
+template <> __device__ __forceinline__ f16x8 frag_scale<f16>(f16x8 f, float a) { return frag_scale16<f16>(f, a); }
 template <> __device__ __forceinline__ f32x4 frag_scale<float>(f32x4 f, float a) { return f * a; }
 template <> __device__ __forceinline__ X3Frag frag_scale<x3>(X3Frag f, float a) {      // scale the fp32 value, split again
     float x[8];
@@ -87,6 +93,10 @@ template <typename T> __device__ __forceinline__ typename Mma<T>::Frag frag_ones
 template <> __device__ __forceinline__ bf16x8 frag_ones<bf16>() {
     const bf16 o = (bf16)1.0f;
     return bf16x8{o, o, o, o, o, o, o, o};
+}
+template <> __device__ __forceinline__ f16x8 frag_ones<f16>() {
+    const f16 o = (f16)1.0f;
+    return f16x8{o, o, o, o, o, o, o, o};
 }
 template <> __device__ __forceinline__ f32x4 frag_ones<float>() { return f32x4{1.f, 1.f, 1.f, 1.f}; }
 template <> __device__ __forceinline__ X3Frag frag_ones<x3>() {
@@ -144,13 +154,15 @@ template <typename T> struct AT;
 //   * ds_read_b64_tr_b16 transpose reads (32 lanes = 8 consecutive rows x the chunk PAIR {2 dt, 2 dt + 1}): the four rows of
 //     equal parity need four different pairs — XOR by an even number that differs between them, which an odd XOR ((row >> 1) & 7
 //     has them) does not give.
-template <> struct AT<bf16> {
+struct AT16 {
     static constexpr int NF = 2;        // fragments per 64-wide contraction
     static constexpr int ROWB = 128;    // LDS row: 64 el * 2 B
     static constexpr int CPR = 8;       // 16-byte chunks per 64-element row
     static constexpr int EPC = 8;       // elements per chunk
     static __device__ __forceinline__ int sw(int row) { return ((row >> 1) & 3) << 1; }
 };
+template <> struct AT<bf16> : AT16 {};
+template <> struct AT<f16> : AT16 {};
 template <> struct AT<float> {
     static constexpr int NF = 4;
     static constexpr int ROWB = 272;    // 64 el * 4 B + 16 pad, linear
@@ -176,6 +188,11 @@ template <> __device__ __forceinline__ bf16x8 acc_to_bfrag<bf16>(const f32x4 (&t
     const f32x4 a = t[2 * u], b = t[2 * u + 1];
     return bf16x8{(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};
 }
+template <> __device__ __forceinline__ f16x8 acc_to_bfrag<f16>(const f32x4 (&t)[4], int u) {
+    const f32x4 a = t[2 * u], b = t[2 * u + 1];
+    return f16x8{from_f32<f16>(a[0]), from_f32<f16>(a[1]), from_f32<f16>(a[2]), from_f32<f16>(a[3]),
+                 from_f32<f16>(b[0]), from_f32<f16>(b[1]), from_f32<f16>(b[2]), from_f32<f16>(b[3])};
+}
 template <> __device__ __forceinline__ f32x4 acc_to_bfrag<float>(const f32x4 (&t)[4], int u) { return t[u]; }
 template <> __device__ __forceinline__ X3Frag acc_to_bfrag<x3>(const f32x4 (&t)[4], int u) {
     const f32x4 a = t[2 * u], b = t[2 * u + 1];
@@ -189,6 +206,11 @@ template <> __device__ __forceinline__ bf16x8 load_tfrag<bf16>(const char* row, 
     const bf16x4 a = *(const bf16x4*)(row + (32 * u + 4 * g) * 2);
     const bf16x4 b = *(const bf16x4*)(row + (32 * u + 16 + 4 * g) * 2);
     return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+template <> __device__ __forceinline__ f16x8 load_tfrag<f16>(const char* row, int u, int g) {
+    const f16x4 a = *(const f16x4*)(row + (32 * u + 4 * g) * 2);
+    const f16x4 b = *(const f16x4*)(row + (32 * u + 16 + 4 * g) * 2);
+    return f16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 }
 template <> __device__ __forceinline__ f32x4 load_tfrag<float>(const char* row, int u, int g) {
     return *(const f32x4*)(row + (16 * u + 4 * g) * 4);
@@ -292,9 +314,9 @@ __device__ __forceinline__ void tile_store(const TileRegs<T, NT>& r, char* sN, c
 //         lane 4q+p supplies the address of block row q, columns 4p..4p+3; lane i receives column i of the 4 rows)
 //   f32 : 16-byte read from an explicitly transposed LDS tile.
 template <typename T> struct TOp;
-template <> struct TOp<bf16> {
+template <typename T> struct TOp16 {
     static constexpr bool kNeedT = false;
-    static __device__ __forceinline__ bf16x8 load(const char* sN, const char*, int dt, int u, int g, int lane) {
+    static __device__ __forceinline__ typename V16<T>::T8 load(const char* sN, const char*, int dt, int u, int g, int lane) {
         typedef __attribute__((ext_vector_type(4))) short s16x4;
         const int i = lane & 15, q = i >> 2, p = i & 3;
         const int row = 32 * u + 4 * g + q;                         // (row + 16 has the same swizzle)
@@ -304,9 +326,11 @@ template <> struct TOp<bf16> {
         const s16x4 y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1);
         typedef __attribute__((ext_vector_type(8))) short s16x8;
         const s16x8 z = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
-        return __builtin_bit_cast(bf16x8, z);
+        return __builtin_bit_cast(typename V16<T>::T8, z);
     }
 };
+template <> struct TOp<bf16> : TOp16<bf16> {};
+template <> struct TOp<f16> : TOp16<f16> {};
 template <> struct TOp<x3> {      // both planes straight from the natural tile, as bf16
     static constexpr bool kNeedT = false;
     static __device__ __forceinline__ bf16x8 plane(const char* sN, int pl, int dt, int u, int g, int lane) {
@@ -341,6 +365,9 @@ template <> __device__ __forceinline__ void store4<float>(float* p, f32x4 v) { *
 template <> __device__ __forceinline__ void store4<x3>(x3* p, f32x4 v) { *(f32x4*)p = v; }
 template <> __device__ __forceinline__ void store4<bf16>(bf16* p, f32x4 v) {
     *(bf16x4*)p = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+}
+template <> __device__ __forceinline__ void store4<f16>(f16* p, f32x4 v) {
+    *(f16x4*)p = f16x4{from_f32<f16>(v[0]), from_f32<f16>(v[1]), from_f32<f16>(v[2]), from_f32<f16>(v[3])};
 }
 
 // ------------------------------------------------------------------------------------------ forward
@@ -469,8 +496,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* qkv, T* o, fl
 #define ADS_R128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
 #define ADS_TR64(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
 typedef __attribute__((ext_vector_type(2))) unsigned a_u32x2;
-__global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const bf16* qkv, bf16* o, float* lse, int N, int H, float scale, int rot_on) {
-    typedef bf16x8 Frag;
+template <typename T>      // bf16 | f16
+__global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const T* qkv, T* o, float* lse, int N, int H, float scale, int rot_on) {
+    typedef typename Mma<T>::Frag Frag;
     constexpr int TILE = 64 * 128;                       // one K or V tile: 64 rows x 128 B
     __shared__ __attribute__((aligned(16))) char smem[6 * TILE];   // K slots 0..2 | V slots 0..2
     const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
@@ -491,7 +519,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const bf16* qkv, b
         const int q = q0 + qt * 16 + c;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            if (q < N) qf[qt][u] = frag_scale<bf16>(load_nfrag<bf16>(qb + (long)q * ld_b, u, g), c2);
+            if (q < N) qf[qt][u] = frag_scale<T>(load_nfrag<T>(qb + (long)q * ld_b, u, g), c2);
             else { Frag z = {}; qf[qt][u] = z; }
         }
     }
@@ -504,7 +532,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const bf16* qkv, b
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int row = (wave * 2 + i) * 8 + prow;
-        const long off = (long)row * ld_b + ((pchunk ^ AT<bf16>::sw(row)) * 16);
+        const long off = (long)row * ld_b + ((pchunk ^ AT<T>::sw(row)) * 16);
         kp[i] = kb + off;
         vp_[i] = vb + off;
     }
@@ -523,7 +551,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const bf16* qkv, b
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = (wave * 2 + i) * 8 + prow;
-            const long off = (long)min(k0 + row, N - 1) * ld_b + ((pchunk ^ AT<bf16>::sw(row)) * 16);
+            const long off = (long)min(k0 + row, N - 1) * ld_b + ((pchunk ^ AT<T>::sw(row)) * 16);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kb + off),
                                              (__attribute__((address_space(3))) void*)(smem + slot * TILE + (wave * 2 + i) * 1024), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vb + off),
@@ -532,10 +560,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const bf16* qkv, b
     };
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)smem;
     // K fragment (kt, u): row kt*16 + c, logical chunk 4u + g
-    const int swk = AT<bf16>::sw(c);
+    const int swk = AT<T>::sw(c);
     const unsigned ka0 = c * 128 + ((0 + g) ^ swk) * 16, ka1 = c * 128 + ((4 + g) ^ swk) * 16;
     // V transpose fragment (dt, u): rows 32u + 4g + q (+16), logical chunk 2dt + (p>>1), 8-byte half p&1
-    const int vq = c >> 2, vp = c & 3, swv = AT<bf16>::sw(4 * g + vq);
+    const int vq = c >> 2, vp = c & 3, swv = AT<T>::sw(4 * g + vq);
     unsigned va[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) va[dt] = (4 * g + vq) * 128 + (((2 * dt + (vp >> 1)) ^ swv) * 16) + 8 * (vp & 1);
@@ -548,7 +576,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const bf16* qkv, b
     float m[2] = {0.f, 0.f};                                  // reference point, log2 units (see softmax_lagged)
     f32x4 negm[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     f32x4 lacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    const Frag ones = frag_ones<bf16>();
+    const Frag ones = frag_ones<T>();
     const int ntile = (N + 63) / 64, nfull = N / 64;
     // The x-blocks of an (image, head) start together on one XCD and sweep the same K / V tiles at the same pace: in
     // lockstep they all ask one L2 channel for the same lines at the same moment.  Softmax accumulation does not care about
@@ -583,7 +611,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const bf16* qkv, b
             for (int qt = 0; qt < 2; ++qt) {
                 f32x4 a = negm[qt];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) a = Mma<bf16>::mma(__builtin_bit_cast(Frag, kr[kt][u]), qf[qt][u], a);
+                for (int u = 0; u < 2; ++u) a = Mma<T>::mma(__builtin_bit_cast(Frag, kr[kt][u]), qf[qt][u], a);
                 s[qt][kt] = a;
             }
         // V fragments: issued now, consumed after the softmax
@@ -602,8 +630,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const bf16* qkv, b
             Frag pf[2];
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
-                pf[qt] = acc_to_bfrag<bf16>(s[qt], u);
-                lacc[qt] = Mma<bf16>::mma(ones, pf[qt], lacc[qt]);
+                pf[qt] = acc_to_bfrag<T>(s[qt], u);
+                lacc[qt] = Mma<T>::mma(ones, pf[qt], lacc[qt]);
             }
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
@@ -611,7 +639,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const bf16* qkv, b
                 const a_u32x4 z = {vr[dt][u][0][0], vr[dt][u][0][1], vr[dt][u][1][0], vr[dt][u][1][1]};
                 const Frag vf = __builtin_bit_cast(Frag, z);
 #pragma unroll
-                for (int qt = 0; qt < 2; ++qt) oacc[dt][qt] = Mma<bf16>::mma(vf, pf[qt], oacc[dt][qt]);
+                for (int qt = 0; qt < 2; ++qt) oacc[dt][qt] = Mma<T>::mma(vf, pf[qt], oacc[dt][qt]);
             }
         }
     };
@@ -627,15 +655,21 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const bf16* qkv, b
         if (q >= N) continue;
         const float lsum = lacc[qt][0];
         const float inv = 1.0f / lsum;
-        bf16* orow = o + ((long)b * N + q) * H * HD + h * HD;
+        T* orow = o + ((long)b * N + q) * H * HD + h * HD;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) store4<bf16>(orow + dt * 16 + g * 4, oacc[dt][qt] * inv);
+        for (int dt = 0; dt < 4; ++dt) store4<T>(orow + dt * 16 + g * 4, oacc[dt][qt] * inv);
         if (g == 0) lse[((long)b * H + h) * N + q] = (m[qt] + log2f(lsum)) * 0.6931471805599453f;
     }
 }
 
 // dot of two operand fragments (the 16 bytes a lane holds of a row), fp32
 __device__ __forceinline__ float frag_dot(bf16x8 a, bf16x8 b) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s = fmaf((float)a[k], (float)b[k], s);
+    return s;
+}
+__device__ __forceinline__ float frag_dot(f16x8 a, f16x8 b) {
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) s = fmaf((float)a[k], (float)b[k], s);
@@ -1100,13 +1134,16 @@ extern "C" int gd_attention_fwd(const void* qkv, void* o, float* lse, int B, int
     GD_REQUIRE(B > 0 && N > 0 && H > 0, "gd_attention_fwd: bad shape B=%d N=%d H=%d", B, N, H);
     GD_REQUIRE(head_dim == HD, "gd_attention_fwd: head_dim must be 64 (got %d)", head_dim);
     GD_REQUIRE((long)N * 3 * H * HD * 4 < (1L << 31), "gd_attention_fwd: one image's qkv rows must span < 2^31 bytes (32-bit tile offsets): N=%d H=%d", N, H);
-    GD_REQUIRE(dtype == GD_F32 || dtype == GD_BF16 || dtype == GD_F32X3, "gd_attention_fwd: bad dtype %d", dtype);
+    GD_REQUIRE(dtype == GD_F32 || dtype == GD_BF16 || dtype == GD_F32X3 || dtype == GD_F16, "gd_attention_fwd: bad dtype %d", dtype);
     GD_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)o & 15) == 0, "gd_attention_fwd: pointers must be 16-byte aligned");
     dim3 grid(gd_cdiv(N, 128), H, B);
     const int dma = gd_knobs().attn_dma;   // GD_ATTN_DMA=0: the register-staged forward kernel (A/B testing)
     if (dtype == GD_BF16 && dma)
         { const int ro = gd_knobs().attn_rot;
-          hipLaunchKernelGGL(attn_fwd_dma_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, ro); }
+          hipLaunchKernelGGL(attn_fwd_dma_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, ro); }
+    else if (dtype == GD_F16)        // tf32h engine: fp16 q / k / v / p (TF32's significand), the bf16 kernel's layouts
+        { const int ro = gd_knobs().attn_rot;
+          hipLaunchKernelGGL(attn_fwd_dma_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, (const f16*)qkv, (f16*)o, lse, N, H, scale, ro); }
     else if (dtype == GD_BF16)
         hipLaunchKernelGGL(attn_fwd_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale);
     else if (dtype == GD_F32X3)
@@ -1115,6 +1152,28 @@ extern "C" int gd_attention_fwd(const void* qkv, void* o, float* lse, int B, int
         hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)qkv, (float*)o, lse, N, H, scale);
     GD_LAUNCH_OK();
     return 0;
+}
+
+template <typename T>      // bf16 | f16
+static void attn_bwd_launch16(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, float* delta_ws, int B, int N, int H,
+                              float scale, int grad_order, bool no_dk, hipStream_t s) {
+    dim3 grid(gd_cdiv(N, 128), H, B);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, grid, dim3(256), 0, s, (const T*)qkv, (const T*)o, (const T*)dout, lse, delta_ws, (T*)dqkv, N, H, scale);
+        // 128-key blocks of four waves (two blocks per CU, independent barriers, Q / dO tiles staged twice as often) when the last
+        // 256-key block would be less than half full: N = 1370 pads to 1408 keys instead of 1536 (2.7 % instead of 10.8 %):
+        // backward 1574 -> 1514 us at 64 x 12 x 1370; at N = 6401 (long sweeps, 0.4 % vs 2 % padding) the 8-wave form is 2 % faster.
+        // GD_ATTN_DKV_NW = 4 | 8 forces one form.
+        const int dkv_env = gd_knobs().attn_dkv_nw;
+        const int tail = N % 256;
+        const int dkv_nw = dkv_env ? dkv_env : ((N < 4096 && tail > 0 && tail <= 128) ? 4 : 8);
+        if (no_dk && dkv_nw == 4)
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, 4, false>), dim3(gd_cdiv(N, 128), H, B), dim3(256), 0, s, (const T*)qkv, (const T*)dout, lse, delta_ws, (T*)dqkv, N, H, scale, grad_order);
+        else if (no_dk)
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, 8, false>), dim3(gd_cdiv(N, 256), H, B), dim3(512), 0, s, (const T*)qkv, (const T*)dout, lse, delta_ws, (T*)dqkv, N, H, scale, grad_order);
+        else if (dkv_nw == 4)       // (two-wave 64-key blocks: 2213 us — the staging registers spill and every block re-stages all of Q / dO)
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, 4>), dim3(gd_cdiv(N, 128), H, B), dim3(256), 0, s, (const T*)qkv, (const T*)dout, lse, delta_ws, (T*)dqkv, N, H, scale, grad_order);
+        else
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, 8>), dim3(gd_cdiv(N, 256), H, B), dim3(512), 0, s, (const T*)qkv, (const T*)dout, lse, delta_ws, (T*)dqkv, N, H, scale, grad_order);
 }
 
 extern "C" int gd_attention_bwd(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv,
@@ -1126,29 +1185,16 @@ extern "C" int gd_attention_bwd(const void* qkv, const void* o, const void* dout
     GD_REQUIRE(B > 0 && N > 0 && H > 0, "gd_attention_bwd: bad shape B=%d N=%d H=%d", B, N, H);
     GD_REQUIRE(head_dim == HD, "gd_attention_bwd: head_dim must be 64 (got %d)", head_dim);
     GD_REQUIRE((long)N * 3 * H * HD * 4 < (1L << 31), "gd_attention_bwd: one image's qkv rows must span < 2^31 bytes (32-bit tile offsets): N=%d H=%d", N, H);
-    GD_REQUIRE(dtype == GD_F32 || dtype == GD_BF16 || dtype == GD_F32X3, "gd_attention_bwd: bad dtype %d", dtype);
+    GD_REQUIRE(dtype == GD_F32 || dtype == GD_BF16 || dtype == GD_F32X3 || dtype == GD_F16, "gd_attention_bwd: bad dtype %d", dtype);
     GD_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)dout & 15) == 0 && ((uintptr_t)dqkv & 15) == 0,
                "gd_attention_bwd: pointers must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     GD_REQUIRE(((uintptr_t)o & 15) == 0, "gd_attention_bwd: o must be 16-byte aligned");
     dim3 grid(gd_cdiv(N, 128), H, B);
     if (dtype == GD_BF16) {
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)qkv, (const bf16*)o, (const bf16*)dout, lse, delta_ws, (bf16*)dqkv, N, H, scale);
-        // 128-key blocks of four waves (two blocks per CU, independent barriers, Q / dO tiles staged twice as often) when the last
-        // 256-key block would be less than half full: N = 1370 pads to 1408 keys instead of 1536 (2.7 % instead of 10.8 %):
-        // backward 1574 -> 1514 us at 64 x 12 x 1370; at N = 6401 (long sweeps, 0.4 % vs 2 % padding) the 8-wave form is 2 % faster.
-        // GD_ATTN_DKV_NW = 4 | 8 forces one form.
-        const int dkv_env = gd_knobs().attn_dkv_nw;
-        const int tail = N % 256;
-        const int dkv_nw = dkv_env ? dkv_env : ((N < 4096 && tail > 0 && tail <= 128) ? 4 : 8);
-        if (no_dk && dkv_nw == 4)
-            hipLaunchKernelGGL((attn_bwd_dkv_kernel<bf16, 4, false>), dim3(gd_cdiv(N, 128), H, B), dim3(256), 0, s, (const bf16*)qkv, (const bf16*)dout, lse, delta_ws, (bf16*)dqkv, N, H, scale, grad_order);
-        else if (no_dk)
-            hipLaunchKernelGGL((attn_bwd_dkv_kernel<bf16, 8, false>), dim3(gd_cdiv(N, 256), H, B), dim3(512), 0, s, (const bf16*)qkv, (const bf16*)dout, lse, delta_ws, (bf16*)dqkv, N, H, scale, grad_order);
-        else if (dkv_nw == 4)       // (two-wave 64-key blocks: 2213 us — the staging registers spill and every block re-stages all of Q / dO)
-            hipLaunchKernelGGL((attn_bwd_dkv_kernel<bf16, 4>), dim3(gd_cdiv(N, 128), H, B), dim3(256), 0, s, (const bf16*)qkv, (const bf16*)dout, lse, delta_ws, (bf16*)dqkv, N, H, scale, grad_order);
-        else
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<bf16, 8>), dim3(gd_cdiv(N, 256), H, B), dim3(512), 0, s, (const bf16*)qkv, (const bf16*)dout, lse, delta_ws, (bf16*)dqkv, N, H, scale, grad_order);
+        attn_bwd_launch16<bf16>(qkv, o, dout, lse, dqkv, delta_ws, B, N, H, scale, grad_order, no_dk, s);
+    } else if (dtype == GD_F16) {      // tf32h engine: dout arrives times a power of two (the caller's gd_amax_scale), dqkv leaves with it
+        attn_bwd_launch16<f16>(qkv, o, dout, lse, dqkv, delta_ws, B, N, H, scale, grad_order, no_dk, s);
     } else if (dtype == GD_F32X3) {
         hipLaunchKernelGGL(attn_bwd_dq_kernel<x3>, grid, dim3(256), 0, s, (const x3*)qkv, (const x3*)o, (const x3*)dout, lse, delta_ws, (x3*)dqkv, N, H, scale);
         // four-wave 128-key blocks with the whole register file per wave (the (hi, lo) fragments double the operand registers)

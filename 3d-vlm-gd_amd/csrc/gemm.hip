@@ -423,6 +423,10 @@ __device__ __forceinline__ void load8_as_f32(const void* base, long off, int dt,
         bf16x8 v = *(const bf16x8*)((const bf16*)base + off);
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
+    } else if (dt == GD_F16) {
+        f16x8 v = *(const f16x8*)((const f16*)base + off);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
     } else {
         const f32x4* q = (const f32x4*)((const float*)base + off);
         f32x4 a = q[0], b = q[1];
@@ -607,7 +611,11 @@ __global__ __launch_bounds__(320) void gemm_tn_skinny_kernel(GemmTnParams p) {
     constexpr int U = 8;
     const int kcl = live ? kc : 0;   // threads past K read column 0 (their results are never written): no divergent load
     auto load_x = [&](int m, float (&x)[8]) {
-        if (sizeof(TX) == 2) {
+        if constexpr (std::is_same<TX, f16>::value) {
+            const f16x8 v = *(const f16x8*)((const f16*)X + (long)m * p.ldx + kcl);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x[k] = (float)v[k];
+        } else if (sizeof(TX) == 2) {
             const bf16x8 v = *(const bf16x8*)((const bf16*)X + (long)m * p.ldx + kcl);
 #pragma unroll
             for (int k = 0; k < 8; ++k) x[k] = (float)v[k];
@@ -887,6 +895,7 @@ extern "C" int gd_gemm_tn(const void* Y, const void* X, float* G, int M, int N, 
         p.mchunk = mchunk;
         dim3 grid(1, gd_cdiv(M, mchunk), 1);
         if (x_dtype == GD_BF16) hipLaunchKernelGGL(gemm_tn_skinny_kernel<bf16>, grid, dim3(nth), 0, (hipStream_t)stream, p);
+        else if (x_dtype == GD_F16) hipLaunchKernelGGL(gemm_tn_skinny_kernel<f16>, grid, dim3(nth), 0, (hipStream_t)stream, p);
         else hipLaunchKernelGGL(gemm_tn_skinny_kernel<float>, grid, dim3(nth), 0, (hipStream_t)stream, p);
         GD_LAUNCH_OK();
         return 0;

@@ -25,19 +25,34 @@ from .model import Adapter, BlockWithAdapter, _LoRA_qkv  # noqa: F401
 
 
 def _dt(name):
-    # "tf32x": fp32 storage and arithmetic everywhere except the big frozen-weight GEMMs, which run as 3-term bf16 splits (ops.split3)
-    return {"f32": torch.float32, "bf16": torch.bfloat16, "tf32x": torch.float32, torch.float32: torch.float32,
+    # "tf32x" / "tf32h": fp32 storage and arithmetic everywhere except the matrix products, which take their operands as 3-term bf16 splits
+    # (ops.split3: ~4e-6 products) resp. as fp16 (ops.cast16: TF32's 11-bit significand, one MFMA per term)
+    return {"f32": torch.float32, "bf16": torch.bfloat16, "tf32x": torch.float32, "tf32h": torch.float32, torch.float32: torch.float32,
             torch.bfloat16: torch.bfloat16}[name]
 
 
-def _mm(x, plan, key, xs=None, **kw):
-    """x . W^T with the plan's frozen weight `key`: one GEMM in the f32 / bf16 engines; in the tf32x engine the weight was split once
-    (plan['x3']) and the activation is split on the way in (xs: its split, when the caller already has it) — three bf16 MFMA products
-    per term, fp32 accumulation / output / epilogue."""
-    if plan.get("x3"):
-        if not kw.get("out_split"):
-            kw.setdefault("out_dtype", torch.float32)
-        return ops.gemm_nt(xs if xs is not None else ops.split3(x, "a"), plan[key], **kw)
+def _opa(x, fmt, sc=None):
+    """left operand of a product in the operand format `fmt`: "x3" -> [hi | lo | hi] bf16 planes; "h" -> fp16 (times the power-of-two scale
+    sc[0] of ops.amax_scale for a gradient tensor: the consuming GEMM then takes alpha_dev = sc[1:2])."""
+    return ops.split3(x, "a") if fmt == "x3" else ops.cast16(x, scale_dev=None if sc is None else sc[0:1])
+
+
+def _opw(w, fmt):
+    """right operand (a weight): "x3" -> [hi | hi | lo] bf16 planes; "h" -> fp16."""
+    return ops.split3(w, "w") if fmt == "x3" else ops.cast16(w)
+
+
+def _mm(x, plan, key, xs=None, sc=None, **kw):
+    """x . W^T with the plan's frozen weight `key`: one GEMM in the f32 / bf16 engines; in the tf32x / tf32h engines the weight was put into
+    the operand format once (plan['x3'] = "x3" | "h") and the activation goes in on the way (xs: its formatted copy, when the caller already
+    has it) — fp32 accumulation / output / epilogue.  sc (tf32h, gradients): the ops.amax_scale triple the left operand was / is scaled with."""
+    fmt = plan.get("x3")
+    if fmt:
+        if not kw.get("out_split") and kw.get("out_dtype") is None:
+            kw["out_dtype"] = torch.float32
+        if fmt == "h" and sc is not None and kw.get("out_dtype") != torch.float16:      # an fp16 result stays in the scaled domain
+            kw["alpha_dev"] = sc[1:2]
+        return ops.gemm_nt(xs if xs is not None else _opa(x, fmt, sc), plan[key], **kw)
     return ops.gemm_nt(x, plan[key], **kw)
 
 
@@ -78,14 +93,14 @@ class GDBlock(nn.Module):
         self.mlp = GDMlp(dim, int(dim * mlp_ratio))
         self.ls2 = GDLayerScale(dim, init_values) if init_values else nn.Identity()
         self._plan = None
-        self.split3 = False          # tf32x engine (set by GDViT): frozen weights are kept as 3-term bf16 splits
+        self.split3 = False          # tf32x / tf32h engines (set by GDViT to "x3" / "h"): frozen weights are kept in that operand format
 
     def forward(self, x):
         return run_block(self, x)
 
     # ---- frozen-weight plan: casted / folded / pre-transposed copies, built once per dtype ----
     def plan(self, dtype):
-        x3 = bool(self.split3) and dtype == torch.float32
+        x3 = (("x3" if self.split3 is True else self.split3) or "") if dtype == torch.float32 else ""
         if self._plan is not None and self._plan["dtype"] == dtype and self._plan["x3"] == x3:
             return self._plan
         base = self.attn.qkv.qkv if hasattr(self.attn.qkv, "linear_a_q") else self.attn.qkv      # any _LoRA_qkv-shaped wrapper
@@ -109,8 +124,8 @@ class GDBlock(nn.Module):
         wqkv, w1 = f32(base.weight), f32(self.mlp.fc1.weight)
 
         def both(w):
-            if x3:      # [N, 3K] bf16 planes [hi | hi | lo] of W and of W^T (ops.split3)
-                return ops.split3(w.contiguous(), "w"), ops.split3(w.t().contiguous(), "w")
+            if x3:      # [N, 3K] bf16 planes [hi | hi | lo] of W and of W^T (ops.split3), or their fp16 casts
+                return _opw(w.contiguous(), x3), _opw(w.t().contiguous(), x3)
             return w.to(dtype).contiguous(), w.t().to(dtype).contiguous()
 
         p = {"dtype": dtype, "x3": x3, "D": D, "H": self.attn.num_heads, "eps1": self.norm1.eps, "eps2": self.norm2.eps,
@@ -122,7 +137,7 @@ class GDBlock(nn.Module):
         p["wqkv"], p["wqkv_t"] = both(wqkv)
         # the attention backward hands back (dq, dv, dk): W^T with its K blocks in that order for dX = dqkv . W
         wqvk_t = torch.cat([wqkv[:D], wqkv[2 * D:], wqkv[D:2 * D]], 0).t().contiguous()
-        p["wqkv_t_qvk"] = ops.split3(wqvk_t, "w") if x3 else wqvk_t.to(dtype).contiguous()
+        p["wqkv_t_qvk"] = _opw(wqvk_t, x3) if x3 else wqvk_t.to(dtype).contiguous()
         p["wproj"], p["wproj_t"] = both(wproj)
         p["w1"], p["w1_t"] = both(w1)
         p["w2"], p["w2_t"] = both(wfc2)
@@ -162,20 +177,28 @@ class _BlockFn(torch.autograd.Function):
                 bt[:r, :D] = b_q.detach().t()
                 bt[r:, 2 * D:] = b_v.detach().t()
                 at_T = at.to(T).contiguous()
-        y1s = ops.split3(y1, "a") if plan["x3"] else None                     # tf32x: ONE split of LN1(x) feeds the LoRA-A and the QKV GEMM
+        fmt = plan["x3"]
+        y1s = _opa(y1, fmt) if fmt else None                     # tf32x / tf32h: ONE formatted copy of LN1(x) feeds the LoRA-A and the QKV GEMM
         if a_q is not None:
             if plan["x3"]:     # [M, 2r] on the streaming N <= 8 bf16 kernel over the 3K-wide operands (the fp32 tile kernel spends a 128-wide tile on 8 columns)
-                t = ops.gemm_nt(y1s, ops.split3(at.contiguous(), "w"), out_dtype=torch.float32)
+                t = ops.gemm_nt(y1s, _opw(at.contiguous(), fmt), out_dtype=torch.float32)
             else:
                 t = ops.gemm_nt(y1, at_T, out_dtype=torch.float32)  # [M, 2r]
-        qkv = _mm(y1, plan, "wqkv", xs=y1s, bias=plan["bqkv"], lora_t=t, lora_b=bt)
-        o, lse = ops.attention_fwd(qkv, B, Nt, H, x3=plan["x3"])
-        x1 = _mm(o, plan, "wproj", bias=plan["bproj"], residual=x)
+        if fmt == "h":     # tf32h: q / k / v, the attention output and their gradients live as fp16 — they are operands of matrix products only
+            qkv = _mm(y1, plan, "wqkv", xs=y1s, bias=plan["bqkv"], lora_t=t, lora_b=bt, out_dtype=torch.float16)
+            o, lse = ops.attention_fwd(qkv, B, Nt, H)
+            x1 = _mm(None, plan, "wproj", xs=o, bias=plan["bproj"], residual=x)
+        else:
+            qkv = _mm(y1, plan, "wqkv", xs=y1s, bias=plan["bqkv"], lora_t=t, lora_b=bt)
+            o, lse = ops.attention_fwd(qkv, B, Nt, H, x3=bool(fmt))
+            x1 = _mm(o, plan, "wproj", bias=plan["bproj"], residual=x)
         y2, mean2, rstd2 = ops.layernorm_fwd(x1, plan["ln2_w"], plan["ln2_b"], plan["eps2"], save_stats=need)
         pre = torch.empty(M, plan["w1"].shape[0], dtype=T, device=x.device) if need else None
         # tf32x: fc1 writes GELU(.) directly as the split left operand of fc2 (no f32 [M, 4D] round trip + split pass)
-        hs = plan["x3"] and ops.split_out_ok(M, plan["w1"].shape[0], plan["w1"].shape[1])
-        h = _mm(y2, plan, "w1", bias=plan["b1"], act=3, preact=pre, out_split=hs)   # pre <- GELU'(fc1 output): all the backward needs
+        # (tf32h: as fp16)
+        hs = bool(fmt) and ops.split_out_ok(M, plan["w1"].shape[0], plan["w1"].shape[1])
+        hkw = {} if not hs else {"out_split": True} if fmt == "x3" else {"out_dtype": torch.float16}
+        h = _mm(y2, plan, "w1", bias=plan["b1"], act=3, preact=pre, **hkw)   # pre <- GELU'(fc1 output): all the backward needs
         x2 = _mm(None if hs else h, plan, "w2", xs=h if hs else None, bias=plan["b2"], residual=x1)
         out, hd = x2, None
         if down is not None:
@@ -184,10 +207,10 @@ class _BlockFn(torch.autograd.Function):
             if ops.adapter_fused_supported(x2, down.shape[0]):
                 out, hd = ops.adapter_fused(x2, down_T, up_T, save_hidden=need)
             elif plan["x3"]:        # tf32x: both projections as split-precision products on the bf16 kernels (the fp32 tile kernel: 2 x 370 us)
-                w_dn = tw["down_w3"] if tw is not None and "down_w3" in tw else ops.split3(down_T, "w")
-                w_up = tw["up_w3"] if tw is not None and "up_w3" in tw else ops.split3(up_T, "w")
-                hd = ops.gemm_nt(ops.split3(x2, "a"), w_dn, act=2, out_dtype=torch.float32)
-                out = ops.gemm_nt(ops.split3(hd, "a"), w_up, residual=x2, out_dtype=torch.float32)
+                w_dn = tw["down_w3"] if tw is not None and "down_w3" in tw else _opw(down_T, fmt)
+                w_up = tw["up_w3"] if tw is not None and "up_w3" in tw else _opw(up_T, fmt)
+                hd = ops.gemm_nt(_opa(x2, fmt), w_dn, act=2, out_dtype=torch.float32)
+                out = ops.gemm_nt(_opa(hd, fmt), w_up, residual=x2, out_dtype=torch.float32)
             else:
                 hd = ops.gemm_nt(x2, down_T, act=2)
                 out = ops.gemm_nt(hd, up_T, residual=x2)
@@ -207,6 +230,10 @@ class _BlockFn(torch.autograd.Function):
         g_down = g_up = g_aq = g_bq = g_av = g_bv = None
         dx2 = dout
         tw = ctx.tw
+        fmt = plan["x3"]
+        # tf32h: ONE power-of-two scale per block, from the incoming gradient's maximum (on the device), carries every gradient operand of
+        # the block into fp16's range: |dout| * s <= 64 leaves 2^10 of headroom above and 2^20 of full-precision range below
+        sc = ops.amax_scale(dout.view(-1, D), 64.0) if fmt == "h" else None
         # the four weight-gradient accumulators of the block come out of ONE zero-filled buffer
         bott = down.shape[0] if ctx.has_ad else 0
         r2 = at.shape[0] if ctx.has_lora else 0
@@ -224,40 +251,49 @@ class _BlockFn(torch.autograd.Function):
             if ops.adapter_fused_supported(dout, bott):
                 dx2, dhp = ops.adapter_fused(dout, up_tT, down_tT, gate_src=hd)                   # dX and d(hidden) [M, 64]
             elif plan["x3"]:
-                w_ut = tw["up_tw3"] if tw is not None and "up_tw3" in tw else ops.split3(up_tT, "w")
-                w_dt = tw["down_tw3"] if tw is not None and "down_tw3" in tw else ops.split3(down_tT, "w")
-                dhp = ops.gemm_nt(ops.split3(dout, "a"), w_ut, dact_src=hd, dact=2, out_dtype=torch.float32)
-                dx2 = ops.gemm_nt(ops.split3(dhp, "a"), w_dt, residual=dout, out_dtype=torch.float32)
+                w_ut = tw["up_tw3"] if tw is not None and "up_tw3" in tw else _opw(up_tT, fmt)
+                w_dt = tw["down_tw3"] if tw is not None and "down_tw3" in tw else _opw(down_tT, fmt)
+                ad = None if sc is None else sc[1:2]
+                dhp = ops.gemm_nt(_opa(dout.view(-1, D), fmt, sc), w_ut, dact_src=hd, dact=2, out_dtype=torch.float32, alpha_dev=ad)
+                dx2 = ops.gemm_nt(_opa(dhp, fmt, sc), w_dt, residual=dout.view(-1, D), out_dtype=torch.float32, alpha_dev=ad)
             else:
                 dhp = ops.gemm_nt(dout, up_tT, dact_src=hd, dact=2)                               # [M, 64]
                 dx2 = ops.gemm_nt(dhp, down_tT, residual=dout)
             g_up = ops.gemm_tn(dout, hd, out=z_up)                                                # [D, 64]
             g_down = ops.gemm_tn(dhp, x2, out=z_down)                                             # [64, D]
-        hs = plan["x3"] and ops.split_out_ok(dx2.shape[0], plan["w2_t"].shape[0], plan["w2_t"].shape[1])
-        dpre = _mm(dx2, plan, "w2_t", dact_src=pre, dact=3, out_split=hs)                         # [M, 4D] (x stored GELU')
-        dy2 = _mm(None if hs else dpre, plan, "w1_t", xs=dpre if hs else None)
+        hs = bool(fmt) and ops.split_out_ok(dx2.shape[0], plan["w2_t"].shape[0], plan["w2_t"].shape[1])
+        hkw = {} if not hs else {"out_split": True} if fmt == "x3" else {"out_dtype": torch.float16}      # (tf32h: fp16, still times s)
+        dpre = _mm(dx2, plan, "w2_t", sc=sc, dact_src=pre, dact=3, **hkw)                         # [M, 4D] (x stored GELU')
+        dy2 = _mm(None if hs else dpre, plan, "w1_t", xs=dpre if hs else None, sc=sc)
         del dpre
         dx1 = ops.layernorm_bwd(dy2, x1, plan["ln2_w"], mean2, rstd2, dres=dx2)
-        do = _mm(dx1, plan, "wproj_t")
+        do = _mm(dx1, plan, "wproj_t", sc=sc, **({"out_dtype": torch.float16} if fmt == "h" else {}))      # (tf32h: fp16, times s)
         # gradient columns come back as (dq, dv, dk): the q / v LoRA factors only ever touch the first two thirds
         # the first trainable block: no gradient flows below it, dK has no consumer (the LoRA factors contract dq and dv only)
-        dqkv = ops.attention_bwd(qkv, o, do, lse, B, Nt, H, vfirst=True, need_dk=bool(ctx.needs_input_grad[0]), x3=plan["x3"])
+        dqkv = ops.attention_bwd(qkv, o, do, lse, B, Nt, H, vfirst=True, need_dk=bool(ctx.needs_input_grad[0]), x3=fmt == "x3")
         if ctx.has_lora:
             r = at.shape[0] // 2
             bt_T = tw["bt_T"] if tw is not None else bt.to(T).contiguous()
             bt_qv = tw["bt_qv"] if tw is not None else torch.cat([bt_T[:, :D], bt_T[:, 2 * D:]], 1).contiguous()   # [2r, 2D]
             dqv = dqkv[:, :2 * D]
-            if plan["x3"]:
+            if fmt:
+                ad = None if sc is None else sc[1:2]
                 if ctx.needs_input_grad[0]:
                     # tf32x: dt = dqv . Bt^T on the split of the WHOLE dqkv row (the dX GEMM below needs that split anyway) against
                     # [Bt_q | Bt_v | 0] — the dk third contributes zeros; bf16 tile kernel instead of the fp32 one
-                    dqkv_s = ops.split3(dqkv, "a")
+                    dqkv_s = dqkv if fmt == "h" else _opa(dqkv, fmt, sc)           # (tf32h: already fp16, already times s)
                     btz = torch.zeros(bt_qv.shape[0], 3 * D, dtype=torch.float32, device=dqkv.device)
                     btz[:, :2 * D] = bt_qv
-                    dt = ops.gemm_nt(dqkv_s, ops.split3(btz, "w"), out_dtype=torch.float32)      # [M, 2r]
+                    dt = ops.gemm_nt(dqkv_s, _opw(btz, fmt), out_dtype=torch.float32, alpha_dev=ad)      # [M, 2r]
                 else:      # first trainable block: the dk third of dqkv was never written — split the (dq, dv) view only
-                    dt = ops.gemm_nt(ops.split3(dqv, "a"), ops.split3(bt_qv.contiguous(), "w"), out_dtype=torch.float32)
-                gbt = ops.gemm_tn(t, dqv, out=z_bt)                                               # [2r, 2D]
+                    dt = ops.gemm_nt(dqv if fmt == "h" else _opa(dqv, fmt, sc), _opw(bt_qv.contiguous(), fmt), out_dtype=torch.float32,
+                                     alpha_dev=ad)
+                if fmt == "h":       # dqv carries the block's scale s: contract into a scratch and add it unscaled
+                    gs = ops.gemm_tn(t, dqv)
+                    z_bt.add_(gs * sc[1])
+                    gbt = z_bt
+                else:
+                    gbt = ops.gemm_tn(t, dqv, out=z_bt)                                           # [2r, 2D]
             elif ops.lora_bwd_fused_supported(dqv, t, bt_qv, z_bt):
                 dt = ops.lora_bwd_fused(dqv, t, bt_qv, z_bt)                                      # both products, one pass over dqv
                 gbt = z_bt
@@ -275,9 +311,9 @@ class _BlockFn(torch.autograd.Function):
         if not ctx.needs_input_grad[0]:   # first trainable block: nothing below it learns, skip dX (one GEMM + one LN backward)
             return None, None, None, None, g_aq, g_bq, g_av, g_bv, g_down, g_up
         if ctx.has_lora:
-            dy1 = _mm(dqkv, plan, "wqkv_t_qvk", xs=dqkv_s if plan["x3"] else None, lora_t=dt, lora_b=at.contiguous())   # dqkv.W + dt.At
+            dy1 = _mm(dqkv, plan, "wqkv_t_qvk", xs=dqkv_s if fmt else None, sc=sc, lora_t=dt, lora_b=at.contiguous())   # dqkv.W + dt.At
         else:
-            dy1 = _mm(dqkv, plan, "wqkv_t_qvk")
+            dy1 = _mm(dqkv, plan, "wqkv_t_qvk", sc=sc)
         dx = ops.layernorm_bwd(dy1, x, plan["ln1_w"], mean1, rstd1, dres=dx1)
         return dx, None, None, None, g_aq, g_bq, g_av, g_bv, g_down, g_up
 
@@ -402,9 +438,10 @@ class GDViT(nn.Module):
         self.dtype = _dt(dtype)
         # tf32x: TF32-class GEMMs on the bf16 matrix cores (gfx950 has no TF32 MFMA; the reference's MASt3R path computes its matmuls in
         # TF32, dust3r/croco/models/croco.py:12): fp32 everywhere, the eight big frozen-weight GEMMs of a block as 3-term bf16 splits
-        self.gemm_split3 = dtype == "tf32x"
+        self.opfmt = {"tf32x": "x3", "tf32h": "h"}.get(dtype, "")
+        self.gemm_split3 = bool(self.opfmt)
         for blk in self.blocks:
-            blk.split3 = self.gemm_split3
+            blk.split3 = self.opfmt
         self._pos_cache = {}
         self._pe_plan = None
         # dtype of the final-normed tap grids that feed the keypoint features (None = the engine dtype).  torch.float32 keeps
@@ -488,8 +525,8 @@ class GDViT(nn.Module):
             at_T, bt_T, down_T, up_T = at.to(T), bt.to(T), down.to(T), up.to(T)
             bt_qv = torch.cat([bt_T[:, :, :D], bt_T[:, :, 2 * D:]], 2).contiguous()      # [L, 2r, 2D]: the (dq, dv) column order
             down_tT, up_tT = down_T.transpose(1, 2).contiguous(), up_T.transpose(1, 2).contiguous()
-            if getattr(self, "gemm_split3", False):      # tf32x: the adapter weights as right-hand split operands (four small passes per step)
-                w3 = lambda w: ops.split3(w.reshape(-1, w.shape[-1]).contiguous(), "w").view(L, w.shape[1], 3 * w.shape[2])
+            if getattr(self, "gemm_split3", False):      # tf32x / tf32h: the adapter weights as right-hand operands (four small passes per step)
+                w3 = lambda w: _opw(w.reshape(-1, w.shape[-1]).contiguous(), self.opfmt).view(L, w.shape[1], -1)
                 for i, pack in enumerate(zip(w3(down_T), w3(up_T), w3(down_tT), w3(up_tT))):
                     extra[i].update(zip(("down_w3", "up_w3", "down_tw3", "up_tw3"), pack))
         for i, (inner, _, _) in enumerate(lo):

@@ -37,7 +37,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "tf32x": 2500.0 / 3}   # dense MFMA peaks, MI355X_MICROARCH.md; tf32x: three bf16 MFMAs per product
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "tf32x": 2500.0 / 3, "tf32h": 2500.0}   # dense MFMA peaks, MI355X_MICROARCH.md; tf32x: three bf16 MFMAs per product
 PEAK_HBM_GBS = 8000.0
 PATCH = 14
 
@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--config", default=None, help="a reference yaml (config/finetune_timm_*.yaml): variant and loss "
                     "weights are taken from it (gd_amd.config); explicit flags below win")
     ap.add_argument("--pairs-per-gpu", type=int, default=32)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "tf32x"],
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "tf32x", "tf32h"],
                     help="engine dtype: bf16 (headline), f32 (exact-f32 MFMA: the reference's fp32 arithmetic), tf32x (fp32 storage, the big "
                          "GEMMs as 3-term bf16 splits: TF32-class, what the reference's MASt3R path computes its matmuls in)")
     ap.add_argument("--variant", default=None, choices=["mast3r", "vggt"])
@@ -159,14 +159,15 @@ class Job:
 def gemm_roofline(prof, dtype, dt, steps):
     # the dominant kernel: the 256x256 persistent MFMA kernel (bf16: every gd_gemm_nt launch with M >= 1024, N >= 256);
     # the N <= 8 LoRA projections run on an HBM-bound streaming kernel and are not part of this figure
-    big = (lambda t: t[0] >= 1024 and t[1] >= 256 and t[6] == "bfloat16" and "+" not in t[4]) if dtype in ("bf16", "tf32x") else None
+    big = (lambda t: t[0] >= 1024 and t[1] >= 256 and t[6] in ("bfloat16", "float16") and "+" not in t[4]) if dtype in ("bf16", "tf32x", "tf32h") else None
     fl, ms, n = prof.totals(big)
     if dtype == "tf32x":
         fl /= 3.0            # the profiler sees the 3K-wide bf16 GEMMs: algorithmic FLOPs = executed / 3
     ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     kname = {"bf16": "gemm_nt_persist_kernel<bf16> (256x256 persistent tile kernel, all epilogue instantiations)",
              "f32": "gemm_nt_kernel<float> (128x128 tiles, exact-f32 MFMA v_mfma_f32_16x16x4_f32)",
-             "tf32x": "bf16 256x256 tile kernels on 3-term split operands (gd_split3): algorithmic FLOPs, peak = bf16 MFMA peak / 3"}[dtype]
+             "tf32x": "bf16 256x256 tile kernels on 3-term split operands (gd_split3): algorithmic FLOPs, peak = bf16 MFMA peak / 3",
+             "tf32h": "gemm_nt_persist_kernel<f16> (256x256 persistent tile kernel on fp16 operands: TF32's significand, one MFMA per term)"}[dtype]
     out = {"kernel": kname, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
            "frac": round(ach / PEAK_TFLOPS[dtype], 4), "traffic": None, "launches": n,
            "avg_launch_us": round(ms / max(n, 1) * 1e3, 2), "share_of_step": round(ms / (dt * 1e3), 3)}

@@ -96,3 +96,31 @@ def test_attention_split_precision(B, N, H):
     assert torch.equal(d2[:, :D], dqkv[:, :D]) and torch.equal(d2[:, D:2 * D], dqkv[:, 2 * D:]) and torch.equal(d2[:, 2 * D:], dqkv[:, D:2 * D])
     d3 = ops.attention_bwd(qkv, o, dout, lse, B, N, H, vfirst=True, need_dk=False, x3=True)
     assert torch.equal(d3[:, :2 * D], d2[:, :2 * D])
+
+
+def test_attention_fp16_operands():
+    """dtype GD_F16 (tf32h engine): the bf16 kernels' layouts on fp16 q / k / v / p — TF32's significand.  Output, lse and gradients against
+    the fp64 reference of the same fp16-rounded inputs: an order of magnitude inside the bf16 kernels' error; a gradient-sized dout goes in
+    times a power of two and the gradients come back with it (linear in dout); nothing overflows to inf."""
+    from gd_amd import ops
+    B, N, H = 2, 1370, 12
+    g = torch.Generator(device="cuda").manual_seed(0)
+    qkv32 = torch.randn(B * N, 3 * H * 64, generator=g, device="cuda")
+    do32 = torch.randn(B * N, H * 64, generator=g, device="cuda") * 1e-6
+    s = 2.0 ** 24
+    qkv, do = qkv32.half(), (do32 * s).half()
+    o, lse = ops.attention_fwd(qkv, B, N, H)
+    dqkv = ops.attention_bwd(qkv, o, do, lse, B, N, H)
+    assert o.dtype == torch.float16 and dqkv.dtype == torch.float16 and bool(torch.isfinite(dqkv.float()).all())
+    q, k, v = [t.reshape(B, N, H, 64).permute(0, 2, 1, 3).double().requires_grad_(True) for t in qkv.float().view(B * N, 3, H * 64).unbind(1)]
+    sc = (q @ k.transpose(-1, -2)) * 64 ** -0.5
+    ref = torch.softmax(sc, -1) @ v
+    ref_o = ref.permute(0, 2, 1, 3).reshape(B * N, H * 64)
+    ref_o.backward(do.double() / s)
+    ref_lse = torch.logsumexp(sc, -1)
+    assert rel_err(o, ref_o.detach()) < 1e-3 and rel_err(lse, ref_lse.detach()) < 1e-4
+    got = dqkv.double().view(B * N, 3, H, 64) / s
+    for i, t in enumerate((q, k, v)):
+        assert rel_err(got[:, i], t.grad.permute(0, 2, 1, 3).reshape(B * N, H, 64)) < 2e-3, i
+    ob, _ = ops.attention_fwd(qkv32.bfloat16(), B, N, H)
+    assert rel_err(o, ref_o.detach()) < 0.25 * rel_err(ob, ref_o.detach())

@@ -163,6 +163,26 @@ def test_full_step_tf32x_matches_oracle():
     assert plan["x3"] and plan["wqkv"].dtype == torch.bfloat16 and plan["wqkv"].shape == (3 * 64, 3 * 64)
 
 
+def test_full_step_tf32h_matches_oracle():
+    """The tf32h engine (fp32 storage; every big product takes its operands as fp16 = TF32's 11-bit significand, one MFMA per term, gradient
+    operands under a per-block power-of-two scale taken on the device) on the toy student: loss 1e-4, gradients 1e-2 of the fp64 oracle —
+    the accuracy class of the TF32 arithmetic the reference's MASt3R path runs in (dust3r/croco/models/croco.py:12)."""
+    P, h, w, N = 2, 56, 70, 12
+    eng = _engine("vggt", "shared", "tf32h", teacher_patch=14)
+    assert eng.model.gemm_split3 and eng.model.opfmt == "h" and eng.model.dtype == torch.float32
+    batch = synthetic_batch(P, h, w, N, 20, "cuda", seed=3, counts=[12, 9])
+    ref_loss, ref_terms, ref_grads, _, ref_norm = _oracle_step(eng, batch, P)
+    eng.configure_optimizers()
+    loss, terms = eng.training_step(batch)
+    eng.backward(loss)
+    assert abs(loss.item() - ref_loss) < 1e-4 * abs(ref_loss)
+    g_hip = torch.cat([q.grad.detach().double().cpu().reshape(-1) for q in eng.trainable_parameters()])
+    g_ref = torch.cat([g.reshape(-1) for g in ref_grads])
+    assert bool(torch.isfinite(g_hip).all()) and float((g_hip - g_ref).norm() / g_ref.norm()) < 1e-2
+    plan = eng.model.blocks[5].block.plan(torch.float32)
+    assert plan["x3"] == "h" and plan["wqkv"].dtype == torch.float16 and plan["wqkv"].shape == (3 * 64, 64)
+
+
 @pytest.mark.parametrize("variant,geometry", [("vggt", "shared"), ("mast3r", "shared"), ("vggt", "reference")])
 def test_full_step_f32_matches_oracle(variant, geometry):
     P, h, w, N = 2, 56, 70, 12
