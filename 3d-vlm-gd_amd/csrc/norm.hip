@@ -18,6 +18,9 @@ template <> __device__ __forceinline__ void store4n<float>(float* p, f32x4 v) { 
 template <> __device__ __forceinline__ void store4n<bf16>(bf16* p, f32x4 v) {
     *(bf16x4*)p = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
 }
+template <> __device__ __forceinline__ void store4n<f16>(f16* p, f32x4 v) {      // tf32h operands: saturated
+    *(f16x4*)p = f16x4{from_f32<f16>(v[0]), from_f32<f16>(v[1]), from_f32<f16>(v[2]), from_f32<f16>(v[3])};
+}
 
 template <typename T, typename TO, int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* x, const float* gamma, const float* beta, TO* y,
@@ -66,10 +69,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* x, const float* ga
 template <typename T, typename TD, int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* dy, const T* x, const float* gamma, const float* mean,
                                                      const float* rstd, const T* dres, const T* dres2, T* dx, int M, int D,
-                                                     long ldd, long ldx, float dyscale) {
+                                                     long ldd, long ldx, float dyscale, f16* dx16 = nullptr, const float* sdev = nullptr) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const float mu = mean[row], rs = rstd[row];
+    const float s16 = (dx16 && sdev) ? *sdev : 1.0f;      // gd_layernorm_bwd_cast: dx also leaves as fp16(dx * s), the next product's operand
     const T* xr = x + (long)row * ldx;
     const TD* dr = dy + (long)row * ldd;
     f32x4 xh[NV], g[NV];
@@ -109,6 +113,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* dy, const T* x, c
                 for (int k = 0; k < 4; ++k) o[k] += r[k];
             }
             store4n<T>(or_ + c, o);
+            if (dx16) store4n<f16>(dx16 + (long)row * D + c, o * s16);
         }
     }
 }
@@ -257,6 +262,7 @@ extern "C" int gd_layernorm_fwd(const void* x, const float* gamma, const float* 
 #define F_BB(NV) hipLaunchKernelGGL((ln_fwd_kernel<bf16, bf16, NV>), grid, blk, 0, s, (const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, M, D, ldx, ldy, eps)
 #define F_BF(NV) hipLaunchKernelGGL((ln_fwd_kernel<bf16, float, NV>), grid, blk, 0, s, (const bf16*)x, gamma, beta, (float*)y, mean, rstd, M, D, ldx, ldy, eps)
 #define F_FF(NV) hipLaunchKernelGGL((ln_fwd_kernel<float, float, NV>), grid, blk, 0, s, (const float*)x, gamma, beta, (float*)y, mean, rstd, M, D, ldx, ldy, eps)
+#define F_FH(NV) hipLaunchKernelGGL((ln_fwd_kernel<float, f16, NV>), grid, blk, 0, s, (const float*)x, gamma, beta, (f16*)y, mean, rstd, M, D, ldx, ldy, eps)
     const int ln16 = gd_knobs().ln_16b;
     const bool wide = ln16 && dtype == GD_BF16 && y_dtype == GD_BF16 && D % 8 == 0 && D <= 1024 && ldx % 8 == 0 && ldy % 8 == 0 &&
                       ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)gamma % 16) == 0 && ((uintptr_t)beta % 16) == 0;
@@ -265,6 +271,7 @@ extern "C" int gd_layernorm_fwd(const void* x, const float* gamma, const float* 
     else if (dtype == GD_BF16 && y_dtype == GD_BF16) LN_DISPATCH_NV(D, F_BB);
     else if (dtype == GD_BF16 && y_dtype == GD_F32) LN_DISPATCH_NV(D, F_BF);
     else if (dtype == GD_F32 && y_dtype == GD_F32) LN_DISPATCH_NV(D, F_FF);
+    else if (dtype == GD_F32 && y_dtype == GD_F16) LN_DISPATCH_NV(D, F_FH);      // tf32h engine: LN(x) is only ever a product operand
     else {
         gd_set_error("gd_layernorm_fwd: unsupported dtype pair %d -> %d", dtype, y_dtype);
         return -1;
@@ -296,6 +303,21 @@ extern "C" int gd_layernorm_bwd(const void* dy, const void* x, const float* gamm
         gd_set_error("gd_layernorm_bwd: unsupported dtype pair x=%d dy=%d", dtype, dy_dtype);
         return -1;
     }
+    GD_LAUNCH_OK();
+    return 0;
+}
+
+// fp32 LayerNorm backward that ALSO writes fp16(dx * *scale_dev) [M, D] (contiguous): the tf32h engine's next product takes dx as its left
+// operand under the block's power-of-two gradient scale (gd_amax_scale) — one pass instead of backward + gd_cast_f16.
+extern "C" int gd_layernorm_bwd_cast(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                     const float* dres, const float* dres2, float* dx, void* dx16, const float* scale_dev, int M, int D,
+                                     long ldd, long ldx, float dyscale, void* stream) {
+    GD_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * LN_MAXV, "gd_layernorm_bwd_cast: D=%d must be a multiple of 4 and <= 2048", D);
+    GD_REQUIRE(ldx % 4 == 0 && ldd % 4 == 0 && dx16 != nullptr, "gd_layernorm_bwd_cast: row strides must be multiples of 4 elements; dx16 required");
+    dim3 grid(gd_cdiv(M, 4)), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+#define B_FH(NV) hipLaunchKernelGGL((ln_bwd_kernel<float, float, NV>), grid, blk, 0, s, dy, x, gamma, mean, rstd, dres, dres2, dx, M, D, ldd, ldx, dyscale, (f16*)dx16, scale_dev)
+    LN_DISPATCH_NV(D, B_FH);
     GD_LAUNCH_OK();
     return 0;
 }

@@ -378,9 +378,19 @@ def layernorm_fwd(x, gamma, beta, eps, *, save_stats=True, out_dtype=None):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, dyscale=1.0, dres2=None):
-    """dx [M,D] (dtype of x) = LN'(dy * dyscale) (+ dres) (+ dres2)."""
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, dyscale=1.0, dres2=None, cast_scale=None):
+    """dx [M,D] (dtype of x) = LN'(dy * dyscale) (+ dres) (+ dres2).  cast_scale (fp32 tensors; a device scalar, e.g. amax_scale(...)[0:1]):
+    also returns fp16(dx * cast_scale) — (dx, dx16) — the tf32h engine's next left operand, from the same pass."""
     M, D = x.shape
+    if cast_scale is not None:
+        _req(x.is_contiguous() and x.dtype == torch.float32 and dy.dtype == torch.float32 and dy.stride(-1) == 1 and
+             all(t is None or (t.is_contiguous() and t.dtype == x.dtype and t.numel() == x.numel()) for t in (dres, dres2)),
+             "layernorm_bwd(cast_scale=): fp32 tensors, contiguous")
+        dx = torch.empty_like(x)
+        dx16 = torch.empty(M, D, dtype=torch.float16, device=x.device)
+        check(lib().gd_layernorm_bwd_cast(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dres2), ptr(dx), ptr(dx16),
+                                          ptr(cast_scale), M, D, dy.stride(0), x.stride(0), float(dyscale), stream()), "gd_layernorm_bwd_cast")
+        return dx, dx16
     _req(x.is_contiguous() and dy.stride(-1) == 1 and all(t is None or (t.is_contiguous() and t.dtype == x.dtype and
                                                                         t.numel() == x.numel()) for t in (dres, dres2)),
          "layernorm_bwd: layout")

@@ -275,6 +275,11 @@ int gd_split3(const float* in, void* out, long rows, int K, long ld_in, int whic
  * gd_gemm_nt_scaled: gd_gemm_nt with alpha multiplied by the device scalar *alpha_dev (the 1/s of a scaled operand) — no host round trip.
  * gd_gemm_nt itself takes ab_dtype GD_F16 (f32 results, or c_dtype GD_F16: an fp16 C beside f32 preact / dact_src). */
 int gd_cast_f16(const float* in, void* out, long rows, int K, long ld_in, float scale, const float* scale_dev, void* stream);
+/* gd_layernorm_fwd with y_dtype GD_F16 (f32 rows in): LN(x) written as the fp16 operand directly.  gd_layernorm_bwd_cast: the f32 backward
+ * that also writes dx16 [M, D] = fp16(sat(dx * *scale_dev)) — backward + gd_cast_f16 in one pass. */
+int gd_layernorm_bwd_cast(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                          const float* dres, const float* dres2, float* dx, void* dx16, const float* scale_dev, int M, int D,
+                          long ldd, long ldx, float dyscale, void* stream);
 int gd_amax_scale(const float* in, long rows, int K, long ld_in, float target, float* scale3, void* stream);
 int gd_gemm_nt_scaled(const void* A, const void* W, void* C, int M, int N, int K, long lda, long ldw, long ldc,
                       int batch, long sA, long sW, long sC, int ab_dtype, int c_dtype, float alpha, const float* alpha_dev,
