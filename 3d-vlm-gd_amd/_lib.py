@@ -30,6 +30,8 @@ SIGNATURES = {
                                   c_void_p, c_long, c_int, c_void_p, c_long, c_int, c_void_p]),
     "gd_layernorm_bwd_cast": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_int, c_int, c_long, c_long, c_float, c_void_p]),
+    "gd_gemm_tn_scaled": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_long, c_long,
+                                  c_int, c_long, c_long, c_long, c_int, c_int, c_float, c_void_p, c_void_p]),
     "gd_cast_f16": (c_int, [c_void_p, c_void_p, c_long, c_int, c_long, c_float, c_void_p, c_void_p]),
     "gd_amax_scale": (c_int, [c_void_p, c_long, c_int, c_long, c_float, c_void_p, c_void_p]),
     "gd_gemm_tn": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_long, c_long,

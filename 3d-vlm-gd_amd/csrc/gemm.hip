@@ -410,6 +410,7 @@ struct GemmTnParams {
     int y_dtype, x_dtype;
     int mchunk;
     float alpha;
+    const float* alpha_dev;   // device scalar multiplied into alpha (gd_gemm_tn_scaled), or null
     long sY, sX, sG;   // batch strides in elements (grid.z = batch)
 };
 
@@ -496,7 +497,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnParams p) {
             for (int r = 0; r < 4; ++r) {
                 const int n = tn * TN_ + wy * 32 + i * 16 + (lane >> 4) * 4 + r;
                 const int k = tk * TK_ + wx * 32 + j * 16 + (lane & 15);
-                if (n < p.N && k < p.K) atomicAdd(p.G + (long)n * p.ldg + k, p.alpha * acc[i][j][r]);
+                if (n < p.N && k < p.K) atomicAdd(p.G + (long)n * p.ldg + k, (p.alpha_dev ? p.alpha * *p.alpha_dev : p.alpha) * acc[i][j][r]);
             }
 }
 
@@ -517,6 +518,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int rowb, int col0, 
     return __builtin_bit_cast(bf16x8, z);
 }
 
+template <typename T>       // bf16 | f16
 __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmTnParams p) {
     constexpr int ROWB = 272;   // 128 bf16 + 16 B pad
     __shared__ __attribute__((aligned(16))) char sY[64 * ROWB];
@@ -530,9 +532,11 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmTnParams p) {
     const int tile = t % (int)gridDim.x, mc = t / (int)gridDim.x;
     const int tn = tile % tiles_n, tk = tile / tiles_n;
     const int m_begin = mc * p.mchunk, m_end = min(p.M, m_begin + p.mchunk);
-    const bf16* Y = (const bf16*)p.Y + (long)blockIdx.z * p.sY;
-    const bf16* X = (const bf16*)p.X + (long)blockIdx.z * p.sX;
+    const T* Y = (const T*)p.Y + (long)blockIdx.z * p.sY;
+    const T* X = (const T*)p.X + (long)blockIdx.z * p.sX;
     float* G = p.G + (long)blockIdx.z * p.sG;
+    typedef typename Mma<T>::Frag Frag;
+    const float alpha = p.alpha_dev ? p.alpha * *p.alpha_dev : p.alpha;
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -563,16 +567,16 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmTnParams p) {
         if (m0 + 64 < m_end) gload(m0 + 64);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            bf16x8 a[4], b[4];
+            Frag a[4], b[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                a[t] = tr_frag(sY, ROWB, wy * 64 + t * 16, u, lane);
-                b[t] = tr_frag(sX, ROWB, wx * 64 + t * 16, u, lane);
+                a[t] = __builtin_bit_cast(Frag, tr_frag(sY, ROWB, wy * 64 + t * 16, u, lane));
+                b[t] = __builtin_bit_cast(Frag, tr_frag(sX, ROWB, wx * 64 + t * 16, u, lane));
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(a[i], b[j], acc[i][j]);
         }
     }
 #pragma unroll
@@ -583,7 +587,7 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmTnParams p) {
             for (int r = 0; r < 4; ++r) {
                 const int n = tn * 128 + wy * 64 + i * 16 + (lane >> 4) * 4 + r;
                 const int k = tk * 128 + wx * 64 + j * 16 + (lane & 15);
-                if (n < p.N && k < p.K) atomicAdd(G + (long)n * p.ldg + k, p.alpha * acc[i][j][r]);
+                if (n < p.N && k < p.K) atomicAdd(G + (long)n * p.ldg + k, alpha * acc[i][j][r]);
             }
 }
 
@@ -659,7 +663,7 @@ __global__ __launch_bounds__(320) void gemm_tn_skinny_kernel(GemmTnParams p) {
         for (int k = 0; k < 8; ++k) sG[kc + k] = acc[n][k];
         __syncthreads();
         for (int k = tid; k < W; k += nth)
-            if (k < p.K) atomicAdd(p.G + (long)n * p.ldg + k, p.alpha * sG[k]);
+            if (k < p.K) atomicAdd(p.G + (long)n * p.ldg + k, (p.alpha_dev ? p.alpha * *p.alpha_dev : p.alpha) * sG[k]);
     }
 }
 
@@ -878,15 +882,15 @@ extern "C" int gd_gemm_nt_scaled(const void* A, const void* W, void* C, int M, i
                         preact, ldp, act, dact_src, ldd, dact, residual, ldr, accumulate, stream);
 }
 
-extern "C" int gd_gemm_tn(const void* Y, const void* X, float* G, int M, int N, int K, long ldy, long ldx, long ldg,
-                          int batch, long sY, long sX, long sG, int y_dtype, int x_dtype, float alpha, void* stream) {
+static int gemm_tn_impl(const void* Y, const void* X, float* G, int M, int N, int K, long ldy, long ldx, long ldg,
+                        int batch, long sY, long sX, long sG, int y_dtype, int x_dtype, float alpha, const float* alpha_dev, void* stream) {
     GD_REQUIRE(M > 0 && N > 0 && K > 0, "gd_gemm_tn: bad shape M=%d N=%d K=%d", M, N, K);
     GD_REQUIRE(N % 8 == 0 && K % 8 == 0 && ldy % 8 == 0 && ldx % 8 == 0,
                "gd_gemm_tn: N (%d), K (%d), ldy (%ld), ldx (%ld) must be multiples of 8", N, K, ldy, ldx);
     GD_REQUIRE(((uintptr_t)Y & 15) == 0 && ((uintptr_t)X & 15) == 0, "gd_gemm_tn: Y and X must be 16-byte aligned");
     GemmTnParams p;
     p.Y = Y; p.X = X; p.G = G; p.M = M; p.N = N; p.K = K; p.ldy = ldy; p.ldx = ldx; p.ldg = ldg;
-    p.y_dtype = y_dtype; p.x_dtype = x_dtype; p.alpha = alpha; p.sY = sY; p.sX = sX; p.sG = sG;
+    p.y_dtype = y_dtype; p.x_dtype = x_dtype; p.alpha = alpha; p.alpha_dev = alpha_dev; p.sY = sY; p.sX = sX; p.sG = sG;
     GD_REQUIRE(batch >= 1 && sY % 8 == 0 && sX % 8 == 0, "gd_gemm_tn: bad batch / batch strides");
     if (N == 8 && ldy == 8 && y_dtype == GD_F32 && batch == 1 && K <= 2560 && ((uintptr_t)X & 15) == 0 && ((uintptr_t)Y & 15) == 0) {   // LoRA weight gradients
         const int nth = gd_cdiv(gd_cdiv(K, 8), 64) * 64;
@@ -900,7 +904,8 @@ extern "C" int gd_gemm_tn(const void* Y, const void* X, float* G, int M, int N, 
         GD_LAUNCH_OK();
         return 0;
     }
-    const bool bf = y_dtype == GD_BF16 && x_dtype == GD_BF16 && N >= 64 && K >= 64;   // bf16 MFMA + transpose reads
+    const bool h16 = y_dtype == GD_F16 && x_dtype == GD_F16 && N >= 64 && K >= 64;    // tf32h: fp16 MFMA, same kernel
+    const bool bf = (y_dtype == GD_BF16 && x_dtype == GD_BF16 && N >= 64 && K >= 64) || h16;   // bf16 MFMA + transpose reads
     const int tl = bf ? 128 : 64;
     const int tiles = gd_cdiv(N, tl) * gd_cdiv(K, tl);
     // enough M-chunks to fill the chip without shredding the reduction (every chunk ends in N x K fp32 atomics: at 87 680 x 768 x 64
@@ -911,8 +916,19 @@ extern "C" int gd_gemm_tn(const void* Y, const void* X, float* G, int M, int N, 
     if (mchunk < 256) mchunk = 256;
     p.mchunk = mchunk;
     dim3 grid(tiles, gd_cdiv(M, mchunk), batch);
-    if (bf) hipLaunchKernelGGL(gemm_tn_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    if (h16) hipLaunchKernelGGL(gemm_tn_bf16_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    else if (bf) hipLaunchKernelGGL(gemm_tn_bf16_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
     GD_LAUNCH_OK();
     return 0;
+}
+
+extern "C" int gd_gemm_tn(const void* Y, const void* X, float* G, int M, int N, int K, long ldy, long ldx, long ldg,
+                          int batch, long sY, long sX, long sG, int y_dtype, int x_dtype, float alpha, void* stream) {
+    return gemm_tn_impl(Y, X, G, M, N, K, ldy, ldx, ldg, batch, sY, sX, sG, y_dtype, x_dtype, alpha, nullptr, stream);
+}
+extern "C" int gd_gemm_tn_scaled(const void* Y, const void* X, float* G, int M, int N, int K, long ldy, long ldx, long ldg,
+                                 int batch, long sY, long sX, long sG, int y_dtype, int x_dtype, float alpha, const float* alpha_dev,
+                                 void* stream) {
+    return gemm_tn_impl(Y, X, G, M, N, K, ldy, ldx, ldg, batch, sY, sX, sG, y_dtype, x_dtype, alpha, alpha_dev, stream);
 }

@@ -337,7 +337,7 @@ class FinetuneGD(nn.Module):
         xn = self.model.norm(x)
         # conv and bilinear sample are both linear: mix the input patches first, convolve B*Nk rows instead of the whole grid
         feat = conv3x3_at_keypoints(xn, self.refine_conv.weight, self.refine_conv.bias, pts, gh, gw, (gw * P) / w, (gh * P) / h,
-                                    gh * Pi, gw * Pi, Pi, x3=getattr(self.model, "gemm_split3", False))
+                                    gh * Pi, gw * Pi, Pi, x3=getattr(self.model, "opfmt", ""))
         if feat is None:
             fmap, pitch = conv3x3_tokens(xn, self.refine_conv.weight, self.refine_conv.bias, gh, gw)
             feat = kp_gather([fmap], pts, gh, gw, (gw * P) / w, (gh * P) / h, gh * Pi, gw * Pi, Pi, pitch=pitch)

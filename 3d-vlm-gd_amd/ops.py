@@ -165,8 +165,9 @@ def gemm_nt_x3(a, w3, **kw):
     return gemm_nt(split3(a, "a"), w3, **kw)
 
 
-def gemm_tn(y, x, out=None, *, alpha=1.0):
-    """out[N,K] (fp32) += alpha * y[M,N]^T @ x[M,K]   (weight gradients; fp32 accumulation)."""
+def gemm_tn(y, x, out=None, *, alpha=1.0, alpha_dev=None):
+    """out[N,K] (fp32) += alpha * y[M,N]^T @ x[M,K]   (weight gradients; fp32 accumulation).  alpha_dev: a device scalar multiplied into alpha
+    (the 1/s of a scaled fp16 gradient operand, ops.amax_scale)."""
     _req(y.is_cuda and x.is_cuda and y.stride(-1) == 1 and x.stride(-1) == 1 and y.shape[:-1] == x.shape[:-1],
          "gemm_tn: bad operands")
     batched = y.dim() == 3
@@ -176,9 +177,9 @@ def gemm_tn(y, x, out=None, *, alpha=1.0):
     if out is None:
         out = torch.zeros((B, N, K) if batched else (N, K), dtype=torch.float32, device=y.device)
     _req(out.dtype == torch.float32 and out.stride(-1) == 1, "gemm_tn: out must be fp32, contiguous rows")
-    rc = lib().gd_gemm_tn(ptr(y), ptr(x), ptr(out), M, N, K, y.stride(-2), x.stride(-2), out.stride(-2), B,
-                          y.stride(0) if batched else 0, x.stride(0) if batched else 0,
-                          out.stride(0) if batched else 0, dtype_code(y), dtype_code(x), float(alpha), stream())
+    args = (ptr(y), ptr(x), ptr(out), M, N, K, y.stride(-2), x.stride(-2), out.stride(-2), B, y.stride(0) if batched else 0,
+            x.stride(0) if batched else 0, out.stride(0) if batched else 0, dtype_code(y), dtype_code(x), float(alpha))
+    rc = lib().gd_gemm_tn(*args, stream()) if alpha_dev is None else lib().gd_gemm_tn_scaled(*args, ptr(alpha_dev), stream())
     check(rc, "gd_gemm_tn")
     return out
 

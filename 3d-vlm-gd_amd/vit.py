@@ -201,7 +201,7 @@ class _BlockFn(torch.autograd.Function):
         hkw = {} if not hs else {"out_split": True} if fmt == "x3" else {"out_dtype": torch.float16}
         h = _mm(None if fmt == "h" else y2, plan, "w1", xs=y2 if fmt == "h" else None, bias=plan["b1"], act=3, preact=pre, **hkw)   # pre <- GELU'(fc1 output): all the backward needs
         x2 = _mm(None if hs else h, plan, "w2", xs=h if hs else None, bias=plan["b2"], residual=x1)
-        out, hd = x2, None
+        out, hd, hd16 = x2, None, None
         if down is not None:
             down_T = tw["down_T"] if tw is not None else down.detach().to(T).contiguous()
             up_T = tw["up_T"] if tw is not None else up.detach().to(T).contiguous()
@@ -210,14 +210,19 @@ class _BlockFn(torch.autograd.Function):
             elif plan["x3"]:        # tf32x: both projections as split-precision products on the bf16 kernels (the fp32 tile kernel: 2 x 370 us)
                 w_dn = tw["down_w3"] if tw is not None and "down_w3" in tw else _opw(down_T, fmt)
                 w_up = tw["up_w3"] if tw is not None and "up_w3" in tw else _opw(up_T, fmt)
-                hd = ops.gemm_nt(_opa(x2, fmt), w_dn, act=2, out_dtype=torch.float32)
-                out = ops.gemm_nt(_opa(hd, fmt), w_up, residual=x2, out_dtype=torch.float32)
+                x2a = _opa(x2, fmt)
+                hd = ops.gemm_nt(x2a, w_dn, act=2, out_dtype=torch.float32)
+                hda = _opa(hd, fmt)
+                out = ops.gemm_nt(hda, w_up, residual=x2, out_dtype=torch.float32)
+                if fmt == "h" and need:      # the backward contracts these two again (adapter weight gradients): keep the fp16 copies, not x2
+                    x2, hd16 = x2a, hda
             else:
                 hd = ops.gemm_nt(x2, down_T, act=2)
                 out = ops.gemm_nt(hd, up_T, residual=x2)
         if need:
             ctx.plan, ctx.dims, ctx.tw = plan, (B, Nt), tw
             ctx.has_lora, ctx.has_ad = a_q is not None, down is not None
+            ctx.hd16 = hd16
             ctx.save_for_backward(x, mean1, rstd1, y1, t, at, bt, qkv, o, lse, x1, mean2, rstd2, pre, x2, hd,
                                   down, up)
         return out
@@ -255,13 +260,21 @@ class _BlockFn(torch.autograd.Function):
                 w_ut = tw["up_tw3"] if tw is not None and "up_tw3" in tw else _opw(up_tT, fmt)
                 w_dt = tw["down_tw3"] if tw is not None and "down_tw3" in tw else _opw(down_tT, fmt)
                 ad = None if sc is None else sc[1:2]
-                dhp = ops.gemm_nt(_opa(dout.view(-1, D), fmt, sc), w_ut, dact_src=hd, dact=2, out_dtype=torch.float32, alpha_dev=ad)
-                dx2 = ops.gemm_nt(_opa(dhp, fmt, sc), w_dt, residual=dout.view(-1, D), out_dtype=torch.float32, alpha_dev=ad)
+                douta = _opa(dout.view(-1, D), fmt, sc)
+                dhp = ops.gemm_nt(douta, w_ut, dact_src=hd, dact=2, out_dtype=torch.float32, alpha_dev=ad)
+                dhpa = _opa(dhp, fmt, sc)
+                dx2 = ops.gemm_nt(dhpa, w_dt, residual=dout.view(-1, D), out_dtype=torch.float32, alpha_dev=ad)
             else:
                 dhp = ops.gemm_nt(dout, up_tT, dact_src=hd, dact=2)                               # [M, 64]
                 dx2 = ops.gemm_nt(dhp, down_tT, residual=dout)
-            g_up = ops.gemm_tn(dout, hd, out=z_up)                                                # [D, 64]
-            g_down = ops.gemm_tn(dhp, x2, out=z_down)                                             # [64, D]
+            if fmt == "h" and ctx.hd16 is not None and x2.dtype == torch.float16:
+                # the weight gradients on the fp16 MFMA kernel from the operands at hand: (dout s)^T hd and (dhp s)^T x2, times 1/s on the device
+                g_up = ops.gemm_tn(douta, ctx.hd16, out=z_up, alpha_dev=sc[1:2])                  # [D, 64]
+                g_down = ops.gemm_tn(dhpa, x2, out=z_down, alpha_dev=sc[1:2])                     # [64, D]
+                del douta, dhpa
+            else:
+                g_up = ops.gemm_tn(dout, hd, out=z_up)                                            # [D, 64]
+                g_down = ops.gemm_tn(dhp, x2, out=z_down)                                         # [64, D]
         hs = bool(fmt) and ops.split_out_ok(dx2.shape[0], plan["w2_t"].shape[0], plan["w2_t"].shape[1])
         hkw = {} if not hs else {"out_split": True} if fmt == "x3" else {"out_dtype": torch.float16}      # (tf32h: fp16, still times s)
         dpre = _mm(dx2, plan, "w2_t", sc=sc, dact_src=pre, dact=3, **hkw)                         # [M, 4D] (x stored GELU')
@@ -607,7 +620,8 @@ class GDViT(nn.Module):
             wp = torch.zeros(D, Kp, dtype=torch.float32, device=w.device)
             wp[:, :K] = w.reshape(D, K)
             b = self.patch_embed.proj.bias
-            self._pe_plan = {"dtype": self.dtype, "w": wp.to(self.dtype).contiguous(), "Kp": Kp,
+            fmt = getattr(self, "opfmt", "") if self.dtype == torch.float32 else ""
+            self._pe_plan = {"dtype": self.dtype, "w": _opw(wp.contiguous(), fmt) if fmt else wp.to(self.dtype).contiguous(), "Kp": Kp, "fmt": fmt,
                              "b": b.detach().float().contiguous() if b is not None else None,
                              "cls": self.cls_token.detach().float().reshape(-1).contiguous()}
         return self._pe_plan
@@ -635,7 +649,10 @@ class GDViT(nn.Module):
             gh, gw = 1 + (H - P) // st[0], 1 + (W - P) // st[1]
             col = ops.patch_im2col(img, H, W, P, pp["Kp"], self.mean, self.std, self.dtype, stride=st)
             pos = self._pos_strided(gh, gw, H, W)
-        tok = ops.gemm_nt(col, pp["w"], bias=pp["b"])
+        if pp["fmt"]:       # tf32x / tf32h: the patch projection on formatted operands too (the exact-f32 MFMA spends 0.7 ms on it)
+            tok = ops.gemm_nt(_opa(col, pp["fmt"]), pp["w"], bias=pp["b"], out_dtype=torch.float32)
+        else:
+            tok = ops.gemm_nt(col, pp["w"], bias=pp["b"])
         x = ops.assemble_tokens(tok, pp["cls"], pos, B, gh * gw).view(B, gh * gw + 1, -1)
         if not isinstance(self.norm_pre, nn.Identity):
             x = self.norm_pre(x)
@@ -784,8 +801,11 @@ class _ConvAtKpFn(torch.autograd.Function):
         sparse_dx = tok.requires_grad and Nk <= 1024 and D % 8 == 0 and D <= 1024 and os.environ.get("GD_CONV_DX_AT_KP", "1") != "0"
         # [n, (ky, kx, c)], the flipped [ci, (kx, ky, n)] of the dense backward, [(ky, kx, c), n] of the backward at the keypoints
         wk, wt, wu = ops.conv_weight_pack(weight, T, with_wu=sparse_dx)
-        x3 = bool(x3) and T == torch.float32 and sparse_dx        # tf32x engine: the two K = 9D GEMMs as 3-term bf16 splits
-        if x3:
+        x3 = ("x3" if x3 is True else x3) if (x3 and T == torch.float32 and sparse_dx) else ""   # tf32x / tf32h: the K = 9D GEMMs on formatted operands
+        if x3 == "h":         # fp16 operands; the gathered patches are kept as fp16 only (the weight gradient contracts them again)
+            colp = ops.cast16(colp)
+            out = ops.gemm_nt(colp, ops.cast16(wk), bias=bias.detach().float().contiguous(), out_dtype=torch.float32)
+        elif x3:
             out = ops.gemm_nt_x3(colp, ops.split3(wk, "w"), bias=bias.detach().float().contiguous())
         else:
             out = ops.gemm_nt(colp, wk, bias=bias.detach().float().contiguous(), out_dtype=torch.float32)
@@ -798,16 +818,24 @@ class _ConvAtKpFn(torch.autograd.Function):
     def backward(ctx, dfeat):
         colp, wt, kp = ctx.saved_tensors
         (gh, gw, sx, sy, img_h, img_w, patch), B, Nt, D, Nk = ctx.meta
-        T = colp.dtype
+        T = torch.float32 if ctx.x3 == "h" else colp.dtype
         dfe = dfeat.reshape(B * Nk, D).contiguous().float()
-        dft = dfe if T == torch.float32 else ops.cast(dfe, T)
-        gk = ops.gemm_tn(dft, colp)                                    # [Dout, (ky, kx, Din)]
+        if ctx.x3 == "h":     # gradient operand under its own power-of-two scale (ops.amax_scale), undone on the device
+            sc = ops.amax_scale(dfe, 8.0)
+            dft = ops.cast16(dfe, scale_dev=sc[0:1])
+            gk = ops.gemm_tn(dft, colp, alpha_dev=sc[1:2])
+        else:
+            dft = dfe if T == torch.float32 else ops.cast(dfe, T)
+            gk = ops.gemm_tn(dft, colp)                                    # [Dout, (ky, kx, Din)]
         gweight = gk.view(D, 3, 3, D).permute(0, 3, 1, 2).contiguous()
         gbias = dfe.sum(0)
         dtok = None
         if ctx.needs_input_grad[0] and ctx.sparse_dx:
             # dcol = dfeat . W over the B*Nk keypoint rows, then every token gathers its contributions (no atomics, no dense GEMM)
-            U = ops.gemm_nt_x3(dft, ops.split3(wt, "w")) if ctx.x3 else ops.gemm_nt(dft, wt, out_dtype=T)   # (`wt` holds wu here) [B*Nk, 9D]
+            if ctx.x3 == "h":
+                U = ops.gemm_nt(dft, ops.cast16(wt), out_dtype=torch.float32, alpha_dev=sc[1:2])
+            else:
+                U = ops.gemm_nt_x3(dft, ops.split3(wt, "w")) if ctx.x3 else ops.gemm_nt(dft, wt, out_dtype=T)   # (`wt` holds wu here) [B*Nk, 9D]
             dtok = ops.kp_patch_bwd_det(U, kp, T, B, Nk, Nt, gh, gw, D, sx, sy, img_h, img_w, patch)
         elif ctx.needs_input_grad[0]:
             rows = B * gh * (gw + 1)
@@ -827,7 +855,7 @@ def conv3x3_at_keypoints(tok, weight, bias, kp, gh, gw, sx, sy, img_h, img_w, pa
     es = 2 if tok.dtype == torch.bfloat16 else 4
     if os.environ.get("GD_CONV_AT_KP", "1") == "0" or (tok.shape[-1] * es) % 16 != 0:
         return None
-    return _ConvAtKpFn.apply(tok, weight, bias, kp, (gh, gw, float(sx), float(sy), int(img_h), int(img_w), int(patch)), bool(x3))
+    return _ConvAtKpFn.apply(tok, weight, bias, kp, (gh, gw, float(sx), float(sy), int(img_h), int(img_w), int(patch)), x3)
 
 
 def conv3x3_tokens(tok, weight, bias, gh, gw):

@@ -20,8 +20,10 @@ Extra objects on the line:
   parity                engine loss vs the CPU oracle (oracle/gd_oracle.py, fp32) on the same weights and the same pairs
   f32                   the same workload on the f32 engine (the reference's arithmetic precision): same --steps / --warmup, own
                         roofline and parity (also as config.reference_precision_run and roofline.f32_engine)
-  tf32x                 the same workload on the TF32-class engine (fp32 storage, 3-term bf16 split products on the matrix cores): same
-                        --steps / --warmup, own roofline and parity (also as config.tf32_class_run and roofline.tf32x_engine)
+  tf32h                 the same workload on the fp16-operand TF32-class engine (fp32 storage; products on fp16 operands = TF32's significand):
+                        same --steps / --warmup, own roofline and parity (also as config.tf32_class_run and roofline.tf32h_engine)
+  tf32x                 the same workload on the split-precision engine (fp32 storage, 3-term bf16 split products on the matrix cores): same
+                        --steps / --warmup, own roofline and parity (also as config.tf32x_run and roofline.tf32x_engine)
   other_configs         short runs of BASELINE configs 3 / 5-like and of the reference's own token geometry
   comm                  N > 1: all-reduce time of the two gradient chunks and the exposed fraction of the step
   cpu_baseline          the CPU oracle on a bounded sample of the same workload, rank 0 / N=1 only
@@ -64,12 +66,17 @@ def parse():
                          "reference's geometry (80x80-token forwards for the keypoint features + the teacher-grid forward)")
     ap.add_argument("--gemm-shapes", action="store_true", help="per-shape gemm_nt breakdown on stderr")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--steps-only", action="store_true", help="profiling aid: the timed steps and nothing else (no cost-volume roofline leg, "
+                    "no CPU legs, no companion runs): a kernel trace of this run holds the step's kernels only")
     ap.add_argument("--exchange", default="torch", choices=["torch", "direct"],
                     help="gradient exchange: torch = torch.distributed all-reduce in two overlapped chunks (default); direct = "
                          "one gd_flat_allreduce (C ABI, RCCL reduce-scatter + all-gather) after the backward")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); 'gloo' lets two "
                     "ranks share one GPU for a functional check of the N>1 path")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.steps_only:
+        args.no_cpu_baseline = args.no_extras = args.no_kernel_events = True
+    return args
 
 
 def launch_ranks(args):
@@ -251,10 +258,11 @@ def main():
             if args.gemm_shapes:
                 for k, (cnt, sms, tf) in sorted(prof.by_shape().items(), key=lambda kv: -kv[1][1]):
                     print(f"gemm_nt {str(k):58s} x{cnt:4d} {sms / args.steps:8.3f} ms/step {tf:7.1f} TF/s", file=sys.stderr)
-        cvr = cost_volume_roofline(job, args, dev, variant)
-        out["roofline_cost_volume"] = cvr
-        if "roofline" in out:       # the driver's parser keeps `roofline` and `config`: the second north-star kernel rides inside
-            out["roofline"]["cost_volume_kl_fwd"] = cvr
+        if not args.steps_only:
+            cvr = cost_volume_roofline(job, args, dev, variant)
+            out["roofline_cost_volume"] = cvr
+            if "roofline" in out:       # the driver's parser keeps `roofline` and `config`: the second north-star kernel rides inside
+                out["roofline"]["cost_volume_kl_fwd"] = cvr
         if comm:
             out["comm"] = comm
         # the CPU oracle legs (parity of the benched batch, cpu_baseline) and the companion measurements run at N = 1 only: on N > 1
@@ -278,9 +286,21 @@ def main():
                     "reference trains in fp32; gfx950 has no TF32"}
                 if "roofline" in out and "roofline" in f:
                     out["roofline"]["f32_engine"] = f["roofline"]
+            if "tf32h" in extras:
+                f = extras["tf32h"]
+                out["config"]["tf32_class_run"] = {
+                    "dtype": "tf32h", "value": f["value"], "unit": "image-pairs/s", "ms_per_step": f["ms_per_step"], "steps": f["steps"],
+                    "warmup": f["warmup"], "vit_frac_of_mfma_peak": f["vit_frac_of_mfma_peak"], "parity_rel_err": f.get("parity", {}).get("rel_err"),
+                    "note": "same workload, fp32 storage; every big GEMM and the attention products take fp16 operands (gd_cast_f16, GD_F16): "
+                            "TF32's 11-bit significand, one MFMA per term, gradient operands under a per-block power-of-two scale taken on the "
+                            "device (gd_amax_scale) — the precision class the reference's MASt3R path computes its matmuls in "
+                            "(dust3r/croco/models/croco.py:12, allow_tf32); at full size: loss 2e-7, gradient 0.5 % of the fp64 oracle "
+                            "(tests/test_gpu_fullsize.py)"}
+                if "roofline" in out and "roofline" in f:
+                    out["roofline"]["tf32h_engine"] = f["roofline"]
             if "tf32x" in extras:
                 f = extras["tf32x"]
-                out["config"]["tf32_class_run"] = {
+                out["config"]["tf32x_run"] = {
                     "dtype": "tf32x", "value": f["value"], "unit": "image-pairs/s", "ms_per_step": f["ms_per_step"], "steps": f["steps"],
                     "warmup": f["warmup"], "parity_rel_err": f.get("parity", {}).get("rel_err"),
                     "note": "same workload, fp32 storage, every big GEMM and the attention products as three bf16 MFMAs of (hi, lo) operand splits "
@@ -509,6 +529,9 @@ def companion_runs(args, variant, backbone, weights, dev, rank, world):
                          prof=not args.no_kernel_events, wts=weights, parity=world == 1)
     if args.dtype != "tf32x":
         out["tf32x"] = run(backbone, variant, "tf32x", args.geometry, P, steps=args.steps, warmup=args.warmup,
+                           prof=not args.no_kernel_events, wts=weights, parity=world == 1)
+    if args.dtype != "tf32h":
+        out["tf32h"] = run(backbone, variant, "tf32h", args.geometry, P, steps=args.steps, warmup=args.warmup,
                            prof=not args.no_kernel_events, wts=weights, parity=world == 1)
     if world == 1 and args.geometry == "shared" and backbone == "vit_base":
         out["other_configs"] = {

@@ -275,6 +275,10 @@ int gd_split3(const float* in, void* out, long rows, int K, long ld_in, int whic
  * gd_gemm_nt_scaled: gd_gemm_nt with alpha multiplied by the device scalar *alpha_dev (the 1/s of a scaled operand) — no host round trip.
  * gd_gemm_nt itself takes ab_dtype GD_F16 (f32 results, or c_dtype GD_F16: an fp16 C beside f32 preact / dact_src). */
 int gd_cast_f16(const float* in, void* out, long rows, int K, long ld_in, float scale, const float* scale_dev, void* stream);
+/* gd_gemm_tn with alpha multiplied by the device scalar *alpha_dev (weight gradients contracted from SCALED fp16 gradient operands);
+ * gd_gemm_tn takes fp16 Y and X on the MFMA kernel (N, K >= 64) and fp16 X on the N = 8 streaming kernel. */
+int gd_gemm_tn_scaled(const void* Y, const void* X, float* G, int M, int N, int K, long ldy, long ldx, long ldg,
+                      int batch, long sY, long sX, long sG, int y_dtype, int x_dtype, float alpha, const float* alpha_dev, void* stream);
 /* gd_layernorm_fwd with y_dtype GD_F16 (f32 rows in): LN(x) written as the fp16 operand directly.  gd_layernorm_bwd_cast: the f32 backward
  * that also writes dx16 [M, D] = fp16(sat(dx * *scale_dev)) — backward + gd_cast_f16 in one pass. */
 int gd_layernorm_bwd_cast(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
