@@ -822,6 +822,9 @@ static int cv_fwd_common(const void* f1, const void* f2, const float* inv1, cons
     q.f1 = f1; q.f2 = f2; q.t1 = t1; q.t2 = t2; q.stats = stats; q.part1 = part1; q.part2 = part2;
     q.hw = hw; q.C = C; q.tiles = tiles; q.nslab = nslab; q.ldt = ldt; q.P = P;
     if (gd_knobs().cv_mask_skip) { q.m1 = m1; q.m2 = m2; }      // the persistent kernel skips the teacher entries of masked-out rows / columns
+    // (A 256 x 256-tile forward on the persistent GEMM skeleton — half the feature bytes staged per FLOP, teacher entries streamed through registers
+    // in a two-pass epilogue — was built and measured in round 3: 291 us against 263 us with every row kept, 221 against 193 with the trainer's masks;
+    // shelved as tools/experiments/cv_persist256.h)
     const int persist = gd_knobs().cv_persist;     // GD_CV_PERSIST=0: the one-tile-per-block kernel (A/B)
     const long rowb = (long)C * gd_dtype_size(dtype);
     if (persist && rowb % 128 == 0 && rowb / 128 >= 3 && ldt % 4 == 0 && ((uintptr_t)t1 & 15) == 0 && ((uintptr_t)t2 & 15) == 0) {
