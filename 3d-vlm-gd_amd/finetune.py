@@ -13,13 +13,13 @@ side), cost features at the teacher grid — the reference's three resolutions (
 geometry = "shared": one forward per image at the teacher grid feeds all three extractors (BASELINE 518^2).
 """
 import math
-import os
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
+from .options import option
 from .model import Adapter, BlockWithAdapter, DepthAwareFeatureFusion, _LoRA_qkv
 from .vit import conv3x3_at_keypoints, conv3x3_tokens, create_vit, kp_gather
 
@@ -213,7 +213,7 @@ class FinetuneGD(nn.Module):
         # buffer (GDViT.prepare_trainables(flat)): ~45 fewer torch-side launches per step (no per-block zero-filled scratch, no
         # AccumulateGrad copies of the strided LoRA-B views, no 48-tensor gather).  Step time equal within run-to-run noise on one box
         # (round 2: 539.3 vs 542.9 image-pairs/s); the default since round 3, GD_DIRECT_GRADS=0 restores the autograd gather.
-        loss, terms = self.training_step(batch, direct_grads=os.environ.get("GD_DIRECT_GRADS", "1") != "0")
+        loss, terms = self.training_step(batch, direct_grads=bool(option("direct_grads")))
         if reducer is None:
             self.backward(loss)
             scale = 1.0

@@ -4,6 +4,7 @@ import torch
 
 from . import _lib
 from ._lib import check, dtype_code, lib, ptr, stream
+from .options import option
 
 
 def _req(cond, msg):
@@ -511,8 +512,7 @@ def skinny_tn_mfma(t, x, out):
 
 
 def lora_bwd_fused_supported(dqv, t, bt_qv, gbt):
-    import os
-    return (os.environ.get("GD_LORA_FUSED", "1") != "0" and dqv.dtype == torch.bfloat16 and (bt_qv is None or bt_qv.dtype == torch.bfloat16)
+    return (option("lora_fused") and dqv.dtype == torch.bfloat16 and (bt_qv is None or bt_qv.dtype == torch.bfloat16)
             and t.dtype == torch.float32 and t.shape[1] == 8 and t.is_contiguous() and (bt_qv is None or bt_qv.is_contiguous()) and gbt.is_contiguous()
             and dqv.stride(1) == 1 and dqv.shape[1] % 256 == 0 and dqv.shape[1] // 256 in (1, 2, 3, 4, 6, 8) and dqv.stride(0) % 8 == 0)
 
@@ -541,9 +541,8 @@ def kp_gather_bwd_det(kp, dout, scale, out_dtype, B, Nk, gh, gw, D, sx, sy, img_
     """Deterministic interpolate_features backward (no atomics, no zero-fill, no cast pass): -> [B, prefix + gh*pitch, D] of
     `out_dtype`, every element written (prefix rows / separator columns zero).  None when the shape is outside the kernel's range
     (Nk > 1024, D % 8, D > 1024) or GD_GATHER_DET=0: the caller then takes the atomic scatter."""
-    import os
     pt = gw if pitch is None else pitch
-    if os.environ.get("GD_GATHER_DET", "1") == "0" or Nk > 1024 or D % 8 != 0 or D > 1024:
+    if not option("gather_det") or Nk > 1024 or D % 8 != 0 or D > 1024:
         return None
     out = torch.empty(B, prefix + gh * pt, D, dtype=out_dtype, device=kp.device)
     dout = dout.contiguous().float()

@@ -21,6 +21,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
+from .options import option
 from .model import Adapter, BlockWithAdapter, _LoRA_qkv  # noqa: F401
 
 
@@ -797,8 +798,7 @@ class _ConvAtKpFn(torch.autograd.Function):
         Nk = kp.shape[1]
         T = tok.dtype
         colp = ops.kp_patch_gather(tok[:, Nt - gh * gw:], Nt * D, kp, B, Nk, gh, gw, D, sx, sy, img_h, img_w, patch)
-        import os
-        sparse_dx = tok.requires_grad and Nk <= 1024 and D % 8 == 0 and D <= 1024 and os.environ.get("GD_CONV_DX_AT_KP", "1") != "0"
+        sparse_dx = tok.requires_grad and Nk <= 1024 and D % 8 == 0 and D <= 1024 and bool(option("conv_dx_at_kp"))
         # [n, (ky, kx, c)], the flipped [ci, (kx, ky, n)] of the dense backward, [(ky, kx, c), n] of the backward at the keypoints
         wk, wt, wu = ops.conv_weight_pack(weight, T, with_wu=sparse_dx)
         x3 = ("x3" if x3 is True else x3) if (x3 and T == torch.float32 and sparse_dx) else ""   # tf32x / tf32h: the K = 9D GEMMs on formatted operands
@@ -851,9 +851,8 @@ class _ConvAtKpFn(torch.autograd.Function):
 def conv3x3_at_keypoints(tok, weight, bias, kp, gh, gw, sx, sy, img_h, img_w, patch, x3=False):
     """refine_conv (3x3, padding 1) of the token grid of tok [B, prefix + gh*gw, D], bilinearly sampled at kp [B, Nk, 2] (pixels)
     -> [B, Nk, D] fp32, or None when the layout does not allow it (rows that are not 16-byte multiples; GD_CONV_AT_KP=0)."""
-    import os
     es = 2 if tok.dtype == torch.bfloat16 else 4
-    if os.environ.get("GD_CONV_AT_KP", "1") == "0" or (tok.shape[-1] * es) % 16 != 0:
+    if not option("conv_at_kp") or (tok.shape[-1] * es) % 16 != 0:
         return None
     return _ConvAtKpFn.apply(tok, weight, bias, kp, (gh, gw, float(sx), float(sy), int(img_h), int(img_w), int(patch)), x3)
 
@@ -862,9 +861,8 @@ def conv3x3_tokens(tok, weight, bias, gh, gw):
     """refine_conv (3x3, padding 1) on the token grid of tok [B, prefix + gh*gw, D].  -> (fmap, pitch): fmap [B, gh*pitch, D] fp32
     with pitch = gw + 1 (separator-column layout, the default) or gw (im2col path: GD_CONV_STACKED=0, or D rows that are not
     multiples of 16 bytes)."""
-    import os
     es = 2 if tok.dtype == torch.bfloat16 else 4
-    if os.environ.get("GD_CONV_STACKED", "1") != "0" and (tok.shape[-1] * es) % 16 == 0:
+    if option("conv_stacked") and (tok.shape[-1] * es) % 16 == 0:
         return _Conv3x3StackedFn.apply(tok, weight, bias, gh, gw), gw + 1
     return _Conv3x3Fn.apply(tok, weight, bias, gh, gw), gw
 

@@ -163,7 +163,7 @@ def test_vit_base_518_tf32h_step_matches_oracle():
 
 
 # BASELINE config 3: ViT-L/14 + VGGT losses (dense cost volume at C = 1024, hw = 1369)
-@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+@pytest.mark.parametrize("dtype", ["bf16", "f32", "tf32h"])
 def test_vit_large_518_vggt_step_matches_oracle(dtype):
     rec = _run_case(f"vit_large_518_vggt_{dtype}", "vit_large", "vggt", dtype, P=1)
     _check(rec, cos=0.999 if dtype == "f32" else 0.99)
@@ -193,11 +193,12 @@ def test_prenorm_vit_large_bf16_mast3r_mixed_losses_step_matches_oracle():
 # group takes a coin-flip direction in ANY reduced-precision run, so dW is compared as a vector, not element-wise.
 BF16_TRAJ_DW_FRO, BF16_TRAJ_DW_COS = 0.10, 0.99      # measured (profiles/r03_fullsize_parity.json): 0.049 / 0.9988
 F32_TRAJ_DW_FRO = 0.01                                 # measured: 0.0014
+TF32H_TRAJ_DW_FRO, TF32H_TRAJ_DW_COS = 0.03, 0.999     # the fp16-operand TF32-class engine (bf16 x 8 finer operand rounding)
 _STEP_ORACLE = {}
 _TRAJ_ORACLE = {}                                      # the fp32 oracle's trajectory is the same for both engine dtypes: run it once
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+@pytest.mark.parametrize("dtype", ["bf16", "f32", "tf32h"])
 def test_vit_base_518_ten_steps_follow_the_fp32_oracle(dtype):
     from gd_amd.finetune import FinetuneGD
     torch.manual_seed(0)
@@ -232,8 +233,8 @@ def test_vit_base_518_ten_steps_follow_the_fp32_oracle(dtype):
     rec["weights_rel_fro"] = float((w_hip - w_ref).norm() / w_ref.norm())
     rec["max_weight_diff_over_lr"] = float((w_hip - w_ref).abs().max() / 1e-5)
     rec["groups_dw"] = _group_table(names, d_hip, d_ref, float(b.norm()))
-    rec["stated_tolerance"] = {"loss_rel": TOL, "dw_rel_fro": BF16_TRAJ_DW_FRO if dtype == "bf16" else F32_TRAJ_DW_FRO,
-                               "dw_cos": BF16_TRAJ_DW_COS if dtype == "bf16" else 0.9999}
+    rec["stated_tolerance"] = {"loss_rel": TOL, "dw_rel_fro": {"bf16": BF16_TRAJ_DW_FRO, "tf32h": TF32H_TRAJ_DW_FRO}.get(dtype, F32_TRAJ_DW_FRO),
+                               "dw_cos": {"bf16": BF16_TRAJ_DW_COS, "tf32h": TF32H_TRAJ_DW_COS}.get(dtype, 0.9999)}
     _record(f"trajectory10_vit_base_518_mast3r_{dtype}", rec)
     assert max(rec["loss_rel_err"]) < TOL, rec["loss_rel_err"]
     assert rec["loss"][-1] < rec["loss"][0]                  # and it trains

@@ -460,9 +460,7 @@ def test_direct_weight_gradients_equal_the_autograd_path(dtype, monkeypatch):
     b = _engine("vggt", "shared", dtype, teacher_patch=14)
     fa, fb = a.configure_optimizers(), b.configure_optimizers()
     assert fa["spans"] is not None and fa["spans"]["L"] == 4
-    monkeypatch.setenv("GD_DIRECT_GRADS", "1")
-    la, _, na = a.fit_step(batch)                              # direct path (the default of fit_step)
-    monkeypatch.delenv("GD_DIRECT_GRADS")
+    la, _, na = a.fit_step(batch)                              # direct path (the default of fit_step: options.direct_grads)
     lb, _ = b.training_step(batch)                             # autograd returns every gradient, gathered by one multi-tensor copy
     b.backward(lb)
     assert abs(la.item() - lb.item()) < 1e-6 * abs(lb.item())
