@@ -128,6 +128,7 @@ struct CvTileParams {
     // backward only
     const unsigned char* m1; const unsigned char* m2; const float* gloss;
     void* G1; void* G2; int hwp;
+    const float* gscale;      // fp16 G (tf32h engine): device scalar s multiplied into G before it is rounded; the GEMMs that contract G undo it
 };
 
 // S tile (cosine similarities, fp32) parked in LDS so that BOTH teacher sweeps read global memory row-contiguously:
@@ -666,7 +667,7 @@ __global__ __launch_bounds__(256, 2) void cv_bwd_tile_kernel(CvTileParams q) {
     cv_s_tile<T>(q, p, tm, tn, smem, sSt, acc);
     float* sS = (float*)smem;            // [128][64]
     float* sG = (float*)smem + 128 * 64; // [128][64]
-    const float coef = q.gloss[p] * 0.5f / (float)hw;
+    const float coef = q.gloss[p] * 0.5f / (float)hw * (q.gscale ? q.gscale[0] : 1.0f);
     T* G1 = (T*)q.G1 + (long)p * hw * hwp;
     T* G2 = (T*)q.G2 + (long)p * hw * hwp;
 
@@ -796,7 +797,8 @@ static int cv_fwd_common(const void* f1, const void* f2, const float* inv1, cons
                          int dtype, float* loss, float* stats, void* workspace, void* stream) {
     GD_REQUIRE(P > 0 && hw > 0 && C > 0 && ldt >= hw, "gd_cost_volume_kl_fwd: bad shape P=%d hw=%d C=%d ldt=%d", P, hw, C, ldt);
     GD_REQUIRE(variant == 0 || variant == 1, "gd_cost_volume_kl_fwd: variant must be 0 (vggt) or 1 (mast3r)");
-    GD_REQUIRE(dtype == GD_F32 || dtype == GD_BF16, "gd_cost_volume_kl_fwd: bad dtype %d", dtype);
+    GD_REQUIRE(dtype == GD_F32 || dtype == GD_BF16 || dtype == GD_F16, "gd_cost_volume_kl_fwd: bad dtype %d", dtype);
+    GD_REQUIRE(dtype != GD_F16 || inv1 != nullptr, "gd_cost_volume_kl_fwd: fp16 features (tf32h engine) come with the row norms of their f32 source (..._prenorm)");
     GD_REQUIRE((C * gd_dtype_size(dtype)) % 16 == 0, "gd_cost_volume_kl_fwd: C*elsize must be a multiple of 16 B");
     GD_REQUIRE((double)hw * 7.3890561 * CV_EPS < 1.0, "gd_cost_volume_kl_fwd: hw too large for the clamp-free softmax");
     GD_REQUIRE(((uintptr_t)f1 & 15) == 0 && ((uintptr_t)f2 & 15) == 0 && ((uintptr_t)stats & 15) == 0 &&
@@ -839,8 +841,11 @@ static int cv_fwd_common(const void* f1, const void* f2, const float* inv1, cons
         }
         if (q.dbg && dtype == GD_BF16) hipLaunchKernelGGL((cv_fwd_persist_kernel<bf16, true>), dim3(grid), dim3(768), 0, s, q);
         else if (dtype == GD_BF16) hipLaunchKernelGGL((cv_fwd_persist_kernel<bf16, false>), dim3(grid), dim3(768), 0, s, q);
+        else if (dtype == GD_F16) hipLaunchKernelGGL((cv_fwd_persist_kernel<f16, false>), dim3(grid), dim3(768), 0, s, q);
         else hipLaunchKernelGGL((cv_fwd_persist_kernel<float, false>), dim3(grid), dim3(768), 0, s, q);
-    } else if (dtype == GD_BF16)
+    } else if (dtype == GD_F16)
+        hipLaunchKernelGGL(cv_fwd_tile_kernel<f16>, dim3(tiles * tiles, P), dim3(256), 0, s, q);
+    else if (dtype == GD_BF16)
         hipLaunchKernelGGL(cv_fwd_tile_kernel<bf16>, dim3(tiles * tiles, P), dim3(256), 0, s, q);
     else
         hipLaunchKernelGGL(cv_fwd_tile_kernel<float>, dim3(tiles * tiles, P), dim3(256), 0, s, q);
@@ -910,6 +915,66 @@ extern "C" int gd_cost_volume_kl_bwd(const void* f1, const void* f2, const float
     else
         hipLaunchKernelGGL(cv_norm_bwd_kernel<float>, dim3(gd_cdiv(hw, 4), 2, P), dim3(256), 0, s, (const float*)f1,
                            (const float*)f2, da, db, stats, (float*)df1, (float*)df2, hw, C);
+    GD_LAUNCH_OK();
+    return 0;
+}
+
+// ---- backward of the tf32h engine: S is recomputed from the fp16 copies of the features the forward ran on, G = dloss/dS leaves as fp16 under a
+// power-of-two scale taken from the loss gradients on the device (|G| ~ 1e-9 otherwise: far below fp16's range), the two G contractions run on the
+// fp16 MFMA kernels and undo the scale in their epilogue; the gradient through the L2 normalisation stays fp32 on the fp32 features.
+__global__ void cv_gscale_kernel(const float* gloss, int P, int hw, float* out2) {
+    float m = 0.f;
+    for (int p = threadIdx.x; p < P; p += 64) m = fmaxf(m, fabsf(gloss[p]));
+    m = wave_max(m) * 0.5f / (float)hw;
+    if (threadIdx.x == 0) {
+        float s = 1.0f;
+        if (m > 0.f && m < 3.0e38f) s = exp2f(floorf(log2f(4096.0f / m)));      // coef * s <= 4096: G = coef s (p - t) inv sits in fp16's normal range
+        s = fminf(fmaxf(s, 1.0f), 7.9e28f);
+        out2[0] = s;
+        out2[1] = 1.0f / s;
+    }
+}
+extern "C" int gd_gemm_nt_scaled(const void* A, const void* W, void* C, int M, int N, int K, long lda, long ldw, long ldc,
+                                 int batch, long sA, long sW, long sC, int ab_dtype, int c_dtype, float alpha, const float* alpha_dev,
+                                 const float* bias, const float* lora_t, const float* lora_b, int lora_rt, void* preact,
+                                 long ldp, int act, const void* dact_src, long ldd, int dact, const void* residual, long ldr,
+                                 int accumulate, void* stream);
+
+extern "C" size_t gd_cost_volume_kl_bwd_h_workspace_bytes(int P, int hw, int C) {
+    const size_t hwp = (size_t)cv_hwp(hw);
+    return 2 * align256((size_t)P * hw * hwp * 2) + 2 * align256((size_t)P * C * hwp * 2) + 2 * align256((size_t)P * hw * C * sizeof(float)) + 256;
+}
+
+extern "C" int gd_cost_volume_kl_bwd_h(const float* f1, const float* f2, const void* f1h, const void* f2h, const float* t1, const float* t2, int ldt,
+                                       const unsigned char* m1, const unsigned char* m2, int P, int hw, int C, const float* gloss,
+                                       const float* stats, float* df1, float* df2, void* workspace, void* stream) {
+    GD_REQUIRE(P > 0 && hw > 0 && C > 0 && ldt >= hw, "gd_cost_volume_kl_bwd_h: bad shape P=%d hw=%d C=%d ldt=%d", P, hw, C, ldt);
+    GD_REQUIRE(C % 8 == 0, "gd_cost_volume_kl_bwd_h: C must be a multiple of 8");
+    hipStream_t s = (hipStream_t)stream;
+    const int tiles = cv_tiles(hw), hwp = cv_hwp(hw);
+    char* w = (char*)workspace;
+    void* G1 = w; w += align256((size_t)P * hw * hwp * 2);
+    void* G2 = w; w += align256((size_t)P * hw * hwp * 2);
+    void* at = w; w += align256((size_t)P * C * hwp * 2);
+    void* bt = w; w += align256((size_t)P * C * hwp * 2);
+    float* da = (float*)w; w += align256((size_t)P * hw * C * sizeof(float));
+    float* db = (float*)w; w += align256((size_t)P * hw * C * sizeof(float));
+    float* gs = (float*)w;
+    hipLaunchKernelGGL(cv_gscale_kernel, dim3(1), dim3(64), 0, s, gloss, P, hw, gs);
+    CvTileParams q = {};
+    q.f1 = f1h; q.f2 = f2h; q.t1 = t1; q.t2 = t2; q.stats = (float*)stats; q.hw = hw; q.C = C; q.tiles = tiles;
+    q.m1 = m1; q.m2 = m2; q.gloss = gloss; q.G1 = G1; q.G2 = G2; q.hwp = hwp; q.ldt = ldt; q.P = P; q.gscale = gs;
+    dim3 tgrid(gd_cdiv(hwp, 32), gd_cdiv(C, 32), 2 * P);
+    hipLaunchKernelGGL(cv_bwd_tile_kernel<f16>, dim3(tiles * tiles, P), dim3(256), 0, s, q);
+    hipLaunchKernelGGL(cv_transpose_kernel<f16>, tgrid, dim3(256), 0, s, (const f16*)f1h, (const f16*)f2h, (f16*)at, (f16*)bt, hw, hwp, C);
+    GD_LAUNCH_OK();
+    int rc = gd_gemm_nt_scaled(G1, bt, da, hw, C, hwp, hwp, hwp, C, P, (long)hw * hwp, (long)C * hwp, (long)hw * C, GD_F16, GD_F32, 1.0f, gs + 1,
+                               nullptr, nullptr, nullptr, 0, nullptr, 0, 0, nullptr, 0, 0, nullptr, 0, 0, stream);
+    if (rc) return rc;
+    rc = gd_gemm_nt_scaled(G2, at, db, hw, C, hwp, hwp, hwp, C, P, (long)hw * hwp, (long)C * hwp, (long)hw * C, GD_F16, GD_F32, 1.0f, gs + 1,
+                           nullptr, nullptr, nullptr, 0, nullptr, 0, 0, nullptr, 0, 0, nullptr, 0, 0, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(cv_norm_bwd_kernel<float>, dim3(gd_cdiv(hw, 4), 2, P), dim3(256), 0, s, f1, f2, da, db, stats, df1, df2, hw, C);
     GD_LAUNCH_OK();
     return 0;
 }

@@ -377,7 +377,7 @@ class FinetuneGD(nn.Module):
             m2 = F.interpolate(mask_2[:, None].float(), size=(ph, pw), mode="nearest").reshape(P, -1) > 0
         f1, f2 = ops.split_pairs(f, P)
         return ops.cost_volume_kl(f1, f2, cost_1, cost_2, m1, m2, self.variant, tstats=cost_tstats, inv_norms=(inv[:P], inv[P:]),
-                                  x3=getattr(self.model, "gemm_split3", False))
+                                  x3=getattr(self.model, "opfmt", ""))
 
     def calculate_matching_loss(self, rgbs, kp_1, kp_2, pts3d_1, pts3d_2, counts=None):
         """src/finetune_timm_vggt.py:536-574 / src/finetune_timm_mast3r.py:543-589.  pts3d_k [P,N,3] are the

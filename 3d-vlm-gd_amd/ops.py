@@ -231,7 +231,15 @@ class _CostVolumeKL(torch.autograd.Function):
         if inv1 is not None:
             _req(inv1.shape == (P, hw) and inv2.shape == (P, hw) and inv1.dtype == torch.float32 and inv2.dtype == torch.float32 and
                  inv1.is_contiguous() and inv2.is_contiguous(), "cost_volume_kl: inv_norms must be two contiguous fp32 [P, hw] tensors")
-            if x3 and f1.dtype == torch.float32 and C % 8 == 0:
+            ctx.h16 = None
+            if x3 == "h" and f1.dtype == torch.float32 and C % 8 == 0:
+                # tf32h: S from the fp16 copies of the features (TF32's significand); the backward recomputes S from the SAME copies (kept)
+                a16, b16 = cast16(f1.view(P * hw, C)), cast16(f2.view(P * hw, C))
+                ws = torch.empty(lib().gd_cost_volume_kl_workspace_bytes(P, hw, C, 3, 0), dtype=torch.uint8, device=f1.device)
+                rc = lib().gd_cost_volume_kl_fwd_prenorm(ptr(a16), ptr(b16), ptr(inv1), ptr(inv2), ptr(t1), ptr(t2), ldt, ptr(tstats), ptr(m1),
+                                                         ptr(m2), P, hw, C, VARIANTS[variant], 3, ptr(loss), ptr(stats), ptr(ws), stream())
+                ctx.h16 = (a16, b16)
+            elif x3 and f1.dtype == torch.float32 and C % 8 == 0:
                 # tf32x: S = f1 . f2^T as three bf16 MFMA products of the (hi, lo) splits on the bf16 tile kernel (K = 3C) instead of the
                 # exact-f32 MFMA; the row norms stay those of the f32 rows, and the backward (which recomputes S in f32) reads the same
                 # stats layout — logZ from this S agrees with its own to ~1e-6
@@ -253,6 +261,15 @@ class _CostVolumeKL(torch.autograd.Function):
     def backward(ctx, gloss):
         f1, f2, t1, t2, m1, m2, stats = ctx.saved_tensors
         P, hw, C = f1.shape
+        if getattr(ctx, "h16", None) is not None:      # tf32h: fp16 S recompute and G contractions, fp32 gradient through the normalisation
+            a16, b16 = ctx.h16
+            dfull = torch.empty((2 * P, hw, C), dtype=torch.float32, device=f1.device)
+            ws = torch.empty(lib().gd_cost_volume_kl_bwd_h_workspace_bytes(P, hw, C), dtype=torch.uint8, device=f1.device)
+            g = gloss.contiguous().float()
+            rc = lib().gd_cost_volume_kl_bwd_h(ptr(f1), ptr(f2), ptr(a16), ptr(b16), ptr(t1), ptr(t2), t1.shape[-1], ptr(m1), ptr(m2), P, hw, C,
+                                               ptr(g), ptr(stats), ptr(dfull[:P]), ptr(dfull[P:]), ptr(ws), stream())
+            check(rc, "gd_cost_volume_kl_bwd_h")
+            return dfull[:P], dfull[P:], None, None, None, None, None, None, None, None, None
         dt = dtype_code(f1)
         # the two halves of ONE buffer: split_pairs' backward hands it on without a concatenation pass (134 MB at the step's size)
         dfull = torch.empty((2 * P, hw, C), dtype=f1.dtype, device=f1.device)

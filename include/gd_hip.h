@@ -275,6 +275,13 @@ int gd_split3(const float* in, void* out, long rows, int K, long ld_in, int whic
  * gd_gemm_nt_scaled: gd_gemm_nt with alpha multiplied by the device scalar *alpha_dev (the 1/s of a scaled operand) — no host round trip.
  * gd_gemm_nt itself takes ab_dtype GD_F16 (f32 results, or c_dtype GD_F16: an fp16 C beside f32 preact / dact_src). */
 int gd_cast_f16(const float* in, void* out, long rows, int K, long ld_in, float scale, const float* scale_dev, void* stream);
+/* Cost-volume KL of the tf32h engine: gd_cost_volume_kl_fwd_prenorm takes dtype GD_F16 (fp16 copies of the fp32 features, the fp32 rows' norms);
+ * the backward recomputes S from the same fp16 copies, writes G = dloss/dS as fp16 under a power-of-two scale taken from `gloss` on the device,
+ * contracts it on the fp16 MFMA kernels and takes the gradient through the L2 normalisation in fp32 on the fp32 features (df1, df2 fp32). */
+size_t gd_cost_volume_kl_bwd_h_workspace_bytes(int P, int hw, int C);
+int gd_cost_volume_kl_bwd_h(const float* f1, const float* f2, const void* f1h, const void* f2h, const float* t1, const float* t2, int ldt,
+                            const unsigned char* m1, const unsigned char* m2, int P, int hw, int C, const float* gloss, const float* stats,
+                            float* df1, float* df2, void* workspace, void* stream);
 /* gd_gemm_tn with alpha multiplied by the device scalar *alpha_dev (weight gradients contracted from SCALED fp16 gradient operands);
  * gd_gemm_tn takes fp16 Y and X on the MFMA kernel (N, K >= 64) and fp16 X on the N = 8 streaming kernel. */
 int gd_gemm_tn_scaled(const void* Y, const void* X, float* G, int M, int N, int K, long ldy, long ldx, long ldg,

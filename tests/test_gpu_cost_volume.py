@@ -180,3 +180,34 @@ def test_split_precision_forward(variant):
     assert rel_err(loss, ol) < 1e-5
     assert rel_err(f1.grad, og1) < 1e-4 and rel_err(f2.grad, og2) < 1e-4
 
+
+
+@pytest.mark.parametrize("variant", ["mast3r", "vggt"])
+def test_fp16_operand_forward_and_backward(variant):
+    """cost_volume_kl(x3="h") on fp32 features (tf32h engine): S from fp16 copies of the features (forward and the backward's recompute), G = dloss/dS
+    as fp16 under a device-side power-of-two scale (|G| ~ 1e-9 unscaled), both contractions on the fp16 MFMA kernels, the gradient through the
+    normalisation in fp32: loss within 1e-4, gradients within 2e-3 of the fp64 oracle (bf16 features: 1e-3 / 1e-2), finite for a zero loss gradient."""
+    from gd_amd import ops
+    P, hw, C = 2, 1369, 768
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    f1 = torch.randn(P, hw, C, generator=gen, device="cuda").requires_grad_(True)
+    f2 = torch.randn(P, hw, C, generator=gen, device="cuda").requires_grad_(True)
+    t1 = torch.softmax(3 * torch.randn(P, hw, hw, generator=gen, device="cuda"), -1)
+    t2 = torch.softmax(3 * torch.randn(P, hw, hw, generator=gen, device="cuda"), -1)
+    m1 = torch.rand(P, hw, generator=gen, device="cuda") > 0.5
+    m2 = torch.rand(P, hw, generator=gen, device="cuda") > 0.5
+    c1, c2, ts = _teacher("cached", t1, t2)
+    inv1 = 1.0 / f1.detach().norm(dim=-1).clamp_min(1e-12)
+    inv2 = 1.0 / f2.detach().norm(dim=-1).clamp_min(1e-12)
+    loss = ops.cost_volume_kl(f1, f2, c1, c2, m1, m2, variant, tstats=ts, inv_norms=(inv1, inv2), x3="h")
+    (loss * torch.tensor([1.0, 1e-3], device="cuda")).sum().backward()          # pairs with very different loss gradients share one scale
+    ol, og1, og2 = _oracle(f1.detach(), f2.detach(), t1, t2, m1, m2, variant)
+    assert rel_err(loss, ol) < 1e-4
+    w = torch.tensor([1.0, 1e-3], dtype=torch.float64).view(P, 1, 1)
+    assert f1.grad.dtype == torch.float32 and bool(torch.isfinite(f1.grad).all())
+    for p in range(P):
+        assert rel_err(f1.grad[p], (og1 * w)[p]) < (2e-3 if p == 0 else 2e-2) and rel_err(f2.grad[p], (og2 * w)[p]) < (2e-3 if p == 0 else 2e-2), p
+    f1.grad = f2.grad = None
+    loss = ops.cost_volume_kl(f1, f2, c1, c2, m1, m2, variant, tstats=ts, inv_norms=(inv1, inv2), x3="h")
+    (loss * 0.0).sum().backward()
+    assert float(f1.grad.abs().max()) == 0.0 and bool(torch.isfinite(f2.grad).all())
