@@ -240,7 +240,16 @@ class _BlockFn(torch.autograd.Function):
         fmt = plan["x3"]
         # tf32h: ONE power-of-two scale per block, from the incoming gradient's maximum (on the device), carries every gradient operand of
         # the block into fp16's range: |dout| * s <= 8 leaves 2^13 of headroom above and 2^17 of full-precision range below
-        sc = ops.amax_scale(dout.view(-1, D), 8.0) if fmt == "h" else None
+        # (with a per-step pack the scale is taken ONCE, by the first block that runs its backward — the last ViT block — and shared down the stack)
+        sc = None
+        if fmt == "h":
+            holder = tw.get("gs") if tw is not None else None
+            if holder is not None and holder[0] is not None:
+                sc = holder[0]
+            else:
+                sc = ops.amax_scale(dout.view(-1, D), 8.0)
+                if holder is not None:
+                    holder[0] = sc
         # the four weight-gradient accumulators of the block come out of ONE zero-filled buffer
         bott = down.shape[0] if ctx.has_ad else 0
         r2 = at.shape[0] if ctx.has_lora else 0
@@ -549,7 +558,9 @@ class GDViT(nn.Module):
                 w3 = lambda w: _opw(w.reshape(-1, w.shape[-1]).contiguous(), self.opfmt).view(L, w.shape[1], -1)
                 for i, pack in enumerate(zip(w3(down_T), w3(up_T), w3(down_tT), w3(up_tT))):
                     extra[i].update(zip(("down_w3", "up_w3", "down_tw3", "up_tw3"), pack))
+        gs_holder = [None]      # tf32h: the step's gradient scale (ops.amax_scale triple), set by the first block backward of the step
         for i, (inner, _, _) in enumerate(lo):
+            extra[i]["gs"] = gs_holder
             inner._tw = {"dtype": T, "at": at[i], "bt": bt[i], "at_T": at_T[i], "bt_T": bt_T[i], "bt_qv": bt_qv[i], "down_T": down_T[i],
                          "up_T": up_T[i], "down_tT": down_tT[i], "up_tT": up_tT[i], **extra[i]}
 
