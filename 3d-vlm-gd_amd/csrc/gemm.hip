@@ -20,6 +20,7 @@ struct GemmNtParams {
     int c_dtype;                     // dtype of C / preact / dact_src / residual
     float alpha;
     const float* alpha_dev;          // device scalar multiplied into alpha (gd_gemm_nt_scaled), or null
+    const float* copy_scale;         // gd_gemm_nt_copy16: device scalar multiplied into the fp16 copy of the result (p.preact), or null
     const float* bias;               // [N]
     const float* lora_t; const float* lora_b; int lora_rt;   // v += sum_r t[m,r] * b[r,n]
     void* preact; long ldp;          // store v before the activation
@@ -741,7 +742,13 @@ static int gemm_nt_impl(const void* A, const void* W, void* C, int M, int N, int
                         int batch, long sA, long sW, long sC, int ab_dtype, int c_dtype, float alpha, const float* alpha_dev,
                         const float* bias, const float* lora_t, const float* lora_b, int lora_rt, void* preact,
                         long ldp, int act, const void* dact_src, long ldd, int dact, const void* residual, long ldr,
-                        int accumulate, void* stream) {
+                        int accumulate, void* stream, void* copy16 = nullptr, long ldc16 = 0, const float* copy_scale = nullptr) {
+    if (copy16) {       // gd_gemm_nt_copy16: f32 C = ... + residual AND an fp16 copy of it (times *copy_scale): the persistent fp16-operand kernel only
+        GD_REQUIRE(ab_dtype == GD_F16 && c_dtype == GD_F32 && residual && !preact && !dact_src && act == 0 && !accumulate && batch == 1 &&
+                       ((uintptr_t)copy16 & 15) == 0 && (ldc16 * 2) % 16 == 0,
+                   "gd_gemm_nt_copy16: fp16 operands, f32 C with a residual and no other epilogue tensor; copy16 16-byte aligned");
+        preact = copy16; ldp = ldc16;
+    }
     GD_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0, "gd_gemm_nt: bad shape M=%d N=%d K=%d batch=%d", M, N, K, batch);
     GD_REQUIRE(ab_dtype == GD_F32 || ab_dtype == GD_BF16 || ab_dtype == GD_F16, "gd_gemm_nt: bad ab_dtype %d", ab_dtype);
     GD_REQUIRE(c_dtype == GD_F32 || c_dtype == GD_BF16 || c_dtype == GD_F32X3 || c_dtype == GD_F16, "gd_gemm_nt: bad c_dtype %d", c_dtype);
@@ -765,8 +772,9 @@ static int gemm_nt_impl(const void* A, const void* W, void* C, int M, int N, int
                "gd_gemm_nt: batched calls take no epilogue tensors");
     GemmNtParams p;
     p.A = A; p.W = W; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc;
-    p.sA = sA; p.sW = sW; p.sC = sC; p.c_dtype = c_dtype; p.alpha = alpha; p.alpha_dev = alpha_dev; p.bias = bias;
+    p.sA = sA; p.sW = sW; p.sC = sC; p.c_dtype = c_dtype; p.alpha = alpha; p.alpha_dev = alpha_dev; p.copy_scale = copy_scale; p.bias = bias;
     p.lora_t = lora_t; p.lora_b = lora_b; p.lora_rt = lora_rt; p.preact = preact; p.ldp = ldp; p.act = act == 3 ? 1 : act; p.act_deriv = act == 3;
+    if (copy16) preact = nullptr;      // (for the dispatch below: not a pre-activation store)
     p.dact_src = dact_src; p.ldd = ldd; p.dact = dact_src ? dact : 0; p.residual = residual; p.ldr = ldr;
     p.accumulate = accumulate;
     const bool chalf = c_dtype == GD_F16;         // fp16 C beside f32 preact / dact_src / residual
@@ -827,7 +835,7 @@ static int gemm_nt_impl(const void* A, const void* W, void* C, int M, int N, int
             else if ((act == 1 || act == 3) && !preact) pk = ch ? gemm_nt_persist_kernel<f16, 0, 1, 0, true, 0, 2> : gemm_nt_persist_kernel<f16, 0, 1, 0, true>;
             else if (act == 3 && preact) pk = ch ? gemm_nt_persist_kernel<f16, 0, 1, 2, true, 0, 2> : gemm_nt_persist_kernel<f16, 0, 1, 2, true>;
         } else if (dact_src && dact == 3 && act == 0 && !preact) pk = ch ? gemm_nt_persist_kernel<f16, 3, 0, 0, true, 0, 2> : gemm_nt_persist_kernel<f16, 3, 0, 0, true>;
-        else if (residual && act == 0 && !preact && !ch) pk = gemm_nt_persist_kernel<f16, 2, 0, 0, true>;
+        else if (residual && act == 0 && !preact && !ch) pk = copy16 ? gemm_nt_persist_kernel<f16, 2, 0, 3, true> : gemm_nt_persist_kernel<f16, 2, 0, 0, true>;
     }
     // (the bf16 f32-output instantiations serve the tf32x engine: 3K-wide split operands, fp32 C / preact / dact_src / residual)
     const bool persist_ok = big && persist && pk && p.vec_epilogue && N % 8 == 0 && (!lora_t || lora_rt == 8) && 256 * ldmax * cs < 0x7fffffffL;
@@ -837,6 +845,7 @@ static int gemm_nt_impl(const void* A, const void* W, void* C, int M, int N, int
     GD_REQUIRE(!chalf || persist_ok || (!preact && !dact_src && !residual),
                "gd_gemm_nt: an fp16 C beside f32 epilogue tensors is served by the persistent kernel only (M >= 1024, N >= 256, K %% 64 == 0; "
                "GELU(+derivative) or dact 3 epilogues): M=%d N=%d K=%d act=%d dact=%d", M, N, K, act, dact);
+    GD_REQUIRE(!copy16 || persist_ok, "gd_gemm_nt_copy16: served by the persistent kernel only (M >= 1024, N >= 256, K %% 64 == 0): M=%d N=%d K=%d", M, N, K);
     if (persist_ok) {
         // (Tile quantisation — e.g. 1029 tiles of the N = 768 GEMMs on 256 CUs — costs far less than a round: the left-over
         // tiles run alone on an idle chip.  Handing them to the 128 x 128 kernel or cutting them into K slices was measured
@@ -921,6 +930,13 @@ static int gemm_tn_impl(const void* Y, const void* X, float* G, int M, int N, in
     else hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
     GD_LAUNCH_OK();
     return 0;
+}
+
+extern "C" int gd_gemm_nt_copy16(const void* A, const void* W, void* C, int M, int N, int K, long lda, long ldw, long ldc, float alpha,
+                                 const float* alpha_dev, const float* bias, const void* residual, long ldr, void* copy16, long ldc16,
+                                 const float* copy_scale_dev, void* stream) {
+    return gemm_nt_impl(A, W, C, M, N, K, lda, ldw, ldc, 1, 0, 0, 0, GD_F16, GD_F32, alpha, alpha_dev, bias, nullptr, nullptr, 0, nullptr, 0, 0, nullptr,
+                        0, 0, residual, ldr, 0, stream, copy16, ldc16, copy_scale_dev);
 }
 
 extern "C" int gd_gemm_tn(const void* Y, const void* X, float* G, int M, int N, int K, long ldy, long ldx, long ldg,

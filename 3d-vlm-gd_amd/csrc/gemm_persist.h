@@ -17,7 +17,7 @@
 #include <type_traits>
 
 // Compile-time epilogue: SIDE 0 none | 1 v *= dGELU(dact_src) | 2 v += residual | 3 v *= dact_src (bf16 side tensor,
-// prefetched); ACT 0 none | 1 GELU | 2 ReLU; PREACT 0 none | 1 store v before the activation | 2 store GELU'(v) (the
+// prefetched); ACT 0 none | 1 GELU | 2 ReLU; PREACT 0 none | 1 store v before the activation | 3 store an fp16 copy of the FINAL v times *copy_scale (p.preact: the tf32h engine's next left operand) | 2 store GELU'(v) (the
 // backward then only multiplies: SIDE 3 — recomputing dGELU from the stored pre-activation cost 20 k cycles per tile of
 // the fc1 backward GEMM); CF32 C / preact are f32 (else bf16).
 // (With these as run-time flags the 16-item unrolled epilogue was ~160 scalar branches per tile: 4 k cycles of a
@@ -63,6 +63,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
     const bool lora = p.lora_t != nullptr;
     const float alpha = p.alpha_dev ? p.alpha * *p.alpha_dev : p.alpha;      // gd_gemm_nt_scaled: the operands' power-of-two scale, undone here
     const float ia = 1.0f / alpha;
+    const float cscale = (PREACT == 3 && p.copy_scale) ? *p.copy_scale : 1.0f;
 
     // DMA sources: wave-uniform tile base (SGPRs) + one 32-bit byte offset per lane and 1-KB piece.  LDS row rho of
     // piece i is (wave*APW + i)*8 + (lane>>3); rows past the matrix edge are clamped (read, never stored).
@@ -233,7 +234,8 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
                                                      (int)min((long)0x7fffffff, (long)vrows * ld * es), 0x00020000);
         };
         const __amdgpu_buffer_rsrc_t crs = mk(Cb, p.ldc, ccsz);
-        const __amdgpu_buffer_rsrc_t prs = mk(PREACT ? p.preact : Cb, PREACT ? p.ldp : p.ldc, PREACT ? csz : ccsz);
+        constexpr int psz = PREACT == 3 ? 2 : csz;
+        const __amdgpu_buffer_rsrc_t prs = mk(PREACT ? p.preact : Cb, PREACT ? p.ldp : p.ldc, PREACT ? psz : ccsz);
         const __amdgpu_buffer_rsrc_t srs = mk(pre ? side_src : (const void*)Cb, pre ? side_ld : p.ldc, pre ? ssz : ccsz);
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
         if (p.bias) {
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
         // per-item 32-bit multiply (quarter rate) + select.  A lane past N keeps OOB as its base: OOB + (< 2^31) stays >= every
         // num_records as an unsigned offset.
         const int cbase = cok ? (rloc * ldc_i + col0) * ccsz : OOB;
-        const int pbase = cok ? (rloc * ldp_i + col0) * csz : OOB;
+        const int pbase = cok ? (rloc * ldp_i + col0) * psz : OOB;
         const int sbase = cok ? (rloc * lds_i + col0) * ssz : OOB;
         constexpr int NITEM = 4 * WMT;   // idx = 4 i + r
         typedef typename std::conditional<CF32, gd_u32x4, gd_u32x2>::type SideReg;    // four side values of an item: f32 or bf16
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
                 asm volatile("" ::: "memory");   // nothing younger may be hoisted above the DMA: `after` counts on it
                 GD_PROBE({ const unsigned long long c = __builtin_amdgcn_s_memtime(); pd += c - pc0; pc0 = c; })
             }
-            const int coff = cbase + (i * 16 + r) * ccsz * ldc_i, poff = pbase + (i * 16 + r) * csz * ldp_i;
+            const int coff = cbase + (i * 16 + r) * ccsz * ldc_i, poff = pbase + (i * 16 + r) * psz * ldp_i;
             float v[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = fmaf(alpha, acc[i][j][r], bv[j]);
@@ -325,6 +327,10 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
                     if (SIDE == 2) v[j] += x[j];
                     if (SIDE == 3) v[j] *= x[j];
                 }
+            }
+            if (PREACT == 3) {
+                const float c16[4] = {v[0] * cscale, v[1] * cscale, v[2] * cscale, v[3] * cscale};
+                bst4_aux<GD_PERSIST_STORE_AUX>(prs, poff, GD_F16, c16);
             }
             if (CSPLIT) {
                 float lo[4];

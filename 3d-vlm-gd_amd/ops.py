@@ -129,6 +129,23 @@ def split_out_ok(M, N, K3):
     return M >= 1024 and N >= 256 and N % 8 == 0 and K3 % 64 == 0
 
 
+def gemm_nt_copy16(a, w, residual, *, bias=None, alpha=1.0, alpha_dev=None, copy_scale=None):
+    """fp16 operands: out [M,N] f32 = alpha * alpha_dev * a.w^T + bias + residual, and copy [M,N] fp16 = sat(out * copy_scale[0]) from the same
+    epilogue — the residual-stream result plus the operand the next tf32h product takes (gd_gemm_nt_copy16; copy16_ok() says which shapes)."""
+    _req(a.dtype == torch.float16 and w.dtype == torch.float16 and a.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1 and
+         residual.dtype == torch.float32 and residual.stride(1) == 1, "gemm_nt_copy16: fp16 operands, fp32 residual")
+    (M, K), N = a.shape, w.shape[0]
+    out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    copy = torch.empty(M, N, dtype=torch.float16, device=a.device)
+    check(lib().gd_gemm_nt_copy16(ptr(a), ptr(w), ptr(out), M, N, K, a.stride(0), w.stride(0), N, float(alpha), ptr(alpha_dev), ptr(bias),
+                                  ptr(residual), residual.stride(0), ptr(copy), N, ptr(copy_scale), stream()), "gd_gemm_nt_copy16")
+    return out, copy
+
+
+def copy16_ok(M, N, K):
+    return M >= 1024 and N >= 256 and N % 8 == 0 and K % 64 == 0
+
+
 def cast16(x, scale=1.0, scale_dev=None):
     """f32 [rows, K] (rows may be strided) -> fp16 [rows, K] = sat(x * scale * scale_dev[0]): an operand of the tf32h engine's products (fp16
     carries TF32's 11-bit significand).  Forward activations and weights go in unscaled; gradients with the power of two of `amax_scale`."""

@@ -201,7 +201,12 @@ class _BlockFn(torch.autograd.Function):
         hs = bool(fmt) and ops.split_out_ok(M, plan["w1"].shape[0], plan["w1"].shape[1])
         hkw = {} if not hs else {"out_split": True} if fmt == "x3" else {"out_dtype": torch.float16}
         h = _mm(None if fmt == "h" else y2, plan, "w1", xs=y2 if fmt == "h" else None, bias=plan["b1"], act=3, preact=pre, **hkw)   # pre <- GELU'(fc1 output): all the backward needs
-        x2 = _mm(None if hs else h, plan, "w2", xs=h if hs else None, bias=plan["b2"], residual=x1)
+        x2a = None
+        if fmt == "h" and hs and down is not None and ops.copy16_ok(M, D, plan["w2"].shape[1]):
+            # tf32h: fc2 writes the residual-stream result and, from the same epilogue, the fp16 copy the adapter's down projection takes
+            x2, x2a = ops.gemm_nt_copy16(h, plan["w2"], x1, bias=plan["b2"])
+        else:
+            x2 = _mm(None if hs else h, plan, "w2", xs=h if hs else None, bias=plan["b2"], residual=x1)
         out, hd, hd16 = x2, None, None
         if down is not None:
             down_T = tw["down_T"] if tw is not None else down.detach().to(T).contiguous()
@@ -211,7 +216,8 @@ class _BlockFn(torch.autograd.Function):
             elif plan["x3"]:        # tf32x: both projections as split-precision products on the bf16 kernels (the fp32 tile kernel: 2 x 370 us)
                 w_dn = tw["down_w3"] if tw is not None and "down_w3" in tw else _opw(down_T, fmt)
                 w_up = tw["up_w3"] if tw is not None and "up_w3" in tw else _opw(up_T, fmt)
-                x2a = _opa(x2, fmt)
+                if x2a is None:
+                    x2a = _opa(x2, fmt)
                 hd = ops.gemm_nt(x2a, w_dn, act=2, out_dtype=torch.float32)
                 hda = _opa(hd, fmt)
                 out = ops.gemm_nt(hda, w_up, residual=x2, out_dtype=torch.float32)
@@ -235,7 +241,7 @@ class _BlockFn(torch.autograd.Function):
         T, D, H = plan["dtype"], plan["D"], plan["H"]
         dout = dout.contiguous().to(T)
         g_down = g_up = g_aq = g_bq = g_av = g_bv = None
-        dx2 = dout
+        dx2, dx2a = dout, None
         tw = ctx.tw
         fmt = plan["x3"]
         # tf32h: ONE power-of-two scale per block, from the incoming gradient's maximum (on the device), carries every gradient operand of
@@ -273,7 +279,10 @@ class _BlockFn(torch.autograd.Function):
                 douta = _opa(dout.view(-1, D), fmt, sc)
                 dhp = ops.gemm_nt(douta, w_ut, dact_src=hd, dact=2, out_dtype=torch.float32, alpha_dev=ad)
                 dhpa = _opa(dhp, fmt, sc)
-                dx2 = ops.gemm_nt(dhpa, w_dt, residual=dout.view(-1, D), out_dtype=torch.float32, alpha_dev=ad)
+                if fmt == "h" and ops.copy16_ok(dhpa.shape[0], D, dhpa.shape[1]):      # dx2 and its scaled fp16 copy (the fc2 backward's operand) at once
+                    dx2, dx2a = ops.gemm_nt_copy16(dhpa, w_dt, dout.view(-1, D), alpha_dev=ad, copy_scale=sc[0:1])
+                else:
+                    dx2 = ops.gemm_nt(dhpa, w_dt, residual=dout.view(-1, D), out_dtype=torch.float32, alpha_dev=ad)
             else:
                 dhp = ops.gemm_nt(dout, up_tT, dact_src=hd, dact=2)                               # [M, 64]
                 dx2 = ops.gemm_nt(dhp, down_tT, residual=dout)
@@ -287,7 +296,7 @@ class _BlockFn(torch.autograd.Function):
                 g_down = ops.gemm_tn(dhp, x2, out=z_down)                                         # [64, D]
         hs = bool(fmt) and ops.split_out_ok(dx2.shape[0], plan["w2_t"].shape[0], plan["w2_t"].shape[1])
         hkw = {} if not hs else {"out_split": True} if fmt == "x3" else {"out_dtype": torch.float16}      # (tf32h: fp16, still times s)
-        dpre = _mm(dx2, plan, "w2_t", sc=sc, dact_src=pre, dact=3, **hkw)                         # [M, 4D] (x stored GELU')
+        dpre = _mm(dx2, plan, "w2_t", xs=dx2a, sc=sc, dact_src=pre, dact=3, **hkw)                # [M, 4D] (x stored GELU')
         dy2 = _mm(None if hs else dpre, plan, "w1_t", xs=dpre if hs else None, sc=sc)
         del dpre
         if fmt == "h":      # the LN backward also writes fp16(dx1 * s), the left operand of the projection's backward; do leaves as fp16, times s

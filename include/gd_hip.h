@@ -282,6 +282,11 @@ size_t gd_cost_volume_kl_bwd_h_workspace_bytes(int P, int hw, int C);
 int gd_cost_volume_kl_bwd_h(const float* f1, const float* f2, const void* f1h, const void* f2h, const float* t1, const float* t2, int ldt,
                             const unsigned char* m1, const unsigned char* m2, int P, int hw, int C, const float* gloss, const float* stats,
                             float* df1, float* df2, void* workspace, void* stream);
+/* gd_gemm_nt_copy16: C[M,N] (f32) = alpha * (*alpha_dev) * A.W^T + bias + residual on fp16 operands, AND copy16[M,N] = fp16(sat(C * *copy_scale_dev)) —
+ * the residual-stream result together with the fp16 operand the next product of the tf32h engine takes (persistent-kernel shapes only). */
+int gd_gemm_nt_copy16(const void* A, const void* W, void* C, int M, int N, int K, long lda, long ldw, long ldc, float alpha,
+                      const float* alpha_dev, const float* bias, const void* residual, long ldr, void* copy16, long ldc16,
+                      const float* copy_scale_dev, void* stream);
 /* gd_gemm_tn with alpha multiplied by the device scalar *alpha_dev (weight gradients contracted from SCALED fp16 gradient operands);
  * gd_gemm_tn takes fp16 Y and X on the MFMA kernel (N, K >= 64) and fp16 X on the N = 8 streaming kernel. */
 int gd_gemm_tn_scaled(const void* Y, const void* X, float* G, int M, int N, int K, long ldy, long ldx, long ldg,

@@ -368,3 +368,21 @@ def test_fp16_gradient_operands_carry_a_device_side_scale():
     big = ops.gemm_nt(ops.cast16(torch.full((1024, 64), 60000.0, device="cuda")), ops.cast16(torch.ones(256, 64, device="cuda")),
                       out_dtype=torch.float16)
     assert bool(torch.isfinite(big).all()) and float(big.max()) == 65504.0
+
+
+def test_gemm_nt_copy16_writes_the_f32_result_and_its_scaled_fp16_copy():
+    """gd_gemm_nt_copy16 (tf32h engine): the residual-stream result in f32 and, from the same epilogue, fp16(sat(result * s)) with s a device
+    scalar — bit-identical to the plain call followed by gd_cast_f16; other shapes are refused."""
+    from gd_amd import ops
+    from gd_amd._lib import GdHipError
+    M, N, K = 1300, 768, 192
+    a, w = _mk((M, K), torch.float32, 61).half(), _mk((N, K), torch.float32, 62).half()
+    res, bias = _mk((M, N), torch.float32, 63), _mk((N,), torch.float32, 64)
+    sc = ops.amax_scale(res * 1e-5, 8.0)
+    out, c16 = ops.gemm_nt_copy16(a, w, res, bias=bias, alpha_dev=sc[1:2], copy_scale=sc[0:1])
+    ref = ops.gemm_nt(a, w, out_dtype=torch.float32, bias=bias, residual=res, alpha_dev=sc[1:2])
+    assert torch.equal(out, ref) and c16.dtype == torch.float16
+    want = ops.cast16(ref, scale_dev=sc[0:1])
+    assert float((c16 != want).float().mean()) < 0.01 and rel_err(c16.float(), want.float()) < 1e-3       # (packed vs scalar multiply: last-ulp differences)
+    with pytest.raises(GdHipError):
+        ops.gemm_nt_copy16(a[:512], w, res[:512])
