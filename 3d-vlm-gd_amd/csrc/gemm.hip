@@ -680,8 +680,9 @@ static bool gd_force_small_tiles() { return gd_knobs().gemm_small_tiles == 1; } 
 // flight), W lives in LDS as [K-step][8 rows][64 B] (conflict-free linear fragment reads; columns 8..15 of the MFMA tile
 // are fed zeros) and the 16 x 8 result leaves as two 16-byte stores per row.
 #define SK_ROWS 8
-template <typename TC>
+template <typename TC, typename TA = bf16>      // TA: the 16-bit operand type (bf16 | f16)
 __global__ __launch_bounds__(512) void gemm_nt_skinny_kernel(GemmNtParams p) {
+    typedef typename Mma<TA>::Frag Frag;
     extern __shared__ __attribute__((aligned(16))) char sW[];       // K/32 x 512 B
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -690,7 +691,7 @@ __global__ __launch_bounds__(512) void gemm_nt_skinny_kernel(GemmNtParams p) {
     for (int q = tid; q < SK_ROWS * (p.K >> 3); q += 512) {
         const int r = q / (p.K >> 3), j = q % (p.K >> 3);
         uint4 v = {0u, 0u, 0u, 0u};
-        if (r < p.N) v = *(const uint4*)((const bf16*)p.W + (long)r * p.ldw + j * 8);
+        if (r < p.N) v = *(const uint4*)((const TA*)p.W + (long)r * p.ldw + j * 8);
         *(uint4*)(sW + (j >> 2) * 512 + r * 64 + (j & 3) * 16) = v;
     }
     __syncthreads();
@@ -700,31 +701,31 @@ __global__ __launch_bounds__(512) void gemm_nt_skinny_kernel(GemmNtParams p) {
     const char* wr = sW + (c & 7) * 64 + 16 * g;
     const bool wlive = c < SK_ROWS;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    bf16x8 a0[4], a1[4];
+    Frag a0[4], a1[4];
     const int nb = nks >> 2;                                        // batches of four K-steps (K % 128 == 0)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) a0[k] = *(const bf16x8*)(ar + k * 64);
+    for (int k = 0; k < 4; ++k) a0[k] = *(const Frag*)(ar + k * 64);
     for (int b = 0; b < nb; b += 2) {
         if (b + 1 < nb) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) a1[k] = *(const bf16x8*)(ar + (b + 1) * 256 + k * 64);
+            for (int k = 0; k < 4; ++k) a1[k] = *(const Frag*)(ar + (b + 1) * 256 + k * 64);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            bf16x8 w = {};
-            if (wlive) w = *(const bf16x8*)(wr + (b * 4 + k) * 512);
-            if (k & 1) acc1 = Mma<bf16>::mma(a0[k], w, acc1); else acc0 = Mma<bf16>::mma(a0[k], w, acc0);
+            Frag w = {};
+            if (wlive) w = *(const Frag*)(wr + (b * 4 + k) * 512);
+            if (k & 1) acc1 = Mma<TA>::mma(a0[k], w, acc1); else acc0 = Mma<TA>::mma(a0[k], w, acc0);
         }
         if (b + 2 < nb) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) a0[k] = *(const bf16x8*)(ar + (b + 2) * 256 + k * 64);
+            for (int k = 0; k < 4; ++k) a0[k] = *(const Frag*)(ar + (b + 2) * 256 + k * 64);
         }
         if (b + 1 < nb) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                bf16x8 w = {};
-                if (wlive) w = *(const bf16x8*)(wr + ((b + 1) * 4 + k) * 512);
-                if (k & 1) acc1 = Mma<bf16>::mma(a1[k], w, acc1); else acc0 = Mma<bf16>::mma(a1[k], w, acc0);
+                Frag w = {};
+                if (wlive) w = *(const Frag*)(wr + ((b + 1) * 4 + k) * 512);
+                if (k & 1) acc1 = Mma<TA>::mma(a1[k], w, acc1); else acc0 = Mma<TA>::mma(a1[k], w, acc0);
             }
         }
     }
@@ -792,10 +793,11 @@ static int gemm_nt_impl(const void* A, const void* W, void* C, int M, int N, int
     dim3 gridb(gd_cdiv(M, 256) * gd_cdiv(N, 256), batch);
     hipStream_t st = (hipStream_t)stream;
     const int persist = gd_knobs().gemm_persist, ncu = gd_knobs().ncu;
-    if (ab_dtype == GD_BF16 && N <= SK_ROWS && M >= 4096 && batch == 1 && K % 128 == 0 && K <= 4096 && !bias && !lora_t && !preact &&
+    if ((ab_dtype == GD_BF16 || (ab_dtype == GD_F16 && c_dtype == GD_F32)) && N <= SK_ROWS && M >= 4096 && batch == 1 && K % 128 == 0 && K <= 4096 && !bias && !lora_t && !preact &&
         act == 0 && !dact_src && !residual && !accumulate) {
         const size_t lds = (size_t)(K / 32) * 512;
-        if (c_dtype == GD_F32) hipLaunchKernelGGL(gemm_nt_skinny_kernel<float>, dim3(gd_cdiv(M, 128)), dim3(512), lds, st, p);
+        if (ab_dtype == GD_F16) hipLaunchKernelGGL((gemm_nt_skinny_kernel<float, f16>), dim3(gd_cdiv(M, 128)), dim3(512), lds, st, p);
+        else if (c_dtype == GD_F32) hipLaunchKernelGGL(gemm_nt_skinny_kernel<float>, dim3(gd_cdiv(M, 128)), dim3(512), lds, st, p);
         else hipLaunchKernelGGL(gemm_nt_skinny_kernel<bf16>, dim3(gd_cdiv(M, 128)), dim3(512), lds, st, p);
         GD_LAUNCH_OK();
         return 0;
