@@ -371,6 +371,9 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_nt_kernel(GemmNtParams p)
 }
 
 #include "gemm_persist.h"
+#ifdef GD_GEMM_EXPERIMENT32
+#include "gemm_persist32.h"      // tools/experiments (make FLAGS+="-DGD_GEMM_EXPERIMENT32 -I../../tools/experiments")
+#endif
 
 // Phase probe of the persistent kernel: exists only in -DGD_GEMM_STAGE_PROBE builds (its s_memtime reads cost 20 % even unarmed,
 // and its accumulator is process-wide state); the shipped library has neither the device code nor the global, and the entry
@@ -848,6 +851,19 @@ static int gemm_nt_impl(const void* A, const void* W, void* C, int M, int N, int
                "gd_gemm_nt: an fp16 C beside f32 epilogue tensors is served by the persistent kernel only (M >= 1024, N >= 256, K %% 64 == 0; "
                "GELU(+derivative) or dact 3 epilogues): M=%d N=%d K=%d act=%d dact=%d", M, N, K, act, dact);
     GD_REQUIRE(!copy16 || persist_ok, "gd_gemm_nt_copy16: served by the persistent kernel only (M >= 1024, N >= 256, K %% 64 == 0): M=%d N=%d K=%d", M, N, K);
+#ifdef GD_GEMM_EXPERIMENT32
+    if (persist == 32 && big && ab_dtype == GD_BF16 && c_dtype == GD_BF16 && !bias && !lora_t && !preact && act == 0 && !dact_src && !residual &&
+        !accumulate && (K * 2) % 128 == 0) {
+        const int ntiles = gd_cdiv(M, 256) * gd_cdiv(N, 256);
+        dim3 gridp(ntiles < ncu ? ntiles : ncu, batch);
+        const int v = gd_knobs().gemm_anat;
+        if (v == 1) hipLaunchKernelGGL(gemm_nt_p32_kernel<1>, gridp, dim3(512), 0, st, p);
+        else if (v == 4) hipLaunchKernelGGL(gemm_nt_p32_kernel<4>, gridp, dim3(512), 0, st, p);
+        else hipLaunchKernelGGL(gemm_nt_p32_kernel<0>, gridp, dim3(512), 0, st, p);
+        GD_LAUNCH_OK();
+        return 0;
+    }
+#endif
     if (persist_ok) {
         // (Tile quantisation — e.g. 1029 tiles of the N = 768 GEMMs on 256 CUs — costs far less than a round: the left-over
         // tiles run alone on an idle chip.  Handing them to the 128 x 128 kernel or cutting them into K slices was measured
