@@ -756,8 +756,8 @@ static int gemm_nt_impl(const void* A, const void* W, void* C, int M, int N, int
     GD_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0, "gd_gemm_nt: bad shape M=%d N=%d K=%d batch=%d", M, N, K, batch);
     GD_REQUIRE(ab_dtype == GD_F32 || ab_dtype == GD_BF16 || ab_dtype == GD_F16, "gd_gemm_nt: bad ab_dtype %d", ab_dtype);
     GD_REQUIRE(c_dtype == GD_F32 || c_dtype == GD_BF16 || c_dtype == GD_F32X3 || c_dtype == GD_F16, "gd_gemm_nt: bad c_dtype %d", c_dtype);
-    // fp16 operands (tf32h engine): C / preact / dact_src / residual are f32, or C alone is fp16 (c_dtype GD_F16: the operand of the next
-    // product, saturated at +-65504) with f32 preact / dact_src / residual; bf16 operands never write fp16
+    // fp16 operands (tf32h engine): C / preact / dact_src / residual are all f32, or all fp16 (c_dtype GD_F16: C is the operand of the next
+    // product, saturated at +-65504; preact = GELU'(v) and dact_src are factors of an elementwise product, kept at fp16's 11 bits); bf16 operands never write fp16
     GD_REQUIRE((c_dtype != GD_F16 && (ab_dtype != GD_F16 || c_dtype == GD_F32)) || (ab_dtype == GD_F16 && c_dtype == GD_F16),
                "gd_gemm_nt: fp16 operands write f32 or fp16; fp16 results come from fp16 operands only (ab_dtype %d, c_dtype %d)", ab_dtype, c_dtype);
     GD_REQUIRE(c_dtype != GD_F32X3 || ab_dtype == GD_BF16, "gd_gemm_nt: split output takes bf16 (split) operands");
@@ -781,8 +781,7 @@ static int gemm_nt_impl(const void* A, const void* W, void* C, int M, int N, int
     if (copy16) preact = nullptr;      // (for the dispatch below: not a pre-activation store)
     p.dact_src = dact_src; p.ldd = ldd; p.dact = dact_src ? dact : 0; p.residual = residual; p.ldr = ldr;
     p.accumulate = accumulate;
-    const bool chalf = c_dtype == GD_F16;         // fp16 C beside f32 preact / dact_src / residual
-    const int cs = chalf ? 4 : gd_dtype_size(c_dtype), ccs = (csplit || chalf) ? 2 : cs;
+    const int cs = gd_dtype_size(c_dtype), ccs = csplit ? 2 : cs;
     auto al = [&](const void* q, long ld) { return q == nullptr || ((((uintptr_t)q) & 15) == 0 && (ld * cs) % 16 == 0); };
     p.vec_epilogue = ((uintptr_t)C & 15) == 0 && (ldc * ccs) % 16 == 0 && (sC * ccs) % 16 == 0 && al(preact, ldp) && al(dact_src, ldd) && al(residual, ldr) &&
                      (bias == nullptr || ((uintptr_t)bias & 15) == 0) && (lora_b == nullptr || (((uintptr_t)lora_b & 15) == 0 && N % 4 == 0));
@@ -833,13 +832,13 @@ static int gemm_nt_impl(const void* A, const void* W, void* C, int M, int N, int
             else if (dact_src && dact == 3 && act == 0 && !preact) pk = gemm_nt_persist_kernel<bf16, 3, 0, 0, true, 0, 1>;
         }
     } else if (ab_dtype == GD_F16 && !accumulate && !(dact_src && residual)) {
-        // fp16 operands (tf32h engine): f32 results, or an fp16 C beside f32 preact / dact_src
+        // fp16 operands (tf32h engine): f32 results with f32 epilogue tensors, or fp16 results with fp16 preact / dact_src (as the bf16 engine's)
         const bool ch = c_dtype == GD_F16;
         if (!dact_src && !residual) {
             if (act == 0 && !preact) pk = ch ? gemm_nt_persist_kernel<f16, 0, 0, 0, false> : gemm_nt_persist_kernel<f16, 0, 0, 0, true>;
-            else if ((act == 1 || act == 3) && !preact) pk = ch ? gemm_nt_persist_kernel<f16, 0, 1, 0, true, 0, 2> : gemm_nt_persist_kernel<f16, 0, 1, 0, true>;
-            else if (act == 3 && preact) pk = ch ? gemm_nt_persist_kernel<f16, 0, 1, 2, true, 0, 2> : gemm_nt_persist_kernel<f16, 0, 1, 2, true>;
-        } else if (dact_src && dact == 3 && act == 0 && !preact) pk = ch ? gemm_nt_persist_kernel<f16, 3, 0, 0, true, 0, 2> : gemm_nt_persist_kernel<f16, 3, 0, 0, true>;
+            else if ((act == 1 || act == 3) && !preact) pk = ch ? gemm_nt_persist_kernel<f16, 0, 1, 0, false> : gemm_nt_persist_kernel<f16, 0, 1, 0, true>;
+            else if (act == 3 && preact) pk = ch ? gemm_nt_persist_kernel<f16, 0, 1, 2, false> : gemm_nt_persist_kernel<f16, 0, 1, 2, true>;
+        } else if (dact_src && dact == 3 && act == 0 && !preact) pk = ch ? gemm_nt_persist_kernel<f16, 3, 0, 0, false> : gemm_nt_persist_kernel<f16, 3, 0, 0, true>;
         else if (residual && act == 0 && !preact && !ch) pk = copy16 ? gemm_nt_persist_kernel<f16, 2, 0, 3, true> : gemm_nt_persist_kernel<f16, 2, 0, 0, true>;
     }
     // (the bf16 f32-output instantiations serve the tf32x engine: 3K-wide split operands, fp32 C / preact / dact_src / residual)
@@ -847,9 +846,6 @@ static int gemm_nt_impl(const void* A, const void* W, void* C, int M, int N, int
     GD_REQUIRE(!csplit || (persist_ok && ldc >= 3L * N && batch == 1),
                "gd_gemm_nt: split output (c_dtype 2) is served by the persistent kernel only: bf16 operands, M >= 1024, N >= 256, K %% 64 == 0, "
                "ldc >= 3N, and the GELU(+derivative) or dact 3 epilogues (M=%d N=%d K=%d act=%d dact=%d)", M, N, K, act, dact);
-    GD_REQUIRE(!chalf || persist_ok || (!preact && !dact_src && !residual),
-               "gd_gemm_nt: an fp16 C beside f32 epilogue tensors is served by the persistent kernel only (M >= 1024, N >= 256, K %% 64 == 0; "
-               "GELU(+derivative) or dact 3 epilogues): M=%d N=%d K=%d act=%d dact=%d", M, N, K, act, dact);
     GD_REQUIRE(!copy16 || persist_ok, "gd_gemm_nt_copy16: served by the persistent kernel only (M >= 1024, N >= 256, K %% 64 == 0): M=%d N=%d K=%d", M, N, K);
 #ifdef GD_GEMM_EXPERIMENT32
     if (persist == 32 && big && ab_dtype == GD_BF16 && c_dtype == GD_BF16 && !bias && !lora_t && !preact && act == 0 && !dact_src && !residual &&

@@ -30,8 +30,7 @@
 // ANAT (anatomy builds, tools/bench_kernels.py gemm_anat; never the product path): 1 = no operand DMA in the main loop (the LDS-read +
 // MFMA + barrier loop alone), 2 = no MFMAs (DMA + LDS reads + barriers), 3 = neither LDS reads nor MFMAs (the DMA ring alone), 4 = no C stores (everything else of the epilogue stays).
 // Instantiated only in -DGD_GEMM_ANATOMY builds (gemm.hip); round-3 results: profiles/r03_gemm_anatomy.txt.
-// COUT (with CF32; 0 = C has the side tensors' type): 2 = C alone leaves as the 16-bit operand type T (fp16 operands: saturated; the left operand of the next
-// tf32h product) while preact / side stay f32;  1 = C leaves as the three-plane bf16 operand split of the f32 result — [hi | lo | hi] over 3N columns of row stride
+// COUT (with CF32; 0 = C has the side tensors' type): 1 = C leaves as the three-plane bf16 operand split of the f32 result — [hi | lo | hi] over 3N columns of row stride
 // ldc (gd_split3 'a' layout), the A operand of the next tf32x GEMM — instead of f32 followed by a gd_split3 pass; side / preact stay f32.
 template <typename T, int SIDE, int ACT, int PREACT, bool CF32, int ANAT = 0, int COUT = 0>
 __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
@@ -54,8 +53,9 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
     const char* Wb = (const char*)p.W + batch * p.sW * (long)sizeof(T);
     const long lda_b = p.lda * (long)sizeof(T), ldw_b = p.ldw * (long)sizeof(T);
     const int nk = p.K * (int)sizeof(T) / 128;
-    static_assert(COUT == 0 || CF32, "split / 16-bit-beside-f32 output comes from f32 values");
+    static_assert(COUT == 0 || (COUT == 1 && CF32), "split output comes from f32 values");
     constexpr bool CSPLIT = COUT == 1;
+    constexpr bool XGELU = std::is_same<T, f16>::value;      // fp16 results (tf32h engine) carry 11 significant bits: the erf form, not the bf16-grade fit
     constexpr int t16 = std::is_same<T, f16>::value ? GD_F16 : GD_BF16;      // dtype code of a 16-bit C
     constexpr int cdt = CF32 ? GD_F32 : t16, csz = CF32 ? 4 : 2;
     constexpr int ccsz = COUT ? 2 : csz;   // element size of C itself (preact / side tensors keep csz / ssz)
@@ -267,8 +267,13 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
                 const f32x4 q = __builtin_bit_cast(f32x4, sd[idx % SDEP]);
                 x[0] = q[0]; x[1] = q[1]; x[2] = q[2]; x[3] = q[3];
             } else {
-                const bf16x4 q = __builtin_bit_cast(bf16x4, sd[idx % SDEP]);
-                x[0] = (float)q[0]; x[1] = (float)q[1]; x[2] = (float)q[2]; x[3] = (float)q[3];
+                if constexpr (std::is_same<T, f16>::value) {
+                    const f16x4 q = __builtin_bit_cast(f16x4, sd[idx % SDEP]);
+                    x[0] = (float)q[0]; x[1] = (float)q[1]; x[2] = (float)q[2]; x[3] = (float)q[3];
+                } else {
+                    const bf16x4 q = __builtin_bit_cast(bf16x4, sd[idx % SDEP]);
+                    x[0] = (float)q[0]; x[1] = (float)q[1]; x[2] = (float)q[2]; x[3] = (float)q[3];
+                }
             }
         };
         if (pre) {
@@ -305,7 +310,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float Phi, dPhi;
-                    if (CF32) { float ex; gelu_parts(v[j], Phi, ex); dPhi = ex * 0.39894228040143268f; }
+                    if (CF32 || XGELU) { float ex; gelu_parts(v[j], Phi, ex); dPhi = ex * 0.39894228040143268f; }
                     else gelu_sig_parts(v[j], Phi, dPhi);       // bf16 outputs: the sigmoid-form fit (gd_common.h)
                     dv[j] = fmaf(v[j], dPhi, Phi);
                     v[j] *= Phi;
@@ -313,7 +318,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
                 bst4_aux<GD_PERSIST_STORE_AUX>(prs, poff, cdt, dv);
             } else if (ACT == 1) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = CF32 ? gelu_f(v[j]) : gelu_sig(v[j]);
+                for (int j = 0; j < 4; ++j) v[j] = (CF32 || XGELU) ? gelu_f(v[j]) : gelu_sig(v[j]);
             } else if (ACT == 2) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
@@ -341,7 +346,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
                 bst4_aux<GD_PERSIST_STORE_AUX>(crs, coff + plane, GD_BF16, lo);
                 bst4_aux<GD_PERSIST_STORE_AUX>(crs, coff + 2 * plane, GD_BF16, v);
             } else
-            if (ANAT != 4) bst4_aux<GD_PERSIST_STORE_AUX>(crs, coff, COUT == 2 ? t16 : cdt, v);
+            if (ANAT != 4) bst4_aux<GD_PERSIST_STORE_AUX>(crs, coff, cdt, v);
             else asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
             if (pre && idx + SDEP < NITEM) side_load(idx + SDEP);
         }

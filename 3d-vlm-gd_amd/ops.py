@@ -69,7 +69,7 @@ def gemm_nt(a, w, out=None, *, out_dtype=None, alpha=1.0, bias=None, lora_t=None
     out_split: the f32 result leaves as its bf16 operand split [M, 3N] = [hi | lo | hi] (what split3(out, "a") would give: the left
     operand of the next tf32x GEMM) without the f32 tensor ever reaching memory; preact / dact_src stay f32.  split_out_ok() says
     whether a shape is served.
-    fp16 operands (tf32h engine, `cast16`): f32 results, or out_dtype=torch.float16 — an fp16 C (saturated) beside f32 preact / dact_src;
+    fp16 operands (tf32h engine, `cast16`): f32 results with f32 epilogue tensors, or out_dtype=torch.float16 — fp16 C (saturated), preact, dact_src;
     alpha_dev: a device scalar multiplied into alpha (the 1/s of an operand scaled by `amax_scale`)."""
     _req(a.is_cuda and w.is_cuda and a.dtype == w.dtype, "gemm_nt: a and w must be CUDA tensors of one dtype")
     _req(a.stride(-1) == 1 and w.stride(-1) == 1, "gemm_nt: a and w must be contiguous along K")
@@ -92,7 +92,7 @@ def gemm_nt(a, w, out=None, *, out_dtype=None, alpha=1.0, bias=None, lora_t=None
         out = torch.empty((B, M, N) if batched else (M, N), dtype=odt, device=a.device)
     _req(out.stride(-1) == 1, "gemm_nt: out must be contiguous along N")
     cdt = F32X3 if out_split else dtype_code(out)
-    sdt = torch.float32 if (out_split or out.dtype == torch.float16) else out.dtype
+    sdt = torch.float32 if out_split else out.dtype
     for t, name in ((preact, "preact"), (dact_src, "dact_src"), (residual, "residual")):
         if t is not None:
             _req(t.dtype == sdt and t.stride(-1) == 1 and tuple(t.shape) == (M, N), f"gemm_nt: bad {name}")

@@ -195,10 +195,10 @@ class _BlockFn(torch.autograd.Function):
             o, lse = ops.attention_fwd(qkv, B, Nt, H, x3=bool(fmt))
             x1 = _mm(o, plan, "wproj", bias=plan["bproj"], residual=x)
         y2, mean2, rstd2 = ops.layernorm_fwd(x1, plan["ln2_w"], plan["ln2_b"], plan["eps2"], save_stats=need, **h16)
-        pre = torch.empty(M, plan["w1"].shape[0], dtype=T, device=x.device) if need else None
         # tf32x: fc1 writes GELU(.) directly as the split left operand of fc2 (no f32 [M, 4D] round trip + split pass)
-        # (tf32h: as fp16)
+        # (tf32h: as fp16, and the stored GELU'(.) — a factor of an elementwise product in the backward — as fp16 too)
         hs = bool(fmt) and ops.split_out_ok(M, plan["w1"].shape[0], plan["w1"].shape[1])
+        pre = torch.empty(M, plan["w1"].shape[0], dtype=torch.float16 if (fmt == "h" and hs) else T, device=x.device) if need else None
         hkw = {} if not hs else {"out_split": True} if fmt == "x3" else {"out_dtype": torch.float16}
         h = _mm(None if fmt == "h" else y2, plan, "w1", xs=y2 if fmt == "h" else None, bias=plan["b1"], act=3, preact=pre, **hkw)   # pre <- GELU'(fc1 output): all the backward needs
         x2a = None
@@ -294,7 +294,7 @@ class _BlockFn(torch.autograd.Function):
             else:
                 g_up = ops.gemm_tn(dout, hd, out=z_up)                                            # [D, 64]
                 g_down = ops.gemm_tn(dhp, x2, out=z_down)                                         # [64, D]
-        hs = bool(fmt) and ops.split_out_ok(dx2.shape[0], plan["w2_t"].shape[0], plan["w2_t"].shape[1])
+        hs = bool(fmt) and ops.split_out_ok(dx2.shape[0], plan["w2_t"].shape[0], plan["w2_t"].shape[1]) and (fmt != "h" or pre.dtype == torch.float16)
         hkw = {} if not hs else {"out_split": True} if fmt == "x3" else {"out_dtype": torch.float16}      # (tf32h: fp16, still times s)
         dpre = _mm(dx2, plan, "w2_t", xs=dx2a, sc=sc, dact_src=pre, dact=3, **hkw)                # [M, 4D] (x stored GELU')
         dy2 = _mm(None if hs else dpre, plan, "w1_t", xs=dpre if hs else None, sc=sc)

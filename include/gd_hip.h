@@ -273,7 +273,7 @@ int gd_split3(const float* in, void* out, long rows, int K, long ld_in, int whic
  * gd_cast_f16: out [rows, K] fp16 = sat(in * scale * (scale_dev ? *scale_dev : 1)), in f32 with row stride ld_in.
  * gd_amax_scale: scale3 (device, 3 floats) <- {s, 1/s, scratch} with s the power of two that puts max|in| into (target/2, target].
  * gd_gemm_nt_scaled: gd_gemm_nt with alpha multiplied by the device scalar *alpha_dev (the 1/s of a scaled operand) — no host round trip.
- * gd_gemm_nt itself takes ab_dtype GD_F16 (f32 results, or c_dtype GD_F16: an fp16 C beside f32 preact / dact_src). */
+ * gd_gemm_nt itself takes ab_dtype GD_F16 (f32 results with f32 epilogue tensors, or c_dtype GD_F16: fp16 C, preact and dact_src). */
 int gd_cast_f16(const float* in, void* out, long rows, int K, long ld_in, float scale, const float* scale_dev, void* stream);
 /* Cost-volume KL of the tf32h engine: gd_cost_volume_kl_fwd_prenorm takes dtype GD_F16 (fp16 copies of the fp32 features, the fp32 rows' norms);
  * the backward recomputes S from the same fp16 copies, writes G = dloss/dS as fp16 under a power-of-two scale taken from `gloss` on the device,

@@ -360,8 +360,8 @@ def test_fp16_gradient_operands_carry_a_device_side_scale():
     tf32 = lambda x: ((x.view(torch.int32) + 0x1000) & ~0x1FFF).view(torch.float32)
     assert fro(got) < 1.05 * fro(tf32(d.clone()).double() @ tf32(w.clone()).double().t())
     assert fro(ops.gemm_nt(ops.cast16(d), wh, out_dtype=torch.float32)) > 0.05          # unscaled: the operand is mostly subnormal / zero
-    # fp16 C beside f32 epilogue tensors; saturation
-    src = torch.rand(M, N, generator=g, device="cuda")
+    # fp16 C with fp16 epilogue tensors; saturation
+    src = torch.rand(M, N, generator=g, device="cuda").half()
     c16 = ops.gemm_nt(dh, wh, out_dtype=torch.float16, dact_src=src, dact=3)
     want = (dh.double() @ wh.double().t()) * src.double()
     assert c16.dtype == torch.float16 and float((c16.double() - want).norm() / want.norm()) < 5e-4
