@@ -55,7 +55,9 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
     const int nk = p.K * (int)sizeof(T) / 128;
     static_assert(COUT == 0 || (COUT == 1 && CF32), "split output comes from f32 values");
     constexpr bool CSPLIT = COUT == 1;
-    constexpr bool XGELU = std::is_same<T, f16>::value;      // fp16 results (tf32h engine) carry 11 significant bits: the erf form, not the bf16-grade fit
+    // fp16 results (tf32h engine) carry 11 significant bits (4.9e-4 relative): the sigmoid-form fit's 2.5e-5 absolute error on y Phi(y) and 1.1e-4 on the
+    // derivative sit below that, and the erf form costs 60-70 us per fc1 launch — set to true for the erf form
+    constexpr bool XGELU = false;
     constexpr int t16 = std::is_same<T, f16>::value ? GD_F16 : GD_BF16;      // dtype code of a 16-bit C
     constexpr int cdt = CF32 ? GD_F32 : t16, csz = CF32 ? 4 : 2;
     constexpr int ccsz = COUT ? 2 : csz;   // element size of C itself (preact / side tensors keep csz / ssz)
