@@ -927,7 +927,7 @@ extern "C" int gd_cast(const void* in, void* out, long n, float scale, int in_dt
 // cost-volume loss normalises exactly these rows (F.normalize, src/finetune_timm_vggt.py:514-515), and taking the norm here saves
 // its own pass over the features there (gd_cost_volume_kl_fwd_prenorm).  Fixed summation order: bit-reproducible.
 template <typename T>
-__global__ __launch_bounds__(256) void tap_mean_norm_fwd_kernel(TapMeanParams p, T* out, float* inv_norm, int B, int hw, int D) {
+__global__ __launch_bounds__(256) void tap_mean_norm_fwd_kernel(TapMeanParams p, T* out, float* inv_norm, int B, int hw, int D, f16* out16 = nullptr) {
     constexpr int V = 16 / sizeof(T);
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -955,6 +955,12 @@ __global__ __launch_bounds__(256) void tap_mean_norm_fwd_kernel(TapMeanParams p,
             ss += x * x;
         }
         *(uint4*)(out + row * D + (long)v * V) = o;
+        if (sizeof(T) == 4 && out16) {      // tf32h engine: the fp16 copy the cost-volume products take, from the same pass
+            f16x4 h;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) h[k] = from_f32<f16>(to_f32<T>(oe[k]));
+            *(f16x4*)(out16 + row * D + (long)v * 4) = h;
+        }
     }
     ss = wave_sum(ss);
     if (lane == 0) inv_norm[row] = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
@@ -1065,6 +1071,19 @@ extern "C" int gd_tap_mean_norm_fwd(const void* const* grids, int ngrid, long bs
     const unsigned blocks = (unsigned)(((long)B * hw + 3) / 4);
     if (dtype == GD_BF16) hipLaunchKernelGGL(tap_mean_norm_fwd_kernel<bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, (bf16*)out, inv_norm, B, hw, D);
     else hipLaunchKernelGGL(tap_mean_norm_fwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, (float*)out, inv_norm, B, hw, D);
+    GD_LAUNCH_OK();
+    return 0;
+}
+
+// fp32 rows, and their fp16 copy (out16 [B, hw, D]) for the tf32h engine's cost-volume products
+extern "C" int gd_tap_mean_norm_fwd_h(const void* const* grids, int ngrid, long bstride, int prefix, float* out, void* out16, float* inv_norm,
+                                      int B, int hw, int D, void* stream) {
+    GD_REQUIRE(ngrid >= 1 && ngrid <= 4 && B > 0 && hw > 0 && D > 0 && D % 8 == 0 && inv_norm != nullptr && out16 != nullptr, "gd_tap_mean_norm_fwd_h: bad arguments");
+    TapMeanParams p = {};
+    for (int t = 0; t < ngrid; ++t) p.grid[t] = grids[t];
+    p.ngrid = ngrid; p.bstride = bstride; p.prefix = prefix;
+    const unsigned blocks = (unsigned)(((long)B * hw + 3) / 4);
+    hipLaunchKernelGGL(tap_mean_norm_fwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, out, inv_norm, B, hw, D, (f16*)out16);
     GD_LAUNCH_OK();
     return 0;
 }

@@ -351,6 +351,8 @@ class FinetuneGD(nn.Module):
         ch, cw = h // self.resize_patch_size, w // self.resize_patch_size
         taps, _ = self._forward(rgbs, ch, cw)
         sel = [taps[3]] if self.variant == "vggt" else list(taps)
+        if with_norm and getattr(self.model, "opfmt", "") == "h" and sel[0].dtype == torch.float32:
+            with_norm = 2       # tf32h: the fp16 copy of the rows comes out of the same pass (-> (features, inverse norms, fp16 features))
         return ops.tap_mean(sel, prefix=self.model.num_prefix_tokens, with_norm=with_norm)
 
     # ------------------------------------------------------------------ losses (per-pair vectors [P])
@@ -367,7 +369,8 @@ class FinetuneGD(nn.Module):
         padded to 16-byte rows with `cost_tstats` = the cached teacher-row statistics (teacher_cache.TeacherTargetCache)."""
         h, w = rgbs.shape[-2:]
         P = rgbs.shape[0] // 2
-        f, inv = self.get_feature_cost(rgbs, with_norm=True)
+        fc = self.get_feature_cost(rgbs, with_norm=True)
+        f, inv, f16 = fc if len(fc) == 3 else (fc[0], fc[1], None)
         ph, pw = h // self.resize_patch_size, w // self.resize_patch_size
         if self.variant == "mast3r" or mask_1 is None:
             m1 = ops.patch_mask(kp_1, h, w, self.patch_size)
@@ -377,7 +380,7 @@ class FinetuneGD(nn.Module):
             m2 = F.interpolate(mask_2[:, None].float(), size=(ph, pw), mode="nearest").reshape(P, -1) > 0
         f1, f2 = ops.split_pairs(f, P)
         return ops.cost_volume_kl(f1, f2, cost_1, cost_2, m1, m2, self.variant, tstats=cost_tstats, inv_norms=(inv[:P], inv[P:]),
-                                  x3=getattr(self.model, "opfmt", ""))
+                                  x3=getattr(self.model, "opfmt", ""), h16=None if f16 is None else (f16[:P], f16[P:]))
 
     def calculate_matching_loss(self, rgbs, kp_1, kp_2, pts3d_1, pts3d_2, counts=None):
         """src/finetune_timm_vggt.py:536-574 / src/finetune_timm_mast3r.py:543-589.  pts3d_k [P,N,3] are the

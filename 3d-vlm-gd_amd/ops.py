@@ -231,7 +231,7 @@ def cost_volume_teacher_stats(t1, t2):
 
 class _CostVolumeKL(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, f1, f2, t1, t2, m1, m2, variant, tstats, inv1=None, inv2=None, x3=False):
+    def forward(ctx, f1, f2, t1, t2, m1, m2, variant, tstats, inv1=None, inv2=None, x3=False, h16=None):
         P, hw, C = f1.shape
         f1, f2 = f1.contiguous(), f2.contiguous()
         t1, t2 = t1.contiguous().float(), t2.contiguous().float()
@@ -251,7 +251,11 @@ class _CostVolumeKL(torch.autograd.Function):
             ctx.h16 = None
             if x3 == "h" and f1.dtype == torch.float32 and C % 8 == 0:
                 # tf32h: S from the fp16 copies of the features (TF32's significand); the backward recomputes S from the SAME copies (kept)
-                a16, b16 = cast16(f1.view(P * hw, C)), cast16(f2.view(P * hw, C))
+                if h16 is not None:
+                    a16, b16 = h16[0].contiguous(), h16[1].contiguous()
+                    _req(a16.dtype == torch.float16 and a16.shape == f1.shape and b16.shape == f2.shape, "cost_volume_kl: h16 must be the fp16 copies of f1, f2")
+                else:
+                    a16, b16 = cast16(f1.view(P * hw, C)), cast16(f2.view(P * hw, C))
                 ws = torch.empty(lib().gd_cost_volume_kl_workspace_bytes(P, hw, C, 3, 0), dtype=torch.uint8, device=f1.device)
                 rc = lib().gd_cost_volume_kl_fwd_prenorm(ptr(a16), ptr(b16), ptr(inv1), ptr(inv2), ptr(t1), ptr(t2), ldt, ptr(tstats), ptr(m1),
                                                          ptr(m2), P, hw, C, VARIANTS[variant], 3, ptr(loss), ptr(stats), ptr(ws), stream())
@@ -286,7 +290,7 @@ class _CostVolumeKL(torch.autograd.Function):
             rc = lib().gd_cost_volume_kl_bwd_h(ptr(f1), ptr(f2), ptr(a16), ptr(b16), ptr(t1), ptr(t2), t1.shape[-1], ptr(m1), ptr(m2), P, hw, C,
                                                ptr(g), ptr(stats), ptr(dfull[:P]), ptr(dfull[P:]), ptr(ws), stream())
             check(rc, "gd_cost_volume_kl_bwd_h")
-            return dfull[:P], dfull[P:], None, None, None, None, None, None, None, None, None
+            return dfull[:P], dfull[P:], None, None, None, None, None, None, None, None, None, None
         dt = dtype_code(f1)
         # the two halves of ONE buffer: split_pairs' backward hands it on without a concatenation pass (134 MB at the step's size)
         dfull = torch.empty((2 * P, hw, C), dtype=f1.dtype, device=f1.device)
@@ -296,10 +300,10 @@ class _CostVolumeKL(torch.autograd.Function):
         rc = lib().gd_cost_volume_kl_bwd(ptr(f1), ptr(f2), ptr(t1), ptr(t2), t1.shape[-1], ptr(m1), ptr(m2), P, hw, C, dt, ptr(g),
                                          ptr(stats), ptr(df1), ptr(df2), ptr(ws), stream())
         check(rc, "gd_cost_volume_kl_bwd")
-        return df1, df2, None, None, None, None, None, None, None, None, None
+        return df1, df2, None, None, None, None, None, None, None, None, None, None
 
 
-def cost_volume_kl(f1, f2, t1, t2, m1, m2, variant="vggt", tstats=None, inv_norms=None, x3=False):
+def cost_volume_kl(f1, f2, t1, t2, m1, m2, variant="vggt", tstats=None, inv_norms=None, x3=False, h16=None):
     """Fused dense cost-volume KL for P pairs.  f1,f2 [P,hw,C] raw student features (f32|bf16); t1,t2 [P,hw,ldt] teacher
     maps (f32; ldt = hw, or hw padded to a multiple of 4 by `pad_teacher_maps`: the fast path); m1,m2 [P,hw] bool row
     masks; tstats: `cost_volume_teacher_stats(t1, t2)` computed once per cached pair (None: recomputed here, one more pass
@@ -308,7 +312,7 @@ def cost_volume_kl(f1, f2, t1, t2, m1, m2, variant="vggt", tstats=None, inv_norm
     x3 (fp32 features with inv_norms): the forward's similarity matrix as a split-precision bf16 product (tf32x engine)
     -> loss [P] (f32)."""
     if inv_norms is not None:
-        return _CostVolumeKL.apply(f1, f2, t1, t2, m1, m2, variant, tstats, inv_norms[0].detach(), inv_norms[1].detach(), x3)
+        return _CostVolumeKL.apply(f1, f2, t1, t2, m1, m2, variant, tstats, inv_norms[0].detach(), inv_norms[1].detach(), x3, h16)
     return _CostVolumeKL.apply(f1, f2, t1, t2, m1, m2, variant, tstats)
 
 
@@ -623,6 +627,14 @@ class _TapMean(torch.autograd.Function):
         gs = [g.contiguous() for g in grids]
         out = torch.empty(B, Nt - prefix, D, dtype=gs[0].dtype, device=gs[0].device)
         ctx.meta = (prefix, len(gs), B, Nt, D)
+        if with_norm == 2:      # + the fp16 copy of the rows (tf32h engine: the cost-volume products' operands)
+            _req(out.dtype == torch.float32 and D % 8 == 0, "tap_mean(with_norm=2): fp32 taps, D % 8 == 0")
+            inv = torch.empty(B, Nt - prefix, dtype=torch.float32, device=gs[0].device)
+            o16 = torch.empty(B, Nt - prefix, D, dtype=torch.float16, device=gs[0].device)
+            check(lib().gd_tap_mean_norm_fwd_h(_ptr_array(gs), len(gs), Nt * D, prefix, ptr(out), ptr(o16), ptr(inv), B, Nt - prefix, D, stream()),
+                  "gd_tap_mean_norm_fwd_h")
+            ctx.mark_non_differentiable(inv, o16)
+            return out, inv, o16
         if with_norm:
             inv = torch.empty(B, Nt - prefix, dtype=torch.float32, device=gs[0].device)
             check(lib().gd_tap_mean_norm_fwd(_ptr_array(gs), len(gs), Nt * D, prefix, ptr(out), ptr(inv), B, Nt - prefix, D,
@@ -646,8 +658,9 @@ class _TapMean(torch.autograd.Function):
 
 def tap_mean(grids, prefix=1, with_norm=False):
     """mean of 1..4 tap outputs [B, prefix+hw, D], prefix tokens dropped -> contiguous [B, hw, D]; with_norm: -> (mean, inv_norm
-    [B, hw] fp32 = 1 / max(||row||, 1e-12) of the rows as stored, not differentiable: an input of cost_volume_kl(inv_norms=...))."""
-    return _TapMean.apply(prefix, bool(with_norm), *grids)
+    [B, hw] fp32 = 1 / max(||row||, 1e-12) of the rows as stored, not differentiable: an input of cost_volume_kl(inv_norms=...));
+    with_norm=2 (fp32 taps): -> (mean, inv_norm, fp16 copy of mean) — cost_volume_kl(x3="h", h16=...)."""
+    return _TapMean.apply(prefix, 2 if with_norm == 2 else bool(with_norm), *grids)
 
 
 def kp_depth(depth, kp):

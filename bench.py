@@ -13,15 +13,20 @@ shared 37x37-token forward per image, taps 4-7 + final), the three distillation 
 teacher targets, backward through LoRA/adapters/refine_conv/depth head, flat-gradient all-reduce (N>1), global-norm
 clip + AdamW.  Inputs are resident in HBM before the timed region.  Prints ONE JSON line (rank 0).
 
+The headline engine is `tf32h`: fp32 tensors, every matrix product (GEMMs, attention, cost volume) on fp16 operands — TF32's 11-bit significand, fp32
+accumulation — i.e. the precision class the reference's benched MASt3R path computes in (torch.backends.cuda.matmul.allow_tf32, dust3r/croco/models/
+croco.py:12; gfx950 has no TF32 MFMA).  The bf16 engine (16-bit storage, faster, narrower than the reference) is reported beside it as config.bf16_run.
+
 Extra objects on the line:
   roofline              the dominant kernel (persistent gemm_nt, MFMA-bound) from HIP events around every launch in the timed region
   roofline_cost_volume  the HBM-bound fused cost-volume KL, timed on its own after the run (also as roofline.cost_volume_kl_fwd);
                         frac = bytes that must move / time / peak, for the benched row masks and for every row kept (`unmasked`)
   parity                engine loss vs the CPU oracle (oracle/gd_oracle.py, fp32) on the same weights and the same pairs
+  bf16                  the same workload on the bf16 engine (16-bit storage: the throughput mode, narrower than the reference's arithmetic): same
+                        --steps / --warmup, own roofline and parity (also as config.bf16_run and roofline.bf16_engine)
   f32                   the same workload on the f32 engine (the reference's arithmetic precision): same --steps / --warmup, own
                         roofline and parity (also as config.reference_precision_run and roofline.f32_engine)
-  tf32h                 the same workload on the fp16-operand TF32-class engine (fp32 storage; products on fp16 operands = TF32's significand):
-                        same --steps / --warmup, own roofline and parity (also as config.tf32_class_run and roofline.tf32h_engine)
+  (tf32h                when --dtype is not tf32h: the fp16-operand TF32-class engine as a companion run, config.tf32_class_run)
   tf32x                 the same workload on the split-precision engine (fp32 storage, 3-term bf16 split products on the matrix cores): same
                         --steps / --warmup, own roofline and parity (also as config.tf32x_run and roofline.tf32x_engine)
   other_configs         short runs of BASELINE configs 3 / 5-like and of the reference's own token geometry
@@ -52,9 +57,11 @@ def parse():
     ap.add_argument("--config", default=None, help="a reference yaml (config/finetune_timm_*.yaml): variant and loss "
                     "weights are taken from it (gd_amd.config); explicit flags below win")
     ap.add_argument("--pairs-per-gpu", type=int, default=32)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "tf32x", "tf32h"],
-                    help="engine dtype: bf16 (headline), f32 (exact-f32 MFMA: the reference's fp32 arithmetic), tf32x (fp32 storage, the big "
-                         "GEMMs as 3-term bf16 splits: TF32-class, what the reference's MASt3R path computes its matmuls in)")
+    ap.add_argument("--dtype", default="tf32h", choices=["tf32h", "bf16", "f32", "tf32x"],
+                    help="engine dtype.  tf32h (the headline): fp32 storage, every matrix product on fp16 operands = TF32's 11-bit significand — the "
+                         "precision class the reference's benched (MASt3R) path computes its matmuls in (allow_tf32); bf16: the 16-bit-storage "
+                         "throughput mode (narrower than the reference: reported as config.bf16_run); f32: exact-f32 MFMA; tf32x: 3-term bf16 "
+                         "splits (better than TF32)")
     ap.add_argument("--variant", default=None, choices=["mast3r", "vggt"])
     ap.add_argument("--backbone", default=None)
     ap.add_argument("--img", type=int, default=518)
@@ -178,7 +185,7 @@ def gemm_roofline(prof, dtype, dt, steps):
     out = {"kernel": kname, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
            "frac": round(ach / PEAK_TFLOPS[dtype], 4), "traffic": None, "launches": n,
            "avg_launch_us": round(ms / max(n, 1) * 1e3, 2), "share_of_step": round(ms / (dt * 1e3), 3)}
-    if dtype == "bf16":
+    if dtype in ("bf16", "tf32h"):     # (fp16 and bf16 MFMAs run at one rate; the ceilings were measured on the bf16 instantiation)
         # context, not the yardstick (NOT measured in this run; profiles/r03_gemm_anatomy.txt, profiles/r02_micro_mfma_gap.txt):
         #  * back-to-back 16x16x32 bf16 MFMAs from registers, no memory traffic: 2328 TFLOP/s — the part's power-limited MFMA clock;
         #  * this kernel's own LDS-read + MFMA + barrier loop with the operand DMA switched off: 1668 TFLOP/s-equivalent at 4096^3
@@ -239,7 +246,13 @@ def main():
                           "world_size_seen": world, "backend": args.backend or "nccl (RCCL)", "exchange": args.exchange,
                           "teacher": "excluded from the timed region: targets are synthetic and resident, as a warm TeacherTargetCache "
                                      "holds them (the frozen teacher runs once per pair, outside the student step)",
-                          "engine_dtype": args.dtype},
+                          "engine_dtype": args.dtype,
+                          "dtype_note": {"tf32h": "fp32 storage; every matrix product on fp16 operands (TF32's 11-bit significand), fp32 accumulation: the "
+                                                  "reference's matmul precision class on this config (allow_tf32); product error <= 1.05 x emulated TF32 "
+                                                  "(tests/test_gpu_gemm.py), full step: loss 2e-7, gradient 0.5 %, ten-step dW 1 % of the fp64 / fp32 oracle",
+                                         "bf16": "16-bit storage and operands: NARROWER than the reference's fp32 / TF32 arithmetic (throughput mode)",
+                                         "f32": "exact-f32 MFMA: the reference's fp32 arithmetic", "tf32x": "fp32 storage, 3-term bf16 split products "
+                                         "(error 4e-6: better than TF32)"}[args.dtype]},
                "loss": round(float(loss.detach()), 6),
                "vit_algorithmic_tflops": round(pairs_per_s / world * flop_pair / 1e12, 2),
                "vit_frac_of_mfma_peak": round(pairs_per_s / world * flop_pair / 1e12 / PEAK_TFLOPS[args.dtype], 4)}
@@ -247,13 +260,13 @@ def main():
             out["roofline"] = gemm_roofline(prof, args.dtype, dt, args.steps)
             # memory-side bytes per launch: PMC counters cannot be read from inside the timed run, so this REPLAYS the committed
             # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE measurement of this same command (profiles/README.md), default workload only
-            pmc = os.path.join(ROOT, "profiles", "r03_pmc_gemm_traffic.json")
-            if (os.path.exists(pmc) and args.dtype == "bf16" and backbone == "vit_base" and P == 32
+            pmc = os.path.join(ROOT, "profiles", f"r03_pmc_gemm_traffic_{args.dtype}.json")
+            if (os.path.exists(pmc) and backbone == "vit_base" and P == 32
                     and args.geometry == "shared" and variant == "mast3r"):
                 with open(pmc) as fh:
                     t = json.load(fh)
                 out["roofline"]["traffic"] = round(t["hbm_side_mb_per_launch"] * 1e6)
-                out["roofline"]["traffic_replayed_from"] = ("profiles/r03_pmc_gemm_traffic.json (2 x FETCH_SIZE + WRITE_SIZE per "
+                out["roofline"]["traffic_replayed_from"] = (f"profiles/r03_pmc_gemm_traffic_{args.dtype}.json (2 x FETCH_SIZE + WRITE_SIZE per "
                                                             "persistent-kernel launch, separate --pmc passes; NOT measured in this run)")
             if args.gemm_shapes:
                 for k, (cnt, sms, tf) in sorted(prof.by_shape().items(), key=lambda kv: -kv[1][1]):
@@ -286,6 +299,15 @@ def main():
                     "reference trains in fp32; gfx950 has no TF32"}
                 if "roofline" in out and "roofline" in f:
                     out["roofline"]["f32_engine"] = f["roofline"]
+            if "bf16" in extras:
+                f = extras["bf16"]
+                out["config"]["bf16_run"] = {
+                    "dtype": "bf16", "value": f["value"], "unit": "image-pairs/s", "ms_per_step": f["ms_per_step"], "steps": f["steps"],
+                    "warmup": f["warmup"], "vit_frac_of_mfma_peak": f["vit_frac_of_mfma_peak"], "parity_rel_err": f.get("parity", {}).get("rel_err"),
+                    "note": "same workload on the bf16 engine (16-bit storage and operands, fp32 accumulation / losses / optimiser): the throughput mode — "
+                            "NARROWER than the reference's arithmetic (fp32, TF32 matmuls), loss parity 1e-3, gradients ~3 % (DESIGN.md section 4)"}
+                if "roofline" in out and "roofline" in f:
+                    out["roofline"]["bf16_engine"] = f["roofline"]
             if "tf32h" in extras:
                 f = extras["tf32h"]
                 out["config"]["tf32_class_run"] = {
@@ -322,11 +344,13 @@ def cost_volume_roofline(job, args, dev, variant):
     byte count (2 hw D s + 2 hw^2 4 + 2 hw per pair)."""
     from gd_amd import ops
     P, hw, D = job.P, job.hw, job.eng.embedding_dim
-    es = 2 if args.dtype == "bf16" else 4
+    fmt = getattr(job.eng.model, "opfmt", "")          # "h": the kernel contracts the fp16 copies the feature producer writes beside the fp32 rows
+    es = 2 if (args.dtype == "bf16" or fmt == "h") else 4      # bytes per feature element the contraction READS
     b = job.batches[0]
     Tt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     f1 = torch.randn(P, hw, D, device=dev).to(Tt).requires_grad_(True)
     f2 = torch.randn(P, hw, D, device=dev).to(Tt).requires_grad_(True)
+    h16 = (f1.detach().half(), f2.detach().half()) if fmt == "h" else None
     # the row masks of the benched trainer, from the benched batch: keypoint-patch masks (MASt3R: src/finetune_timm_mast3r.py:515-519)
     # or the co-view masks down-sampled to the patch grid (VGGT: src/finetune_timm_vggt.py:504-509) — as calculate_cost_loss builds them
     h = w = args.img
@@ -344,7 +368,7 @@ def cost_volume_roofline(job, args, dev, variant):
     inv = (1.0 / f1.detach().float().norm(dim=-1).clamp_min(1e-12), 1.0 / f2.detach().float().norm(dim=-1).clamp_min(1e-12))
 
     def timed(ma, mb, backward=False, own_norm=False):
-        kw = dict(tstats=b["cost_tstats"]) if own_norm else dict(tstats=b["cost_tstats"], inv_norms=inv)
+        kw = dict(tstats=b["cost_tstats"]) if own_norm else dict(tstats=b["cost_tstats"], inv_norms=inv, x3=fmt, h16=h16)
 
         def fwd():
             with torch.no_grad():
@@ -357,7 +381,7 @@ def cost_volume_roofline(job, args, dev, variant):
 
     def replay(name):    # HBM traffic per launch: PMC counters cannot be read inside the run; committed passes of this configuration
         path = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(path) and (P, hw, D, args.dtype) == (32, 1369, 768, "bf16"):
+        if os.path.exists(path) and (P, hw, D) == (32, 1369, 768) and es == 2:      # (one kernel template on the two 16-bit types: same traffic)
             with open(path) as fh:
                 return json.load(fh)["fwd_hbm_bytes_per_launch"], f"profiles/{name} (FETCH_SIZE / WRITE_SIZE, separate --pmc passes, width-corrected; NOT measured in this run)"
         return None, None
@@ -524,6 +548,9 @@ def companion_runs(args, variant, backbone, weights, dev, rank, world):
         torch.cuda.empty_cache()
         return rec
 
+    if args.dtype != "bf16":
+        out["bf16"] = run(backbone, variant, "bf16", args.geometry, P, steps=args.steps, warmup=args.warmup,
+                          prof=not args.no_kernel_events, wts=weights, parity=world == 1)
     if args.dtype != "f32":
         out["f32"] = run(backbone, variant, "f32", args.geometry, P, steps=args.steps, warmup=args.warmup,
                          prof=not args.no_kernel_events, wts=weights, parity=world == 1)

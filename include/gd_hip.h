@@ -293,6 +293,8 @@ int gd_gemm_tn_scaled(const void* Y, const void* X, float* G, int M, int N, int 
                       int batch, long sY, long sX, long sG, int y_dtype, int x_dtype, float alpha, const float* alpha_dev, void* stream);
 /* gd_layernorm_fwd with y_dtype GD_F16 (f32 rows in): LN(x) written as the fp16 operand directly.  gd_layernorm_bwd_cast: the f32 backward
  * that also writes dx16 [M, D] = fp16(sat(dx * *scale_dev)) — backward + gd_cast_f16 in one pass. */
+int gd_tap_mean_norm_fwd_h(const void* const* grids, int ngrid, long bstride, int prefix, float* out, void* out16, float* inv_norm,
+                           int B, int hw, int D, void* stream);      /* gd_tap_mean_norm_fwd on fp32 taps + the fp16 copy of the rows it writes */
 int gd_layernorm_bwd_cast(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                           const float* dres, const float* dres2, float* dx, void* dx16, const float* scale_dev, int M, int D,
                           long ldd, long ldx, float dyscale, void* stream);

@@ -1,5 +1,5 @@
 """Summarise two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, as MI355X_MICROARCH.md prescribes) over
-`bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-events --no-extras` into the per-launch HBM-side traffic of the
+`bench.py --steps 1 --warmup 1 --steps-only` into the per-launch HBM-side traffic of the
 persistent GEMM kernel that bench.py replays as roofline.traffic.  usage: pmc_gemm_traffic.py <fetch_dir> <write_dir> <out.json>"""
 import collections
 import csv
