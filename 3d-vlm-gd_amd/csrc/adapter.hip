@@ -312,6 +312,163 @@ __global__ __launch_bounds__(256, 1) void adapter_persist_kernel(const bf16* __r
     }
 }
 
+// ---- tf32h engine: the same persistent kernel on fp32 tensors with fp16 operands -----------------------------------------------
+// x32 [M, D] fp32 is read ONCE per tile into registers (24 x 16 B per thread), rounded to fp16 (times *in_scale: the backward's gradient scale)
+// on its way into the LDS image the bf16 kernel uses, both products run on the fp16 MFMA, the hidden tile leaves as fp16 (forward: relu(x.down^T),
+// the backward's gate and weight-gradient operand; backward: the scaled d(hidden)), and the result is out32 = x32 + alpha * (hidden . w2^T) in
+// fp32 — the residual taken from x32 again (a second read of lines this CU fetched a few microseconds earlier: L2 hits) — plus, when asked for,
+// out16 = fp16(out32 * *copy_scale), the operand of the next product.  Replaces, per call, a cast pass, the N = 64 GEMM, a second cast and the
+// K = 64 GEMM (whose 129 us are pure residual / result traffic) of the unfused tf32h path.
+template <int D>
+__global__ __launch_bounds__(256, 1) void adapter_persist_h_kernel(const float* __restrict__ x32, const f16* __restrict__ w1, const f16* __restrict__ w2,
+                                                                   const f16* __restrict__ gate, f16* __restrict__ hout, float* __restrict__ out32,
+                                                                   f16* __restrict__ out16, const float* in_scale, const float* alpha_dev,
+                                                                   const float* copy_scale, int M) {
+    constexpr int CPR = D / 8, KS = D / 32, NG = D / 256;
+    constexpr int PPT = AD_BM * CPR / 256;      // fp16 16-byte chunks (8 elements = two fp32 16-byte loads) of a tile per thread
+    static_assert(D <= 768, "both weights and the fp32 prefetch have to fit 512 registers");
+    __shared__ __attribute__((aligned(16))) char sX[AD_BM * D * 2];
+    __shared__ __attribute__((aligned(16))) char sH[AD_BM * AD_BOT * 2];
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntiles = (M + AD_BM - 1) / AD_BM;
+    const bool gated = gate != nullptr;
+    const float sin = in_scale ? *in_scale : 1.0f, alpha = alpha_dev ? *alpha_dev : 1.0f, scp = copy_scale ? *copy_scale : 1.0f;
+
+    int tile = blockIdx.x;
+    f32x4 pre[PPT][2];
+    static_for<PPT>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = ic;
+        const int lin = i * 256 + tid, row = lin / CPR, p = lin % CPR;
+        const float* src = x32 + (long)min(tile * AD_BM + row, M - 1) * D + p * 8;
+        pre[i][0] = *(const f32x4*)src;
+        pre[i][1] = *(const f32x4*)(src + 4);
+    });
+    // the first weight stays in registers for the whole launch; the second (96 KB at D = 768) is streamed from L2 per column group, one group
+    // ahead — with it resident too the fp32 prefetch (96 registers) does not fit the 512-register budget
+    f16x8 b1[KS];
+    {
+        const char* w1r = (const char*)w1 + (long)(16 * wave + c) * (D * 2) + 16 * g;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) b1[ks] = *(const f16x8*)(w1r + ks * 64);
+    }
+    int c2 = c;      // made opaque once per tile: the (tile-invariant) second-weight loads are otherwise hoisted out of the tile loop — back into registers
+    auto load_b2 = [&](int gq, f16x8 (&b2)[4][2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                b2[j][ks] = *(const f16x8*)((const char*)w2 + (long)(wave * (D / 4) + 64 * gq + 4 * c2 + j) * (AD_BOT * 2) + 64 * ks + 16 * g);
+    };
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * AD_BM;
+        __syncthreads();                        // the previous tile's readers are done with sX and sH
+        static_for<PPT>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = ic;
+            const int lin = i * 256 + tid, row = lin / CPR, p = lin % CPR;
+            f16x8 h;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { h[k] = from_f32<f16>(pre[i][0][k] * sin); h[4 + k] = from_f32<f16>(pre[i][1][k] * sin); }
+            *(f16x8*)(sX + (row * CPR + (p ^ (row & 15))) * 16) = h;
+        });
+        unsigned short gt[8];
+        {
+            const f16* gp = gated ? gate : w1;
+            static_for<8>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = ic / 4, r = ic % 4;
+                const int row = min(row0 + 16 * i + 4 * g + r, M - 1);
+                gt[ic] = ((const unsigned short*)gp)[gated ? (long)row * AD_BOT + 16 * wave + c : 0];
+            });
+        }
+        __syncthreads();
+        {   // next tile into registers (the last iteration re-reads its own tile: harmless, keeps the loads unconditional)
+            const int nt = tile + (int)gridDim.x < ntiles ? tile + (int)gridDim.x : tile;
+            static_for<PPT>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = ic;
+                const int lin = i * 256 + tid, row = lin / CPR, p = lin % CPR;
+                const float* src = x32 + (long)min(nt * AD_BM + row, M - 1) * D + p * 8;
+                pre[i][0] = *(const f32x4*)src;
+                pre[i][1] = *(const f32x4*)(src + 4);
+            });
+        }
+        // ---- phase 1 ----
+        f32x4 acc1[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc1[i][0] = acc1[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        constexpr int KB = 4;
+#pragma unroll
+        for (int k0 = 0; k0 < KS; k0 += KB) {
+            f16x8 a[KB][2];
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    a[kk][i] = *(const f16x8*)(sX + (((16 * i + c) * CPR + ((4 * (k0 + kk) + g) ^ c)) * 16));
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc1[i][kk & 1] = Mma<f16>::mma(a[kk][i], b1[k0 + kk], acc1[i][kk & 1]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc1[i][0][r] + acc1[i][1][r];
+                // fp16 > 0 <=> its bits, as int16, > 0 (the gate is the forward's relu output: non-negative, -0 never occurs)
+                v = gated ? ((short)gt[4 * i + r] > 0 ? v : 0.f) : fmaxf(v, 0.f);
+                ((f16*)sH)[(16 * i + 4 * g + r) * AD_BOT + 16 * wave + c] = from_f32<f16>(v);
+            }
+        __syncthreads();
+        if (hout != nullptr && row0 + (tid >> 3) < M)
+            *(uint4*)((char*)hout + (long)row0 * (AD_BOT * 2) + tid * 16) = *(const uint4*)(sH + tid * 16);
+        // ---- phase 2 ----
+        f16x8 ah[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) ah[i][ks] = *(const f16x8*)(sH + (16 * i + c) * (AD_BOT * 2) + 64 * ks + 16 * g);
+        const bool full = row0 + AD_BM <= M;
+        asm volatile("" : "+v"(c2));
+        f16x8 b2[2][4][2];
+        load_b2(0, b2[0]);
+#pragma unroll
+        for (int gq = 0; gq < NG; ++gq) {
+            if (gq + 1 < NG) load_b2(gq + 1, b2[(gq + 1) & 1]);
+            const int col = wave * (D / 4) + 64 * gq + 4 * c;
+            f32x4 xr[2][4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xr[i][r] = *(const f32x4*)(x32 + (long)min(row0 + 16 * i + 4 * g + r, M - 1) * D + col);
+            f32x4 acc[2][4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = Mma<f16>::mma(ah[i][ks], b2[gq & 1][j][ks], acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * i + 4 * g + r;
+                    if (!(full || row0 + row < M)) continue;
+                    const f32x4 o = {fmaf(alpha, acc[i][0][r], xr[i][r][0]), fmaf(alpha, acc[i][1][r], xr[i][r][1]),
+                                     fmaf(alpha, acc[i][2][r], xr[i][r][2]), fmaf(alpha, acc[i][3][r], xr[i][r][3])};
+                    *(f32x4*)(out32 + (long)(row0 + row) * D + col) = o;
+                    if (out16) {
+                        const f16x4 h = {from_f32<f16>(o[0] * scp), from_f32<f16>(o[1] * scp), from_f32<f16>(o[2] * scp), from_f32<f16>(o[3] * scp)};
+                        *(f16x4*)(out16 + (long)(row0 + row) * D + col) = h;
+                    }
+                }
+        }
+    }
+}
+
 template <int D>
 static void adapter_launch(const void* x, const void* w1, const void* w2, const void* gate, void* hout, void* out, int M,
                            hipStream_t s) {
@@ -348,6 +505,30 @@ extern "C" int gd_adapter_fused(const void* x, const void* w1, const void* w2, c
         case 768: adapter_launch<768>(x, w1, w2, gate_src, hidden, out, M, s); break;
         default: adapter_launch<1024>(x, w1, w2, gate_src, hidden, out, M, s); break;
     }
+    GD_LAUNCH_OK();
+    return 0;
+}
+
+// fp32 x / out with fp16 operands (tf32h engine): out32 = x32 + alpha * gate(fp16(x32 * in_scale) . w1^T) . w2^T, hidden [M, 64] fp16 (the gated
+// first product, still times in_scale), out16 (optional) = fp16(out32 * copy_scale); in_scale / alpha / copy_scale are DEVICE scalars (null = 1).
+extern "C" int gd_adapter_fused_h_supported(int D, int bottleneck, long M) { return bottleneck == AD_BOT && (D == 256 || D == 512 || D == 768) && M >= 256L * AD_BM; }
+extern "C" int gd_adapter_fused_h(const float* x32, const void* w1, const void* w2, const void* gate_src, void* hidden, float* out32, void* out16,
+                                  const float* in_scale, const float* alpha_dev, const float* copy_scale, int M, int D, int bottleneck, void* stream) {
+    GD_REQUIRE(M > 0 && gd_adapter_fused_h_supported(D, bottleneck, M),
+               "gd_adapter_fused_h: unsupported configuration M=%d D=%d bottleneck=%d (bottleneck 64, D in {256,512,768}, M >= 8192)", M, D, bottleneck);
+    GD_REQUIRE(((uintptr_t)x32 & 15) == 0 && ((uintptr_t)w1 & 15) == 0 && ((uintptr_t)w2 & 15) == 0 && ((uintptr_t)out32 & 15) == 0 &&
+                   ((uintptr_t)hidden & 15) == 0 && ((uintptr_t)out16 & 7) == 0 && ((uintptr_t)gate_src & 1) == 0,
+               "gd_adapter_fused_h: x32, w1, w2, out32, hidden must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const int cus = gd_knobs().ncu, blocks = min(cus, gd_cdiv(M, AD_BM));
+#define GD_ADH(DD) hipLaunchKernelGGL(adapter_persist_h_kernel<DD>, dim3(blocks), dim3(256), 0, s, x32, (const f16*)w1, (const f16*)w2, (const f16*)gate_src, \
+                                      (f16*)hidden, out32, (f16*)out16, in_scale, alpha_dev, copy_scale, M)
+    switch (D) {
+        case 256: GD_ADH(256); break;
+        case 512: GD_ADH(512); break;
+        default: GD_ADH(768); break;
+    }
+#undef GD_ADH
     GD_LAUNCH_OK();
     return 0;
 }

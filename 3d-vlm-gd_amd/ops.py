@@ -403,6 +403,28 @@ def adapter_fused(x, w1, w2, gate_src=None, save_hidden=True):
     return out, hidden
 
 
+def adapter_fused_h_supported(M, D, bottleneck):
+    return bool(option("adapter_h_fused")) and bool(lib().gd_adapter_fused_h_supported(int(D), int(bottleneck), int(M)))
+
+
+def adapter_fused_h(x32, w1, w2, gate_src=None, in_scale=None, alpha_dev=None, copy_scale=None, want_copy=False):
+    """The adapter pass of the tf32h engine in one kernel: x32 [M,D] fp32, w1 [64,D] / w2 [D,64] fp16 ->
+    out32 = x32 + alpha * gate(fp16(x32 * in_scale) @ w1.T) @ w2.T (fp32), hidden [M,64] fp16 (the gated first product, still times in_scale),
+    and with want_copy fp16(out32 * copy_scale).  gate_src None: ReLU (forward); gate_src [M,64] fp16: keep where gate_src > 0 (backward-to-input:
+    x32 = dOut, in_scale = s, alpha = 1/s).  The three scales are device scalars (ops.amax_scale slices) or None = 1."""
+    M, D = x32.shape
+    bott = w1.shape[0]
+    _req(x32.dtype == torch.float32 and x32.is_contiguous() and w1.dtype == torch.float16 and w2.dtype == torch.float16 and w1.is_contiguous() and
+         w2.is_contiguous() and w1.shape == (bott, D) and w2.shape == (D, bott), "adapter_fused_h: layout")
+    _req(gate_src is None or (gate_src.is_contiguous() and gate_src.shape == (M, bott) and gate_src.dtype == torch.float16), "adapter_fused_h: gate_src layout")
+    out = torch.empty_like(x32)
+    hidden = torch.empty(M, bott, dtype=torch.float16, device=x32.device)
+    copy = torch.empty(M, D, dtype=torch.float16, device=x32.device) if want_copy else None
+    check(lib().gd_adapter_fused_h(ptr(x32), ptr(w1), ptr(w2), ptr(gate_src), ptr(hidden), ptr(out), ptr(copy), ptr(in_scale), ptr(alpha_dev),
+                                   ptr(copy_scale), M, D, bott, stream()), "gd_adapter_fused_h")
+    return out, hidden, copy
+
+
 # ----------------------------------------------------------------------------------------------
 # normalisation
 # ----------------------------------------------------------------------------------------------

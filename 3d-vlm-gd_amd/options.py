@@ -10,6 +10,7 @@ _DEFS = {
     "conv_stacked": ("GD_CONV_STACKED", 1),      # dense 3x3 conv as stacked-row GEMMs; 0: the im2col form
     "lora_fused": ("GD_LORA_FUSED", 1),          # one-pass LoRA backward kernel (bf16)
     "gather_det": ("GD_GATHER_DET", 1),          # atomics-free keypoint-gather backward
+    "adapter_h_fused": ("GD_ADAPTER_H_FUSED", 1),  # tf32h: the one-pass fp16-operand adapter kernel (0: cast + two GEMMs)
     "direct_grads": ("GD_DIRECT_GRADS", 1),      # fit_step: block weight gradients accumulate straight into the flat gradient buffer
 }
 _VALUES = {k: int(os.environ.get(env, str(d))) for k, (env, d) in _DEFS.items()}

@@ -202,7 +202,8 @@ class _BlockFn(torch.autograd.Function):
         hkw = {} if not hs else {"out_split": True} if fmt == "x3" else {"out_dtype": torch.float16}
         h = _mm(None if fmt == "h" else y2, plan, "w1", xs=y2 if fmt == "h" else None, bias=plan["b1"], act=3, preact=pre, **hkw)   # pre <- GELU'(fc1 output): all the backward needs
         x2a = None
-        if fmt == "h" and hs and down is not None and ops.copy16_ok(M, D, plan["w2"].shape[1]):
+        ad_h = fmt == "h" and down is not None and ops.adapter_fused_h_supported(M, D, down.shape[0])      # the fused fp16-operand adapter kernel
+        if fmt == "h" and hs and down is not None and not ad_h and ops.copy16_ok(M, D, plan["w2"].shape[1]):
             # tf32h: fc2 writes the residual-stream result and, from the same epilogue, the fp16 copy the adapter's down projection takes
             x2, x2a = ops.gemm_nt_copy16(h, plan["w2"], x1, bias=plan["b2"])
         else:
@@ -213,6 +214,11 @@ class _BlockFn(torch.autograd.Function):
             up_T = tw["up_T"] if tw is not None else up.detach().to(T).contiguous()
             if ops.adapter_fused_supported(x2, down.shape[0]):
                 out, hd = ops.adapter_fused(x2, down_T, up_T, save_hidden=need)
+            elif ad_h:      # tf32h: one pass — x2 read once (rounded to fp16 in flight), both products on the fp16 MFMA, fp32 residual add
+                w_dn = tw["down_w3"] if tw is not None and "down_w3" in tw else _opw(down_T, fmt)
+                w_up = tw["up_w3"] if tw is not None and "up_w3" in tw else _opw(up_T, fmt)
+                out, hd16, _ = ops.adapter_fused_h(x2, w_dn, w_up)
+                hd = hd16
             elif plan["x3"]:        # tf32x: both projections as split-precision products on the bf16 kernels (the fp32 tile kernel: 2 x 370 us)
                 w_dn = tw["down_w3"] if tw is not None and "down_w3" in tw else _opw(down_T, fmt)
                 w_up = tw["up_w3"] if tw is not None and "up_w3" in tw else _opw(up_T, fmt)
@@ -270,8 +276,18 @@ class _BlockFn(torch.autograd.Function):
         if ctx.has_ad:
             up_tT = tw["up_tT"] if tw is not None else up.detach().t().to(T).contiguous()
             down_tT = tw["down_tT"] if tw is not None else down.detach().t().to(T).contiguous()
+            ad_h = fmt == "h" and hd.dtype == torch.float16 and ops.adapter_fused_h_supported(dout.shape[0], D, bott)
             if ops.adapter_fused_supported(dout, bott):
                 dx2, dhp = ops.adapter_fused(dout, up_tT, down_tT, gate_src=hd)                   # dX and d(hidden) [M, 64]
+            elif ad_h:
+                # dX = dOut + ((dOut s . up) * [h > 0]) . down / s in one pass; d(hidden) leaves as fp16 (times s), dX also as the scaled fp16
+                # operand of the fc2 backward; the two weight gradients contract the fp32 dOut / x2 against the fp16 hidden tiles
+                w_ut = tw["up_tw3"] if tw is not None and "up_tw3" in tw else _opw(up_tT, fmt)
+                w_dt = tw["down_tw3"] if tw is not None and "down_tw3" in tw else _opw(down_tT, fmt)
+                dx2, dhpa, dx2a = ops.adapter_fused_h(dout.view(-1, D), w_ut, w_dt, gate_src=hd, in_scale=sc[0:1], alpha_dev=sc[1:2], copy_scale=sc[0:1],
+                                                      want_copy=True)
+                g_up = ops.gemm_tn(dout.view(-1, D), hd, out=z_up)                                # [D, 64]
+                g_down = ops.gemm_tn(dhpa, x2, out=z_down, alpha_dev=sc[1:2])                     # [64, D]
             elif plan["x3"]:
                 w_ut = tw["up_tw3"] if tw is not None and "up_tw3" in tw else _opw(up_tT, fmt)
                 w_dt = tw["down_tw3"] if tw is not None and "down_tw3" in tw else _opw(down_tT, fmt)
@@ -286,7 +302,9 @@ class _BlockFn(torch.autograd.Function):
             else:
                 dhp = ops.gemm_nt(dout, up_tT, dact_src=hd, dact=2)                               # [M, 64]
                 dx2 = ops.gemm_nt(dhp, down_tT, residual=dout)
-            if fmt == "h" and ctx.hd16 is not None and x2.dtype == torch.float16:
+            if ad_h:
+                pass      # (weight gradients taken above)
+            elif fmt == "h" and ctx.hd16 is not None and x2.dtype == torch.float16:
                 # the weight gradients on the fp16 MFMA kernel from the operands at hand: (dout s)^T hd and (dhp s)^T x2, times 1/s on the device
                 g_up = ops.gemm_tn(douta, ctx.hd16, out=z_up, alpha_dev=sc[1:2])                  # [D, 64]
                 g_down = ops.gemm_tn(dhpa, x2, out=z_down, alpha_dev=sc[1:2])                     # [64, D]

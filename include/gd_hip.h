@@ -293,6 +293,12 @@ int gd_gemm_tn_scaled(const void* Y, const void* X, float* G, int M, int N, int 
                       int batch, long sY, long sX, long sG, int y_dtype, int x_dtype, float alpha, const float* alpha_dev, void* stream);
 /* gd_layernorm_fwd with y_dtype GD_F16 (f32 rows in): LN(x) written as the fp16 operand directly.  gd_layernorm_bwd_cast: the f32 backward
  * that also writes dx16 [M, D] = fp16(sat(dx * *scale_dev)) — backward + gd_cast_f16 in one pass. */
+/* Bottleneck adapter of the tf32h engine, fused (utils/model.py:7-25 forward, and its backward-to-input): fp32 x / out, fp16 operands.
+ * out32 = x32 + alpha * gate(fp16(x32 * in_scale) . w1^T) . w2^T; hidden [M,64] fp16 = the gated first product (relu when gate_src is null, else kept
+ * where gate_src > 0); out16 (nullable) = fp16(out32 * copy_scale).  in_scale / alpha_dev / copy_scale: DEVICE scalars, null = 1. */
+int gd_adapter_fused_h_supported(int D, int bottleneck, long M);
+int gd_adapter_fused_h(const float* x32, const void* w1, const void* w2, const void* gate_src, void* hidden, float* out32, void* out16,
+                       const float* in_scale, const float* alpha_dev, const float* copy_scale, int M, int D, int bottleneck, void* stream);
 int gd_tap_mean_norm_fwd_h(const void* const* grids, int ngrid, long bstride, int prefix, float* out, void* out16, float* inv_norm,
                            int B, int hw, int D, void* stream);      /* gd_tap_mean_norm_fwd on fp32 taps + the fp16 copy of the rows it writes */
 int gd_layernorm_bwd_cast(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,

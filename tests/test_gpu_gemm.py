@@ -386,3 +386,33 @@ def test_gemm_nt_copy16_writes_the_f32_result_and_its_scaled_fp16_copy():
     assert float((c16 != want).float().mean()) < 0.01 and rel_err(c16.float(), want.float()) < 1e-3       # (packed vs scalar multiply: last-ulp differences)
     with pytest.raises(GdHipError):
         ops.gemm_nt_copy16(a[:512], w, res[:512])
+
+
+@pytest.mark.parametrize("M", [8192, 8192 + 50])
+def test_adapter_fused_fp16_operands(M):
+    """gd_adapter_fused_h (tf32h engine): fp32 x / out, both products on fp16 operands, in one pass.  Forward (ReLU) and backward-to-input
+    (gated by the forward's hidden, dOut under a device-side scale, the scaled fp16 copy of dX beside the fp32 one) against the fp64
+    arithmetic of the same fp16-rounded operands; shapes the kernel does not serve are refused."""
+    from gd_amd import ops
+    from gd_amd._lib import GdHipError
+    D, bott = 768, 64
+    x = _mk((M, D), torch.float32, 71)
+    down, up = (_mk((bott, D), torch.float32, 72) * 0.05).half(), (_mk((D, bott), torch.float32, 73) * 0.05).half()
+    out, hid, cp = ops.adapter_fused_h(x, down, up)
+    assert out.dtype == torch.float32 and hid.dtype == torch.float16 and cp is None
+    h_ref = torch.relu(x.half().double() @ down.double().t())
+    assert rel_err(hid, h_ref) < 1e-3
+    assert rel_err(out, x.double() + hid.double() @ up.double().t()) < 1e-6          # (the kernel's own fp16 hidden tile feeds its second product)
+    # backward-to-input: dX = dOut + ((dOut . up) * [h > 0]) . down
+    dout = _mk((M, D), torch.float32, 74) * 1e-6
+    sc = ops.amax_scale(dout, 8.0)
+    s = float(sc[0])
+    dx, dh, dx16 = ops.adapter_fused_h(dout, up.t().contiguous(), down.t().contiguous(), gate_src=hid, in_scale=sc[0:1], alpha_dev=sc[1:2],
+                                       copy_scale=sc[0:1], want_copy=True)
+    d16 = (dout * s).half().double()
+    dh_ref = (d16 @ up.double()) * (hid.double() > 0)
+    assert rel_err(dh, dh_ref) < 1e-3
+    dx_ref = dout.double() + (dh.double() @ down.double()) / s
+    assert rel_err(dx, dx_ref) < 1e-6 and rel_err(dx16.double() / s, dx_ref) < 1e-3 and bool(torch.isfinite(dx16.float()).all())
+    with pytest.raises(GdHipError):
+        ops.adapter_fused_h(x[:1000], down, up)
