@@ -522,7 +522,9 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int rowb, int col0, 
     return __builtin_bit_cast(bf16x8, z);
 }
 
-template <typename T>       // bf16 | f16
+// YF32 / XF32 (tf32h engine, T = f16): that operand is fp32 in memory and is rounded to fp16 on its way into LDS — a gradient Y times 1 / *alpha_dev
+// (the scale its consumer undoes: alpha_dev = 1 / s) — so that a weight gradient contracts an fp32 tensor without a separate cast pass.
+template <typename T, bool YF32 = false, bool XF32 = false>       // bf16 | f16
 __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmTnParams p) {
     constexpr int ROWB = 272;   // 128 bf16 + 16 B pad
     __shared__ __attribute__((aligned(16))) char sY[64 * ROWB];
@@ -536,11 +538,26 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmTnParams p) {
     const int tile = t % (int)gridDim.x, mc = t / (int)gridDim.x;
     const int tn = tile % tiles_n, tk = tile / tiles_n;
     const int m_begin = mc * p.mchunk, m_end = min(p.M, m_begin + p.mchunk);
-    const T* Y = (const T*)p.Y + (long)blockIdx.z * p.sY;
-    const T* X = (const T*)p.X + (long)blockIdx.z * p.sX;
+    typedef typename std::conditional<YF32, float, T>::type TY;
+    typedef typename std::conditional<XF32, float, T>::type TX;
+    const TY* Y = (const TY*)p.Y + (long)blockIdx.z * p.sY;
+    const TX* X = (const TX*)p.X + (long)blockIdx.z * p.sX;
     float* G = p.G + (long)blockIdx.z * p.sG;
     typedef typename Mma<T>::Frag Frag;
     const float alpha = p.alpha_dev ? p.alpha * *p.alpha_dev : p.alpha;
+    const float ys = (YF32 && p.alpha_dev) ? 1.0f / *p.alpha_dev : 1.0f;
+    auto ld8 = [&](const auto* q, float sc) __attribute__((always_inline)) {      // 8 elements -> one 16-byte chunk of T
+        typedef typename std::remove_cv<typename std::remove_pointer<decltype(q)>::type>::type E;
+        if constexpr (std::is_same<E, float>::value) {
+            const f32x4 a = *(const f32x4*)q, b = *(const f32x4*)(q + 4);
+            Frag h;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { h[k] = from_f32<T>(a[k] * sc); h[4 + k] = from_f32<T>(b[k] * sc); }
+            return __builtin_bit_cast(uint4, h);
+        } else {
+            return *(const uint4*)q;
+        }
+    };
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -554,8 +571,8 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmTnParams p) {
         for (int i = 0; i < 4; ++i) {
             const int ch = tid + 256 * i, rr = ch >> 4, cc = (ch & 15) * 8;
             const int m = m0 + rr, yn = tn * 128 + cc, xk = tk * 128 + cc;
-            ry[i] = (m < m_end && yn < p.N) ? *(const uint4*)(Y + (long)m * p.ldy + yn) : make_uint4(0, 0, 0, 0);
-            rx[i] = (m < m_end && xk < p.K) ? *(const uint4*)(X + (long)m * p.ldx + xk) : make_uint4(0, 0, 0, 0);
+            ry[i] = (m < m_end && yn < p.N) ? ld8(Y + (long)m * p.ldy + yn, ys) : make_uint4(0, 0, 0, 0);
+            rx[i] = (m < m_end && xk < p.K) ? ld8(X + (long)m * p.ldx + xk, 1.0f) : make_uint4(0, 0, 0, 0);
         }
     };
     gload(m_begin);
@@ -928,7 +945,9 @@ static int gemm_tn_impl(const void* Y, const void* X, float* G, int M, int N, in
         return 0;
     }
     const bool h16 = y_dtype == GD_F16 && x_dtype == GD_F16 && N >= 64 && K >= 64;    // tf32h: fp16 MFMA, same kernel
-    const bool bf = (y_dtype == GD_BF16 && x_dtype == GD_BF16 && N >= 64 && K >= 64) || h16;   // bf16 MFMA + transpose reads
+    // tf32h, one operand still fp32 in memory (it is rounded to fp16 on the way into LDS; a gradient Y under the scale 1 / *alpha_dev)
+    const bool hy32 = y_dtype == GD_F32 && x_dtype == GD_F16 && N >= 64 && K >= 64, hx32 = y_dtype == GD_F16 && x_dtype == GD_F32 && N >= 64 && K >= 64;
+    const bool bf = (y_dtype == GD_BF16 && x_dtype == GD_BF16 && N >= 64 && K >= 64) || h16 || hy32 || hx32;   // bf16 MFMA + transpose reads
     const int tl = bf ? 128 : 64;
     const int tiles = gd_cdiv(N, tl) * gd_cdiv(K, tl);
     // enough M-chunks to fill the chip without shredding the reduction (every chunk ends in N x K fp32 atomics: at 87 680 x 768 x 64
@@ -939,7 +958,9 @@ static int gemm_tn_impl(const void* Y, const void* X, float* G, int M, int N, in
     if (mchunk < 256) mchunk = 256;
     p.mchunk = mchunk;
     dim3 grid(tiles, gd_cdiv(M, mchunk), batch);
-    if (h16) hipLaunchKernelGGL(gemm_tn_bf16_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    if (hy32) hipLaunchKernelGGL((gemm_tn_bf16_kernel<f16, true, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else if (hx32) hipLaunchKernelGGL((gemm_tn_bf16_kernel<f16, false, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else if (h16) hipLaunchKernelGGL(gemm_tn_bf16_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, p);
     else if (bf) hipLaunchKernelGGL(gemm_tn_bf16_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
     GD_LAUNCH_OK();

@@ -286,7 +286,7 @@ class _BlockFn(torch.autograd.Function):
                 w_dt = tw["down_tw3"] if tw is not None and "down_tw3" in tw else _opw(down_tT, fmt)
                 dx2, dhpa, dx2a = ops.adapter_fused_h(dout.view(-1, D), w_ut, w_dt, gate_src=hd, in_scale=sc[0:1], alpha_dev=sc[1:2], copy_scale=sc[0:1],
                                                       want_copy=True)
-                g_up = ops.gemm_tn(dout.view(-1, D), hd, out=z_up)                                # [D, 64]
+                g_up = ops.gemm_tn(dout.view(-1, D), hd, out=z_up, alpha_dev=sc[1:2])             # [D, 64]  (dOut rounded to fp16 under s inside the kernel)
                 g_down = ops.gemm_tn(dhpa, x2, out=z_down, alpha_dev=sc[1:2])                     # [64, D]
             elif plan["x3"]:
                 w_ut = tw["up_tw3"] if tw is not None and "up_tw3" in tw else _opw(up_tT, fmt)

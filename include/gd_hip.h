@@ -288,7 +288,8 @@ int gd_gemm_nt_copy16(const void* A, const void* W, void* C, int M, int N, int K
                       const float* alpha_dev, const float* bias, const void* residual, long ldr, void* copy16, long ldc16,
                       const float* copy_scale_dev, void* stream);
 /* gd_gemm_tn with alpha multiplied by the device scalar *alpha_dev (weight gradients contracted from SCALED fp16 gradient operands);
- * gd_gemm_tn takes fp16 Y and X on the MFMA kernel (N, K >= 64) and fp16 X on the N = 8 streaming kernel. */
+ * gd_gemm_tn takes fp16 Y and X on the MFMA kernel (N, K >= 64) and fp16 X on the N = 8 streaming kernel; with ONE of Y / X fp16 and the other fp32
+ * (N, K >= 64) the fp32 one is rounded to fp16 inside the kernel — an fp32 Y times 1 / *alpha_dev first (a gradient under the scale its alpha undoes). */
 int gd_gemm_tn_scaled(const void* Y, const void* X, float* G, int M, int N, int K, long ldy, long ldx, long ldg,
                       int batch, long sY, long sX, long sG, int y_dtype, int x_dtype, float alpha, const float* alpha_dev, void* stream);
 /* gd_layernorm_fwd with y_dtype GD_F16 (f32 rows in): LN(x) written as the fp16 operand directly.  gd_layernorm_bwd_cast: the f32 backward

@@ -416,3 +416,22 @@ def test_adapter_fused_fp16_operands(M):
     assert rel_err(dx, dx_ref) < 1e-6 and rel_err(dx16.double() / s, dx_ref) < 1e-3 and bool(torch.isfinite(dx16.float()).all())
     with pytest.raises(GdHipError):
         ops.adapter_fused_h(x[:1000], down, up)
+
+
+def test_gemm_tn_rounds_an_fp32_operand_to_fp16_in_the_kernel():
+    """gd_gemm_tn with one fp16 and one fp32 operand (tf32h weight gradients): the fp32 one is rounded to fp16 on its way into LDS — an fp32 Y
+    (a gradient) under the scale 1 / alpha_dev, which alpha undoes — and the result equals the cast-then-contract path."""
+    from gd_amd import ops
+    M, N, K = 8200, 768, 64
+    g = torch.Generator(device="cuda").manual_seed(9)
+    y = torch.randn(M, N, generator=g, device="cuda") * 1e-6
+    x = torch.randn(M, K, generator=g, device="cuda").half()
+    sc = ops.amax_scale(y, 8.0)
+    got = ops.gemm_tn(y, x, alpha_dev=sc[1:2])
+    ref = ops.gemm_tn(ops.cast16(y, scale_dev=sc[0:1]), x, alpha_dev=sc[1:2])
+    exact = y.double().t() @ x.double()
+    assert rel_err(got, ref) < 1e-5 and rel_err(got, exact) < 1e-3
+    x32 = torch.randn(M, N, generator=g, device="cuda")
+    y16 = (torch.randn(M, K, generator=g, device="cuda")).half()
+    got = ops.gemm_tn(y16, x32)
+    assert rel_err(got, y16.double().t() @ x32.half().double()) < 1e-5
