@@ -449,7 +449,7 @@ def test_two_ranks_on_one_gpu_equal_one_rank_on_the_whole_batch(tmp_path):
     assert float(diff.max()) <= 2.1 * flat["lr"] and float(diff[solid].max()) < 0.02 * flat["lr"]
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "tf32h"])
 def test_direct_weight_gradients_equal_the_autograd_path(dtype, monkeypatch):
     """fit_step prepares the blocks with the flat-buffer record: weight packs are views of the flat parameter buffer and the
     LoRA / adapter weight gradients accumulate straight into the flat gradient buffer (LoRA-B through one transposing pass).
@@ -500,7 +500,7 @@ def _load_reference_student(eng, sd):
 
 
 @pytest.mark.parametrize("variant", ["vggt", "mast3r"])
-@pytest.mark.parametrize("dtype,tol,utol", [("f32", 1e-4, 5e-3), ("bf16", 1e-2, 0.5)])
+@pytest.mark.parametrize("dtype,tol,utol", [("f32", 1e-4, 5e-3), ("bf16", 1e-2, 0.5), ("tf32h", 1e-3, 0.25)])
 def test_full_step_written_by_the_reference_g18(variant, dtype, tol, utol):
     from conftest import load_golden
     from gd_amd.finetune import FinetuneGD
@@ -539,8 +539,10 @@ def test_full_step_written_by_the_reference_g18(variant, dtype, tol, utol):
         for name, key in (("ap_loss", "term_ap"), ("depth_loss", "term_depth"), ("intra_depth_loss", "term_intra"), ("kl_loss", "term_kl")):
             ref = float(t[key])
             assert abs(terms[name][q].item() - ref) < tol * max(abs(ref), 1e-3), (q, name, terms[name][q].item(), ref)
-    # bf16 on a 64-wide toy student: the gradient norm carries a few per cent of rounding noise (full-size: tests/test_gpu_fullsize.py)
-    assert abs(float(norm) - float(g["clip_norm"])) < (1e-3 if dtype == "f32" else 5e-2) * float(g["clip_norm"])
+    # bf16 on a 64-wide toy student: the gradient norm carries a few per cent of rounding noise (full-size: tests/test_gpu_fullsize.py);
+    # the first AdamW step moves every element by ~lr * sign(g): on this toy student a handful of near-zero gradients take the other sign in
+    # any reduced-precision run (tf32h: 15 % of ONE small tensor's update norm; utol 0.25) — the trajectory tests compare dW at full size
+    assert abs(float(norm) - float(g["clip_norm"])) < {"f32": 1e-3, "tf32h": 1e-2}.get(dtype, 5e-2) * float(g["clip_norm"])
     live = {int(i) for i in g["n_live"]}
     for i, (p_, a1, b0) in enumerate(zip(eng.trainable_parameters(), after, before)):
         got = p_.detach().float().cpu()
