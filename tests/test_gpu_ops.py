@@ -35,6 +35,39 @@ def test_layernorm(dtype, tol, M, D):
     assert rel_err(dx2, 0.25 * xr.grad) < tol * 3
 
 
+def test_layernorm_fp16_operand_outputs():
+    """tf32h engine: LayerNorm writes its result as the fp16 operand directly (y_dtype GD_F16), and the fp32 backward also emits
+    fp16(dx * s) with s a device scalar (gd_layernorm_bwd_cast) — both bit-identical to the fp32 kernel followed by gd_cast_f16."""
+    from gd_amd import ops
+    M, D = 700, 768
+    x = torch.randn(M, D, generator=_g(11), device="cuda") * 2 + 0.5
+    gm, bt = torch.randn(D, generator=_g(12), device="cuda"), torch.randn(D, generator=_g(13), device="cuda")
+    dy = torch.randn(M, D, generator=_g(14), device="cuda") * 1e-6
+    dres = torch.randn(M, D, generator=_g(15), device="cuda") * 1e-6
+    y32, mean, rstd = ops.layernorm_fwd(x, gm, bt, 1e-6)
+    y16, m2, r2 = ops.layernorm_fwd(x, gm, bt, 1e-6, out_dtype=torch.float16)
+    assert y16.dtype == torch.float16 and torch.equal(y16, ops.cast16(y32)) and torch.equal(mean, m2) and torch.equal(rstd, r2)
+    sc = ops.amax_scale(dy, 8.0)
+    dx, dx16 = ops.layernorm_bwd(dy, x, gm, mean, rstd, dres=dres, cast_scale=sc[0:1])
+    ref = ops.layernorm_bwd(dy, x, gm, mean, rstd, dres=dres)
+    assert torch.equal(dx, ref) and dx16.dtype == torch.float16
+    want = ops.cast16(ref, scale_dev=sc[0:1])
+    assert float((dx16 != want).float().mean()) < 0.01 and rel_err(dx16.float(), want.float()) < 1e-3
+
+
+def test_tap_mean_with_fp16_copy():
+    """ops.tap_mean(with_norm=2) on fp32 taps: the mean rows, their inverse norms and the fp16 copy of the rows (the cost-volume products' operands in
+    the tf32h engine) from one pass — the copy equals gd_cast_f16 of the rows."""
+    from gd_amd import ops
+    taps = [torch.randn(4, 1 + 300, 256, generator=_g(20 + i), device="cuda").requires_grad_(True) for i in range(4)]
+    f, inv, f16 = ops.tap_mean(taps, prefix=1, with_norm=2)
+    f0, inv0 = ops.tap_mean(taps, prefix=1, with_norm=True)
+    assert torch.equal(f, f0) and torch.equal(inv, inv0) and f16.dtype == torch.float16 and not f16.requires_grad
+    assert torch.equal(f16.view(-1, 256), ops.cast16(f.detach().view(-1, 256)))
+    f.sum().backward()
+    assert taps[0].grad is not None
+
+
 def test_l2norm():
     from gd_amd import ops
     x = torch.randn(2, 37, 96, generator=_g(6), device="cuda").requires_grad_(True)
