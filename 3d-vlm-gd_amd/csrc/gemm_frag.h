@@ -112,6 +112,9 @@ __device__ __forceinline__ void bst4_aux(__amdgpu_buffer_rsrc_t rs, int off, int
 #define GD_PROBE(...)
 #define GD_PROBE_DECL(...)
 #endif
+#ifndef GD_SDEP32
+#define GD_SDEP32 8      // f32 side tensors: items in flight per lane (16 bytes each)
+#endif
 #ifndef GD_PERSIST_SIDE_AUX
 #define GD_PERSIST_SIDE_AUX 2     // side tensors are read once: stream them past the L2's operand panels
 #endif

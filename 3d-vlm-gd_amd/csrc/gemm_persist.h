@@ -36,7 +36,7 @@ template <typename T, int SIDE, int ACT, int PREACT, bool CF32, int ANAT = 0, in
 __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
     constexpr int NWN = 4, WMT = 8, NW = 8, BM = 256, BN = 256;
     constexpr int ABYTES = BM * 128, STAGE = (BM + BN) * 128, APW = BM / 8 / NW, BPW = BN / 8 / NW;
-    constexpr int SDEP = CF32 ? 8 : 16;   // side-input prefetch depth (items per lane in flight: 8 bytes each for bf16 side tensors, 16 for f32)
+    constexpr int SDEP = CF32 ? GD_SDEP32 : 16;   // side-input prefetch depth (items per lane in flight: 8 bytes each for bf16 side tensors, 16 for f32)
     constexpr int ssz = CF32 ? 4 : 2;     // element size of the side tensor (dact_src / residual): the dtype of C
     constexpr int LORA_OFF = 2 * STAGE, BIAS_OFF = LORA_OFF + (BM + BN) * 32;
     __shared__ __attribute__((aligned(16))) char smem[BIAS_OFF + 2 * BN * 4];
