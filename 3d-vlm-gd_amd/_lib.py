@@ -30,6 +30,9 @@ SIGNATURES = {
                                   c_void_p, c_long, c_int, c_void_p, c_long, c_int, c_void_p]),
     "gd_layernorm_bwd_cast": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_int, c_int, c_long, c_long, c_float, c_void_p]),
+    "gd_cost_volume_kl_rows_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "gd_cost_volume_kl_fwd_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                           c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gd_cost_volume_kl_bwd_h_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gd_cost_volume_kl_bwd_h": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

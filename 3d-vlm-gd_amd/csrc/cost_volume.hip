@@ -128,6 +128,7 @@ struct CvTileParams {
     // backward only
     const unsigned char* m1; const unsigned char* m2; const float* gloss;
     void* G1; void* G2; int hwp;
+    const int* idx; int kcap;   // kept-row form (cv_fwd_rows_kernel): [P][2][kcap] kept-row indices (padded with a kept index), kcap % 128 == 0
     const float* gscale;      // fp16 G (tf32h engine): device scalar s multiplied into G before it is rounded; the GEMMs that contract G undo it
 };
 
@@ -331,6 +332,7 @@ __global__ __launch_bounds__(256, 2) void cv_fwd_tile_kernel(CvTileParams q) {
 //     S never touches LDS; per element: one v_exp (both directions' Z), and max + fma per direction.
 //   One s_barrier per K-step joins all 12 waves (step n landed / slot n-1 free); the epilogue has none.
 // ---------------------------------------------------------------------------------------------------
+#define CV_FCH 8      // loss chunks per pair (cv_finalize_*)
 #define CVP_SLOTS 4
 #define CVP_STAGE 32768
 #define CVP_STAT_OFF (CVP_SLOTS * CVP_STAGE)            // 2 x 256 float4 (tile parity)
@@ -597,8 +599,293 @@ __global__ __launch_bounds__(768) void cv_fwd_persist_kernel(CvTileParams q) {
     cvp_barrier();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// KEPT-ROW form of the persistent forward (sparse row masks: the MASt3R trainer's keypoint-patch masks keep <= N_kp of the hw rows).
+// A masked-out row's KL term is a constant and needs neither its teacher row nor its scores — and direction 2's "rows" are S's columns —
+// so the two directions are computed as TWO compacted row problems instead of one hw x hw sweep:
+//   direction d (0 | 1): A = the kept rows of view d's features, gathered through an index list (the LDS-DMA takes per-lane addresses: the
+//   gather is free), B = ALL rows of the other view, teacher rows = the kept rows of T_d (row-contiguous), statistics per kept row only.
+// Tile space [pair][direction][kcap / 128 row tiles][hw / 128 column tiles] instead of [pair][tiles][tiles]: 2 x 3 x 11 = 66 tiles per pair at 300
+// keypoints against 121, each with HALF the epilogue (one direction), every teacher byte it loads needed.  Same ring, roles and waits as
+// cv_fwd_persist_kernel; what differs is marked ROWS.
+template <typename T>
+__global__ __launch_bounds__(768) void cv_fwd_rows_kernel(CvTileParams q) {
+    constexpr bool DBG = false;
+    __shared__ __attribute__((aligned(16))) char smem[CVP_SMEM];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hw = q.hw, tiles = q.tiles, ldt = q.ldt;
+    const long rowb = (long)q.C * sizeof(T);
+    const int nk = (int)(rowb / 128);
+    // this block's share: XCD x (blocks b and b + 8 share one) takes a contiguous range of the pair-major tile list, its
+    // blocks stride through it — the ~32 tiles in flight on an XCD belong to one or two pairs: their features stay in its L2
+    const int tiles_r = q.kcap >> 7, kcap = q.kcap;                  // ROWS: row tiles over the compacted (kept) rows
+    const int total = q.P * 2 * tiles_r * tiles, nbx = gridDim.x >> 3, xc = blockIdx.x & 7, kb = blockIdx.x >> 3;
+    const int qT = total >> 3, rT = total & 7;
+    const int beg = xc < rT ? xc * (qT + 1) : rT * (qT + 1) + (xc - rT) * qT;
+    const int cnt = qT + (xc < rT ? 1 : 0);
+    const int n_tiles = cnt > kb ? (cnt - kb + nbx - 1) / nbx : 0;
+    if (n_tiles == 0) return;
+    const int n_total = n_tiles * nk;
+    const unsigned smem_base = (unsigned)(uintptr_t)smem;      // LDS byte address of the block's array (generic -> LDS offset)
+    // ROWS: tile l -> (pd = 2 pair + direction, tm = row tile of the kept rows, tn = column tile); .p holds pd
+    auto rtile = [&](int l) __attribute__((always_inline)) {
+        const int per = tiles_r * tiles;
+        CvpTile t;
+        t.p = l / per;
+        const int r = l - t.p * per;
+        t.tm = r / tiles;
+        t.tn = r - t.tm * tiles;
+        return t;
+    };
+
+    if (wave >= 8) {
+        // ======================================= LOADER waves =======================================
+        const int lw = wave - 8;
+        const char* asrc[4];
+        const char* wsrc[4];
+        const char* ssrc = nullptr;
+        int it_i = 0, k_i = 0;                 // (tile, K-step) of the next step to issue
+        auto issue = [&](int n) {
+            char* sA = smem + (n & (CVP_SLOTS - 1)) * CVP_STAGE;
+            char* sB = sA + 128 * 128;
+            if (k_i == 0) {
+                const CvpTile t = rtile(beg + kb + it_i * nbx);
+                const int pr = t.p >> 1, dir = t.p & 1;
+                const char* Ab = (const char*)(dir ? q.f2 : q.f1) + (long)pr * hw * rowb;      // ROWS: view d's kept rows against all rows of the other view
+                const char* Wb = (const char*)(dir ? q.f1 : q.f2) + (long)pr * hw * rowb;
+                const int* ix = q.idx + (long)t.p * kcap + t.tm * 128;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = (lw * 4 + i) * 8 + (lane >> 3);
+                    asrc[i] = Ab + (long)ix[row] * rowb + (((lane & 7) ^ swz(row)) * 16);      // ROWS: gathered (the list is padded with valid indices)
+                    wsrc[i] = Wb + (long)min(t.tn * 128 + cv_nperm64(row), hw - 1) * rowb + (((lane & 7) ^ swz(row)) * 16);
+                }
+                const int e = lw * 64 + lane, which = e >> 7;
+                const int idx = which ? min(t.tn * 128 + (e & 127), hw - 1) : ix[e & 127];
+                ssrc = (const char*)(q.stats + (((long)pr * 2 + (which ? 1 - dir : dir)) * hw + idx) * 4);
+                // the tile's 256 row / column statistics: first (oldest) piece of the step, parity buffer of the tile
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ssrc,
+                                                 (__attribute__((address_space(3))) void*)(smem + CVP_STAT_OFF + (it_i & 1) * 4096 + lw * 1024),
+                                                 16, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + (long)k_i * 128),
+                                                 (__attribute__((address_space(3))) void*)(sA + (lw * 4 + i) * 1024), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + (long)k_i * 128),
+                                                 (__attribute__((address_space(3))) void*)(sB + (lw * 4 + i) * 1024), 16, 0, 0);
+            if (++k_i == nk) { k_i = 0; ++it_i; }
+        };
+        // previous tile's partial sums: LDS (written by the compute waves before the barrier just passed) -> slabs
+        const uintptr_t p1 = (uintptr_t)q.part1, p2 = (uintptr_t)q.part2;
+        auto flush = [&](int it) {
+            const CvpTile t = rtile(beg + kb + it * nbx);
+            const unsigned pb = smem_base + CVP_PART_OFF + (it & 1) * 6144;
+            const int e = lw * 64 + lane;          // 0..127 rows, 128..255 columns
+            // one code path for both halves (a pointer picked by a per-lane branch became a vector load from the kernel
+            // argument block + s_waitcnt vmcnt(0): it drained the loader's DMA ring once per tile)
+            const bool isrow = e < 128;
+            const int c = e & 127;
+            const unsigned zo = isrow ? c : 512 + c, bo = isrow ? 256 + c : 1024 + c;
+            float Z = cvp_lds_f32(pb + zo * 4) + cvp_lds_f32(pb + (zo + 128) * 4);
+            float B = cvp_lds_f32(pb + bo * 4) + cvp_lds_f32(pb + (bo + 128) * 4);
+            const float Z2 = cvp_lds_f32(pb + (512 + 256 + c) * 4) + cvp_lds_f32(pb + (512 + 384 + c) * 4);
+            const float B2 = cvp_lds_f32(pb + (1024 + 256 + c) * 4) + cvp_lds_f32(pb + (1024 + 384 + c) * 4);
+            (void)Z2; (void)B2; (void)p2;
+            // ROWS: row partials only, in the compacted row space [pd][column tile][kcap]
+            if (isrow)          // explicitly a GLOBAL store: a flat store is out of order with respect to vmcnt
+                *(__attribute__((address_space(1))) f32x2*)(p1 + ((((long)t.p * tiles + t.tn) * kcap + t.tm * 128 + c) * 2) * sizeof(float)) = f32x2{Z, B};
+        };
+        for (int n = 0; n < 3 && n < n_total; ++n) issue(n);
+        int kk = 0, it = 0;
+        for (int n = 0; n < n_total; ++n) {
+            const int rem = n_total - 1 - n;
+            // every operation older than the two youngest steps (8 DMA pieces each) has landed: step n is in LDS
+            if (rem >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (rem == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (n + 3 < n_total) issue(n + 3);
+            if (kk == 0 && it > 0) flush(it - 1);
+            if (++kk == nk) { kk = 0; ++it; }
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        flush(n_tiles - 1);
+        return;
+    }
+
+    // ======================================= COMPUTE waves =======================================
+    const int wm = wave >> 1, wn = wave & 1, g = lane >> 4, c = lane & 15;
+    typedef typename Mma<T>::Frag Frag;
+    const int sa = swz(c);
+    const int abase = (wm * 32 + c) * 128, bbase = 128 * 128 + (wn * 64 + c) * 128;
+    // this lane's columns of the tile: cl(jb) = wn*64 + 4c + jb (see cv_nperm64); its rows: wm*32 + ib*16 + 4g + r
+    f32x4 t1v[2][4];         // direction 1: T1[row = tm*128 + wm*32 + ib*16 + 4g + r][col = tn*128 + wn*64 + 4c .. +3]   ([ib][r], element jb)
+    // branch-free: every address is clamped into the pair's map (rows / columns past hw re-read valid entries; the
+    // epilogue multiplies them by a zeroed s), so the 16 loads of a tile go out back to back with no wait between them
+    auto prefetch = [&](int it) {      // ROWS: direction-d teacher rows of the tile's kept rows (all needed: no mask tests), nothing for the columns
+        const CvpTile t = rtile(beg + kb + it * nbx);
+        const int pr = t.p >> 1, dir = t.p & 1;
+        const float* T1 = (dir ? q.t2 : q.t1) + (long)pr * hw * ldt;
+        const int* ix = q.idx + (long)t.p * kcap + t.tm * 128 + wm * 32 + 4 * g;
+        const int col0 = min(t.tn * 128 + wn * 64 + 4 * c, ldt - 4);          // ldt % 4 == 0: aligned, inside the row
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t1v[ib][r] = *(const f32x4*)(T1 + (long)ix[ib * 16 + r] * ldt + col0);
+    };
+    const int dbg = DBG ? q.dbg : 0;     // diagnostics (GD_CV_DBG): 1 = no teacher loads, 2 = no epilogue math, 4 = no MFMAs
+    if (dbg & 1) {
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) t1v[ib][jb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else prefetch(0);
+    int n = 0;
+    for (int it = 0; it < n_tiles; ++it) {
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < nk; ++k, ++n) {
+            cvp_barrier();
+            const char* sb = smem + (n & (CVP_SLOTS - 1)) * CVP_STAGE;
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) {
+                const int co = (((kc * 4 + g) ^ sa) * 16);
+                Frag a[2], b[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) b[t] = *(const Frag*)(sb + bbase + t * 2048 + co);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) a[t] = *(const Frag*)(sb + abase + t * 2048 + co);
+                if (!(dbg & 4)) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(a[i], b[j], acc[i][j]);
+                } else acc[0][0][0] += (float)a[0][0] + (float)b[0][0] + (float)a[1][0] + (float)b[1][0] + (float)b[2][0] + (float)b[3][0];
+            }
+        }
+        if (dbg & 2) {
+            if (it + 1 < n_tiles && !(dbg & 1)) prefetch(it + 1);
+            if (acc[0][0][0] == 12345.678f) ((float*)smem)[tid] = acc[1][1][1] + t1v[0][0][0];
+            continue;
+        }
+        // ---------------- epilogue, all from registers ----------------
+        const CvpTile t = rtile(beg + kb + it * nbx);
+        const f32x4* sSt = (const f32x4*)(smem + CVP_STAT_OFF + (it & 1) * 4096);
+        float* sP = (float*)(smem + CVP_PART_OFF + (it & 1) * 6144);
+        float inv2[4];
+        bool cok[4];
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+            const int cl = wn * 64 + 4 * c + jb;
+            inv2[jb] = sSt[128 + cl][0];
+            cok[jb] = t.tn * 128 + cl < hw;
+        }
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rl = wm * 32 + ib * 16 + 4 * g + r;
+                const f32x4 v = sSt[rl];
+                const float inv1 = v[0], ir1 = 1.0f / v[1];
+                const bool rok = true;      // (rows past the kept count are padded copies of a kept row: finite, never read by the finalize pass)
+                float zr = 0.f, b1 = 0.f;
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb) {
+                    const bool ok = rok && cok[jb];
+                    const float sv = acc[ib][jb][r] * inv1 * inv2[jb];
+                    const float e = ok ? __expf(sv) : 0.f;
+                    const float sm = ok ? sv : 0.f;
+                    zr += e;
+                    b1 = fmaf(fmaxf(t1v[ib][r][jb] * ir1, CV_EPS), sm, b1);
+                }
+                zr = row16_sum(zr);
+                b1 = row16_sum(b1);
+                if (c == 0) { sP[wn * 128 + rl] = zr; sP[256 + wn * 128 + rl] = b1; }
+            }
+        if (it + 1 < n_tiles && !(dbg & 1)) prefetch(it + 1);
+    }
+    cvp_barrier();
+}
+
+
+// kept rows of one (pair, direction) in ascending order -> idx[pd][0 .. cnt), the rest of the kcap entries padded with the last kept row (row 0
+// when nothing is kept); cnt[pd] = min(kept, kcap).  One block per (pair, direction).
+__global__ __launch_bounds__(256) void cv_rows_compact_kernel(const unsigned char* m1, const unsigned char* m2, int* idx, int* cnt, int hw, int kcap) {
+    __shared__ int sc[256];
+    const int pd = blockIdx.x, tid = threadIdx.x;
+    const unsigned char* m = ((pd & 1) ? m2 : m1) + (long)(pd >> 1) * hw;
+    const int per = (hw + 255) / 256, r0 = tid * per, r1 = min(hw, r0 + per);
+    int n = 0;
+    for (int r = r0; r < r1; ++r) n += m[r] != 0;
+    sc[tid] = n;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {      // inclusive scan
+        const int v = tid >= o ? sc[tid - o] : 0;
+        __syncthreads();
+        sc[tid] += v;
+        __syncthreads();
+    }
+    const int total = sc[255];
+    int pos = sc[tid] - n;
+    int* out = idx + (long)pd * kcap;
+    int last = -1;
+    for (int r = r0; r < r1; ++r)
+        if (m[r] != 0) { if (pos < kcap) out[pos] = r; ++pos; last = r; }
+    __shared__ int slast;
+    if (tid == 0) slast = 0;
+    __syncthreads();
+    if (last >= 0) atomicMax(&slast, last);
+    __syncthreads();
+    const int kept = min(total, kcap);
+    for (int e = kept + tid; e < kcap; e += 256) out[e] = slast;
+    if (tid == 0) cnt[pd] = kept;
+}
+
+// finalize of the kept-row form: Z, B summed over the column tiles per kept row, logZ / W saved at the row's ORIGINAL index for the backward,
+// per-chunk partial losses (fixed order: deterministic); masked-out rows contribute their constant (hw - kept of them per direction)
+__global__ __launch_bounds__(256) void cv_finalize_rows_kernel(const float* part, const float* tstats, const int* idx, const int* cnt, float* stats,
+                                                               double* chunk_loss, int hw, int tiles, int kcap, int variant) {
+    const int p = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
+    const float masked_const = variant == 1 ? (float)hw * (CV_EPS * logf(CV_EPS * (float)hw)) : 0.f;
+    double total = 0.0;
+    const int per = (2 * kcap + CV_FCH - 1) / CV_FCH;
+    for (int e = ch * per + tid; e < min(2 * kcap, (ch + 1) * per); e += 256) {
+        const int d = e >= kcap, kk = d ? e - kcap : e, pd = p * 2 + d;
+        if (kk >= cnt[pd]) continue;
+        const int row = idx[(long)pd * kcap + kk];
+        float Z = 0.f, B = 0.f;
+        for (int sidx = 0; sidx < tiles; ++sidx) {
+            const f32x2 v = *(const f32x2*)(part + (((long)pd * tiles + sidx) * kcap + kk) * 2);
+            Z += v[0]; B += v[1];
+        }
+        const float Wt = tstats[((long)pd * hw + row) * 4 + 1], A = tstats[((long)pd * hw + row) * 4 + 2];
+        const float logZ = logf(Z);
+        float* st = stats + ((long)pd * hw + row) * 4;
+        st[2] = logZ;
+        st[3] = Wt;
+        total += (double)(A - B + Wt * logZ);
+    }
+    if (ch == 0 && tid < 2) total += (double)masked_const * (double)(hw - cnt[p * 2 + tid]);
+    __shared__ double red[256];
+    red[tid] = total;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) chunk_loss[p * CV_FCH + ch] = red[0];
+}
+
 // reduce the slabs, save logZ and W for the backward, emit per-chunk partial losses (CV_FCH chunks per pair), then sum
-#define CV_FCH 8
 __global__ __launch_bounds__(256) void cv_finalize_kernel(const float* part1, const float* part2, const float* tstats,
                                                           const unsigned char* m1, const unsigned char* m2,
                                                           float* stats, double* chunk_loss, int hw, int nslab, int variant) {
@@ -975,6 +1262,55 @@ extern "C" int gd_cost_volume_kl_bwd_h(const float* f1, const float* f2, const v
                            nullptr, nullptr, nullptr, 0, nullptr, 0, 0, nullptr, 0, 0, nullptr, 0, 0, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(cv_norm_bwd_kernel<float>, dim3(gd_cdiv(hw, 4), 2, P), dim3(256), 0, s, f1, f2, da, db, stats, df1, df2, hw, C);
+    GD_LAUNCH_OK();
+    return 0;
+}
+
+// ---- kept-row forward (sparse row masks).  kcap: a multiple of 128 >= the number of kept rows of any (pair, view) — the MASt3R trainer's masks keep at
+// most N_kp patches (src/finetune_timm_mast3r.py:515-519).  Needs the rows' inverse norms (the ..._prenorm contract) and the cached teacher statistics.
+extern "C" size_t gd_cost_volume_kl_rows_workspace_bytes(int P, int hw, int kcap) {
+    return align256((size_t)P * 2 * cv_tiles(hw) * kcap * 2 * sizeof(float)) + align256((size_t)P * CV_FCH * sizeof(double)) +
+           align256((size_t)P * 2 * kcap * sizeof(int)) + align256((size_t)P * 2 * sizeof(int));
+}
+extern "C" int gd_cost_volume_kl_fwd_rows(const void* f1, const void* f2, const float* inv_norm1, const float* inv_norm2, const float* t1, const float* t2,
+                                          int ldt, const float* tstats, const unsigned char* m1, const unsigned char* m2, int P, int hw, int C, int kcap,
+                                          int variant, int dtype, float* loss, float* stats, void* workspace, void* stream) {
+    GD_REQUIRE(P > 0 && hw > 0 && C > 0 && ldt >= hw && kcap > 0 && kcap % 128 == 0, "gd_cost_volume_kl_fwd_rows: bad shape P=%d hw=%d C=%d ldt=%d kcap=%d", P, hw, C, ldt, kcap);
+    GD_REQUIRE(variant == 0 || variant == 1, "gd_cost_volume_kl_fwd_rows: variant must be 0 (vggt) or 1 (mast3r)");
+    GD_REQUIRE(dtype == GD_F32 || dtype == GD_BF16 || dtype == GD_F16, "gd_cost_volume_kl_fwd_rows: bad dtype %d", dtype);
+    GD_REQUIRE(inv_norm1 && inv_norm2 && tstats && m1 && m2, "gd_cost_volume_kl_fwd_rows: inverse row norms, teacher statistics and both masks are required");
+    GD_REQUIRE((double)hw * 7.3890561 * CV_EPS < 1.0, "gd_cost_volume_kl_fwd_rows: hw too large for the clamp-free softmax");
+    const long rowb = (long)C * gd_dtype_size(dtype);
+    GD_REQUIRE(rowb % 128 == 0 && rowb / 128 >= 3 && ldt % 4 == 0 && ((uintptr_t)t1 & 15) == 0 && ((uintptr_t)t2 & 15) == 0 &&
+                   ((uintptr_t)f1 & 15) == 0 && ((uintptr_t)f2 & 15) == 0 && ((uintptr_t)stats & 15) == 0 && ((uintptr_t)workspace & 15) == 0,
+               "gd_cost_volume_kl_fwd_rows: rows of C*elsize %% 128 == 0 bytes (>= 384), teacher rows padded to 16 bytes, 16-byte aligned pointers");
+    hipStream_t s = (hipStream_t)stream;
+    const int tiles = cv_tiles(hw);
+    char* w = (char*)workspace;
+    float* part = (float*)w; w += align256((size_t)P * 2 * tiles * kcap * 2 * sizeof(float));
+    double* chunk_loss = (double*)w; w += align256((size_t)P * CV_FCH * sizeof(double));
+    int* idx = (int*)w; w += align256((size_t)P * 2 * kcap * sizeof(int));
+    int* cnt = (int*)w;
+    const long n = 2L * P * hw;
+    hipLaunchKernelGGL(cv_stats_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, inv_norm1, inv_norm2, tstats, stats, hw, n);
+    hipLaunchKernelGGL(cv_rows_compact_kernel, dim3(2 * P), dim3(256), 0, s, m1, m2, idx, cnt, hw, kcap);
+    CvTileParams q = {};
+    q.f1 = f1; q.f2 = f2; q.t1 = t1; q.t2 = t2; q.stats = stats; q.part1 = part; q.part2 = part;
+    q.hw = hw; q.C = C; q.tiles = tiles; q.nslab = tiles; q.ldt = ldt; q.P = P; q.idx = idx; q.kcap = kcap;
+    int ncu = 256;
+    if (gd_knobs().ncu >= 8) ncu = gd_knobs().ncu / 8 * 8;
+    const long total = (long)P * 2 * (kcap / 128) * tiles;
+    int grid = (int)(total < ncu ? (total + 7) / 8 * 8 : ncu);
+    if (gd_knobs().cv_grid) {
+        const int gv = gd_knobs().cv_grid / 8 * 8;
+        if (gv >= 8 && gv < grid) grid = gv;
+    }
+    if (dtype == GD_BF16) hipLaunchKernelGGL(cv_fwd_rows_kernel<bf16>, dim3(grid), dim3(768), 0, s, q);
+    else if (dtype == GD_F16) hipLaunchKernelGGL(cv_fwd_rows_kernel<f16>, dim3(grid), dim3(768), 0, s, q);
+    else hipLaunchKernelGGL(cv_fwd_rows_kernel<float>, dim3(grid), dim3(768), 0, s, q);
+    GD_LAUNCH_OK();
+    hipLaunchKernelGGL(cv_finalize_rows_kernel, dim3(P, CV_FCH), dim3(256), 0, s, part, tstats, idx, cnt, stats, chunk_loss, hw, tiles, kcap, variant);
+    hipLaunchKernelGGL(cv_loss_kernel, dim3(gd_cdiv(P, 64)), dim3(64), 0, s, chunk_loss, loss, P, hw);
     GD_LAUNCH_OK();
     return 0;
 }

@@ -372,15 +372,17 @@ class FinetuneGD(nn.Module):
         fc = self.get_feature_cost(rgbs, with_norm=True)
         f, inv, f16 = fc if len(fc) == 3 else (fc[0], fc[1], None)
         ph, pw = h // self.resize_patch_size, w // self.resize_patch_size
+        kmax = None
         if self.variant == "mast3r" or mask_1 is None:
             m1 = ops.patch_mask(kp_1, h, w, self.patch_size)
             m2 = ops.patch_mask(kp_2, h, w, self.patch_size)
+            kmax = max(kp_1.shape[1], kp_2.shape[1])        # a keypoint marks one patch: at most this many rows are kept per view
         else:
             m1 = F.interpolate(mask_1[:, None].float(), size=(ph, pw), mode="nearest").reshape(P, -1) > 0
             m2 = F.interpolate(mask_2[:, None].float(), size=(ph, pw), mode="nearest").reshape(P, -1) > 0
         f1, f2 = ops.split_pairs(f, P)
         return ops.cost_volume_kl(f1, f2, cost_1, cost_2, m1, m2, self.variant, tstats=cost_tstats, inv_norms=(inv[:P], inv[P:]),
-                                  x3=getattr(self.model, "opfmt", ""), h16=None if f16 is None else (f16[:P], f16[P:]))
+                                  x3=getattr(self.model, "opfmt", ""), h16=None if f16 is None else (f16[:P], f16[P:]), kept_rows_max=kmax)
 
     def calculate_matching_loss(self, rgbs, kp_1, kp_2, pts3d_1, pts3d_2, counts=None):
         """src/finetune_timm_vggt.py:536-574 / src/finetune_timm_mast3r.py:543-589.  pts3d_k [P,N,3] are the

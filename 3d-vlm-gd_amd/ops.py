@@ -231,7 +231,7 @@ def cost_volume_teacher_stats(t1, t2):
 
 class _CostVolumeKL(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, f1, f2, t1, t2, m1, m2, variant, tstats, inv1=None, inv2=None, x3=False, h16=None):
+    def forward(ctx, f1, f2, t1, t2, m1, m2, variant, tstats, inv1=None, inv2=None, x3=False, h16=None, kcap=0):
         P, hw, C = f1.shape
         f1, f2 = f1.contiguous(), f2.contiguous()
         t1, t2 = t1.contiguous().float(), t2.contiguous().float()
@@ -249,6 +249,16 @@ class _CostVolumeKL(torch.autograd.Function):
             _req(inv1.shape == (P, hw) and inv2.shape == (P, hw) and inv1.dtype == torch.float32 and inv2.dtype == torch.float32 and
                  inv1.is_contiguous() and inv2.is_contiguous(), "cost_volume_kl: inv_norms must be two contiguous fp32 [P, hw] tensors")
             ctx.h16 = None
+            rows = kcap > 0 and tstats is not None and ldt % 4 == 0      # sparse row masks: the kept-row kernel (gd_cost_volume_kl_fwd_rows)
+
+            def fwd(fa, fb, cc, code):
+                if rows and (cc * (2 if code else 4)) % 128 == 0 and cc * (2 if code else 4) >= 384:
+                    wsr = torch.empty(lib().gd_cost_volume_kl_rows_workspace_bytes(P, hw, kcap), dtype=torch.uint8, device=f1.device)
+                    return lib().gd_cost_volume_kl_fwd_rows(ptr(fa), ptr(fb), ptr(inv1), ptr(inv2), ptr(t1), ptr(t2), ldt, ptr(tstats), ptr(m1), ptr(m2),
+                                                            P, hw, cc, kcap, VARIANTS[variant], code, ptr(loss), ptr(stats), ptr(wsr), stream())
+                wsd = torch.empty(lib().gd_cost_volume_kl_workspace_bytes(P, hw, cc, code, 0), dtype=torch.uint8, device=f1.device)
+                return lib().gd_cost_volume_kl_fwd_prenorm(ptr(fa), ptr(fb), ptr(inv1), ptr(inv2), ptr(t1), ptr(t2), ldt, ptr(tstats), ptr(m1), ptr(m2),
+                                                           P, hw, cc, VARIANTS[variant], code, ptr(loss), ptr(stats), ptr(wsd), stream())
             if x3 == "h" and f1.dtype == torch.float32 and C % 8 == 0:
                 # tf32h: S from the fp16 copies of the features (TF32's significand); the backward recomputes S from the SAME copies (kept)
                 if h16 is not None:
@@ -256,9 +266,7 @@ class _CostVolumeKL(torch.autograd.Function):
                     _req(a16.dtype == torch.float16 and a16.shape == f1.shape and b16.shape == f2.shape, "cost_volume_kl: h16 must be the fp16 copies of f1, f2")
                 else:
                     a16, b16 = cast16(f1.view(P * hw, C)), cast16(f2.view(P * hw, C))
-                ws = torch.empty(lib().gd_cost_volume_kl_workspace_bytes(P, hw, C, 3, 0), dtype=torch.uint8, device=f1.device)
-                rc = lib().gd_cost_volume_kl_fwd_prenorm(ptr(a16), ptr(b16), ptr(inv1), ptr(inv2), ptr(t1), ptr(t2), ldt, ptr(tstats), ptr(m1),
-                                                         ptr(m2), P, hw, C, VARIANTS[variant], 3, ptr(loss), ptr(stats), ptr(ws), stream())
+                rc = fwd(a16, b16, C, 3)
                 ctx.h16 = (a16, b16)
             elif x3 and f1.dtype == torch.float32 and C % 8 == 0:
                 # tf32x: S = f1 . f2^T as three bf16 MFMA products of the (hi, lo) splits on the bf16 tile kernel (K = 3C) instead of the
@@ -269,8 +277,7 @@ class _CostVolumeKL(torch.autograd.Function):
                 rc = lib().gd_cost_volume_kl_fwd_prenorm(ptr(a3), ptr(b3), ptr(inv1), ptr(inv2), ptr(t1), ptr(t2), ldt, ptr(tstats), ptr(m1),
                                                          ptr(m2), P, hw, 3 * C, VARIANTS[variant], 1, ptr(loss), ptr(stats), ptr(ws), stream())
             else:
-                rc = lib().gd_cost_volume_kl_fwd_prenorm(ptr(f1), ptr(f2), ptr(inv1), ptr(inv2), ptr(t1), ptr(t2), ldt, ptr(tstats), ptr(m1),
-                                                         ptr(m2), P, hw, C, VARIANTS[variant], dt, ptr(loss), ptr(stats), ptr(ws), stream())
+                rc = fwd(f1, f2, C, dt)
         else:
             rc = lib().gd_cost_volume_kl_fwd(ptr(f1), ptr(f2), ptr(t1), ptr(t2), ldt, ptr(tstats), ptr(m1), ptr(m2), P, hw, C,
                                              VARIANTS[variant], dt, ptr(loss), ptr(stats), ptr(ws), stream())
@@ -290,7 +297,7 @@ class _CostVolumeKL(torch.autograd.Function):
             rc = lib().gd_cost_volume_kl_bwd_h(ptr(f1), ptr(f2), ptr(a16), ptr(b16), ptr(t1), ptr(t2), t1.shape[-1], ptr(m1), ptr(m2), P, hw, C,
                                                ptr(g), ptr(stats), ptr(dfull[:P]), ptr(dfull[P:]), ptr(ws), stream())
             check(rc, "gd_cost_volume_kl_bwd_h")
-            return dfull[:P], dfull[P:], None, None, None, None, None, None, None, None, None, None
+            return dfull[:P], dfull[P:], None, None, None, None, None, None, None, None, None, None, None
         dt = dtype_code(f1)
         # the two halves of ONE buffer: split_pairs' backward hands it on without a concatenation pass (134 MB at the step's size)
         dfull = torch.empty((2 * P, hw, C), dtype=f1.dtype, device=f1.device)
@@ -300,19 +307,26 @@ class _CostVolumeKL(torch.autograd.Function):
         rc = lib().gd_cost_volume_kl_bwd(ptr(f1), ptr(f2), ptr(t1), ptr(t2), t1.shape[-1], ptr(m1), ptr(m2), P, hw, C, dt, ptr(g),
                                          ptr(stats), ptr(df1), ptr(df2), ptr(ws), stream())
         check(rc, "gd_cost_volume_kl_bwd")
-        return df1, df2, None, None, None, None, None, None, None, None, None, None
+        return df1, df2, None, None, None, None, None, None, None, None, None, None, None
 
 
-def cost_volume_kl(f1, f2, t1, t2, m1, m2, variant="vggt", tstats=None, inv_norms=None, x3=False, h16=None):
+def cost_volume_kl(f1, f2, t1, t2, m1, m2, variant="vggt", tstats=None, inv_norms=None, x3=False, h16=None, kept_rows_max=None):
     """Fused dense cost-volume KL for P pairs.  f1,f2 [P,hw,C] raw student features (f32|bf16); t1,t2 [P,hw,ldt] teacher
     maps (f32; ldt = hw, or hw padded to a multiple of 4 by `pad_teacher_maps`: the fast path); m1,m2 [P,hw] bool row
     masks; tstats: `cost_volume_teacher_stats(t1, t2)` computed once per cached pair (None: recomputed here, one more pass
     over the maps); inv_norms = (inv1, inv2), fp32 [P, hw] each: 1 / max(||row||, 1e-12) of the feature rows as stored, when their
     producer already took them (`tap_mean(..., with_norm=True)`) — the op then skips its own pass over the features
     x3 (fp32 features with inv_norms): the forward's similarity matrix as a split-precision bf16 product (tf32x engine)
+    kept_rows_max (with inv_norms and tstats): a bound on the number of kept rows of any (pair, view) — e.g. the keypoint count behind keypoint-patch
+    masks; when it is below half of hw the forward runs as two compacted row problems (gd_cost_volume_kl_fwd_rows) instead of one hw x hw sweep
     -> loss [P] (f32)."""
     if inv_norms is not None:
-        return _CostVolumeKL.apply(f1, f2, t1, t2, m1, m2, variant, tstats, inv_norms[0].detach(), inv_norms[1].detach(), x3, h16)
+        hw = f1.shape[1]
+        kcap = 0
+        if kept_rows_max is not None and tstats is not None:      # sparse row masks: the caller's bound on kept rows per (pair, view)
+            kc = (min(int(kept_rows_max), hw) + 127) // 128 * 128
+            kcap = kc if 2 * kc <= hw else 0                      # (above half the rows the two compacted problems cost more than one dense sweep)
+        return _CostVolumeKL.apply(f1, f2, t1, t2, m1, m2, variant, tstats, inv_norms[0].detach(), inv_norms[1].detach(), x3, h16, kcap)
     return _CostVolumeKL.apply(f1, f2, t1, t2, m1, m2, variant, tstats)
 
 

@@ -367,8 +367,8 @@ def cost_volume_roofline(job, args, dev, variant):
     # as the step calls it: the inverse row norms come with the features from their producer (ops.tap_mean(with_norm=True))
     inv = (1.0 / f1.detach().float().norm(dim=-1).clamp_min(1e-12), 1.0 / f2.detach().float().norm(dim=-1).clamp_min(1e-12))
 
-    def timed(ma, mb, backward=False, own_norm=False):
-        kw = dict(tstats=b["cost_tstats"]) if own_norm else dict(tstats=b["cost_tstats"], inv_norms=inv, x3=fmt, h16=h16)
+    def timed(ma, mb, backward=False, own_norm=False, kmax=None):
+        kw = dict(tstats=b["cost_tstats"]) if own_norm else dict(tstats=b["cost_tstats"], inv_norms=inv, x3=fmt, h16=h16, kept_rows_max=kmax)
 
         def fwd():
             with torch.no_grad():
@@ -386,8 +386,8 @@ def cost_volume_roofline(job, args, dev, variant):
                 return json.load(fh)["fwd_hbm_bytes_per_launch"], f"profiles/{name} (FETCH_SIZE / WRITE_SIZE, separate --pmc passes, width-corrected; NOT measured in this run)"
         return None, None
 
-    def leg(ma, mb, pmc_file):
-        t = timed(ma, mb)
+    def leg(ma, mb, pmc_file, kmax=None):
+        t = timed(ma, mb, kmax=kmax)
         kept = int(ma.sum()) + int(mb.sum())
         needed = feat_bytes + kept * hw * 4
         traffic, src = replay(pmc_file) if pmc_file else (None, None)
@@ -396,11 +396,15 @@ def cost_volume_roofline(job, args, dev, variant):
                 "frac": round(needed / t / 1e9 / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_replayed_from": src,
                 "traffic_over_needed": round(traffic / needed, 3) if traffic else None}, t
     ones = torch.ones(P, hw, dtype=torch.bool, device=dev)
-    bench_masks, tf = leg(m1, m2, "r03_pmc_cost_volume_traffic_kp.json" if variant == "mast3r" else None)
+    # keypoint-patch masks keep at most N_kp rows per view: the trainer (finetune.calculate_cost_loss) passes that bound and the op runs its kept-row form
+    kmax = int(b["kp_1"].shape[1]) if variant == "mast3r" else None
+    bench_masks, tf = leg(m1, m2, None, kmax=kmax)
     unmasked, tfu = leg(ones, ones, "r03_pmc_cost_volume_traffic_full.json")
-    tfb = timed(m1, m2, backward=True)
+    tfb = timed(m1, m2, backward=True, kmax=kmax)
     tfbu = timed(ones, ones, backward=True)
-    out = {"kernel": "cost_volume_kl fwd (contraction + both softmax-KL directions in one persistent kernel; feature row norms from the producer, teacher-row statistics cached per pair)",
+    out = {"kernel": "cost_volume_kl fwd (persistent MFMA contraction + softmax-KL; sparse keypoint masks: both directions as compacted kept-row problems, "
+                     "gd_cost_volume_kl_fwd_rows; dense masks / `unmasked`: one hw x hw sweep serving both directions; row norms from the producer, teacher-row "
+                     "statistics cached per pair)",
            "bound": "hbm", "peak": PEAK_HBM_GBS, "unit": "GB/s",
            "masks": "keypoint-patch masks of the benched batch" if variant == "mast3r" else "co-view masks of the benched batch",
            "frac_definition": "bytes the launch must move (features + KEPT teacher rows + masks) / time / peak: skipped rows earn nothing"}

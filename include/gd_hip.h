@@ -278,6 +278,13 @@ int gd_cast_f16(const float* in, void* out, long rows, int K, long ld_in, float 
 /* Cost-volume KL of the tf32h engine: gd_cost_volume_kl_fwd_prenorm takes dtype GD_F16 (fp16 copies of the fp32 features, the fp32 rows' norms);
  * the backward recomputes S from the same fp16 copies, writes G = dloss/dS as fp16 under a power-of-two scale taken from `gloss` on the device,
  * contracts it on the fp16 MFMA kernels and takes the gradient through the L2 normalisation in fp32 on the fp32 features (df1, df2 fp32). */
+/* Kept-row forward for SPARSE row masks (the MASt3R trainer's keypoint-patch masks keep at most N_kp of the hw rows): both directions as compacted row
+ * problems — kept rows of one view (gathered) against all rows of the other — instead of one hw x hw sweep; same loss and saved statistics as
+ * gd_cost_volume_kl_fwd_prenorm.  kcap: a multiple of 128, >= the number of kept rows of any (pair, view). */
+size_t gd_cost_volume_kl_rows_workspace_bytes(int P, int hw, int kcap);
+int gd_cost_volume_kl_fwd_rows(const void* f1, const void* f2, const float* inv_norm1, const float* inv_norm2, const float* t1, const float* t2, int ldt,
+                               const float* tstats, const unsigned char* m1, const unsigned char* m2, int P, int hw, int C, int kcap, int variant,
+                               int dtype, float* loss, float* stats, void* workspace, void* stream);
 size_t gd_cost_volume_kl_bwd_h_workspace_bytes(int P, int hw, int C);
 int gd_cost_volume_kl_bwd_h(const float* f1, const float* f2, const void* f1h, const void* f2h, const float* t1, const float* t2, int ldt,
                             const unsigned char* m1, const unsigned char* m2, int P, int hw, int C, const float* gloss, const float* stats,

@@ -211,3 +211,44 @@ def test_fp16_operand_forward_and_backward(variant):
     loss = ops.cost_volume_kl(f1, f2, c1, c2, m1, m2, variant, tstats=ts, inv_norms=(inv1, inv2), x3="h")
     (loss * 0.0).sum().backward()
     assert float(f1.grad.abs().max()) == 0.0 and bool(torch.isfinite(f2.grad).all())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("variant", ["mast3r", "vggt"])
+def test_kept_row_forward_matches_the_dense_sweep(dtype, variant):
+    """cost_volume_kl(kept_rows_max=...) with sparse row masks (keypoint-patch masks: <= N_kp rows kept per view): both directions as compacted row
+    problems (gd_cost_volume_kl_fwd_rows) — same loss as the hw x hw sweep to fp32 summation order, same gradients (the backward reads the saved
+    logZ / W of the kept rows), the fp64 oracle within the dtype's tolerance; ragged kept counts per pair and view, one view of one pair with NO kept row."""
+    from gd_amd import ops
+    P, hw, C = 3, 1369, 256
+    gen = torch.Generator(device="cuda").manual_seed(17)
+    f1 = torch.randn(P, hw, C, generator=gen, device="cuda").to(dtype).requires_grad_(True)
+    f2 = torch.randn(P, hw, C, generator=gen, device="cuda").to(dtype).requires_grad_(True)
+    t1 = torch.softmax(3 * torch.randn(P, hw, hw, generator=gen, device="cuda"), -1)
+    t2 = torch.softmax(3 * torch.randn(P, hw, hw, generator=gen, device="cuda"), -1)
+    m1 = torch.zeros(P, hw, dtype=torch.bool, device="cuda")
+    m2 = torch.zeros(P, hw, dtype=torch.bool, device="cuda")
+    for p, (k1, k2) in enumerate([(300, 211), (129, 0), (7, 256)]):
+        m1[p, torch.randperm(hw, generator=gen, device="cuda")[:k1]] = True
+        m2[p, torch.randperm(hw, generator=gen, device="cuda")[:k2]] = True
+    c1, c2, ts = _teacher("cached", t1, t2)
+    inv1 = 1.0 / f1.detach().float().norm(dim=-1).clamp_min(1e-12)
+    inv2 = 1.0 / f2.detach().float().norm(dim=-1).clamp_min(1e-12)
+    dense = ops.cost_volume_kl(f1, f2, c1, c2, m1, m2, variant, tstats=ts, inv_norms=(inv1, inv2))
+    dense.sum().backward()
+    g1, g2 = f1.grad.clone(), f2.grad.clone()
+    f1.grad = f2.grad = None
+    rows = ops.cost_volume_kl(f1, f2, c1, c2, m1, m2, variant, tstats=ts, inv_norms=(inv1, inv2), kept_rows_max=300)
+    rows.sum().backward()
+    assert rel_err(rows, dense) < 1e-6
+    assert rel_err(f1.grad, g1) < (1e-5 if dtype == torch.float32 else 2e-2) and rel_err(f2.grad, g2) < (1e-5 if dtype == torch.float32 else 2e-2)
+    ol, og1, og2 = _oracle(f1.detach().float(), f2.detach().float(), t1, t2, m1, m2, variant)
+    assert rel_err(rows, ol) < (1e-5 if dtype == torch.float32 else 1e-3)
+    # few persistent blocks: every block walks many tiles
+    from gd_amd._lib import lib
+    lib().gd_debug_set(b"cv_grid", 8)
+    try:
+        again = ops.cost_volume_kl(f1, f2, c1, c2, m1, m2, variant, tstats=ts, inv_norms=(inv1, inv2), kept_rows_max=300)
+    finally:
+        lib().gd_debug_set(b"cv_grid", 0)
+    assert torch.equal(again, rows)
