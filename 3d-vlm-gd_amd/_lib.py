@@ -33,6 +33,9 @@ SIGNATURES = {
     "gd_cost_volume_kl_rows_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gd_cost_volume_kl_fwd_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                            c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gd_cost_volume_kl_bwd_rows_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "gd_cost_volume_kl_bwd_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
+                                           c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gd_cost_volume_kl_bwd_h_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gd_cost_volume_kl_bwd_h": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

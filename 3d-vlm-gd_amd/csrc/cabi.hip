@@ -21,7 +21,7 @@ struct KnobDef { const char* name; const char* env; int GdKnobs::*field; int def
 static const KnobDef KNOBS[] = {
     {"gemm_persist", "GD_GEMM_PERSIST", &GdKnobs::gemm_persist, 1},       {"gemm_small_tiles", "GD_GEMM_SMALL_TILES", &GdKnobs::gemm_small_tiles, 0},
     {"gemm_f32_big", "GD_GEMM_F32_BIG", &GdKnobs::gemm_f32_big, 0},       {"gemm_cstore", "GD_GEMM_CSTORE", &GdKnobs::gemm_cstore, 1},
-    {"gemm_anat", "GD_GEMM_ANAT", &GdKnobs::gemm_anat, 0},
+    {"gemm_anat", "GD_GEMM_ANAT", &GdKnobs::gemm_anat, 0},                {"gemm_batch_big_m", "GD_GEMM_BATCH_BIG_M", &GdKnobs::gemm_batch_big_m, 384},
     {"gemm_krot", "GD_GEMM_KROT", &GdKnobs::gemm_krot, 1},                {"tn_blocks", "GD_TN_BLOCKS", &GdKnobs::tn_blocks, 0},
     {"attn_dma", "GD_ATTN_DMA", &GdKnobs::attn_dma, 1},                   {"attn_rot", "GD_ATTN_ROT", &GdKnobs::attn_rot, 1},
     {"attn_dkv_nw", "GD_ATTN_DKV_NW", &GdKnobs::attn_dkv_nw, 0},          {"cv_mask_skip", "GD_CV_MASK_SKIP", &GdKnobs::cv_mask_skip, 1},

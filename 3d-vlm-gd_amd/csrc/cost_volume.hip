@@ -129,6 +129,7 @@ struct CvTileParams {
     const unsigned char* m1; const unsigned char* m2; const float* gloss;
     void* G1; void* G2; int hwp;
     const int* idx; int kcap;   // kept-row form (cv_fwd_rows_kernel): [P][2][kcap] kept-row indices (padded with a kept index), kcap % 128 == 0
+    const void* fc; const int* cnt;      // kept-row backward (cv_bwd_rows_kernel): compacted kept feature rows [2][P][kcap][C], kept counts [P][2]
     const float* gscale;      // fp16 G (tf32h engine): device scalar s multiplied into G before it is rounded; the GEMMs that contract G undo it
 };
 
@@ -1016,28 +1017,191 @@ __global__ __launch_bounds__(256, 2) void cv_bwd_tile_kernel(CvTileParams q) {
     }
 }
 
-// out[p][c][j] = in[p][j][c] for j < hw, 0 for hw <= j < hwp   (tile transpose through LDS)
+// ---- kept-row backward (sparse row masks): the two directions as separate compacted row problems, like cv_fwd_rows_kernel.  Block (tm, tn) of
+//      (direction d, pair p) recomputes S_c = A_kept B^T for 128 kept rows x 128 columns (A_kept: the gathered feature rows q.fc, B: the other
+//      view's features), forms G = dloss/dS_c and stores Gc[k][j] = G inv_B[j] ([kcap][hwp]) and GcT[j][k] = G inv_A[k] ([hw][kcap]): two batched
+//      NT GEMMs per direction contract them with the other view's features (-> kept rows of this view's gradient, scattered by cv_rows_scatter)
+//      and with the kept rows (-> the other view's gradient, dense).  Rows k >= cnt and columns j >= hw are written as zeros. ----
 template <typename T>
-__global__ __launch_bounds__(256) void cv_transpose_kernel(const T* f1, const T* f2, T* o1, T* o2, int hw, int hwp,
-                                                           int C) {
-    __shared__ float tile[32][33];
-    const int p = blockIdx.z >> 1, which = blockIdx.z & 1;
-    const T* in = (which ? f2 : f1) + (long)p * hw * C;
-    T* out = (which ? o2 : o1) + (long)p * C * hwp;
-    const int j0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int k = ty; k < 32; k += 8) {
-        const int j = j0 + k, cc = c0 + tx;
-        tile[k][tx] = (j < hw && cc < C) ? to_f32<T>(in[(long)j * C + cc]) : 0.f;
+__global__ __launch_bounds__(256, 2) void cv_bwd_rows_kernel(CvTileParams q) {
+    __shared__ __attribute__((aligned(16))) char smem[CV_RING + 4096];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, g = lane >> 4, c = lane & 15;
+    const int hw = q.hw, hwp = q.hwp, kcap = q.kcap, ldt = q.ldt;
+    const int pdl = blockIdx.y, d = pdl / q.P, p = pdl - d * q.P;      // Gc / GcT / fc are laid out [direction][pair]; idx / cnt / stats [pair][direction]
+    const int tiles_r = kcap / 128;
+    const int wg = xcd_remap(blockIdx.x, tiles_r * q.tiles);
+    const int tm = wg / q.tiles, tn = wg % q.tiles;
+    const int* ix = q.idx + ((long)p * 2 + d) * kcap;
+    const int cntk = q.cnt[p * 2 + d];
+    T* Gc = (T*)q.G1 + (long)pdl * kcap * hwp;
+    T* GcT = (T*)q.G2 + (long)pdl * hw * kcap;
+    if (tm * 128 >= cntk) {      // nothing kept in this row tile: its slice of GcT is contracted against (duplicated) kept rows and has to be zero
+        for (int e = tid; e < 128 * 128; e += 256) {
+            const int col = tn * 128 + (e >> 7), kk = tm * 128 + (e & 127);
+            if (col < hw) GcT[(long)col * kcap + kk] = from_f32<T>(0.f);
+        }
+        return;
     }
-    __syncthreads();
-    for (int k = ty; k < 32; k += 8) {
-        const int cc = c0 + k, j = j0 + tx;
-        if (cc < C && j < hwp) out[(long)cc * hwp + j] = from_f32<T>(tile[tx][k]);
+    const float* Tt = (d ? q.t2 : q.t1) + (long)p * hw * ldt;
+    f32x4* sSt = (f32x4*)(smem + CV_RING);
+    {
+        const int which = tid >> 7, t = tid & 127;
+        f32x4 o = {0.f, 0.f, 0.f, -1.f};
+        if (which == 0) {
+            const int kk = tm * 128 + t;
+            const f32x4 v = *(const f32x4*)(q.stats + (((long)p * 2 + d) * hw + ix[kk]) * 4);
+            o = f32x4{v[0], 1.0f / v[1], v[2], kk < cntk ? v[3] : -1.f};
+        } else {
+            const int j = tn * 128 + t;
+            if (j < hw) o = f32x4{q.stats[(((long)p * 2 + (1 - d)) * hw + j) * 4], 0.f, 0.f, 0.f};
+        }
+        sSt[tid] = o;
+    }
+    float t1v[2][32];   // teacher values of both halves: in flight under the main loop
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {   // tile row wave+4k (a kept row: its teacher row is ix[...]), column = 64h + lane
+        const int kk = tm * 128 + wave + 4 * k;
+        const long ro = (long)ix[kk] * ldt;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int col = tn * 128 + 64 * h + lane;
+            t1v[h][k] = (kk < cntk && col < hw) ? Tt[ro + col] : 0.f;
+        }
+    }
+    f32x4 acc[4][4];
+    {
+        const long rowb = (long)q.C * sizeof(T);
+        const char* Ab = (const char*)q.fc + (long)pdl * kcap * rowb;
+        const char* Wb = (const char*)(d ? q.f1 : q.f2) + (long)p * hw * rowb;
+        if (rowb % 128 == 0) dma_mainloop<T, 2, 2, 4>(Ab, rowb, kcap, Wb, rowb, hw, (int)(rowb / 128), tm, tn, smem, acc);
+        else mma_tile_128x128<T>(Ab, rowb, kcap, Wb, rowb, hw, (int)rowb, tm, tn, smem, acc);
+        float invc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) invc[j] = sSt[128 + wn * 64 + j * 16 + c][0];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float invr = sSt[wm * 64 + i * 16 + g * 4 + r][0];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j][r] *= invr * invc[j];
+            }
+    }
+    float* sS = (float*)smem;            // [128][64]
+    float* sG = (float*)smem + 128 * 64; // [128][64]
+    const float coef = q.gloss[p] * 0.5f / (float)hw * (q.gscale ? q.gscale[0] : 1.0f);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (wn == h) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sS[sidx(wm * 64 + i * 16 + g * 4 + r, j * 16 + c, 64)] = acc[i][j][r];
+        }
+        const int col0 = tn * 128 + 64 * h;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {      // lane = column
+            const int rr = wave + 4 * k;
+            const f32x4 v = sSt[rr];
+            float term = 0.f;
+            if (v[3] >= 0.f && col0 + lane < hw)
+                term = (v[3] * __expf(sS[sidx(rr, lane, 64)] - v[2]) - fmaxf(t1v[h][k] * v[1], CV_EPS)) * coef;
+            sG[sidx(rr, lane, 64)] = term;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {      // GcT rows (lane = tile row: contiguous k)
+            const int jl = wave + 4 * k, col = col0 + jl;
+            if (col < hw) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int il = lane + 64 * e;
+                    GcT[(long)col * kcap + tm * 128 + il] = from_f32<T>(sG[sidx(il, jl, 64)] * sSt[il][0]);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {      // Gc rows (lane = column)
+            const int rr = wave + 4 * k, col = col0 + lane;
+            if (col < hwp) Gc[(long)(tm * 128 + rr) * hwp + col] = from_f32<T>(sG[sidx(rr, lane, 64)] * sSt[128 + 64 * h + lane][0]);
+        }
+        __syncthreads();
     }
 }
 
-// da = inv*dah - a * inv^3 * (a . dah)   (gradient through x / max(||x||, 1e-12))
+// kept feature rows of both views, gathered: fc[d][p][k][:] = f_d[p][idx[p][d][k]][:]   (16 bytes per thread)
+__global__ __launch_bounds__(256) void cv_rows_gather_kernel(const char* f1, const char* f2, const int* idx, char* fc, int P, int hw, int kcap, int rowb) {
+    const int v16 = rowb / 16;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;      // (d, p, k, chunk)
+    if (i >= 2L * P * kcap * v16) return;
+    const int ch = (int)(i % v16);
+    const long r = i / v16;
+    const int k = (int)(r % kcap), dp = (int)(r / kcap), d = dp / P, p = dp - d * P;
+    const int row = idx[((long)p * 2 + d) * kcap + k];
+    *(f32x4*)(fc + r * rowb + ch * 16L) = *(const f32x4*)((d ? f2 : f1) + ((long)p * hw + row) * rowb + ch * 16L);
+}
+
+// the kept rows' gradients added at their original rows: d_d[p][idx[p][d][k]][:] += dk[d][p][k][:] for k < cnt   (distinct rows: no atomics)
+__global__ __launch_bounds__(256) void cv_rows_scatter_kernel(const float* dk, const int* idx, const int* cnt, float* d1, float* d2, int P, int hw,
+                                                              int kcap, int C) {
+    const int v4 = C / 4;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2L * P * kcap * v4) return;
+    const int ch = (int)(i % v4);
+    const long r = i / v4;
+    const int k = (int)(r % kcap), dp = (int)(r / kcap), d = dp / P, p = dp - d * P;
+    if (k >= cnt[p * 2 + d]) return;
+    const int row = idx[((long)p * 2 + d) * kcap + k];
+    f32x4* o = (f32x4*)((d ? d2 : d1) + ((long)p * hw + row) * C) + ch;
+    const f32x4 a = *o, b = *((const f32x4*)(dk + r * C) + ch);
+    *o = f32x4{a[0] + b[0], a[1] + b[1], a[2] + b[2], a[3] + b[3]};
+}
+
+// out[p][c][j] = in[p][j][c] for j < hw, 0 for hw <= j < hwp   (64 x 64 tile transpose through LDS: 16-byte loads along c, 16-byte stores along j;
+// needs C*sizeof(T) % 16 == 0 and hwp % 64 == 0 — cv_hwp gives that — and 16-byte aligned bases)
+template <typename T>
+__global__ __launch_bounds__(256) void cv_transpose_kernel(const T* f1, const T* f2, T* o1, T* o2, int hw, int hwp, int C) {
+    constexpr int VE = 16 / (int)sizeof(T), VPR = 64 / VE, LDR = 64 + VE;      // elements per vector, vectors per tile row, padded LDS row (16-byte aligned)
+    typedef T vec_t __attribute__((ext_vector_type(VE)));
+    __shared__ __attribute__((aligned(16))) T tile[64 * LDR];      // [c][j]
+    const int p = blockIdx.z >> 1, which = blockIdx.z & 1;
+    const T* in = (which ? f2 : f1) + (long)p * hw * C;
+    T* out = (which ? o2 : o1) + (long)p * C * hwp;
+    const int j0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+#pragma unroll
+    for (int v = threadIdx.x; v < 64 * VPR; v += 256) {
+        const int j = j0 + v / VPR, cc = c0 + (v % VPR) * VE;
+        vec_t x;
+#pragma unroll
+        for (int e = 0; e < VE; ++e) x[e] = (T)0.f;
+        if (j < hw && cc < C) x = *(const vec_t*)(in + (long)j * C + cc);      // (C % VE == 0: a vector is inside the row or outside it)
+#pragma unroll
+        for (int e = 0; e < VE; ++e) tile[((v % VPR) * VE + e) * LDR + v / VPR] = x[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int v = threadIdx.x; v < 64 * VPR; v += 256) {
+        const int cc = c0 + v / VPR, j = j0 + (v % VPR) * VE;
+        if (cc < C && j < hwp) *(vec_t*)(out + (long)cc * hwp + j) = *(const vec_t*)(tile + (v / VPR) * LDR + (v % VPR) * VE);
+    }
+}
+
+// da = inv*dah - a * inv^3 * (a . dah)   (gradient through x / max(||x||, 1e-12)); one wave per row, the row held in registers between the dot
+// product and the output when C <= 1024 (one pass over memory)
+template <typename T> __device__ __forceinline__ f32x4 cv_ldv4(const T* p);
+template <> __device__ __forceinline__ f32x4 cv_ldv4<float>(const float* p) { return *(const f32x4*)p; }
+template <> __device__ __forceinline__ f32x4 cv_ldv4<bf16>(const bf16* p) {
+    const bf16x4 v = *(const bf16x4*)p;
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+template <typename T> __device__ __forceinline__ void cv_stv4(T* p, f32x4 v);
+template <> __device__ __forceinline__ void cv_stv4<float>(float* p, f32x4 v) { *(f32x4*)p = v; }
+template <> __device__ __forceinline__ void cv_stv4<bf16>(bf16* p, f32x4 v) { *(bf16x4*)p = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]}; }
+
 template <typename T>
 __global__ __launch_bounds__(256) void cv_norm_bwd_kernel(const T* f1, const T* f2, const float* d1, const float* d2,
                                                           const float* stats, T* o1, T* o2, int hw, int C) {
@@ -1049,6 +1213,29 @@ __global__ __launch_bounds__(256) void cv_norm_bwd_kernel(const T* f1, const T* 
     const float* dh = (which ? d2 : d1) + off;
     T* o = (which ? o2 : o1) + off;
     const float inv = stats[(((long)p * 2 + which) * hw + row) * 4];
+    constexpr int NV = 4;
+    if (C % 4 == 0 && C <= 256 * NV) {
+        f32x4 av[NV], dv[NV];
+        float dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int c = (lane + 64 * k) * 4;
+            if (c < C) {
+                av[k] = cv_ldv4<T>(a + c);
+                dv[k] = *(const f32x4*)(dh + c);
+                dot += av[k][0] * dv[k][0] + av[k][1] * dv[k][1] + av[k][2] * dv[k][2] + av[k][3] * dv[k][3];
+            }
+        }
+        dot = wave_sum(dot);
+        const float kk = inv * inv * inv * dot;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int c = (lane + 64 * k) * 4;
+            if (c < C) cv_stv4<T>(o + c, f32x4{inv * dv[k][0] - av[k][0] * kk, inv * dv[k][1] - av[k][1] * kk, inv * dv[k][2] - av[k][2] * kk,
+                                              inv * dv[k][3] - av[k][3] * kk});
+        }
+        return;
+    }
     float dot = 0.f;
     for (int c = lane; c < C; c += 64) dot += to_f32<T>(a[c]) * dh[c];
     dot = wave_sum(dot);
@@ -1178,7 +1365,7 @@ extern "C" int gd_cost_volume_kl_bwd(const void* f1, const void* f2, const float
     CvTileParams q = {};
     q.f1 = f1; q.f2 = f2; q.t1 = t1; q.t2 = t2; q.stats = (float*)stats; q.hw = hw; q.C = C; q.tiles = tiles;
     q.m1 = m1; q.m2 = m2; q.gloss = gloss; q.G1 = G1; q.G2 = G2; q.hwp = hwp; q.ldt = ldt; q.P = P;
-    dim3 tgrid(gd_cdiv(hwp, 32), gd_cdiv(C, 32), 2 * P);
+    dim3 tgrid(hwp / 64, gd_cdiv(C, 64), 2 * P);
     if (dtype == GD_BF16) {
         hipLaunchKernelGGL(cv_bwd_tile_kernel<bf16>, dim3(tiles * tiles, P), dim3(256), 0, s, q);
         hipLaunchKernelGGL(cv_transpose_kernel<bf16>, tgrid, dim3(256), 0, s, (const bf16*)f1, (const bf16*)f2,
@@ -1251,7 +1438,7 @@ extern "C" int gd_cost_volume_kl_bwd_h(const float* f1, const float* f2, const v
     CvTileParams q = {};
     q.f1 = f1h; q.f2 = f2h; q.t1 = t1; q.t2 = t2; q.stats = (float*)stats; q.hw = hw; q.C = C; q.tiles = tiles;
     q.m1 = m1; q.m2 = m2; q.gloss = gloss; q.G1 = G1; q.G2 = G2; q.hwp = hwp; q.ldt = ldt; q.P = P; q.gscale = gs;
-    dim3 tgrid(gd_cdiv(hwp, 32), gd_cdiv(C, 32), 2 * P);
+    dim3 tgrid(hwp / 64, gd_cdiv(C, 64), 2 * P);
     hipLaunchKernelGGL(cv_bwd_tile_kernel<f16>, dim3(tiles * tiles, P), dim3(256), 0, s, q);
     hipLaunchKernelGGL(cv_transpose_kernel<f16>, tgrid, dim3(256), 0, s, (const f16*)f1h, (const f16*)f2h, (f16*)at, (f16*)bt, hw, hwp, C);
     GD_LAUNCH_OK();
@@ -1311,6 +1498,89 @@ extern "C" int gd_cost_volume_kl_fwd_rows(const void* f1, const void* f2, const 
     GD_LAUNCH_OK();
     hipLaunchKernelGGL(cv_finalize_rows_kernel, dim3(P, CV_FCH), dim3(256), 0, s, part, tstats, idx, cnt, stats, chunk_loss, hw, tiles, kcap, variant);
     hipLaunchKernelGGL(cv_loss_kernel, dim3(gd_cdiv(P, 64)), dim3(64), 0, s, chunk_loss, loss, P, hw);
+    GD_LAUNCH_OK();
+    return 0;
+}
+
+// ---- kept-row backward.  dtype GD_F32 / GD_BF16: f1, f2 (and df1, df2) in that type, f1h = f2h = null.  dtype GD_F16 (tf32h engine): f1, f2 fp32,
+// f1h, f2h their fp16 copies (S, G and the four contractions run on those, G under the device-side scale of gd_cost_volume_kl_bwd_h), df1, df2 fp32.
+// `stats` as saved by either forward (logZ and W sit at the rows' original indices).
+extern "C" size_t gd_cost_volume_kl_bwd_rows_workspace_bytes(int P, int hw, int C, int kcap, int dtype) {
+    const size_t es = (size_t)gd_dtype_size(dtype), hwp = (size_t)cv_hwp(hw);
+    return align256((size_t)2 * P * kcap * hwp * es) + align256((size_t)2 * P * hw * kcap * es) + align256((size_t)2 * P * C * hwp * es) +
+           2 * align256((size_t)2 * P * kcap * C * es) + align256((size_t)2 * P * kcap * C * sizeof(float)) +
+           align256((size_t)2 * P * hw * C * sizeof(float)) + align256((size_t)P * 2 * kcap * sizeof(int)) + align256((size_t)P * 2 * sizeof(int)) + 256;
+}
+
+template <typename T>
+static void cv_bwd_rows_launch(const CvTileParams& q, const void* fa, const void* fb, void* fc, void* fct, void* at, void* bt, hipStream_t s) {
+    const int P = q.P, hw = q.hw, C = q.C, kcap = q.kcap, hwp = q.hwp, rowb = C * (int)sizeof(T);
+    const long ng = 2L * P * kcap * (rowb / 16);
+    hipLaunchKernelGGL(cv_rows_gather_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, s, (const char*)fa, (const char*)fb, q.idx, (char*)fc,
+                       P, hw, kcap, rowb);
+    hipLaunchKernelGGL(cv_bwd_rows_kernel<T>, dim3(kcap / 128 * q.tiles, 2 * P), dim3(256), 0, s, q);
+    hipLaunchKernelGGL(cv_transpose_kernel<T>, dim3(hwp / 64, gd_cdiv(C, 64), 2 * P), dim3(256), 0, s, (const T*)fa, (const T*)fb, (T*)at, (T*)bt,
+                       hw, hwp, C);
+    hipLaunchKernelGGL(cv_transpose_kernel<T>, dim3(kcap / 64, gd_cdiv(C, 64), 2 * P), dim3(256), 0, s, (const T*)fc, (const T*)fc + (long)P * kcap * C,
+                       (T*)fct, (T*)fct + (long)P * C * kcap, kcap, kcap, C);
+}
+
+extern "C" int gd_cost_volume_kl_bwd_rows(const void* f1, const void* f2, const void* f1h, const void* f2h, const float* t1, const float* t2, int ldt,
+                                          const unsigned char* m1, const unsigned char* m2, int P, int hw, int C, int kcap, int dtype,
+                                          const float* gloss, const float* stats, void* df1, void* df2, void* workspace, void* stream) {
+    GD_REQUIRE(P > 0 && hw > 0 && C > 0 && ldt >= hw && kcap > 0 && kcap % 128 == 0, "gd_cost_volume_kl_bwd_rows: bad shape P=%d hw=%d C=%d ldt=%d kcap=%d", P, hw, C, ldt, kcap);
+    GD_REQUIRE(dtype == GD_F32 || dtype == GD_BF16 || dtype == GD_F16, "gd_cost_volume_kl_bwd_rows: bad dtype %d", dtype);
+    GD_REQUIRE(m1 && m2, "gd_cost_volume_kl_bwd_rows: both masks are required");
+    GD_REQUIRE((dtype == GD_F16) == (f1h != nullptr && f2h != nullptr), "gd_cost_volume_kl_bwd_rows: fp16 feature copies go with dtype GD_F16 and only with it");
+    const size_t es = (size_t)gd_dtype_size(dtype);
+    GD_REQUIRE((C * es) % 16 == 0 && C % 4 == 0, "gd_cost_volume_kl_bwd_rows: C*elsize must be a multiple of 16 B");
+    hipStream_t s = (hipStream_t)stream;
+    const int tiles = cv_tiles(hw), hwp = cv_hwp(hw);
+    // every [direction][pair] array is one contiguous batch of 2P problems: direction 0 = kept rows of view 1 against view 2, direction 1 the reverse
+    char* w = (char*)workspace;
+    void* Gc = w; w += align256((size_t)2 * P * kcap * hwp * es);
+    void* GcT = w; w += align256((size_t)2 * P * hw * kcap * es);
+    void* tb = w; w += align256((size_t)2 * P * C * hwp * es);      // transposed features of the OTHER view: [0] = view 2, [1] = view 1
+    void* fc = w; w += align256((size_t)2 * P * kcap * C * es);
+    void* fct = w; w += align256((size_t)2 * P * kcap * C * es);
+    float* dk = (float*)w; w += align256((size_t)2 * P * kcap * C * sizeof(float));
+    float* dd = (float*)w; w += align256((size_t)2 * P * hw * C * sizeof(float));      // gradients of the OTHER view's normalised rows: [0] = view 2, [1] = view 1
+    int* idx = (int*)w; w += align256((size_t)P * 2 * kcap * sizeof(int));
+    int* cnt = (int*)w; w += align256((size_t)P * 2 * sizeof(int));
+    float* gs = (float*)w;
+    float* db = dd;
+    float* da = dd + (long)P * hw * C;
+    void* bt = tb;
+    void* at = (char*)tb + (size_t)P * C * hwp * es;
+    const void* fa = dtype == GD_F16 ? f1h : f1;
+    const void* fb = dtype == GD_F16 ? f2h : f2;
+    hipLaunchKernelGGL(cv_rows_compact_kernel, dim3(2 * P), dim3(256), 0, s, m1, m2, idx, cnt, hw, kcap);
+    if (dtype == GD_F16) hipLaunchKernelGGL(cv_gscale_kernel, dim3(1), dim3(64), 0, s, gloss, P, hw, gs);
+    CvTileParams q = {};
+    q.f1 = fa; q.f2 = fb; q.fc = fc; q.t1 = t1; q.t2 = t2; q.stats = (float*)stats; q.hw = hw; q.C = C; q.tiles = tiles;
+    q.gloss = gloss; q.G1 = Gc; q.G2 = GcT; q.hwp = hwp; q.ldt = ldt; q.P = P; q.idx = idx; q.cnt = cnt; q.kcap = kcap;
+    q.gscale = dtype == GD_F16 ? gs : nullptr;
+    if (dtype == GD_BF16) cv_bwd_rows_launch<bf16>(q, fa, fb, fc, fct, at, bt, s);
+    else if (dtype == GD_F16) cv_bwd_rows_launch<f16>(q, fa, fb, fc, fct, at, bt, s);
+    else cv_bwd_rows_launch<float>(q, fa, fb, fc, fct, at, bt, s);
+    GD_LAUNCH_OK();
+    const float* adev = dtype == GD_F16 ? gs + 1 : nullptr;
+    // the other view's gradient, dense: d b_hat = GcT[0] a_kept ,  d a_hat = GcT[1] b_kept   (contraction over the kcap kept rows)
+    int rc = gd_gemm_nt_scaled(GcT, fct, dd, hw, C, kcap, kcap, kcap, C, 2 * P, (long)hw * kcap, (long)C * kcap, (long)hw * C, dtype, GD_F32, 1.0f, adev,
+                               nullptr, nullptr, nullptr, 0, nullptr, 0, 0, nullptr, 0, 0, nullptr, 0, 0, stream);
+    if (rc) return rc;
+    // this view's kept rows: d a_hat[kept] = Gc[0] b ,  d b_hat[kept] = Gc[1] a   (contraction over the padded hw axis)
+    rc = gd_gemm_nt_scaled(Gc, tb, dk, kcap, C, hwp, hwp, hwp, C, 2 * P, (long)kcap * hwp, (long)C * hwp, (long)kcap * C, dtype, GD_F32, 1.0f, adev,
+                           nullptr, nullptr, nullptr, 0, nullptr, 0, 0, nullptr, 0, 0, nullptr, 0, 0, stream);
+    if (rc) return rc;
+    const long nsc = 2L * P * kcap * (C / 4);
+    hipLaunchKernelGGL(cv_rows_scatter_kernel, dim3((unsigned)((nsc + 255) / 256)), dim3(256), 0, s, dk, idx, cnt, da, db, P, hw, kcap, C);
+    if (dtype == GD_BF16)
+        hipLaunchKernelGGL(cv_norm_bwd_kernel<bf16>, dim3(gd_cdiv(hw, 4), 2, P), dim3(256), 0, s, (const bf16*)f1, (const bf16*)f2, da, db, stats,
+                           (bf16*)df1, (bf16*)df2, hw, C);
+    else
+        hipLaunchKernelGGL(cv_norm_bwd_kernel<float>, dim3(gd_cdiv(hw, 4), 2, P), dim3(256), 0, s, (const float*)f1, (const float*)f2, da, db, stats,
+                           (float*)df1, (float*)df2, hw, C);
     GD_LAUNCH_OK();
     return 0;
 }

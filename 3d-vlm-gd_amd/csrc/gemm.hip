@@ -808,7 +808,7 @@ static int gemm_nt_impl(const void* A, const void* W, void* C, int M, int N, int
       p.c_policy = (cp && (long)256 * ldc * ccs < 0x7fffffffL && !accumulate) ? cp : 0; }
     p.probe = gd_probe_buffer();
     p.k_rot = gd_knobs().gemm_krot;
-    const bool big = dma && N >= 256 && M >= 1024 && !gd_force_small_tiles();
+    const bool big = dma && N >= 256 && M >= (batch > 1 ? gd_knobs().gemm_batch_big_m : 1024) && !gd_force_small_tiles();
     dim3 gridb(gd_cdiv(M, 256) * gd_cdiv(N, 256), batch);
     hipStream_t st = (hipStream_t)stream;
     const int persist = gd_knobs().gemm_persist, ncu = gd_knobs().ncu;

@@ -251,8 +251,11 @@ class _CostVolumeKL(torch.autograd.Function):
             ctx.h16 = None
             rows = kcap > 0 and tstats is not None and ldt % 4 == 0      # sparse row masks: the kept-row kernel (gd_cost_volume_kl_fwd_rows)
 
+            ctx.kcap = 0
+
             def fwd(fa, fb, cc, code):
                 if rows and (cc * (2 if code else 4)) % 128 == 0 and cc * (2 if code else 4) >= 384:
+                    ctx.kcap = kcap      # the backward takes the kept-row form too
                     wsr = torch.empty(lib().gd_cost_volume_kl_rows_workspace_bytes(P, hw, kcap), dtype=torch.uint8, device=f1.device)
                     return lib().gd_cost_volume_kl_fwd_rows(ptr(fa), ptr(fb), ptr(inv1), ptr(inv2), ptr(t1), ptr(t2), ldt, ptr(tstats), ptr(m1), ptr(m2),
                                                             P, hw, cc, kcap, VARIANTS[variant], code, ptr(loss), ptr(stats), ptr(wsr), stream())
@@ -289,6 +292,17 @@ class _CostVolumeKL(torch.autograd.Function):
     def backward(ctx, gloss):
         f1, f2, t1, t2, m1, m2, stats = ctx.saved_tensors
         P, hw, C = f1.shape
+        kcap = getattr(ctx, "kcap", 0)
+        if kcap and option("cv_bwd_rows"):      # sparse row masks: G only for the kept rows of each direction (gd_cost_volume_kl_bwd_rows)
+            h = getattr(ctx, "h16", None)
+            code = 3 if h is not None else dtype_code(f1)
+            dfull = torch.empty((2 * P, hw, C), dtype=f1.dtype, device=f1.device)
+            ws = torch.empty(lib().gd_cost_volume_kl_bwd_rows_workspace_bytes(P, hw, C, kcap, code), dtype=torch.uint8, device=f1.device)
+            g = gloss.contiguous().float()
+            rc = lib().gd_cost_volume_kl_bwd_rows(ptr(f1), ptr(f2), ptr(h[0]) if h else None, ptr(h[1]) if h else None, ptr(t1), ptr(t2), t1.shape[-1],
+                                                  ptr(m1), ptr(m2), P, hw, C, kcap, code, ptr(g), ptr(stats), ptr(dfull[:P]), ptr(dfull[P:]), ptr(ws), stream())
+            check(rc, "gd_cost_volume_kl_bwd_rows")
+            return dfull[:P], dfull[P:], None, None, None, None, None, None, None, None, None, None, None
         if getattr(ctx, "h16", None) is not None:      # tf32h: fp16 S recompute and G contractions, fp32 gradient through the normalisation
             a16, b16 = ctx.h16
             dfull = torch.empty((2 * P, hw, C), dtype=torch.float32, device=f1.device)

@@ -285,6 +285,15 @@ size_t gd_cost_volume_kl_rows_workspace_bytes(int P, int hw, int kcap);
 int gd_cost_volume_kl_fwd_rows(const void* f1, const void* f2, const float* inv_norm1, const float* inv_norm2, const float* t1, const float* t2, int ldt,
                                const float* tstats, const unsigned char* m1, const unsigned char* m2, int P, int hw, int C, int kcap, int variant,
                                int dtype, float* loss, float* stats, void* workspace, void* stream);
+/* Kept-row backward, the counterpart of gd_cost_volume_kl_fwd_rows (same masks, same kcap; `stats` as saved by either forward): G = dloss/dS only for
+ * the kept rows of each direction ([kcap, hw] and its transpose instead of two [hw, hw] matrices), four batched contractions (kept rows' gradients,
+ * scattered back to their rows; the other view's gradient, dense), then the gradient through the L2 normalisation.
+ * dtype GD_F32 | GD_BF16: f1, f2, df1, df2 in that type, f1h = f2h = NULL.  dtype GD_F16 (tf32h engine): f1, f2, df1, df2 fp32 and f1h, f2h the fp16
+ * copies the forward ran on (G under the device-side power-of-two scale of gd_cost_volume_kl_bwd_h). */
+size_t gd_cost_volume_kl_bwd_rows_workspace_bytes(int P, int hw, int C, int kcap, int dtype);
+int gd_cost_volume_kl_bwd_rows(const void* f1, const void* f2, const void* f1h, const void* f2h, const float* t1, const float* t2, int ldt,
+                               const unsigned char* m1, const unsigned char* m2, int P, int hw, int C, int kcap, int dtype, const float* gloss,
+                               const float* stats, void* df1, void* df2, void* workspace, void* stream);
 size_t gd_cost_volume_kl_bwd_h_workspace_bytes(int P, int hw, int C);
 int gd_cost_volume_kl_bwd_h(const float* f1, const float* f2, const void* f1h, const void* f2h, const float* t1, const float* t2, int ldt,
                             const unsigned char* m1, const unsigned char* m2, int P, int hw, int C, const float* gloss, const float* stats,

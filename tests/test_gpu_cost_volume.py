@@ -244,6 +244,21 @@ def test_kept_row_forward_matches_the_dense_sweep(dtype, variant):
     assert rel_err(f1.grad, g1) < (1e-5 if dtype == torch.float32 else 2e-2) and rel_err(f2.grad, g2) < (1e-5 if dtype == torch.float32 else 2e-2)
     ol, og1, og2 = _oracle(f1.detach().float(), f2.detach().float(), t1, t2, m1, m2, variant)
     assert rel_err(rows, ol) < (1e-5 if dtype == torch.float32 else 1e-3)
+    # the kept-row backward (gd_cost_volume_kl_bwd_rows: G for the kept rows of each direction only) against the fp64 oracle, and the dense backward
+    # behind the kept-row forward (GD_CV_BWD_ROWS=0) against both
+    gtol = 1e-4 if dtype == torch.float32 else 1e-2
+    assert rel_err(f1.grad, og1) < gtol and rel_err(f2.grad, og2) < gtol
+    assert float(f2.grad[1].abs().max()) > 0 and float(f1.grad[1].float().abs().max()) > 0      # pair 1: view 2 keeps nothing, view 1's direction still reaches both
+    from gd_amd.options import set_option
+    r1, r2 = f1.grad.clone(), f2.grad.clone()
+    f1.grad = f2.grad = None
+    old = set_option("cv_bwd_rows", 0)
+    try:
+        ops.cost_volume_kl(f1, f2, c1, c2, m1, m2, variant, tstats=ts, inv_norms=(inv1, inv2), kept_rows_max=300).sum().backward()
+    finally:
+        set_option("cv_bwd_rows", old)
+    dtol = 1e-5 if dtype == torch.float32 else 5e-3      # (logZ of the two forwards differs in fp32 summation order: bf16 G rounds differently)
+    assert rel_err(f1.grad, g1) < dtol and rel_err(f2.grad, g2) < dtol and rel_err(r1, f1.grad) < (1e-5 if dtype == torch.float32 else 2e-2)
     # few persistent blocks: every block walks many tiles
     from gd_amd._lib import lib
     lib().gd_debug_set(b"cv_grid", 8)
@@ -252,3 +267,44 @@ def test_kept_row_forward_matches_the_dense_sweep(dtype, variant):
     finally:
         lib().gd_debug_set(b"cv_grid", 0)
     assert torch.equal(again, rows)
+
+
+@pytest.mark.parametrize("variant", ["mast3r", "vggt"])
+def test_kept_row_backward_fp16_operands(variant):
+    """The tf32h engine's cost volume with sparse row masks at the step's shape (hw 1369, C 768, <= 384 kept rows): kept-row forward and kept-row
+    backward on the fp16 copies, G under the device-side scale — gradients within 2e-3 of the fp64 oracle and of the dense fp16 backward, pairs with
+    loss gradients three orders of magnitude apart under one scale, exact zeros for a zero loss gradient."""
+    from gd_amd import ops
+    P, hw, C = 2, 1369, 768
+    gen = torch.Generator(device="cuda").manual_seed(23)
+    f1 = torch.randn(P, hw, C, generator=gen, device="cuda").requires_grad_(True)
+    f2 = torch.randn(P, hw, C, generator=gen, device="cuda").requires_grad_(True)
+    t1 = torch.softmax(3 * torch.randn(P, hw, hw, generator=gen, device="cuda"), -1)
+    t2 = torch.softmax(3 * torch.randn(P, hw, hw, generator=gen, device="cuda"), -1)
+    m1 = torch.zeros(P, hw, dtype=torch.bool, device="cuda")
+    m2 = torch.zeros(P, hw, dtype=torch.bool, device="cuda")
+    for p, (k1, k2) in enumerate([(384, 257), (301, 128)]):
+        m1[p, torch.randperm(hw, generator=gen, device="cuda")[:k1]] = True
+        m2[p, torch.randperm(hw, generator=gen, device="cuda")[:k2]] = True
+    c1, c2, ts = _teacher("cached", t1, t2)
+    inv1 = 1.0 / f1.detach().norm(dim=-1).clamp_min(1e-12)
+    inv2 = 1.0 / f2.detach().norm(dim=-1).clamp_min(1e-12)
+    wv = torch.tensor([1.0, 1e-3], device="cuda")
+    dense = ops.cost_volume_kl(f1, f2, c1, c2, m1, m2, variant, tstats=ts, inv_norms=(inv1, inv2), x3="h")
+    (dense * wv).sum().backward()
+    d1, d2 = f1.grad.clone(), f2.grad.clone()
+    f1.grad = f2.grad = None
+    loss = ops.cost_volume_kl(f1, f2, c1, c2, m1, m2, variant, tstats=ts, inv_norms=(inv1, inv2), x3="h", kept_rows_max=384)
+    (loss * wv).sum().backward()
+    ol, og1, og2 = _oracle(f1.detach(), f2.detach(), t1, t2, m1, m2, variant)
+    assert rel_err(loss, ol) < 1e-4 and rel_err(loss, dense) < 1e-6
+    w = wv.double().cpu().view(P, 1, 1)
+    assert f1.grad.dtype == torch.float32 and bool(torch.isfinite(f1.grad).all())
+    for p in range(P):
+        tol = 2e-3 if p == 0 else 2e-2
+        assert rel_err(f1.grad[p], (og1 * w)[p]) < tol and rel_err(f2.grad[p], (og2 * w)[p]) < tol, p
+        assert rel_err(f1.grad[p], d1[p]) < tol and rel_err(f2.grad[p], d2[p]) < tol, p
+    f1.grad = f2.grad = None
+    loss = ops.cost_volume_kl(f1, f2, c1, c2, m1, m2, variant, tstats=ts, inv_norms=(inv1, inv2), x3="h", kept_rows_max=384)
+    (loss * 0.0).sum().backward()
+    assert float(f1.grad.abs().max()) == 0.0 and float(f2.grad.abs().max()) == 0.0
