@@ -411,7 +411,7 @@ def cost_volume_roofline(job, args, dev, variant):
     out.update(bench_masks)
     out["unmasked"] = dict(unmasked, algorithmic_bytes_per_launch_survey_8d=fwd_bytes,
                            fwd_bwd_GBps=round((fwd_bytes + bwd_bytes) / tfbu / 1e9, 1), us_per_pair_fwd_bwd=round(tfbu / P * 1e6, 2))
-    out["us_per_pair_fwd_bwd"] = round(tfb / P * 1e6, 2)
+    out["us_per_pair_fwd_bwd"] = round(tfb / P * 1e6, 2)      # (sparse keypoint masks: kept-row forward AND kept-row backward, gd_cost_volume_kl_bwd_rows)
     out["row_norms"] = ("from the feature producer (gd_tap_mean_norm_fwd -> gd_cost_volume_kl_fwd_prenorm), as in the step; with the op's own "
                         f"norm pass over the features: {timed(ones, ones, own_norm=True) / P * 1e6:.2f} us/pair unmasked")
     return out
