@@ -819,7 +819,8 @@ __global__ __launch_bounds__(768) void cv_fwd_rows_kernel(CvTileParams q) {
 
 
 // kept rows of one (pair, direction) in ascending order -> idx[pd][0 .. cnt), the rest of the kcap entries padded with the last kept row (row 0
-// when nothing is kept); cnt[pd] = min(kept, kcap).  One block per (pair, direction).
+// when nothing is kept); cnt[pd] = the number kept, or -1 when it EXCEEDS kcap (the caller's bound was wrong: the loss of that pair comes out NaN and so do
+// its gradients — never a silently truncated sum).  One block per (pair, direction).
 __global__ __launch_bounds__(256) void cv_rows_compact_kernel(const unsigned char* m1, const unsigned char* m2, int* idx, int* cnt, int hw, int kcap) {
     __shared__ int sc[256];
     const int pd = blockIdx.x, tid = threadIdx.x;
@@ -848,7 +849,7 @@ __global__ __launch_bounds__(256) void cv_rows_compact_kernel(const unsigned cha
     __syncthreads();
     const int kept = min(total, kcap);
     for (int e = kept + tid; e < kcap; e += 256) out[e] = slast;
-    if (tid == 0) cnt[pd] = kept;
+    if (tid == 0) cnt[pd] = total > kcap ? -1 : kept;
 }
 
 // finalize of the kept-row form: Z, B summed over the column tiles per kept row, logZ / W saved at the row's ORIGINAL index for the backward,
@@ -875,7 +876,10 @@ __global__ __launch_bounds__(256) void cv_finalize_rows_kernel(const float* part
         st[3] = Wt;
         total += (double)(A - B + Wt * logZ);
     }
-    if (ch == 0 && tid < 2) total += (double)masked_const * (double)(hw - cnt[p * 2 + tid]);
+    if (ch == 0 && tid < 2) {
+        const int c = cnt[p * 2 + tid];
+        total += c < 0 ? (double)__builtin_nanf("") : (double)masked_const * (double)(hw - c);      // more kept rows than the caller's bound: poisoned, not truncated
+    }
     __shared__ double red[256];
     red[tid] = total;
     __syncthreads();
@@ -1154,9 +1158,11 @@ __global__ __launch_bounds__(256) void cv_rows_scatter_kernel(const float* dk, c
     const int ch = (int)(i % v4);
     const long r = i / v4;
     const int k = (int)(r % kcap), dp = (int)(r / kcap), d = dp / P, p = dp - d * P;
-    if (k >= cnt[p * 2 + d]) return;
+    const int c = cnt[p * 2 + d];
     const int row = idx[((long)p * 2 + d) * kcap + k];
     f32x4* o = (f32x4*)((d ? d2 : d1) + ((long)p * hw + row) * C) + ch;
+    if (c < 0 && k == 0) { const float n = __builtin_nanf(""); *o = f32x4{n, n, n, n}; return; }      // bound exceeded: poison the pair's gradient
+    if (k >= c) return;
     const f32x4 a = *o, b = *((const f32x4*)(dk + r * C) + ch);
     *o = f32x4{a[0] + b[0], a[1] + b[1], a[2] + b[2], a[3] + b[3]};
 }

@@ -308,3 +308,28 @@ def test_kept_row_backward_fp16_operands(variant):
     loss = ops.cost_volume_kl(f1, f2, c1, c2, m1, m2, variant, tstats=ts, inv_norms=(inv1, inv2), x3="h", kept_rows_max=384)
     (loss * 0.0).sum().backward()
     assert float(f1.grad.abs().max()) == 0.0 and float(f2.grad.abs().max()) == 0.0
+
+
+def test_kept_row_bound_exceeded_is_loud():
+    """kept_rows_max is the caller's promise; a pair whose mask keeps MORE rows than the bound gets a NaN loss and NaN gradients (never a silently
+    truncated sum), the other pairs are unaffected."""
+    from gd_amd import ops
+    P, hw, C = 2, 1369, 256
+    gen = torch.Generator(device="cuda").manual_seed(29)
+    f1 = torch.randn(P, hw, C, generator=gen, device="cuda").requires_grad_(True)
+    f2 = torch.randn(P, hw, C, generator=gen, device="cuda").requires_grad_(True)
+    t1 = torch.softmax(3 * torch.randn(P, hw, hw, generator=gen, device="cuda"), -1)
+    t2 = torch.softmax(3 * torch.randn(P, hw, hw, generator=gen, device="cuda"), -1)
+    m1 = torch.zeros(P, hw, dtype=torch.bool, device="cuda")
+    m2 = torch.zeros(P, hw, dtype=torch.bool, device="cuda")
+    for p, (k1, k2) in enumerate([(100, 128), (129, 90)]):      # bound 100 -> kcap 128: pair 1 / view 1 keeps one row too many
+        m1[p, torch.randperm(hw, generator=gen, device="cuda")[:k1]] = True
+        m2[p, torch.randperm(hw, generator=gen, device="cuda")[:k2]] = True
+    c1, c2, ts = _teacher("cached", t1, t2)
+    inv1 = 1.0 / f1.detach().norm(dim=-1).clamp_min(1e-12)
+    inv2 = 1.0 / f2.detach().norm(dim=-1).clamp_min(1e-12)
+    dense = ops.cost_volume_kl(f1, f2, c1, c2, m1, m2, "mast3r", tstats=ts, inv_norms=(inv1, inv2))
+    loss = ops.cost_volume_kl(f1, f2, c1, c2, m1, m2, "mast3r", tstats=ts, inv_norms=(inv1, inv2), kept_rows_max=100)
+    assert rel_err(loss[0], dense[0]) < 1e-6 and bool(torch.isnan(loss[1]))
+    loss.sum().backward()
+    assert bool(torch.isfinite(f1.grad[0]).all()) and bool(torch.isnan(f1.grad[1]).any())
