@@ -1070,7 +1070,7 @@ __global__ __launch_bounds__(256, 2) void cv_bwd_rows_kernel(CvTileParams q) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int col = tn * 128 + 64 * h + lane;
-            t1v[h][k] = (kk < cntk && col < hw) ? Tt[ro + col] : 0.f;
+            t1v[h][k] = (kk < cntk && col < hw && !(q.dbg & 1)) ? Tt[ro + col] : 0.f;
         }
     }
     f32x4 acc[4][4];
@@ -1078,7 +1078,13 @@ __global__ __launch_bounds__(256, 2) void cv_bwd_rows_kernel(CvTileParams q) {
         const long rowb = (long)q.C * sizeof(T);
         const char* Ab = (const char*)q.fc + (long)pdl * kcap * rowb;
         const char* Wb = (const char*)(d ? q.f1 : q.f2) + (long)p * hw * rowb;
-        if (rowb % 128 == 0) dma_mainloop<T, 2, 2, 4>(Ab, rowb, kcap, Wb, rowb, hw, (int)(rowb / 128), tm, tn, smem, acc);
+        if (q.dbg & 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            __syncthreads();
+        } else if (rowb % 128 == 0) dma_mainloop<T, 2, 2, 4>(Ab, rowb, kcap, Wb, rowb, hw, (int)(rowb / 128), tm, tn, smem, acc);
         else mma_tile_128x128<T>(Ab, rowb, kcap, Wb, rowb, hw, (int)rowb, tm, tn, smem, acc);
         float invc[4];
 #pragma unroll
@@ -1112,7 +1118,7 @@ __global__ __launch_bounds__(256, 2) void cv_bwd_rows_kernel(CvTileParams q) {
             const int rr = wave + 4 * k;
             const f32x4 v = sSt[rr];
             float term = 0.f;
-            if (v[3] >= 0.f && col0 + lane < hw)
+            if (v[3] >= 0.f && col0 + lane < hw && !(q.dbg & 8))
                 term = (v[3] * __expf(sS[sidx(rr, lane, 64)] - v[2]) - fmaxf(t1v[h][k] * v[1], CV_EPS)) * coef;
             sG[sidx(rr, lane, 64)] = term;
         }
@@ -1120,7 +1126,7 @@ __global__ __launch_bounds__(256, 2) void cv_bwd_rows_kernel(CvTileParams q) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) {      // GcT rows (lane = tile row: contiguous k)
             const int jl = wave + 4 * k, col = col0 + jl;
-            if (col < hw) {
+            if (col < hw && !(q.dbg & 2)) {
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const int il = lane + 64 * e;
@@ -1131,7 +1137,7 @@ __global__ __launch_bounds__(256, 2) void cv_bwd_rows_kernel(CvTileParams q) {
 #pragma unroll
         for (int k = 0; k < 32; ++k) {      // Gc rows (lane = column)
             const int rr = wave + 4 * k, col = col0 + lane;
-            if (col < hwp) Gc[(long)(tm * 128 + rr) * hwp + col] = from_f32<T>(sG[sidx(rr, lane, 64)] * sSt[128 + 64 * h + lane][0]);
+            if (col < hwp && !(q.dbg & 2)) Gc[(long)(tm * 128 + rr) * hwp + col] = from_f32<T>(sG[sidx(rr, lane, 64)] * sSt[128 + 64 * h + lane][0]);
         }
         __syncthreads();
     }
@@ -1566,6 +1572,7 @@ extern "C" int gd_cost_volume_kl_bwd_rows(const void* f1, const void* f2, const 
     q.f1 = fa; q.f2 = fb; q.fc = fc; q.t1 = t1; q.t2 = t2; q.stats = (float*)stats; q.hw = hw; q.C = C; q.tiles = tiles;
     q.gloss = gloss; q.G1 = Gc; q.G2 = GcT; q.hwp = hwp; q.ldt = ldt; q.P = P; q.idx = idx; q.cnt = cnt; q.kcap = kcap;
     q.gscale = dtype == GD_F16 ? gs : nullptr;
+    q.dbg = gd_knobs().cv_dbg;      // anatomy switches (timing experiments only: results are wrong with any bit set)
     if (dtype == GD_BF16) cv_bwd_rows_launch<bf16>(q, fa, fb, fc, fct, at, bt, s);
     else if (dtype == GD_F16) cv_bwd_rows_launch<f16>(q, fa, fb, fc, fct, at, bt, s);
     else cv_bwd_rows_launch<float>(q, fa, fb, fc, fct, at, bt, s);
