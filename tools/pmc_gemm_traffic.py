@@ -25,8 +25,8 @@ w_mb = sum(write.values()) / nw / 1e3
 out = {"kernel": "gemm_nt_persist_kernel (all instantiations of the profiled steps)", "dispatches_fetch_pass": nf,
        "dispatches_write_pass": nw, "fetch_size_raw_mb_per_launch": round(f_mb, 1), "write_size_mb_per_launch": round(w_mb, 1),
        "hbm_side_mb_per_launch": round(2 * f_mb + w_mb, 1),
-       "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --steps 1 --warmup 1 --no-cpu-baseline "
-               "--no-kernel-events --no-extras`; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests of "
+       "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --steps 1 --warmup 1 --steps-only` "
+               "(tools/prof_r03.sh); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests of "
                "16-B-per-lane reads at 64 B), Infinity-Cache hits are counted"}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out))
