@@ -616,26 +616,32 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmTnParams p) {
 // gemm_tn for a SKINNY left operand (N <= 8, f32): the LoRA weight gradients  G[8, K] += T[M, 8]^T X[M, K].
 // HBM-bound (X is read once, 404 MB for the q/v LoRA of one block) and far too thin for MFMA tiles: the 64x64-tile
 // kernel above ran it at 1.6 TB/s.  Here a thread owns 8 consecutive columns of X (one 16-byte load per row) and all
-// 8 rows of G (64 fp32 accumulators); the T row is wave-uniform (scalar loads), rows are unrolled 8 deep so every wave
-// keeps 8 independent loads in flight; the block's partial is transposed through LDS once so the closing fp32 atomics
-// are lane-contiguous.
+// 8 rows of G (64 fp32 accumulators); the T row is wave-uniform (scalar loads); rows are unrolled U deep and held RAW
+// (16 bytes per row for the 16-bit types) until they are used.  A block is RG row groups of K/8 threads: each group
+// streams its own slice of the block's row chunk, the groups' partials are summed through LDS, and ONE set of fp32
+// atomics per block closes it.  With one group per block (rounds 1-2: 512 blocks of 2-5 waves) the kernel's time was
+// 39 us + bytes / 14 TB/s: a chain of 11 dependent groups of loads per wave at about one wave per SIMD, then 512 blocks'
+// worth of atomics onto the same 24-72 KB.  The row groups are there for the waves per SIMD (15-16 per CU, 8 KB in flight
+// each) and for FEWER closing atomics (one block per CU), not for the arithmetic.
+// <RG 8, NTK 128>: K <= 1024 (1024 threads);  <RG 3, NTK 320>: K <= 2560 (960 threads);  rows U = 8 deep (128 VGPRs).
 // ------------------------------------------------------------------------------------------
-template <typename TX>
-__global__ __launch_bounds__(320) void gemm_tn_skinny_kernel(GemmTnParams p) {
-    __shared__ float sG[320 * 8];   // one G row of the block at a time
-    const int tid = threadIdx.x, nth = blockDim.x, kc = tid * 8;
+template <typename TX, int RG, int U, int NTK>      // NTK: the largest row-group width (threads) this instantiation is launched with
+__global__ __launch_bounds__(RG * NTK) void gemm_tn_skinny_kernel(GemmTnParams p) {
+    __shared__ float sG[RG * NTK * 8];   // [row group][K slot]: one G row of the block at a time
+    const int nthk = blockDim.x / RG;                              // threads per row group: a multiple of 64, so a wave is inside one group
+    const int tid = threadIdx.x, rg = __builtin_amdgcn_readfirstlane(tid / nthk), kt = tid - rg * nthk, kc = kt * 8;
     const bool live = kc < p.K;
     const float* __restrict__ Y = (const float*)p.Y;
     const TX* __restrict__ X = (const TX*)p.X;
-    const int m_begin = blockIdx.y * p.mchunk, m_end = min(p.M, m_begin + p.mchunk);
+    const int per = p.mchunk / RG;                                 // (the host rounds mchunk to a multiple of RG * 16)
+    const int m_begin = blockIdx.y * p.mchunk + rg * per, m_end = min(p.M, m_begin + per);
     float acc[8][8];
 #pragma unroll
     for (int n = 0; n < 8; ++n)
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc[n][k] = 0.f;
-    constexpr int U = 8;
     const int kcl = live ? kc : 0;   // threads past K read column 0 (their results are never written): no divergent load
-    auto load_x = [&](int m, float (&x)[8]) {
+    auto load_x = [&](int m, float (&x)[8]) __attribute__((always_inline)) {
         if constexpr (std::is_same<TX, f16>::value) {
             const f16x8 v = *(const f16x8*)((const f16*)X + (long)m * p.ldx + kcl);
 #pragma unroll
@@ -651,19 +657,46 @@ __global__ __launch_bounds__(320) void gemm_tn_skinny_kernel(GemmTnParams p) {
         }
     };
     int m0 = m_begin;
-    for (; m0 + U <= m_end; m0 += U) {   // full groups: the 8 T rows are one contiguous, wave-uniform 256-byte block (scalar loads, no branches)
-        float x[U][8];
-#pragma unroll
-        for (int r = 0; r < U; ++r) load_x(m0 + r, x[r]);
+    for (; m0 + U <= m_end; m0 += U) {   // full groups: the U T rows are one contiguous, wave-uniform block (scalar loads, no branches)
         const float* __restrict__ trow = Y + (long)m0 * 8;
+        if constexpr (sizeof(TX) == 2) {
+            uint4 raw[U];
 #pragma unroll
-        for (int r = 0; r < U; ++r)
+            for (int r = 0; r < U; ++r) raw[r] = *(const uint4*)((const char*)X + ((long)(m0 + r) * p.ldx + kcl) * 2);
 #pragma unroll
-            for (int n = 0; n < 8; ++n) {
-                const float t = trow[r * 8 + n];
+            for (int r = 0; r < U; ++r) {
+                if (r == 8) __builtin_amdgcn_sched_barrier(0);      // (the T values of the second half are fetched after the first half's: 128 live SGPRs spill)
+                float x[8];
+                if constexpr (std::is_same<TX, f16>::value) {
+                    const f16x8 v = __builtin_bit_cast(f16x8, raw[r]);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) acc[n][k] = fmaf(t, x[r][k], acc[n][k]);
+                    for (int k = 0; k < 8; ++k) x[k] = (float)v[k];
+                } else {
+                    const bf16x8 v = __builtin_bit_cast(bf16x8, raw[r]);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) x[k] = (float)v[k];
+                }
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
+                    const float t = trow[r * 8 + n];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[n][k] = fmaf(t, x[k], acc[n][k]);
+                }
             }
+        } else {
+            static_assert(sizeof(TX) == 2 || U == 8, "f32 rows: 8 deep");
+            float x[U][8];
+#pragma unroll
+            for (int r = 0; r < U; ++r) load_x(m0 + r, x[r]);
+#pragma unroll
+            for (int r = 0; r < U; ++r)
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
+                    const float t = trow[r * 8 + n];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[n][k] = fmaf(t, x[r][k], acc[n][k]);
+                }
+        }
     }
     for (; m0 < m_end; ++m0) {
         float x[8];
@@ -675,16 +708,22 @@ __global__ __launch_bounds__(320) void gemm_tn_skinny_kernel(GemmTnParams p) {
             for (int k = 0; k < 8; ++k) acc[n][k] = fmaf(t, x[k], acc[n][k]);
         }
     }
-    const int W = nth * 8;
+    const int W = nthk * 8;
+    const float alpha = p.alpha_dev ? p.alpha * *p.alpha_dev : p.alpha;
 #pragma unroll
     for (int n = 0; n < 8; ++n) {
         if (n >= p.N) break;
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 8; ++k) sG[kc + k] = acc[n][k];
+        for (int k = 0; k < 8; ++k) sG[rg * W + kc + k] = acc[n][k];
         __syncthreads();
-        for (int k = tid; k < W; k += nth)
-            if (k < p.K) atomicAdd(p.G + (long)n * p.ldg + k, (p.alpha_dev ? p.alpha * *p.alpha_dev : p.alpha) * sG[k]);
+        for (int k = tid; k < W; k += blockDim.x)
+            if (k < p.K) {
+                float v = sG[k];
+#pragma unroll
+                for (int g = 1; g < RG; ++g) v += sG[g * W + k];      // fixed order within the block
+                atomicAdd(p.G + (long)n * p.ldg + k, alpha * v);
+            }
     }
 }
 
@@ -933,14 +972,19 @@ static int gemm_tn_impl(const void* Y, const void* X, float* G, int M, int N, in
     p.y_dtype = y_dtype; p.x_dtype = x_dtype; p.alpha = alpha; p.alpha_dev = alpha_dev; p.sY = sY; p.sX = sX; p.sG = sG;
     GD_REQUIRE(batch >= 1 && sY % 8 == 0 && sX % 8 == 0, "gd_gemm_tn: bad batch / batch strides");
     if (N == 8 && ldy == 8 && y_dtype == GD_F32 && batch == 1 && K <= 2560 && ((uintptr_t)X & 15) == 0 && ((uintptr_t)Y & 15) == 0) {   // LoRA weight gradients
-        const int nth = gd_cdiv(gd_cdiv(K, 8), 64) * 64;
-        int mchunk = ((gd_cdiv(M, 512) + 7) / 8) * 8;   // 512 blocks (more, narrower chunks measured slower: 63 vs 56 us at K = 768)
-        if (mchunk < 64) mchunk = 64;
+        const int nth = gd_cdiv(gd_cdiv(K, 8), 64) * 64;      // threads per row group
+        const bool narrow = nth <= 128;                       // 8 row groups of <= 128 threads; else 3 groups of <= 320; rows 8 deep
+        const int rgs = narrow ? 8 : 3;
+        // one block per CU (measured at 87 680 rows, tf32h step: 128 blocks 45 / 80 us (K 768 / 2304), 256: 34 / 55, 512: 43 / 66; the one-group
+        // 512-block form of rounds 1-2: 58 / 75) — every block closes with N x K fp32 atomics on the same lines, so fewer, fatter blocks win
+        const int nblk = gd_knobs().ncu > 0 ? gd_knobs().ncu : 256;
+        int mchunk = ((gd_cdiv(M, nblk) + rgs * 8 - 1) / (rgs * 8)) * (rgs * 8);      // whole row groups of whole 8-row steps
         p.mchunk = mchunk;
-        dim3 grid(1, gd_cdiv(M, mchunk), 1);
-        if (x_dtype == GD_BF16) hipLaunchKernelGGL(gemm_tn_skinny_kernel<bf16>, grid, dim3(nth), 0, (hipStream_t)stream, p);
-        else if (x_dtype == GD_F16) hipLaunchKernelGGL(gemm_tn_skinny_kernel<f16>, grid, dim3(nth), 0, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL(gemm_tn_skinny_kernel<float>, grid, dim3(nth), 0, (hipStream_t)stream, p);
+        dim3 grid(1, gd_cdiv(M, mchunk), 1), blk(nth * rgs);
+        hipStream_t st = (hipStream_t)stream;
+        if (x_dtype == GD_BF16) { if (narrow) hipLaunchKernelGGL((gemm_tn_skinny_kernel<bf16, 8, 8, 128>), grid, blk, 0, st, p); else hipLaunchKernelGGL((gemm_tn_skinny_kernel<bf16, 3, 8, 320>), grid, blk, 0, st, p); }
+        else if (x_dtype == GD_F16) { if (narrow) hipLaunchKernelGGL((gemm_tn_skinny_kernel<f16, 8, 8, 128>), grid, blk, 0, st, p); else hipLaunchKernelGGL((gemm_tn_skinny_kernel<f16, 3, 8, 320>), grid, blk, 0, st, p); }
+        else { if (narrow) hipLaunchKernelGGL((gemm_tn_skinny_kernel<float, 8, 8, 128>), grid, blk, 0, st, p); else hipLaunchKernelGGL((gemm_tn_skinny_kernel<float, 3, 8, 320>), grid, blk, 0, st, p); }
         GD_LAUNCH_OK();
         return 0;
     }
