@@ -416,6 +416,7 @@ struct GemmTnParams {
     float alpha;
     const float* alpha_dev;   // device scalar multiplied into alpha (gd_gemm_tn_scaled), or null
     long sY, sX, sG;   // batch strides in elements (grid.z = batch)
+    int anat;          // GD_GEMM_ANAT (timing experiments): 4 = no closing atomics (results are not written)
 };
 
 __device__ __forceinline__ void load8_as_f32(const void* base, long off, int dt, bool ok, float (&o)[8]) {
@@ -510,6 +511,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnParams p) {
 // the tile ROW index (m), i.e. both are "transposed" reads of row-major tiles: served by ds_read_b64_tr_b16 from
 // natural LDS tiles Y[m][n], X[m][k] (same k-slot permutation on both sides).  128 x 128 output tile, 4 waves 2x2,
 // 64-row m stages, register-prefetched; M split across blockIdx.y with fp32 atomics.
+// Round-3 measurements at 87 680 x 64 x 768 (adapter weight gradients of the tf32h step, 768 blocks): 89-101 us, of which the closing atomics are 35
+// (GD_GEMM_ANAT=4 takes them out: 53-67 us) — 6.3 M lane atomics = 393 K sixteen-lane line operations, the same ~12 G line-ops/s the skinny kernel's
+// closing atomics run at.  Two restructurings were built and were SLOWER: a second stage of register prefetch (occupancy 3 -> 2 blocks per SIMD set:
+// 116-122 us) and three row groups per block in lockstep on block-wide barriers with a third of the chunks (120-126 us; 473 vs 303 us at N = K = 768)
+// — independent blocks drift apart and hide each other's load round trips, lockstep groups all wait at once.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int rowb, int col0, int u, int lane) {
     typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -527,8 +533,9 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int rowb, int col0, 
 template <typename T, bool YF32 = false, bool XF32 = false>       // bf16 | f16
 __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmTnParams p) {
     constexpr int ROWB = 272;   // 128 bf16 + 16 B pad
-    __shared__ __attribute__((aligned(16))) char sY[64 * ROWB];
-    __shared__ __attribute__((aligned(16))) char sX[64 * ROWB];
+    __shared__ __attribute__((aligned(16))) char smem_tn[2 * 64 * ROWB];      // the two stage tiles; the closing exchange reuses them as one 32 KB tile
+    char* const sY = smem_tn;
+    char* const sX = smem_tn + 64 * ROWB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wy = wave >> 1, wx = wave & 1;
     const int tiles_k = (p.K + 127) / 128, tiles_n = (p.N + 127) / 128;
@@ -600,16 +607,29 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(GemmTnParams p) {
                 for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(a[i], b[j], acc[i][j]);
         }
     }
+    // closing atomics as FULL lines: a lane's accumulator layout gives 16 consecutive k per tile row and instruction (four 64-byte pieces); through
+    // LDS, 64 rows at a time, every wave instruction adds 64 consecutive k of one row — half the line operations the memory side has to serialise
+    static_assert(2 * 64 * ROWB >= 64 * 128 * 4, "a 64-row half of the fp32 tile fits the two stage tiles");
+    float* red = (float*)smem_tn;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int h = 0; h < 2; ++h) {
+        if (tn * 128 + h * 64 >= p.N) break;      // (uniform) no row of this half inside G
+        __syncthreads();
+        if (wy == h) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = tn * 128 + wy * 64 + i * 16 + (lane >> 4) * 4 + r;
-                const int k = tk * 128 + wx * 64 + j * 16 + (lane & 15);
-                if (n < p.N && k < p.K) atomicAdd(G + (long)n * p.ldg + k, alpha * acc[i][j][r]);
-            }
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[(i * 16 + (lane >> 4) * 4 + r) * 128 + wx * 64 + j * 16 + (lane & 15)] = acc[i][j][r];
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int e = 0; e < 32; ++e) {
+            const int idx = e * 256 + tid, n = tn * 128 + h * 64 + (idx >> 7), k = tk * 128 + (idx & 127);
+            if (n < p.N && k < p.K && p.anat != 4) atomicAdd(G + (long)n * p.ldg + k, alpha * red[idx]);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -722,7 +742,7 @@ __global__ __launch_bounds__(RG * NTK) void gemm_tn_skinny_kernel(GemmTnParams p
                 float v = sG[k];
 #pragma unroll
                 for (int g = 1; g < RG; ++g) v += sG[g * W + k];      // fixed order within the block
-                atomicAdd(p.G + (long)n * p.ldg + k, alpha * v);
+                if (p.anat != 4) atomicAdd(p.G + (long)n * p.ldg + k, alpha * v);
             }
     }
 }
@@ -969,7 +989,7 @@ static int gemm_tn_impl(const void* Y, const void* X, float* G, int M, int N, in
     GD_REQUIRE(((uintptr_t)Y & 15) == 0 && ((uintptr_t)X & 15) == 0, "gd_gemm_tn: Y and X must be 16-byte aligned");
     GemmTnParams p;
     p.Y = Y; p.X = X; p.G = G; p.M = M; p.N = N; p.K = K; p.ldy = ldy; p.ldx = ldx; p.ldg = ldg;
-    p.y_dtype = y_dtype; p.x_dtype = x_dtype; p.alpha = alpha; p.alpha_dev = alpha_dev; p.sY = sY; p.sX = sX; p.sG = sG;
+    p.y_dtype = y_dtype; p.x_dtype = x_dtype; p.alpha = alpha; p.alpha_dev = alpha_dev; p.sY = sY; p.sX = sX; p.sG = sG; p.anat = gd_knobs().gemm_anat;
     GD_REQUIRE(batch >= 1 && sY % 8 == 0 && sX % 8 == 0, "gd_gemm_tn: bad batch / batch strides");
     if (N == 8 && ldy == 8 && y_dtype == GD_F32 && batch == 1 && K <= 2560 && ((uintptr_t)X & 15) == 0 && ((uintptr_t)Y & 15) == 0) {   // LoRA weight gradients
         const int nth = gd_cdiv(gd_cdiv(K, 8), 64) * 64;      // threads per row group
