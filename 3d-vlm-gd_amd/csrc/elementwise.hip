@@ -710,7 +710,7 @@ extern "C" int gd_kp_gather_bwd_det(void* dgrid, int out_dtype, long bstride, in
 // in keypoint order (compacted per grid line by wave ballots + a block scan, as in kp_gather_bwd_det_kernel), and is written once in
 // the output dtype — prefix rows zero.  Replaces scatter + stacked-row buffer + a K = 9D GEMM over the whole grid + un-pitching.
 template <typename TU, typename TO>
-__global__ __launch_bounds__(256) void kp_patch_bwd_det_kernel(GatherParams p, const TU* U, TO* dtok, int prefix_rows) {
+__global__ __launch_bounds__(512) void kp_patch_bwd_det_kernel(GatherParams p, const TU* U, TO* dtok, int prefix_rows) {
     __shared__ int s_kp[KPB_MAXK];
     __shared__ short s_x0[KPB_MAXK];
     __shared__ signed char s_dx[KPB_MAXK], s_ky0[KPB_MAXK], s_ky1[KPB_MAXK];
@@ -719,20 +719,22 @@ __global__ __launch_bounds__(256) void kp_patch_bwd_det_kernel(GatherParams p, c
     const int y = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_total = 0;
     __syncthreads();
+    // (512 threads: the first 256 compact the line's keypoints, all four 128-thread slots then walk the line's tokens — a token's sum is a chain of
+    // dependent global loads, so the slots are there for the loads in flight: 344 -> 270 us at 64 x 300 keypoints, D 768, f32; eight slots: 266)
     for (int base = 0; base < p.Nk; base += 256) {
         const int k = base + tid;
         bool m = false;
         int x0 = 0, y0 = 0, x1 = 0, y1 = 0; float wx = 0.f, wy = 0.f;
-        if (k < p.Nk) {
+        if (k < p.Nk && tid < 256) {
             gather_coords(p, (long)b * p.Nk + k, x0, y0, x1, y1, wx, wy);
             m = y >= y0 - 1 && y <= y0 + 2;            // rows of the 4 x 4 block (the forward reads offsets {0, 1} unconditionally)
         }
         const unsigned long long bal = __ballot(m);
         const int pre = __popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0) s_wcnt[wave] = __popcll(bal);
+        if (lane == 0 && wave < 4) s_wcnt[wave] = __popcll(bal);
         __syncthreads();
         int off = s_total;
-        for (int w = 0; w < wave; ++w) off += s_wcnt[w];
+        for (int w = 0; w < min(wave, 4); ++w) off += s_wcnt[w];
         if (m) {
             const int e = off + pre;
             const int ky0 = y - y0 + 1, ky1 = y - (y0 + 1) + 1;        // tap row through neighbour a = 0 / a = 1 (rows y0, y0 + 1)
@@ -751,10 +753,10 @@ __global__ __launch_bounds__(256) void kp_patch_bwd_det_kernel(GatherParams p, c
     const int slot = tid >> 7, ch = tid & 127;
     TO* line = dtok + (long)b * p.bstride + ((long)prefix_rows + (long)y * p.gw) * p.D;
     if (y == 0) {
-        for (long i = tid; i < (long)prefix_rows * p.D; i += 256) dtok[(long)b * p.bstride + i] = from_f32<TO>(0.f);
+        for (long i = tid; i < (long)prefix_rows * p.D; i += 512) dtok[(long)b * p.bstride + i] = from_f32<TO>(0.f);
     }
     const long urow = 9L * p.D;
-    for (int x = slot; x < p.gw; x += 2) {
+    for (int x = slot; x < p.gw; x += 4) {
         if (ch >= nch) continue;
         float acc[V];
 #pragma unroll
@@ -804,9 +806,9 @@ extern "C" int gd_kp_patch_bwd_det(const void* U, void* dtok, int dtype, long bs
     GD_REQUIRE(((uintptr_t)dtok % 16) == 0 && ((uintptr_t)U % 16) == 0 && (bstride * gd_dtype_size(dtype)) % 16 == 0,
                "gd_kp_patch_bwd_det: 16-byte alignment");
     if (dtype == GD_BF16)
-        hipLaunchKernelGGL((kp_patch_bwd_det_kernel<bf16, bf16>), dim3(gh, B), dim3(256), 0, (hipStream_t)stream, p, (const bf16*)U, (bf16*)dtok, prefix_rows);
+        hipLaunchKernelGGL((kp_patch_bwd_det_kernel<bf16, bf16>), dim3(gh, B), dim3(512), 0, (hipStream_t)stream, p, (const bf16*)U, (bf16*)dtok, prefix_rows);
     else
-        hipLaunchKernelGGL((kp_patch_bwd_det_kernel<float, float>), dim3(gh, B), dim3(256), 0, (hipStream_t)stream, p, (const float*)U, (float*)dtok, prefix_rows);
+        hipLaunchKernelGGL((kp_patch_bwd_det_kernel<float, float>), dim3(gh, B), dim3(512), 0, (hipStream_t)stream, p, (const float*)U, (float*)dtok, prefix_rows);
     GD_LAUNCH_OK();
     return 0;
 }
