@@ -766,6 +766,11 @@ __global__ __launch_bounds__(512) void gemm_nt_skinny_kernel(GemmNtParams p) {
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nks = p.K >> 5;
+    const int row0 = (blockIdx.x * 8 + wave) * 16;
+    const char* ar = (const char*)p.A + (long)min(row0 + c, p.M - 1) * p.lda * 2 + 16 * g;      // (rows past M re-read row M - 1: never written)
+    Frag a0[4], a1[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a0[k] = *(const Frag*)(ar + k * 64);      // the first batch of A is in flight under the W staging
     // W -> LDS: 16-byte chunk j of row r goes to K-step j/4, row r, sub-chunk j%4
     for (int q = tid; q < SK_ROWS * (p.K >> 3); q += 512) {
         const int r = q / (p.K >> 3), j = q % (p.K >> 3);
@@ -774,16 +779,11 @@ __global__ __launch_bounds__(512) void gemm_nt_skinny_kernel(GemmNtParams p) {
         *(uint4*)(sW + (j >> 2) * 512 + r * 64 + (j & 3) * 16) = v;
     }
     __syncthreads();
-    const int row0 = (blockIdx.x * 8 + wave) * 16;
     if (row0 >= p.M) return;
-    const char* ar = (const char*)p.A + (long)min(row0 + c, p.M - 1) * p.lda * 2 + 16 * g;
     const char* wr = sW + (c & 7) * 64 + 16 * g;
     const bool wlive = c < SK_ROWS;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    Frag a0[4], a1[4];
     const int nb = nks >> 2;                                        // batches of four K-steps (K % 128 == 0)
-#pragma unroll
-    for (int k = 0; k < 4; ++k) a0[k] = *(const Frag*)(ar + k * 64);
     for (int b = 0; b < nb; b += 2) {
         if (b + 1 < nb) {
 #pragma unroll
