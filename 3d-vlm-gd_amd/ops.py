@@ -28,6 +28,27 @@ class GemmProfiler:
         ms = sum(r[0].elapsed_time(r[1]) for r in recs)
         return flops, ms, len(recs)
 
+    def roofline_time(self, keep, peak_flops, peak_bytes):
+        """(sum over the kept launches of max(FLOPs / peak_flops, algorithmic bytes / peak_bytes) in ms, measured ms, launches whose bound is the
+        byte term, launches).  Algorithmic bytes of a launch: both operands once, C once, every [M, N] epilogue tensor (preact, dact_src,
+        residual, the accumulate read) once — what the launch must move if nothing is re-read."""
+        torch.cuda.synchronize()
+        es = {"float32": 4, "bfloat16": 2, "float16": 2}
+        lim = ms = 0.0
+        nb = n = 0
+        for e0, e1, fl, tag in self.records:
+            if keep is not None and not keep(tag):
+                continue
+            M, N, K, B, epi, odt, adt = tag
+            nt = sum(epi.split("a")[0].count(c) for c in "pdr") + (1 if epi.endswith("+") else 0)
+            by = B * (M * K + N * K) * es[adt] + B * M * N * es[odt] * (1 + nt)
+            tf, tb = fl / peak_flops, by / peak_bytes
+            lim += max(tf, tb) * 1e3
+            nb += tb > tf
+            ms += e0.elapsed_time(e1)
+            n += 1
+        return lim, ms, nb, n
+
     def by_shape(self):
         """{(M, N, K, B, epilogue tag): (launches, ms, TFLOP/s)} — where the step's GEMM time goes."""
         torch.cuda.synchronize()

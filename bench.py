@@ -185,6 +185,14 @@ def gemm_roofline(prof, dtype, dt, steps):
     out = {"kernel": kname, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
            "frac": round(ach / PEAK_TFLOPS[dtype], 4), "traffic": None, "launches": n,
            "avg_launch_us": round(ms / max(n, 1) * 1e3, 2), "share_of_step": round(ms / (dt * 1e3), 3)}
+    if big is not None and ms > 0:
+        # the same launches against their OWN bounds: a launch with fp32 epilogue tensors at K = 768 has more bytes to move than MFMA work to do
+        # (tf32h: A + residual + C = 5 B per output element against 2 K / peak) — per launch max(FLOPs / MFMA peak, algorithmic bytes / HBM peak)
+        lim, ms2, nb, n2 = prof.roofline_time(big, PEAK_TFLOPS[dtype] * 1e12 * (3.0 if dtype == "tf32x" else 1.0), PEAK_HBM_GBS * 1e9)
+        out["per_launch_bounds"] = {"sum_of_bounds_ms_per_step": round(lim / steps, 3), "measured_ms_per_step": round(ms2 / steps, 3),
+                                    "frac_of_bound": round(lim / ms2, 4), "launches_bound_by_hbm": nb, "launches": n2,
+                                    "what": "sum over the persistent-kernel launches of max(FLOPs / MFMA peak, algorithmic bytes / 8 TB/s) divided by their "
+                                            "measured time: `frac` above prices every launch against the MFMA peak alone"}
     if dtype in ("bf16", "tf32h"):     # (fp16 and bf16 MFMAs run at one rate; the ceilings were measured on the bf16 instantiation)
         # context, not the yardstick (NOT measured in this run; profiles/r03_gemm_anatomy.txt, profiles/r02_micro_mfma_gap.txt):
         #  * back-to-back 16x16x32 bf16 MFMAs from registers, no memory traffic: 2328 TFLOP/s — the part's power-limited MFMA clock;
