@@ -1363,7 +1363,10 @@ extern "C" int gd_cost_volume_kl_bwd(const void* f1, const void* f2, const float
                                      void* workspace, void* stream) {
     GD_REQUIRE(P > 0 && hw > 0 && C > 0 && ldt >= hw, "gd_cost_volume_kl_bwd: bad shape P=%d hw=%d C=%d ldt=%d", P, hw, C, ldt);
     GD_REQUIRE(dtype == GD_F32 || dtype == GD_BF16, "gd_cost_volume_kl_bwd: bad dtype %d", dtype);
-    GD_REQUIRE((C * gd_dtype_size(dtype)) % 16 == 0, "gd_cost_volume_kl_bwd: C*elsize must be a multiple of 16 B");
+    GD_REQUIRE((C * gd_dtype_size(dtype)) % 16 == 0 && C % 4 == 0, "gd_cost_volume_kl_bwd: C*elsize must be a multiple of 16 B");
+    GD_REQUIRE(((uintptr_t)f1 & 15) == 0 && ((uintptr_t)f2 & 15) == 0 && ((uintptr_t)df1 & 15) == 0 && ((uintptr_t)df2 & 15) == 0 &&
+                   ((uintptr_t)workspace & 255) == 0,
+               "gd_cost_volume_kl_bwd: features and gradients must be 16-byte aligned (vector transpose / normalisation backward), the workspace 256-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const size_t es = (size_t)gd_dtype_size(dtype);
     const int tiles = cv_tiles(hw), hwp = cv_hwp(hw);
@@ -1436,6 +1439,9 @@ extern "C" int gd_cost_volume_kl_bwd_h(const float* f1, const float* f2, const v
                                        const float* stats, float* df1, float* df2, void* workspace, void* stream) {
     GD_REQUIRE(P > 0 && hw > 0 && C > 0 && ldt >= hw, "gd_cost_volume_kl_bwd_h: bad shape P=%d hw=%d C=%d ldt=%d", P, hw, C, ldt);
     GD_REQUIRE(C % 8 == 0, "gd_cost_volume_kl_bwd_h: C must be a multiple of 8");
+    GD_REQUIRE(((uintptr_t)f1 & 15) == 0 && ((uintptr_t)f2 & 15) == 0 && ((uintptr_t)f1h & 15) == 0 && ((uintptr_t)f2h & 15) == 0 &&
+                   ((uintptr_t)df1 & 15) == 0 && ((uintptr_t)df2 & 15) == 0 && ((uintptr_t)workspace & 255) == 0,
+               "gd_cost_volume_kl_bwd_h: features and gradients must be 16-byte aligned, the workspace 256-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const int tiles = cv_tiles(hw), hwp = cv_hwp(hw);
     char* w = (char*)workspace;
@@ -1546,6 +1552,9 @@ extern "C" int gd_cost_volume_kl_bwd_rows(const void* f1, const void* f2, const 
     GD_REQUIRE((dtype == GD_F16) == (f1h != nullptr && f2h != nullptr), "gd_cost_volume_kl_bwd_rows: fp16 feature copies go with dtype GD_F16 and only with it");
     const size_t es = (size_t)gd_dtype_size(dtype);
     GD_REQUIRE((C * es) % 16 == 0 && C % 4 == 0, "gd_cost_volume_kl_bwd_rows: C*elsize must be a multiple of 16 B");
+    GD_REQUIRE(((uintptr_t)f1 & 15) == 0 && ((uintptr_t)f2 & 15) == 0 && ((uintptr_t)f1h & 15) == 0 && ((uintptr_t)f2h & 15) == 0 &&
+                   ((uintptr_t)df1 & 15) == 0 && ((uintptr_t)df2 & 15) == 0 && ((uintptr_t)stats & 15) == 0 && ((uintptr_t)workspace & 255) == 0,
+               "gd_cost_volume_kl_bwd_rows: features, gradients and stats must be 16-byte aligned, the workspace 256-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const int tiles = cv_tiles(hw), hwp = cv_hwp(hw);
     // every [direction][pair] array is one contiguous batch of 2P problems: direction 0 = kept rows of view 1 against view 2, direction 1 the reverse
