@@ -72,6 +72,7 @@ SIGNATURES = {
     "gd_kp_gather_bwd": (c_int, [ctypes.POINTER(c_void_p), c_int, c_long, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                  c_int, c_float, c_float, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "gd_lora_bwd_fused": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "gd_lora_bwd_fused_scaled": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "gd_conv_weight_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "gd_kp_patch_bwd_det": (c_int, [c_void_p, c_void_p, c_int, c_long, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                     c_float, c_int, c_int, c_int, c_int, c_void_p]),

@@ -620,6 +620,24 @@ def skinny_tn_mfma(t, x, out):
     return out
 
 
+def lora_bwd_fused_h(dqv, t, bt_qv, gbt, t_mul=None, out_mul=None):
+    """The fused LoRA backward on fp16 operands (tf32h engine): dqv [M, K] fp16 view, t [M, 8] f32, bt_qv [8, K] fp16 or None (then only
+    gbt [8, K] f32 += (t * t_mul)^T . dqv * out_mul), t_mul / out_mul: one-element device tensors (the step's gradient scale s and 1 / s) or None
+    -> dt [M, 8] f32 = dqv . bt_qv^T * out_mul (None without bt_qv).  gd_lora_bwd_fused_scaled."""
+    M, K = dqv.shape
+    dt = torch.empty(M, 8, dtype=torch.float32, device=dqv.device) if bt_qv is not None else None
+    check(lib().gd_lora_bwd_fused_scaled(ptr(dqv), dqv.stride(0), ptr(t), ptr(bt_qv), ptr(dt), ptr(gbt), M, K, dtype_code(dqv), ptr(t_mul), ptr(out_mul),
+                                         stream()), "gd_lora_bwd_fused_scaled")
+    return dt
+
+
+def lora_bwd_fused_h_supported(dqv, t, bt_qv, gbt):
+    return (option("lora_fused") and dqv.dtype == torch.float16 and (bt_qv is None or (bt_qv.dtype == torch.float16 and bt_qv.is_contiguous()))
+            and t.dtype == torch.float32 and t.shape[1] == 8 and t.is_contiguous() and gbt.is_contiguous() and gbt.dtype == torch.float32
+            and dqv.stride(1) == 1 and dqv.shape[1] % 256 == 0 and dqv.shape[1] // 256 in (1, 2, 3, 4, 6, 8) and dqv.stride(0) % 8 == 0
+            and dqv.data_ptr() % 16 == 0)
+
+
 def lora_bwd_fused_supported(dqv, t, bt_qv, gbt):
     return (option("lora_fused") and dqv.dtype == torch.bfloat16 and (bt_qv is None or bt_qv.dtype == torch.bfloat16)
             and t.dtype == torch.float32 and t.shape[1] == 8 and t.is_contiguous() and (bt_qv is None or bt_qv.is_contiguous()) and gbt.is_contiguous()

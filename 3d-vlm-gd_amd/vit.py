@@ -332,7 +332,16 @@ class _BlockFn(torch.autograd.Function):
             bt_T = tw["bt_T"] if tw is not None else bt.to(T).contiguous()
             bt_qv = tw["bt_qv"] if tw is not None else torch.cat([bt_T[:, :D], bt_T[:, 2 * D:]], 1).contiguous()   # [2r, 2D]
             dqv = dqkv[:, :2 * D]
-            if fmt:
+            gat = None
+            if fmt == "h" and sc is not None and y1.dtype == torch.float16 and ops.lora_bwd_fused_h_supported(dqv, t, None, z_bt):
+                # tf32h: both LoRA-backward products in one pass over the fp16 (dq, dv) block (it carries the step's scale s: results times 1 / s),
+                # then the LoRA-A gradient dt^T . LN(x) on the same kernel with dt going in under s
+                dt = ops.lora_bwd_fused_h(dqv, t, ops.cast16(bt_qv.float().contiguous()), z_bt, out_mul=sc[1:2])
+                gbt = z_bt
+                ops.lora_bwd_fused_h(y1, dt, None, z_at, t_mul=sc[0:1], out_mul=sc[1:2])
+                gat = z_at
+                dqkv_s = dqkv
+            elif fmt:
                 ad = None if sc is None else sc[1:2]
                 if ctx.needs_input_grad[0]:
                     # tf32x: dt = dqv . Bt^T on the split of the WHOLE dqkv row (the dX GEMM below needs that split anyway) against
@@ -356,7 +365,9 @@ class _BlockFn(torch.autograd.Function):
             else:
                 dt = ops.gemm_nt(dqv, bt_qv, out_dtype=torch.float32)                             # [M, 2r], streams 2/3 of dqkv
                 gbt = ops.gemm_tn(t, dqv, out=z_bt)                                               # [2r, 2D]
-            if ops.lora_bwd_fused_supported(y1, dt, None, z_at):
+            if gat is not None:
+                pass                                                                              # (tf32h: taken above)
+            elif ops.lora_bwd_fused_supported(y1, dt, None, z_at):
                 gat = ops.skinny_tn_mfma(dt, y1, z_at)                                            # [2r, D] on the same slab kernel
             else:
                 gat = ops.gemm_tn(dt, y1, out=z_at)                                               # [2r, D]

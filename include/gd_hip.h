@@ -75,6 +75,11 @@ int gd_attention_bwd(const void* qkv, const void* o, const void* dout, const flo
  * transposed.  bt == NULL: only the second product (dt may be NULL too) — any [8, K] += t^T . X with an [M, 8] f32 left operand, e.g. the
  * LoRA-A gradient dt^T . LN(x).  K % 256 == 0, K / 256 in {1, 2, 3, 4, 6, 8}. */
 int gd_lora_bwd_fused(const void* dqv, long ldx, const float* t, const void* bt, float* dt, float* gbt, int M, int K, void* stream);
+/* The same pass on either 16-bit operand type (dtype GD_BF16 | GD_F16) with the tf32h engine's device-side scales: t is multiplied by *t_mul_dev
+ * before it is split into its high and low 16-bit parts (a GRADIENT in the t role goes in under the step's power-of-two scale), dt and the gbt
+ * partial by *out_mul_dev on the way out (1 / s when dqv or t carried s).  NULL = 1. */
+int gd_lora_bwd_fused_scaled(const void* dqv, long ldx, const float* t, const void* bt, float* dt, float* gbt, int M, int K, int dtype,
+                             const float* t_mul_dev, const float* out_mul_dev, void* stream);
 
 /* Dense cost-volume KL for P pairs, fused: calculate_cost_loss (src/finetune_timm_vggt.py:488-533 variant 0,
  * src/finetune_timm_mast3r.py:504-540 variant 1) = F.normalize + bmm x2 + softmax + get_masked_patch_cost

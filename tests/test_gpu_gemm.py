@@ -287,6 +287,38 @@ def test_lora_bwd_fused(M, K, ldx):
     assert rel_err(g2, rg) < 2e-5
 
 
+@pytest.mark.parametrize("M,K,ldx", [(87680, 1536, 2304), (1000, 768, 768), (130, 2048, 3072)])
+def test_lora_bwd_fused_fp16_operands_with_device_scales(M, K, ldx):
+    """gd_lora_bwd_fused_scaled on fp16 operands (tf32h engine).  (1) the (dq, dv) block carries the step's scale s = 2^12 (its true values ~1e-4:
+    below fp16's normal range unscaled): dt = dqv . bt^T and gbt += t^T . dqv come back times 1 / s, within 1e-3 of fp64 on the fp16-rounded
+    operands' exact values (t goes in as a high + low fp16 pair: ~2^-22).  (2) the LoRA-A gradient form: a GRADIENT in the t role (values ~1e-5)
+    goes in under s and comes out times 1 / s — unscaled it would lose most of its bits to fp16 subnormals."""
+    from gd_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(M + K + 1)
+    s = torch.tensor([4096.0, 1.0 / 4096.0], device="cuda")
+    true = torch.randn(M, ldx, generator=g, device="cuda") * 1e-4
+    buf = (true * s[0]).half()                                   # what the attention backward leaves: fp16(dqkv * s)
+    dqv = buf[:, :K]
+    t = torch.randn(M, 8, generator=g, device="cuda") * 0.3
+    bt = (torch.randn(8, K, generator=g, device="cuda") * 0.05).half()
+    g0 = torch.randn(8, K, generator=g, device="cuda") * 1e-3
+    gbt = g0.clone()
+    assert ops.lora_bwd_fused_h_supported(dqv, t, bt, gbt)
+    dt = ops.lora_bwd_fused_h(dqv, t, bt, gbt, out_mul=s[1:2])
+    xd = dqv.double() / 4096.0
+    assert rel_err(dt, xd @ bt.double().t()) < 1e-5
+    assert rel_err(gbt - g0, t.double().t() @ xd) < 1e-4 and rel_err(gbt, g0.double() + t.double().t() @ xd) < 1e-4
+    # (2) gat = dt^T . y with dt a gradient
+    y = torch.randn(M, ldx, generator=g, device="cuda").half()[:, :K]
+    dtg = torch.randn(M, 8, generator=g, device="cuda") * 1e-5
+    gat = torch.zeros(8, K, device="cuda")
+    ops.lora_bwd_fused_h(y, dtg, None, gat, t_mul=s[0:1], out_mul=s[1:2])
+    assert rel_err(gat, dtg.double().t() @ y.double()) < 1e-4
+    unscaled = torch.zeros(8, K, device="cuda")
+    ops.lora_bwd_fused_h(y, dtg, None, unscaled)
+    assert rel_err(unscaled, dtg.double().t() @ y.double()) > 10 * rel_err(gat, dtg.double().t() @ y.double())      # why the scale is there
+
+
 @pytest.mark.parametrize("M,N,K", [(1370, 2304, 768), (5480, 768, 3072), (300, 128, 64)])
 def test_split3_product_accuracy(M, N, K):
     """ops.split3 + gemm_nt on the 3K-wide bf16 operands (gd_split3: TF32-class products on the bf16 matrix cores): the planes are
