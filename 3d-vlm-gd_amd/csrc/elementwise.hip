@@ -442,7 +442,9 @@ extern "C" int gd_patch_im2col_strided(const float* img, void* col, int B, int h
                "gd_patch_im2col: bad geometry H=%d W=%d P=%d stride=(%d,%d) Kp=%d", H, W, P, stride_y, stride_x, Kp);
     const long rows = (long)B * (1 + (H - P) / stride_y) * (1 + (W - P) / stride_x);
 #define GD_PI2C(TT, PCV) hipLaunchKernelGGL((patch_im2col_kernel<TT, PCV>), dim3((unsigned)(rows < 65536 * 4 ? rows : 65536 * 4)), dim3(256), 0, (hipStream_t)stream, img, (TT*)col, B, h, w, H, W, P, Kp, stride_y, stride_x, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2])
+    GD_REQUIRE(dtype == GD_F32 || dtype == GD_BF16 || dtype == GD_F16, "gd_patch_im2col: bad output dtype %d", dtype);
     if (dtype == GD_BF16) { if (P == 14) GD_PI2C(bf16, 14); else if (P == 16) GD_PI2C(bf16, 16); else GD_PI2C(bf16, 0); }
+    else if (dtype == GD_F16) { if (P == 14) GD_PI2C(f16, 14); else if (P == 16) GD_PI2C(f16, 16); else GD_PI2C(f16, 0); }      // tf32h: the projection's operand directly
     else { if (P == 14) GD_PI2C(float, 14); else if (P == 16) GD_PI2C(float, 16); else GD_PI2C(float, 0); }
 #undef GD_PI2C
     GD_LAUNCH_OK();

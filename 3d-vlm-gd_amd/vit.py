@@ -685,10 +685,11 @@ class GDViT(nn.Module):
         B, _, h, w = img.shape
         H, W = size if size is not None else (h, w)
         pp = self._patch_plan()
+        cdt = torch.float16 if pp["fmt"] == "h" else self.dtype      # tf32h: im2col writes the projection's fp16 operand itself (the patch conv is frozen)
         if st == (P, P):
             assert H % P == 0 and W % P == 0, f"image size {(H, W)} not a multiple of patch {P}"
             gh, gw = H // P, W // P
-            col = ops.patch_im2col(img, H, W, P, pp["Kp"], self.mean, self.std, self.dtype)
+            col = ops.patch_im2col(img, H, W, P, pp["Kp"], self.mean, self.std, cdt)
             pos = self._pos(gh, gw)
         else:
             # src/evaluate_timm.py:262-279: the tracking evaluation sets `patch_embed.proj.stride = (s, s)` (s = patch / 2) on the
@@ -697,10 +698,10 @@ class GDViT(nn.Module):
             if st[0] <= 0 or st[1] <= 0 or H < P or W < P:
                 raise ops._lib.GdHipError(f"patch_embed.proj.stride = {st} with image {(H, W)} and patch {P}")
             gh, gw = 1 + (H - P) // st[0], 1 + (W - P) // st[1]
-            col = ops.patch_im2col(img, H, W, P, pp["Kp"], self.mean, self.std, self.dtype, stride=st)
+            col = ops.patch_im2col(img, H, W, P, pp["Kp"], self.mean, self.std, cdt, stride=st)
             pos = self._pos_strided(gh, gw, H, W)
         if pp["fmt"]:       # tf32x / tf32h: the patch projection on formatted operands too (the exact-f32 MFMA spends 0.7 ms on it)
-            tok = ops.gemm_nt(_opa(col, pp["fmt"]), pp["w"], bias=pp["b"], out_dtype=torch.float32)
+            tok = ops.gemm_nt(col if pp["fmt"] == "h" else _opa(col, pp["fmt"]), pp["w"], bias=pp["b"], out_dtype=torch.float32)
         else:
             tok = ops.gemm_nt(col, pp["w"], bias=pp["b"])
         x = ops.assemble_tokens(tok, pp["cls"], pos, B, gh * gw).view(B, gh * gw + 1, -1)

@@ -129,7 +129,8 @@ int gd_l2norm_fwd(const float* x, float* y, float* inv, int M, int D, float eps,
 int gd_l2norm_bwd(const float* y, const float* dy, const float* inv, float* dx, int M, int D, void* stream);
 
 /* a0 + patch-embed prologue: torchvision bilinear resize (h,w)->(H,W) (src/finetune_timm_vggt.py:270,340), timm
- * Normalize (:153), im2col for the PxP/stride-P conv of timm PatchEmbed; col [B*(H/P)*(W/P), Kp] zero-padded. */
+ * Normalize (:153), im2col for the PxP/stride-P conv of timm PatchEmbed; col [B*(H/P)*(W/P), Kp] zero-padded, in `dtype`
+ * (GD_F32 | GD_BF16 | GD_F16: the tf32h engine takes the projection's fp16 operand straight from here — the patch conv is frozen). */
 int gd_patch_im2col(const float* img, void* col, int B, int h, int w, int H, int W, int P, int Kp,
                     const float* mean3, const float* std3, int dtype, void* stream);
 /* The same with the conv stride decoupled from the patch size: src/evaluate_timm.py:262-266 sets
