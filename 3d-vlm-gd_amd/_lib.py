@@ -80,6 +80,8 @@ SIGNATURES = {
                                      c_float, c_float, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "gd_kp_patch_gather": (c_int, [c_void_p, c_long, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float,
                                    c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "gd_kp_patch_gather_h": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float,
+                                     c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "gd_stack3_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_long, c_long, c_int, c_int, c_int, c_void_p]),
     "gd_unpitch_tokens": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "gd_tap_mean_fwd": (c_int, [ctypes.POINTER(c_void_p), c_int, c_long, c_int, c_void_p, c_int, c_int, c_int, c_int,

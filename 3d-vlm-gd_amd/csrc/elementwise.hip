@@ -592,11 +592,12 @@ __global__ __launch_bounds__(128) void kp_patch_gather_kernel(GatherParams p, TO
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-                TO r[V];
+                __attribute__((aligned(16))) TO r[V];
 #pragma unroll
                 for (int k = 0; k < V; ++k)
                     r[k] = from_f32<TO>(w00 * t[ky][kx][k] + w01 * t[ky][kx + 1][k] + w10 * t[ky + 1][kx][k] + w11 * t[ky + 1][kx + 1][k]);
-                *(uint4*)(o + (ky * 3 + kx) * p.D) = *(const uint4*)r;
+                if constexpr (V * sizeof(TO) == 16) *(uint4*)(o + (ky * 3 + kx) * p.D) = *(const uint4*)r;
+                else *(uint2*)(o + (ky * 3 + kx) * p.D) = *(const uint2*)r;      // fp32 grid -> fp16 taps: 4 channels = 8 bytes
             }
     }
 }
@@ -613,6 +614,20 @@ extern "C" int gd_kp_patch_gather(const void* grid, long bstride, int grid_dtype
         hipLaunchKernelGGL((kp_patch_gather_kernel<bf16, bf16>), dim3(B * Nk), dim3(128), 0, (hipStream_t)stream, p, (bf16*)out);
     else
         hipLaunchKernelGGL((kp_patch_gather_kernel<float, float>), dim3(B * Nk), dim3(128), 0, (hipStream_t)stream, p, (float*)out);
+    GD_LAUNCH_OK();
+    return 0;
+}
+
+// tf32h engine: the same gather from an fp32 grid with the [B*Nk, 9*D] taps written as fp16 — the operand of the K = 9D GEMM and of the weight
+// gradient — instead of an fp32 block (531 MB at 64 x 300 keypoints, D 768) and a cast pass over it
+extern "C" int gd_kp_patch_gather_h(const float* grid, long bstride, const float* kp, void* out16, int B, int Nk, int gh, int gw, int D, float sx,
+                                    float sy, int img_h, int img_w, int patch, int stride, int pitch, void* stream) {
+    GatherParams p = {};
+    const void* one[1] = {grid};
+    if (fill_gather(p, one, 1, bstride, GD_F32, kp, B, Nk, gh, gw, D, sx, sy, img_h, img_w, patch, stride, pitch)) return -1;
+    GD_REQUIRE(D % 4 == 0 && ((uintptr_t)grid % 16) == 0 && ((uintptr_t)out16 % 16) == 0 && (bstride * 4) % 16 == 0,
+               "gd_kp_patch_gather_h: D must be a multiple of 4, grid and out 16-byte aligned");
+    hipLaunchKernelGGL((kp_patch_gather_kernel<float, f16>), dim3(B * Nk), dim3(128), 0, (hipStream_t)stream, p, (f16*)out16);
     GD_LAUNCH_OK();
     return 0;
 }

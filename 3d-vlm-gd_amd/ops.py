@@ -679,9 +679,16 @@ def kp_gather_bwd_det(kp, dout, scale, out_dtype, B, Nk, gh, gw, D, sx, sy, img_
     return out
 
 
-def kp_patch_gather(grid, bstride, kp, B, Nk, gh, gw, D, sx, sy, img_h, img_w, patch, stride=None, pitch=None):
+def kp_patch_gather(grid, bstride, kp, B, Nk, gh, gw, D, sx, sy, img_h, img_w, patch, stride=None, pitch=None, half=False):
     """-> [B*Nk, 9*D] (grid dtype): the bilinear mix of the four neighbours' 3x3 input patches, K order (ky, kx, c) — the GEMM
-    operand of refine_conv evaluated at the keypoints only (gd_kp_patch_gather).  `grid` is addressed from its data_ptr."""
+    operand of refine_conv evaluated at the keypoints only (gd_kp_patch_gather).  `grid` is addressed from its data_ptr.
+    half (fp32 grid): the taps leave as fp16, the tf32h engine's operand (gd_kp_patch_gather_h)."""
+    if half:
+        _req(grid.dtype == torch.float32 and D % 4 == 0, "kp_patch_gather(half=True): an fp32 grid with D % 4 == 0")
+        out = torch.empty(B * Nk, 9 * D, dtype=torch.float16, device=grid.device)
+        check(lib().gd_kp_patch_gather_h(ptr(grid), bstride, ptr(kp), ptr(out), B, Nk, gh, gw, D, float(sx), float(sy), img_h, img_w, patch,
+                                         patch if stride is None else stride, gw if pitch is None else pitch, stream()), "gd_kp_patch_gather_h")
+        return out
     out = torch.empty(B * Nk, 9 * D, dtype=grid.dtype, device=grid.device)
     check(lib().gd_kp_patch_gather(ptr(grid), bstride, dtype_code(grid), ptr(kp), ptr(out), B, Nk, gh, gw, D, float(sx), float(sy),
                                    img_h, img_w, patch, patch if stride is None else stride, gw if pitch is None else pitch,

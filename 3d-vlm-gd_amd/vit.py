@@ -847,13 +847,12 @@ class _ConvAtKpFn(torch.autograd.Function):
         kp = kp.contiguous().float()
         Nk = kp.shape[1]
         T = tok.dtype
-        colp = ops.kp_patch_gather(tok[:, Nt - gh * gw:], Nt * D, kp, B, Nk, gh, gw, D, sx, sy, img_h, img_w, patch)
         sparse_dx = tok.requires_grad and Nk <= 1024 and D % 8 == 0 and D <= 1024 and bool(option("conv_dx_at_kp"))
+        x3 = ("x3" if x3 is True else x3) if (x3 and T == torch.float32 and sparse_dx) else ""   # tf32x / tf32h: the K = 9D GEMMs on formatted operands
+        colp = ops.kp_patch_gather(tok[:, Nt - gh * gw:], Nt * D, kp, B, Nk, gh, gw, D, sx, sy, img_h, img_w, patch, half=x3 == "h")
         # [n, (ky, kx, c)], the flipped [ci, (kx, ky, n)] of the dense backward, [(ky, kx, c), n] of the backward at the keypoints
         wk, wt, wu = ops.conv_weight_pack(weight, T, with_wu=sparse_dx)
-        x3 = ("x3" if x3 is True else x3) if (x3 and T == torch.float32 and sparse_dx) else ""   # tf32x / tf32h: the K = 9D GEMMs on formatted operands
-        if x3 == "h":         # fp16 operands; the gathered patches are kept as fp16 only (the weight gradient contracts them again)
-            colp = ops.cast16(colp)
+        if x3 == "h":         # fp16 operands; the gathered patches are fp16 only, written so by the gather (the weight gradient contracts them again)
             out = ops.gemm_nt(colp, ops.cast16(wk), bias=bias.detach().float().contiguous(), out_dtype=torch.float32)
         elif x3:
             out = ops.gemm_nt_x3(colp, ops.split3(wk, "w"), bias=bias.detach().float().contiguous())

@@ -184,6 +184,10 @@ int gd_kp_gather_bwd_det(void* dgrid, int out_dtype, long bstride, int prefix_ro
 int gd_kp_patch_gather(const void* grid, long bstride, int grid_dtype, const float* kp, void* out, int B, int Nk, int gh,
                        int gw, int D, float sx, float sy, int img_h, int img_w, int patch, int stride, int pitch,
                        void* stream);
+/* the same gather from an fp32 grid with the taps written as fp16 (tf32h engine: the K = 9D GEMM's operand and the weight gradient's, no fp32 block
+ * and no cast pass); D % 4 == 0 */
+int gd_kp_patch_gather_h(const float* grid, long bstride, const float* kp, void* out16, int B, int Nk, int gh, int gw, int D, float sx, float sy,
+                         int img_h, int img_w, int patch, int stride, int pitch, void* stream);
 /* extract_kp_depth (utils/functions.py:348-372) and get_patch_mask_from_kp_tensor (:375-399; mask pre-zeroed). */
 int gd_kp_depth(const float* depth, const float* kp, float* out, int B, int Nk, int H, int W, void* stream);
 int gd_patch_mask(const float* kp, unsigned char* mask, int B, int Nk, int H, int W, int P, void* stream);
