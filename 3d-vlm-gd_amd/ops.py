@@ -345,6 +345,15 @@ class _CostVolumeKL(torch.autograd.Function):
         return df1, df2, None, None, None, None, None, None, None, None, None, None, None
 
 
+def kept_row_capacity(hw, kept_rows_max):
+    """Row capacity (a multiple of 128) of the kept-row cost-volume kernels for a caller's bound on the kept rows of any (pair, view), or 0 when the
+    dense hw x hw sweep is the better form: no bound given, or the two compacted problems (2 x capacity rows) would cover more than the hw rows."""
+    if kept_rows_max is None or int(kept_rows_max) <= 0:
+        return 0
+    kc = (min(int(kept_rows_max), int(hw)) + 127) // 128 * 128
+    return kc if 2 * kc <= hw else 0
+
+
 def cost_volume_kl(f1, f2, t1, t2, m1, m2, variant="vggt", tstats=None, inv_norms=None, x3=False, h16=None, kept_rows_max=None):
     """Fused dense cost-volume KL for P pairs.  f1,f2 [P,hw,C] raw student features (f32|bf16); t1,t2 [P,hw,ldt] teacher
     maps (f32; ldt = hw, or hw padded to a multiple of 4 by `pad_teacher_maps`: the fast path); m1,m2 [P,hw] bool row
@@ -356,11 +365,7 @@ def cost_volume_kl(f1, f2, t1, t2, m1, m2, variant="vggt", tstats=None, inv_norm
     masks; when it is below half of hw the forward runs as two compacted row problems (gd_cost_volume_kl_fwd_rows) instead of one hw x hw sweep
     -> loss [P] (f32)."""
     if inv_norms is not None:
-        hw = f1.shape[1]
-        kcap = 0
-        if kept_rows_max is not None and tstats is not None:      # sparse row masks: the caller's bound on kept rows per (pair, view)
-            kc = (min(int(kept_rows_max), hw) + 127) // 128 * 128
-            kcap = kc if 2 * kc <= hw else 0                      # (above half the rows the two compacted problems cost more than one dense sweep)
+        kcap = kept_row_capacity(f1.shape[1], kept_rows_max) if tstats is not None else 0
         return _CostVolumeKL.apply(f1, f2, t1, t2, m1, m2, variant, tstats, inv_norms[0].detach(), inv_norms[1].detach(), x3, h16, kcap)
     return _CostVolumeKL.apply(f1, f2, t1, t2, m1, m2, variant, tstats)
 
