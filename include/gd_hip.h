@@ -75,7 +75,7 @@ int gd_attention_bwd(const void* qkv, const void* o, const void* dout, const flo
  * transposed.  bt == NULL: only the second product (dt may be NULL too) — any [8, K] += t^T . X with an [M, 8] f32 left operand, e.g. the
  * LoRA-A gradient dt^T . LN(x).  K % 256 == 0, K / 256 in {1, 2, 3, 4, 6, 8}. */
 int gd_lora_bwd_fused(const void* dqv, long ldx, const float* t, const void* bt, float* dt, float* gbt, int M, int K, void* stream);
-/* The same pass on either 16-bit operand type (dtype GD_BF16 | GD_F16) with the tf32h engine's device-side scales: t is multiplied by *t_mul_dev
+/* The same pass (autograd of _LoRA_qkv, utils/model.py:57-71) on either 16-bit operand type (dtype GD_BF16 | GD_F16) with the tf32h engine's device-side scales: t is multiplied by *t_mul_dev
  * before it is split into its high and low 16-bit parts (a GRADIENT in the t role goes in under the step's power-of-two scale), dt and the gbt
  * partial by *out_mul_dev on the way out (1 / s when dqv or t carried s).  NULL = 1. */
 int gd_lora_bwd_fused_scaled(const void* dqv, long ldx, const float* t, const void* bt, float* dt, float* gbt, int M, int K, int dtype,
@@ -184,7 +184,7 @@ int gd_kp_gather_bwd_det(void* dgrid, int out_dtype, long bstride, int prefix_ro
 int gd_kp_patch_gather(const void* grid, long bstride, int grid_dtype, const float* kp, void* out, int B, int Nk, int gh,
                        int gw, int D, float sx, float sy, int img_h, int img_w, int patch, int stride, int pitch,
                        void* stream);
-/* the same gather from an fp32 grid with the taps written as fp16 (tf32h engine: the K = 9D GEMM's operand and the weight gradient's, no fp32 block
+/* the same gather (src/finetune_timm_vggt.py:319-325) from an fp32 grid with the taps written as fp16 (tf32h engine: the K = 9D GEMM's operand and the weight gradient's, no fp32 block
  * and no cast pass); D % 4 == 0 */
 int gd_kp_patch_gather_h(const float* grid, long bstride, const float* kp, void* out16, int B, int Nk, int gh, int gw, int D, float sx, float sy,
                          int img_h, int img_w, int patch, int stride, int pitch, void* stream);
@@ -288,14 +288,16 @@ int gd_cast_f16(const float* in, void* out, long rows, int K, long ld_in, float 
 /* Cost-volume KL of the tf32h engine: gd_cost_volume_kl_fwd_prenorm takes dtype GD_F16 (fp16 copies of the fp32 features, the fp32 rows' norms);
  * the backward recomputes S from the same fp16 copies, writes G = dloss/dS as fp16 under a power-of-two scale taken from `gloss` on the device,
  * contracts it on the fp16 MFMA kernels and takes the gradient through the L2 normalisation in fp32 on the fp32 features (df1, df2 fp32). */
-/* Kept-row forward for SPARSE row masks (the MASt3R trainer's keypoint-patch masks keep at most N_kp of the hw rows): both directions as compacted row
+/* Kept-row forward for SPARSE row masks (the MASt3R trainer's keypoint-patch masks, src/finetune_timm_mast3r.py:515-519 -> get_masked_patch_cost,
+ * utils/functions.py:402-422, keep at most N_kp of the hw rows; same loss as src/finetune_timm_mast3r.py:522-540): both directions as compacted row
  * problems — kept rows of one view (gathered) against all rows of the other — instead of one hw x hw sweep; same loss and saved statistics as
  * gd_cost_volume_kl_fwd_prenorm.  kcap: a multiple of 128, >= the number of kept rows of any (pair, view). */
 size_t gd_cost_volume_kl_rows_workspace_bytes(int P, int hw, int kcap);
 int gd_cost_volume_kl_fwd_rows(const void* f1, const void* f2, const float* inv_norm1, const float* inv_norm2, const float* t1, const float* t2, int ldt,
                                const float* tstats, const unsigned char* m1, const unsigned char* m2, int P, int hw, int C, int kcap, int variant,
                                int dtype, float* loss, float* stats, void* workspace, void* stream);
-/* Kept-row backward, the counterpart of gd_cost_volume_kl_fwd_rows (same masks, same kcap; `stats` as saved by either forward): G = dloss/dS only for
+/* Kept-row backward (autograd of src/finetune_timm_mast3r.py:522-540 / utils/losses.py:5-15 under those masks), the counterpart of
+ * gd_cost_volume_kl_fwd_rows (same masks, same kcap; `stats` as saved by either forward): G = dloss/dS only for
  * the kept rows of each direction ([kcap, hw] and its transpose instead of two [hw, hw] matrices), four batched contractions (kept rows' gradients,
  * scattered back to their rows; the other view's gradient, dense), then the gradient through the L2 normalisation.
  * dtype GD_F32 | GD_BF16: f1, f2, df1, df2 in that type, f1h = f2h = NULL.  dtype GD_F16 (tf32h engine): f1, f2, df1, df2 fp32 and f1h, f2h the fp16
