@@ -48,7 +48,11 @@ SIGNATURES = {
     "gd_gemm_tn_scaled": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_long, c_long,
                                   c_int, c_long, c_long, c_long, c_int, c_int, c_float, c_void_p, c_void_p]),
     "gd_cast_f16": (c_int, [c_void_p, c_void_p, c_long, c_int, c_long, c_float, c_void_p, c_void_p]),
-    "gd_amax_scale": (c_int, [c_void_p, c_long, c_int, c_long, c_float, c_void_p, c_void_p]),
+    "gd_amax_scale": (c_int, [c_void_p, c_long, c_int, c_long, c_float, c_void_p, c_void_p, c_void_p]),
+    "gd_scale_from_amax": (c_int, [c_void_p, c_float, c_void_p, c_void_p]),
+    "gd_cast_f16_ex": (c_int, [c_void_p, c_void_p, c_long, c_int, c_long, c_float, c_void_p, c_void_p, c_void_p]),
+    "gd_layernorm_bwd_ex": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_int, c_int, c_long, c_long, c_float, c_void_p]),
     "gd_gemm_tn": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_long, c_long,
                            c_int, c_long, c_long, c_long, c_int, c_int, c_float, c_void_p]),
     "gd_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_long,
@@ -72,7 +76,7 @@ SIGNATURES = {
     "gd_kp_gather_bwd": (c_int, [ctypes.POINTER(c_void_p), c_int, c_long, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                  c_int, c_float, c_float, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "gd_lora_bwd_fused": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
-    "gd_lora_bwd_fused_scaled": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "gd_lora_bwd_fused_scaled": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "gd_conv_weight_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "gd_kp_patch_bwd_det": (c_int, [c_void_p, c_void_p, c_int, c_long, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                     c_float, c_int, c_int, c_int, c_int, c_void_p]),

@@ -1045,6 +1045,12 @@ __global__ __launch_bounds__(256, 2) void cv_bwd_rows_kernel(CvTileParams q) {
             const int col = tn * 128 + (e >> 7), kk = tm * 128 + (e & 127);
             if (col < hw) GcT[(long)col * kcap + kk] = from_f32<T>(0.f);
         }
+        // ... and so are its Gc rows: the batched GEMM Gc . (other view) contracts every row of the [kcap, hwp] workspace, and what cv_rows_scatter
+        // then skips (k >= cnt) must still not be computed from uninitialised memory (NaN / Inf bit patterns in a torch.empty buffer)
+        for (int e = tid; e < 128 * 128; e += 256) {
+            const int kk = tm * 128 + (e >> 7), col = tn * 128 + (e & 127);
+            if (col < hwp) Gc[(long)kk * hwp + col] = from_f32<T>(0.f);
+        }
         return;
     }
     const float* Tt = (d ? q.t2 : q.t1) + (long)p * hw * ldt;

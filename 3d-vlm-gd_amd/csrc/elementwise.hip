@@ -1020,10 +1020,13 @@ extern "C" int gd_split3(const float* in, void* out, long rows, int K, long ld_i
 
 // ---- fp16 operands of the tf32h engine: x -> f16(sat(x * scale)); the scale of a GRADIENT tensor is a power of two taken from its own
 // maximum on the device (gd_amax_scale), carried to the consuming GEMM as a device scalar (gd_gemm_nt_scaled) — no host round trip.
-__global__ __launch_bounds__(256) void cast_f16_kernel(const float* in, f16* out, long rows, int K, long ld_in, float scale, const float* scale_dev) {
+// range (nullable, 2 words, accumulated): how many results saturated at +-65504 ([0]) / fell below fp16's normal range 2^-14 with a non-zero
+// input ([1]: subnormal — fewer than 11 bits — or flushed to zero).  Counted per thread, one atomic per wave and only when non-zero.
+__global__ __launch_bounds__(256) void cast_f16_kernel(const float* in, f16* out, long rows, int K, long ld_in, float scale, const float* scale_dev, unsigned* range) {
     const int kv = K / 8;
     const long total = rows * kv;
     const float sc = scale_dev ? scale * *scale_dev : scale;
+    unsigned nsat = 0u, nlow = 0u;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const long r = idx / kv;
         const int c = (int)(idx - r * kv) * 8;
@@ -1032,51 +1035,98 @@ __global__ __launch_bounds__(256) void cast_f16_kernel(const float* in, f16* out
 #pragma unroll
         for (int k = 0; k < 4; ++k) { h[k] = from_f32<f16>(a[k] * sc); h[4 + k] = from_f32<f16>(b[k] * sc); }
         *(f16x8*)(out + r * (long)K + c) = h;
+        if (range) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const unsigned u = __builtin_bit_cast(unsigned, (k < 4 ? a[k] : b[k - 4]) * sc) & 0x7fffffffu;
+                nsat += u > 0x477fe000u;
+                nlow += (u < 0x38800000u) & (u != 0u);
+            }
+        }
+    }
+    if (range) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { nsat += (unsigned)__shfl_xor((int)nsat, o, 64); nlow += (unsigned)__shfl_xor((int)nlow, o, 64); }
+        if ((threadIdx.x & 63) == 0 && nsat) atomicAdd(range + 0, nsat);
+        if ((threadIdx.x & 63) == 0 && nlow) atomicAdd(range + 1, nlow);
     }
 }
+// max |in| as a BIT PATTERN (non-negative floats order like their bit patterns, and an Inf / NaN pattern is larger than every finite one: a
+// non-finite element survives the reduction — fmaxf would drop a NaN — and gd_scale_from_amax turns it into a NaN scale that poisons every
+// consumer, as the f32 / bf16 engines' arithmetic would)
 __global__ __launch_bounds__(256) void amax_kernel(const float* in, long rows, int K, long ld_in, unsigned* bits) {
     const int kv = K / 4;
     const long total = rows * kv;
-    float m = 0.f;
+    unsigned m = 0u;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const long r = idx / kv;
         const int c = (int)(idx - r * kv) * 4;
         const f32x4 a = *(const f32x4*)(in + r * ld_in + c);
-        m = fmaxf(fmaxf(m, fmaxf(fabsf(a[0]), fabsf(a[1]))), fmaxf(fabsf(a[2]), fabsf(a[3])));      // fmaxf drops NaNs
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const unsigned u = __builtin_bit_cast(unsigned, a[k]) & 0x7fffffffu; m = u > m ? u : m; }
     }
-    m = wave_max(m);
-    __shared__ float sm[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned w = (unsigned)__shfl_xor((int)m, o, 64); m = w > m ? w : m; }
+    __shared__ unsigned sm[4];
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
     __syncthreads();
-    // one atomic per block (one per wave of 8192 blocks serialised on the single address: 387 us for 270 MB)
-    if (threadIdx.x == 0) atomicMax(bits, __builtin_bit_cast(unsigned, fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]))));   // non-negative floats order like their bit patterns
+    // one atomic per block (one per wave of 8192 blocks serialised on the single address: 387 us for 270 MB), spread over the slots
+    if (threadIdx.x == 0) {
+        const unsigned a = sm[0] > sm[1] ? sm[0] : sm[1], b = sm[2] > sm[3] ? sm[2] : sm[3];
+        atomicMax(bits + (blockIdx.x & 255), a > b ? a : b);
+    }
 }
-// s = the power of two with  target / 2 < amax * s <= target  (1 for an all-zero or non-finite tensor); out = {s, 1 / s}
-__global__ void amax_scale_kernel(const unsigned* bits, float target, float* out) {
-    const float amax = __builtin_bit_cast(float, *bits);
+// slots: 256 words of max-|x| bit patterns (amax_kernel, ln_bwd_kernel); s = the power of two with  target / 2 < amax * s <= target  (1 for an
+// all-zero tensor, NaN for a non-finite maximum); out = {s, 1 / s}.  The slots are zeroed for their next use.
+__global__ __launch_bounds__(256) void amax_scale_kernel(unsigned* slots, float target, float* out) {
+    unsigned m = slots[threadIdx.x];
+    slots[threadIdx.x] = 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned w = (unsigned)__shfl_xor((int)m, o, 64); m = w > m ? w : m; }
+    __shared__ unsigned sm[4];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const unsigned a = sm[0] > sm[1] ? sm[0] : sm[1], b = sm[2] > sm[3] ? sm[2] : sm[3];
+    const unsigned mb = a > b ? a : b;
+    const float amax = __builtin_bit_cast(float, mb);
     float s = 1.0f;
-    if (amax > 0.f && amax < 3.0e38f) s = exp2f(floorf(log2f(target / amax)));
-    s = fminf(fmaxf(s, 1.0f / 16777216.0f / 16777216.0f), 16777216.0f * 16777216.0f * 16777216.0f);  // 2^-48 .. 2^72: s and 1/s stay normal floats
+    if (mb >= 0x7f800000u) s = __builtin_nanf("");
+    else {
+        if (amax > 0.f) s = exp2f(floorf(log2f(target / amax)));
+        s = fminf(fmaxf(s, 1.0f / 16777216.0f / 16777216.0f), 16777216.0f * 16777216.0f * 16777216.0f);  // 2^-48 .. 2^72: s and 1/s stay normal floats
+    }
     out[0] = s;
     out[1] = 1.0f / s;
 }
 
-extern "C" int gd_cast_f16(const float* in, void* out, long rows, int K, long ld_in, float scale, const float* scale_dev, void* stream) {
+extern "C" int gd_cast_f16_ex(const float* in, void* out, long rows, int K, long ld_in, float scale, const float* scale_dev, unsigned* range_counters,
+                              void* stream) {
     GD_REQUIRE(in && out && rows > 0 && K > 0 && K % 8 == 0 && ld_in >= K && ld_in % 4 == 0, "gd_cast_f16: bad arguments (K must be a multiple of 8, ld_in of 4)");
     GD_REQUIRE(((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 15) == 0, "gd_cast_f16: in / out must be 16-byte aligned");
-    hipLaunchKernelGGL(cast_f16_kernel, dim3(ew_blocks(rows * (K / 8))), dim3(256), 0, (hipStream_t)stream, in, (f16*)out, rows, K, ld_in, scale, scale_dev);
+    hipLaunchKernelGGL(cast_f16_kernel, dim3(ew_blocks(rows * (K / 8))), dim3(256), 0, (hipStream_t)stream, in, (f16*)out, rows, K, ld_in, scale, scale_dev, range_counters);
+    GD_LAUNCH_OK();
+    return 0;
+}
+extern "C" int gd_cast_f16(const float* in, void* out, long rows, int K, long ld_in, float scale, const float* scale_dev, void* stream) {
+    return gd_cast_f16_ex(in, out, rows, K, ld_in, scale, scale_dev, nullptr, stream);
+}
+
+extern "C" int gd_scale_from_amax(unsigned* amax_slots, float target, float* scale2, void* stream) {
+    GD_REQUIRE(amax_slots && scale2 && target > 0.f, "gd_scale_from_amax: bad arguments");
+    hipLaunchKernelGGL(amax_scale_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, amax_slots, target, scale2);
     GD_LAUNCH_OK();
     return 0;
 }
 
-extern "C" int gd_amax_scale(const float* in, long rows, int K, long ld_in, float target, float* scale3, void* stream) {
-    GD_REQUIRE(in && scale3 && rows > 0 && K > 0 && K % 4 == 0 && ld_in >= K && ld_in % 4 == 0 && target > 0.f, "gd_amax_scale: bad arguments");
+// scale3 = {s, 1/s, unused}; amax_slots: 256 zeroed words (zeroed again on return) — a caller that keeps one such buffer saves the memset
+extern "C" int gd_amax_scale(const float* in, long rows, int K, long ld_in, float target, float* scale3, unsigned* amax_slots, void* stream) {
+    GD_REQUIRE(in && scale3 && amax_slots && rows > 0 && K > 0 && K % 4 == 0 && ld_in >= K && ld_in % 4 == 0 && target > 0.f, "gd_amax_scale: bad arguments");
     GD_REQUIRE(((uintptr_t)in & 15) == 0, "gd_amax_scale: in must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(scale3 + 2, 0, 4, st) != hipSuccess) { gd_set_error("gd_amax_scale: memset failed"); return -2; }
     { const int nb = ew_blocks(rows * (K / 4));
-      hipLaunchKernelGGL(amax_kernel, dim3(nb > 2048 ? 2048 : nb), dim3(256), 0, st, in, rows, K, ld_in, (unsigned*)(scale3 + 2)); }
-    hipLaunchKernelGGL(amax_scale_kernel, dim3(1), dim3(1), 0, st, (const unsigned*)(scale3 + 2), target, scale3);
+      hipLaunchKernelGGL(amax_kernel, dim3(nb > 2048 ? 2048 : nb), dim3(256), 0, st, in, rows, K, ld_in, amax_slots); }
+    hipLaunchKernelGGL(amax_scale_kernel, dim3(1), dim3(256), 0, st, amax_slots, target, scale3);
     GD_LAUNCH_OK();
     return 0;
 }

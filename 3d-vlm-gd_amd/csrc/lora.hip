@@ -19,6 +19,7 @@ struct LoraBwdParams {
     // tf32h engine (fp16 operands): t is multiplied by *t_mul before it is split into its high and low 16-bit parts (a gradient in the t role goes
     // in under the step's power-of-two scale s), dt and the gbt partial by *out_mul on the way out (1 / s: X or t carried s).  null = 1.
     const float* t_mul; const float* out_mul;
+    int dt_scaled;                  // 1: dt leaves WITHOUT *out_mul (still in X's scaled domain: the consumers take it under s anyway)
 };
 
 #define LB_ROWS 64
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = chunk * LB_ROWS + 16 * wave + 4 * g + r;
-                if (m < p.M) p.dt[(long)m * 8 + c] = dacc[r] * omul;
+                if (m < p.M) p.dt[(long)m * 8 + c] = dacc[r] * (p.dt_scaled ? 1.0f : omul);
             }
         }
     }
@@ -174,16 +175,16 @@ extern "C" int gd_lora_bwd_fused(const void* dqv, long ldx, const float* t, cons
                                  void* stream) {
     GD_REQUIRE(M > 0 && K > 0 && K % LB_SLAB == 0 && K / LB_SLAB <= 8 && ldx % 8 == 0, "gd_lora_bwd_fused: K must be a multiple of 256 (<= 2048), ldx of 8");
     GD_REQUIRE(((uintptr_t)dqv & 15) == 0 && ((uintptr_t)bt & 15) == 0 && t && gbt && (dt || !bt), "gd_lora_bwd_fused: alignment / null pointers");
-    LoraBwdParams p = {dqv, ldx, t, bt, dt, gbt, M, K, nullptr, nullptr};
+    LoraBwdParams p = {dqv, ldx, t, bt, dt, gbt, M, K, nullptr, nullptr, 0};
     return lora_bwd_launch<bf16>(p, (hipStream_t)stream);
 }
 
 // the same pass on either 16-bit operand type, with the tf32h engine's device-side scales (LoraBwdParams): dtype GD_BF16 | GD_F16
 extern "C" int gd_lora_bwd_fused_scaled(const void* dqv, long ldx, const float* t, const void* bt, float* dt, float* gbt, int M, int K, int dtype,
-                                        const float* t_mul_dev, const float* out_mul_dev, void* stream) {
+                                        const float* t_mul_dev, const float* out_mul_dev, int dt_scaled, void* stream) {
     GD_REQUIRE(M > 0 && K > 0 && K % LB_SLAB == 0 && K / LB_SLAB <= 8 && ldx % 8 == 0, "gd_lora_bwd_fused_scaled: K must be a multiple of 256 (<= 2048), ldx of 8");
     GD_REQUIRE(((uintptr_t)dqv & 15) == 0 && ((uintptr_t)bt & 15) == 0 && t && gbt && (dt || !bt), "gd_lora_bwd_fused_scaled: alignment / null pointers");
     GD_REQUIRE(dtype == GD_BF16 || dtype == GD_F16, "gd_lora_bwd_fused_scaled: operands are bf16 or fp16 (dtype %d)", dtype);
-    LoraBwdParams p = {dqv, ldx, t, bt, dt, gbt, M, K, t_mul_dev, out_mul_dev};
+    LoraBwdParams p = {dqv, ldx, t, bt, dt, gbt, M, K, t_mul_dev, out_mul_dev, dt_scaled};
     return dtype == GD_F16 ? lora_bwd_launch<f16>(p, (hipStream_t)stream) : lora_bwd_launch<bf16>(p, (hipStream_t)stream);
 }

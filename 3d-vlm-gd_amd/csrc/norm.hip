@@ -65,15 +65,38 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* x, const float* ga
     }
 }
 
+template <> __device__ __forceinline__ f32x4 load4<f16>(const f16* p) {
+    const f16x4 v = *(const f16x4*)p;
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+// max over the 64 lanes of non-negative-float bit patterns (integer order = float order, and a NaN / Inf pattern beats every finite one)
+__device__ __forceinline__ unsigned wave_umax(unsigned v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned w = (unsigned)__shfl_xor((int)v, o, 64); v = w > v ? w : v; }
+    return v;
+}
+__device__ __forceinline__ unsigned wave_uadd(unsigned v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += (unsigned)__shfl_xor((int)v, o, 64);
+    return v;
+}
+#define GD_AMAX_SLOTS 256
+
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;  dx += dres when given
+// tf32h extras (gd_layernorm_bwd_ex): dy may arrive as fp16 under a device-side power-of-two scale (dys = 1 / s undoes it); dx also leaves as
+// fp16(dx * *sdev) (the next product's operand); `amax` (GD_AMAX_SLOTS words) receives max |dx| bit patterns — the NEXT block's gradient scale
+// without a pass of its own (one atomicMax per wave, spread over the slots, skipped when the slot already holds a larger value); `range`
+// counts the fp16 copies that saturated ([0]) or fell below fp16's normal range ([1]: subnormal or flushed, the input not zero).
 template <typename T, typename TD, int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* dy, const T* x, const float* gamma, const float* mean,
                                                      const float* rstd, const T* dres, const T* dres2, T* dx, int M, int D,
-                                                     long ldd, long ldx, float dyscale, f16* dx16 = nullptr, const float* sdev = nullptr) {
+                                                     long ldd, long ldx, float dyscale, f16* dx16 = nullptr, const float* sdev = nullptr,
+                                                     const float* dys_dev = nullptr, unsigned* amax = nullptr, unsigned* range = nullptr) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const float mu = mean[row], rs = rstd[row];
     const float s16 = (dx16 && sdev) ? *sdev : 1.0f;      // gd_layernorm_bwd_cast: dx also leaves as fp16(dx * s), the next product's operand
+    if (dys_dev) dyscale *= *dys_dev;
     const T* xr = x + (long)row * ldx;
     const TD* dr = dy + (long)row * ldd;
     f32x4 xh[NV], g[NV];
@@ -95,6 +118,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* dy, const T* x, c
     s1 = wave_sum(s1) / (float)D;
     s2 = wave_sum(s2) / (float)D;
     T* or_ = dx + (long)row * ldx;
+    unsigned mb = 0u, nsat = 0u, nlow = 0u;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = (lane + 64 * i) * 4;
@@ -113,8 +137,33 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* dy, const T* x, c
                 for (int k = 0; k < 4; ++k) o[k] += r[k];
             }
             store4n<T>(or_ + c, o);
-            if (dx16) store4n<f16>(dx16 + (long)row * D + c, o * s16);
+            if (amax) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const unsigned b = __builtin_bit_cast(unsigned, o[k]) & 0x7fffffffu; mb = b > mb ? b : mb; }
+            }
+            if (dx16) {
+                const f32x4 os = o * s16;
+                store4n<f16>(dx16 + (long)row * D + c, os);
+                if (range) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const unsigned b = __builtin_bit_cast(unsigned, os[k]) & 0x7fffffffu;
+                        nsat += b > 0x477fe000u;                        // |v| > 65504 (Inf / NaN included)
+                        nlow += (b < 0x38800000u) & (b != 0u);          // 0 < |v| < 2^-14
+                    }
+                }
+            }
         }
+    }
+    if (amax) {
+        mb = wave_umax(mb);
+        unsigned* slot = amax + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (GD_AMAX_SLOTS - 1));
+        if (lane == 0 && mb > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, mb);
+    }
+    if (range) {
+        nsat = wave_uadd(nsat); nlow = wave_uadd(nlow);
+        if (lane == 0 && nsat) atomicAdd(range + 0, nsat);
+        if (lane == 0 && nlow) atomicAdd(range + 1, nlow);
     }
 }
 
@@ -318,6 +367,25 @@ extern "C" int gd_layernorm_bwd_cast(const float* dy, const float* x, const floa
     hipStream_t s = (hipStream_t)stream;
 #define B_FH(NV) hipLaunchKernelGGL((ln_bwd_kernel<float, float, NV>), grid, blk, 0, s, dy, x, gamma, mean, rstd, dres, dres2, dx, M, D, ldd, ldx, dyscale, (f16*)dx16, scale_dev)
     LN_DISPATCH_NV(D, B_FH);
+    GD_LAUNCH_OK();
+    return 0;
+}
+
+// The tf32h block backward's LayerNorm pass with every device-side extra (kernel comment above): dy f32 or fp16 (dy_dtype) times *dy_scale_dev,
+// dx16 / cast_scale_dev as gd_layernorm_bwd_cast (dx16 nullable here), amax_slots (GD_AMAX_SLOTS = 256 words, zeroed by gd_scale_from_amax after
+// each use) and range_counters (2 words, accumulated) nullable.
+extern "C" int gd_layernorm_bwd_ex(const void* dy, int dy_dtype, const float* dy_scale_dev, const float* x, const float* gamma, const float* mean,
+                                   const float* rstd, const float* dres, const float* dres2, float* dx, void* dx16, const float* cast_scale_dev,
+                                   unsigned* amax_slots, unsigned* range_counters, int M, int D, long ldd, long ldx, float dyscale, void* stream) {
+    GD_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * LN_MAXV, "gd_layernorm_bwd_ex: D=%d must be a multiple of 4 and <= 2048", D);
+    GD_REQUIRE(ldx % 4 == 0 && ldd % 4 == 0, "gd_layernorm_bwd_ex: row strides must be multiples of 4 elements");
+    GD_REQUIRE(dy_dtype == GD_F32 || dy_dtype == GD_F16, "gd_layernorm_bwd_ex: dy is f32 or fp16 (dy_dtype %d)", dy_dtype);
+    GD_REQUIRE(((uintptr_t)dy & 7) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)dx & 15) == 0, "gd_layernorm_bwd_ex: alignment");
+    dim3 grid(gd_cdiv(M, 4)), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+#define B_XF(NV) hipLaunchKernelGGL((ln_bwd_kernel<float, float, NV>), grid, blk, 0, s, (const float*)dy, x, gamma, mean, rstd, dres, dres2, dx, M, D, ldd, ldx, dyscale, (f16*)dx16, cast_scale_dev, dy_scale_dev, amax_slots, range_counters)
+#define B_XH(NV) hipLaunchKernelGGL((ln_bwd_kernel<float, f16, NV>), grid, blk, 0, s, (const f16*)dy, x, gamma, mean, rstd, dres, dres2, dx, M, D, ldd, ldx, dyscale, (f16*)dx16, cast_scale_dev, dy_scale_dev, amax_slots, range_counters)
+    if (dy_dtype == GD_F16) LN_DISPATCH_NV(D, B_XH); else LN_DISPATCH_NV(D, B_XF);
     GD_LAUNCH_OK();
     return 0;
 }

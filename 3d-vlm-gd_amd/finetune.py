@@ -160,6 +160,27 @@ class FinetuneGD(nn.Module):
             self._apply_optimizer_state(st)
         return self._flat
 
+    # ------------------------------------------------------------------ tf32h: the range contract, observed
+    def _range_counters(self):
+        """Two device counters every scaled fp16 gradient cast of the tf32h engine adds to (ops.set_range_counters): operands that saturated at
+        +-65504, and non-zero operands that fell below fp16's normal range (2^-14 after the block's power-of-two scale: fewer than 11 bits, or
+        flushed).  Device-side, one atomic per wave and only when a count is non-zero: nothing here synchronises."""
+        if getattr(self, "_range", None) is None:
+            dev = next(self.parameters()).device
+            self._range = torch.zeros(2, dtype=torch.int32, device=dev)
+        return self._range
+
+    def range_report(self, reset=True):
+        """{'saturated': n, 'below_normal': n} since the last reset (ONE host read: call it every N steps, not every step).  A healthy run
+        reports saturated == 0; below_normal counts gradient entries more than 2^17 under their block's largest one, which a TF32 tensor core
+        would still have carried at full precision (the range contract)."""
+        if getattr(self, "_range", None) is None:
+            return {"saturated": 0, "below_normal": 0}
+        v = self._range.tolist()
+        if reset:
+            self._range.zero_()
+        return {"saturated": int(v[0]), "below_normal": int(v[1])}
+
     def zero_grad_flat(self):
         self._flat["g"].zero_()
 
@@ -399,6 +420,7 @@ class FinetuneGD(nn.Module):
         pts3d_1, pts3d_2 [P,N,3]; depth_1, depth_2 [P,h,w]; cost_1, cost_2 [P,hw,hw];
         mask_1, mask_2 [P,h,w] bool (vggt)."""
         self.clear_cache()
+        ops.set_range_counters(self._range_counters() if getattr(self.model, "opfmt", "") == "h" else None)
         # per-step pack of the LoRA / adapter weights (dropped again below: never stale).  direct_grads (fit_step): built from
         # views of the flat parameter buffer, and the blocks write their weight gradients into the flat gradient buffer — the
         # caller must then use `self.backward(loss)` (it zeroes that buffer first and finishes the LoRA-B transposes)

@@ -167,22 +167,62 @@ def copy16_ok(M, N, K):
     return M >= 1024 and N >= 256 and N % 8 == 0 and K % 64 == 0
 
 
+# ---- tf32h range bookkeeping (device side; nothing here synchronises) ------------------------------------------------------------------
+# _RANGE: the engine's two range counters (saturated / below-normal-range fp16 gradient operands; FinetuneGD.range_report reads them), or
+# None.  _SLOTS: per device, the 256-word max-|x| scratch the amax kernels share (every user leaves it zeroed).  _AMAX: scales that a
+# producer computed for the tensor it returned (layernorm_bwd(want_amax=True)), keyed by the tensor's address until its consumer takes it.
+_RANGE = None
+_SLOTS = {}
+_AMAX = {}
+GRAD_TARGET = 8.0      # |gradient| * s <= 8: 2^13 of fp16 headroom above the block's incoming gradient, 2^17 of full-precision range below
+
+
+def set_range_counters(t):
+    """t: a zeroed int32 CUDA tensor [2] (or None): every scaled fp16 cast of the tf32h engine adds its saturated / below-normal-range counts."""
+    global _RANGE
+    _RANGE = t
+
+
+def _slots(dev):
+    t = _SLOTS.get(dev)
+    if t is None:
+        t = _SLOTS[dev] = torch.zeros(256, dtype=torch.int32, device=dev)
+    return t
+
+
+def amax_register(t, sc):
+    _AMAX[t.data_ptr()] = (sc, t.numel())
+
+
+def amax_take(t):
+    """the scale a producer registered for exactly this tensor (popped), or None."""
+    rec = _AMAX.pop(t.data_ptr(), None)
+    return rec[0] if rec is not None and rec[1] == t.numel() else None
+
+
+def amax_clear():
+    _AMAX.clear()
+
+
 def cast16(x, scale=1.0, scale_dev=None):
     """f32 [rows, K] (rows may be strided) -> fp16 [rows, K] = sat(x * scale * scale_dev[0]): an operand of the tf32h engine's products (fp16
-    carries TF32's 11-bit significand).  Forward activations and weights go in unscaled; gradients with the power of two of `amax_scale`."""
+    carries TF32's 11-bit significand).  Forward activations and weights go in unscaled; gradients with the power of two of `amax_scale`
+    (those casts are counted in the range counters, when the engine has registered a pair)."""
     _req(x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1, "cast16: a 2-D fp32 CUDA tensor with contiguous rows")
     rows, K = x.shape
     out = torch.empty(rows, K, dtype=torch.float16, device=x.device)
-    check(lib().gd_cast_f16(ptr(x), ptr(out), rows, K, x.stride(0), float(scale), ptr(scale_dev), stream()), "gd_cast_f16")
+    rng = _RANGE if (scale_dev is not None and _RANGE is not None and _RANGE.device == x.device) else None
+    check(lib().gd_cast_f16_ex(ptr(x), ptr(out), rows, K, x.stride(0), float(scale), ptr(scale_dev), ptr(rng), stream()), "gd_cast_f16_ex")
     return out
 
 
 def amax_scale(x, target=64.0):
-    """-> device fp32 [3] = {s, 1/s, scratch}: s the power of two with target/2 < max|x| * s <= target (1 for an all-zero tensor).  No host
-    round trip: s goes to `cast16(scale_dev=r[0:1])`, 1/s to `gemm_nt(alpha_dev=r[1:2])`."""
+    """-> device fp32 [3] = {s, 1/s, unused}: s the power of two with target/2 < max|x| * s <= target (1 for an all-zero tensor, NaN when x holds
+    a non-finite element: every product scaled with it is then NaN, as it would be in fp32).  No host round trip: s goes to
+    `cast16(scale_dev=r[0:1])`, 1/s to `gemm_nt(alpha_dev=r[1:2])`."""
     _req(x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1, "amax_scale: a 2-D fp32 CUDA tensor with contiguous rows")
     out = torch.empty(3, dtype=torch.float32, device=x.device)
-    check(lib().gd_amax_scale(ptr(x), x.shape[0], x.shape[1], x.stride(0), float(target), ptr(out), stream()), "gd_amax_scale")
+    check(lib().gd_amax_scale(ptr(x), x.shape[0], x.shape[1], x.stride(0), float(target), ptr(out), ptr(_slots(x.device)), stream()), "gd_amax_scale")
     return out
 
 
@@ -269,7 +309,7 @@ class _CostVolumeKL(torch.autograd.Function):
         if inv1 is not None:
             _req(inv1.shape == (P, hw) and inv2.shape == (P, hw) and inv1.dtype == torch.float32 and inv2.dtype == torch.float32 and
                  inv1.is_contiguous() and inv2.is_contiguous(), "cost_volume_kl: inv_norms must be two contiguous fp32 [P, hw] tensors")
-            ctx.h16 = None
+            h16_saved = None
             rows = kcap > 0 and tstats is not None and ldt % 4 == 0      # sparse row masks: the kept-row kernel (gd_cost_volume_kl_fwd_rows)
 
             ctx.kcap = 0
@@ -291,7 +331,7 @@ class _CostVolumeKL(torch.autograd.Function):
                 else:
                     a16, b16 = cast16(f1.view(P * hw, C)), cast16(f2.view(P * hw, C))
                 rc = fwd(a16, b16, C, 3)
-                ctx.h16 = (a16, b16)
+                h16_saved = (a16, b16)
             elif x3 and f1.dtype == torch.float32 and C % 8 == 0:
                 # tf32x: S = f1 . f2^T as three bf16 MFMA products of the (hi, lo) splits on the bf16 tile kernel (K = 3C) instead of the
                 # exact-f32 MFMA; the row norms stay those of the f32 rows, and the backward (which recomputes S in f32) reads the same
@@ -306,16 +346,20 @@ class _CostVolumeKL(torch.autograd.Function):
             rc = lib().gd_cost_volume_kl_fwd(ptr(f1), ptr(f2), ptr(t1), ptr(t2), ldt, ptr(tstats), ptr(m1), ptr(m2), P, hw, C,
                                              VARIANTS[variant], dt, ptr(loss), ptr(stats), ptr(ws), stream())
         check(rc, "gd_cost_volume_kl_fwd")
-        ctx.save_for_backward(f1, f2, t1, t2, m1, m2, stats)
+        # (the fp16 feature copies are saved tensors like the rest — autograd's lifetime and version checks apply to them; ctx keeps plain ints only)
+        if inv1 is None:
+            h16_saved, ctx.kcap = None, 0
+        ctx.has_h16 = h16_saved is not None
+        ctx.save_for_backward(f1, f2, t1, t2, m1, m2, stats, *(h16_saved or ()))
         return loss
 
     @staticmethod
     def backward(ctx, gloss):
-        f1, f2, t1, t2, m1, m2, stats = ctx.saved_tensors
+        f1, f2, t1, t2, m1, m2, stats = ctx.saved_tensors[:7]
+        h = tuple(ctx.saved_tensors[7:9]) if ctx.has_h16 else None
         P, hw, C = f1.shape
-        kcap = getattr(ctx, "kcap", 0)
+        kcap = ctx.kcap
         if kcap and option("cv_bwd_rows"):      # sparse row masks: G only for the kept rows of each direction (gd_cost_volume_kl_bwd_rows)
-            h = getattr(ctx, "h16", None)
             code = 3 if h is not None else dtype_code(f1)
             dfull = torch.empty((2 * P, hw, C), dtype=f1.dtype, device=f1.device)
             ws = torch.empty(lib().gd_cost_volume_kl_bwd_rows_workspace_bytes(P, hw, C, kcap, code), dtype=torch.uint8, device=f1.device)
@@ -324,8 +368,8 @@ class _CostVolumeKL(torch.autograd.Function):
                                                   ptr(m1), ptr(m2), P, hw, C, kcap, code, ptr(g), ptr(stats), ptr(dfull[:P]), ptr(dfull[P:]), ptr(ws), stream())
             check(rc, "gd_cost_volume_kl_bwd_rows")
             return dfull[:P], dfull[P:], None, None, None, None, None, None, None, None, None, None, None
-        if getattr(ctx, "h16", None) is not None:      # tf32h: fp16 S recompute and G contractions, fp32 gradient through the normalisation
-            a16, b16 = ctx.h16
+        if h is not None:      # tf32h: fp16 S recompute and G contractions, fp32 gradient through the normalisation
+            a16, b16 = h
             dfull = torch.empty((2 * P, hw, C), dtype=torch.float32, device=f1.device)
             ws = torch.empty(lib().gd_cost_volume_kl_bwd_h_workspace_bytes(P, hw, C), dtype=torch.uint8, device=f1.device)
             g = gloss.contiguous().float()
@@ -494,19 +538,28 @@ def layernorm_fwd(x, gamma, beta, eps, *, save_stats=True, out_dtype=None):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, dyscale=1.0, dres2=None, cast_scale=None):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, dyscale=1.0, dres2=None, cast_scale=None, dy_scale=None, want_amax=False):
     """dx [M,D] (dtype of x) = LN'(dy * dyscale) (+ dres) (+ dres2).  cast_scale (fp32 tensors; a device scalar, e.g. amax_scale(...)[0:1]):
-    also returns fp16(dx * cast_scale) — (dx, dx16) — the tf32h engine's next left operand, from the same pass."""
+    also returns fp16(dx * cast_scale) — (dx, dx16) — the tf32h engine's next left operand, from the same pass.
+    tf32h extras (fp32 x): dy may be fp16 with dy_scale (a device scalar multiplied in: 1/s of a gradient kept in its scaled domain);
+    want_amax: the pass also takes max |dx| and the scale for the tensor's consumer is registered under it (`amax_take`)."""
     M, D = x.shape
-    if cast_scale is not None:
-        _req(x.is_contiguous() and x.dtype == torch.float32 and dy.dtype == torch.float32 and dy.stride(-1) == 1 and
+    if cast_scale is not None or dy_scale is not None or want_amax or dy.dtype == torch.float16:
+        _req(x.is_contiguous() and x.dtype == torch.float32 and dy.dtype in (torch.float32, torch.float16) and dy.stride(-1) == 1 and
              all(t is None or (t.is_contiguous() and t.dtype == x.dtype and t.numel() == x.numel()) for t in (dres, dres2)),
-             "layernorm_bwd(cast_scale=): fp32 tensors, contiguous")
+             "layernorm_bwd (tf32h form): fp32 x / dres, fp32 or fp16 dy, contiguous")
         dx = torch.empty_like(x)
-        dx16 = torch.empty(M, D, dtype=torch.float16, device=x.device)
-        check(lib().gd_layernorm_bwd_cast(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dres2), ptr(dx), ptr(dx16),
-                                          ptr(cast_scale), M, D, dy.stride(0), x.stride(0), float(dyscale), stream()), "gd_layernorm_bwd_cast")
-        return dx, dx16
+        dx16 = torch.empty(M, D, dtype=torch.float16, device=x.device) if cast_scale is not None else None
+        slots = _slots(x.device) if want_amax else None
+        rng = _RANGE if (dx16 is not None and _RANGE is not None and _RANGE.device == x.device) else None
+        check(lib().gd_layernorm_bwd_ex(ptr(dy), dtype_code(dy), ptr(dy_scale), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dres2), ptr(dx),
+                                        ptr(dx16), ptr(cast_scale), ptr(slots), ptr(rng), M, D, dy.stride(0), x.stride(0), float(dyscale), stream()),
+              "gd_layernorm_bwd_ex")
+        if want_amax:
+            sc = torch.empty(3, dtype=torch.float32, device=x.device)
+            check(lib().gd_scale_from_amax(ptr(slots), GRAD_TARGET, ptr(sc), stream()), "gd_scale_from_amax")
+            amax_register(dx, sc)
+        return (dx, dx16) if cast_scale is not None else dx
     _req(x.is_contiguous() and dy.stride(-1) == 1 and all(t is None or (t.is_contiguous() and t.dtype == x.dtype and
                                                                         t.numel() == x.numel()) for t in (dres, dres2)),
          "layernorm_bwd: layout")
@@ -625,14 +678,15 @@ def skinny_tn_mfma(t, x, out):
     return out
 
 
-def lora_bwd_fused_h(dqv, t, bt_qv, gbt, t_mul=None, out_mul=None):
+def lora_bwd_fused_h(dqv, t, bt_qv, gbt, t_mul=None, out_mul=None, dt_scaled=False):
     """The fused LoRA backward on fp16 operands (tf32h engine): dqv [M, K] fp16 view, t [M, 8] f32, bt_qv [8, K] fp16 or None (then only
     gbt [8, K] f32 += (t * t_mul)^T . dqv * out_mul), t_mul / out_mul: one-element device tensors (the step's gradient scale s and 1 / s) or None
-    -> dt [M, 8] f32 = dqv . bt_qv^T * out_mul (None without bt_qv).  gd_lora_bwd_fused_scaled."""
+    -> dt [M, 8] f32 = dqv . bt_qv^T * out_mul (None without bt_qv); dt_scaled: dt without out_mul (still in dqv's scaled domain).
+    gd_lora_bwd_fused_scaled."""
     M, K = dqv.shape
     dt = torch.empty(M, 8, dtype=torch.float32, device=dqv.device) if bt_qv is not None else None
     check(lib().gd_lora_bwd_fused_scaled(ptr(dqv), dqv.stride(0), ptr(t), ptr(bt_qv), ptr(dt), ptr(gbt), M, K, dtype_code(dqv), ptr(t_mul), ptr(out_mul),
-                                         stream()), "gd_lora_bwd_fused_scaled")
+                                         1 if dt_scaled else 0, stream()), "gd_lora_bwd_fused_scaled")
     return dt
 
 

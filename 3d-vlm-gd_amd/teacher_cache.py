@@ -109,15 +109,19 @@ class TeacherTargetCache:
 
     def collate(self, keys, rgb_1, rgb_2):
         """-> batch dict for FinetuneGD.training_step: cached targets of `keys` stacked, keypoints padded with -1 to the
-        longest set, `counts` int32 [P].  Pairs cached as empty (no keypoint survived) are left out together with their
-        rows of rgb_1 / rgb_2; None when nothing is left (the caller skips the step, as the reference does)."""
-        keep = [i for i, k in enumerate(keys) if not self._d[k].get("_empty")]
-        if not keep:
+        longest set, `counts` int32 [P].  A pair cached as empty (no keypoint survived) STAYS in the batch with counts = 0 — the
+        reference counts such a step as a zero-loss sample (src/finetune_timm_mast3r.py:604-607) and so does training_step's
+        `torch.where(counts > 0, ...)` before the mean: the divisor, the rows of rgb_1 / rgb_2 and, under data parallelism, every
+        rank's P stay what the caller passed.  Its dense targets are borrowed from a non-empty pair of the batch (they are never
+        evaluated into the loss).  None when every pair is empty (the caller skips the step, as the reference does)."""
+        live = [self._d[k] for k in keys if not self._d[k].get("_empty")]
+        if not live:
             return None
-        if len(keep) != len(keys):
-            idx = torch.tensor(keep, device=rgb_1.device)
-            rgb_1, rgb_2 = rgb_1.index_select(0, idx), rgb_2.index_select(0, idx)
-        es = [self._d[keys[i]] for i in keep]
+        empty = dict(live[0])
+        empty["kp_1"], empty["kp_2"] = live[0]["kp_1"][:0], live[0]["kp_2"][:0]
+        if "pts3d_1" in empty:
+            empty["pts3d_1"], empty["pts3d_2"] = live[0]["pts3d_1"][:0], live[0]["pts3d_2"][:0]
+        es = [empty if self._d[k].get("_empty") else self._d[k] for k in keys]
         n = [int(e["kp_1"].shape[0]) for e in es]
         N = max(max(n), 1)
 

@@ -250,18 +250,16 @@ class _BlockFn(torch.autograd.Function):
         dx2, dx2a = dout, None
         tw = ctx.tw
         fmt = plan["x3"]
-        # tf32h: ONE power-of-two scale per block, from the incoming gradient's maximum (on the device), carries every gradient operand of
-        # the block into fp16's range: |dout| * s <= 8 leaves 2^13 of headroom above and 2^17 of full-precision range below
-        # (with a per-step pack the scale is taken ONCE, by the first block that runs its backward — the last ViT block — and shared down the stack)
+        # tf32h: ONE power-of-two scale per BLOCK, from the incoming gradient's maximum (on the device), carries every gradient operand of
+        # the block into fp16's range: |dout| * s <= 8 leaves 2^13 of headroom above and 2^17 of full-precision range below.  The maximum
+        # comes for free: the LayerNorm backward that PRODUCED dout (the block above, or a tap's) took it on its way out and registered the
+        # scale under the tensor (ops.layernorm_bwd(want_amax=True)); only a gradient that arrives from elsewhere (the loss side of the top
+        # block of each backward graph) costs a pass of its own.  A non-finite dout makes s NaN: every gradient of the block is then NaN.
         sc = None
         if fmt == "h":
-            holder = tw.get("gs") if tw is not None else None
-            if holder is not None and holder[0] is not None:
-                sc = holder[0]
-            else:
-                sc = ops.amax_scale(dout.view(-1, D), 8.0)
-                if holder is not None:
-                    holder[0] = sc
+            sc = ops.amax_take(dout)
+            if sc is None:
+                sc = ops.amax_scale(dout.view(-1, D), ops.GRAD_TARGET)
         # the four weight-gradient accumulators of the block come out of ONE zero-filled buffer
         bott = down.shape[0] if ctx.has_ad else 0
         r2 = at.shape[0] if ctx.has_lora else 0
@@ -315,10 +313,13 @@ class _BlockFn(torch.autograd.Function):
         hs = bool(fmt) and ops.split_out_ok(dx2.shape[0], plan["w2_t"].shape[0], plan["w2_t"].shape[1]) and (fmt != "h" or pre.dtype == torch.float16)
         hkw = {} if not hs else {"out_split": True} if fmt == "x3" else {"out_dtype": torch.float16}      # (tf32h: fp16, still times s)
         dpre = _mm(dx2, plan, "w2_t", xs=dx2a, sc=sc, dact_src=pre, dact=3, **hkw)                # [M, 4D] (x stored GELU')
-        dy2 = _mm(None if hs else dpre, plan, "w1_t", xs=dpre if hs else None, sc=sc)
+        # tf32h: the two dX products that feed a LayerNorm backward leave as fp16 IN THE SCALED DOMAIN (half the C bytes written and read
+        # again; the LayerNorm backward multiplies 1/s back in and does its arithmetic in fp32)
+        h16dy = fmt == "h" and hs and bool(option("h16_dy"))
+        dy2 = _mm(None if hs else dpre, plan, "w1_t", xs=dpre if hs else None, sc=sc, **({"out_dtype": torch.float16} if h16dy else {}))
         del dpre
         if fmt == "h":      # the LN backward also writes fp16(dx1 * s), the left operand of the projection's backward; do leaves as fp16, times s
-            dx1, dx1h = ops.layernorm_bwd(dy2, x1, plan["ln2_w"], mean2, rstd2, dres=dx2, cast_scale=sc[0:1])
+            dx1, dx1h = ops.layernorm_bwd(dy2, x1, plan["ln2_w"], mean2, rstd2, dres=dx2, cast_scale=sc[0:1], dy_scale=sc[1:2] if h16dy else None)
             do = _mm(None, plan, "wproj_t", xs=dx1h, sc=sc, out_dtype=torch.float16)
             del dx1h
         else:
@@ -333,14 +334,18 @@ class _BlockFn(torch.autograd.Function):
             bt_qv = tw["bt_qv"] if tw is not None else torch.cat([bt_T[:, :D], bt_T[:, 2 * D:]], 1).contiguous()   # [2r, 2D]
             dqv = dqkv[:, :2 * D]
             gat = None
+            dt_is_scaled = False
             if fmt == "h" and sc is not None and y1.dtype == torch.float16 and ops.lora_bwd_fused_h_supported(dqv, t, None, z_bt):
                 # tf32h: both LoRA-backward products in one pass over the fp16 (dq, dv) block (it carries the step's scale s: results times 1 / s),
                 # then the LoRA-A gradient dt^T . LN(x) on the same kernel with dt going in under s
-                dt = ops.lora_bwd_fused_h(dqv, t, ops.cast16(bt_qv.float().contiguous()), z_bt, out_mul=sc[1:2])
+                # (dt stays in the scaled domain with h16dy: both of its consumers — the LoRA-A gradient and the rank update of the dX GEMM —
+                #  take it under s)
+                dt = ops.lora_bwd_fused_h(dqv, t, ops.cast16(bt_qv.float().contiguous()), z_bt, out_mul=sc[1:2], dt_scaled=h16dy)
                 gbt = z_bt
-                ops.lora_bwd_fused_h(y1, dt, None, z_at, t_mul=sc[0:1], out_mul=sc[1:2])
+                ops.lora_bwd_fused_h(y1, dt, None, z_at, t_mul=None if h16dy else sc[0:1], out_mul=sc[1:2])
                 gat = z_at
                 dqkv_s = dqkv
+                dt_is_scaled = h16dy
             elif fmt:
                 ad = None if sc is None else sc[1:2]
                 if ctx.needs_input_grad[0]:
@@ -378,10 +383,17 @@ class _BlockFn(torch.autograd.Function):
         if not ctx.needs_input_grad[0]:   # first trainable block: nothing below it learns, skip dX (one GEMM + one LN backward)
             return None, None, None, None, g_aq, g_bq, g_av, g_bv, g_down, g_up
         if ctx.has_lora:
-            dy1 = _mm(dqkv, plan, "wqkv_t_qvk", xs=dqkv_s if fmt else None, sc=sc, lora_t=dt, lora_b=at.contiguous())   # dqkv.W + dt.At
+            # (fp16 dy1: dqkv_s . W + dt_s . At, everything under s — the LoRA rank update needs dt in the same domain as the main product)
+            h16dy1 = h16dy and dt_is_scaled
+            dy1 = _mm(dqkv, plan, "wqkv_t_qvk", xs=dqkv_s if fmt else None, sc=sc, lora_t=dt, lora_b=at.contiguous(),   # dqkv.W + dt.At
+                      **({"out_dtype": torch.float16} if h16dy1 else {}))
         else:
-            dy1 = _mm(dqkv, plan, "wqkv_t_qvk", sc=sc)
-        dx = ops.layernorm_bwd(dy1, x, plan["ln1_w"], mean1, rstd1, dres=dx1)
+            h16dy1 = h16dy and dqkv.dtype == torch.float16
+            dy1 = _mm(dqkv, plan, "wqkv_t_qvk", xs=dqkv if dqkv.dtype == torch.float16 else None, sc=sc, **({"out_dtype": torch.float16} if h16dy1 else {}))
+        if fmt == "h":      # max |dx| rides along: the block below takes its gradient scale from it without a pass of its own
+            dx = ops.layernorm_bwd(dy1, x, plan["ln1_w"], mean1, rstd1, dres=dx1, dy_scale=sc[1:2] if dy1.dtype == torch.float16 else None, want_amax=True)
+        else:
+            dx = ops.layernorm_bwd(dy1, x, plan["ln1_w"], mean1, rstd1, dres=dx1)
         return dx, None, None, None, g_aq, g_bq, g_av, g_bv, g_down, g_up
 
 
@@ -437,8 +449,9 @@ class _TapFn(torch.autograd.Function):
     pass-through gradients into the LayerNorm backward kernel as residuals (one pass)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, eps, out_dtype=None):
+    def forward(ctx, x, w, b, eps, out_dtype=None, amax=False):
         shp = x.shape
+        ctx.amax = bool(amax)      # tf32h: the summed gradient is the block below's dout — take its maximum on the way out
         x2 = x.reshape(-1, shp[-1]).contiguous()
         wf, bf = w.detach().float().contiguous(), b.detach().float().contiguous()
         y, mean, rstd = ops.layernorm_fwd(x2, wf, bf, eps, save_stats=x.requires_grad, out_dtype=out_dtype)
@@ -458,8 +471,8 @@ class _TapFn(torch.autograd.Function):
             if dy.dtype not in (torch.float32, x2.dtype) or (x2.dtype == torch.float32 and dy.dtype != torch.float32):
                 dy = dy.float()
             dx = ops.layernorm_bwd(dy, x2, wf, mean, rstd, dres=res[0] if res else None,
-                                   dres2=res[1] if len(res) > 1 else None)
-        return (dx.view(ctx.shp) if dx is not None else None), None, None, None, None
+                                   dres2=res[1] if len(res) > 1 else None, want_amax=ctx.amax and x2.dtype == torch.float32)
+        return (dx.view(ctx.shp) if dx is not None else None), None, None, None, None, None
 
 
 class GDLayerNorm(nn.LayerNorm):
@@ -596,9 +609,8 @@ class GDViT(nn.Module):
                 w3 = lambda w: _opw(w.reshape(-1, w.shape[-1]).contiguous(), self.opfmt).view(L, w.shape[1], -1)
                 for i, pack in enumerate(zip(w3(down_T), w3(up_T), w3(down_tT), w3(up_tT))):
                     extra[i].update(zip(("down_w3", "up_w3", "down_tw3", "up_tw3"), pack))
-        gs_holder = [None]      # tf32h: the step's gradient scale (ops.amax_scale triple), set by the first block backward of the step
+        ops.amax_clear()        # (tf32h: scales registered for gradients of an earlier step that nobody consumed)
         for i, (inner, _, _) in enumerate(lo):
-            extra[i]["gs"] = gs_holder
             inner._tw = {"dtype": T, "at": at[i], "bt": bt[i], "at_T": at_T[i], "bt_T": bt_T[i], "bt_qv": bt_qv[i], "down_T": down_T[i],
                          "up_T": up_T[i], "down_tT": down_tT[i], "up_tT": up_tT[i], **extra[i]}
 
@@ -738,7 +750,7 @@ class GDViT(nn.Module):
             x = run_block(blk, x)      # not blk(x): a foreign wrapper class (utils/model.py's own) is fused by shape, never called
             if i in taps:
                 if norm_taps and i + 1 < len(self.blocks):
-                    x, outs[i], normed[i] = _TapFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps, self.tap_norm_dtype)
+                    x, outs[i], normed[i] = _TapFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps, self.tap_norm_dtype, self.opfmt == "h")
                 else:
                     outs[i] = x
                     if norm_taps:

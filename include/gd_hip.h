@@ -77,9 +77,10 @@ int gd_attention_bwd(const void* qkv, const void* o, const void* dout, const flo
 int gd_lora_bwd_fused(const void* dqv, long ldx, const float* t, const void* bt, float* dt, float* gbt, int M, int K, void* stream);
 /* The same pass (autograd of _LoRA_qkv, utils/model.py:57-71) on either 16-bit operand type (dtype GD_BF16 | GD_F16) with the tf32h engine's device-side scales: t is multiplied by *t_mul_dev
  * before it is split into its high and low 16-bit parts (a GRADIENT in the t role goes in under the step's power-of-two scale), dt and the gbt
- * partial by *out_mul_dev on the way out (1 / s when dqv or t carried s).  NULL = 1. */
+ * partial by *out_mul_dev on the way out (1 / s when dqv or t carried s).  NULL = 1.  dt_scaled = 1: dt leaves WITHOUT *out_mul_dev — still
+ * in dqv's scaled domain, for consumers that take it under s anyway (the LoRA rank update of a scaled-domain dX GEMM, the LoRA-A gradient). */
 int gd_lora_bwd_fused_scaled(const void* dqv, long ldx, const float* t, const void* bt, float* dt, float* gbt, int M, int K, int dtype,
-                             const float* t_mul_dev, const float* out_mul_dev, void* stream);
+                             const float* t_mul_dev, const float* out_mul_dev, int dt_scaled, void* stream);
 
 /* Dense cost-volume KL for P pairs, fused: calculate_cost_loss (src/finetune_timm_vggt.py:488-533 variant 0,
  * src/finetune_timm_mast3r.py:504-540 variant 1) = F.normalize + bmm x2 + softmax + get_masked_patch_cost
@@ -281,7 +282,11 @@ int gd_split3(const float* in, void* out, long rows, int K, long ld_in, int whic
  * bf16 rate, and the missing exponent range is covered by scaling — forward activations and frozen weights go in as they are (saturated at
  * +-65504, far above anything a ViT produces), a gradient tensor is multiplied by a power of two taken from its own maximum on the device.
  * gd_cast_f16: out [rows, K] fp16 = sat(in * scale * (scale_dev ? *scale_dev : 1)), in f32 with row stride ld_in.
- * gd_amax_scale: scale3 (device, 3 floats) <- {s, 1/s, scratch} with s the power of two that puts max|in| into (target/2, target].
+ * gd_amax_scale: scale3 (device, 3 floats) <- {s, 1/s, unused} with s the power of two that puts max|in| into (target/2, target]; a non-finite
+ *   element makes s (and 1/s) NaN, so every consumer's result is poisoned as the f32 engine's arithmetic would be.  amax_slots: 256 zeroed words
+ *   owned by the caller (zeroed again on return).  gd_scale_from_amax: the same {s, 1/s} from slots another kernel filled (gd_layernorm_bwd_ex).
+ * gd_cast_f16_ex: gd_cast_f16 that also counts, in range_counters (2 words, accumulated; nullable), the results that saturated at +-65504 ([0]) and
+ *   the non-zero inputs that fell below fp16's normal range 2^-14 ([1]) — the engine's run-time view of its range contract.
  * gd_gemm_nt_scaled: gd_gemm_nt with alpha multiplied by the device scalar *alpha_dev (the 1/s of a scaled operand) — no host round trip.
  * gd_gemm_nt itself takes ab_dtype GD_F16 (f32 results with f32 epilogue tensors, or c_dtype GD_F16: fp16 C, preact and dact_src). */
 int gd_cast_f16(const float* in, void* out, long rows, int K, long ld_in, float scale, const float* scale_dev, void* stream);
@@ -333,7 +338,16 @@ int gd_tap_mean_norm_fwd_h(const void* const* grids, int ngrid, long bstride, in
 int gd_layernorm_bwd_cast(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                           const float* dres, const float* dres2, float* dx, void* dx16, const float* scale_dev, int M, int D,
                           long ldd, long ldx, float dyscale, void* stream);
-int gd_amax_scale(const float* in, long rows, int K, long ld_in, float target, float* scale3, void* stream);
+int gd_amax_scale(const float* in, long rows, int K, long ld_in, float target, float* scale3, unsigned* amax_slots, void* stream);
+int gd_scale_from_amax(unsigned* amax_slots, float target, float* scale2, void* stream);
+int gd_cast_f16_ex(const float* in, void* out, long rows, int K, long ld_in, float scale, const float* scale_dev, unsigned* range_counters, void* stream);
+/* The tf32h block backward's LayerNorm pass (autograd of nn.LayerNorm inside timm's Block, frozen affine: dX only) with the device-side extras:
+ * dy f32 or fp16 (dy_dtype), multiplied by *dy_scale_dev when given (an fp16 dy under the block's scale s: 1/s); dx16 (nullable) = fp16(sat(dx *
+ * *cast_scale_dev)); amax_slots (nullable, 256 words): max |dx| bit patterns, the NEXT block's gradient scale through gd_scale_from_amax without
+ * a pass of its own; range_counters (nullable, 2 words): saturated / below-normal-range counts of dx16 as in gd_cast_f16_ex. */
+int gd_layernorm_bwd_ex(const void* dy, int dy_dtype, const float* dy_scale_dev, const float* x, const float* gamma, const float* mean,
+                        const float* rstd, const float* dres, const float* dres2, float* dx, void* dx16, const float* cast_scale_dev,
+                        unsigned* amax_slots, unsigned* range_counters, int M, int D, long ldd, long ldx, float dyscale, void* stream);
 int gd_gemm_nt_scaled(const void* A, const void* W, void* C, int M, int N, int K, long lda, long ldw, long ldc,
                       int batch, long sA, long sW, long sC, int ab_dtype, int c_dtype, float alpha, const float* alpha_dev,
                       const float* bias, const float* lora_t, const float* lora_b, int lora_rt, void* preact, long ldp,

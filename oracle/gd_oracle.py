@@ -291,8 +291,19 @@ def vit_block(x, p, i, cfg, lora=None, ad=None):
     y = F.layer_norm(x, (D,), p[pre + "norm1.weight"], p[pre + "norm1.bias"], eps)
     qkv = lora_qkv(y, p[pre + "attn.qkv.weight"], p.get(pre + "attn.qkv.bias"), lora)
     q, k, v = qkv.reshape(B, N, 3, h, d).permute(2, 0, 3, 1, 4).unbind(0)
-    s = (q * d ** -0.5) @ k.transpose(-1, -2)
-    a = torch.softmax(s, dim=-1) @ v
+    if cfg.get("attention_chunk"):
+        # the same softmax(q k^T / sqrt d) v, evaluated for `attention_chunk` query rows at a time under gradient checkpointing: at the reference
+        # geometry's 6 401 tokens the [h, N, N] score and probability matrices of every trainable block (3.9 GB each in fp64, four big forwards
+        # per pair) do not have to stay alive for the backward.  Row blocks of a softmax are independent: identical values and gradients.
+        from torch.utils.checkpoint import checkpoint
+
+        def rows(qc, k_, v_):
+            return torch.softmax((qc * d ** -0.5) @ k_.transpose(-1, -2), dim=-1) @ v_
+        c = int(cfg["attention_chunk"])
+        a = torch.cat([checkpoint(rows, q[:, :, i:i + c], k, v, use_reentrant=False) for i in range(0, N, c)], dim=2)
+    else:
+        s = (q * d ** -0.5) @ k.transpose(-1, -2)
+        a = torch.softmax(s, dim=-1) @ v
     a = a.transpose(1, 2).reshape(B, N, D)
     a = F.linear(a, p[pre + "attn.proj.weight"], p.get(pre + "attn.proj.bias"))
     if pre + "ls1.gamma" in p:

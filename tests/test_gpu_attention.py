@@ -41,7 +41,9 @@ def test_attention(dtype, tol, gtol, B, N, H):
     assert torch.equal(d3[:, :2 * D], d2[:, :2 * D])
 
 
-@pytest.mark.parametrize("dtype,tol,gtol", [(torch.float32, 2e-5, 1e-4), (torch.bfloat16, 2e-2, 4e-2)])
+# fp16 (the tf32h engine's kernels, clamp-free conversions: p <= 2^8 by the lagged reference point, |dS| <= |dP - delta|): the same four cases,
+# finite outputs, and 8x tighter bounds than bf16 (11 significant bits against 8)
+@pytest.mark.parametrize("dtype,tol,gtol", [(torch.float32, 2e-5, 1e-4), (torch.bfloat16, 2e-2, 4e-2), (torch.float16, 3e-3, 6e-3)])
 @pytest.mark.parametrize("case", ["peaked", "rising", "all_negative", "outlier_token"])
 def test_attention_reference_point_moves(dtype, tol, gtol, case):
     """The forward keeps a LAGGED softmax reference point (raised only when a score exceeds it by 2^8): logits with a
@@ -68,13 +70,14 @@ def test_attention_reference_point_moves(dtype, tol, gtol, case):
     dqkv = ops.attention_bwd(qkv, o, dout, lse, B, N, H)
     ro, rl, rg = _ref(qkv, B, N, H, dout)
     assert torch.isfinite(o.float()).all() and torch.isfinite(dqkv.float()).all()
-    assert rel_err(o, ro) < tol
+    assert rel_err(o, ro) < (tol if not (dtype == torch.float16 and case in ("rising", "all_negative")) else 4 * tol)
     # bf16: q * scale * log2(e) is rounded to bf16 once more, a relative 2^-9 on every score; in "rising" / "all_negative" the
     # scores are ~40-60 (log2 units) and built from ONE coordinate that is the same for every query, so that rounding is
     # coherent instead of averaging out: p is off by a few percent there (a 0.2 % temperature error).  f32 is exact.
-    coherent = dtype == torch.bfloat16 and case in ("rising", "all_negative")
-    assert float((lse.double().cpu() - rl.cpu()).abs().max()) < (1e-4 if dtype == torch.float32 else 0.15 if coherent else 8e-2)
-    assert rel_err(dqkv, rg) < (0.2 if coherent else gtol)
+    coherent = dtype != torch.float32 and case in ("rising", "all_negative")
+    lse_tol = {torch.float32: (1e-4, 1e-4), torch.bfloat16: (8e-2, 0.15), torch.float16: (1e-2, 2e-2)}[dtype][int(coherent)]
+    assert float((lse.double().cpu() - rl.cpu()).abs().max()) < lse_tol
+    assert rel_err(dqkv, rg) < ((0.2 if dtype == torch.bfloat16 else 0.03) if coherent else gtol)
 
 
 @pytest.mark.parametrize("B,N,H", [(1, 17, 1), (2, 64, 2), (1, 257, 3), (2, 1370, 2), (2, 200, 2)])
@@ -124,3 +127,21 @@ def test_attention_fp16_operands():
         assert rel_err(got[:, i], t.grad.permute(0, 2, 1, 3).reshape(B * N, H, 64)) < 2e-3, i
     ob, _ = ops.attention_fwd(qkv32.bfloat16(), B, N, H)
     assert rel_err(o, ref_o.detach()) < 0.25 * rel_err(ob, ref_o.detach())
+
+
+@pytest.mark.parametrize("dtype,tol,gtol", [(torch.float32, 2e-5, 5e-5), (torch.bfloat16, 2e-2, 4e-2), (torch.float16, 3e-3, 6e-3)])
+@pytest.mark.parametrize("N", [4801, 6401])
+def test_attention_reference_geometry_token_counts(dtype, tol, gtol, N):
+    """The reference's own keypoint-feature geometry (target_res 640 / downsample 8: 60 x 80 + 1 = 4801 tokens on 4:3 inputs, 80 x 80 + 1 = 6401 on
+    square ones; src/finetune_timm_mast3r.py:145,251-256) through all three kernels of every engine dtype: long key sweeps
+    (100 tiles), the eight-wave dK/dV form, a partial last tile, 12 heads."""
+    from gd_amd import ops
+    B, H = 1, 12
+    g = torch.Generator(device="cuda").manual_seed(N)
+    qkv = torch.randn(B * N, 3 * H * 64, generator=g, device="cuda").to(dtype)
+    dout = torch.randn(B * N, H * 64, generator=g, device="cuda").to(dtype)
+    o, lse = ops.attention_fwd(qkv, B, N, H)
+    dqkv = ops.attention_bwd(qkv, o, dout, lse, B, N, H)
+    ro, rl, rg = _ref(qkv, B, N, H, dout)
+    assert bool(torch.isfinite(dqkv.float()).all())
+    assert rel_err(o, ro) < tol and rel_err(lse, rl) < (1e-5 if dtype == torch.float32 else 1e-2) and rel_err(dqkv, rg) < gtol

@@ -40,19 +40,40 @@ def _record(name, rec):
         json.dump(data, fh, indent=1, sort_keys=True)
 
 
-def _run_case(name, backbone, variant, dtype, img=518, P=2, N=300, vit_kwargs=None, counts=None, eng_kwargs=None):
+def _run_case(name, backbone, variant, dtype, img=518, P=2, N=300, vit_kwargs=None, counts=None, eng_kwargs=None, geometry="shared"):
     from gd_amd.finetune import FinetuneGD
     torch.manual_seed(0)
     vk = dict(init_values=1.0) if vit_kwargs is None else vit_kwargs
-    eng = FinetuneGD(r=4, backbone=backbone, patch_size=14, img_size=img, variant=variant, geometry="shared", dtype=dtype,
+    eng = FinetuneGD(r=4, backbone=backbone, patch_size=14, img_size=img, variant=variant, geometry=geometry, dtype=dtype,
                      teacher_patch=14, lora_b_std=1e-3, vit_kwargs=vk, **(eng_kwargs or {})).cuda()
     hw = (img // 14) ** 2
     batch = synthetic_batch(P, img, img, N, hw, "cuda", seed=1234, teacher_patch=14, counts=counts)
-    key = (backbone, variant, img, P, N, str(vk), str(eng_kwargs), str(counts))      # the fp64 oracle does not depend on the engine dtype:
-    if key not in _STEP_ORACLE:                                                       # (same fp32 master weights, same batch) run it once
-        orc = OracleTrainer(eng)
-        _STEP_ORACLE[key] = orc.step(batch, P) + (orc.names, orc.l1_residuals)
-    ref_loss, ref_terms, ref_grads, ref_params, ref_norm, names, l1_residuals = _STEP_ORACLE[key]
+    key = (backbone, variant, img, P, N, str(vk), str(eng_kwargs), str(counts), geometry)      # the fp64 oracle does not depend on the engine dtype:
+
+    def oracle(bt, k):                                                                # (same fp32 master weights, same batch) run it once
+        if k not in _STEP_ORACLE:
+            orc = OracleTrainer(eng)
+            if geometry == "reference":  # 6 401-token forwards: the oracle evaluates its attention in checkpointed query-row blocks (oracle/gd_oracle.py)
+                orc.cfg["attention_chunk"] = 512
+            _STEP_ORACLE[k] = orc.step(bt, P) + (orc.names, orc.l1_residuals)
+        return _STEP_ORACLE[k]
+    ref_loss, ref_terms, ref_grads, ref_params, ref_norm, names, l1_residuals = oracle(batch, key)
+    # The depth-L1 term |pred - target| has a kink: a keypoint whose residual is within the engine's feature noise of zero takes either sign,
+    # and ONE flipped keypoint turns its whole gradient contribution around — 2 / sqrt(#keypoints) of the depth branch's gradient norm (0.115 at
+    # 300 keypoints; tools/diag_bf16_head.py shows the same gradient change in fp64 torch when only the features are swapped).  Such keypoints
+    # say nothing about the engine: they are DROPPED from the batch — from every loss, on both sides (the oracle runs again on the reduced
+    # batch) — and the flat tolerance is held on what remains.  The features do not depend on the keypoints and the L1 residual of a keypoint
+    # depends on that keypoint only, so the other residuals stay what the first oracle pass measured.
+    dropped = 0
+    if eng.depth_loss_weight != 0 and dtype in ("bf16", "tf32h"):
+        band = KINK_BAND if dtype == "bf16" else TF32H_KINK_BAND
+        drop = [(r.abs().reshape(-1) < band).nonzero().reshape(-1).tolist() if r is not None else [] for r in l1_residuals]
+        dropped = sum(len(d) for d in drop)
+        if dropped:
+            batch = _drop_keypoints(batch, drop)
+            ref_loss, ref_terms, ref_grads, ref_params, ref_norm, names, l1_residuals = oracle(batch, key + ("drop", band))
+            res = torch.cat([r.abs().reshape(-1) for r in l1_residuals if r is not None])
+            assert float(res.min()) >= band        # (independent per keypoint: nothing new moved into the band)
     flat = eng.configure_optimizers()
     before = [q.detach().clone() for q in eng.trainable_parameters()]
     loss, terms = eng.training_step(batch)
@@ -70,19 +91,8 @@ def _run_case(name, backbone, variant, dtype, img=518, P=2, N=300, vit_kwargs=No
     rec["grad_rel_fro"] = ((g_hip - g_ref).norm() / g_ref.norm()).item()
     rec["grad_cos"] = (torch.dot(g_hip, g_ref) / (g_hip.norm() * g_ref.norm())).item()
     rec["groups"] = _group_table(names, [q.grad.detach().double().cpu() for q in ps], ref_grads, float(g_ref.norm()))
-    # The depth-L1 term |pred - target| has a kink: a keypoint whose residual is within the engine's feature noise of zero takes
-    # either sign, and ONE flipped keypoint turns its whole gradient contribution around — 2 / sqrt(#keypoints) of the depth
-    # branch's gradient norm (0.115 at 300 keypoints; tools/diag_bf16_head.py shows the same gradient change in fp64 torch when only
-    # the features are swapped).  Count the keypoints inside the noise band and widen the gradient tolerance by that much.
-    if eng.depth_loss_weight != 0 and dtype in ("bf16", "tf32h"):
-        band, base = (KINK_BAND, BF16_GRAD_FRO) if dtype == "bf16" else (TF32H_KINK_BAND, TF32H_GRAD_FRO)
-        res = torch.cat([r.abs() for r in l1_residuals if r is not None])
-        nkp = int(res.numel())
-        rec["l1_kink"] = {"band": band, "keypoints_in_band": int((res < band).sum()), "min_abs_residual": float(res.min()),
-                          "keypoints": nkp}
-        rec["grad_fro_tol"] = base + 2.3 * rec["l1_kink"]["keypoints_in_band"] / nkp ** 0.5
-    else:
-        rec["grad_fro_tol"] = {"bf16": BF16_GRAD_FRO, "tf32h": TF32H_GRAD_FRO, "tf32x": 2e-3}.get(dtype, 2e-4)
+    rec["kink_keypoints_dropped"] = dropped
+    rec["grad_fro_tol"] = {"bf16": BF16_GRAD_FRO, "tf32h": TF32H_GRAD_FRO, "tf32x": 2e-3}.get(dtype, 2e-4)
     norm = eng.optimizer_step()
     rec["grad_norm"], rec["ref_grad_norm"] = norm.item(), ref_norm.item()
     # updated weights: the step moved every element by <= lr; compare the UPDATE vectors (post - pre), not the weights
@@ -95,6 +105,26 @@ def _run_case(name, backbone, variant, dtype, img=518, P=2, N=300, vit_kwargs=No
     rec["max_weight_diff_over_lr"] = ((w_hip - w_ref).abs().max() / flat["lr"]).item()
     _record(name, rec)
     return rec
+
+
+def _drop_keypoints(batch, drop):
+    """batch without the keypoints drop[p] of pair p: the survivors move up, the tail is padded (-1 / 0) and `counts` says how many are left."""
+    out = dict(batch)
+    P, N = batch["kp_1"].shape[:2]
+    counts = batch["counts"].tolist() if "counts" in batch else [N] * P
+    for k in ("kp_1", "kp_2", "pts3d_1", "pts3d_2"):
+        out[k] = batch[k].clone()
+    new_counts = []
+    for p in range(P):
+        keep = [i for i in range(counts[p]) if i not in set(drop[p])]
+        idx = torch.tensor(keep, dtype=torch.long, device=batch["kp_1"].device)
+        for k, fill in (("kp_1", -1.0), ("kp_2", -1.0), ("pts3d_1", 0.0), ("pts3d_2", 0.0)):
+            rows = batch[k][p, idx]
+            out[k][p] = fill
+            out[k][p, :len(keep)] = rows
+        new_counts.append(len(keep))
+    out["counts"] = torch.tensor(new_counts, dtype=torch.int32, device=batch["kp_1"].device)
+    return out
 
 
 def _group_table(names, g_hip, g_ref, total_norm):
@@ -117,8 +147,6 @@ def _group_table(names, g_hip, g_ref, total_norm):
 
 
 def _check(rec, tol=TOL, cos=0.99):
-    if rec.get("l1_kink", {}).get("keypoints_in_band"):       # a keypoint on the |.| kink: direction checks follow the widened tolerance
-        cos = min(cos, 1.0 - 0.5 * rec["grad_fro_tol"] ** 2 - 1e-3)
     assert rec["rel_err"] < tol, rec
     for k, t in rec["terms"].items():
         assert t["rel_err"] < tol, (k, t)
@@ -169,9 +197,11 @@ def test_vit_large_518_vggt_step_matches_oracle(dtype):
     _check(rec, cos=0.999 if dtype == "f32" else 0.99)
 
 
-# BASELINE config 5: CLIP-style pre-norm ViT-L/14 (no LayerScale, LN eps 1e-5, timm pos-embed resample), bf16, all four losses
-def test_prenorm_vit_large_bf16_step_matches_oracle():
-    rec = _run_case("prenorm_vit_large_336_vggt_bf16", "vit_large", "vggt", "bf16", img=336, P=1, N=200,
+# BASELINE config 5: CLIP-style pre-norm ViT-L/14 (no LayerScale, LN eps 1e-5, timm pos-embed resample), all four losses; bf16 as BASELINE words
+# it, and tf32h — the headline engine, which bench.py's other_configs times on this student
+@pytest.mark.parametrize("dtype", ["bf16", "tf32h"])
+def test_prenorm_vit_large_bf16_step_matches_oracle(dtype):
+    rec = _run_case(f"prenorm_vit_large_336_vggt_{dtype}", "vit_large", "vggt", dtype, img=336, P=1, N=200,
                     vit_kwargs=dict(pre_norm=True, ln_eps=1e-5, pos_interp="timm"))
     _check(rec)
 
@@ -179,10 +209,20 @@ def test_prenorm_vit_large_bf16_step_matches_oracle():
 # BASELINE config 5 as worded: CLIP-style ViT-L/14 student + MASt3R teacher, "mixed corr + depth + cost losses", bf16 — the MASt3R
 # trainer's loss kernels (masked rows -> softmax KL, keypoint patch masks) with the depth L1 term switched on as well, at the
 # benched resolution (518^2, 1370 tokens, hw = 1369)
-def test_prenorm_vit_large_bf16_mast3r_mixed_losses_step_matches_oracle():
-    rec = _run_case("prenorm_vit_large_518_mast3r_all_losses_bf16", "vit_large", "mast3r", "bf16", img=518, P=1, N=300,
+@pytest.mark.parametrize("dtype", ["bf16", "tf32h"])
+def test_prenorm_vit_large_bf16_mast3r_mixed_losses_step_matches_oracle(dtype):
+    rec = _run_case(f"prenorm_vit_large_518_mast3r_all_losses_{dtype}", "vit_large", "mast3r", dtype, img=518, P=1, N=300,
                     vit_kwargs=dict(pre_norm=True, ln_eps=1e-5, pos_interp="timm"), eng_kwargs=dict(depth_loss_weight=1.0))
     _check(rec)
+
+
+# The REFERENCE's token geometry at full size (src/finetune_timm_mast3r.py:145,251-256: target_res 640 / downsample 8 -> 80 x 80 + 1 = 6 401 tokens
+# for the keypoint features, 37 x 37 for the cost features): ViT-B/14, one pair, MASt3R losses, in the exact-f32 engine and in
+# the headline tf32h engine — attention at N = 6 401 (eight-wave dK/dV, 100 key tiles), three forwards per image, gradients summed over them.
+@pytest.mark.parametrize("dtype", ["f32", "tf32h"])
+def test_vit_base_reference_geometry_step_matches_oracle(dtype):
+    rec = _run_case(f"vit_base_518_mast3r_reference_geometry_{dtype}", "vit_base", "mast3r", dtype, P=1, counts=[300], geometry="reference")
+    _check(rec, cos=0.999 if dtype == "f32" else 0.99)
 
 
 # The bf16 engine against the fp32 CPU oracle over a TRAJECTORY: ten optimiser steps from the same weights on the same pair

@@ -495,3 +495,24 @@ def test_flat_allreduce_cabi_single_rank():
     red.start()
     assert red.finish() == 1.0
     comm.close()
+
+
+def test_fp16_operand_outputs_of_the_gather_and_im2col_kernels_equal_their_f32_forms_rounded():
+    """tf32h engine: gd_kp_patch_gather writes the refine-conv GEMM's left operand as fp16 directly (`half=True`), gd_patch_im2col /
+    gd_patch_im2col_strided the patch projection's (dtype fp16) — the f32 form of the same launch rounded once, no separate cast pass."""
+    from gd_amd import ops
+    B, gh, gw, D, P = 2, 9, 11, 64, 14
+    grid = torch.randn(B, 1 + gh * gw, D, generator=_g(31), device="cuda")
+    kp = torch.rand(B, 17, 2, generator=_g(32), device="cuda") * torch.tensor([gw * P - 1.0, gh * P - 1.0], device="cuda")
+    kp[:, 0] = 0.0
+    kp[:, 1] = -1.0
+    a32 = ops.kp_patch_gather(grid[:, 1:], (1 + gh * gw) * D, kp, B, 17, gh, gw, D, 1.0, 1.0, gh * P, gw * P, P)
+    a16 = ops.kp_patch_gather(grid[:, 1:], (1 + gh * gw) * D, kp, B, 17, gh, gw, D, 1.0, 1.0, gh * P, gw * P, P, half=True)
+    assert a32.dtype == torch.float32 and a16.dtype == torch.float16 and a16.shape == a32.shape
+    assert torch.equal(a16, a32.half())
+    mean, std = (0.48, 0.45, 0.40), (0.26, 0.25, 0.27)
+    img = torch.rand(B, 3, 56, 70, generator=_g(33), device="cuda")
+    for stride in (None, (7, 7)):
+        c32 = ops.patch_im2col(img, 56, 70, P, 640, mean, std, torch.float32, stride=stride)
+        c16 = ops.patch_im2col(img, 56, 70, P, 640, mean, std, torch.float16, stride=stride)
+        assert c16.dtype == torch.float16 and c16.shape == c32.shape and torch.equal(c16, c32.half()), stride

@@ -232,8 +232,15 @@ def test_target_composites_and_cache_feed_the_step():
     calls.clear()
     assert cache.get("empty", lambda: (calls.append(1), None)[1], temperature=1.0) is None
     assert cache.get("empty", lambda: (calls.append(1), None)[1], temperature=0.7) is None and len(calls) == 1
+    # ... and it STAYS in the batch as a zero-loss sample (counts = 0): the reference's step returns a constant zero for it, so the mean's
+    # divisor, the image rows and every data-parallel rank's pair count are what the caller passed
     b2 = cache.collate(["pair0", "empty", "pair1"], rgb[:3], rgb[1:4])
-    assert b2["counts"].shape[0] == 2 and torch.equal(b2["rgb_1"], rgb[[0, 2]]) and torch.equal(b2["rgb_2"], rgb[[1, 3]])
+    assert b2["counts"].tolist()[1] == 0 and b2["counts"].shape[0] == 3 and torch.equal(b2["rgb_1"], rgb[:3])
+    assert torch.equal(b2["rgb_2"], rgb[1:4]) and bool((b2["kp_1"][1] == -1).all())
+    loss3, terms3 = eng.training_step(b2)
+    both = cache.collate(["pair0", "pair1"], rgb[[0, 2]], rgb[[1, 3]])
+    loss2, _ = eng.training_step(both)
+    assert bool(torch.isfinite(loss3)) and abs(loss3.item() * 3 - loss2.item() * 2) < 1e-3 * abs(loss2.item() * 2)
     assert cache.collate(["empty"], rgb[:1], rgb[1:2]) is None
 
 
