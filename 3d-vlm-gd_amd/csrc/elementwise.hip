@@ -1038,7 +1038,7 @@ __global__ __launch_bounds__(256) void cast_f16_kernel(const float* in, f16* out
         if (range) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const unsigned u = __builtin_bit_cast(unsigned, (k < 4 ? a[k] : b[k - 4]) * sc) & 0x7fffffffu;
+                const unsigned u = gd_f2u((k < 4 ? a[k] : b[k - 4]) * sc) & 0x7fffffffu;
                 nsat += u > 0x477fe000u;
                 nlow += (u < 0x38800000u) & (u != 0u);
             }
@@ -1063,7 +1063,7 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* in, long rows, i
         const int c = (int)(idx - r * kv) * 4;
         const f32x4 a = *(const f32x4*)(in + r * ld_in + c);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { const unsigned u = __builtin_bit_cast(unsigned, a[k]) & 0x7fffffffu; m = u > m ? u : m; }
+        for (int k = 0; k < 4; ++k) { const unsigned u = gd_f2u(a[k]) & 0x7fffffffu; m = u > m ? u : m; }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const unsigned w = (unsigned)__shfl_xor((int)m, o, 64); m = w > m ? w : m; }

@@ -39,6 +39,10 @@ void gd_set_error(const char* fmt, ...);
 __host__ __device__ static inline int gd_dtype_size(int dt) { return (dt == GD_BF16 || dt == GD_F16) ? 2 : 4; }
 static inline int gd_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// bit pattern of a float VALUE (__builtin_bit_cast applied directly to an ext-vector element expression v[k] reads element 0 on ROCm 7.2's clang:
+// always go through a by-value float)
+__device__ __forceinline__ unsigned gd_f2u(float v) { return __builtin_bit_cast(unsigned, v); }
+
 // ---- scalar conversions ----
 template <typename T> __device__ __forceinline__ float to_f32(T v);
 template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }

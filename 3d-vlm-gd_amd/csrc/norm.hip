@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* dy, const T* x, c
             store4n<T>(or_ + c, o);
             if (amax) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { const unsigned b = __builtin_bit_cast(unsigned, o[k]) & 0x7fffffffu; mb = b > mb ? b : mb; }
+                for (int k = 0; k < 4; ++k) { const unsigned b = gd_f2u(o[k]) & 0x7fffffffu; mb = b > mb ? b : mb; }
             }
             if (dx16) {
                 const f32x4 os = o * s16;
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* dy, const T* x, c
                 if (range) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const unsigned b = __builtin_bit_cast(unsigned, os[k]) & 0x7fffffffu;
+                        const unsigned b = gd_f2u(os[k]) & 0x7fffffffu;
                         nsat += b > 0x477fe000u;                        // |v| > 65504 (Inf / NaN included)
                         nlow += (b < 0x38800000u) & (b != 0u);          // 0 < |v| < 2^-14
                     }
