@@ -6,7 +6,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgd_hip.so")
+# GD_HIP_LIB: another build of the same library (A/B timing of two builds in one session; never set in production)
+LIB_PATH = os.environ.get("GD_HIP_LIB") or os.path.join(_HERE, "lib", "libgd_hip.so")
 _lib = None
 
 F32, BF16, F16 = 0, 1, 3

@@ -316,8 +316,11 @@ __global__ __launch_bounds__(256, 1) void adapter_persist_kernel(const bf16* __r
 // x32 [M, D] fp32 is read ONCE per tile into registers (24 x 16 B per thread), rounded to fp16 (times *in_scale: the backward's gradient scale)
 // on its way into the LDS image the bf16 kernel uses, both products run on the fp16 MFMA, the hidden tile leaves as fp16 (forward: relu(x.down^T),
 // the backward's gate and weight-gradient operand; backward: the scaled d(hidden)), and the result is out32 = x32 + alpha * (hidden . w2^T) in
-// fp32 — the residual taken from x32 again (a second read of lines this CU fetched a few microseconds earlier: L2 hits) — plus, when asked for,
-// out16 = fp16(out32 * *copy_scale), the operand of the next product.  Replaces, per call, a cast pass, the N = 64 GEMM, a second cast and the
+// fp32 — plus, when asked for, out16 = fp16(out32 * *copy_scale), the operand of the next product.
+// Round 4: the fp32 tile is ALSO parked in LDS (96 KB at D = 768: with the fp16 image and the hidden tile 148 of the 160 KB) and the residual add
+// reads it from there, and BOTH weights stay in registers for the whole launch (the 32 residual registers are gone) — phase 2 issues no vector-memory
+// load at all.  Before, every tile re-read its 96 KB of x from L2 and streamed the 96 KB second weight from L2, and those loads sat behind the next
+// tile's 48 HBM prefetch loads of the same wave in the in-order vector-memory queue: the phase waited for the prefetch it was meant to hide.  Replaces, per call, a cast pass, the N = 64 GEMM, a second cast and the
 // K = 64 GEMM (whose 129 us are pure residual / result traffic) of the unfused tf32h path.
 template <int D>
 __global__ __launch_bounds__(256, 1) void adapter_persist_h_kernel(const float* __restrict__ x32, const f16* __restrict__ w1, const f16* __restrict__ w2,
@@ -328,6 +331,7 @@ __global__ __launch_bounds__(256, 1) void adapter_persist_h_kernel(const float* 
     constexpr int PPT = AD_BM * CPR / 256;      // fp16 16-byte chunks (8 elements = two fp32 16-byte loads) of a tile per thread
     static_assert(D <= 768, "both weights and the fp32 prefetch have to fit 512 registers");
     __shared__ __attribute__((aligned(16))) char sX[AD_BM * D * 2];
+    __shared__ __attribute__((aligned(16))) char sR[AD_BM * D * 4];      // the same tile in fp32: the residual of phase 2
     __shared__ __attribute__((aligned(16))) char sH[AD_BM * AD_BOT * 2];
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -344,22 +348,21 @@ __global__ __launch_bounds__(256, 1) void adapter_persist_h_kernel(const float* 
         pre[i][0] = *(const f32x4*)src;
         pre[i][1] = *(const f32x4*)(src + 4);
     });
-    // the first weight stays in registers for the whole launch; the second (96 KB at D = 768) is streamed from L2 per column group, one group
-    // ahead — with it resident too the fp32 prefetch (96 registers) does not fit the 512-register budget
+    // both weights stay in registers for the whole launch (96 + 96 registers at D = 768, beside the 96 of the fp32 prefetch)
     f16x8 b1[KS];
     {
         const char* w1r = (const char*)w1 + (long)(16 * wave + c) * (D * 2) + 16 * g;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) b1[ks] = *(const f16x8*)(w1r + ks * 64);
     }
-    int c2 = c;      // made opaque once per tile: the (tile-invariant) second-weight loads are otherwise hoisted out of the tile loop — back into registers
-    auto load_b2 = [&](int gq, f16x8 (&b2)[4][2]) __attribute__((always_inline)) {
+    f16x8 b2[NG][4][2];
+#pragma unroll
+    for (int gq = 0; gq < NG; ++gq)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
-                b2[j][ks] = *(const f16x8*)((const char*)w2 + (long)(wave * (D / 4) + 64 * gq + 4 * c2 + j) * (AD_BOT * 2) + 64 * ks + 16 * g);
-    };
+                b2[gq][j][ks] = *(const f16x8*)((const char*)w2 + (long)(wave * (D / 4) + 64 * gq + 4 * c + j) * (AD_BOT * 2) + 64 * ks + 16 * g);
     for (; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * AD_BM;
         __syncthreads();                        // the previous tile's readers are done with sX and sH
@@ -370,6 +373,8 @@ __global__ __launch_bounds__(256, 1) void adapter_persist_h_kernel(const float* 
 #pragma unroll
             for (int k = 0; k < 4; ++k) { h[k] = from_f32<f16>(pre[i][0][k] * sin); h[4 + k] = from_f32<f16>(pre[i][1][k] * sin); }
             *(f16x8*)(sX + (row * CPR + (p ^ (row & 15))) * 16) = h;
+            *(f32x4*)(sR + (row * D + p * 8) * 4) = pre[i][0];
+            *(f32x4*)(sR + (row * D + p * 8 + 4) * 4) = pre[i][1];
         });
         unsigned short gt[8];
         {
@@ -428,18 +433,9 @@ __global__ __launch_bounds__(256, 1) void adapter_persist_h_kernel(const float* 
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) ah[i][ks] = *(const f16x8*)(sH + (16 * i + c) * (AD_BOT * 2) + 64 * ks + 16 * g);
         const bool full = row0 + AD_BM <= M;
-        asm volatile("" : "+v"(c2));
-        f16x8 b2[2][4][2];
-        load_b2(0, b2[0]);
 #pragma unroll
         for (int gq = 0; gq < NG; ++gq) {
-            if (gq + 1 < NG) load_b2(gq + 1, b2[(gq + 1) & 1]);
             const int col = wave * (D / 4) + 64 * gq + 4 * c;
-            f32x4 xr[2][4];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) xr[i][r] = *(const f32x4*)(x32 + (long)min(row0 + 16 * i + 4 * g + r, M - 1) * D + col);
             f32x4 acc[2][4];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -450,15 +446,17 @@ __global__ __launch_bounds__(256, 1) void adapter_persist_h_kernel(const float* 
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = Mma<f16>::mma(ah[i][ks], b2[gq & 1][j][ks], acc[i][j]);
+                    for (int j = 0; j < 4; ++j) acc[i][j] = Mma<f16>::mma(ah[i][ks], b2[gq][j][ks], acc[i][j]);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = 16 * i + 4 * g + r;
                     if (!(full || row0 + row < M)) continue;
-                    const f32x4 o = {fmaf(alpha, acc[i][0][r], xr[i][r][0]), fmaf(alpha, acc[i][1][r], xr[i][r][1]),
-                                     fmaf(alpha, acc[i][2][r], xr[i][r][2]), fmaf(alpha, acc[i][3][r], xr[i][r][3])};
+                    // (16 lanes of a row read 256 contiguous bytes; the lane groups of a ds_read_b128 — rows 4g and 4g + 4 — land on disjoint banks)
+                    const f32x4 xr = *(const f32x4*)(sR + (row * D + col) * 4);
+                    const f32x4 o = {fmaf(alpha, acc[i][0][r], xr[0]), fmaf(alpha, acc[i][1][r], xr[1]),
+                                     fmaf(alpha, acc[i][2][r], xr[2]), fmaf(alpha, acc[i][3][r], xr[3])};
                     *(f32x4*)(out32 + (long)(row0 + row) * D + col) = o;
                     if (out16) {
                         const f16x4 h = {from_f32<f16>(o[0] * scp), from_f32<f16>(o[1] * scp), from_f32<f16>(o[2] * scp), from_f32<f16>(o[3] * scp)};

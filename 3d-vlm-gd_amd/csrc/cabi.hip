@@ -29,7 +29,13 @@ static const KnobDef KNOBS[] = {
     {"cv_persist", "GD_CV_PERSIST", &GdKnobs::cv_persist, 1},             {"cv_dbg", "GD_CV_DBG", &GdKnobs::cv_dbg, 0},
     {"cv_grid", "GD_CV_GRID", &GdKnobs::cv_grid, 0},                      {"pair_rank_wave", "GD_PAIR_RANK_WAVE", &GdKnobs::pair_rank_wave, 0},
     {"ln_16b", "GD_LN_16B", &GdKnobs::ln_16b, 1},                         {"adapter_persist", "GD_ADAPTER_PERSIST", &GdKnobs::adapter_persist, 1},
+    {"reserve_cus", "GD_RESERVE_CUS", &GdKnobs::reserve_cus, 0},
 };
+static void gd_apply_reserve(GdKnobs& v) {
+    int r = v.reserve_cus < 0 ? 0 : v.reserve_cus;
+    if (r > v.ncu_dev - 8) r = v.ncu_dev - 8;      // never fewer than one CU per XCD
+    v.ncu = v.ncu_dev - (r > 0 ? r : 0);
+}
 
 GdKnobs& gd_knobs_mut() {
     static GdKnobs k = [] {
@@ -38,10 +44,11 @@ GdKnobs& gd_knobs_mut() {
             const char* e = getenv(d.env);
             v.*(d.field) = e ? atoi(e) : d.def;
         }
-        v.ncu = 256;
+        v.ncu_dev = 256;
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
-            v.ncu = cus;
+            v.ncu_dev = cus;
+        gd_apply_reserve(v);
         return v;
     }();
     return k;
@@ -50,7 +57,7 @@ GdKnobs& gd_knobs_mut() {
 extern "C" int gd_debug_set(const char* name, int value) {
     GD_REQUIRE(name != nullptr, "gd_debug_set: null name");
     for (const KnobDef& d : KNOBS)
-        if (strcmp(d.name, name) == 0) { gd_knobs_mut().*(d.field) = value; return 0; }
+        if (strcmp(d.name, name) == 0) { gd_knobs_mut().*(d.field) = value; gd_apply_reserve(gd_knobs_mut()); return 0; }
     gd_set_error("gd_debug_set: unknown option '%s'", name);
     return -1;
 }

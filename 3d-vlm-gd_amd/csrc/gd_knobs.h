@@ -24,7 +24,10 @@ struct GdKnobs {
     int pair_rank_wave;    // GD_PAIR_RANK_WAVE    0 tiled kernel | 1 | 2 | 3 older forms
     int ln_16b;            // GD_LN_16B            1: 16-byte LayerNorm accesses
     int adapter_persist;   // GD_ADAPTER_PERSIST   blocks per CU of the persistent adapter kernel (0: one block per tile)
-    int ncu;               // compute units of the current device at first use (256 on MI355X)
+    int reserve_cus;       // GD_RESERVE_CUS       compute units the persistent kernels leave free (data parallelism: RCCL's kernels need CUs to run
+                           //                      UNDER a backward made of one-block-per-CU launches; dp / bench.py set it when world > 1; 0 otherwise)
+    int ncu_dev;           // compute units of the current device at first use (256 on MI355X)
+    int ncu;               // = ncu_dev - reserve_cus: the grid of every persistent kernel
 };
 GdKnobs& gd_knobs_mut();                                                // cabi.hip
 static inline const GdKnobs& gd_knobs() { return gd_knobs_mut(); }

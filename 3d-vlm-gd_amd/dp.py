@@ -166,6 +166,37 @@ class DirectGradReducer:
         return 1.0 / self.world
 
 
+def reserve_cus_for_collectives(k):
+    """Leave k compute units out of every persistent kernel's grid (csrc/gd_knobs.h `reserve_cus`): the backward of this engine is a chain of
+    one-block-per-CU launches that hold all 256 CUs, so an RCCL kernel issued from a gradient hook finds no CU until a launch ends.  Whether the
+    overlapped exchange needs this — and which k pays — can only be measured on a multi-GPU node: bench.py --reserve-cus k (A/B in its `comm`
+    object).  Process-wide; 0 restores the full grid."""
+    from ._lib import check, lib
+    check(lib().gd_debug_set(b"reserve_cus", int(k)), "gd_debug_set(reserve_cus)")
+
+
+def one_hop_slices(n, world, align=1024):
+    """The slice arithmetic of a hand-written one-hop exchange over the fully connected xGMI mesh (NOT built: it needs peer-mapped
+    buffers and a multi-GPU node to validate — `gd_flat_allreduce` algo 0 / 1 are RCCL-scheduled): the flat buffer of n floats is cut into
+    `world` contiguous slices whose boundaries are multiples of `align` floats (whole 4-KB pages of fp32: one DMA descriptor per slice and peer);
+    rank j OWNS slice j — every rank pushes its copy of slice j to rank j over its own link (reduce-scatter: world - 1 messages in, all at
+    once), rank j sums the world copies in rank order (deterministic) and pushes the result back to every peer (all-gather).
+    -> (bounds, push_plan): bounds[j] = (start, stop) of slice j (the last one takes the remainder; empty slices when n < world * align);
+    push_plan[r] = [(peer, start, stop), ...] the reduce-scatter messages rank r sends, in the order that starts with its right-hand neighbour
+    so that no two ranks target the same peer in the same slot."""
+    assert n >= 0 and world >= 1 and align >= 1
+    per = (n // world) // align * align
+    bounds = []
+    for j in range(world):
+        a = min(j * per, n)
+        b = n if j == world - 1 else min((j + 1) * per, n)
+        bounds.append((a, b))
+    plan = []
+    for r in range(world):
+        plan.append([((r + k) % world,) + bounds[(r + k) % world] for k in range(1, world)])
+    return bounds, plan
+
+
 def shard_pairs(n_pairs, rank, world):
     """Contiguous split of a global batch of pairs."""
     per = n_pairs // world

@@ -49,6 +49,20 @@ class GemmProfiler:
             n += 1
         return lim, ms, nb, n
 
+    def algorithmic_bytes(self, keep=None):
+        """(sum of the kept launches' algorithmic bytes — both operands once, C once, every [M, N] epilogue tensor once, as roofline_time counts
+        them — and the number of launches)."""
+        es = {"float32": 4, "bfloat16": 2, "float16": 2}
+        tot = n = 0
+        for _, _, _, tag in self.records:
+            if keep is not None and not keep(tag):
+                continue
+            M, N, K, B, epi, odt, adt = tag
+            nt = sum(epi.split("a")[0].count(c) for c in "pdr") + (1 if epi.endswith("+") else 0)
+            tot += B * (M * K + N * K) * es[adt] + B * M * N * es[odt] * (1 + nt)
+            n += 1
+        return tot, n
+
     def by_shape(self):
         """{(M, N, K, B, epilogue tag): (launches, ms, TFLOP/s)} — where the step's GEMM time goes."""
         torch.cuda.synchronize()

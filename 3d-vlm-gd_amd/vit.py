@@ -183,7 +183,7 @@ class _BlockFn(torch.autograd.Function):
         y1s = (y1 if fmt == "h" else _opa(y1, fmt)) if fmt else None    # tf32x / tf32h: ONE formatted copy of LN1(x) feeds the LoRA-A and the QKV GEMM
         if a_q is not None:
             if plan["x3"]:     # [M, 2r] on the streaming N <= 8 bf16 kernel over the 3K-wide operands (the fp32 tile kernel spends a 128-wide tile on 8 columns)
-                t = ops.gemm_nt(y1s, _opw(at.contiguous(), fmt), out_dtype=torch.float32)
+                t = ops.gemm_nt(y1s, tw["at_w3"] if tw is not None and "at_w3" in tw else _opw(at.contiguous(), fmt), out_dtype=torch.float32)
             else:
                 t = ops.gemm_nt(y1, at_T, out_dtype=torch.float32)  # [M, 2r]
         if fmt == "h":     # tf32h: q / k / v, the attention output and their gradients live as fp16 — they are operands of matrix products only
@@ -340,9 +340,13 @@ class _BlockFn(torch.autograd.Function):
                 # then the LoRA-A gradient dt^T . LN(x) on the same kernel with dt going in under s
                 # (dt stays in the scaled domain with h16dy: both of its consumers — the LoRA-A gradient and the rank update of the dX GEMM —
                 #  take it under s)
-                dt = ops.lora_bwd_fused_h(dqv, t, ops.cast16(bt_qv.float().contiguous()), z_bt, out_mul=sc[1:2], dt_scaled=h16dy)
+                bt16 = tw["bt_qv_w3"] if tw is not None and "bt_qv_w3" in tw and tw["bt_qv_w3"].dtype == torch.float16 else ops.cast16(bt_qv.float().contiguous())
+                dt = ops.lora_bwd_fused_h(dqv, t, bt16, z_bt, out_mul=sc[1:2], dt_scaled=h16dy)
                 gbt = z_bt
-                ops.lora_bwd_fused_h(y1, dt, None, z_at, t_mul=None if h16dy else sc[0:1], out_mul=sc[1:2])
+                if ops.lora_bwd_fused_h_supported(y1, dt, None, z_at):
+                    ops.lora_bwd_fused_h(y1, dt, None, z_at, t_mul=None if h16dy else sc[0:1], out_mul=sc[1:2])
+                else:       # (D not a multiple of 256, e.g. ViT-S: the streaming N = 8 kernel, fp32 dt against the fp16 LN(x))
+                    ops.gemm_tn(dt, y1, out=z_at, alpha_dev=sc[1:2] if h16dy else None)
                 gat = z_at
                 dqkv_s = dqkv
                 dt_is_scaled = h16dy
@@ -609,6 +613,10 @@ class GDViT(nn.Module):
                 w3 = lambda w: _opw(w.reshape(-1, w.shape[-1]).contiguous(), self.opfmt).view(L, w.shape[1], -1)
                 for i, pack in enumerate(zip(w3(down_T), w3(up_T), w3(down_tT), w3(up_tT))):
                     extra[i].update(zip(("down_w3", "up_w3", "down_tw3", "up_tw3"), pack))
+                # ... and the LoRA factors every block would otherwise format on its own (two launches instead of 2 L: A for the forward's rank
+                # projection, the (dq, dv) columns of B for the backward's)
+                for i, pack in enumerate(zip(w3(at.float()), w3(bt_qv.float()))):
+                    extra[i].update(zip(("at_w3", "bt_qv_w3"), pack))
         ops.amax_clear()        # (tf32h: scales registered for gradients of an earlier step that nobody consumed)
         for i, (inner, _, _) in enumerate(lo):
             inner._tw = {"dtype": T, "at": at[i], "bt": bt[i], "at_T": at_T[i], "bt_T": bt_T[i], "bt_qv": bt_qv[i], "down_T": down_T[i],

