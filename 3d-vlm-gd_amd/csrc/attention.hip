@@ -129,9 +129,11 @@ __device__ __forceinline__ void softmax_lagged(f32x4 (&s)[2][4], float (&m)[2], 
                 if (TAIL && k0 + kt * 16 + g * 4 + r >= N) s[qt][kt][r] = -1e30f;
                 tmax = fmaxf(tmax, s[qt][kt][r]);
             }
-        tmax = quad_rows_max(tmax);
-        const bool need = first || tmax > ATT_THR;
-        if (__any(need)) {
+        // the cross-lane maximum is only needed when SOME lane of the wave sees a score above the threshold (if no lane's own 16 scores exceed
+        // it, no query's 64 do): the steady state pays one compare and a wave-uniform branch, not the two lane exchanges
+        if (first || __any(tmax > ATT_THR)) {
+            tmax = quad_rows_max(tmax);
+            const bool need = first || tmax > ATT_THR;
             const float d = need ? tmax : 0.f;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
@@ -847,10 +849,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd32_kernel(const T* qkv, T* o, 
                     if (tail && k0 + 32 * kt2 + 8 * (r >> 2) + 4 * hh + (r & 3) >= N) s[kt2][r] = -1e30f;
                     tmax = fmaxf(tmax, s[kt2][r]);
                 }
-            tmax = half_swap_max(tmax);
             const bool first = t == 0;
-            const bool need = first || tmax > ATT_THR;
-            if (__any(need)) {
+            if (first || __any(tmax > ATT_THR)) {
+                tmax = half_swap_max(tmax);
+                const bool need = first || tmax > ATT_THR;
                 const float d = need ? tmax : 0.f;
 #pragma unroll
                 for (int kt2 = 0; kt2 < 2; ++kt2)

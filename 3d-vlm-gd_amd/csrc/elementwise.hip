@@ -1020,8 +1020,9 @@ extern "C" int gd_split3(const float* in, void* out, long rows, int K, long ld_i
 
 // ---- fp16 operands of the tf32h engine: x -> f16(sat(x * scale)); the scale of a GRADIENT tensor is a power of two taken from its own
 // maximum on the device (gd_amax_scale), carried to the consuming GEMM as a device scalar (gd_gemm_nt_scaled) — no host round trip.
-// range (nullable, 2 words, accumulated): how many results saturated at +-65504 ([0]) / fell below fp16's normal range 2^-14 with a non-zero
-// input ([1]: subnormal — fewer than 11 bits — or flushed to zero).  Counted per thread, one atomic per wave and only when non-zero.
+// range (nullable, 2 x 64 words of partial sums, accumulated): how many results saturated at +-65504 (words 0-63) / fell below fp16's normal range
+// 2^-14 with a non-zero input (words 64-127: subnormal — fewer than 11 bits — or flushed to zero).  Counted per thread, one atomic per block and
+// counter, and only when non-zero.
 __global__ __launch_bounds__(256) void cast_f16_kernel(const float* in, f16* out, long rows, int K, long ld_in, float scale, const float* scale_dev, unsigned* range) {
     const int kv = K / 8;
     const long total = rows * kv;
@@ -1044,11 +1045,17 @@ __global__ __launch_bounds__(256) void cast_f16_kernel(const float* in, f16* out
             }
         }
     }
-    if (range) {
+    if (range) {      // one atomic per block and counter, spread over 64 slots each ([0, 64) saturated, [64, 128) below normal range)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { nsat += (unsigned)__shfl_xor((int)nsat, o, 64); nlow += (unsigned)__shfl_xor((int)nlow, o, 64); }
-        if ((threadIdx.x & 63) == 0 && nsat) atomicAdd(range + 0, nsat);
-        if ((threadIdx.x & 63) == 0 && nlow) atomicAdd(range + 1, nlow);
+        __shared__ unsigned red[2][4];
+        if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = nsat; red[1][threadIdx.x >> 6] = nlow; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned ns = red[0][0] + red[0][1] + red[0][2] + red[0][3], nl = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+            if (ns) atomicAdd(range + (blockIdx.x & 63), ns);
+            if (nl) atomicAdd(range + 64 + (blockIdx.x & 63), nl);
+        }
     }
 }
 // max |in| as a BIT PATTERN (non-negative floats order like their bit patterns, and an Inf / NaN pattern is larger than every finite one: a

@@ -81,6 +81,7 @@ __device__ __forceinline__ unsigned wave_uadd(unsigned v) {
     return v;
 }
 #define GD_AMAX_SLOTS 256
+#define GD_RANGE_SLOTS 64      // range counters: [0, 64) saturated, [64, 128) below-normal-range — partial sums, spread so that the blocks' atomics do not queue on one line
 
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;  dx += dres when given
 // tf32h extras (gd_layernorm_bwd_ex): dy may arrive as fp16 under a device-side power-of-two scale (dys = 1 / s undoes it); dx also leaves as
@@ -92,8 +93,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* dy, const T* x, c
                                                      const float* rstd, const T* dres, const T* dres2, T* dx, int M, int D,
                                                      long ldd, long ldx, float dyscale, f16* dx16 = nullptr, const float* sdev = nullptr,
                                                      const float* dys_dev = nullptr, unsigned* amax = nullptr, unsigned* range = nullptr) {
-    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
+    const int lane = threadIdx.x & 63;
+    int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const bool live = row < M;
+    if (!live) {
+        if (!amax && !range) return;
+        row = M - 1;      // (with the block-level reductions below every wave reaches the barrier: a wave past M recomputes the last row and stores nothing)
+    }
     const float mu = mean[row], rs = rstd[row];
     const float s16 = (dx16 && sdev) ? *sdev : 1.0f;      // gd_layernorm_bwd_cast: dx also leaves as fp16(dx * s), the next product's operand
     if (dys_dev) dyscale *= *dys_dev;
@@ -136,15 +142,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* dy, const T* x, c
 #pragma unroll
                 for (int k = 0; k < 4; ++k) o[k] += r[k];
             }
-            store4n<T>(or_ + c, o);
+            if (live) store4n<T>(or_ + c, o);
             if (amax) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { const unsigned b = gd_f2u(o[k]) & 0x7fffffffu; mb = b > mb ? b : mb; }
             }
             if (dx16) {
                 const f32x4 os = o * s16;
-                store4n<f16>(dx16 + (long)row * D + c, os);
-                if (range) {
+                if (live) store4n<f16>(dx16 + (long)row * D + c, os);
+                if (range && live) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const unsigned b = gd_f2u(os[k]) & 0x7fffffffu;
@@ -155,15 +161,27 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* dy, const T* x, c
             }
         }
     }
-    if (amax) {
-        mb = wave_umax(mb);
-        unsigned* slot = amax + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (GD_AMAX_SLOTS - 1));
-        if (lane == 0 && mb > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, mb);
-    }
-    if (range) {
-        nsat = wave_uadd(nsat); nlow = wave_uadd(nlow);
-        if (lane == 0 && nsat) atomicAdd(range + 0, nsat);
-        if (lane == 0 && nlow) atomicAdd(range + 1, nlow);
+    // ONE atomic per block and counter, spread over the slots (a wave-level atomic of every one of the 87 680 rows on one address serialises at
+    // the memory side: measured +200 us on a 190 us pass)
+    if (amax || range) {
+        __shared__ unsigned red[3][4];
+        const int w = threadIdx.x >> 6;
+        if (amax) mb = wave_umax(mb);
+        if (range) { nsat = wave_uadd(nsat); nlow = wave_uadd(nlow); }
+        if (lane == 0) { red[0][w] = mb; red[1][w] = nsat; red[2][w] = nlow; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (amax) {
+                const unsigned a = red[0][0] > red[0][1] ? red[0][0] : red[0][1], b = red[0][2] > red[0][3] ? red[0][2] : red[0][3], m4 = a > b ? a : b;
+                unsigned* slot = amax + (blockIdx.x & (GD_AMAX_SLOTS - 1));
+                if (m4 > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, m4);
+            }
+            if (range) {
+                const unsigned ns = red[1][0] + red[1][1] + red[1][2] + red[1][3], nl = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+                if (ns) atomicAdd(range + (blockIdx.x & (GD_RANGE_SLOTS - 1)), ns);
+                if (nl) atomicAdd(range + GD_RANGE_SLOTS + (blockIdx.x & (GD_RANGE_SLOTS - 1)), nl);
+            }
+        }
     }
 }
 
@@ -373,7 +391,7 @@ extern "C" int gd_layernorm_bwd_cast(const float* dy, const float* x, const floa
 
 // The tf32h block backward's LayerNorm pass with every device-side extra (kernel comment above): dy f32 or fp16 (dy_dtype) times *dy_scale_dev,
 // dx16 / cast_scale_dev as gd_layernorm_bwd_cast (dx16 nullable here), amax_slots (GD_AMAX_SLOTS = 256 words, zeroed by gd_scale_from_amax after
-// each use) and range_counters (2 words, accumulated) nullable.
+// each use) and range_counters (2 x GD_RANGE_SLOTS = 128 words of partial sums, accumulated) nullable.
 extern "C" int gd_layernorm_bwd_ex(const void* dy, int dy_dtype, const float* dy_scale_dev, const float* x, const float* gamma, const float* mean,
                                    const float* rstd, const float* dres, const float* dres2, float* dx, void* dx16, const float* cast_scale_dev,
                                    unsigned* amax_slots, unsigned* range_counters, int M, int D, long ldd, long ldx, float dyscale, void* stream) {

@@ -167,7 +167,7 @@ class FinetuneGD(nn.Module):
         flushed).  Device-side, one atomic per wave and only when a count is non-zero: nothing here synchronises."""
         if getattr(self, "_range", None) is None:
             dev = next(self.parameters()).device
-            self._range = torch.zeros(2, dtype=torch.int32, device=dev)
+            self._range = torch.zeros(128, dtype=torch.int32, device=dev)      # 2 x 64 partial sums (csrc: GD_RANGE_SLOTS)
         return self._range
 
     def range_report(self, reset=True):
@@ -176,7 +176,7 @@ class FinetuneGD(nn.Module):
         would still have carried at full precision (the range contract)."""
         if getattr(self, "_range", None) is None:
             return {"saturated": 0, "below_normal": 0}
-        v = self._range.tolist()
+        v = self._range.view(2, 64).sum(1).tolist()
         if reset:
             self._range.zero_()
         return {"saturated": int(v[0]), "below_normal": int(v[1])}

@@ -192,9 +192,15 @@ GRAD_TARGET = 8.0      # |gradient| * s <= 8: 2^13 of fp16 headroom above the bl
 
 
 def set_range_counters(t):
-    """t: a zeroed int32 CUDA tensor [2] (or None): every scaled fp16 cast of the tf32h engine adds its saturated / below-normal-range counts."""
+    """t: a zeroed int32 CUDA tensor [128] (or None): every scaled fp16 cast of the tf32h engine adds its saturated (words 0-63) / below-normal-range
+    (words 64-127) counts as per-block partial sums; `range_totals(t)` adds them up."""
     global _RANGE
     _RANGE = t
+
+
+def range_totals(t):
+    """[saturated, below_normal] from a range-counter tensor (one host read)."""
+    return [int(v) for v in t.view(2, 64).sum(1).tolist()]
 
 
 def _slots(dev):

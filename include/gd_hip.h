@@ -285,8 +285,9 @@ int gd_split3(const float* in, void* out, long rows, int K, long ld_in, int whic
  * gd_amax_scale: scale3 (device, 3 floats) <- {s, 1/s, unused} with s the power of two that puts max|in| into (target/2, target]; a non-finite
  *   element makes s (and 1/s) NaN, so every consumer's result is poisoned as the f32 engine's arithmetic would be.  amax_slots: 256 zeroed words
  *   owned by the caller (zeroed again on return).  gd_scale_from_amax: the same {s, 1/s} from slots another kernel filled (gd_layernorm_bwd_ex).
- * gd_cast_f16_ex: gd_cast_f16 that also counts, in range_counters (2 words, accumulated; nullable), the results that saturated at +-65504 ([0]) and
- *   the non-zero inputs that fell below fp16's normal range 2^-14 ([1]) — the engine's run-time view of its range contract.
+ * gd_cast_f16_ex: gd_cast_f16 that also counts, in range_counters (128 words of partial sums, accumulated; nullable), the results that saturated at
+ *   +-65504 (sum of words 0-63) and the non-zero inputs that fell below fp16's normal range 2^-14 (sum of words 64-127) — the engine's run-time view
+ *   of its range contract (partial sums: one atomic per block, spread so that they do not queue on one line).
  * gd_gemm_nt_scaled: gd_gemm_nt with alpha multiplied by the device scalar *alpha_dev (the 1/s of a scaled operand) — no host round trip.
  * gd_gemm_nt itself takes ab_dtype GD_F16 (f32 results with f32 epilogue tensors, or c_dtype GD_F16: fp16 C, preact and dact_src). */
 int gd_cast_f16(const float* in, void* out, long rows, int K, long ld_in, float scale, const float* scale_dev, void* stream);
@@ -344,7 +345,7 @@ int gd_cast_f16_ex(const float* in, void* out, long rows, int K, long ld_in, flo
 /* The tf32h block backward's LayerNorm pass (autograd of nn.LayerNorm inside timm's Block, frozen affine: dX only) with the device-side extras:
  * dy f32 or fp16 (dy_dtype), multiplied by *dy_scale_dev when given (an fp16 dy under the block's scale s: 1/s); dx16 (nullable) = fp16(sat(dx *
  * *cast_scale_dev)); amax_slots (nullable, 256 words): max |dx| bit patterns, the NEXT block's gradient scale through gd_scale_from_amax without
- * a pass of its own; range_counters (nullable, 2 words): saturated / below-normal-range counts of dx16 as in gd_cast_f16_ex. */
+ * a pass of its own; range_counters (nullable, 128 words): saturated / below-normal-range partial sums of dx16 as in gd_cast_f16_ex. */
 int gd_layernorm_bwd_ex(const void* dy, int dy_dtype, const float* dy_scale_dev, const float* x, const float* gamma, const float* mean,
                         const float* rstd, const float* dres, const float* dres2, float* dx, void* dx16, const float* cast_scale_dev,
                         unsigned* amax_slots, unsigned* range_counters, int M, int D, long ldd, long ldx, float dyscale, void* stream);
