@@ -414,7 +414,8 @@ def cost_volume_roofline(job, args, dev, variant):
     ones = torch.ones(P, hw, dtype=torch.bool, device=dev)
     # keypoint-patch masks keep at most N_kp rows per view: the trainer (finetune.calculate_cost_loss) passes that bound and the op runs its kept-row form
     kmax = int(b["kp_1"].shape[1]) if variant == "mast3r" else None
-    bench_masks, tf = leg(m1, m2, None, kmax=kmax)
+    # (the kept-row kernel's own PMC passes: round 4, tools/pmc_cv_r04.sh — taken on the fp16 copies; the bf16 instantiation moves the same bytes)
+    bench_masks, tf = leg(m1, m2, "r04_pmc_cost_volume_traffic_rows.json" if kmax else None, kmax=kmax)
     unmasked, tfu = leg(ones, ones, "r03_pmc_cost_volume_traffic_full.json")
     tfb = timed(m1, m2, backward=True, kmax=kmax)
     tfbu = timed(ones, ones, backward=True)
@@ -467,9 +468,8 @@ def comm_report(job, args, dev, dt):
            "exposed_comm_frac": round(max(0.0, (dt - dt0) / dt), 4)}
     # the same ranks, inputs and steps with (a) the OTHER exchange mode and (b) the other CU reservation: what the first multi-GPU run should look at
     variants = {}
+    flat, eng, keep = job.flat, job.eng, job.reducer
     try:
-        flat, eng = job.flat, job.eng
-        keep = job.reducer
         keep.detach()
         if args.exchange == "torch":
             job.reducer = dp.DirectGradReducer(flat["g"], dp.RcclComm(dist.get_rank(), world))
@@ -480,22 +480,31 @@ def comm_report(job, args, dev, dt):
         dtx, _ = job.timed(args.steps, 1, dev)
         other = "direct" if args.exchange == "torch" else "torch"
         variants["exchange_" + other] = {"ms_per_step": round(dtx / args.steps * 1e3, 3), "exposed_comm_frac": round(max(0.0, (dtx - dt0) / dtx), 4)}
-        job.reducer.detach()
+    except Exception as e:       # a variant that cannot run (e.g. two ranks sharing one GPU: no RCCL communicator) must not cost the headline line
+        variants["exchange_error"] = repr(e)[:200]
+    finally:
+        try:
+            job.reducer.detach()
+        except Exception:
+            pass
         job.reducer = keep
+        job.reducer.world = world
         job.reducer.attach()
-        alt = 0 if args.reserve_cus else 8
+    alt = 0 if args.reserve_cus else 8
+    try:
         dp.reserve_cus_for_collectives(alt)
         dtr, _ = job.timed(args.steps, 1, dev)
         job.reducer.world = 1
         job.reducer.detach()
         dtr0, _ = job.timed(args.steps, 1, dev)
+        variants[f"reserve_cus_{alt}"] = {"ms_per_step": round(dtr / args.steps * 1e3, 3), "ms_per_step_without_exchange": round(dtr0 / args.steps * 1e3, 3),
+                                          "exposed_comm_frac": round(max(0.0, (dtr - dtr0) / dtr), 4)}
+    except Exception as e:
+        variants["reserve_error"] = repr(e)[:200]
+    finally:
         job.reducer.world = world
         job.reducer.attach()
         dp.reserve_cus_for_collectives(args.reserve_cus)
-        variants[f"reserve_cus_{alt}"] = {"ms_per_step": round(dtr / args.steps * 1e3, 3), "ms_per_step_without_exchange": round(dtr0 / args.steps * 1e3, 3),
-                                          "exposed_comm_frac": round(max(0.0, (dtr - dtr0) / dtr), 4)}
-    except Exception as e:       # a variant that cannot run (e.g. no RCCL for the direct path) must not cost the headline line
-        variants["error"] = repr(e)[:200]
     out["variants"] = variants
     return out
 

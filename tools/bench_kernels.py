@@ -164,6 +164,29 @@ def pmc_cv_kp(full=False):
     torch.cuda.synchronize()
 
 
+def pmc_cv_rows():
+    """the kept-row forward as the tf32h trainer runs it (gd_cost_volume_kl_fwd_rows on the fp16 feature copies, kept_rows_max = the keypoint
+    count): the target of the round-4 --pmc passes behind bench.py's masked `roofline_cost_volume.traffic`."""
+    P, hw, C, img, patch = 32, 1369, 768, 518, 14
+    g = torch.Generator(device="cuda").manual_seed(0)
+    f1 = torch.randn(P, hw, C, device="cuda", generator=g)
+    f2 = torch.randn(P, hw, C, device="cuda", generator=g)
+    t1 = torch.softmax(3 * torch.randn(P, hw, hw, device="cuda", generator=g), -1)
+    t2 = torch.softmax(3 * torch.randn(P, hw, hw, device="cuda", generator=g), -1)
+    kp1 = torch.rand(P, 300, 2, device="cuda", generator=g) * (img - 1)
+    kp2 = torch.rand(P, 300, 2, device="cuda", generator=g) * (img - 1)
+    m1, m2 = ops.patch_mask(kp1, img, img, patch), ops.patch_mask(kp2, img, img, patch)
+    t1, t2 = ops.pad_teacher_maps(t1), ops.pad_teacher_maps(t2)
+    ts = ops.cost_volume_teacher_stats(t1, t2)
+    print("kept rows", int(m1.sum()), int(m2.sum()), "of", P * hw, "each")
+    inv = (1.0 / f1.norm(dim=-1).clamp_min(1e-12), 1.0 / f2.norm(dim=-1).clamp_min(1e-12))
+    h16 = (f1.half(), f2.half())
+    with torch.no_grad():
+        for _ in range(3):
+            ops.cost_volume_kl(f1, f2, t1, t2, m1, m2, "mast3r", tstats=ts, inv_norms=inv, x3="h", h16=h16, kept_rows_max=300)
+    torch.cuda.synchronize()
+
+
 def bench_attn():
     for (B, N, H) in ((64, 1370, 12), (8, 6401, 12)):
         _bench_attn(B, N, H)
@@ -355,6 +378,8 @@ if __name__ == "__main__":
         pmc_cv_kp()
     if "pmc_cv_full" in which:
         pmc_cv_kp(full=True)
+    if "pmc_cv_rows" in which:
+        pmc_cv_rows()
     if "attn" in which:
         bench_attn()
     if "attn_x3" in which:

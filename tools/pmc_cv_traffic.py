@@ -33,6 +33,29 @@ def per_kernel(d, counter):
 fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
 tag, kept = sys.argv[4], (int(sys.argv[5]), int(sys.argv[6]))
 P, hw, C = 32, 1369, 768
+if tag == "rows":
+    # round 4: the kept-row forward (cv_fwd_rows_kernel<f16>: both directions as compacted row problems).  Its read streams: the other view's
+    # feature rows and the gathered kept rows by LDS-DMA (8 rows x 128 B per instruction: 128-byte requests, FETCH_SIZE tallies 1/2) and the
+    # kept rows' teacher rows (row-contiguous, 256 B per row and instruction: 128-byte requests, 1/2): expected_raw = needed / 2 for the tile
+    # kernel; the index-list / finalize / loss kernels read dwords (1 : 1).
+    feat = P * 2 * hw * C * 2 + sum(kept) * C * 2                  # every row of the other view per direction + the kept rows of the own view
+    teach = sum(kept) * hw * 4
+    needed = feat + teach + P * 2 * hw
+    raw_tile = sum(mb for k, mb in fetch.items() if "fwd_rows" in k)
+    expected_raw = (feat + teach) / 2e6
+    over = raw_tile / expected_raw
+    moved = over * (feat + teach) / 1e6 + sum(mb for k, mb in fetch.items() if "fwd_rows" not in k) + sum(write.values())
+    out = {"what": "HBM-side traffic of the KEPT-ROW cost-volume KL forward per launch (keypoint-patch row masks; 32 pairs, hw = 1369, C = 768, fp16 feature "
+                   "copies, teacher maps [P, hw, 1376] with cached row statistics, row norms from the producer): rocprofv3 --pmc FETCH_SIZE and --pmc "
+                   "WRITE_SIZE in separate passes on tools/bench_kernels.py pmc_cv_rows",
+           "kept_rows": kept, "raw_fetch_MB": {k: round(v, 2) for k, v in fetch.items()}, "write_MB": {k: round(v, 2) for k, v in write.items()},
+           "correction": "cv_fwd_rows: features (LDS-DMA) and kept teacher rows (256 contiguous bytes per row and instruction) are 128-byte requests, "
+                         "FETCH_SIZE counts 1/2 (MI355X_MICROARCH.md); small kernels 1 : 1",
+           "cv_fwd_rows_expected_raw_MB": round(expected_raw, 2), "cv_fwd_rows_over_fetch": round(over, 3),
+           "fwd_hbm_bytes_per_launch": int(moved * 1e6), "needed_bytes_per_launch": needed, "ratio_to_needed": round(moved * 1e6 / needed, 3)}
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    print(json.dumps(out))
+    sys.exit(0)
 needed = P * (2 * hw * C * 2 + 2 * hw) + sum(kept) * hw * 4
 feat_mb = P * 2 * hw * C * 2 / 1e6
 t1_mb, t2_mb = kept[0] * hw * 4 / 1e6, kept[1] * hw * 4 / 1e6
