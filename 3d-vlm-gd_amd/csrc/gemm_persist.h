@@ -133,10 +133,20 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
     const void* side_src = SIDE == 2 ? p.residual : p.dact_src;
     const long side_ld = SIDE == 2 ? p.ldr : p.ldd;
 
+    // tile order inside an XCD's contiguous chunk: row-panel-major (group_m = 1: the tiles_n tiles of a row panel, then the next panel), or
+    // GROUPED — group_m row panels per W panel before the next W panel (the 32 tiles an XCD works on at one time then share group_m A panels and
+    // 32 / group_m W panels instead of ~3 A panels and the whole W: a smaller working set in the 4 MB L2)
+    auto tile_of = [&](int wg_, int& tm_, int& tn_) {
+        if (p.group_m <= 1) { tm_ = wg_ / tiles_n; tn_ = wg_ % tiles_n; return; }
+        const int per = p.group_m * tiles_n, gid = wg_ / per, first = gid * p.group_m;
+        const int gsz = min(tiles_m - first, p.group_m), r = wg_ - gid * per;
+        tm_ = first + r % gsz; tn_ = r / gsz;
+    };
     int t = blockIdx.x, slot = 0;
     if (t >= ntiles) return;
     int wg = xcd_remap(t, ntiles);
-    int tm = wg / tiles_n, tn = wg % tiles_n;
+    int tm, tn;
+    tile_of(wg, tm, tn);
     auto prologue = [&](int tm_, int tn_, int slot_) {
         set_tile(tm_, tn_);
         issue(0, 0);
@@ -296,7 +306,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
             if (idx == DMA_AT) {
                 if (more) {
                     wg = xcd_remap(t, ntiles);
-                    tm = wg / tiles_n; tn = wg % tiles_n; slot ^= 1;
+                    tile_of(wg, tm, tn); slot ^= 1;
                     prologue(tm, tn, slot);
                 }
                 asm volatile("" ::: "memory");   // nothing younger may be hoisted above the DMA: `after` counts on it
