@@ -10,6 +10,7 @@ struct GdKnobs {
     int gemm_f32_big;      // GD_GEMM_F32_BIG      1: 256x256 tiles for f32 operands
     int gemm_cstore;       // GD_GEMM_CSTORE       C store policy of the staged kernels (0 LDS-staged, 1 direct)
     int gemm_group_m;      // GD_GEMM_GROUP_M      persistent kernel: row panels per W panel in an XCD's tile walk (1 = row-panel-major)
+    int gemm_stagger;      // GD_GEMM_STAGGER      persistent kernel: start-up skew of block group (b >> 3) & 3, in 10 ns ticks per group (0 none)
     int gemm_krot;         // GD_GEMM_KROT         per-tile K-step rotation of the persistent kernel (0 off)
     int gemm_batch_big_m;  // GD_GEMM_BATCH_BIG_M  batched gemm_nt: smallest M served by the 256 x 256 kernels (384: the kept-row cost-volume contractions, 97 vs 149 us; un-batched: 1024)
     int gemm_anat;         // GD_GEMM_ANAT         anatomy instantiations of the persistent main loop (0 = the product kernel)

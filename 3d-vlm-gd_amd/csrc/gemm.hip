@@ -32,6 +32,7 @@ struct GemmNtParams {
     int vec_epilogue;                // every epilogue tensor is 16-byte aligned with 16-byte-multiple row strides
     int c_policy;                    // 0 plain C stores, 1 write-through (sc1) C stores (GD_GEMM_CSTORE, default 1)
     unsigned long long* probe;       // gd_gemm_phase_probe accumulators (device) in -DGD_GEMM_STAGE_PROBE builds, else null
+    int stagger;                     // persistent kernel: start-up skew between the four block groups of an XCD, in 10 ns ticks (GD_GEMM_STAGGER; 0 = none)
     int group_m;                     // persistent kernel: tiles of an XCD's chunk walk GM row panels per W panel (GD_GEMM_GROUP_M; 1 = row-panel-major order)
     int k_rot;                       // persistent kernel: per-tile rotation of the K-step order, krot = (tn * k_rot + tm) % nk (GD_GEMM_KROT, default 1, 0 = off: +1.3 % on the step, in-step A/B 525.6 vs 518.8 pairs/s)
 };
@@ -869,6 +870,7 @@ static int gemm_nt_impl(const void* A, const void* W, void* C, int M, int N, int
     p.probe = gd_probe_buffer();
     p.k_rot = gd_knobs().gemm_krot;
     p.group_m = gd_knobs().gemm_group_m > 0 ? gd_knobs().gemm_group_m : 1;
+    p.stagger = gd_knobs().gemm_stagger;
     const bool big = dma && N >= 256 && M >= (batch > 1 ? gd_knobs().gemm_batch_big_m : 1024) && !gd_force_small_tiles();
     dim3 gridb(gd_cdiv(M, 256) * gd_cdiv(N, 256), batch);
     hipStream_t st = (hipStream_t)stream;

@@ -154,6 +154,11 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
         if (nk > 1) issue(1, 1);
     };
     prologue(tm, tn, slot);
+    if (p.stagger) {
+        // start-up skew (experiment): the CUs of an XCD run their epilogues at four different phases of a tile instead of all at once
+        const unsigned long long until = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(((blockIdx.x >> 3) & 3) * p.stagger);
+        while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(8);
+    }
     // VMEM instructions every wave issues unconditionally in one epilogue (buffer ops, range-checked by the hardware)
     int after = 0;   // of those, how many were issued after this tile's stage-1 DMA (0 for the block's first tile)
 

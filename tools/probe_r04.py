@@ -79,9 +79,16 @@ def shapes():
     wq_t = wqkv.t().contiguous()
     cases[-2] = (cases[-2][0], D, 3 * D, lambda: ops.gemm_nt(dqkv, wq_t, lora_t=t8, lora_b=at, out_dtype=torch.float32, alpha_dev=one))
     cases[-1] = (cases[-1][0], D, 3 * D, lambda: ops.gemm_nt(dqkv, wq_t, lora_t=t8, lora_b=at, out_dtype=torch.float16))
+    staggers = [int(v) for v in os.environ.get("STAGGERS", "0").split(",")]
+    from gd_amd._lib import lib
     for name, N, K, fn in cases:
-        t = timeit(fn, warm=10, it=60)
-        print(f"shape {name} {M}x{N}x{K}: {t * 1e6:8.1f} us  {2.0 * M * N * K / t / 1e12:7.1f} TF/s", flush=True)
+        line = f"shape {name} {M}x{N}x{K}:"
+        for sg in staggers:
+            lib().gd_debug_set(b"gemm_stagger", sg)
+            t = timeit(fn, warm=10, it=60)
+            line += f"  [skew {sg * 10} ns] {t * 1e6:7.1f} us {2.0 * M * N * K / t / 1e12:6.1f} TF/s"
+        lib().gd_debug_set(b"gemm_stagger", 0)
+        print(line, flush=True)
 
 
 def ln():
