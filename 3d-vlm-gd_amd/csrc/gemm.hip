@@ -870,7 +870,10 @@ static int gemm_nt_impl(const void* A, const void* W, void* C, int M, int N, int
     p.probe = gd_probe_buffer();
     p.k_rot = gd_knobs().gemm_krot;
     p.group_m = gd_knobs().gemm_group_m > 0 ? gd_knobs().gemm_group_m : 1;
-    p.stagger = gd_knobs().gemm_stagger;
+    // start-up skew of the persistent kernel (gemm_persist.h), an experiment knob: back-to-back stand-alone launches of the K = 768 shapes gain 6 ... 24 us
+    // (proj + fp32 residual 176 -> 152 us: the CUs stop running their epilogues in lockstep), the step does not (58.2 vs 58.2 ms, two alternating pairs of
+    // runs: in the step a launch starts on CUs that the previous kernel releases at different times) — profiles/r04_gemm_stagger.txt.  Default 0.
+    p.stagger = gd_knobs().gemm_stagger > 0 ? gd_knobs().gemm_stagger : 0;
     const bool big = dma && N >= 256 && M >= (batch > 1 ? gd_knobs().gemm_batch_big_m : 1024) && !gd_force_small_tiles();
     dim3 gridb(gd_cdiv(M, 256) * gd_cdiv(N, 256), batch);
     hipStream_t st = (hipStream_t)stream;

@@ -155,8 +155,11 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
     };
     prologue(tm, tn, slot);
     if (p.stagger) {
-        // start-up skew (experiment): the CUs of an XCD run their epilogues at four different phases of a tile instead of all at once
-        const unsigned long long until = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(((blockIdx.x >> 3) & 3) * p.stagger);
+        // start-up skew (experiment): the CUs run their epilogues at P different phases of a tile instead of all at once.
+        // p.stagger = ticks (10 ns) | P << 16 (0: 4) | mode << 24 (0: phase = CU slot within its XCD; 1: phase = XCD)
+        const int P = ((p.stagger >> 16) & 0xff) ? ((p.stagger >> 16) & 0xff) : 4, mode = p.stagger >> 24;
+        const int ph = (mode == 1 ? (int)blockIdx.x : (int)(blockIdx.x >> 3)) % P;
+        const unsigned long long until = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(ph * (p.stagger & 0xffff));
         while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(8);
     }
     // VMEM instructions every wave issues unconditionally in one epilogue (buffer ops, range-checked by the hardware)
