@@ -1,3 +1,7 @@
+// Probe of the cross-lane row maximum the attention forward uses (v_permlane16_swap + v_permlane32_swap, attention.hip quad_rows_max):
+// the maximum over lanes {l, l^16, l^32, l^48}.  Written with by-value scalars (a0, a1) it is correct; with
+// __builtin_bit_cast(float, a[1]) applied to the ELEMENT EXPRESSION of the builtin's ext-vector result, ROCm 7.2's clang reads element 0
+// and the "maximum" is one lane group's value ("Range contract").  hipcc --offload-arch=gfx950 permlane_bitcast_probe.hip && ./a.out
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 __global__ void k(float* out) {
