@@ -241,8 +241,14 @@ def main():
     job = Job(backbone, variant, args.dtype, args.geometry, P, img, N, dev, rank, world, weights=weights, exchange=args.exchange)
     eng, hw = job.eng, job.hw
     prof = None if args.no_kernel_events else ops.GemmProfiler()
+    if args.dtype == "tf32h":
+        eng_rr = job.eng.range_report()              # reset: the report below covers the warm-up + timed steps of this run
     dt, loss = job.timed(args.steps, args.warmup, dev, prof)
     pairs_per_s = P * world * args.steps / dt
+    # tf32h: how many scaled fp16 gradient operands saturated / fell below fp16's normal range over these steps (device counters, ONE host read here)
+    fp16_range = dict(job.eng.range_report(), steps=args.steps + args.warmup,
+                      what="scaled fp16 gradient casts of the tf32h engine: elements clamped at +-65504 / elements below 2^-14 after the block's "
+                           "power-of-two scale (DESIGN.md 4, range contract); 0 saturated = no gradient operand lost its top") if args.dtype == "tf32h" else None
 
     comm = comm_report(job, args, dev, dt) if world > 1 else None
 
@@ -268,6 +274,7 @@ def main():
                                          "f32": "exact-f32 MFMA: the reference's fp32 arithmetic", "tf32x": "fp32 storage, 3-term bf16 split products "
                                          "(error 4e-6: better than TF32)"}[args.dtype]},
                "loss": round(float(loss.detach()), 6),
+               **({"fp16_range": fp16_range} if fp16_range else {}),
                "vit_algorithmic_tflops": round(pairs_per_s / world * flop_pair / 1e12, 2),
                "vit_frac_of_mfma_peak": round(pairs_per_s / world * flop_pair / 1e12 / PEAK_TFLOPS[args.dtype], 4)}
         if prof:

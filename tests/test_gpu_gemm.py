@@ -177,6 +177,28 @@ def test_gemm_nt_persistent_ragged_n_and_batched():
     assert out.dtype == torch.float32 and rel_err(out, ab.double() @ wb.double().transpose(1, 2)) < 1e-5
 
 
+def test_gemm_nt_persistent_schedule_knobs_do_not_change_results():
+    """the persistent kernel's schedule options — grouped tile order (gemm_group_m), start-up skew of the blocks (gemm_stagger), compute units left to
+    collectives (reserve_cus) — change WHEN and WHERE a tile is computed, never its value: outputs are bit-identical to the default schedule, with a
+    side tensor and a ragged last tile row in play."""
+    from gd_amd import ops
+    from gd_amd._lib import lib
+    M, N, K = 256 * 37 + 19, 768, 768                      # 114 tiles: fewer than one round at 256 CUs but several per block at reserve_cus = 200
+    a, w = _mk((M, K), torch.float16, 71), _mk((N, K), torch.float16, 72) * 0.05
+    bias, res = _mk((N,), torch.float32, 73), _mk((M, N), torch.float32, 74)
+    run = lambda: ops.gemm_nt(a, w, bias=bias, residual=res, out_dtype=torch.float32)
+    ref = run()
+    try:
+        for name, val in [("gemm_group_m", 4), ("gemm_stagger", 150 | (8 << 16)), ("gemm_stagger", 300 | (4 << 16) | (1 << 24)), ("reserve_cus", 200)]:
+            assert lib().gd_debug_set(name.encode(), val) == 0
+            out = run()
+            assert lib().gd_debug_set(name.encode(), 1 if name == "gemm_group_m" else 0) == 0
+            assert torch.equal(out, ref), name
+    finally:
+        for name, val in [("gemm_group_m", 1), ("gemm_stagger", 0), ("reserve_cus", 0)]:
+            lib().gd_debug_set(name.encode(), val)
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 1e-2)])
 def test_gemm_nt_batched_strided(dtype, tol):
     from gd_amd import ops
