@@ -9,24 +9,26 @@ from gd_amd.finetune import FinetuneGD
 from gd_testutil import synthetic_batch
 
 
-def compare(steps=40, P=8):
-    """bf16 and f32 engines from the same initial weights on the same fixed batch: the two loss trajectories side by side
-    (training-level parity of the throughput mode against the reference-precision mode)."""
+def compare(steps=40, P=8, others=("bf16",), lr=1e-4):
+    """the f32 engine and the faster engines from the same initial weights on the same fixed batch: the loss trajectories side by side
+    (training-level parity of the throughput / TF32-class modes against the reference-precision mode).  For tf32h the fp16 range counters
+    of the whole run are printed (saturated must stay 0 while the gradients shrink with the loss)."""
     dev = torch.device("cuda", 0)
     img, N, patch = 518, 300, 14
     hw = (img // patch) ** 2
     engs = {}
-    for dt in ("f32", "bf16"):
+    for dt in ("f32",) + tuple(others):
         torch.manual_seed(0)
         e = FinetuneGD(r=4, backbone="vit_base", patch_size=patch, img_size=img, variant="mast3r", geometry="shared",
                        dtype=dt, teacher_patch=patch, lora_b_std=1e-3, vit_kwargs=dict(init_values=1.0)).to(dev)
-        e.configure_optimizers(lr=1e-4)
+        e.configure_optimizers(lr=lr)
         engs[dt] = e
     with torch.no_grad():        # identical weights (the constructor's init is seeded, but make it explicit)
-        for a, b in zip(engs["f32"].parameters(), engs["bf16"].parameters()):
-            b.copy_(a)
+        for dt in others:
+            for a, b in zip(engs["f32"].parameters(), engs[dt].parameters()):
+                b.copy_(a)
     batch = synthetic_batch(P, img, img, N, hw, dev, seed=7, teacher_patch=patch)
-    worst = 0.0
+    worst = {dt: 0.0 for dt in others}
     for s in range(steps):
         row = {}
         for dt, e in engs.items():
@@ -34,12 +36,15 @@ def compare(steps=40, P=8):
             e.backward(loss)
             e.optimizer_step()
             row[dt] = float(loss)
-        rel = abs(row["bf16"] - row["f32"]) / abs(row["f32"])
-        worst = max(worst, rel)
+        for dt in others:
+            worst[dt] = max(worst[dt], abs(row[dt] - row["f32"]) / abs(row["f32"]))
         if s % 5 == 0 or s == steps - 1:
-            print(f"step {s:3d}  f32 {row['f32']:.5f}  bf16 {row['bf16']:.5f}  rel diff {rel:.2e}")
-    print(f"worst relative difference of the loss over {steps} steps: {worst:.2e}")
-    assert worst < 5e-3
+            print(f"step {s:3d}  f32 {row['f32']:.5f}  " + "  ".join(f"{dt} {row[dt]:.5f} (rel {abs(row[dt] - row['f32']) / abs(row['f32']):.1e})" for dt in others), flush=True)
+    for dt in others:
+        print(f"{dt}: worst relative difference of the loss over {steps} steps (lr {lr:g}): {worst[dt]:.2e}")
+    if "tf32h" in engs:
+        print("tf32h fp16 range counters over the run:", engs["tf32h"].range_report())
+    assert all(w < 5e-3 for w in worst.values())
 
 
 def main(steps=40, P=8):
@@ -66,7 +71,10 @@ def main(steps=40, P=8):
 
 
 if __name__ == "__main__":
-    if "compare" in sys.argv[1:]:
+    if "compare3" in sys.argv[1:]:          # python tools/train_check.py compare3 [steps] [lr]
+        extra = [a for a in sys.argv[1:] if a != "compare3"]
+        compare(steps=int(extra[0]) if extra else 100, others=("tf32h", "bf16"), lr=float(extra[1]) if len(extra) > 1 else 1e-4)
+    elif "compare" in sys.argv[1:]:
         compare()
     else:
         main()
