@@ -370,8 +370,7 @@ __global__ __launch_bounds__(256, 1) void adapter_persist_h_kernel(const float* 
             constexpr int i = ic;
             const int lin = i * 256 + tid, row = lin / CPR, p = lin % CPR;
             f16x8 h;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { h[k] = from_f32<f16>(pre[i][0][k] * sin); h[4 + k] = from_f32<f16>(pre[i][1][k] * sin); }
+            { const float t8[8] = {pre[i][0][0] * sin, pre[i][0][1] * sin, pre[i][0][2] * sin, pre[i][0][3] * sin, pre[i][1][0] * sin, pre[i][1][1] * sin, pre[i][1][2] * sin, pre[i][1][3] * sin}; h = f16_sat8(t8); }
             *(f16x8*)(sX + (row * CPR + (p ^ (row & 15))) * 16) = h;
             *(f32x4*)(sR + (row * D + p * 8) * 4) = pre[i][0];
             *(f32x4*)(sR + (row * D + p * 8 + 4) * 4) = pre[i][1];
@@ -459,7 +458,7 @@ __global__ __launch_bounds__(256, 1) void adapter_persist_h_kernel(const float* 
                                      fmaf(alpha, acc[i][2][r], xr[2]), fmaf(alpha, acc[i][3][r], xr[3])};
                     *(f32x4*)(out32 + (long)(row0 + row) * D + col) = o;
                     if (out16) {
-                        const f16x4 h = {from_f32<f16>(o[0] * scp), from_f32<f16>(o[1] * scp), from_f32<f16>(o[2] * scp), from_f32<f16>(o[3] * scp)};
+                        const f16x4 h = f16_sat4(o[0] * scp, o[1] * scp, o[2] * scp, o[3] * scp);
                         *(f16x4*)(out16 + (long)(row0 + row) * D + col) = h;
                     }
                 }

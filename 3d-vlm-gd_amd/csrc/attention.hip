@@ -380,7 +380,7 @@ template <> __device__ __forceinline__ void store4<bf16>(bf16* p, f32x4 v) {
     *(bf16x4*)p = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
 }
 template <> __device__ __forceinline__ void store4<f16>(f16* p, f32x4 v) {
-    *(f16x4*)p = f16x4{from_f32<f16>(v[0]), from_f32<f16>(v[1]), from_f32<f16>(v[2]), from_f32<f16>(v[3])};
+    *(f16x4*)p = f16_sat4(v[0], v[1], v[2], v[3]);
 }
 
 // ------------------------------------------------------------------------------------------ forward

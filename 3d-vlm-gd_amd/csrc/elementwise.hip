@@ -975,9 +975,7 @@ __global__ __launch_bounds__(256) void tap_mean_norm_fwd_kernel(TapMeanParams p,
         }
         *(uint4*)(out + row * D + (long)v * V) = o;
         if (sizeof(T) == 4 && out16) {      // tf32h engine: the fp16 copy the cost-volume products take, from the same pass
-            f16x4 h;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) h[k] = from_f32<f16>(to_f32<T>(oe[k]));
+            const f16x4 h = f16_sat4(to_f32<T>(oe[0]), to_f32<T>(oe[1]), to_f32<T>(oe[2]), to_f32<T>(oe[3]));
             *(f16x4*)(out16 + row * D + (long)v * 4) = h;
         }
     }
@@ -1033,8 +1031,7 @@ __global__ __launch_bounds__(256) void cast_f16_kernel(const float* in, f16* out
         const int c = (int)(idx - r * kv) * 8;
         const f32x4 a = *(const f32x4*)(in + r * ld_in + c), b = *(const f32x4*)(in + r * ld_in + c + 4);
         f16x8 h;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { h[k] = from_f32<f16>(a[k] * sc); h[4 + k] = from_f32<f16>(b[k] * sc); }
+        { const float t8[8] = {a[0] * sc, a[1] * sc, a[2] * sc, a[3] * sc, b[0] * sc, b[1] * sc, b[2] * sc, b[3] * sc}; h = f16_sat8(t8); }
         *(f16x8*)(out + r * (long)K + c) = h;
         if (range) {
 #pragma unroll

@@ -51,9 +51,31 @@ template <> __device__ __forceinline__ float to_f32<f16>(f16 v) { return (float)
 template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf16)v; }
-// fp16 has 5 exponent bits: saturate instead of producing inf (the tf32h engine's operands; see gd_cast_f16)
-__device__ __forceinline__ float f16_sat(float v) { return __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f); }
-template <> __device__ __forceinline__ f16 from_f32<f16>(float v) { return (f16)f16_sat(v); }
+// fp32 -> fp16 for the tf32h engine's operands: SATURATING at +-65504 (fp16 has 5 exponent bits; see gd_cast_f16) and NaN-PROPAGATING.  Convert first
+// (round to nearest even: overflow -> inf, NaN -> NaN), then clamp with gfx950's IEEE-754-2019 minimum / maximum (v_[pk_]minimum3_f16 / v_[pk_]maximum3_f16
+// return NaN when an operand is NaN).  v_med3_f32 / v_min / v_max return the OTHER operand for a NaN: the fp32 median-of-three clamp this replaces turned
+// NaN into -65504 and hid a poisoned activation from everything downstream (the packed pair form costs the same three instructions per two elements).
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+__device__ __forceinline__ f16 f16_clamp(f16 h) { return __builtin_elementwise_minimum(__builtin_elementwise_maximum(h, (f16)-65504.0f), (f16)65504.0f); }
+__device__ __forceinline__ f16x2 f16_sat2(float a, float b) {
+    const f16x2 lo = {(f16)-65504.0f, (f16)-65504.0f}, hi = {(f16)65504.0f, (f16)65504.0f};
+    const f16x2 h = {(f16)a, (f16)b};
+    return __builtin_elementwise_minimum(__builtin_elementwise_maximum(h, lo), hi);
+}
+__device__ __forceinline__ f16x4 f16_sat4(float a, float b, float c, float d) {
+    const f16x2 p = f16_sat2(a, b), q = f16_sat2(c, d);
+    return f16x4{p[0], p[1], q[0], q[1]};
+}
+template <int N> __device__ __forceinline__ void f16_satn(const float (&v)[N], f16* out) {      // N even; out may be an element pointer into an ext-vector's storage copy
+    static_assert(N % 2 == 0, "pairs");
+#pragma unroll
+    for (int k = 0; k < N; k += 2) { const f16x2 p = f16_sat2(v[k], v[k + 1]); out[k] = p[0]; out[k + 1] = p[1]; }
+}
+__device__ __forceinline__ f16x8 f16_sat8(const float (&v)[8]) {
+    const f16x2 a = f16_sat2(v[0], v[1]), b = f16_sat2(v[2], v[3]), c = f16_sat2(v[4], v[5]), d = f16_sat2(v[6], v[7]);
+    return f16x8{a[0], a[1], b[0], b[1], c[0], c[1], d[0], d[1]};
+}
+template <> __device__ __forceinline__ f16 from_f32<f16>(float v) { return f16_clamp((f16)v); }
 
 // load/store one element of a runtime-typed buffer (dt = GD_F32 / GD_BF16)
 __device__ __forceinline__ float ld_rt(const void* p, long i, int dt) {

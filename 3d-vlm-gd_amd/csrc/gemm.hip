@@ -122,9 +122,7 @@ __device__ __forceinline__ void st8_rt(void* p, long i, int dt, const float (&v)
     if (dt == GD_BF16) {
         *(bf16x8*)((bf16*)p + i) = bf16x8{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
     } else if (dt == GD_F16) {
-        f16x8 h;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) h[k] = from_f32<f16>(v[k]);
+        const f16x8 h = f16_sat8(v);
         *(f16x8*)((f16*)p + i) = h;
     } else {
         *(f32x4*)((float*)p + i) = f32x4{v[0], v[1], v[2], v[3]};
@@ -142,9 +140,7 @@ __device__ __forceinline__ void st8_wt(__amdgpu_buffer_rsrc_t rs, int byte_off, 
         const bf16x8 b = bf16x8{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, b), rs, byte_off, 0, 16);
     } else if (dt == GD_F16) {
-        f16x8 h;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) h[k] = from_f32<f16>(v[k]);
+        const f16x8 h = f16_sat8(v);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h), rs, byte_off, 0, 16);
     } else {
         const f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};

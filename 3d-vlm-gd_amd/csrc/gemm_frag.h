@@ -91,7 +91,7 @@ __device__ __forceinline__ void bst4_aux(__amdgpu_buffer_rsrc_t rs, int off, int
         const bf16x4 b = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(gd_u32x2, b), rs, off, 0, AUX);
     } else if (dt == GD_F16) {
-        const f16x4 b = f16x4{from_f32<f16>(v[0]), from_f32<f16>(v[1]), from_f32<f16>(v[2]), from_f32<f16>(v[3])};
+        const f16x4 b = f16_sat4(v[0], v[1], v[2], v[3]);
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(gd_u32x2, b), rs, off, 0, AUX);
     } else {
         const f32x4 a = {v[0], v[1], v[2], v[3]};

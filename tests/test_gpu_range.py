@@ -240,3 +240,29 @@ def test_over_capacity_kept_rows_give_a_nan_gradient_norm_in_the_fp16_operand_en
         eng.clear_cache()
         norm = eng.optimizer_step()
         assert bool(torch.isnan(norm)), (dtype, float(norm))
+
+
+def test_fp16_conversions_saturate_infinities_and_propagate_nan():
+    """every fp32 -> fp16 conversion of the tf32h engine saturates at +-65504 (finite overflow and +-inf alike) and PROPAGATES NaN: the clamp is
+    gfx950's IEEE-754-2019 minimum / maximum on the converted halves (csrc/gd_common.h f16_sat2), not a median-of-three — v_med3_f32 returns
+    -65504 for a NaN and would hide a poisoned activation.  Checked on the stand-alone cast, on an fp16-C GEMM epilogue (persistent and tile
+    kernels) and on the LayerNorm forward's fp16 output."""
+    from gd_amd import ops
+    nan, inf = float("nan"), float("inf")
+    x = torch.tensor([[nan, inf, -inf, 7e4, -7e4, 65519.0, 1.0, -0.0]] * 2, device="cuda")
+    h = ops.cast16(x)
+    assert torch.isnan(h[:, 0]).all() and torch.equal(h[:, 1:6], torch.tensor([[65504.0, -65504.0, 65504.0, -65504.0, 65504.0]] * 2, device="cuda").half())
+    assert h[0, 6] == 1.0 and h[0, 7] == 0.0
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for M, N, K in [(2048, 512, 256), (300, 128, 64)]:           # persistent 256 x 256 kernel / 128 x 128 tile kernel
+        a = torch.randn(M, K, device="cuda", generator=g).half()
+        w = torch.randn(N, K, device="cuda", generator=g).half()
+        a[3, 5] = nan
+        o = ops.gemm_nt(a, w, out_dtype=torch.float16)
+        assert torch.isnan(o[3]).all() and torch.isfinite(o[:3]).all() and torch.isfinite(o[4:]).all(), (M, N, K)
+        big = ops.gemm_nt(a[8:] * 0 + 200.0, w * 0 + 200.0, out_dtype=torch.float16)      # 200 * 200 * K > 65504: saturates, does not become inf
+        assert torch.equal(big, torch.full_like(big, 65504.0))
+    xs = torch.randn(64, 768, device="cuda", generator=g)
+    xs[7, 100] = nan
+    y, _, _ = ops.layernorm_fwd(xs, torch.ones(768, device="cuda"), torch.zeros(768, device="cuda"), 1e-6, out_dtype=torch.float16)
+    assert torch.isnan(y[7]).all() and torch.isfinite(y[:7]).all() and torch.isfinite(y[8:]).all()
