@@ -195,6 +195,7 @@ class FinetuneGD(nn.Module):
             p.grad = None
         self._flat["g"].zero_()          # BEFORE the backward: blocks prepared with the flat record accumulate straight into it
         loss.backward()
+        ops.amax_clear()                 # (tf32h: a gradient scale nobody consumed must not outlive its backward pass)
         self.model.finish_trainable_grads()
         if pre_gather is not None:       # e.g. OverlappedGradReducer.wait_early: hook-launched all-reduces of some p.grad
             pre_gather()

@@ -211,13 +211,15 @@ def _slots(dev):
 
 
 def amax_register(t, sc):
-    _AMAX[t.data_ptr()] = (sc, t.numel())
+    # the entry keeps the tensor alive: its address cannot be handed to another tensor while the scale waits for its consumer, so a hit is
+    # never a stale scale (an unconsumed entry pins one gradient tensor until amax_clear(): FinetuneGD.backward's end, prepare_trainables)
+    _AMAX[t.data_ptr()] = (sc, t)
 
 
 def amax_take(t):
     """the scale a producer registered for exactly this tensor (popped), or None."""
     rec = _AMAX.pop(t.data_ptr(), None)
-    return rec[0] if rec is not None and rec[1] == t.numel() else None
+    return rec[0] if rec is not None and rec[1].numel() == t.numel() and rec[1].dtype == t.dtype else None
 
 
 def amax_clear():
