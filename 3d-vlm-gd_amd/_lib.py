@@ -15,6 +15,7 @@ F32, BF16, F16 = 0, 1, 3
 c_int, c_long, c_float, c_void_p, c_size_t = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
 
 # name -> (restype, argtypes).  Must list every symbol of include/gd_hip.h (tests check this).
+ABI_VERSION = 2      # include/gd_hip.h GD_ABI_VERSION: the version this signature table was written for
 SIGNATURES = {
     "gd_last_error": (ctypes.c_char_p, []),
     "gd_abi_version": (c_int, []),
@@ -180,6 +181,10 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
+        got = L.gd_abi_version()
+        if got != ABI_VERSION:
+            raise GdHipError(f"{LIB_PATH} has C-ABI version {got}, this package binds version {ABI_VERSION}: rebuild it "
+                             "(`python -c 'import __graft_entry__ as g; g.build()'`)")
         _lib = L
     return _lib
 

@@ -69,4 +69,4 @@ extern "C" int gd_debug_get(const char* name) {
     gd_set_error("gd_debug_get: unknown option '%s'", name ? name : "(null)");
     return -1;
 }
-extern "C" int gd_abi_version(void) { return 1; }
+extern "C" int gd_abi_version(void) { return GD_ABI_VERSION; }

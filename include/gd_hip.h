@@ -25,6 +25,9 @@ extern "C" {
 #define GD_F16 3     /* IEEE half: the operand format of the tf32h engine (gd_cast_f16 -> gd_gemm_nt_scaled, gd_attention_*): 11-bit significands = TF32's */
 
 const char* gd_last_error(void);
+/* Bumped whenever an exported signature changes (round 4: gd_amax_scale and gd_lora_bwd_fused_scaled took one more argument -> 2); the Python
+ * loader refuses a library whose version differs from the one its signature table was written for. */
+#define GD_ABI_VERSION 2
 int gd_abi_version(void);
 
 /* Debug hooks (no reference counterpart; NOT for production use, process-wide, not thread-safe).
