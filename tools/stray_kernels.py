@@ -13,7 +13,7 @@ dev = torch.device("cuda", 0)
 img, N, patch, P = 518, 300, 14, 32
 hw = (img // patch) ** 2
 eng = FinetuneGD(r=4, backbone="vit_base", patch_size=patch, img_size=img, variant="mast3r", geometry="shared",
-                 dtype="bf16", teacher_patch=patch, lora_b_std=1e-3, vit_kwargs=dict(init_values=1.0)).to(dev)
+                 dtype=os.environ.get("DT", "tf32h"), teacher_patch=patch, lora_b_std=1e-3, vit_kwargs=dict(init_values=1.0)).to(dev)
 eng.configure_optimizers(lr=1e-4)
 batch = synthetic_batch(P, img, img, N, hw, dev, seed=7, teacher_patch=patch)
 
