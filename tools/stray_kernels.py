@@ -18,10 +18,8 @@ eng.configure_optimizers(lr=1e-4)
 batch = synthetic_batch(P, img, img, N, hw, dev, seed=7, teacher_patch=patch)
 
 
-def step():
-    loss, _ = eng.training_step(batch)
-    eng.backward(loss)
-    eng.optimizer_step()
+def step():          # what bench.py times: fit_step (weight gradients accumulate straight into the flat buffer)
+    eng.fit_step(batch)
 
 
 for _ in range(3):
