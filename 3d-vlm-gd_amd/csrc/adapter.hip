@@ -12,13 +12,6 @@
 // gate taken from the saved forward hidden tile instead of the value's own sign, second weight = down^T [D, 64].
 // The gated hidden tile (forward: h, backward: dh) is written out because the weight gradients contract it (gd_gemm_tn).
 #include "gd_common.h"
-#include <utility>
-
-// compile-time index loop: array indices are constants when the IR is built, so per-thread arrays that live across the
-// persistent kernel's (not unrolled) tile loop are promoted to registers instead of scratch
-template <typename F, int... I>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
-template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 #define AD_BM 32
 #define AD_BOT 64

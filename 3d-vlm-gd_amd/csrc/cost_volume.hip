@@ -18,6 +18,7 @@
 // NT GEMMs (G b and G^T a), then cv_norm_bwd pulls the gradient through the L2 normalisation.
 #include "gd_common.h"
 #include "gemm_tile.h"
+#include "gemm_frag.h"
 #include <stdlib.h>
 
 extern "C" int gd_gemm_nt(const void* A, const void* W, void* C, int M, int N, int K, long lda, long ldw, long ldc,
@@ -818,6 +819,22 @@ __global__ __launch_bounds__(768) void cv_fwd_rows_kernel(CvTileParams q) {
 }
 
 
+#include "cv_panel.h"
+
+// grid of the panel kernels: one block per CU, a multiple of 8 (XCD-major block ids); 0 = the shape is not theirs (the caller falls back)
+static int cv_panel_grid(long total_tiles, long rowb, int ldt, const void* t1, const void* t2) {
+    if (!gd_knobs().cv_panel || (rowb != 6 * 128 && rowb != 12 * 128) || ldt % 4 != 0 || ldt < 8 || ((uintptr_t)t1 & 15) || ((uintptr_t)t2 & 15)) return 0;
+    int ncu = 256;
+    if (gd_knobs().ncu >= 8) ncu = gd_knobs().ncu / 8 * 8;
+    int grid = (int)(total_tiles < ncu ? (total_tiles + 7) / 8 * 8 : ncu);
+    if (gd_knobs().cv_grid) {      // tests (gd_debug_set): few blocks, so that every block walks many tiles
+        const int gv = gd_knobs().cv_grid / 8 * 8;
+        if (gv >= 8 && gv < grid) grid = gv;
+    }
+    if ((total_tiles + grid - 1) / grid + 64 > CVA_LIST_MAX) return 0;       // (a block's slice of every pair segment rounds up: generous margin)
+    return grid;
+}
+
 // kept rows of one (pair, direction) in ascending order -> idx[pd][0 .. cnt), the rest of the kcap entries padded with the last kept row (row 0
 // when nothing is kept); cnt[pd] = the number kept, or -1 when it EXCEEDS kcap (the caller's bound was wrong: the loss of that pair comes out NaN and so do
 // its gradients — never a silently truncated sum).  One block per (pair, direction).
@@ -1321,7 +1338,19 @@ static int cv_fwd_common(const void* f1, const void* f2, const float* inv1, cons
     // shelved as tools/experiments/cv_persist256.h)
     const int persist = gd_knobs().cv_persist;     // GD_CV_PERSIST=0: the one-tile-per-block kernel (A/B)
     const long rowb = (long)C * gd_dtype_size(dtype);
-    if (persist && rowb % 128 == 0 && rowb / 128 >= 3 && ldt % 4 == 0 && ((uintptr_t)t1 & 15) == 0 && ((uintptr_t)t2 & 15) == 0) {
+    const int pgrid = (persist && dtype != GD_F32 && !gd_knobs().cv_dbg) ? cv_panel_grid((long)P * tiles * tiles, rowb, ldt, t1, t2) : 0;
+    if (pgrid) {
+        // round 5: the row panel stays in registers, only the column operand streams (cv_panel.h).  Teacher entries of masked-out rows are
+        // fetched here (no q.m1 / q.m2 tests in the prefetch): GD_CV_PANEL=0 restores the round-4 kernel with its mask skip.
+        q.m1 = q.m2 = nullptr;
+        if (rowb == 12 * 128) {
+            if (dtype == GD_BF16) hipLaunchKernelGGL((cv_fwd_panel_kernel<bf16, 12, false>), dim3(pgrid), dim3(512), 0, s, q);
+            else hipLaunchKernelGGL((cv_fwd_panel_kernel<f16, 12, false>), dim3(pgrid), dim3(512), 0, s, q);
+        } else {
+            if (dtype == GD_BF16) hipLaunchKernelGGL((cv_fwd_panel_kernel<bf16, 6, false>), dim3(pgrid), dim3(512), 0, s, q);
+            else hipLaunchKernelGGL((cv_fwd_panel_kernel<f16, 6, false>), dim3(pgrid), dim3(512), 0, s, q);
+        }
+    } else if (persist && rowb % 128 == 0 && rowb / 128 >= 3 && ldt % 4 == 0 && ((uintptr_t)t1 & 15) == 0 && ((uintptr_t)t2 & 15) == 0) {
         int ncu = 256;
         if (gd_knobs().ncu >= 8) ncu = gd_knobs().ncu / 8 * 8;
         const long total = (long)P * tiles * tiles;
@@ -1516,7 +1545,16 @@ extern "C" int gd_cost_volume_kl_fwd_rows(const void* f1, const void* f2, const 
         const int gv = gd_knobs().cv_grid / 8 * 8;
         if (gv >= 8 && gv < grid) grid = gv;
     }
-    if (dtype == GD_BF16) hipLaunchKernelGGL(cv_fwd_rows_kernel<bf16>, dim3(grid), dim3(768), 0, s, q);
+    const int pgrid = dtype != GD_F32 ? cv_panel_grid(total, rowb, ldt, t1, t2) : 0;
+    if (pgrid) {      // round 5: the kept rows of a row tile stay in registers for the sweep of column tiles (cv_panel.h, ROWS form)
+        if (rowb == 12 * 128) {
+            if (dtype == GD_BF16) hipLaunchKernelGGL((cv_fwd_panel_kernel<bf16, 12, true>), dim3(pgrid), dim3(512), 0, s, q);
+            else hipLaunchKernelGGL((cv_fwd_panel_kernel<f16, 12, true>), dim3(pgrid), dim3(512), 0, s, q);
+        } else {
+            if (dtype == GD_BF16) hipLaunchKernelGGL((cv_fwd_panel_kernel<bf16, 6, true>), dim3(pgrid), dim3(512), 0, s, q);
+            else hipLaunchKernelGGL((cv_fwd_panel_kernel<f16, 6, true>), dim3(pgrid), dim3(512), 0, s, q);
+        }
+    } else if (dtype == GD_BF16) hipLaunchKernelGGL(cv_fwd_rows_kernel<bf16>, dim3(grid), dim3(768), 0, s, q);
     else if (dtype == GD_F16) hipLaunchKernelGGL(cv_fwd_rows_kernel<f16>, dim3(grid), dim3(768), 0, s, q);
     else hipLaunchKernelGGL(cv_fwd_rows_kernel<float>, dim3(grid), dim3(768), 0, s, q);
     GD_LAUNCH_OK();

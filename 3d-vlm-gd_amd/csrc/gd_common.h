@@ -18,6 +18,13 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 #include "gd_hip.h"
 #include "gd_knobs.h"
 
+// compile-time index loop: array indices are constants when the IR is built, so per-thread arrays that live across a persistent
+// kernel's (not unrolled) tile loop are promoted to registers instead of scratch
+#include <utility>
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
 // ---- host-side error plumbing (definitions in cabi.hip) ----
 void gd_set_error(const char* fmt, ...);
 #define GD_REQUIRE(cond, ...)                 \

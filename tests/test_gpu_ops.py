@@ -80,20 +80,23 @@ def test_l2norm():
     assert rel_err(y, yr) < 1e-6 and rel_err(x.grad, xr.grad) < 1e-5
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.bfloat16, 1e-2)])
-@pytest.mark.parametrize("hw_in,HW", [((56, 70), (56, 70)), ((40, 52), (56, 84))])
-def test_patch_im2col_and_tokens(dtype, tol, hw_in, HW):
+# patch 14 (BASELINE's DINOv2-style students) and patch 16 (the reference's own CLIP ViT-B/16: config/*.yaml:2, src/finetune_timm_mast3r.py:68-70):
+# identity and real bilinear resizes, the engine's three operand dtypes (fp16 = the tf32h engine's patch operand), K padded to 128 / 64 multiples
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.bfloat16, 1e-2), (torch.float16, 1e-3)])
+@pytest.mark.parametrize("P,hw_in,HW", [(14, (56, 70), (56, 70)), (14, (40, 52), (56, 84)), (16, (64, 80), (64, 80)), (16, (48, 64), (96, 128))])
+def test_patch_im2col_and_tokens(dtype, tol, P, hw_in, HW):
     from gd_amd import ops
-    P, B, D = 14, 2, 32
+    B, D = 2, 32
     mean, std = (0.48, 0.45, 0.40), (0.26, 0.25, 0.27)
     img = torch.rand(B, 3, *hw_in, generator=_g(8), device="cuda")
-    Kp = 640
+    Kp = 640 if P == 14 else 768
     col = ops.patch_im2col(img, HW[0], HW[1], P, Kp, mean, std, dtype)
     ref = O.normalize_image(O.resize_bilinear(img.cpu(), HW), mean, std)
     refcol = F.unfold(ref, P, stride=P).transpose(1, 2).reshape(-1, 3 * P * P)
     assert rel_err(col[:, :3 * P * P], refcol) < tol and float(col[:, 3 * P * P:].abs().max()) == 0.0
     Np = (HW[0] // P) * (HW[1] // P)
-    patch = torch.randn(B * Np, D, generator=_g(9), device="cuda").to(dtype)
+    tdt = torch.float32 if dtype == torch.float16 else dtype       # (tf32h engine: the patch projection's fp32 output is what gets assembled)
+    patch = torch.randn(B * Np, D, generator=_g(9), device="cuda").to(tdt)
     cls = torch.randn(D, generator=_g(10), device="cuda")
     pos = torch.randn(Np + 1, D, generator=_g(11), device="cuda")
     tok = ops.assemble_tokens(patch, cls, pos, B, Np).view(B, Np + 1, D)

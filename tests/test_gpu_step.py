@@ -104,6 +104,33 @@ class OracleTrainer:
         self.state = [(torch.zeros_like(t.detach()), torch.zeros_like(t.detach())) for t in self.leaves]
         self.nstep = 0
 
+    def _pair(self, cb, q):
+        """pair q of the CPU batch in the oracle's pair_losses layout"""
+        dt, cfg = self.dtype, self.cfg
+        n = int(cb["counts"][q]) if "counts" in cb else cb["kp_1"].shape[1]
+        h, w = cb["rgb_1"].shape[-2:]
+        tp = cfg["teacher_patch"]
+        hw = (h // tp) * (w // tp)
+        return {"rgb_1": cb["rgb_1"][q:q + 1].to(dt), "rgb_2": cb["rgb_2"][q:q + 1].to(dt),
+                "kp_1": cb["kp_1"][q:q + 1, :n], "kp_2": cb["kp_2"][q:q + 1, :n],
+                "depth_1": cb["depth_1"][q].to(dt), "depth_2": cb["depth_2"][q].to(dt),
+                "cost_1": cb["cost_1"][q:q + 1, :, :hw].to(dt), "cost_2": cb["cost_2"][q:q + 1, :, :hw].to(dt),
+                "pts3d_1": cb["pts3d_1"][q:q + 1, :n].to(dt), "pts3d_2": cb["pts3d_2"][q:q + 1, :n].to(dt),
+                "mask_patch_1": F.interpolate(cb["mask_1"][q][None, None].float(), size=(h // tp, w // tp), mode="nearest").bool().view(-1),
+                "mask_patch_2": F.interpolate(cb["mask_2"][q][None, None].float(), size=(h // tp, w // tp), mode="nearest").bool().view(-1)}
+
+    def residuals(self, batch, P):
+        """Forward only (no autograd graph, a third of a step): per pair, pred - target of the depth-L1 term at every keypoint — what the
+        full-size tests need to find the keypoints that sit on the |.| kink before they pay for the gradient pass."""
+        cb = {k: v.detach().cpu() for k, v in batch.items()}
+        out = []
+        with torch.no_grad():
+            for q in range(P):
+                aux = {}
+                O.pair_losses(self._pair(cb, q), self.p, self.cfg, self.tr, self.refine, self.head, aux=aux)
+                out.append(aux.get("l1_residual"))
+        return out
+
     def step(self, batch, P):
         dt, cfg = self.dtype, self.cfg
         for t in self.leaves:
@@ -112,17 +139,7 @@ class OracleTrainer:
         self.l1_residuals = []          # per pair: pred - target of the depth-L1 term at every keypoint (the |.| kink, see depth_losses)
         cb = {k: v.detach().cpu() for k, v in batch.items()}
         for q in range(P):
-            n = int(cb["counts"][q]) if "counts" in cb else cb["kp_1"].shape[1]
-            h, w = cb["rgb_1"].shape[-2:]
-            tp = cfg["teacher_patch"]
-            hw = (h // tp) * (w // tp)
-            one = {"rgb_1": cb["rgb_1"][q:q + 1].to(dt), "rgb_2": cb["rgb_2"][q:q + 1].to(dt),
-                   "kp_1": cb["kp_1"][q:q + 1, :n], "kp_2": cb["kp_2"][q:q + 1, :n],
-                   "depth_1": cb["depth_1"][q].to(dt), "depth_2": cb["depth_2"][q].to(dt),
-                   "cost_1": cb["cost_1"][q:q + 1, :, :hw].to(dt), "cost_2": cb["cost_2"][q:q + 1, :, :hw].to(dt),
-                   "pts3d_1": cb["pts3d_1"][q:q + 1, :n].to(dt), "pts3d_2": cb["pts3d_2"][q:q + 1, :n].to(dt),
-                   "mask_patch_1": F.interpolate(cb["mask_1"][q][None, None].float(), size=(h // tp, w // tp), mode="nearest").bool().view(-1),
-                   "mask_patch_2": F.interpolate(cb["mask_2"][q][None, None].float(), size=(h // tp, w // tp), mode="nearest").bool().view(-1)}
+            one = self._pair(cb, q)
             aux = {}
             terms = O.pair_losses(one, self.p, cfg, self.tr, self.refine, self.head, aux=aux)
             self.l1_residuals.append(aux.get("l1_residual"))

@@ -103,6 +103,42 @@ def bench_cv():
                   f"fwd+bwd {tfb*1e6/P:8.1f} us/pair {(fwd_bytes+bwd_bytes)/tfb/1e9:8.1f} GB/s")
 
 
+def bench_cv_ab(rounds=3):
+    """Round 5: the row-panel-stationary forward kernels (gd_debug_set("cv_panel", 1), csrc/cv_panel.h) against the round-4 persistent kernels (0) in ONE
+    process, interleaved rounds (cdna_hip_programming.md rule 24): the tf32h trainer's call (fp16 feature copies, producer-side norms, cached teacher
+    statistics) at 32 pairs, hw = 1369, C = 768 — every row kept (the dense sweep), and with the MASt3R trainer's keypoint-patch masks (the kept-row form).
+    Forward only, whole op (statistics init + tile kernel + finalize + loss), what bench.py's roofline_cost_volume times."""
+    L = gd_amd._lib.lib()
+    P, hw, C, img, patch = 32, 1369, 768, 518, 14
+    g = torch.Generator(device="cuda").manual_seed(0)
+    f1 = torch.randn(P, hw, C, device="cuda", generator=g)
+    f2 = torch.randn(P, hw, C, device="cuda", generator=g)
+    t1 = torch.softmax(3 * torch.randn(P, hw, hw, device="cuda", generator=g), -1)
+    t2 = torch.softmax(3 * torch.randn(P, hw, hw, device="cuda", generator=g), -1)
+    kp1 = torch.rand(P, 300, 2, device="cuda", generator=g) * (img - 1)
+    kp2 = torch.rand(P, 300, 2, device="cuda", generator=g) * (img - 1)
+    mk1, mk2 = ops.patch_mask(kp1, img, img, patch), ops.patch_mask(kp2, img, img, patch)
+    on1, on2 = torch.ones_like(mk1), torch.ones_like(mk2)
+    t1, t2 = ops.pad_teacher_maps(t1), ops.pad_teacher_maps(t2)
+    ts = ops.cost_volume_teacher_stats(t1, t2)
+    inv = (1.0 / f1.norm(dim=-1).clamp_min(1e-12), 1.0 / f2.norm(dim=-1).clamp_min(1e-12))
+    h16 = (f1.half(), f2.half())
+    alg = P * (2 * hw * C * 2 + 2 * hw * hw * 4 + 2 * hw)
+    cases = {"dense (every row kept)": lambda: ops.cost_volume_kl(f1, f2, t1, t2, on1, on2, "mast3r", tstats=ts, inv_norms=inv, x3="h", h16=h16),
+             "kept rows (keypoint-patch masks)": lambda: ops.cost_volume_kl(f1, f2, t1, t2, mk1, mk2, "mast3r", tstats=ts, inv_norms=inv, x3="h", h16=h16, kept_rows_max=300)}
+    with torch.no_grad():
+        for name, fn in cases.items():
+            res = {0: [], 1: []}
+            for _ in range(rounds):
+                for v in (0, 1):
+                    L.gd_debug_set(b"cv_panel", v)
+                    res[v].append(timeit(fn, warm=3, it=20))
+            L.gd_debug_set(b"cv_panel", 1)
+            a, b = min(res[0]), min(res[1])
+            print(f"cv_ab {name:34s}: round-4 kernel {a * 1e6:7.1f} us ({a * 1e6 / P:5.2f} us/pair, {alg / a / 8e12:5.3f} of 8 TB/s by the dense byte count) | "
+                  f"panel kernel {b * 1e6:7.1f} us ({b * 1e6 / P:5.2f} us/pair, {alg / b / 8e12:5.3f})   all rounds: {[round(x * 1e6, 1) for x in res[0]]} vs {[round(x * 1e6, 1) for x in res[1]]}", flush=True)
+
+
 def bench_adapter():
     """fused adapter kernel against the two-GEMM formulation (M = 87680 rows of the P = 32 step)."""
     for D in (768, 1024):
@@ -334,8 +370,9 @@ def probe_gemm():
 def pmc_attn():
     import os
     B, N, H = (8, 6401, 12) if os.environ.get("GD_PMC_LONG") else (64, 1370, 12)
-    qkv = torch.randn(B * N, 3 * H * 64, device="cuda").bfloat16()
-    dout = torch.randn(B * N, H * 64, device="cuda").bfloat16()
+    dt = torch.float16 if os.environ.get("GD_PMC_F16") else torch.bfloat16      # fp16 = the tf32h engine's attention operands
+    qkv = torch.randn(B * N, 3 * H * 64, device="cuda").to(dt)
+    dout = torch.randn(B * N, H * 64, device="cuda").to(dt)
     for _ in range(2):
         o, lse = ops.attention_fwd(qkv, B, N, H)
         ops.attention_bwd(qkv, o, dout, lse, B, N, H)
@@ -370,6 +407,8 @@ if __name__ == "__main__":
         bench_gemm_anat()
     if "cv" in which:
         bench_cv()
+    if "cv_ab" in which:
+        bench_cv_ab()
     if "gelu" in which:
         bench_gelu()
     if "pmc_cv" in which:
