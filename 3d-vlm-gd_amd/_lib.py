@@ -75,6 +75,8 @@ SIGNATURES = {
     "gd_col2im3x3": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "gd_kp_gather_fwd": (c_int, [ctypes.POINTER(c_void_p), c_int, c_long, c_int, c_void_p, c_void_p, c_int, c_int,
                                  c_int, c_int, c_int, c_float, c_float, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "gd_kp_gather_fwd_ln": (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), c_int, c_long, c_long, c_int, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "gd_kp_gather_bwd": (c_int, [ctypes.POINTER(c_void_p), c_int, c_long, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                  c_int, c_float, c_float, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "gd_lora_bwd_fused": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),

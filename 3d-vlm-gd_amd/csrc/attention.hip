@@ -397,6 +397,19 @@ __device__ __forceinline__ void attn_block_coords(int& xb, int& h, int& b) {
     b = r / (nx * ny);
 }
 
+// Start-up skew between the workgroups that share a CU (round 5, GD_ATTN_STAGGER = ticks of 64 cycles per slot; default 0 = off).  The PMC pass of
+// round 5 (profiles/r05_pmc_attention_stall.json) shows the matrix pipe busy in 49 % and the vector ALU in ~40 % of the SIMD cycles but the two
+// TOGETHER in only 16 %: the two or three waves of a SIMD — one from each co-resident workgroup, same program, same tile period — run their MFMA and
+// softmax phases at the same time.  Workgroups are dealt round-robin (XCD, then CU), so launch index / 256 mod `slots` is the workgroup's slot on its
+// CU for the first generation, and every later workgroup inherits the phase of the one whose place it takes (equal work per workgroup).
+__device__ __forceinline__ void attn_stagger(int packed) {
+    if (packed == 0) return;
+    const int ticks = packed & 0xffff, slots = packed >> 16;
+    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int slot = (lin >> 8) % slots;
+    for (int i = 0; i < slot * ticks; ++i) __builtin_amdgcn_s_sleep(1);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* qkv, T* o, float* lse, int N, int H, float scale) {
     constexpr int NF = AT<T>::NF, ROWB = AT<T>::ROWB;
@@ -516,6 +529,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const T* qkv, T* o
     __shared__ __attribute__((aligned(16))) char smem[6 * TILE];   // K slots 0..2 | V slots 0..2
     const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    attn_stagger(rot_on >> 8);      // (bits 8..: GD_ATTN_STAGGER ticks | slots << 16)
+    rot_on &= 0xff;
     int xb_, h, b;
     attn_block_coords(xb_, h, b);
     const int q0 = xb_ * 128 + wave * 32;
@@ -943,7 +958,8 @@ __device__ __forceinline__ float frag_dot(const X3Frag& a, const X3Frag& b) {
 // ------------------------------------------------------------------------------------------ backward: dQ
 template <typename T>
 __global__ __launch_bounds__(256, IsX3<T>::v ? 1 : 2) void attn_bwd_dq_kernel(const T* qkv, const T* o, const T* dout, const float* lse,
-                                                          float* delta, T* dqkv, int N, int H, float scale) {
+                                                          float* delta, T* dqkv, int N, int H, float scale, int stagger = 0) {
+    attn_stagger(stagger);
     constexpr int NF = AT<T>::NF, ROWB = AT<T>::ROWB;
     typedef typename Mma<T>::Frag Frag;
     __shared__ __attribute__((aligned(16))) char sK[64 * ROWB];
@@ -1082,6 +1098,8 @@ __global__ __launch_bounds__(256, IsX3<T>::v ? 1 : 2) void attn_bwd_dq_kernel(co
 template <typename T, int NW, bool DK = true>
 __global__ __launch_bounds__(64 * NW, (NW >= 8 || IsX3<T>::v) ? 1 : 2) void attn_bwd_dkv_kernel(const T* qkv, const T* dout, const float* lse,
                                                            const float* delta, T* dqkv, int N, int H, float scale, int vfirst) {
+    attn_stagger(vfirst >> 8);      // (bits 8..: GD_ATTN_STAGGER ticks | slots << 16)
+    vfirst &= 0xff;
     constexpr int NF = AT<T>::NF, ROWB = AT<T>::ROWB;
     typedef typename Mma<T>::Frag Frag;
     __shared__ __attribute__((aligned(16))) char sQ[64 * ROWB];
@@ -1397,6 +1415,12 @@ extern "C" int gd_cross_view_attn(const void* q, const void* k, float* out, int 
 }
 
 // ------------------------------------------------------------------------------------------ C ABI
+// kernel argument of attn_stagger: GD_ATTN_STAGGER ticks (of 64 cycles) per slot | workgroups per CU << 16; 0 = off
+static inline int attn_stagger_arg(int slots) {
+    const int t = gd_knobs().attn_stagger;
+    return t > 0 ? ((t & 0xffff) | (slots << 16)) : 0;
+}
+
 extern "C" int gd_attention_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, int head_dim, float scale,
                                 int dtype, void* stream) {
     GD_REQUIRE(B > 0 && N > 0 && H > 0, "gd_attention_fwd: bad shape B=%d N=%d H=%d", B, N, H);
@@ -1415,10 +1439,10 @@ extern "C" int gd_attention_fwd(const void* qkv, void* o, float* lse, int B, int
           hipLaunchKernelGGL(attn_fwd32_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, (const f16*)qkv, (f16*)o, lse, N, H, scale, ro); }
     else if (dtype == GD_BF16 && dma)
         { const int ro = gd_knobs().attn_rot;
-          hipLaunchKernelGGL(attn_fwd_dma_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, ro); }
+          hipLaunchKernelGGL(attn_fwd_dma_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, ro | attn_stagger_arg(3) << 8); }
     else if (dtype == GD_F16 && dma)        // tf32h engine: fp16 q / k / v / p (TF32's significand), the bf16 kernel's layouts
         { const int ro = gd_knobs().attn_rot;
-          hipLaunchKernelGGL(attn_fwd_dma_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, (const f16*)qkv, (f16*)o, lse, N, H, scale, ro); }
+          hipLaunchKernelGGL(attn_fwd_dma_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, (const f16*)qkv, (f16*)o, lse, N, H, scale, ro | attn_stagger_arg(3) << 8); }
     else if (dtype == GD_F16)
         hipLaunchKernelGGL(attn_fwd_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, (const f16*)qkv, (f16*)o, lse, N, H, scale);
     else if (dtype == GD_BF16)
@@ -1435,7 +1459,7 @@ template <typename T>      // bf16 | f16
 static void attn_bwd_launch16(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, float* delta_ws, int B, int N, int H,
                               float scale, int grad_order, bool no_dk, hipStream_t s) {
     dim3 grid(gd_cdiv(N, 128), H, B);
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, grid, dim3(256), 0, s, (const T*)qkv, (const T*)o, (const T*)dout, lse, delta_ws, (T*)dqkv, N, H, scale);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, grid, dim3(256), 0, s, (const T*)qkv, (const T*)o, (const T*)dout, lse, delta_ws, (T*)dqkv, N, H, scale, attn_stagger_arg(3));
         // 128-key blocks of four waves (two blocks per CU, independent barriers, Q / dO tiles staged twice as often) when the last
         // 256-key block would be less than half full: N = 1370 pads to 1408 keys instead of 1536 (2.7 % instead of 10.8 %):
         // backward 1574 -> 1514 us at 64 x 12 x 1370; at N = 6401 (long sweeps, 0.4 % vs 2 % padding) the 8-wave form is 2 % faster.
@@ -1444,11 +1468,11 @@ static void attn_bwd_launch16(const void* qkv, const void* o, const void* dout, 
         const int tail = N % 256;
         const int dkv_nw = dkv_env ? dkv_env : ((N < 4096 && tail > 0 && tail <= 128) ? 4 : 8);
         if (no_dk && dkv_nw == 4)
-            hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, 4, false>), dim3(gd_cdiv(N, 128), H, B), dim3(256), 0, s, (const T*)qkv, (const T*)dout, lse, delta_ws, (T*)dqkv, N, H, scale, grad_order);
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, 4, false>), dim3(gd_cdiv(N, 128), H, B), dim3(256), 0, s, (const T*)qkv, (const T*)dout, lse, delta_ws, (T*)dqkv, N, H, scale, grad_order | attn_stagger_arg(2) << 8);
         else if (no_dk)
             hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, 8, false>), dim3(gd_cdiv(N, 256), H, B), dim3(512), 0, s, (const T*)qkv, (const T*)dout, lse, delta_ws, (T*)dqkv, N, H, scale, grad_order);
         else if (dkv_nw == 4)       // (two-wave 64-key blocks: 2213 us — the staging registers spill and every block re-stages all of Q / dO)
-            hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, 4>), dim3(gd_cdiv(N, 128), H, B), dim3(256), 0, s, (const T*)qkv, (const T*)dout, lse, delta_ws, (T*)dqkv, N, H, scale, grad_order);
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, 4>), dim3(gd_cdiv(N, 128), H, B), dim3(256), 0, s, (const T*)qkv, (const T*)dout, lse, delta_ws, (T*)dqkv, N, H, scale, grad_order | attn_stagger_arg(2) << 8);
         else
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, 8>), dim3(gd_cdiv(N, 256), H, B), dim3(512), 0, s, (const T*)qkv, (const T*)dout, lse, delta_ws, (T*)dqkv, N, H, scale, grad_order);
 }

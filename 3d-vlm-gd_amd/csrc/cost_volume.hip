@@ -1338,8 +1338,13 @@ static int cv_fwd_common(const void* f1, const void* f2, const float* inv1, cons
     // shelved as tools/experiments/cv_persist256.h)
     const int persist = gd_knobs().cv_persist;     // GD_CV_PERSIST=0: the one-tile-per-block kernel (A/B)
     const long rowb = (long)C * gd_dtype_size(dtype);
-    const int pgrid = (persist && dtype != GD_F32 && !gd_knobs().cv_dbg) ? cv_panel_grid((long)P * tiles * tiles, rowb, ldt, t1, t2) : 0;
-    if (pgrid) {
+    const int pgrid = (persist && dtype != GD_F32 && (!gd_knobs().cv_dbg || (gd_knobs().cv_panel == 2 && dtype == GD_F16 && rowb == 12 * 128)))
+                          ? cv_panel_grid((long)P * tiles * tiles, rowb, ldt, t1, t2) : 0;
+    if (pgrid && gd_knobs().cv_dbg) {      // anatomy (tools/cv_anatomy.py, GD_CV_PANEL=2 + GD_CV_DBG bits): parts of the panel kernel switched off; results meaningless
+        q.m1 = q.m2 = nullptr;
+        q.dbg = gd_knobs().cv_dbg;
+        hipLaunchKernelGGL((cv_fwd_panel_kernel<f16, 12, false, true>), dim3(pgrid), dim3(512), 0, s, q);
+    } else if (pgrid) {
         // round 5: the row panel stays in registers, only the column operand streams (cv_panel.h).  Teacher entries of masked-out rows are
         // fetched here (no q.m1 / q.m2 tests in the prefetch): GD_CV_PANEL=0 restores the round-4 kernel with its mask skip.
         q.m1 = q.m2 = nullptr;

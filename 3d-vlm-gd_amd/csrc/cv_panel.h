@@ -87,7 +87,7 @@ __device__ __forceinline__ void cva_load_frags(Frag (&a)[N], const char* ap) {
     }
 }
 
-template <typename T, int NK, bool ROWS>
+template <typename T, int NK, bool ROWS, bool DBG = false>      // DBG: anatomy builds (GD_CV_DBG bits: 1 no teacher loads, 2 no epilogue math, 4 no LDS reads / MFMAs, 8 no DMA); never the product path
 __global__ __launch_bounds__(512) void cv_fwd_panel_kernel(CvTileParams q) {
     typedef typename Mma<T>::Frag Frag;
     static_assert(sizeof(T) == 2, "16-bit features");
@@ -99,6 +99,7 @@ __global__ __launch_bounds__(512) void cv_fwd_panel_kernel(CvTileParams q) {
     const int tiles_r = ROWS ? (q.kcap >> 7) : TL, kcap = q.kcap;
     const int per = tiles_r * TL;                        // tiles that share one column operand (a pair / a (pair, direction))
     const unsigned lds0 = lds_off(smem);
+    const int dbg = DBG ? q.dbg : 0;
 
     // ---- this block's tile list ----
     {
@@ -158,6 +159,7 @@ __global__ __launch_bounds__(512) void cv_fwd_panel_kernel(CvTileParams q) {
             }
         }
         char* dst = smem + (n_issue & (CVA_NS - 1)) * CVA_STAGE + 2 * wave * 1024;
+        if (!(dbg & 8))
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[i] + (long)k_i * 128),
@@ -223,6 +225,14 @@ __global__ __launch_bounds__(512) void cv_fwd_panel_kernel(CvTileParams q) {
     // direction 2: t2v[j]    = T2[row = column 8 c + j][columns = rows 16 w + 4 g .. + 3]   (element r)
     f32x4 t1v[4][2], t2v[ROWS ? 1 : 8];
     auto prefetch = [&](int it) {
+        if (dbg & 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t1v[r][0] = t1v[r][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < (ROWS ? 1 : 8); ++j) t2v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            markT = seq;
+            return;
+        }
         const int l = tile_at(it);
         const int sp = l / per, rr = l - sp * per, tm = rr / TL, tn = rr - tm * TL;
         const int col0 = min(tn * 128 + 8 * c, ldt - 8);                     // ldt % 4 == 0 and ldt >= 8: aligned, inside the row
@@ -290,6 +300,7 @@ __global__ __launch_bounds__(512) void cv_fwd_panel_kernel(CvTileParams q) {
                     *(__attribute__((address_space(1))) float*)((uintptr_t)q.part2 + ((((long)spp * q.nslab + tmp) * hw + col) * 2 + (lane >> 4)) * sizeof(float)) = s;
             }
             const unsigned sb = fa + slot * CVA_STAGE;
+            if (dbg & 4) continue;
             // B fragments in two groups of four n-blocks through the SAME 16 registers (32 registers of fragments in flight spilled: a scratch
             // reload is a vector-memory load, and the compiler waits for it with vmcnt(0) — which drains the DMA ring)
 #pragma unroll
@@ -312,6 +323,15 @@ __global__ __launch_bounds__(512) void cv_fwd_panel_kernel(CvTileParams q) {
                 acc[7] = Mma<T>::mma(af, __builtin_bit_cast(Frag, b3), acc[7]);
                 __builtin_amdgcn_sched_barrier(0);
             }
+        }
+        if (dbg & 2) {
+            if (acc[0][0] == 12345.678f) ((float*)smem)[tid] = acc[1][1] + t1v[0][0][0] + t2v[0][1];
+            if (it + 1 < n_tiles) {
+                const int ln = tile_at(it + 1);
+                if (ln / TL != cur_panel) { cur_panel = ln / TL; load_panel(ln); }
+                prefetch(it + 1);
+            }
+            continue;
         }
         // ---------------- epilogue, all from registers ----------------
         // the tile's teacher entries have landed

@@ -169,6 +169,9 @@ __global__ __launch_bounds__(256) void col2im3x3_kernel(const T* dcol, T* dx, lo
 struct GatherParams {
     const void* grid[4]; int ngrid; long bstride; int grid_dtype;
     const float* kp; float* out; float* dgrid[4]; const float* dout;
+    // gd_kp_gather_fwd_ln: the grids are the RAW block outputs, normalised where they are sampled — per-token LayerNorm statistics of every grid
+    // (mean, 1 / sigma: [B][tokens per image], indexed like the grid's tokens after the same prefix offset) and the shared affine
+    const float* ln_mean[4]; const float* ln_rstd[4]; const float* ln_w; const float* ln_b; long sstride;
     int B, Nk, gh, gw, D, pitch;     // pitch: tokens per grid line in memory (gw for a dense grid)
     float sx, sy, ax, bx, ay, by;
 };
@@ -233,6 +236,50 @@ __global__ __launch_bounds__(128) void kp_gather_fwd_vec_kernel(GatherParams p) 
         float* o = p.out + bk * p.D + ch * V;
 #pragma unroll
         for (int k = 0; k < V; k += 4) *(f32x4*)(o + k) = f32x4{acc[k] * inv, acc[k + 1] * inv, acc[k + 2] * inv, acc[k + 3] * inv};
+    }
+}
+
+// The same gather on RAW grids with the final LayerNorm applied where it is sampled (round 5): out = mean_t sum_nb w_nb ((x_t[nb] - mu_t[nb]) rstd_t[nb]) * gamma + beta
+// (the bilinear weights of a keypoint sum to 1, so beta comes through once).  The taps' normed copies — four [M, D] passes of ln_fwd_kernel per step, 94 us each —
+// are never written: a tapped block's output is the next block's input, whose LayerNorm forward already took the row statistics.
+template <typename T>
+__global__ __launch_bounds__(128) void kp_gather_fwd_ln_kernel(GatherParams p) {
+    constexpr int V = 16 / sizeof(T);
+    const long bk = blockIdx.x;
+    const long b = bk / p.Nk;
+    int x0, y0, x1, y1; float wx, wy;
+    gather_coords(p, bk, x0, y0, x1, y1, wx, wy);
+    const float w00 = (1.f - wx) * (1.f - wy), w01 = wx * (1.f - wy), w10 = (1.f - wx) * wy, w11 = wx * wy;
+    const float inv = 1.0f / (float)p.ngrid;
+    const long t00 = (long)y0 * p.pitch + x0, t01 = (long)y0 * p.pitch + x1, t10 = (long)y1 * p.pitch + x0, t11 = (long)y1 * p.pitch + x1;
+    // per grid: the four neighbours' weights folded with their 1 / sigma, and the sum of weight * mu / sigma that comes off every channel
+    float a00[4], a01[4], a10[4], a11[4], sub[4];
+    for (int t = 0; t < p.ngrid; ++t) {
+        const float* mu = p.ln_mean[t] + b * p.sstride;
+        const float* rs = p.ln_rstd[t] + b * p.sstride;
+        a00[t] = w00 * rs[t00]; a01[t] = w01 * rs[t01]; a10[t] = w10 * rs[t10]; a11[t] = w11 * rs[t11];
+        sub[t] = a00[t] * mu[t00] + a01[t] * mu[t01] + a10[t] * mu[t10] + a11[t] * mu[t11];
+    }
+    for (int ch = threadIdx.x; ch * V < p.D; ch += 128) {
+        float acc[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc[k] = 0.f;
+        for (int t = 0; t < p.ngrid; ++t) {
+            const T* g = (const T*)p.grid[t] + b * p.bstride + ch * V;
+            const uint4 v00 = *(const uint4*)(g + t00 * p.D), v01 = *(const uint4*)(g + t01 * p.D), v10 = *(const uint4*)(g + t10 * p.D),
+                        v11 = *(const uint4*)(g + t11 * p.D);
+            const T *e00 = (const T*)&v00, *e01 = (const T*)&v01, *e10 = (const T*)&v10, *e11 = (const T*)&v11;
+#pragma unroll
+            for (int k = 0; k < V; ++k)
+                acc[k] += (a00[t] * to_f32<T>(e00[k]) + a01[t] * to_f32<T>(e01[k]) + a10[t] * to_f32<T>(e10[k]) + a11[t] * to_f32<T>(e11[k])) - sub[t];
+        }
+        float* o = p.out + bk * p.D + ch * V;
+        const float* gw_ = p.ln_w + ch * V;
+        const float* gb_ = p.ln_b + ch * V;
+#pragma unroll
+        for (int k = 0; k < V; k += 4)
+            *(f32x4*)(o + k) = f32x4{fmaf(acc[k] * inv, gw_[k], gb_[k]), fmaf(acc[k + 1] * inv, gw_[k + 1], gb_[k + 1]),
+                                     fmaf(acc[k + 2] * inv, gw_[k + 2], gb_[k + 2]), fmaf(acc[k + 3] * inv, gw_[k + 3], gb_[k + 3])};
     }
 }
 
@@ -535,6 +582,27 @@ extern "C" int gd_kp_gather_fwd(const void* const* grids, int ngrid, long bstrid
     else if (vec) hipLaunchKernelGGL(kp_gather_fwd_vec_kernel<float>, dim3(B * Nk), dim3(128), 0, (hipStream_t)stream, p);
     else
     hipLaunchKernelGGL(kp_gather_fwd_kernel, dim3(B * Nk), dim3(256), 0, (hipStream_t)stream, p);
+    GD_LAUNCH_OK();
+    return 0;
+}
+
+extern "C" int gd_kp_gather_fwd_ln(const void* const* grids, const float* const* means, const float* const* rstds, int ngrid, long bstride,
+                                   long sstride, int grid_dtype, const float* ln_w, const float* ln_b, const float* kp, float* out, int B, int Nk, int gh,
+                                   int gw, int D, float sx, float sy, int img_h, int img_w, int patch, int stride, int pitch, void* stream) {
+    GatherParams p = {};
+    if (fill_gather(p, grids, ngrid, bstride, grid_dtype, kp, B, Nk, gh, gw, D, sx, sy, img_h, img_w, patch, stride, pitch)) return -1;
+    GD_REQUIRE(grid_dtype == GD_F32 || grid_dtype == GD_BF16, "gd_kp_gather_fwd_ln: grids are f32 or bf16 (got %d)", grid_dtype);
+    GD_REQUIRE(means && rstds && ln_w && ln_b && sstride > 0, "gd_kp_gather_fwd_ln: statistics and affine required");
+    bool vec = (D * gd_dtype_size(grid_dtype)) % 16 == 0 && (bstride * gd_dtype_size(grid_dtype)) % 16 == 0 && ((uintptr_t)out % 16) == 0 && D % 4 == 0;
+    for (int t = 0; t < ngrid; ++t) {
+        GD_REQUIRE(means[t] && rstds[t], "gd_kp_gather_fwd_ln: statistics of grid %d missing", t);
+        vec = vec && ((uintptr_t)grids[t] % 16) == 0;
+        p.ln_mean[t] = means[t]; p.ln_rstd[t] = rstds[t];
+    }
+    GD_REQUIRE(vec, "gd_kp_gather_fwd_ln: rows and batch strides must be 16-byte multiples, pointers 16-byte aligned, D %% 4 == 0");
+    p.out = out; p.ln_w = ln_w; p.ln_b = ln_b; p.sstride = sstride;
+    if (grid_dtype == GD_BF16) hipLaunchKernelGGL(kp_gather_fwd_ln_kernel<bf16>, dim3(B * Nk), dim3(128), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(kp_gather_fwd_ln_kernel<float>, dim3(B * Nk), dim3(128), 0, (hipStream_t)stream, p);
     GD_LAUNCH_OK();
     return 0;
 }

@@ -18,6 +18,7 @@ struct GdKnobs {
     int attn_dma;          // GD_ATTN_DMA          1: LDS-DMA attention forward; 0: register-staged
     int attn_rot;          // GD_ATTN_ROT          1: forward x-block xb starts at key tile 2 xb
     int attn_mfma32;       // GD_ATTN_MFMA32       1: forward on 32 x 32 x 16 MFMA tiles (measured 10 % slower: default 0, the 16 x 16 x 32 kernels)
+    int attn_stagger;      // GD_ATTN_STAGGER      start-up skew between the workgroups that share a CU, in ticks of 64 cycles per slot (0 = off; attention.hip attn_stagger)
     int attn_dkv_nw;       // GD_ATTN_DKV_NW       0 auto | 4 | 8 waves per dK/dV block
     int cv_mask_skip;      // GD_CV_MASK_SKIP      1: masked teacher rows are not fetched
     int cv_persist;        // GD_CV_PERSIST        1: persistent cost-volume forward

@@ -329,6 +329,7 @@ class FinetuneGD(nn.Module):
 
     def clear_cache(self):
         self._fwd_cache, self._norm_cache = {}, {}
+        ops.ln_stats_clear()
 
     def get_intermediate_feature(self, rgbs, pts=None, n=(4, 5, 6, 7), normalize=True):
         """src/finetune_timm_vggt.py:256-302 (reshape=True path): mean over taps of bilinear samples of the

@@ -226,6 +226,25 @@ def amax_clear():
     _AMAX.clear()
 
 
+# LayerNorm row statistics a block's forward took of its INPUT, offered to whoever else normalises the same tensor (a tapped block output is the
+# next block's input: vit._TapFn / kp_gather apply `model.norm` to it from these statistics instead of a LayerNorm pass of their own).  Keyed by the
+# tensor's address; one entry per tensor, popped by the taker, cleared with the step's other per-step state.
+_LN_STATS = {}
+
+
+def ln_stats_put(x, mean, rstd, eps):
+    _LN_STATS[x.data_ptr()] = (mean, rstd, float(eps), x.numel())
+
+
+def ln_stats_take(x, eps):
+    rec = _LN_STATS.pop(x.data_ptr(), None)
+    return (rec[0], rec[1]) if rec is not None and rec[3] == x.numel() and rec[2] == float(eps) and rec[0] is not None else None
+
+
+def ln_stats_clear():
+    _LN_STATS.clear()
+
+
 def cast16(x, scale=1.0, scale_dev=None):
     """f32 [rows, K] (rows may be strided) -> fp16 [rows, K] = sat(x * scale * scale_dev[0]): an operand of the tf32h engine's products (fp16
     carries TF32's 11-bit significand).  Forward activations and weights go in unscaled; gradients with the power of two of `amax_scale`
@@ -671,6 +690,16 @@ def kp_gather_fwd(grids, bstride, kp, B, Nk, gh, gw, D, sx, sy, img_h, img_w, pa
     check(lib().gd_kp_gather_fwd(_ptr_array(grids), len(grids), bstride, dtype_code(grids[0]), ptr(kp), ptr(out), B,
                                  Nk, gh, gw, D, float(sx), float(sy), img_h, img_w, patch, patch if stride is None else stride,
                                  gw if pitch is None else pitch, stream()), "gd_kp_gather_fwd")
+    return out
+
+
+def kp_gather_fwd_ln(grids, means, rstds, sstride, ln_w, ln_b, bstride, kp, B, Nk, gh, gw, D, sx, sy, img_h, img_w, patch, stride=None, pitch=None):
+    """kp_gather_fwd on RAW grids with the final LayerNorm applied where they are sampled: means / rstds = per-grid fp32 statistics tensors whose
+    data_ptr is the statistic of the grid's first token (same offset as the grid pointers), sstride = statistics per image."""
+    out = torch.empty(B, Nk, D, dtype=torch.float32, device=kp.device)
+    check(lib().gd_kp_gather_fwd_ln(_ptr_array(grids), _ptr_array(means), _ptr_array(rstds), len(grids), bstride, sstride, dtype_code(grids[0]),
+                                    ptr(ln_w), ptr(ln_b), ptr(kp), ptr(out), B, Nk, gh, gw, D, float(sx), float(sy), img_h, img_w, patch,
+                                    patch if stride is None else stride, gw if pitch is None else pitch, stream()), "gd_kp_gather_fwd_ln")
     return out
 
 

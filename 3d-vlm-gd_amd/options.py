@@ -13,6 +13,7 @@ _DEFS = {
     "adapter_h_fused": ("GD_ADAPTER_H_FUSED", 1),  # tf32h: the one-pass fp16-operand adapter kernel (0: cast + two GEMMs)
     "cv_bwd_rows": ("GD_CV_BWD_ROWS", 1),        # sparse row masks: the cost-volume backward in its kept-row form too (0: the dense hw x hw backward)
     "h16_dy": ("GD_H16_DY", 1),                  # tf32h: the two dX GEMMs that feed a LayerNorm backward write fp16 in the block's scaled domain (0: fp32)
+    "tap_norm_fused": ("GD_TAP_NORM_FUSED", 1),  # the taps' final LayerNorm applied inside the keypoint gather from the next block's row statistics (0: a LayerNorm pass per tap)
     "direct_grads": ("GD_DIRECT_GRADS", 1),      # fit_step: block weight gradients accumulate straight into the flat gradient buffer
 }
 _VALUES = {k: int(os.environ.get(env, str(d))) for k, (env, d) in _DEFS.items()}

@@ -167,6 +167,8 @@ class _BlockFn(torch.autograd.Function):
         need = x.requires_grad or any(t is not None and t.requires_grad for t in (a_q, b_q, a_v, b_v, down, up))
         h16 = {"out_dtype": torch.float16} if plan["x3"] == "h" else {}      # tf32h: LN(x) only ever feeds matrix products — written as their fp16 operand
         y1, mean1, rstd1 = ops.layernorm_fwd(x, plan["ln1_w"], plan["ln1_b"], plan["eps1"], save_stats=need, **h16)
+        if need and plan.get("offer_ln_stats"):      # this block's input is a tap: its row statistics serve the tap's `model.norm` too (_TapFn)
+            ops.ln_stats_put(x, mean1, rstd1, plan["eps1"])
         t = at = bt = None
         tw = plan.get("tw")           # per-step pack of the trainable weights (GDViT.prepare_trainables), or None
         if a_q is not None:
@@ -401,8 +403,9 @@ class _BlockFn(torch.autograd.Function):
         return dx, None, None, None, g_aq, g_bq, g_av, g_bv, g_down, g_up
 
 
-def run_block(blk, x):
-    """x [B, Nt, D] (engine dtype) -> block output, fused with its LoRA / adapter wrappers."""
+def run_block(blk, x, offer_ln_stats=False):
+    """x [B, Nt, D] (engine dtype) -> block output, fused with its LoRA / adapter wrappers.  offer_ln_stats: the row statistics the block's first
+    LayerNorm takes of x are left in ops' registry for the tap that normalises the same tensor (forward_all)."""
     inner, lora, adapter = _unwrap(blk)
     B, Nt, D = x.shape
     plan = inner.plan(x.dtype)
@@ -419,6 +422,8 @@ def run_block(blk, x):
     tw = getattr(inner, "_tw", None)
     if tw is not None and tw.get("dtype") == x.dtype:
         plan = dict(plan, tw=tw)
+    if offer_ln_stats:
+        plan = dict(plan, offer_ln_stats=True)
     out = _BlockFn.apply(x.reshape(B * Nt, D), plan, B, Nt, a_q, b_q, a_v, b_v, down, up)
     return out.view(B, Nt, D)
 
@@ -453,11 +458,21 @@ class _TapFn(torch.autograd.Function):
     pass-through gradients into the LayerNorm backward kernel as residuals (one pass)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, eps, out_dtype=None, amax=False):
+    def forward(ctx, x, w, b, eps, out_dtype=None, amax=False, defer=None):
         shp = x.shape
         ctx.amax = bool(amax)      # tf32h: the summed gradient is the block below's dout — take its maximum on the way out
         x2 = x.reshape(-1, shp[-1]).contiguous()
         wf, bf = w.detach().float().contiguous(), b.detach().float().contiguous()
+        if defer is not None:
+            # Round 5: the normed tap is NOT written.  The third output is one more alias of x; `defer` (filled by forward_all once the NEXT block's
+            # LayerNorm has taken the row statistics of this very tensor) tells its one consumer, kp_gather, to apply the norm where it samples
+            # (gd_kp_gather_fwd_ln), and this node's backward where to find the statistics.  4 x 94 us of ln_fwd_kernel<float, float> per step.
+            defer.update(x2=x2, w=wf, b=bf, eps=float(eps))
+            ctx.defer = defer
+            ctx.save_for_backward(x2, wf)
+            ctx.shp = shp
+            return x.view_as(x), x.view_as(x), x.view_as(x)
+        ctx.defer = None
         y, mean, rstd = ops.layernorm_fwd(x2, wf, bf, eps, save_stats=x.requires_grad, out_dtype=out_dtype)
         if x.requires_grad:
             ctx.save_for_backward(x2, wf, mean, rstd)
@@ -466,7 +481,11 @@ class _TapFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_next, g_raw, g_norm):
-        x2, wf, mean, rstd = ctx.saved_tensors
+        if ctx.defer is not None:
+            x2, wf = ctx.saved_tensors
+            mean, rstd = deferred_stats(ctx.defer)
+        else:
+            x2, wf, mean, rstd = ctx.saved_tensors
         res = [g.reshape(x2.shape).contiguous().to(x2.dtype) for g in (g_next, g_raw) if g is not None]
         if g_norm is None:
             dx = None if not res else (res[0] if len(res) == 1 else res[0] + res[1])
@@ -476,7 +495,33 @@ class _TapFn(torch.autograd.Function):
                 dy = dy.float()
             dx = ops.layernorm_bwd(dy, x2, wf, mean, rstd, dres=res[0] if res else None,
                                    dres2=res[1] if len(res) > 1 else None, want_amax=ctx.amax and x2.dtype == torch.float32)
-        return (dx.view(ctx.shp) if dx is not None else None), None, None, None, None, None
+        return (dx.view(ctx.shp) if dx is not None else None), None, None, None, None, None, None
+
+
+def deferred_stats(defer):
+    """(mean, rstd) of a deferred tap norm: what the next block's LayerNorm left in the registry, or — when that block kept none (it ran without
+    saving for a backward) — one statistics pass now."""
+    if "mean" not in defer:
+        _, defer["mean"], defer["rstd"] = ops.layernorm_fwd(defer["x2"], defer["w"], defer["b"], defer["eps"], save_stats=True)
+    return defer["mean"], defer["rstd"]
+
+
+class _DeferredNormFn(torch.autograd.Function):
+    """`model.norm` of a deferred tap, materialised for a consumer that cannot apply it itself.  The tap's own node (_TapFn) expects the gradient with
+    respect to the NORMED tensor on its third output: the backward here hands the incoming gradient through unchanged."""
+
+    @staticmethod
+    def forward(ctx, t, rec):
+        return ops.layernorm_fwd(rec["x2"], rec["w"], rec["b"], rec["eps"], save_stats=False)[0].view(t.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, None
+
+
+def deferred_norm(t):
+    """the materialised `model.norm` of a deferred tap (consumers other than an all-deferred kp_gather; not on the step's path)."""
+    return _DeferredNormFn.apply(t, t._gd_ln)
 
 
 class GDLayerNorm(nn.LayerNorm):
@@ -754,11 +799,27 @@ class GDViT(nn.Module):
         result is (taps, last, normed taps)."""
         x = self.embed(x, size)
         outs, normed = {}, {}
+        pending = None            # (tapped tensor, its deferred-norm record): the next block's LayerNorm fills in the statistics
+        # deferred tap norms (GD_TAP_NORM_FUSED, default on): fp32 / bf16 token rows of 16-byte multiples, autograd on (the consumer is the step's kp_gather)
+        defer_ok = (bool(option("tap_norm_fused")) and norm_taps and torch.is_grad_enabled() and self.tap_norm_dtype is None
+                    and (self.embed_dim * (2 if self.dtype == torch.bfloat16 else 4)) % 16 == 0)
         for i, blk in enumerate(self.blocks):
-            x = run_block(blk, x)      # not blk(x): a foreign wrapper class (utils/model.py's own) is fused by shape, never called
+            x_in = x
+            x = run_block(blk, x, offer_ln_stats=pending is not None)      # not blk(x): a foreign wrapper class (utils/model.py's own) is fused by shape, never called
+            if pending is not None:
+                st = ops.ln_stats_take(x_in.reshape(-1, x_in.shape[-1]), pending["eps"])
+                if st is not None:
+                    pending["mean"], pending["rstd"] = st
+                pending = None
             if i in taps:
                 if norm_taps and i + 1 < len(self.blocks):
-                    x, outs[i], normed[i] = _TapFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps, self.tap_norm_dtype, self.opfmt == "h")
+                    rec = {} if (defer_ok and x.requires_grad) else None
+                    x, outs[i], normed[i] = _TapFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps, self.tap_norm_dtype, self.opfmt == "h", rec)
+                    if rec is not None:
+                        inner = _unwrap(self.blocks[i + 1])[0]
+                        if inner.norm1.eps == self.norm.eps:
+                            pending = rec
+                        normed[i]._gd_ln = rec
                 else:
                     outs[i] = x
                     if norm_taps:
@@ -938,14 +999,20 @@ def conv3x3_tokens(tok, weight, bias, gh, gw):
 
 class _GatherFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, kp, geom, *grids):
+    def forward(ctx, kp, geom, ctx_ln, *grids):
         gh, gw, sx, sy, img_h, img_w, patch, stride, pitch = geom
         B, Ng, D = grids[0].shape
         prefix = Ng - gh * pitch
         gs = [g.contiguous() for g in grids]
         kp = kp.contiguous().float()
-        out = ops.kp_gather_fwd([g[:, prefix:] for g in gs], Ng * D, kp, B, kp.shape[1], gh, gw, D, sx, sy, img_h,
-                                img_w, patch, stride=stride, pitch=pitch)
+        recs = ctx_ln
+        if recs is not None:      # deferred tap norms: raw grids + the next block's row statistics, normalised where they are sampled
+            sts = [deferred_stats(r) for r in recs]
+            out = ops.kp_gather_fwd_ln([g[:, prefix:] for g in gs], [m.view(B, Ng)[:, prefix:] for m, _ in sts], [r.view(B, Ng)[:, prefix:] for _, r in sts], Ng,
+                                       recs[0]["w"], recs[0]["b"], Ng * D, kp, B, kp.shape[1], gh, gw, D, sx, sy, img_h, img_w, patch, stride=stride, pitch=pitch)
+        else:
+            out = ops.kp_gather_fwd([g[:, prefix:] for g in gs], Ng * D, kp, B, kp.shape[1], gh, gw, D, sx, sy, img_h,
+                                    img_w, patch, stride=stride, pitch=pitch)
         ctx.save_for_backward(kp)
         ctx.meta = (geom, B, Ng, D, prefix, len(gs), gs[0].dtype)
         return out
@@ -963,11 +1030,20 @@ class _GatherFn(torch.autograd.Function):
                                    stride=stride, pitch=pitch)[0]
             if dg.dtype != T:
                 dg = dg.to(T)
-        return (None, None) + (dg,) * ng
+        return (None, None, None) + (dg,) * ng
 
 
 def kp_gather(grids, kp, gh, gw, sx, sy, img_h, img_w, patch, stride=None, pitch=None):
     """interpolate_features on token-major grids [B, prefix+gh*pitch, D] (mean over the list) -> [B, Nk, D] fp32; pitch = tokens
     per grid line in memory (default gw; gw + 1 for conv3x3_tokens' separator-column output)."""
+    recs = [getattr(g, "_gd_ln", None) for g in grids]
+    if any(r is not None for r in recs):
+        if all(r is not None for r in recs) and len(grids) <= 4 and grids[0].dtype in (torch.float32, torch.bfloat16):
+            recs = tuple(recs)
+        else:      # mixed / unsupported: materialise the deferred norms (not the step's path)
+            grids = [deferred_norm(g) if r is not None else g for g, r in zip(grids, recs)]
+            recs = None
+    else:
+        recs = None
     return _GatherFn.apply(kp, (gh, gw, float(sx), float(sy), int(img_h), int(img_w), int(patch),
-                                int(patch if stride is None else stride), int(gw if pitch is None else pitch)), *grids)
+                                int(patch if stride is None else stride), int(gw if pitch is None else pitch)), recs, *grids)

@@ -163,6 +163,13 @@ int gd_col2im3x3(const void* dcol, void* dx, long bstride, int B, int gh, int gw
 int gd_kp_gather_fwd(const void* const* grids, int ngrid, long bstride, int grid_dtype, const float* kp, float* out,
                      int B, int Nk, int gh, int gw, int D, float sx, float sy, int img_h, int img_w, int patch,
                      int stride, int pitch, void* stream);
+/* The same gather on RAW block outputs with `model.norm` (the final LayerNorm: src/finetune_timm_vggt.py:262-276, get_intermediate_feature's
+ * `self.model.norm(feat)`) applied where the grids are sampled: means[t] / rstds[t] = per-token LayerNorm statistics of grid t ([B][sstride], addressed
+ * from the same token as grids[t]), ln_w / ln_b the shared affine [D].  A tapped block's output is the next block's input, whose LayerNorm forward
+ * already took the statistics: the taps' normed copies are never materialised.  f32 / bf16 grids, 16-byte rows. */
+int gd_kp_gather_fwd_ln(const void* const* grids, const float* const* means, const float* const* rstds, int ngrid, long bstride, long sstride,
+                        int grid_dtype, const float* ln_w, const float* ln_b, const float* kp, float* out, int B, int Nk, int gh, int gw, int D,
+                        float sx, float sy, int img_h, int img_w, int patch, int stride, int pitch, void* stream);
 int gd_kp_gather_bwd(float* const* dgrids, int ngrid, long bstride, const float* kp, const float* dout, int B, int Nk,
                      int gh, int gw, int D, float sx, float sy, int img_h, int img_w, int patch, int stride, int pitch,
                      void* stream);

@@ -154,6 +154,7 @@ def _run_case(name, backbone, variant, dtype, img=518, P=2, N=300, vit_kwargs=No
         if dropped:
             batch = _drop_keypoints(batch, drop)
     ref_loss, ref_terms, ref_grads, ref_params, ref_norm, names, l1_residuals = oracle(batch, key + ("drop", kink_band))
+    ref_grads, ref_params = [g.double() for g in ref_grads], [q.double() for q in ref_params]      # (an fp32 oracle's tensors: compared in double like the rest)
     if eng.depth_loss_weight != 0 and kink_band:
         res = torch.cat([r.abs().reshape(-1) for r in l1_residuals if r is not None])
         assert float(res.min()) >= kink_band * (1 - 1e-3)        # (independent per keypoint: nothing new moved into the band)

@@ -93,7 +93,8 @@ def test_patch_im2col_and_tokens(dtype, tol, P, hw_in, HW):
     col = ops.patch_im2col(img, HW[0], HW[1], P, Kp, mean, std, dtype)
     ref = O.normalize_image(O.resize_bilinear(img.cpu(), HW), mean, std)
     refcol = F.unfold(ref, P, stride=P).transpose(1, 2).reshape(-1, 3 * P * P)
-    assert rel_err(col[:, :3 * P * P], refcol) < tol and float(col[:, 3 * P * P:].abs().max()) == 0.0
+    assert rel_err(col[:, :3 * P * P], refcol) < tol
+    assert Kp == 3 * P * P or float(col[:, 3 * P * P:].abs().max()) == 0.0        # (patch 16: K = 768 needs no padding)
     Np = (HW[0] // P) * (HW[1] // P)
     tdt = torch.float32 if dtype == torch.float16 else dtype       # (tf32h engine: the patch projection's fp32 output is what gets assembled)
     patch = torch.randn(B * Np, D, generator=_g(9), device="cuda").to(tdt)
@@ -248,6 +249,71 @@ def test_kp_gather_multi_grid_mean():
         grid = t[:, 1:].float().cpu().reshape(B, gh, gw, D).permute(0, 3, 1, 2)
         ref = ref + O.interpolate_features(grid, kp.cpu() * 2.0, gh * P, gw * P, False, P, P).permute(0, 2, 1)
     assert rel_err(out, ref / 4) < 1e-5
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 2e-6)])
+def test_kp_gather_with_the_final_layernorm_applied_at_the_samples(dtype, tol):
+    """gd_kp_gather_fwd_ln (round 5): the mean over four RAW tap grids of bilinear samples of LayerNorm(grid) — get_intermediate_feature's
+    `self.model.norm(feat)` then interpolate_features, src/finetune_timm_vggt.py:262-288 — from per-token statistics, against the gather of the
+    materialised norms (fp64 reference on the same rounded inputs); keypoints on the border and outside; a prefix token; rows with a large mean."""
+    from gd_amd import ops
+    B, gh, gw, D, Nk, P, pre = 3, 7, 9, 256, 40, 14, 1
+    Ng = pre + gh * gw
+    toks = [(torch.randn(B, Ng, D, generator=_g(40 + t), device="cuda") * (1 + t) + 3.0 * t).to(dtype) for t in range(4)]
+    w = 1 + 0.2 * torch.randn(D, generator=_g(50), device="cuda")
+    b = 0.3 * torch.randn(D, generator=_g(51), device="cuda")
+    kp = torch.rand(B, Nk, 2, generator=_g(52), device="cuda") * torch.tensor([gw * P - 1.0, gh * P - 1.0], device="cuda")
+    kp[:, 0] = 0.0
+    kp[:, 1] = torch.tensor([gw * P - 1.0, gh * P - 1.0])
+    kp[:, 2] = torch.tensor([gw * P + 30.0, -12.0])
+    sts = [ops.layernorm_fwd(t.view(-1, D), w, b, 1e-6, save_stats=True)[1:] for t in toks]
+    out = ops.kp_gather_fwd_ln([t[:, pre:] for t in toks], [m.view(B, Ng)[:, pre:] for m, _ in sts], [r.view(B, Ng)[:, pre:] for _, r in sts], Ng, w, b,
+                               Ng * D, kp, B, Nk, gh, gw, D, 1.0, 1.0, gh * P, gw * P, P)
+    ref = 0
+    for t in toks:
+        n = F.layer_norm(t.double().cpu(), (D,), w.double().cpu(), b.double().cpu(), 1e-6)
+        grid = n[:, pre:].reshape(B, gh, gw, D).permute(0, 3, 1, 2)
+        ref = ref + O.interpolate_features(grid, kp.cpu().double(), gh * P, gw * P, False, P, P).permute(0, 2, 1)
+    assert rel_err(out, ref / 4) < 5e-6
+
+
+@pytest.mark.parametrize("taps", [(3, 4, 5, 6), (4, 5, 6, 7)])
+def test_deferred_tap_norm_equals_the_materialised_one(taps):
+    """vit.forward_all(norm_taps=True) with GD_TAP_NORM_FUSED (default): the taps' `model.norm` is not written — the keypoint gather applies it from
+    the row statistics the NEXT block's LayerNorm took of the same tensor (gd_kp_gather_fwd_ln), and _TapFn's backward uses those statistics.  Same
+    features and the same gradients as the materialising path (option off), f32 and tf32h engines.  Taps (3, 4, 5, 6) of the 8-block test ViT are all
+    deferred (the fused gather kernel); with (4, 5, 6, 7) the last tap has no next block: the deferred ones are materialised for the mixed gather
+    (_DeferredNormFn: the gradient still reaches _TapFn as the gradient of the NORMED tap)."""
+    from gd_amd.finetune import FinetuneGD
+    from gd_amd.options import set_option
+    from gd_amd.vit import kp_gather
+    for dt, tol in (("f32", 2e-5), ("tf32h", 2e-5)):
+        res = {}
+        for fused in (1, 0):
+            old = set_option("tap_norm_fused", fused)
+            try:
+                torch.manual_seed(0)
+                eng = FinetuneGD(r=4, backbone="vit_tiny_test", patch_size=14, img_size=56, variant="mast3r", geometry="shared", dtype=dt,
+                                 lora_b_std=0.05, vit_kwargs=dict(init_values=1.0), teacher_patch=14, adapter_start_idx=2).cuda()
+                eng.model.prepare_trainables(None)
+                rgb = torch.rand(2, 3, 56, 70, generator=_g(60), device="cuda")
+                kp = torch.rand(2, 9, 2, generator=_g(61), device="cuda") * torch.tensor([69.0, 55.0], device="cuda")
+                raw, x, normed = eng.model.forward_all(rgb, taps, size=(56, 70), norm_taps=True)
+                flags = [hasattr(t, "_gd_ln") for t in normed]
+                assert flags == ([i + 1 < 8 for i in taps] if fused else [False] * 4)
+                feat = kp_gather(normed, kp, 4, 5, 1.0, 1.0, 56, 70, 14)
+                cw = torch.randn(feat.shape, generator=_g(62), device="cuda")
+                cr = torch.randn(raw[0].shape, generator=_g(63), device="cuda")
+                ((feat * cw).sum() + sum((t.float() * cr).sum() for t in raw) + 0.1 * (x.float() * cr).sum()).backward()
+                res[fused] = (feat.detach().clone(), [q.grad.detach().clone() for q in eng.trainable_parameters() if q.grad is not None])
+                eng.model.release_trainables()
+                eng.clear_cache()
+            finally:
+                set_option("tap_norm_fused", old)
+        assert rel_err(res[1][0], res[0][0]) < tol
+        assert len(res[1][1]) == len(res[0][1]) > 0
+        for a, c in zip(res[1][1], res[0][1]):
+            assert rel_err(a, c) < 50 * tol
 
 
 def test_kp_depth_and_patch_mask_golden():

@@ -367,6 +367,26 @@ def probe_gemm():
         print(f"probe {tag:5s} {M}x{N}x{K}: {t*1e6:7.1f} us {2*M*N*K/t/1e12:7.1f} TF/s | shader-clock cycles per tile: wait {out[0]/n:8.1f}  main {out[1]/n:8.1f}  dma-issue {out[4]/n:8.1f}  epi {out[2]/n:8.1f}  tiles/blk {n/256:5.2f} | of main: stage waits (vmcnt + barrier) {out[5]/n:8.1f} = {out[5]/max(out[1],1):.3f}")
 
 
+def bench_attn_stagger(rounds=3):
+    """Round 5: start-up skew between the workgroups of a CU (gd_debug_set("attn_stagger", ticks of 64 cycles per slot)) — forward, dQ and dK/dV kernels at the
+    benched shape (64 x 12 x 1370, fp16 operands), interleaved rounds in one process; backward = dQ + dK/dV together as the step runs them."""
+    L = gd_amd._lib.lib()
+    B, N, H = 64, 1370, 12
+    qkv = torch.randn(B * N, 3 * H * 64, device="cuda").half()
+    dout = torch.randn(B * N, H * 64, device="cuda").half()
+    o, lse = ops.attention_fwd(qkv, B, N, H)
+    ticks = (0, 4, 8, 12, 16, 24, 32)
+    res = {t: ([], []) for t in ticks}
+    for _ in range(rounds):
+        for t in ticks:
+            L.gd_debug_set(b"attn_stagger", t)
+            res[t][0].append(timeit(lambda: ops.attention_fwd(qkv, B, N, H), warm=2, it=10))
+            res[t][1].append(timeit(lambda: ops.attention_bwd(qkv, o, dout, lse, B, N, H, vfirst=True), warm=2, it=10))
+    L.gd_debug_set(b"attn_stagger", 0)
+    for t in ticks:
+        print(f"attn_stagger {t:3d} ticks: fwd {min(res[t][0]) * 1e6:7.1f} us  bwd {min(res[t][1]) * 1e6:7.1f} us   (all: {[round(x * 1e6, 1) for x in res[t][0]]} / {[round(x * 1e6, 1) for x in res[t][1]]})", flush=True)
+
+
 def pmc_attn():
     import os
     B, N, H = (8, 6401, 12) if os.environ.get("GD_PMC_LONG") else (64, 1370, 12)
@@ -421,6 +441,8 @@ if __name__ == "__main__":
         pmc_cv_rows()
     if "attn" in which:
         bench_attn()
+    if "attn_stagger" in which:
+        bench_attn_stagger()
     if "attn_x3" in which:
         bench_attn_x3()
     if "cva" in which:
