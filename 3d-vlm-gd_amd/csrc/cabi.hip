@@ -30,7 +30,7 @@ static const KnobDef KNOBS[] = {
     {"cv_grid", "GD_CV_GRID", &GdKnobs::cv_grid, 0},                      {"pair_rank_wave", "GD_PAIR_RANK_WAVE", &GdKnobs::pair_rank_wave, 0},
     {"ln_16b", "GD_LN_16B", &GdKnobs::ln_16b, 1},                         {"adapter_persist", "GD_ADAPTER_PERSIST", &GdKnobs::adapter_persist, 1},
     {"reserve_cus", "GD_RESERVE_CUS", &GdKnobs::reserve_cus, 0},          {"gemm_group_m", "GD_GEMM_GROUP_M", &GdKnobs::gemm_group_m, 1},
-    {"gemm_stagger", "GD_GEMM_STAGGER", &GdKnobs::gemm_stagger, 0},       {"cv_panel", "GD_CV_PANEL", &GdKnobs::cv_panel, 1},
+    {"gemm_stagger", "GD_GEMM_STAGGER", &GdKnobs::gemm_stagger, 0},       {"cv_panel", "GD_CV_PANEL", &GdKnobs::cv_panel, 0},
 };
 static void gd_apply_reserve(GdKnobs& v) {
     int r = v.reserve_cus < 0 ? 0 : v.reserve_cus;

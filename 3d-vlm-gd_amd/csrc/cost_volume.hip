@@ -822,16 +822,17 @@ __global__ __launch_bounds__(768) void cv_fwd_rows_kernel(CvTileParams q) {
 #include "cv_panel.h"
 
 // grid of the panel kernels: one block per CU, a multiple of 8 (XCD-major block ids); 0 = the shape is not theirs (the caller falls back)
-static int cv_panel_grid(long total_tiles, long rowb, int ldt, const void* t1, const void* t2) {
-    if (!gd_knobs().cv_panel || (rowb != 6 * 128 && rowb != 12 * 128) || ldt % 4 != 0 || ldt < 8 || ((uintptr_t)t1 & 15) || ((uintptr_t)t2 & 15)) return 0;
+static int cv_panel_grid(long total_tiles, long rowb, int ldt, const void* t1, const void* t2, int nw) {
+    if (!gd_knobs().cv_panel || rowb != 12 * 128 || ldt % 4 != 0 || ldt < 8 || ((uintptr_t)t1 & 15) || ((uintptr_t)t2 & 15)) return 0;
     int ncu = 256;
     if (gd_knobs().ncu >= 8) ncu = gd_knobs().ncu / 8 * 8;
+    if (nw == 4) ncu *= 2;      // two 4-wave blocks per CU
     int grid = (int)(total_tiles < ncu ? (total_tiles + 7) / 8 * 8 : ncu);
     if (gd_knobs().cv_grid) {      // tests (gd_debug_set): few blocks, so that every block walks many tiles
         const int gv = gd_knobs().cv_grid / 8 * 8;
         if (gv >= 8 && gv < grid) grid = gv;
     }
-    if ((total_tiles + grid - 1) / grid + 64 > CVA_LIST_MAX) return 0;       // (a block's slice of every pair segment rounds up: generous margin)
+    if ((total_tiles + grid - 1) / grid + 40 > CVA_LIST_MAX) return 0;       // (a block's slice of every pair segment of its XCD's range rounds up: margin)
     return grid;
 }
 
@@ -910,7 +911,8 @@ __global__ __launch_bounds__(256) void cv_finalize_rows_kernel(const float* part
 // reduce the slabs, save logZ and W for the backward, emit per-chunk partial losses (CV_FCH chunks per pair), then sum
 __global__ __launch_bounds__(256) void cv_finalize_kernel(const float* part1, const float* part2, const float* tstats,
                                                           const unsigned char* m1, const unsigned char* m2,
-                                                          float* stats, double* chunk_loss, int hw, int nslab, int variant) {
+                                                          float* stats, double* chunk_loss, int hw, int nslab, int nslab2, int variant) {
+    // (nslab2: slabs of the direction-2 partials — the number of ROW panels of the forward kernel, which the panel kernels choose themselves)
     const int p = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
     const float masked_const = variant == 1 ? (float)hw * (CV_EPS * logf(CV_EPS * (float)hw)) : 0.f;
     double total = 0.0;
@@ -918,9 +920,10 @@ __global__ __launch_bounds__(256) void cv_finalize_kernel(const float* part1, co
     for (int idx = ch * per + tid; idx < min(2 * hw, (ch + 1) * per); idx += 256) {
         const int d = idx >= hw, row = d ? idx - hw : idx;
         const float* part = d ? part2 : part1;
+        const int ns = d ? nslab2 : nslab;
         float Z = 0.f, B = 0.f;
-        for (int s = 0; s < nslab; ++s) {
-            const f32x2 v = *(const f32x2*)(part + (((long)p * nslab + s) * hw + row) * 2);
+        for (int s = 0; s < ns; ++s) {
+            const f32x2 v = *(const f32x2*)(part + (((long)p * ns + s) * hw + row) * 2);
             Z += v[0]; B += v[1];
         }
         const float Wt = tstats[(((long)p * 2 + d) * hw + row) * 4 + 1], A = tstats[(((long)p * 2 + d) * hw + row) * 4 + 2];
@@ -1285,8 +1288,9 @@ static inline int cv_hwp(int hw) { return (hw + 63) & ~63; }   // K of the two b
 
 extern "C" size_t gd_cost_volume_kl_workspace_bytes(int P, int hw, int C, int dtype, int backward) {
     const size_t es = (size_t)gd_dtype_size(dtype);
-    if (!backward) return 2 * align256((size_t)P * cv_tiles(hw) * hw * 2 * sizeof(float)) + align256((size_t)P * CV_FCH * sizeof(double)) +
-                          align256((size_t)P * 2 * hw * 4 * sizeof(float));
+    // (direction-2 partials: one slab per ROW PANEL of the forward kernel — 64-row panels in the round-5 panel kernel: twice the 128-row tile count)
+    if (!backward) return align256((size_t)P * cv_tiles(hw) * hw * 2 * sizeof(float)) + align256((size_t)P * 2 * cv_tiles(hw) * hw * 2 * sizeof(float)) +
+                          align256((size_t)P * CV_FCH * sizeof(double)) + align256((size_t)P * 2 * hw * 4 * sizeof(float));
     const size_t hwp = (size_t)cv_hwp(hw);
     return 2 * align256((size_t)P * hw * hwp * es) + 2 * align256((size_t)P * C * hwp * es) +
            2 * align256((size_t)P * hw * C * sizeof(float));
@@ -1317,7 +1321,8 @@ static int cv_fwd_common(const void* f1, const void* f2, const float* inv1, cons
     const int tiles = cv_tiles(hw), nslab = tiles;
     float* part1 = (float*)workspace;
     float* part2 = (float*)((char*)workspace + align256((size_t)P * nslab * hw * 2 * sizeof(float)));
-    double* chunk_loss = (double*)((char*)workspace + 2 * align256((size_t)P * nslab * hw * 2 * sizeof(float)));
+    double* chunk_loss = (double*)((char*)part2 + align256((size_t)P * 2 * nslab * hw * 2 * sizeof(float)));
+    int nslab2 = nslab;
     float* ts_ws = (float*)((char*)chunk_loss + align256((size_t)P * CV_FCH * sizeof(double)));
     if (!tstats) {     // no cached teacher statistics: one extra pass over the teacher maps
         hipLaunchKernelGGL(cv_tstats_kernel, dim3(gd_cdiv(hw, 4), 2, P), dim3(256), 0, s, t1, t2, ts_ws, hw, ldt);
@@ -1338,22 +1343,33 @@ static int cv_fwd_common(const void* f1, const void* f2, const float* inv1, cons
     // shelved as tools/experiments/cv_persist256.h)
     const int persist = gd_knobs().cv_persist;     // GD_CV_PERSIST=0: the one-tile-per-block kernel (A/B)
     const long rowb = (long)C * gd_dtype_size(dtype);
-    const int pgrid = (persist && dtype != GD_F32 && (!gd_knobs().cv_dbg || (gd_knobs().cv_panel == 2 && dtype == GD_F16 && rowb == 12 * 128)))
-                          ? cv_panel_grid((long)P * tiles * tiles, rowb, ldt, t1, t2) : 0;
-    if (pgrid && gd_knobs().cv_dbg) {      // anatomy (tools/cv_anatomy.py, GD_CV_PANEL=2 + GD_CV_DBG bits): parts of the panel kernel switched off; results meaningless
+    // round 5: row panels resident in registers, only the column operand streams (cv_panel.h).  GD_CV_PANEL: 1 = 64-row panels, two 4-wave blocks per CU
+    // (default); 8 = 128-row panels, one 8-wave block per CU; 0 = the round-4 kernels.  Teacher entries of masked-out rows are fetched here (no q.m1 /
+    // q.m2 tests in the prefetch).  With GD_CV_DBG set: the 4-wave kernel's anatomy instantiations (-DGD_CV_PANEL_ANAT builds).
+    const int pmode = gd_knobs().cv_panel;
+    const int pnw = pmode == 8 ? 8 : 4;
+    const int pgrid = (persist && pmode && dtype != GD_F32 && (!gd_knobs().cv_dbg || (dtype == GD_F16 && pnw == 4)))
+                          ? cv_panel_grid((long)P * gd_cdiv(hw, 16 * pnw) * tiles, rowb, ldt, t1, t2, pnw) : 0;
+    if (pgrid) {
         q.m1 = q.m2 = nullptr;
-        q.dbg = gd_knobs().cv_dbg;
-        hipLaunchKernelGGL((cv_fwd_panel_kernel<f16, 12, false, true>), dim3(pgrid), dim3(512), 0, s, q);
-    } else if (pgrid) {
-        // round 5: the row panel stays in registers, only the column operand streams (cv_panel.h).  Teacher entries of masked-out rows are
-        // fetched here (no q.m1 / q.m2 tests in the prefetch): GD_CV_PANEL=0 restores the round-4 kernel with its mask skip.
-        q.m1 = q.m2 = nullptr;
-        if (rowb == 12 * 128) {
-            if (dtype == GD_BF16) hipLaunchKernelGGL((cv_fwd_panel_kernel<bf16, 12, false>), dim3(pgrid), dim3(512), 0, s, q);
-            else hipLaunchKernelGGL((cv_fwd_panel_kernel<f16, 12, false>), dim3(pgrid), dim3(512), 0, s, q);
+        nslab2 = gd_cdiv(hw, 16 * pnw);
+        if (gd_knobs().cv_dbg) {
+#ifdef GD_CV_PANEL_ANAT
+            switch (gd_knobs().cv_dbg) {
+#define CVA_AN(M) case M: hipLaunchKernelGGL((cv_fwd_panel_kernel<f16, 12, 4, M>), dim3(pgrid), dim3(256), 0, s, q); break;
+                CVA_AN(1) CVA_AN(2) CVA_AN(3) CVA_AN(4) CVA_AN(5) CVA_AN(6) CVA_AN(7) CVA_AN(8) CVA_AN(12) CVA_AN(15)
+#undef CVA_AN
+                default: hipLaunchKernelGGL((cv_fwd_panel_kernel<f16, 12, 4, 0>), dim3(pgrid), dim3(256), 0, s, q);
+            }
+#else
+            GD_REQUIRE(false, "gd_cost_volume_kl_fwd: the panel kernel's anatomy instantiations need a -DGD_CV_PANEL_ANAT build");
+#endif
+        } else if (pnw == 8) {
+            if (dtype == GD_BF16) hipLaunchKernelGGL((cv_fwd_panel_kernel<bf16, 12, 8>), dim3(pgrid), dim3(512), 0, s, q);
+            else hipLaunchKernelGGL((cv_fwd_panel_kernel<f16, 12, 8>), dim3(pgrid), dim3(512), 0, s, q);
         } else {
-            if (dtype == GD_BF16) hipLaunchKernelGGL((cv_fwd_panel_kernel<bf16, 6, false>), dim3(pgrid), dim3(512), 0, s, q);
-            else hipLaunchKernelGGL((cv_fwd_panel_kernel<f16, 6, false>), dim3(pgrid), dim3(512), 0, s, q);
+            if (dtype == GD_BF16) hipLaunchKernelGGL((cv_fwd_panel_kernel<bf16, 12, 4>), dim3(pgrid), dim3(256), 0, s, q);
+            else hipLaunchKernelGGL((cv_fwd_panel_kernel<f16, 12, 4>), dim3(pgrid), dim3(256), 0, s, q);
         }
     } else if (persist && rowb % 128 == 0 && rowb / 128 >= 3 && ldt % 4 == 0 && ((uintptr_t)t1 & 15) == 0 && ((uintptr_t)t2 & 15) == 0) {
         int ncu = 256;
@@ -1377,7 +1393,7 @@ static int cv_fwd_common(const void* f1, const void* f2, const float* inv1, cons
         hipLaunchKernelGGL(cv_fwd_tile_kernel<float>, dim3(tiles * tiles, P), dim3(256), 0, s, q);
     GD_LAUNCH_OK();
     hipLaunchKernelGGL(cv_finalize_kernel, dim3(P, CV_FCH), dim3(256), 0, s, part1, part2, tstats, m1, m2, stats, chunk_loss, hw,
-                       nslab, variant);
+                       nslab, nslab2, variant);
     hipLaunchKernelGGL(cv_loss_kernel, dim3(gd_cdiv(P, 64)), dim3(64), 0, s, chunk_loss, loss, P, hw);
     GD_LAUNCH_OK();
     return 0;
@@ -1550,16 +1566,7 @@ extern "C" int gd_cost_volume_kl_fwd_rows(const void* f1, const void* f2, const 
         const int gv = gd_knobs().cv_grid / 8 * 8;
         if (gv >= 8 && gv < grid) grid = gv;
     }
-    const int pgrid = dtype != GD_F32 ? cv_panel_grid(total, rowb, ldt, t1, t2) : 0;
-    if (pgrid) {      // round 5: the kept rows of a row tile stay in registers for the sweep of column tiles (cv_panel.h, ROWS form)
-        if (rowb == 12 * 128) {
-            if (dtype == GD_BF16) hipLaunchKernelGGL((cv_fwd_panel_kernel<bf16, 12, true>), dim3(pgrid), dim3(512), 0, s, q);
-            else hipLaunchKernelGGL((cv_fwd_panel_kernel<f16, 12, true>), dim3(pgrid), dim3(512), 0, s, q);
-        } else {
-            if (dtype == GD_BF16) hipLaunchKernelGGL((cv_fwd_panel_kernel<bf16, 6, true>), dim3(pgrid), dim3(512), 0, s, q);
-            else hipLaunchKernelGGL((cv_fwd_panel_kernel<f16, 6, true>), dim3(pgrid), dim3(512), 0, s, q);
-        }
-    } else if (dtype == GD_BF16) hipLaunchKernelGGL(cv_fwd_rows_kernel<bf16>, dim3(grid), dim3(768), 0, s, q);
+    if (dtype == GD_BF16) hipLaunchKernelGGL(cv_fwd_rows_kernel<bf16>, dim3(grid), dim3(768), 0, s, q);
     else if (dtype == GD_F16) hipLaunchKernelGGL(cv_fwd_rows_kernel<f16>, dim3(grid), dim3(768), 0, s, q);
     else hipLaunchKernelGGL(cv_fwd_rows_kernel<float>, dim3(grid), dim3(768), 0, s, q);
     GD_LAUNCH_OK();

@@ -22,7 +22,7 @@ struct GdKnobs {
     int attn_dkv_nw;       // GD_ATTN_DKV_NW       0 auto | 4 | 8 waves per dK/dV block
     int cv_mask_skip;      // GD_CV_MASK_SKIP      1: masked teacher rows are not fetched
     int cv_persist;        // GD_CV_PERSIST        1: persistent cost-volume forward
-    int cv_panel;          // GD_CV_PANEL          1: row-panel-stationary forward kernels (cv_panel.h) where they apply; 0: the round-2..4 persistent kernels
+    int cv_panel;          // GD_CV_PANEL          0 (default): the round-2..4 persistent forward; 1 / 8: the row-panel-stationary experiment of round 5 (cv_panel.h; 4- / 8-wave blocks; measured slower)
     int cv_dbg;            // GD_CV_DBG            anatomy switches of the cost-volume forward (tools/cv_anatomy.py)
     int cv_grid;           // GD_CV_GRID           block count cap of the persistent cost-volume forward (tests: many tiles per block)
     int pair_rank_wave;    // GD_PAIR_RANK_WAVE    0 tiled kernel | 1 | 2 | 3 older forms

@@ -136,9 +136,11 @@ def _debug(name, value):
 # walks dozens of tiles: ring slots, panel reloads in the middle of a slice, slices that end inside a pair, the statistics / partial-sum
 # buffers and the one-tile-ahead teacher prefetch all wrap around many times.  hw = 1369 has a ragged last tile (89 rows / columns), hw = 768 none,
 # hw = 200 two tiles per side (a pair's tiles < blocks per XCD: empty slices).
-@pytest.mark.parametrize("variant,mode,P,hw,C,grid", [("vggt", "bf16", 3, 1369, 768, 0), ("mast3r", "bf16", 5, 768, 384, 8), ("vggt", "h", 2, 1369, 768, 16),
-                                                      ("mast3r", "h", 9, 672, 768, 8), ("vggt", "bf16", 11, 200, 384, 0), ("mast3r", "h", 1, 1369, 768, 0)])
-def test_panel_forward_matches_oracle_and_round4_kernel(variant, mode, P, hw, C, grid):
+# The kernel is an EXPERIMENT behind GD_CV_PANEL (1: two 4-wave blocks per CU, 64-row panels; 8: one 8-wave block, 128-row panels); the default
+# forward is the round-4 persistent kernel.  Kept under test so that the measurements in profiles/NOTES_r05.md can be re-run on a correct kernel.
+@pytest.mark.parametrize("variant,mode,P,hw,C,grid,panel", [("vggt", "bf16", 3, 1369, 768, 0, 1), ("vggt", "h", 2, 1369, 768, 16, 1), ("mast3r", "h", 9, 672, 768, 8, 8),
+                                                            ("vggt", "bf16", 11, 200, 768, 0, 8), ("mast3r", "h", 1, 1369, 768, 0, 1)])
+def test_panel_forward_matches_oracle_and_round4_kernel(variant, mode, P, hw, C, grid, panel):
     from gd_amd import ops
     gen = torch.Generator(device="cuda").manual_seed(hw + C + P)
     f1 = torch.randn(P, hw, C, generator=gen, device="cuda")
@@ -163,11 +165,12 @@ def test_panel_forward_matches_oracle_and_round4_kernel(variant, mode, P, hw, C,
         o1, o2, tol = b1.float(), b2.float(), 1e-3
     _debug("cv_grid", grid)
     try:
+        _debug("cv_panel", panel)
         new, new2 = run(), run()
         _debug("cv_panel", 0)
         old = run()
     finally:
-        _debug("cv_panel", 1)
+        _debug("cv_panel", 0)                      # the default: the experiment is not the product path (it measured slower, profiles/NOTES_r05.md)
         _debug("cv_grid", 0)
     assert torch.equal(new, new2)
     assert rel_err(new, old) < 2e-6

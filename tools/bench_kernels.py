@@ -128,15 +128,15 @@ def bench_cv_ab(rounds=3):
              "kept rows (keypoint-patch masks)": lambda: ops.cost_volume_kl(f1, f2, t1, t2, mk1, mk2, "mast3r", tstats=ts, inv_norms=inv, x3="h", h16=h16, kept_rows_max=300)}
     with torch.no_grad():
         for name, fn in cases.items():
-            res = {0: [], 1: []}
+            res = {0: [], 1: [], 8: []}
             for _ in range(rounds):
-                for v in (0, 1):
+                for v in (0, 1, 8):
                     L.gd_debug_set(b"cv_panel", v)
                     res[v].append(timeit(fn, warm=3, it=20))
-            L.gd_debug_set(b"cv_panel", 1)
+            L.gd_debug_set(b"cv_panel", 0)
             a, b = min(res[0]), min(res[1])
             print(f"cv_ab {name:34s}: round-4 kernel {a * 1e6:7.1f} us ({a * 1e6 / P:5.2f} us/pair, {alg / a / 8e12:5.3f} of 8 TB/s by the dense byte count) | "
-                  f"panel kernel {b * 1e6:7.1f} us ({b * 1e6 / P:5.2f} us/pair, {alg / b / 8e12:5.3f})   all rounds: {[round(x * 1e6, 1) for x in res[0]]} vs {[round(x * 1e6, 1) for x in res[1]]}", flush=True)
+                  f"panel kernel {b * 1e6:7.1f} us ({b * 1e6 / P:5.2f} us/pair, {alg / b / 8e12:5.3f})   | 8-wave panel kernel {min(res[8]) * 1e6:7.1f} us   all rounds: {[round(x * 1e6, 1) for x in res[0]]} vs {[round(x * 1e6, 1) for x in res[1]]} vs {[round(x * 1e6, 1) for x in res[8]]}", flush=True)
 
 
 def bench_adapter():

@@ -1,5 +1,5 @@
 """Round 5: where the row-panel-stationary cost-volume forward (csrc/cv_panel.h, dense form, fp16 features as the tf32h trainer calls it) spends its time:
-the DBG instantiation with parts switched off through GD_CV_DBG bits (1 no teacher loads, 2 no epilogue math, 4 no LDS reads / MFMAs, 8 no DMA), whole op,
+compile-time instantiations (make XFLAGS=-DGD_CV_PANEL_ANAT) with parts switched off, selected by GD_CV_DBG (1 no teacher loads, 2 no epilogue math, 4 no LDS reads / MFMAs, 8 no DMA), whole op,
 32 pairs, every row kept, interleaved with the product kernel and the round-4 kernel in one process."""
 import os, sys, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
@@ -17,8 +17,8 @@ inv = (1.0 / f1.norm(dim=-1).clamp_min(1e-12), 1.0 / f2.norm(dim=-1).clamp_min(1
 h16 = (f1.half(), f2.half())
 run = lambda: ops.cost_volume_kl(f1, f2, t1, t2, m1, m2, "mast3r", tstats=ts, inv_norms=inv, x3="h", h16=h16)
 with torch.no_grad():
-    for panel, dbg in ((1, 0), (0, 0), (2, 32), (2, 1), (2, 2), (2, 4), (2, 3), (2, 7), (2, 15), (2, 12), (2, 8), (1, 0), (0, 0)):
+    for panel, dbg in ((1, 0), (0, 0), (2, 1), (2, 2), (2, 3), (2, 4), (2, 5), (2, 6), (2, 7), (2, 8), (2, 12), (2, 15), (1, 0), (0, 0)):
         L.gd_debug_set(b"cv_panel", panel); L.gd_debug_set(b"cv_dbg", dbg)
         t = ops.time_on_stream(run, 3, 10)
-        print(f"cv_panel={panel} dbg={dbg:2d} (1 no teacher | 2 no epilogue | 4 no LDS reads / MFMAs | 8 no DMA; 32 = DBG build, nothing off): {t * 1e6:8.1f} us for {P} pairs", flush=True)
-L.gd_debug_set(b"cv_panel", 1); L.gd_debug_set(b"cv_dbg", 0)
+        print(f"cv_panel={panel} dbg={dbg:2d} (1 no teacher | 2 no epilogue | 4 no LDS reads / MFMAs | 8 no DMA): {t * 1e6:8.1f} us for {P} pairs", flush=True)
+L.gd_debug_set(b"cv_panel", 0); L.gd_debug_set(b"cv_dbg", 0)
