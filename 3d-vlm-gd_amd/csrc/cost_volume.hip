@@ -18,6 +18,7 @@
 // NT GEMMs (G b and G^T a), then cv_norm_bwd pulls the gradient through the L2 normalisation.
 #include "gd_common.h"
 #include "gemm_tile.h"
+#include <type_traits>
 #include "gemm_frag.h"
 #include <stdlib.h>
 
@@ -550,50 +551,74 @@ __global__ __launch_bounds__(768) void cv_fwd_persist_kernel(CvTileParams q) {
             continue;
         }
         // ---------------- epilogue, all from registers ----------------
+        // Round 5: 14 -> ~7 VALU instructions per entry (the epilogue was the largest single phase of a tile: ~45 issued instructions per entry and lane
+        // with its reductions, all waves of the CU in it at the same time).  (a) scores in the log2 domain: s' = acc * (inv1 log2 e) * inv2, e = exp2(s'),
+        // the B sums carry s' and are scaled by ln 2 once per row / column; (b) max(t / rowsum, EPS) * s = (1 / rowsum) * max(t, EPS rowsum) * s: the
+        // division leaves the loop the same way; (c) no bounds tests per entry (below); (d) the r-pairs of an accumulator as packed
+        // fp32 operations (v_pk_mul / v_pk_add / v_pk_fma_f32).
         const CvpTile t = cvp_tile(beg + kb + it * nbx, tiles);
         const f32x4* sSt = (const f32x4*)(smem + CVP_STAT_OFF + (it & 1) * 4096);
         float* sP = (float*)(smem + CVP_PART_OFF + (it & 1) * 6144);
-        float inv2[4], ir2[4], zc[4], b2[4];
-        bool cok[4];
+        {
+            constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+            // Entries past the ragged edge (tile rows / columns >= hw; their operands are clamped re-reads): the row's / column's inverse norm is
+            // zeroed, which makes s' = 0 — nothing enters a B sum — and e = exp2(0) = 1 exactly; the Z sums of the VALID rows and columns are
+            // corrected by the count of ones they collected (those of invalid rows / columns are never stored).  No per-entry test or select.
+            float inv2[4], thr2[4], badc = 0.f, badr = 0.f;
+            f32x2 zc[4], b2[4];
 #pragma unroll
-        for (int jb = 0; jb < 4; ++jb) {
-            const int cl = wn * 64 + 4 * c + jb;
-            const f32x4 v = sSt[128 + cl];
-            inv2[jb] = v[0]; ir2[jb] = 1.0f / v[1];
-            cok[jb] = t.tn * 128 + cl < hw;
-            zc[jb] = 0.f; b2[jb] = 0.f;
-        }
-#pragma unroll
-        for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int rl = wm * 32 + ib * 16 + 4 * g + r;
-                const f32x4 v = sSt[rl];
-                const float inv1 = v[0], ir1 = 1.0f / v[1];
-                const bool rok = t.tm * 128 + rl < hw;
-                float zr = 0.f, b1 = 0.f;
-#pragma unroll
-                for (int jb = 0; jb < 4; ++jb) {
-                    const bool ok = rok && cok[jb];
-                    const float sv = acc[ib][jb][r] * inv1 * inv2[jb];
-                    const float e = ok ? __expf(sv) : 0.f;
-                    const float sm = ok ? sv : 0.f;
-                    zr += e; zc[jb] += e;
-                    b1 = fmaf(fmaxf(t1v[ib][r][jb] * ir1, CV_EPS), sm, b1);
-                    b2[jb] = fmaf(fmaxf(t2v[ib][jb][r] * ir2[jb], CV_EPS), sm, b2[jb]);
-                }
-                zr = row16_sum(zr);
-                b1 = row16_sum(b1);
-                if (c == 0) { sP[wn * 128 + rl] = zr; sP[256 + wn * 128 + rl] = b1; }
+            for (int jb = 0; jb < 4; ++jb) {
+                const int cl = wn * 64 + 4 * c + jb;
+                const f32x4 v = sSt[128 + cl];
+                const bool ok = t.tn * 128 + cl < hw;
+                inv2[jb] = ok ? v[0] : 0.f; thr2[jb] = CV_EPS * v[1];
+                badc += ok ? 0.f : 1.f;
+                zc[jb] = f32x2{0.f, 0.f}; b2[jb] = f32x2{0.f, 0.f};
             }
 #pragma unroll
-        for (int jb = 0; jb < 4; ++jb) {
-            float z = zc[jb], b = b2[jb];
-            z += __shfl_xor(z, 16, 64); z += __shfl_xor(z, 32, 64);
-            b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
-            if (g == 0) {
-                const int cl = wn * 64 + 4 * c + jb;
-                sP[512 + wm * 128 + cl] = z; sP[1024 + wm * 128 + cl] = b;
+            for (int ib = 0; ib < 2; ++ib) {
+                f32x4 inv1, thr1, zr = {-badc, -badc, -badc, -badc}, b1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rl = wm * 32 + ib * 16 + 4 * g + r;
+                    const f32x4 v = sSt[rl];
+                    const bool ok = t.tm * 128 + rl < hw;
+                    inv1[r] = ok ? v[0] * LOG2E : 0.f; thr1[r] = CV_EPS * v[1];
+                    badr += ok ? 0.f : 1.f;
+                }
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb) {
+                    const f32x4 sv = acc[ib][jb] * inv1 * inv2[jb];
+                    f32x4 e;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(sv[r]);
+                    zr += e;
+                    zc[jb] += f32x2{e[0], e[1]};
+                    zc[jb] += f32x2{e[2], e[3]};
+                    f32x4 m2;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) m2[r] = fmaxf(t2v[ib][jb][r], thr2[jb]);
+                    b2[jb] = __builtin_elementwise_fma(f32x2{m2[0], m2[1]}, f32x2{sv[0], sv[1]}, b2[jb]);
+                    b2[jb] = __builtin_elementwise_fma(f32x2{m2[2], m2[3]}, f32x2{sv[2], sv[3]}, b2[jb]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) b1[r] = fmaf(fmaxf(t1v[ib][r][jb], thr1[r]), sv[r], b1[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rl = wm * 32 + ib * 16 + 4 * g + r;
+                    const float z = row16_sum(zr[r]), b = row16_sum(b1[r]);
+                    if (c == 0) { sP[wn * 128 + rl] = z; sP[256 + wn * 128 + rl] = b * (LN2 * __builtin_amdgcn_rcpf(sSt[rl][1])); }      // (the sum re-read: a register less per row)
+                }
+            }
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) {
+                float z = (zc[jb][0] + zc[jb][1]) - badr, b = b2[jb][0] + b2[jb][1];
+                z += __shfl_xor(z, 16, 64); z += __shfl_xor(z, 32, 64);
+                b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+                if (g == 0) {
+                    const int cl = wn * 64 + 4 * c + jb;
+                    sP[512 + wm * 128 + cl] = z; sP[1024 + wm * 128 + cl] = b * (LN2 * __builtin_amdgcn_rcpf(sSt[128 + cl][1]));
+                }
             }
         }
         if (it + 1 < n_tiles && !(dbg & 1)) prefetch(it + 1);
@@ -783,36 +808,43 @@ __global__ __launch_bounds__(768) void cv_fwd_rows_kernel(CvTileParams q) {
         const CvpTile t = rtile(beg + kb + it * nbx);
         const f32x4* sSt = (const f32x4*)(smem + CVP_STAT_OFF + (it & 1) * 4096);
         float* sP = (float*)(smem + CVP_PART_OFF + (it & 1) * 6144);
-        float inv2[4];
-        bool cok[4];
+        // (the slimmed epilogue of cv_fwd_persist_kernel, one direction: log2-domain scores, the division by the teacher row sum and ln 2 applied to
+        //  the row's B sum, no per-entry bounds tests)
+        {
+            constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+            float inv2[4], badc = 0.f;      // columns past hw: inverse norm 0 -> s' = 0, e = 1 exactly, counted out of the rows' Z below
 #pragma unroll
-        for (int jb = 0; jb < 4; ++jb) {
-            const int cl = wn * 64 + 4 * c + jb;
-            inv2[jb] = sSt[128 + cl][0];
-            cok[jb] = t.tn * 128 + cl < hw;
-        }
+            for (int jb = 0; jb < 4; ++jb) {
+                const int cl = wn * 64 + 4 * c + jb;
+                const bool ok = t.tn * 128 + cl < hw;
+                inv2[jb] = ok ? sSt[128 + cl][0] : 0.f;
+                badc += ok ? 0.f : 1.f;
+            }
 #pragma unroll
-        for (int ib = 0; ib < 2; ++ib)
+            for (int ib = 0; ib < 2; ++ib) {
+                // (rows past the kept count are padded copies of a kept row: finite, never read by the finalize pass)
+                f32x4 inv1, thr1, zr = {-badc, -badc, -badc, -badc}, b1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int rl = wm * 32 + ib * 16 + 4 * g + r;
-                const f32x4 v = sSt[rl];
-                const float inv1 = v[0], ir1 = 1.0f / v[1];
-                const bool rok = true;      // (rows past the kept count are padded copies of a kept row: finite, never read by the finalize pass)
-                float zr = 0.f, b1 = 0.f;
+                for (int r = 0; r < 4; ++r) {
+                    const f32x4 v = sSt[wm * 32 + ib * 16 + 4 * g + r];
+                    inv1[r] = v[0] * LOG2E; thr1[r] = CV_EPS * v[1];
+                }
 #pragma unroll
                 for (int jb = 0; jb < 4; ++jb) {
-                    const bool ok = rok && cok[jb];
-                    const float sv = acc[ib][jb][r] * inv1 * inv2[jb];
-                    const float e = ok ? __expf(sv) : 0.f;
-                    const float sm = ok ? sv : 0.f;
-                    zr += e;
-                    b1 = fmaf(fmaxf(t1v[ib][r][jb] * ir1, CV_EPS), sm, b1);
+                    const f32x4 sv = acc[ib][jb] * inv1 * inv2[jb];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) zr[r] += __builtin_amdgcn_exp2f(sv[r]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) b1[r] = fmaf(fmaxf(t1v[ib][r][jb], thr1[r]), sv[r], b1[r]);
                 }
-                zr = row16_sum(zr);
-                b1 = row16_sum(b1);
-                if (c == 0) { sP[wn * 128 + rl] = zr; sP[256 + wn * 128 + rl] = b1; }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rl = wm * 32 + ib * 16 + 4 * g + r;
+                    const float z = row16_sum(zr[r]), b = row16_sum(b1[r]);
+                    if (c == 0) { sP[wn * 128 + rl] = z; sP[256 + wn * 128 + rl] = b * (LN2 * __builtin_amdgcn_rcpf(sSt[rl][1])); }
+                }
             }
+        }
         if (it + 1 < n_tiles && !(dbg & 1)) prefetch(it + 1);
     }
     cvp_barrier();

@@ -107,6 +107,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* dy, const T* x, c
     const TD* dr = dy + (long)row * ldd;
     f32x4 xh[NV], g[NV];
     float s1 = 0.f, s2 = 0.f;
+    unsigned mb = 0u, nsat = 0u, nlow = 0u;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = (lane + 64 * i) * 4;
@@ -119,12 +120,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD* dy, const T* x, c
                 s1 += g[i][k];
                 s2 += g[i][k] * xh[i][k];
             }
+            // an fp16 dy is the saturating C store of the GEMM that produced it (gemm epilogue f16_sat: no counter there): an element AT the clamp
+            // — or Inf / NaN — is counted here, by the consumer, so that range_report()'s "saturated" covers the dX products too
+            if (sizeof(TD) == 2 && sizeof(T) == 4 && range && live) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) nsat += !(fabsf(dv[k]) < 65504.0f);
+            }
         }
     }
     s1 = wave_sum(s1) / (float)D;
     s2 = wave_sum(s2) / (float)D;
     T* or_ = dx + (long)row * ldx;
-    unsigned mb = 0u, nsat = 0u, nlow = 0u;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = (lane + 64 * i) * 4;

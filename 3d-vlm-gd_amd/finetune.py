@@ -173,7 +173,10 @@ class FinetuneGD(nn.Module):
     def range_report(self, reset=True):
         """{'saturated': n, 'below_normal': n} since the last reset (ONE host read: call it every N steps, not every step).  A healthy run
         reports saturated == 0; below_normal counts gradient entries more than 2^17 under their block's largest one, which a TF32 tensor core
-        would still have carried at full precision (the range contract)."""
+        would still have carried at full precision (the range contract).  What is counted: every scaled fp16 cast (cast kernels, the
+        LayerNorm backward's fp16 copy) and the two dX products per block that leave their GEMM epilogue as saturating fp16 and are read by a
+        LayerNorm backward (counted there: entries at the clamp).  The attention output gradient and the GELU-gated MLP gradient are saturating fp16
+        stores too, consumed by MFMA kernels only: those are not counted."""
         if getattr(self, "_range", None) is None:
             return {"saturated": 0, "below_normal": 0}
         v = self._range.view(2, 64).sum(1).tolist()
@@ -454,4 +457,7 @@ class FinetuneGD(nn.Module):
         self.model.release_trainables()
         terms = {"ap_loss": ap.detach(), "depth_loss": depth_loss.detach(), "intra_depth_loss": intra.detach(),
                  "kl_loss": kl.detach()}
+        if counts is not None:      # the reported terms of an empty pair are the reference's zeros too (its KL term alone is a non-zero constant)
+            keep = counts.to(per_pair.device) > 0
+            terms = {k: torch.where(keep, v, torch.zeros_like(v)) for k, v in terms.items()}
         return per_pair.mean(), terms

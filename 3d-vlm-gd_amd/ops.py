@@ -592,7 +592,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, dyscale=1.0, dres2=None, 
         dx = torch.empty_like(x)
         dx16 = torch.empty(M, D, dtype=torch.float16, device=x.device) if cast_scale is not None else None
         slots = _slots(x.device) if want_amax else None
-        rng = _RANGE if (dx16 is not None and _RANGE is not None and _RANGE.device == x.device) else None
+        rng = _RANGE if ((dx16 is not None or dy.dtype == torch.float16) and _RANGE is not None and _RANGE.device == x.device) else None      # (an fp16 dy: its saturated entries are counted here, its producer's epilogue has no counter)
         check(lib().gd_layernorm_bwd_ex(ptr(dy), dtype_code(dy), ptr(dy_scale), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dres2), ptr(dx),
                                         ptr(dx16), ptr(cast_scale), ptr(slots), ptr(rng), M, D, dy.stride(0), x.stride(0), float(dyscale), stream()),
               "gd_layernorm_bwd_ex")

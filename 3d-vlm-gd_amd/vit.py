@@ -386,6 +386,9 @@ class _BlockFn(torch.autograd.Function):
             g_aq, g_av = gat[:r], gat[r:]
         if direct:       # already in the flat buffer (LoRA-B: GDViT.finish_trainable_grads transposes the stash once per step)
             g_aq = g_bq = g_av = g_bv = g_down = g_up = None
+            if "on_grads" in tw:      # this block's LoRA-A / adapter slices of the flat gradient buffer are final: their exchange may start under the blocks below
+                hook, bi, spans = tw["on_grads"]
+                hook(bi, spans)
         if not ctx.needs_input_grad[0]:   # first trainable block: nothing below it learns, skip dX (one GEMM + one LN backward)
             return None, None, None, None, g_aq, g_bq, g_av, g_bv, g_down, g_up
         if ctx.has_lora:
@@ -486,6 +489,8 @@ class _TapFn(torch.autograd.Function):
             mean, rstd = deferred_stats(ctx.defer)
         else:
             x2, wf, mean, rstd = ctx.saved_tensors
+        if g_next is not None:
+            ops.amax_take(g_next)      # the next block's LN1 backward registered a scale for this tensor; its consumer here (ln_bwd's dres) takes fp32: drop the entry, it pins the tensor
         res = [g.reshape(x2.shape).contiguous().to(x2.dtype) for g in (g_next, g_raw) if g is not None]
         if g_norm is None:
             dx = None if not res else (res[0] if len(res) == 1 else res[0] + res[1])
@@ -614,6 +619,7 @@ class GDViT(nn.Module):
         T = self.dtype
         lo = []
         self._direct = None
+        ops.amax_clear()        # (tf32h: scales registered for gradients of an earlier step that nobody consumed)
         for blk in self.blocks:
             inner, lora, adapter = _unwrap(blk)
             inner._tw = None
@@ -643,6 +649,11 @@ class GDViT(nn.Module):
                 gbt = torch.zeros(L, 2 * r, 2 * D, dtype=torch.float32, device=fp.device)       # t^T [dq | dv] stash
                 for i in range(L):
                     extra[i] = {"g_at": gA[i], "g_bt": gbt[i], "g_down": gAd[i, 0].view(bott, D), "g_up": gAd[i, 1].view(D, bott)}
+                hook = getattr(self, "block_grad_hook", None)      # data parallelism (dp.OverlappedGradReducer): block i's slices are final when its backward returns
+                if hook is not None:
+                    nA, nAd = 2 * r * D, 2 * bott * D
+                    for i in range(L):
+                        extra[i]["on_grads"] = (hook, i, [(sp["A"] + i * nA, sp["A"] + (i + 1) * nA), (sp["ad"] + i * nAd, sp["ad"] + (i + 1) * nAd)])
                 self._direct = {"gbt": gbt, "gB": fg[sp["B"]:sp["B"] + L * 2 * D * r].view(L, 2, D, r), "r": r, "D": D}
             else:
                 at = torch.stack([torch.cat([l.linear_a_q.weight, l.linear_a_v.weight], 0) for _, l, _ in lo]).float()   # [L, 2r, D]
@@ -660,9 +671,11 @@ class GDViT(nn.Module):
                     extra[i].update(zip(("down_w3", "up_w3", "down_tw3", "up_tw3"), pack))
                 # ... and the LoRA factors every block would otherwise format on its own (two launches instead of 2 L: A for the forward's rank
                 # projection, the (dq, dv) columns of B for the backward's)
-                for i, pack in enumerate(zip(w3(at.float()), w3(bt_qv.float()))):
-                    extra[i].update(zip(("at_w3", "bt_qv_w3"), pack))
-        ops.amax_clear()        # (tf32h: scales registered for gradients of an earlier step that nobody consumed)
+                for i, w in enumerate(w3(at.float())):
+                    extra[i]["at_w3"] = w
+                if self.opfmt == "h":      # (only the fp16-operand LoRA backward reads a formatted B: the tf32x one takes the plain tensors)
+                    for i, w in enumerate(w3(bt_qv.float())):
+                        extra[i]["bt_qv_w3"] = w
         for i, (inner, _, _) in enumerate(lo):
             inner._tw = {"dtype": T, "at": at[i], "bt": bt[i], "at_T": at_T[i], "bt_T": bt_T[i], "bt_qv": bt_qv[i], "down_T": down_T[i],
                          "up_T": up_T[i], "down_tT": down_tT[i], "up_tT": up_tT[i], **extra[i]}

@@ -128,15 +128,22 @@ class Job:
     """One engine + its resident synthetic batches + the gradient exchange: `step(i)` is the timed unit."""
 
     def __init__(self, backbone, variant, dtype, geometry, P, img, N, dev, rank, world, vit_kwargs=None, weights=None,
-                 exchange="torch"):
+                 exchange="torch", build=None):
+        """build: () -> FinetuneGD (e.g. gd_amd.config.build_engine of one of the reference's yaml presets) instead of the /14 constructor; img is
+        then the teacher-side image size, an int or (h, w), and the cost grid is img // eng.resize_patch_size per axis."""
         from gd_amd import dp
         from gd_amd.finetune import FinetuneGD
         from gd_amd.synthetic import synthetic_batch
-        self.hw = (img // PATCH) ** 2
+        h, w = (img, img) if isinstance(img, int) else img
         self.P, self.world, self.geometry, self.dtype = P, world, geometry, dtype
-        self.eng = FinetuneGD(r=4, backbone=backbone, patch_size=PATCH, img_size=img, variant=variant, geometry=geometry,
-                              dtype=dtype, teacher_patch=PATCH, lora_b_std=1e-3,
-                              vit_kwargs=dict(init_values=1.0) if vit_kwargs is None else vit_kwargs, **(weights or {})).to(dev)
+        if build is not None:
+            self.eng = build().to(dev)
+        else:
+            self.eng = FinetuneGD(r=4, backbone=backbone, patch_size=PATCH, img_size=img, variant=variant, geometry=geometry,
+                                  dtype=dtype, teacher_patch=PATCH, lora_b_std=1e-3,
+                                  vit_kwargs=dict(init_values=1.0) if vit_kwargs is None else vit_kwargs, **(weights or {})).to(dev)
+        tp = self.eng.resize_patch_size if build is not None else PATCH
+        self.hw = (h // tp) * (w // tp)
         flat = self.eng.configure_optimizers()
         # gradient exchange in two chunks: refine_conv + depth head from grad hooks (under the ViT backward), the rest after it
         early = list(self.eng.refine_conv.parameters()) + list(self.eng.depth_diff_head.parameters())
@@ -144,13 +151,14 @@ class Job:
             self.reducer = dp.DirectGradReducer(flat["g"], dp.RcclComm(rank, world))
         else:
             self.reducer = dp.OverlappedGradReducer(self.eng.trainable_parameters(), flat["views"], flat["g"], early, world)
+            self.reducer.model = self.eng.model      # per-block late chunks: the model reports each block's finished weight-gradient slices
         self.reducer.attach()
         self.flat = flat
         # a few distinct synthetic batches per rank (seed 1234 + 1000*rank + i), resident on the device
         # teacher targets as the per-pair cache holds them: cost maps with 16-byte rows + the teacher-row statistics
         from gd_amd.teacher_cache import cache_cost_targets
-        self.batches = [cache_cost_targets(synthetic_batch(P, img, img, N, self.hw, dev, seed=1234 + 1000 * rank + i,
-                                                           teacher_patch=PATCH)) for i in range(2)]
+        self.batches = [cache_cost_targets(synthetic_batch(P, h, w, N, self.hw, dev, seed=1234 + 1000 * rank + i,
+                                                           teacher_patch=tp)) for i in range(2)]
 
     def step(self, i):
         return self.eng.fit_step(self.batches[i % len(self.batches)], self.reducer)[0]
@@ -242,13 +250,15 @@ def main():
     eng, hw = job.eng, job.hw
     prof = None if args.no_kernel_events else ops.GemmProfiler()
     if args.dtype == "tf32h":
-        eng_rr = job.eng.range_report()              # reset: the report below covers the warm-up + timed steps of this run
+        job.eng.range_report()                       # reset: the report below covers the warm-up + timed steps of this run
     dt, loss = job.timed(args.steps, args.warmup, dev, prof)
     pairs_per_s = P * world * args.steps / dt
     # tf32h: how many scaled fp16 gradient operands saturated / fell below fp16's normal range over these steps (device counters, ONE host read here)
     fp16_range = dict(job.eng.range_report(), steps=args.steps + args.warmup,
-                      what="scaled fp16 gradient casts of the tf32h engine: elements clamped at +-65504 / elements below 2^-14 after the block's "
-                           "power-of-two scale (DESIGN.md 4, range contract); 0 saturated = no gradient operand lost its top") if args.dtype == "tf32h" else None
+                      what="scaled fp16 gradient operands of the tf32h engine: elements clamped at +-65504 / elements below 2^-14 after the block's "
+                           "power-of-two scale (DESIGN.md 4, range contract).  Counted: the cast kernels, the LayerNorm backward's fp16 copy, and the two "
+                           "dX products per block that leave their GEMM as saturating fp16 (counted where the LayerNorm backward reads them); NOT counted: "
+                           "the attention output gradient and the GELU-gated gradient, fp16 C stores consumed by MFMA kernels only") if args.dtype == "tf32h" else None
 
     comm = comm_report(job, args, dev, dt) if world > 1 else None
 
@@ -473,45 +483,52 @@ def comm_report(job, args, dev, dt):
            "allreduce_ms_late_chunk": round(late_ms, 3), "late_chunk_MB": round(n_late * 4 / 1e6, 2),
            "ms_per_step_without_exchange": round(dt0 / args.steps * 1e3, 3),
            "exposed_comm_frac": round(max(0.0, (dt - dt0) / dt), 4)}
-    # the same ranks, inputs and steps with (a) the OTHER exchange mode and (b) the other CU reservation: what the first multi-GPU run should look at
+    # the same ranks, inputs and steps with (a) the OTHER exchange mode and (b) the other CU reservation: what the first multi-GPU run should look at.
+    # Every rank must take the same branch (the timed steps hold barriers and all-reduces): a variant runs only if EVERY rank could set it up
+    # (`all_ok`), a communicator built for a variant is closed again, and a failure inside the timed steps is not caught — ranks that diverged
+    # there cannot be brought back in step, the launcher's timeout is the right outcome.
+    def all_ok(flag):
+        return dp.max_over_ranks(0.0 if flag else 1.0, dev) == 0.0
+
     variants = {}
     flat, eng, keep = job.flat, job.eng, job.reducer
+    keep.detach()
+    alt_red, alt_comm, err = None, None, None
     try:
-        keep.detach()
         if args.exchange == "torch":
-            job.reducer = dp.DirectGradReducer(flat["g"], dp.RcclComm(dist.get_rank(), world))
+            alt_comm = dp.RcclComm(dist.get_rank(), world)
+            alt_red = dp.DirectGradReducer(flat["g"], alt_comm)
         else:
             early = list(eng.refine_conv.parameters()) + list(eng.depth_diff_head.parameters())
-            job.reducer = dp.OverlappedGradReducer(eng.trainable_parameters(), flat["views"], flat["g"], early, world)
+            alt_red = dp.OverlappedGradReducer(eng.trainable_parameters(), flat["views"], flat["g"], early, world)
+            alt_red.model = eng.model
+    except Exception as e:       # e.g. two ranks sharing one GPU: no RCCL communicator
+        err = repr(e)[:200]
+    if all_ok(err is None):
+        job.reducer = alt_red
         job.reducer.attach()
         dtx, _ = job.timed(args.steps, 1, dev)
+        job.reducer.detach()
         other = "direct" if args.exchange == "torch" else "torch"
         variants["exchange_" + other] = {"ms_per_step": round(dtx / args.steps * 1e3, 3), "exposed_comm_frac": round(max(0.0, (dtx - dt0) / dtx), 4)}
-    except Exception as e:       # a variant that cannot run (e.g. two ranks sharing one GPU: no RCCL communicator) must not cost the headline line
-        variants["exchange_error"] = repr(e)[:200]
-    finally:
-        try:
-            job.reducer.detach()
-        except Exception:
-            pass
-        job.reducer = keep
-        job.reducer.world = world
-        job.reducer.attach()
+    else:
+        variants["exchange_error"] = err or "another rank could not set the variant up"
+    if alt_comm is not None:
+        alt_comm.close()
+    job.reducer = keep
+    job.reducer.world = world
+    job.reducer.attach()
     alt = 0 if args.reserve_cus else 8
-    try:
-        dp.reserve_cus_for_collectives(alt)
-        dtr, _ = job.timed(args.steps, 1, dev)
-        job.reducer.world = 1
-        job.reducer.detach()
-        dtr0, _ = job.timed(args.steps, 1, dev)
-        variants[f"reserve_cus_{alt}"] = {"ms_per_step": round(dtr / args.steps * 1e3, 3), "ms_per_step_without_exchange": round(dtr0 / args.steps * 1e3, 3),
-                                          "exposed_comm_frac": round(max(0.0, (dtr - dtr0) / dtr), 4)}
-    except Exception as e:
-        variants["reserve_error"] = repr(e)[:200]
-    finally:
-        job.reducer.world = world
-        job.reducer.attach()
-        dp.reserve_cus_for_collectives(args.reserve_cus)
+    dp.reserve_cus_for_collectives(alt)
+    dtr, _ = job.timed(args.steps, 1, dev)
+    job.reducer.world = 1
+    job.reducer.detach()
+    dtr0, _ = job.timed(args.steps, 1, dev)
+    job.reducer.world = world
+    job.reducer.attach()
+    dp.reserve_cus_for_collectives(args.reserve_cus)
+    variants[f"reserve_cus_{alt}"] = {"ms_per_step": round(dtr / args.steps * 1e3, 3), "ms_per_step_without_exchange": round(dtr0 / args.steps * 1e3, 3),
+                                      "exposed_comm_frac": round(max(0.0, (dtr - dtr0) / dtr), 4)}
     out["variants"] = variants
     return out
 
@@ -593,6 +610,11 @@ def parity_and_cpu_baseline(job, args, ns=4):
     return par, base
 
 
+def _preset_engine(name, dtype):
+    from gd_amd import config
+    return config.build_engine(config.preset(name), geometry="reference", dtype=dtype, lora_b_std=1e-3)[0]
+
+
 def companion_runs(args, variant, backbone, weights, dev, rank, world):
     """Driver-observed runs beside the headline (same process, after it): the f32 engine — the reference's arithmetic precision —
     on the SAME workload with the SAME --steps / --warmup, its own GEMM roofline and its own parity check against the CPU oracle;
@@ -602,16 +624,19 @@ def companion_runs(args, variant, backbone, weights, dev, rank, world):
     out = {}
     P, img, N = args.pairs_per_gpu, args.img, args.keypoints
 
-    def run(bb, var, dtype, geometry, pairs, vit_kwargs=None, steps=2, warmup=1, prof=False, wts=None, parity=False):
-        job = Job(bb, var, dtype, geometry, pairs, img, N, dev, rank, world, vit_kwargs=vit_kwargs, weights=wts)
+    def run(bb, var, dtype, geometry, pairs, vit_kwargs=None, steps=2, warmup=1, prof=False, wts=None, parity=False, build=None, size=None):
+        job = Job(bb, var, dtype, geometry, pairs, size or img, N, dev, rank, world, vit_kwargs=vit_kwargs, weights=wts, build=build)
         pr = ops.GemmProfiler() if prof else None
         dt, loss = job.timed(steps, warmup, dev, pr)
-        fl = flops_per_pair(job.eng, job.hw, geometry)
         pps = pairs * world * steps / dt
         rec = {"value": round(pps, 3), "unit": "image-pairs/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
                "warmup": warmup, "dtype": dtype, "pairs_per_gpu": pairs, "backbone": bb, "variant": var, "geometry": geometry,
-               "loss": round(float(loss.detach()), 6),
-               "vit_frac_of_mfma_peak": round(pps / world * fl / 1e12 / PEAK_TFLOPS[dtype], 4)}
+               "loss": round(float(loss.detach()), 6)}
+        if build is None:      # (the FLOP model below is written for the /14 constructor's token counts)
+            rec["vit_frac_of_mfma_peak"] = round(pps / world * flops_per_pair(job.eng, job.hw, geometry) / 1e12 / PEAK_TFLOPS[dtype], 4)
+        else:
+            rec["image_hw"] = list(size) if not isinstance(size, int) else [size, size]
+            rec["patch"] = job.eng.patch_size
         if pr is not None:
             rec["roofline"] = gemm_roofline(pr, dtype, dt, steps)
         if parity and not args.no_cpu_baseline:
@@ -638,7 +663,11 @@ def companion_runs(args, variant, backbone, weights, dev, rank, world):
             "vit_large_vggt": run("vit_large", "vggt", args.dtype, "shared", 16, parity=1),
             "prenorm_vit_large_all_losses": run("vit_large", "vggt", args.dtype, "shared", 16,
                                                 vit_kwargs=dict(pre_norm=True, ln_eps=1e-5, pos_interp="timm"), parity=1),
-            "reference_geometry": run(backbone, variant, args.dtype, "reference", 8, wts=weights, parity=1)}
+            "reference_geometry": run(backbone, variant, args.dtype, "reference", 8, wts=weights, parity=1),
+            # the reference's OWN backbone, from its yaml preset with no override but the engine dtype (config.preset: ViT-B/16 with a pre-norm, CLIP
+            # mean / std, conv without bias), in its own token geometry: 384 x 512 images -> a 24 x 32 cost grid and 4 801-token keypoint forwards
+            "reference_backbone": run("ViT-B-16", "mast3r", args.dtype, "reference", 8, parity=1, size=(384, 512),
+                                      build=lambda: _preset_engine("finetune_timm_mast3r_objaverse", args.dtype))}
     return out
 
 

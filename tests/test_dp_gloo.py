@@ -86,6 +86,82 @@ def test_overlapped_grad_reducer_world2():
         assert out[r][5] == [(0, 20), (39, 56)]      # flat layout 12 | 5+3 pad | [12 | 7] +1 pad | 16; the late ranges are the complement
 
 
+def _worker_blocks(rank, world, port, out):
+    """The N-chunk late exchange: a stand-in model lays its flat gradient buffer out as GDViT.prepare_trainables(flat) does — [L LoRA-A tensors |
+    L LoRA-B tensors | an early (loss-side) tensor | L adapter tensors] — and its "backward" finishes the blocks from the last to the first,
+    calling the hook the reducer installed after each block exactly as vit._BlockFn.backward does; the LoRA-B slices only become final after the
+    backward (finish_trainable_grads).  The result must equal ONE mean all-reduce of the whole buffer, and every element must be exchanged once."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import gd_amd  # noqa: F401
+    from gd_amd import dp
+    import torch.distributed as dist
+    dp.init_from_env(backend="gloo")
+    L, nA, nB, nE, nAd = 3, 8, 12, 20, 16
+    oA, oB, oE, oAd = 0, L * nA, L * (nA + nB), L * (nA + nB) + nE
+    n = oAd + L * nAd
+    flat_g = torch.zeros(n)
+    pE = torch.nn.Parameter(torch.zeros(nE))
+    vE = flat_g[oE:oE + nE]
+    # (the A / B / adapter tensors only matter as spans here: the engine writes their gradients into the flat buffer itself)
+    dummy = [torch.nn.Parameter(torch.zeros(1)) for _ in range(3)]
+    views = [flat_g[oA:oA + L * nA], flat_g[oB:oB + L * nB], vE, flat_g[oAd:oAd + L * nAd]]
+    params = [dummy[0], dummy[1], pE, dummy[2]]
+
+    class Model:
+        block_grad_hook = None
+    model = Model()
+    red = dp.OverlappedGradReducer(params, views, flat_g, [pE], world)
+    assert red.late == [(0, oE), (oAd, n)]
+    red.attach(model=model)
+    assert model.block_grad_hook is not None
+    truth = torch.arange(n, dtype=torch.float32) * (rank + 1)          # this rank's gradient of every element
+    seen = torch.zeros(n)
+    real_all_reduce = dist.all_reduce
+
+    def counting_all_reduce(t, *a, **k):                                 # every element of the flat buffer goes through exactly one collective
+        if t.untyped_storage().data_ptr() == flat_g.untyped_storage().data_ptr():
+            seen[t.storage_offset():t.storage_offset() + t.numel()] += 1
+        return real_all_reduce(t, *a, **k)
+    dist.all_reduce = counting_all_reduce
+    # ---- the "backward": the loss-side tensor first (its hook fires), then the blocks from the top down
+    (pE * truth[oE:oE + nE]).sum().backward()
+    for i in reversed(range(L)):
+        flat_g[oA + i * nA:oA + (i + 1) * nA] = truth[oA + i * nA:oA + (i + 1) * nA]
+        flat_g[oAd + i * nAd:oAd + (i + 1) * nAd] = truth[oAd + i * nAd:oAd + (i + 1) * nAd]
+        model.block_grad_hook(i, [(oA + i * nA, oA + (i + 1) * nA), (oAd + i * nAd, oAd + (i + 1) * nAd)])
+    in_flight = len(red.works)
+    flat_g[oB:oB + L * nB] = truth[oB:oB + L * nB]                      # finish_trainable_grads: LoRA-B lands after the backward
+    left = red.remaining_late()
+    red.wait_early()
+    vE.copy_(pE.grad)                                                    # the gather of the hook-reduced tensor
+    red.start()
+    scale = red.finish()
+    seen[oE:oE + nE] += 1                                                # (reduced as p.grad, not through the flat buffer)
+    red.detach()
+    dist.all_reduce = real_all_reduce
+    out[rank] = ((flat_g * scale).tolist(), in_flight, left, seen.tolist(), model.block_grad_hook is None, red.done)
+    dist.destroy_process_group()
+
+
+def test_per_block_late_chunks_world2():
+    world, port = 2, 29617
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_blocks, args=(world, port, out), nprocs=world, join=True)
+    L, nA, nB, nE, nAd = 3, 8, 12, 20, 16
+    n = L * (nA + nB) + nE + L * nAd
+    want = (torch.arange(n, dtype=torch.float32) * 1.5).tolist()
+    for r in range(world):
+        vals, in_flight, left, seen, unhooked, done = out[r]
+        assert vals == want
+        assert in_flight == 1 + 2 * L                                    # the hook's all-reduce + two ranges per block, all launched before the backward ended
+        assert left == [(L * nA, L * (nA + nB))]                         # only the LoRA-B region is left for start()
+        assert seen == [1.0] * n
+        assert unhooked and done == []
+
+
 class _GlooComm:
     """Stand-in for dp.RcclComm on CPU: the same two members (`world`, `all_reduce_(flat, algo)`), with algo 1 spelled the way
     gd_flat_allreduce spells it — reduce-scatter onto the rank's n / world slice, then all-gather in place."""
