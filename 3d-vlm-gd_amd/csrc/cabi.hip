@@ -70,3 +70,28 @@ extern "C" int gd_debug_get(const char* name) {
     return -1;
 }
 extern "C" int gd_abi_version(void) { return GD_ABI_VERSION; }
+
+extern "C" int gd_stream_create_cu_mask(int cus, void** stream_out) {
+    GD_REQUIRE(stream_out != nullptr && cus > 0, "gd_stream_create_cu_mask: cus = %d", cus);
+    const int ncu = gd_knobs().ncu_dev;
+    GD_REQUIRE(cus < ncu, "gd_stream_create_cu_mask: %d of %d compute units", cus, ncu);
+    uint32_t mask[32] = {};
+    const int words = (ncu + 31) / 32;
+    GD_REQUIRE(words <= 32, "gd_stream_create_cu_mask: %d compute units", ncu);
+    for (int i = 0; i < cus; ++i) mask[i >> 5] |= 1u << (i & 31);
+    hipStream_t s = nullptr;
+    const hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask);
+    if (e != hipSuccess) {
+        gd_set_error("gd_stream_create_cu_mask: hipExtStreamCreateWithCUMask: %s", hipGetErrorString(e));
+        return -1;
+    }
+    *stream_out = (void*)s;
+    return 0;
+}
+extern "C" int gd_stream_destroy(void* stream) {
+    if (stream && hipStreamDestroy((hipStream_t)stream) != hipSuccess) {
+        gd_set_error("gd_stream_destroy: hipStreamDestroy failed");
+        return -1;
+    }
+    return 0;
+}

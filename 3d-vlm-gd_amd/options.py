@@ -15,6 +15,14 @@ _DEFS = {
     "h16_dy": ("GD_H16_DY", 1),                  # tf32h: the two dX GEMMs that feed a LayerNorm backward write fp16 in the block's scaled domain (0: fp32)
     "tap_norm_fused": ("GD_TAP_NORM_FUSED", 1),  # the taps' final LayerNorm applied inside the keypoint gather from the next block's row statistics (0: a LayerNorm pass per tap)
     "direct_grads": ("GD_DIRECT_GRADS", 1),      # fit_step: block weight gradients accumulate straight into the flat gradient buffer
+    # the blocks' weight-gradient contractions (adapter up / down, LoRA-A: streams over the activations that nothing downstream in the backward reads) on
+    # a SECOND stream, with `wgrad_reserve_cus` compute units kept free of the persistent kernels during the backward (csrc/gd_knobs.h reserve_cus).
+    # 0 (default): off; 1: a plain second stream; 2: a stream confined to the reserved CUs (gd_stream_create_cu_mask).  Needs direct_grads.
+    # MEASURED, round 5 (tools/ab_step.py, profiles/r05_wgrad_stream_ab.txt): 1 gains 0.2 ms of 58 (the side kernels' 768 blocks take every CU and the
+    # one-block-per-CU GEMM behind them waits: the streams mostly take turns); 2 LOSES 12 - 31 ms — the side kernels are not HBM-bound per CU, their time
+    # scales with 256 / k, and CU-time handed to them is CU-time the dX GEMMs lose: partitioning conserves work, it does not create throughput.
+    "wgrad_stream": ("GD_WGRAD_STREAM", 0),
+    "wgrad_reserve_cus": ("GD_WGRAD_RESERVE_CUS", 8),
 }
 _VALUES = {k: int(os.environ.get(env, str(d))) for k, (env, d) in _DEFS.items()}
 

@@ -20,6 +20,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+import contextlib
+
 from . import ops
 from .options import option
 from .model import Adapter, BlockWithAdapter, _LoRA_qkv  # noqa: F401
@@ -158,6 +160,22 @@ def _unwrap(blk):
     return blk, lora, adapter
 
 
+@contextlib.contextmanager
+def _wgrad_side(wg, *keep):
+    """Weight-gradient work of a block on the engine's second stream (FinetuneGD.backward arms `wg["stream"]`; None: stay on the current stream).
+    The side stream first waits for everything the current stream has been given so far (the operands are then complete); `keep` holds the operands
+    until the backward's closing wait — autograd drops its references when the node returns, and the caching allocator would hand a freed block to
+    the next allocation of the MAIN stream while the side stream is still reading it."""
+    s = None if wg is None else wg["stream"]
+    if s is None:
+        yield False
+        return
+    s.wait_stream(torch.cuda.current_stream())
+    wg["keep"].extend(t for t in keep if t is not None)
+    with torch.cuda.stream(s):
+        yield True
+
+
 class _BlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, plan, B, Nt, a_q, b_q, a_v, b_v, down, up):
@@ -266,6 +284,7 @@ class _BlockFn(torch.autograd.Function):
         bott = down.shape[0] if ctx.has_ad else 0
         r2 = at.shape[0] if ctx.has_lora else 0
         direct = tw is not None and "g_at" in tw       # weight gradients accumulate straight into the flat gradient buffer
+        wgs = tw.get("wgrad") if direct else None      # ... and may then be computed on the second stream (_wgrad_side)
         if direct:
             z_up, z_down, z_bt, z_at = tw["g_up"], tw["g_down"], tw["g_bt"], tw["g_at"]
         else:
@@ -286,8 +305,9 @@ class _BlockFn(torch.autograd.Function):
                 w_dt = tw["down_tw3"] if tw is not None and "down_tw3" in tw else _opw(down_tT, fmt)
                 dx2, dhpa, dx2a = ops.adapter_fused_h(dout.view(-1, D), w_ut, w_dt, gate_src=hd, in_scale=sc[0:1], alpha_dev=sc[1:2], copy_scale=sc[0:1],
                                                       want_copy=True)
-                g_up = ops.gemm_tn(dout.view(-1, D), hd, out=z_up, alpha_dev=sc[1:2])             # [D, 64]  (dOut rounded to fp16 under s inside the kernel)
-                g_down = ops.gemm_tn(dhpa, x2, out=z_down, alpha_dev=sc[1:2])                     # [64, D]
+                with _wgrad_side(wgs, dout, hd, dhpa, x2, sc):      # (second stream when armed: under the fc2 / fc1 backward GEMMs)
+                    g_up = ops.gemm_tn(dout.view(-1, D), hd, out=z_up, alpha_dev=sc[1:2])             # [D, 64]  (dOut rounded to fp16 under s inside the kernel)
+                    g_down = ops.gemm_tn(dhpa, x2, out=z_down, alpha_dev=sc[1:2])                     # [64, D]
             elif plan["x3"]:
                 w_ut = tw["up_tw3"] if tw is not None and "up_tw3" in tw else _opw(up_tT, fmt)
                 w_dt = tw["down_tw3"] if tw is not None and "down_tw3" in tw else _opw(down_tT, fmt)
@@ -306,12 +326,14 @@ class _BlockFn(torch.autograd.Function):
                 pass      # (weight gradients taken above)
             elif fmt == "h" and ctx.hd16 is not None and x2.dtype == torch.float16:
                 # the weight gradients on the fp16 MFMA kernel from the operands at hand: (dout s)^T hd and (dhp s)^T x2, times 1/s on the device
-                g_up = ops.gemm_tn(douta, ctx.hd16, out=z_up, alpha_dev=sc[1:2])                  # [D, 64]
-                g_down = ops.gemm_tn(dhpa, x2, out=z_down, alpha_dev=sc[1:2])                     # [64, D]
+                with _wgrad_side(wgs, douta, ctx.hd16, dhpa, x2, sc):
+                    g_up = ops.gemm_tn(douta, ctx.hd16, out=z_up, alpha_dev=sc[1:2])                  # [D, 64]
+                    g_down = ops.gemm_tn(dhpa, x2, out=z_down, alpha_dev=sc[1:2])                     # [64, D]
                 del douta, dhpa
             else:
-                g_up = ops.gemm_tn(dout, hd, out=z_up)                                            # [D, 64]
-                g_down = ops.gemm_tn(dhp, x2, out=z_down)                                         # [64, D]
+                with _wgrad_side(wgs, dout, hd, dhp, x2):
+                    g_up = ops.gemm_tn(dout, hd, out=z_up)                                            # [D, 64]
+                    g_down = ops.gemm_tn(dhp, x2, out=z_down)                                         # [64, D]
         hs = bool(fmt) and ops.split_out_ok(dx2.shape[0], plan["w2_t"].shape[0], plan["w2_t"].shape[1]) and (fmt != "h" or pre.dtype == torch.float16)
         hkw = {} if not hs else {"out_split": True} if fmt == "x3" else {"out_dtype": torch.float16}      # (tf32h: fp16, still times s)
         dpre = _mm(dx2, plan, "w2_t", xs=dx2a, sc=sc, dact_src=pre, dact=3, **hkw)                # [M, 4D] (x stored GELU')
@@ -345,10 +367,11 @@ class _BlockFn(torch.autograd.Function):
                 bt16 = tw["bt_qv_w3"] if tw is not None and "bt_qv_w3" in tw and tw["bt_qv_w3"].dtype == torch.float16 else ops.cast16(bt_qv.float().contiguous())
                 dt = ops.lora_bwd_fused_h(dqv, t, bt16, z_bt, out_mul=sc[1:2], dt_scaled=h16dy)
                 gbt = z_bt
-                if ops.lora_bwd_fused_h_supported(y1, dt, None, z_at):
-                    ops.lora_bwd_fused_h(y1, dt, None, z_at, t_mul=None if h16dy else sc[0:1], out_mul=sc[1:2])
-                else:       # (D not a multiple of 256, e.g. ViT-S: the streaming N = 8 kernel, fp32 dt against the fp16 LN(x))
-                    ops.gemm_tn(dt, y1, out=z_at, alpha_dev=sc[1:2] if h16dy else None)
+                with _wgrad_side(wgs, y1, dt, sc):      # the LoRA-A gradient: nothing in the backward reads it (second stream when armed)
+                    if ops.lora_bwd_fused_h_supported(y1, dt, None, z_at):
+                        ops.lora_bwd_fused_h(y1, dt, None, z_at, t_mul=None if h16dy else sc[0:1], out_mul=sc[1:2])
+                    else:       # (D not a multiple of 256, e.g. ViT-S: the streaming N = 8 kernel, fp32 dt against the fp16 LN(x))
+                        ops.gemm_tn(dt, y1, out=z_at, alpha_dev=sc[1:2] if h16dy else None)
                 gat = z_at
                 dqkv_s = dqkv
                 dt_is_scaled = h16dy
@@ -378,17 +401,20 @@ class _BlockFn(torch.autograd.Function):
                 gbt = ops.gemm_tn(t, dqv, out=z_bt)                                               # [2r, 2D]
             if gat is not None:
                 pass                                                                              # (tf32h: taken above)
-            elif ops.lora_bwd_fused_supported(y1, dt, None, z_at):
-                gat = ops.skinny_tn_mfma(dt, y1, z_at)                                            # [2r, D] on the same slab kernel
             else:
-                gat = ops.gemm_tn(dt, y1, out=z_at)                                               # [2r, D]
+                with _wgrad_side(wgs, dt, y1):
+                    if ops.lora_bwd_fused_supported(y1, dt, None, z_at):
+                        gat = ops.skinny_tn_mfma(dt, y1, z_at)                                    # [2r, D] on the same slab kernel
+                    else:
+                        gat = ops.gemm_tn(dt, y1, out=z_at)                                       # [2r, D]
             g_bq, g_bv = gbt[:r, :D].t(), gbt[r:, D:].t()          # strided views: the gradient gather copies them anyway
             g_aq, g_av = gat[:r], gat[r:]
         if direct:       # already in the flat buffer (LoRA-B: GDViT.finish_trainable_grads transposes the stash once per step)
             g_aq = g_bq = g_av = g_bv = g_down = g_up = None
             if "on_grads" in tw:      # this block's LoRA-A / adapter slices of the flat gradient buffer are final: their exchange may start under the blocks below
                 hook, bi, spans = tw["on_grads"]
-                hook(bi, spans)
+                with _wgrad_side(wgs):      # (issued from the stream that wrote them: the collective orders itself behind that stream)
+                    hook(bi, spans)
         if not ctx.needs_input_grad[0]:   # first trainable block: nothing below it learns, skip dX (one GEMM + one LN backward)
             return None, None, None, None, g_aq, g_bq, g_av, g_bv, g_down, g_up
         if ctx.has_lora:
@@ -676,9 +702,11 @@ class GDViT(nn.Module):
                 if self.opfmt == "h":      # (only the fp16-operand LoRA backward reads a formatted B: the tf32x one takes the plain tensors)
                     for i, w in enumerate(w3(bt_qv.float())):
                         extra[i]["bt_qv_w3"] = w
+        if getattr(self, "_wgrad", None) is None:
+            self._wgrad = {"stream": None, "keep": []}      # armed per backward pass by FinetuneGD.backward (option wgrad_stream)
         for i, (inner, _, _) in enumerate(lo):
             inner._tw = {"dtype": T, "at": at[i], "bt": bt[i], "at_T": at_T[i], "bt_T": bt_T[i], "bt_qv": bt_qv[i], "down_T": down_T[i],
-                         "up_T": up_T[i], "down_tT": down_tT[i], "up_tT": up_tT[i], **extra[i]}
+                         "up_T": up_T[i], "down_tT": down_tT[i], "up_tT": up_tT[i], "wgrad": self._wgrad, **extra[i]}
 
     def finish_trainable_grads(self):
         """After the backward of a step prepared with `prepare_trainables(flat)`: the LoRA-B gradients were accumulated as

@@ -42,6 +42,13 @@ int gd_debug_set(const char* name, int value);
 int gd_debug_get(const char* name);
 int gd_gemm_phase_probe(int enable, unsigned long long* out6);
 
+/* A HIP stream confined to `cus` compute units of the current device (hipExtStreamCreateWithCUMask, the first `cus` mask bits: on MI355X the mask
+ * bits go round the eight XCDs, so a multiple of 8 takes cus / 8 CUs of every XCD — tools/micro/cu_mask_probe.hip).  No reference counterpart: the
+ * engine's backward runs the blocks' weight-gradient contractions on such a stream, on CUs that `reserve_cus` keeps the persistent kernels off, so
+ * that they run under the dX GEMMs / the attention backward (FinetuneGD.backward, options.py wgrad_stream).  *stream_out: a hipStream_t. */
+int gd_stream_create_cu_mask(int cus, void** stream_out);
+int gd_stream_destroy(void* stream);
+
 /* C[M,N] = epilogue(alpha * A[M,K] . W[N,K]^T); replaces torch nn.Linear / torch.bmm on the student path
  * (timm VisionTransformer qkv/proj/fc1/fc2, utils/model.py:57-71 LoRA, :7-25 Adapter; src/finetune_timm_vggt.py:516-517).
  * Epilogue order: +bias[N](f32) -> +lora_t[M,rt].lora_b[rt,N](f32, rt<=8) -> store preact -> act(1 GELU erf,2 ReLU,

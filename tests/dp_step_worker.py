@@ -1,6 +1,7 @@
 """Child job of test_gpu_step.py::test_two_ranks_on_one_gpu_equal_one_rank_on_the_whole_batch: one rank of a 2-rank gloo
 group, every rank on GPU 0.  Takes its contiguous half of a seeded 4-pair batch (dp.shard_pairs), runs one
-FinetuneGD.fit_step with the two-chunk gradient exchange and (rank 0) saves loss / summed gradient / updated weights."""
+FinetuneGD.fit_step with the hook-driven gradient exchange (loss-side tensors from grad hooks, the blocks' slices as each block's
+backward returns, the rest after the backward) and (rank 0) saves loss / summed gradient / updated weights."""
 import os
 import sys
 
@@ -35,14 +36,20 @@ def main():
     eng = make_engine()
     flat = eng.configure_optimizers()
     early = list(eng.refine_conv.parameters()) + list(eng.depth_diff_head.parameters())
-    red = dp.OverlappedGradReducer(eng.trainable_parameters(), flat["views"], flat["g"], early, world)
-    red.attach()
+    class Reducer(dp.OverlappedGradReducer):       # (records which blocks reported their weight-gradient slices while the backward was running)
+        blocks = []
+
+        def _block_done(self, i, spans):
+            self.blocks.append((i, len(self.works)))
+            super()._block_done(i, spans)
+    red = Reducer(eng.trainable_parameters(), flat["views"], flat["g"], early, world)
+    red.attach(model=eng.model)
     loss, _, norm = eng.fit_step(make_batch(lo, hi), red)
     lm = torch.tensor([loss.item()], dtype=torch.float64)
     torch.distributed.all_reduce(lm)
     if rank == 0:
-        torch.save({"loss_mean": lm.item() / world, "norm": norm.item(), "grad": flat["g"].cpu(), "params": flat["p"].cpu()},
-                   sys.argv[1])
+        torch.save({"loss_mean": lm.item() / world, "norm": norm.item(), "grad": flat["g"].cpu(), "params": flat["p"].cpu(),
+                    "blocks": [b for b, _ in red.blocks]}, sys.argv[1])
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 

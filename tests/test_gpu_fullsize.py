@@ -104,7 +104,7 @@ def _stream_statistics(eng, batch):
 
 
 def _run_case(name, backbone, variant, dtype, img=518, P=2, N=300, vit_kwargs=None, counts=None, eng_kwargs=None, geometry="shared", stress=False,
-              build=None, oracle_key=None, oracle_dtype=torch.float64, kink_band=None):
+              build=None, oracle_key=None, oracle_dtype=torch.float64, kink_band=None, lazy_residuals=False):
     """build: () -> FinetuneGD on the CPU (e.g. config.build_engine of one of the reference's yaml presets) instead of the /14 constructor below
     (oracle_key then names the weights + batch the oracle result is shared under across engine dtypes);
     img: the teacher-side image size, an int (square) or (h, w); the cost grid is img // eng.resize_patch_size per axis."""
@@ -144,16 +144,19 @@ def _run_case(name, backbone, variant, dtype, img=518, P=2, N=300, vit_kwargs=No
     # — the widest of the case's engine dtypes, `kink_band` — serves every dtype of a case, the f32 engine included: one gradient pass of the oracle
     # per case instead of up to three.  The features do not depend on the keypoints and the L1 residual of a keypoint depends on that keypoint
     # only, so the survivors' residuals stay what the first pass measured (asserted below).
+    # lazy_residuals (the 4 801 / 6 401-token cases, where the forward-only pass alone costs a minute): the residuals are those of the full step on the
+    # UNTOUCHED batch, run first; with a narrow band (no bf16 engine in the case) usually nothing is inside it and that step is the reference — the
+    # drop-and-rerun only happens when a keypoint does sit in the band.
     dropped = 0
     if eng.depth_loss_weight != 0 and kink_band:
         rk = key + ("residuals",)
         if rk not in _STEP_ORACLE:
-            _STEP_ORACLE[rk] = trainer().residuals(batch, P)
+            _STEP_ORACLE[rk] = oracle(batch, key + ("drop", 0.0))[6] if lazy_residuals else trainer().residuals(batch, P)
         drop = [(r.abs().reshape(-1) < kink_band).nonzero().reshape(-1).tolist() if r is not None else [] for r in _STEP_ORACLE[rk]]
         dropped = sum(len(d) for d in drop)
         if dropped:
             batch = _drop_keypoints(batch, drop)
-    ref_loss, ref_terms, ref_grads, ref_params, ref_norm, names, l1_residuals = oracle(batch, key + ("drop", kink_band))
+    ref_loss, ref_terms, ref_grads, ref_params, ref_norm, names, l1_residuals = oracle(batch, key + ("drop", kink_band if (dropped or not lazy_residuals) else 0.0))
     ref_grads, ref_params = [g.double() for g in ref_grads], [q.double() for q in ref_params]      # (an fp32 oracle's tensors: compared in double like the rest)
     if eng.depth_loss_weight != 0 and kink_band:
         res = torch.cat([r.abs().reshape(-1) for r in l1_residuals if r is not None])
@@ -351,7 +354,7 @@ def _reference_backbone(preset, dtype):
 def test_reference_backbone_vit_b16_mast3r_objaverse_step_matches_oracle(dtype):
     rec = _run_case(f"reference_backbone_vit_b16_mast3r_384x512_{dtype}", "ViT-B-16", "mast3r", dtype, img=(384, 512), P=1, counts=[300],
                     geometry="reference", build=_reference_backbone("finetune_timm_mast3r_objaverse", dtype), oracle_key="ref_b16_mast3r",
-                    oracle_dtype=torch.float32)
+                    oracle_dtype=torch.float32, kink_band=TF32H_KINK_BAND, lazy_residuals=True)
     _check(rec, cos=0.999 if dtype == "f32" else 0.99)
 
 
@@ -359,7 +362,7 @@ def test_reference_backbone_vit_b16_mast3r_objaverse_step_matches_oracle(dtype):
 def test_reference_backbone_vit_b16_vggt_step_matches_oracle(dtype):
     rec = _run_case(f"reference_backbone_vit_b16_vggt_518_{dtype}", "ViT-B-16", "vggt", dtype, img=518, P=1, counts=[300],
                     geometry="reference", build=_reference_backbone("finetune_timm_vggt_objaverse", dtype), oracle_key="ref_b16_vggt",
-                    oracle_dtype=torch.float32)
+                    oracle_dtype=torch.float32, kink_band=TF32H_KINK_BAND, lazy_residuals=True)
     _check(rec, cos=0.999 if dtype == "f32" else 0.99)
 
 
