@@ -21,6 +21,11 @@ SIGNATURES = {
     "gd_abi_version": (c_int, []),
     "gd_debug_set": (c_int, [ctypes.c_char_p, c_int]),
     "gd_debug_get": (c_int, [ctypes.c_char_p]),
+    "gd_gemm_nt_lnfold_emit": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_long, c_long, c_float,
+                                       c_void_p, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p]),
+    "gd_gemm_nt_lnfold_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_long, c_long, c_float,
+                                        c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p]),
+    "gd_ln_fold_stats": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gd_stream_create_cu_mask": (c_int, [c_int, ctypes.POINTER(c_void_p)]),
     "gd_stream_destroy": (c_int, [c_void_p]),
     "gd_gemm_phase_probe": (c_int, [c_int, c_void_p]),

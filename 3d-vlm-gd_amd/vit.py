@@ -144,6 +144,13 @@ class GDBlock(nn.Module):
         p["wproj"], p["wproj_t"] = both(wproj)
         p["w1"], p["w1_t"] = both(w1)
         p["w2"], p["w2_t"] = both(wfc2)
+        if x3 == "h":
+            # LayerNorm fold (options.ln2_fold): norm2 -> fc1 as ONE product on the un-normalised fp16 rows.  W' = W diag(gamma) rounded to fp16, cs = the
+            # row sums of the ROUNDED W' (what the MFMA multiplies the row mean with), b' = b + W beta in fp32.
+            g2w, b2w = p["ln2_w"], p["ln2_b"]
+            wf = (w1 * g2w[None, :]).to(torch.float16).contiguous()
+            p["w1_fold"], p["w1_fold_cs"] = wf, wf.float().sum(1).contiguous()
+            p["b1_fold"] = (p["b1"] + w1 @ b2w).contiguous()
         self._plan = p
         return p
 
@@ -206,21 +213,33 @@ class _BlockFn(torch.autograd.Function):
                 t = ops.gemm_nt(y1s, tw["at_w3"] if tw is not None and "at_w3" in tw else _opw(at.contiguous(), fmt), out_dtype=torch.float32)
             else:
                 t = ops.gemm_nt(y1, at_T, out_dtype=torch.float32)  # [M, 2r]
+        fold2 = False
         if fmt == "h":     # tf32h: q / k / v, the attention output and their gradients live as fp16 — they are operands of matrix products only
             qkv = _mm(y1, plan, "wqkv", xs=y1s, bias=plan["bqkv"], lora_t=t, lora_b=bt, out_dtype=torch.float16)
             o, lse = ops.attention_fwd(qkv, B, Nt, H)
-            x1 = _mm(None, plan, "wproj", xs=o, bias=plan["bproj"], residual=x)
+            fold2 = bool(option("ln2_fold")) and "w1_fold" in plan and ops.lnfold_ok(M, D, D) and ops.lnfold_ok(M, plan["w1"].shape[0], D)
+            if fold2:      # the projection leaves x1, its fp16 copy and the row sums LayerNorm 2 needs: no LayerNorm pass (below)
+                x1, x1h, part2 = ops.gemm_nt_lnfold_emit(o, plan["wproj"], x, bias=plan["bproj"])
+            else:
+                x1 = _mm(None, plan, "wproj", xs=o, bias=plan["bproj"], residual=x)
         else:
             qkv = _mm(y1, plan, "wqkv", xs=y1s, bias=plan["bqkv"], lora_t=t, lora_b=bt)
             o, lse = ops.attention_fwd(qkv, B, Nt, H, x3=bool(fmt))
             x1 = _mm(o, plan, "wproj", bias=plan["bproj"], residual=x)
-        y2, mean2, rstd2 = ops.layernorm_fwd(x1, plan["ln2_w"], plan["ln2_b"], plan["eps2"], save_stats=need, **h16)
+        fold2 = fmt == "h" and fold2
+        if not fold2:
+            y2, mean2, rstd2 = ops.layernorm_fwd(x1, plan["ln2_w"], plan["ln2_b"], plan["eps2"], save_stats=need, **h16)
         # tf32x: fc1 writes GELU(.) directly as the split left operand of fc2 (no f32 [M, 4D] round trip + split pass)
         # (tf32h: as fp16, and the stored GELU'(.) — a factor of an elementwise product in the backward — as fp16 too)
         hs = bool(fmt) and ops.split_out_ok(M, plan["w1"].shape[0], plan["w1"].shape[1])
         pre = torch.empty(M, plan["w1"].shape[0], dtype=torch.float16 if (fmt == "h" and hs) else T, device=x.device) if need else None
         hkw = {} if not hs else {"out_split": True} if fmt == "x3" else {"out_dtype": torch.float16}
-        h = _mm(None if fmt == "h" else y2, plan, "w1", xs=y2 if fmt == "h" else None, bias=plan["b1"], act=3, preact=pre, **hkw)   # pre <- GELU'(fc1 output): all the backward needs
+        if fold2:       # fc1 on the un-normalised rows against W diag(gamma); (mean, rstd) applied to the product in its epilogue
+            st2, mean2, rstd2 = ops.ln_fold_stats(part2, D, plan["eps2"], want_rows=need)
+            h = ops.gemm_nt_lnfold_apply(x1h, plan["w1_fold"], plan["b1_fold"], st2, plan["w1_fold_cs"], preact=pre)
+            del x1h, part2, st2
+        else:
+            h = _mm(None if fmt == "h" else y2, plan, "w1", xs=y2 if fmt == "h" else None, bias=plan["b1"], act=3, preact=pre, **hkw)   # pre <- GELU'(fc1 output): all the backward needs
         x2a = None
         ad_h = fmt == "h" and down is not None and ops.adapter_fused_h_supported(M, D, down.shape[0])      # the fused fp16-operand adapter kernel
         if fmt == "h" and hs and down is not None and not ad_h and ops.copy16_ok(M, D, plan["w2"].shape[1]):

@@ -273,8 +273,15 @@ def test_vit_base_518_tf32x_step_matches_oracle():
 # the fp16-operand TF32-class engine at the benched size: fp32 storage, every big product and the attention on fp16 operands (TF32's 11-bit
 # significand), gradient operands under a per-block power-of-two scale.  Stated tolerances: loss and terms 2e-4, gradient TF32H_GRAD_FRO
 # (+ the kink allowance when a keypoint's depth-L1 residual is inside the engine's feature noise), weights after the step 1e-4.
-def test_vit_base_518_tf32h_step_matches_oracle():
-    rec = _run_case("vit_base_518_mast3r_tf32h", "vit_base", "mast3r", "tf32h", counts=[300, 211])
+@pytest.mark.parametrize("ln2_fold", [0, 1])
+def test_vit_base_518_tf32h_step_matches_oracle(ln2_fold):
+    # ln2_fold = 1: the LayerNorm-2 fold (options.ln2_fold, an experiment that is off by default — profiles/r05_ln2_fold_ab.txt) holds the same tolerances
+    from gd_amd.options import set_option
+    keep = set_option("ln2_fold", ln2_fold)
+    try:
+        rec = _run_case("vit_base_518_mast3r_tf32h" + ("_ln2_fold" if ln2_fold else ""), "vit_base", "mast3r", "tf32h", counts=[300, 211])
+    finally:
+        set_option("ln2_fold", keep)
     assert rec["rel_err"] < 2e-4, rec
     for k, t in rec["terms"].items():
         assert t["rel_err"] < 2e-4, (k, t)

@@ -489,3 +489,56 @@ def test_gemm_tn_rounds_an_fp32_operand_to_fp16_in_the_kernel():
     y16 = (torch.randn(M, K, generator=g, device="cuda")).half()
     got = ops.gemm_tn(y16, x32)
     assert rel_err(got, y16.double().t() @ x32.half().double()) < 1e-5
+
+
+@pytest.mark.parametrize("M,D,H4", [(2740, 768, 3072), (1370 * 3 + 5, 256, 1024)])
+def test_layernorm_fold_gemms_equal_layernorm_then_linear(M, D, H4):
+    """Round 5, the LayerNorm fold of the tf32h forward (gd_gemm_nt_lnfold_emit / gd_ln_fold_stats / gd_gemm_nt_lnfold_apply): the projection GEMM
+    leaves x1 = o Wp^T + b + x (f32), fp16(x1) and per-row partial sums; fc1 multiplies the UN-normalised fp16 rows with W diag(gamma) and normalises
+    the product in its epilogue.  Against fp64 torch: x1 and its statistics to fp32 accuracy; GELU(LN(fp16(x1)) W^T + b) and its derivative to fp16
+    output rounding — the same tolerance as LayerNorm -> fp16 -> GEMM (reference below: 'unfused').  Rows with a large common offset (mean = 6 sigma)
+    and a massive channel exercise the cancellation in rstd (acc - mean cs)."""
+    from gd_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(M + D)
+    o = torch.randn(M, D, generator=g, device="cuda").half()
+    x = torch.randn(M, D, generator=g, device="cuda")
+    x[:, 7] += 40.0                                       # a massive channel
+    x[: M // 3] += 6.0                                    # rows whose mean is several standard deviations
+    wp = (0.05 * torch.randn(D, D, generator=g, device="cuda")).half()
+    bp = 0.1 * torch.randn(D, generator=g, device="cuda")
+    gamma = 1.0 + 0.3 * torch.randn(D, generator=g, device="cuda")
+    beta = 0.2 * torch.randn(D, generator=g, device="cuda")
+    w1 = 0.05 * torch.randn(H4, D, generator=g, device="cuda")
+    b1 = 0.1 * torch.randn(H4, generator=g, device="cuda")
+    eps = 1e-6
+    x1, x1h, part = ops.gemm_nt_lnfold_emit(o, wp, x, bias=bp)
+    ref1 = o.double() @ wp.double().t() + bp.double() + x.double()
+    assert rel_err(x1, ref1) < 2e-6
+    assert torch.equal(x1h, x1.half())
+    assert part.shape == (M, D // 64, 2)
+    sl = x1.double().view(M, D // 64, 64)
+    assert rel_err(part[..., 0], sl.sum(-1)) < 1e-5 and rel_err(part[..., 1], (sl * sl).sum(-1)) < 1e-5
+    st, mean, rstd = ops.ln_fold_stats(part, D, eps)
+    mu = x1.double().mean(-1)
+    rs = 1.0 / torch.sqrt(x1.double().var(-1, unbiased=False) + eps)
+    assert rel_err(mean, mu) < 1e-5 and rel_err(rstd, rs) < 2e-5
+    assert torch.equal(st[:, 0], mean) and torch.equal(st[:, 1], rstd)
+    # the fold
+    wf = (w1 * gamma[None, :]).half().contiguous()
+    cs = wf.float().sum(1).contiguous()
+    bf = (b1 + w1 @ beta).contiguous()
+    pre = torch.empty(M, H4, dtype=torch.float16, device="cuda")
+    h = ops.gemm_nt_lnfold_apply(x1h, wf, bf, st, cs, preact=pre)
+    h_plain = ops.gemm_nt_lnfold_apply(x1h, wf, bf, st, cs)
+    assert torch.equal(h, h_plain)
+    xn = (x1h.double() - mu[:, None]) * rs[:, None]                                  # LayerNorm of the fp16-rounded rows, exact statistics
+    z = (xn * gamma.double() + beta.double()) @ w1.double().t() + b1.double()
+    want = torch.nn.functional.gelu(z)
+    zz = z.clone().requires_grad_(True)
+    torch.nn.functional.gelu(zz).sum().backward()
+    # reference path of the engine without the fold: LayerNorm pass -> fp16 -> GEMM with GELU
+    y2, _, _ = ops.layernorm_fwd(x1, gamma, beta, eps, out_dtype=torch.float16)
+    unf = ops.gemm_nt(y2, w1.half().contiguous(), bias=b1, act=1, out_dtype=torch.float16)
+    e_fold, e_unf = rel_err(h, want), rel_err(unf, want)
+    assert e_fold < 2e-3 and e_fold < 2.0 * e_unf + 2e-4, (e_fold, e_unf)
+    assert rel_err(pre, zz.grad) < 3e-3

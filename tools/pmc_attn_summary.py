@@ -11,6 +11,9 @@ import os
 import sys
 
 d, out = sys.argv[1], sys.argv[2]
+FILTER = sys.argv[3] if len(sys.argv) > 3 else "attn"        # substring of the kernel names to summarise (round 5: "cv_fwd" for the cost-volume forward)
+NOTE = sys.argv[4] if len(sys.argv) > 4 else ("rocprofv3 --pmc passes (counters only + --kernel-trace) over tools/bench_kernels.py pmc_attn, GD_PMC_F16=1: 64 x 12 x 1370, "
+                                              "fp16 operands")
 val = collections.defaultdict(lambda: collections.defaultdict(float))      # kernel -> counter -> sum over dispatches
 cnt = collections.defaultdict(lambda: collections.defaultdict(set))        # kernel -> counter -> dispatch ids
 dur = collections.defaultdict(list)
@@ -20,14 +23,14 @@ for p in sorted(glob.glob(os.path.join(d, "*"))):
     for cc in glob.glob(p + "/*/*counter_collection.csv"):
         for r in csv.DictReader(open(cc)):
             k = r["Kernel_Name"]
-            if "attn" not in k:
+            if FILTER not in k:
                 continue
             val[k][r["Counter_Name"]] += float(r["Counter_Value"])
             cnt[k][r["Counter_Name"]].add(r["Dispatch_Id"])
     if os.path.basename(p) == "a":
         for kt in glob.glob(p + "/*/*kernel_trace.csv"):
             for r in csv.DictReader(open(kt)):
-                if "attn" in r["Kernel_Name"]:
+                if FILTER in r["Kernel_Name"]:
                     dur[r["Kernel_Name"]].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
 res = {}
 for k, cs in val.items():
@@ -60,8 +63,7 @@ failed = []
 fp = os.path.join(d, "failed.txt")
 if os.path.exists(fp):
     failed = [l.strip() for l in open(fp) if l.strip()]
-json.dump({"note": "rocprofv3 --pmc passes (counters only + --kernel-trace) over tools/bench_kernels.py pmc_attn, GD_PMC_F16=1: 64 x 12 x 1370, fp16 operands; "
-                   "values are averages per dispatch; counter collection serialises dispatches: durations here are not the step's",
+json.dump({"note": NOTE + "; values are averages per dispatch; counter collection serialises dispatches: durations here are not the step's",
            "unavailable": failed, "kernels": res}, open(out, "w"), indent=1)
 for k, r in res.items():
     print(k[:70], json.dumps({x: r[x] for x in r if x != "counters_per_dispatch"}))
