@@ -567,8 +567,8 @@ def parity_and_cpu_baseline(job, args, ns=4):
     cores = min(os.cpu_count(), 32)       # torch CPU ops stop scaling (and oversubscribe) well before 256 threads
     torch.set_num_threads(cores)
     p, tr, refine, head, cfg = oracle_params(eng)
-    if job.geometry == "reference":      # 6 401-token forwards: the oracle's attention in checkpointed query-row blocks (same values and gradients)
-        cfg["attention_chunk"] = 512
+    if job.geometry == "reference":      # 4 801 / 6 401-token forwards: no [heads, N, N] matrix kept (same values and gradients)
+        cfg["attention_sdpa"] = True         # (fp32: torch's fused CPU attention, the call timm's blocks make; tests/test_oracle_attention_modes.py)
     for d in tr.values():
         for blk in d.values():
             for k in blk:

@@ -291,7 +291,14 @@ def vit_block(x, p, i, cfg, lora=None, ad=None):
     y = F.layer_norm(x, (D,), p[pre + "norm1.weight"], p[pre + "norm1.bias"], eps)
     qkv = lora_qkv(y, p[pre + "attn.qkv.weight"], p.get(pre + "attn.qkv.bias"), lora)
     q, k, v = qkv.reshape(B, N, 3, h, d).permute(2, 0, 3, 1, 4).unbind(0)
-    if cfg.get("attention_chunk"):
+    if cfg.get("attention_sdpa"):
+        # the same softmax(q k^T / sqrt d) v through torch's fused CPU kernel — the call the student's timm blocks make themselves (timm
+        # Attention.forward with fused_attn: F.scaled_dot_product_attention; the vendored vggt/layers/attention.py:33,98 carries the same switch).
+        # No [h, N, N] matrix is materialised, forward or backward: at the reference geometry's 4 801 / 6 401 tokens it is 8 x faster on the host
+        # than the checkpointed row blocks below (0.74 s against 6.25 s per layer and image on 8 cores) and equal to them to 5e-7
+        # (tests/test_oracle_attention_modes.py).  fp32 oracles only.
+        a = F.scaled_dot_product_attention(q, k, v)
+    elif cfg.get("attention_chunk"):
         # the same softmax(q k^T / sqrt d) v, evaluated for `attention_chunk` query rows at a time under gradient checkpointing: at the reference
         # geometry's 6 401 tokens the [h, N, N] score and probability matrices of every trainable block (3.9 GB each in fp64, four big forwards
         # per pair) do not have to stay alive for the backward.  Row blocks of a softmax are independent: identical values and gradients.
