@@ -1,27 +1,30 @@
-// Row-panel-STATIONARY cost-volume forward (round 5).  Included by cost_volume.hip after CvTileParams / the helpers of the persistent kernels.
+// Row-panel-STATIONARY cost-volume forward (round 5) — an EXPERIMENT behind GD_CV_PANEL (1: NW = 4, 8: NW = 8; default 0 = the persistent kernels of
+// cost_volume.hip).  Correct and bit-reproducible (tests/test_gpu_cost_volume.py::test_panel_forward_matches_oracle_and_round4_kernel) and SLOWER than
+// what it was meant to replace: dense sweep, 32 pairs, 299 us (NW = 4) / 332 us (NW = 8) against 240 us.  DESIGN.md section 5 has the anatomy; in short
+// a wave that owns only 16 rows reads the whole 16 KB column stage per K step for 16 MFMAs (LDS read bandwidth = MFMA time at 8 waves per CU), and
+// at one or two waves per SIMD the phases of a tile add up instead of overlapping.  Included by cost_volume.hip after CvTileParams.
 //
-// Why: cv_fwd_persist_kernel / cv_fwd_rows_kernel re-stream BOTH operand panels of every 128 x 128 score tile from L2 into LDS (393 KB per tile,
-// 1.5 GB per 32-pair launch against 614 MB of HBM bytes) through one vector-memory pipe that also carries the teacher rows; the L2 -> LDS feature
-// stream alone is ~85 of the launch's ~230 us (profiles/NOTES_r01_r03.md).  Here a block owns a 128-row panel of view 1 for a
-// whole sweep of column tiles and keeps it ON CHIP — in REGISTERS, as the MFMA A fragments of the wave that owns the rows:
-//   * 8 waves, wave w owns rows 16 w .. 16 w + 15 of the panel for the full K (768 halves = 24 fragments = 96 VGPRs) and computes the whole
-//     16 x 128 strip of the tile: 8 n-blocks x 4 accumulator registers;
-//   * only the view-2 (column) rows stream: a ring of CVA_NS = 8 stages of 128 rows x 128 B (16 KB), seven stages in flight ACROSS tile
-//     boundaries (112 KB per CU), two LDS-DMA pieces per wave and K-step — half the L2 -> LDS bytes per score, and no A-side LDS reads at all;
-//   * a tile's row statistics are complete inside one wave (no cross-wave combine for direction 1); direction 2's column partials of the eight
-//     waves are summed in fixed order through LDS by the next tile's first step (bit-reproducible, like the kernels this replaces);
-//   * teacher entries go straight into the accumulator layout one tile ahead, as before — by INLINE-ASM loads with hand-counted `s_waitcnt vmcnt`:
-//     the wave's vector-memory queue now also carries its LDS-DMA pieces, and a load the compiler can see is waited for with vmcnt(0) at its first
-//     use (cdna_hip_programming.md, "Pipelining across barriers"), which would drain the ring once per tile;
+// The idea: cv_fwd_persist_kernel re-streams BOTH operand panels of every 128 x 128 score tile from L2 into LDS (393 KB per tile, 1.5 GB per 32-pair
+// launch against 614 MB of HBM bytes) through the vector-memory pipe that also carries the teacher rows.  Here a block owns a 16 NW-row panel of view 1
+// for a whole sweep of column tiles and keeps it ON CHIP — in REGISTERS, as the MFMA A fragments of the wave that owns the rows:
+//   * wave w owns rows 16 w .. 16 w + 15 of the panel for the full K (768 halves = 24 fragments: 23 in registers, the last parked in LDS) and computes
+//     the whole 16 x 128 strip of the tile: 8 n-blocks x 4 accumulator registers;
+//   * only the view-2 (column) rows stream: a ring of NS stages of 128 rows x 128 B (16 KB), NS - 1 stages in flight ACROSS tile boundaries, 16 / NW
+//     LDS-DMA pieces per wave and K step — with NW = 8 half the L2 -> LDS bytes per score, and no A-side LDS reads at all;
+//   * a tile's row statistics are complete inside one wave (no cross-wave combine for direction 1); direction 2's column partials of the NW waves are
+//     summed in fixed order through LDS by the next tile's first step (bit-reproducible, like the kernels this was meant to replace);
+//   * teacher entries go straight into the accumulator layout one tile ahead — by INLINE-ASM loads with hand-counted `s_waitcnt vmcnt`: the wave's
+//     vector-memory queue also carries its LDS-DMA pieces, and a load the compiler can see is waited for with vmcnt(0) at its first use
+//     (cdna_hip_programming.md, "Pipelining across barriers"), which would drain the ring once per tile;
 //   * every LDS access is inline asm for the same reason (a ds_read the compiler can see gets a vmcnt wait to the latest LDS-DMA in front of it).
-// The vmcnt bookkeeping is DYNAMIC: `seq` counts the wave's unconditional vector-memory instructions (DMA pieces, statistics pieces, teacher loads),
-// an 8 x 8-bit packed scalar remembers `seq` after each ring slot's pieces, and a stage is waited for with vmcnt(seq - mark) rounded DOWN to a
-// multiple of 4.  Instructions that a wave may skip (stores under a row mask) are NOT counted: under-counting only waits a little longer.
-// Work split: the global tile list is pair-major with the column tile fastest; an XCD takes a contiguous range (as before), and inside every
-// pair's segment of that range the XCD's blocks take CONTIGUOUS sub-slices — all blocks of an XCD work on the same pair (its view-2 rows stay in
-// that L2) and a block changes its row panel (one reload of the A registers) at most twice per slice.
-// ROWS = the kept-row form (sparse row masks, cv_fwd_rows_kernel's problem): tile (pd = 2 pair + direction, row tile of the compacted kept rows,
-// column tile), A rows gathered through the index list, one direction's epilogue, row partials only.
+// The vmcnt counts are STATIC (cva_wait_vm_c: compile-time arguments after unrolling): per tile and wave the program order is, for K step kt = 0 .. 11,
+// wait(stage (tile, kt)) | barrier | the pieces of the stage NS - 1 steps ahead [+ one statistics piece with the tile's last stage], then the epilogue
+// (one store), [panel reload: drained], the 16 teacher loads of the next tile — so the pieces of stage (tile, kt) have (NS - 2) stages of pieces younger
+// than them, plus the teacher burst iff they were issued before it; statistics pieces and stores are left out (under-counting waits a little longer).
+// Work split: the global tile list is pair-major with the column tile fastest; an XCD takes a contiguous range, and inside every pair's segment of that
+// range the XCD's blocks take CONTIGUOUS sub-slices — all blocks of an XCD work on the same pair (its view-2 rows stay in that L2) and a block changes
+// its row panel (one reload of the A registers: the OUTER loop of the kernel) a few times per slice.  Dense form only (the kept-row form stays on
+// cv_fwd_rows_kernel: with ~1 tile per slice and direction a panel would be reloaded for every tile).
 #pragma once
 
 // LDS layout of a block of NW waves (a panel of 16 NW rows), NS ring slots of 16 KB:
@@ -49,18 +52,6 @@ __device__ __forceinline__ int cva_perm128(int rho) { return ((rho & 15) << 3) |
 #define CVA_DSW128(addr, val, off) asm volatile("ds_write_b128 %0, %1 offset:" #off : : "v"(addr), "v"(val) : "memory")
 #define CVA_DSW64(addr, val, off) asm volatile("ds_write_b64 %0, %1 offset:" #off : : "v"(addr), "v"(val) : "memory")
 
-// wait until at most n (rounded down to a multiple of 4, at most 60) vector-memory operations of this wave are outstanding
-__device__ __forceinline__ void cva_wait_vm(int n) {
-#define CVA_W(k) asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory")
-    if (n >= 32) {
-        if (n >= 48) { if (n >= 56) { if (n >= 60) CVA_W(60); else CVA_W(56); } else { if (n >= 52) CVA_W(52); else CVA_W(48); } }
-        else { if (n >= 40) { if (n >= 44) CVA_W(44); else CVA_W(40); } else { if (n >= 36) CVA_W(36); else CVA_W(32); } }
-    } else {
-        if (n >= 16) { if (n >= 24) { if (n >= 28) CVA_W(28); else CVA_W(24); } else { if (n >= 20) CVA_W(20); else CVA_W(16); } }
-        else { if (n >= 8) { if (n >= 12) CVA_W(12); else CVA_W(8); } else { if (n >= 4) CVA_W(4); else CVA_W(0); } }
-    }
-#undef CVA_W
-}
 __device__ __forceinline__ unsigned cva_lds_u32(unsigned addr) {
     unsigned v;
     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
@@ -121,17 +112,12 @@ __device__ __forceinline__ void cva_wait_vm_c(int n) {
 #undef CVA_W
 }
 
-// DENSE form (both directions from one sweep).  NK = 12 K-steps of 128 bytes (C = 768 halves); the ring runs CVA_NS - 1 = 7 stages ahead.
-// Vector-memory program order of a wave, per tile (what the static vmcnt counts below are derived from):
-//   step kt = 0 .. 11:  wait(stage (it, kt)) | barrier | 2 DMA pieces of stage 7 steps ahead [+ 1 statistics piece at kt = 4] | (stores: not counted)
-//   then:               epilogue (1 store), [panel reload: drained], 16 teacher loads of the next tile.
-//   => younger than the pieces of stage (it, kt) when it is waited for: the 6 stages issued after it (12) + the teacher burst iff the stage was issued
-//      before it (kt <= 6): vmcnt(28) / vmcnt(12); the last tile of a block issues nothing past the end of its list and counts what is left.
-//   Statistics pieces and stores are left out of the count (under-counting is the safe direction).
-// NW = 8: one block per CU, 128-row panels.  NW = 4 (the default since the anatomy of the 8-wave form, profiles/README.md round 5): 64-row panels, TWO
-// independent blocks per CU — the 8-wave block's phases (ring wait, MFMAs, teacher wait, epilogue) simply added up, every wave of a CU being in the
-// same one; two blocks with their own rings and barriers drift apart and one's epilogue runs under the other's MFMAs.  (The column operand is then
-// streamed per 64 rows — the L2 -> LDS bytes of the round-4 kernel — which the anatomy shows is the cheap part: the ring alone cost 19 us.)
+// DENSE form (both directions from one sweep).  NK = 12 K-steps of 128 bytes (C = 768 halves); the ring runs LA = NS - 1 stages ahead, PP = 16 / NW pieces
+// per wave and stage.  Static vmcnt counts (header comment): when stage (tile, kt) is waited for, the LA - 1 stages issued after it are younger
+// (PP (LA - 1) pieces) plus the 16-load teacher burst iff the stage was issued before it (kt < LA); the last tile of a block issues nothing past the end of
+// its list and counts what is left.  NW = 8: vmcnt(28) / vmcnt(12); NW = 4: vmcnt(24) / vmcnt(8).
+// NW = 8: one block per CU, 128-row panels.  NW = 4: 64-row panels, TWO independent blocks per CU — meant to let one block's epilogue run under the
+// other's MFMAs (the 8-wave block's phases simply added up); measured 299 us against 332, both behind the 240 us of the round-4 kernel.
 template <typename T, int NK, int NW, int DBG = 0>      // DBG: anatomy instantiations (-DGD_CV_PANEL_ANAT builds only; bits: 1 no teacher loads, 2 no epilogue math, 4 no LDS reads / MFMAs, 8 no DMA); never the product path
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void cv_fwd_panel_kernel(CvTileParams q) {
     typedef typename Mma<T>::Frag Frag;

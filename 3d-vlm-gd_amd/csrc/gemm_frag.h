@@ -13,7 +13,6 @@ __device__ __forceinline__ int nperm64(int rho) {   // LDS W-row (64w + 16j + fr
 // previous tile's epilogue stores and the just-issued prefetch — exactly the overlap this kernel exists for.
 // Results are "released" by a counted `s_waitcnt lgkmcnt(N)` that lists them as read-write operands (LDS returns in order).
 #define GD_DSR128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
-#define GD_DSR64(dst, addr, off) asm volatile("ds_read_b64 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
 #define GD_DSR32(dst, addr, off) asm volatile("ds_read_b32 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
 __device__ __forceinline__ unsigned lds_off(const void* p) {
     return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
