@@ -31,6 +31,7 @@ static const KnobDef KNOBS[] = {
     {"ln_16b", "GD_LN_16B", &GdKnobs::ln_16b, 1},                         {"adapter_persist", "GD_ADAPTER_PERSIST", &GdKnobs::adapter_persist, 1},
     {"reserve_cus", "GD_RESERVE_CUS", &GdKnobs::reserve_cus, 0},          {"gemm_group_m", "GD_GEMM_GROUP_M", &GdKnobs::gemm_group_m, 1},
     {"gemm_stagger", "GD_GEMM_STAGGER", &GdKnobs::gemm_stagger, 0},       {"cv_panel", "GD_CV_PANEL", &GdKnobs::cv_panel, 0},
+    {"gemm_k64", "GD_GEMM_K64", &GdKnobs::gemm_k64, 0},
 };
 static void gd_apply_reserve(GdKnobs& v) {
     int r = v.reserve_cus < 0 ? 0 : v.reserve_cus;

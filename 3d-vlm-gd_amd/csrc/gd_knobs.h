@@ -13,6 +13,7 @@ struct GdKnobs {
     int gemm_stagger;      // GD_GEMM_STAGGER      persistent kernel: start-up skew of block group (b >> 3) & 3, in 10 ns ticks per group (0 none)
     int gemm_krot;         // GD_GEMM_KROT         per-tile K-step rotation of the persistent kernel (0 off)
     int gemm_batch_big_m;  // GD_GEMM_BATCH_BIG_M  batched gemm_nt: smallest M served by the 256 x 256 kernels (384: the kept-row cost-volume contractions, 97 vs 149 us; un-batched: 1024)
+    int gemm_k64;          // GD_GEMM_K64          1: fp16-operand persistent kernel on a four-slot ring of 64-byte stages (three stages in flight) instead of two slots of 128 bytes
     int gemm_anat;         // GD_GEMM_ANAT         anatomy instantiations of the persistent main loop (0 = the product kernel)
     int tn_blocks;         // GD_TN_BLOCKS         target block count of the tile TN GEMM (0 auto)
     int attn_dma;          // GD_ATTN_DMA          1: LDS-DMA attention forward; 0: register-staged

@@ -924,14 +924,18 @@ static int gemm_nt_impl(const void* A, const void* W, void* C, int M, int N, int
     } else if (ab_dtype == GD_F16 && !accumulate && !(dact_src && residual)) {
         // fp16 operands (tf32h engine): f32 results with f32 epilogue tensors, or fp16 results with fp16 preact / dact_src (as the bf16 engine's)
         const bool ch = c_dtype == GD_F16;
+        // GD_GEMM_K64 (round 5): the four-slot ring of 64-byte stages (gemm_persist.h KS) instead of two slots of 128 bytes
+        const bool k64 = gd_knobs().gemm_k64 != 0;
+#define GD_PK(S, A, P, C, L) (k64 ? gemm_nt_persist_kernel<f16, S, A, P, C, 0, 0, L, 64> : gemm_nt_persist_kernel<f16, S, A, P, C, 0, 0, L, 128>)
         if (!dact_src && !residual) {
-            if (act == 0 && !preact) pk = ch ? gemm_nt_persist_kernel<f16, 0, 0, 0, false> : gemm_nt_persist_kernel<f16, 0, 0, 0, true>;
-            else if ((act == 1 || act == 3) && !preact) pk = ch ? gemm_nt_persist_kernel<f16, 0, 1, 0, false> : gemm_nt_persist_kernel<f16, 0, 1, 0, true>;
-            else if (act == 3 && preact) pk = ch ? gemm_nt_persist_kernel<f16, 0, 1, 2, false> : gemm_nt_persist_kernel<f16, 0, 1, 2, true>;
-        } else if (dact_src && dact == 3 && act == 0 && !preact) pk = ch ? gemm_nt_persist_kernel<f16, 3, 0, 0, false> : gemm_nt_persist_kernel<f16, 3, 0, 0, true>;
-        else if (residual && act == 0 && !preact && !ch) pk = copy16 ? gemm_nt_persist_kernel<f16, 2, 0, 3, true> : gemm_nt_persist_kernel<f16, 2, 0, 0, true>;
-        if (ln_part) pk = gemm_nt_persist_kernel<f16, 2, 0, 3, true, 0, 0, 1>;
-        if (ln_stats) pk = (act == 3 && preact) ? gemm_nt_persist_kernel<f16, 0, 1, 2, false, 0, 0, 2> : !preact ? gemm_nt_persist_kernel<f16, 0, 1, 0, false, 0, 0, 2> : nullptr;
+            if (act == 0 && !preact) pk = ch ? GD_PK(0, 0, 0, false, 0) : GD_PK(0, 0, 0, true, 0);
+            else if ((act == 1 || act == 3) && !preact) pk = ch ? GD_PK(0, 1, 0, false, 0) : GD_PK(0, 1, 0, true, 0);
+            else if (act == 3 && preact) pk = ch ? GD_PK(0, 1, 2, false, 0) : GD_PK(0, 1, 2, true, 0);
+        } else if (dact_src && dact == 3 && act == 0 && !preact) pk = ch ? GD_PK(3, 0, 0, false, 0) : GD_PK(3, 0, 0, true, 0);
+        else if (residual && act == 0 && !preact && !ch) pk = copy16 ? GD_PK(2, 0, 3, true, 0) : GD_PK(2, 0, 0, true, 0);
+        if (ln_part) pk = GD_PK(2, 0, 3, true, 1);
+        if (ln_stats) pk = (act == 3 && preact) ? GD_PK(0, 1, 2, false, 2) : !preact ? GD_PK(0, 1, 0, false, 2) : nullptr;
+#undef GD_PK
     }
     // (the bf16 f32-output instantiations serve the tf32x engine: 3K-wide split operands, fp32 C / preact / dact_src / residual)
     const bool persist_ok = big && persist && pk && p.vec_epilogue && N % 8 == 0 && (!lora_t || lora_rt == 8) && 256 * ldmax * cs < 0x7fffffffL;

@@ -39,13 +39,19 @@
 // the normalisation to the product, v = rstd_m (alpha acc - mean_m cs_n) + bias'_n with cs_n = sum_k W'[n][k] (of the ROUNDED W') and
 // bias' = bias + W beta — LayerNorm(x) W^T + b exactly, for the fp16-rounded x.  The tile's 256 (mean, rstd) pairs and its cs slice arrive by
 // LDS-DMA with the bias slice.
-template <typename T, int SIDE, int ACT, int PREACT, bool CF32, int ANAT = 0, int COUT = 0, int LNF = 0>
+// KS (round 5): bytes of an operand row per ring stage.  128 = the two-slot ring of rounds 1-4 (a K step of two MFMA chunks per stage, ONE stage in flight
+// while a step computes: the loop waits ~40 % of its time for that stage to land).  64 = FOUR slots of one chunk each, the same 128 KB: the stage
+// barrier comes after every chunk and releases the slot just read to the stage four chunks ahead, so THREE half-size stages are in flight under a
+// chunk's MFMAs (96 KB against 64 KB).  The LDS image has 64-byte rows (16 rows per 1-KB DMA piece, swz64).
+template <typename T, int SIDE, int ACT, int PREACT, bool CF32, int ANAT = 0, int COUT = 0, int LNF = 0, int KS = 128>
 __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
     constexpr int NWN = 4, WMT = 8, NW = 8, BM = 256, BN = 256;
-    constexpr int ABYTES = BM * 128, STAGE = (BM + BN) * 128, APW = BM / 8 / NW, BPW = BN / 8 / NW;
+    static_assert(KS == 128 || (KS == 64 && ANAT == 0), "ring stage: 128-byte rows (two slots) or 64-byte rows (four slots)");
+    constexpr int RPP = 1024 / KS, NSLOT = KS == 64 ? 4 : 2;      // rows per 1-KB DMA piece; ring slots
+    constexpr int ABYTES = BM * KS, STAGE = (BM + BN) * KS, APW = BM / RPP / NW, BPW = BN / RPP / NW;
     constexpr int SDEP = CF32 ? GD_SDEP32 : 16;   // side-input prefetch depth (items per lane in flight: 8 bytes each for bf16 side tensors, 16 for f32)
     constexpr int ssz = CF32 ? 4 : 2;     // element size of the side tensor (dact_src / residual): the dtype of C
-    constexpr int LORA_OFF = 2 * STAGE, BIAS_OFF = LORA_OFF + (BM + BN) * 32;
+    constexpr int LORA_OFF = NSLOT * STAGE, BIAS_OFF = LORA_OFF + (BM + BN) * 32;
     constexpr int LNCS_OFF = BIAS_OFF + 2 * BN * 4, LNST_OFF = LNCS_OFF + 2 * BN * 4;      // LNF 2: cs slices [2][BN] f32, (mean, rstd) [2][BM][2] f32
     static_assert(LNF == 0 || (LNF == 1 && SIDE == 2 && PREACT == 3 && CF32) || (LNF == 2 && SIDE == 0), "LayerNorm fold: emit with the residual + fp16 copy, apply without a side tensor");
     constexpr int LNP_OFF = BIAS_OFF + 2 * BN * 4;      // LNF 1: the tile's row partials [BM][4 waves across N][2] f32, written by the epilogue, flushed to global at the top of the next tile
@@ -62,7 +68,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
     const char* Ab = (const char*)p.A + batch * p.sA * (long)sizeof(T);
     const char* Wb = (const char*)p.W + batch * p.sW * (long)sizeof(T);
     const long lda_b = p.lda * (long)sizeof(T), ldw_b = p.ldw * (long)sizeof(T);
-    const int nk = p.K * (int)sizeof(T) / 128;
+    const int nk = p.K * (int)sizeof(T) / KS;      // ring stages per tile
     static_assert(COUT == 0 || (COUT == 1 && CF32), "split output comes from f32 values");
     constexpr bool CSPLIT = COUT == 1;
     // fp16 results (tf32h engine) carry 11 significant bits (4.9e-4 relative): the sigmoid-form fit's 2.5e-5 absolute error on y Phi(y) and 1.1e-4 on the
@@ -93,13 +99,13 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
         const int av = min(BM, p.M - tm * BM) - 1, wv = min(BN, p.N - tn * BN) - 1;
 #pragma unroll
         for (int i = 0; i < APW; ++i) {
-            const int row = (wave * APW + i) * 8 + (lane >> 3);
-            aoff[i] = (unsigned)(min(row, av) * (int)lda_b + ((lane & 7) ^ swz(row)) * 16);
+            const int row = (wave * APW + i) * RPP + (KS == 64 ? lane >> 2 : lane >> 3);
+            aoff[i] = (unsigned)(min(row, av) * (int)lda_b + (KS == 64 ? (lane & 3) ^ swz64(row) : (lane & 7) ^ swz(row)) * 16);
         }
 #pragma unroll
         for (int i = 0; i < BPW; ++i) {
-            const int row = (wave * BPW + i) * 8 + (lane >> 3);
-            woff[i] = (unsigned)(min(nperm64(row), wv) * (int)ldw_b + ((lane & 7) ^ swz(row)) * 16);
+            const int row = (wave * BPW + i) * RPP + (KS == 64 ? lane >> 2 : lane >> 3);
+            woff[i] = (unsigned)(min(nperm64(row), wv) * (int)ldw_b + (KS == 64 ? (lane & 3) ^ swz64(row) : (lane & 7) ^ swz(row)) * 16);
         }
     };
     auto issue = [&](int kt0, int buf) {
@@ -109,11 +115,11 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
         char* sB = sA + ABYTES;
 #pragma unroll
         for (int i = 0; i < APW; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(abase_t + kt * 128 + aoff[i]),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(abase_t + kt * KS + aoff[i]),
                                              (__attribute__((address_space(3))) void*)(sA + (wave * APW + i) * 1024), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < BPW; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wbase_t + kt * 128 + woff[i]),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wbase_t + kt * KS + woff[i]),
                                              (__attribute__((address_space(3))) void*)(sB + (wave * BPW + i) * 1024), 16, 0, 0);
     };
     // f32 LoRA tiles T[BM][8], B[8][BN] and the bias slice [BN] (slot = tile parity: the epilogue still reads the
@@ -148,7 +154,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
         }
     };
 
-    const int abase = (wm * WMT * 16 + fr) * 128, bbase = ABYTES + (wn * 64 + fr) * 128;
+    const int abase = (wm * WMT * 16 + fr) * KS, bbase = ABYTES + (wn * 64 + fr) * KS;
     const int sa = swz(fr);
     const unsigned lds0 = lds_off(smem);
     constexpr bool pre = SIDE != 0;
@@ -174,6 +180,10 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
         issue(0, 0);
         issue_side(tm_, tn_, slot_);
         if (nk > 1) issue(1, 1);
+        if (KS == 64) {
+            if (nk > 2) issue(2, 2);
+            if (nk > 3) issue(3, 3);
+        }
     };
     prologue(tm, tn, slot);
     if (p.stagger) {
@@ -209,7 +219,8 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         // stage 0, LoRA tiles and bias of this tile have landed
-        wait_vm_le(after + (nk > 1 ? APW + BPW : 0));
+        if (KS == 64) wait_vm_le4(min(60, after + (APW + BPW) * min(3, nk - 1)));
+        else wait_vm_le(after + (nk > 1 ? APW + BPW : 0));
         if (LNF == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's LDS partials of the previous tile have landed before the others read them
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -260,6 +271,29 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
         FragHead P, Q;
         FragTail tl;
         constexpr bool AN_MM = ANAT == 0 || ANAT == 1 || ANAT == 4, AN_RD = AN_MM || ANAT == 2;
+        if constexpr (KS == 64) {
+            // Four-slot ring, one chunk per stage.  Program order of a wave: [prologue: stages 0-3] [previous epilogue: `after` operations] then per
+            // chunk c: reads + MFMAs of stage c | wait(stage c + 1) | barrier | DMA of stage c + 4 into the slot just read | ...  When stage c + 1 is
+            // waited for, the stages c + 2 and c + 3 are younger (2 x 4 pieces; fewer at the end of the tile), and so are the previous epilogue's
+            // operations as long as c + 1 is a prologue stage (c <= 2).
+            const int co = (g ^ swz64(fr)) * 16;
+            frag_head_issue64(P, lds0 + abase + co, lds0 + bbase + co);
+            auto chunk = [&](FragHead& cur, FragHead& nxt, int c) __attribute__((always_inline)) {
+                const unsigned sbo = lds0 + (c & 3) * STAGE, nsbo = lds0 + ((c + 1) & 3) * STAGE;
+                chunk_rows05_64<T>(cur, tl, sbo + abase + co, acc);
+                const int ahead = min(2, max(0, nk - 2 - c));      // stages younger than stage c + 1 that have been issued
+                wait_vm_le4(min(60, (APW + BPW) * ahead + (c <= 2 ? after : 0)));
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (c + 4 < nk) issue(c + 4, c & 3);
+                if (c + 1 < nk) frag_head_issue64(nxt, nsbo + abase + co, nsbo + bbase + co);
+                chunk_rows67<T>(cur, tl, acc);
+            };
+            for (int c = 0; c < nk; c += 2) {      // (nk is even: the host takes this form only then)
+                chunk(P, Q, c);
+                chunk(Q, P, c + 1);
+            }
+        } else {
         if (AN_RD) frag_head_issue(P, lds0 + abase + co0, lds0 + bbase + co0);
         for (int kt = 0; kt < nk; ++kt) {
             const unsigned sbo = lds0 + (kt & 1) * STAGE, nsbo = lds0 + ((kt + 1) & 1) * STAGE;
@@ -280,6 +314,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
             if (kt + 2 < nk) issue(kt + 2, kt & 1);
             if (kt + 1 < nk && AN_RD) frag_head_issue(P, nsbo + abase + co0, nsbo + bbase + co0);
             if (AN_MM) chunk_rows67<T>(Q, tl, acc);
+        }
         }
         const int ctm = tm, ctn = tn, cslot = slot;
         GD_PROBE({ const unsigned long long c = __builtin_amdgcn_s_memtime(); pm += c - pc0; pc0 = c; })

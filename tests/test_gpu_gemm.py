@@ -199,6 +199,31 @@ def test_gemm_nt_persistent_schedule_knobs_do_not_change_results():
             lib().gd_debug_set(name.encode(), val)
 
 
+@pytest.mark.parametrize("M,N,K", [(256 * 37 + 19, 768, 768), (4096, 3072, 768), (2048 + 77, 768, 3072)])
+def test_gemm_nt_four_slot_ring_equals_the_two_slot_ring(M, N, K):
+    """GD_GEMM_K64 (round 5, an experiment that measured SLOWER — +2.9 ms per step, profiles/README.md round 5 — and is off): the fp16-operand
+    persistent kernel on a four-slot ring of 64-byte stages (64-byte-row LDS image, swz64, one barrier per MFMA chunk) walks K in the same order
+    as the two-slot ring: bit-identical results, with each of the step's epilogues."""
+    from gd_amd import ops
+    from gd_amd._lib import lib
+    a, w = _mk((M, K), torch.float16, 81), _mk((N, K), torch.float16, 82) * 0.05
+    bias, res = _mk((N,), torch.float32, 83), _mk((M, N), torch.float32, 84)
+    gate = _mk((M, N), torch.float16, 85)
+    runs = {"plain fp16 C": lambda: ops.gemm_nt(a, w, bias=bias, out_dtype=torch.float16),
+            "residual, f32 C": lambda: ops.gemm_nt(a, w, bias=bias, residual=res, out_dtype=torch.float32),
+            "residual + fp16 copy": lambda: torch.cat([t.float() for t in ops.gemm_nt_copy16(a, w, res, bias=bias)], 1),
+            "gated (dact 3)": lambda: ops.gemm_nt(a, w, dact_src=gate, dact=3, out_dtype=torch.float16)}
+    pre = torch.empty(M, N, dtype=torch.float16, device="cuda")
+    runs["GELU + stored derivative"] = lambda: torch.cat([ops.gemm_nt(a, w, bias=bias, act=3, preact=pre, out_dtype=torch.float16), pre.clone()], 1)
+    ref = {k: f() for k, f in runs.items()}
+    try:
+        assert lib().gd_debug_set(b"gemm_k64", 1) == 0
+        for k, f in runs.items():
+            assert torch.equal(f(), ref[k]), k
+    finally:
+        lib().gd_debug_set(b"gemm_k64", 0)
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 1e-2)])
 def test_gemm_nt_batched_strided(dtype, tol):
     from gd_amd import ops

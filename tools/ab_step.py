@@ -1,5 +1,5 @@
 """Round 5: A/B of host-side options on the benched step (tf32h, ViT-B/14, 32 pairs, 518^2) in ONE process, interleaved rounds (the pool's boxes differ
-by +-3 %: only same-process pairs mean anything).  Usage: python3 tools/ab_step.py [name=v0,v1,... ...]; default: the round-5 switches.
+by +-3 %: only same-process pairs mean anything).  Usage: python3 tools/ab_step.py [name=v0,v1,... ...] (options.py names, or lib.<knob> for csrc/gd_knobs.h); default: the round-5 switches.
 Each setting: 2 warm-up steps + 6 timed steps per round, 3 rounds, best and all rounds printed."""
 import os
 import sys
@@ -30,16 +30,20 @@ def main():
         return (time.perf_counter() - t0) / steps * 1e3
 
     timed()
+    L = gd_amd._lib.lib()
     for spec in specs:
         name, vals = spec.split("=")
         vals = [int(v) for v in vals.split(",")]
-        keep = option(name)
+        lib_knob = name.startswith("lib.")      # lib.<knob>: an option of the library (csrc/gd_knobs.h) through gd_debug_set
+        get = (lambda: L.gd_debug_get(name[4:].encode())) if lib_knob else (lambda: option(name))
+        put = (lambda v: L.gd_debug_set(name[4:].encode(), v)) if lib_knob else (lambda v: set_option(name, v))
+        keep = get()
         res = {v: [] for v in vals}
         for _ in range(3):
             for v in vals:
-                set_option(name, v)
+                put(v)
                 res[v].append(timed())
-        set_option(name, keep)
+        put(keep)
         print(f"{name}: " + " | ".join(f"{v}: best {min(r):.2f} ms  {[round(x, 2) for x in r]}" for v, r in res.items()), flush=True)
 
 
