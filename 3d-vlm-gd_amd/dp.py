@@ -65,6 +65,7 @@ class OverlappedGradReducer:
     def __init__(self, params, views, flat_grad, early, world):
         self.world, self.flat = world, flat_grad
         self.model, self.done = None, []
+        self.per_block = True      # False: the blocks' slices wait for start() with the rest of the late ranges (bench.py's comm.variants measures both)
         early_ids = {id(p) for p in early}
         self.early = [p for p in params if id(p) in early_ids]
         base = flat_grad.data_ptr()
@@ -85,7 +86,7 @@ class OverlappedGradReducer:
                 self.handles.append(p.register_post_accumulate_grad_hook(self._hook))
         if model is not None:
             self.model = model
-        if self.world > 1 and self.model is not None:
+        if self.world > 1 and self.model is not None and self.per_block:
             self.model.block_grad_hook = self._block_done
 
     def detach(self):

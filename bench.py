@@ -518,6 +518,17 @@ def comm_report(job, args, dev, dt):
     job.reducer = keep
     job.reducer.world = world
     job.reducer.attach()
+    if isinstance(job.reducer, dp.OverlappedGradReducer) and job.reducer.model is not None:
+        # the blocks' weight-gradient slices exchanged as each block's backward returns (the default) against all of them after the backward
+        job.reducer.detach()
+        job.reducer.per_block = not job.reducer.per_block
+        job.reducer.attach()
+        dtb, _ = job.timed(args.steps, 1, dev)
+        variants["per_block_chunks_" + ("on" if job.reducer.per_block else "off")] = {"ms_per_step": round(dtb / args.steps * 1e3, 3),
+                                                                                      "exposed_comm_frac": round(max(0.0, (dtb - dt0) / dtb), 4)}
+        job.reducer.detach()
+        job.reducer.per_block = not job.reducer.per_block
+        job.reducer.attach()
     alt = 0 if args.reserve_cus else 8
     dp.reserve_cus_for_collectives(alt)
     dtr, _ = job.timed(args.steps, 1, dev)
