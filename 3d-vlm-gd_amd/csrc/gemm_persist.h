@@ -93,7 +93,8 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
     // moment, rotated one tile fetches a slice and the others hit it.
     int krot = 0;
     auto set_tile = [&](int tm, int tn) {
-        krot = p.k_rot ? (tn * p.k_rot + tm) % nk : 0;
+        // (KS = 64: the rotation is taken in 128-byte steps and applied in chunks, so both ring forms walk K in the same order: bit-identical sums)
+        krot = p.k_rot ? ((tn * p.k_rot + tm) % (nk * KS / 128)) * (128 / KS) : 0;
         abase_t = Ab + (long)tm * BM * lda_b;
         wbase_t = Wb + (long)tn * BN * ldw_b;
         const int av = min(BM, p.M - tm * BM) - 1, wv = min(BN, p.N - tn * BN) - 1;
