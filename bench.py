@@ -291,7 +291,7 @@ def main():
             out["roofline"] = gemm_roofline(prof, args.dtype, dt, args.steps)
             # memory-side bytes per launch: PMC counters cannot be read from inside the timed run, so this REPLAYS the committed
             # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE measurement of this same command (profiles/README.md), default workload only
-            pmc = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_gemm_traffic_{args.dtype}.json") for r in (4, 3)) if os.path.exists(q)), None)
+            pmc = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_gemm_traffic_{args.dtype}.json") for r in (5, 4, 3)) if os.path.exists(q)), None)
             if (pmc is not None and backbone == "vit_base" and P == 32
                     and args.geometry == "shared" and variant == "mast3r"):
                 with open(pmc) as fh:
@@ -431,9 +431,9 @@ def cost_volume_roofline(job, args, dev, variant):
     ones = torch.ones(P, hw, dtype=torch.bool, device=dev)
     # keypoint-patch masks keep at most N_kp rows per view: the trainer (finetune.calculate_cost_loss) passes that bound and the op runs its kept-row form
     kmax = int(b["kp_1"].shape[1]) if variant == "mast3r" else None
-    # (the kept-row kernel's own PMC passes: round 4, tools/pmc_cv_r04.sh — taken on the fp16 copies; the bf16 instantiation moves the same bytes)
-    bench_masks, tf = leg(m1, m2, "r04_pmc_cost_volume_traffic_rows.json" if kmax else None, kmax=kmax)
-    unmasked, tfu = leg(ones, ones, "r03_pmc_cost_volume_traffic_full.json")
+    # (the kernels' own PMC passes of round 5, tools/prof_r05.sh — the kept-row one taken on the fp16 copies; the bf16 instantiation moves the same bytes)
+    bench_masks, tf = leg(m1, m2, "r05_pmc_cost_volume_traffic_rows.json" if kmax else None, kmax=kmax)
+    unmasked, tfu = leg(ones, ones, "r05_pmc_cost_volume_traffic_full.json")
     tfb = timed(m1, m2, backward=True, kmax=kmax)
     tfbu = timed(ones, ones, backward=True)
     out = {"kernel": "cost_volume_kl fwd (persistent MFMA contraction + softmax-KL; sparse keypoint masks: both directions as compacted kept-row problems, "
