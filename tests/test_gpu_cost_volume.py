@@ -137,7 +137,7 @@ def _debug(name, value):
 # buffers and the one-tile-ahead teacher prefetch all wrap around many times.  hw = 1369 has a ragged last tile (89 rows / columns), hw = 768 none,
 # hw = 200 two tiles per side (a pair's tiles < blocks per XCD: empty slices).
 # The kernel is an EXPERIMENT behind GD_CV_PANEL (1: two 4-wave blocks per CU, 64-row panels; 8: one 8-wave block, 128-row panels); the default
-# forward is the round-4 persistent kernel.  Kept under test so that the measurements in profiles/NOTES_r05.md can be re-run on a correct kernel.
+# forward is the round-4 persistent kernel.  Kept under test so that the measurements in DESIGN.md section 5 / profiles/r05_cv_panel_*.txt can be re-run on a correct kernel.
 @pytest.mark.parametrize("variant,mode,P,hw,C,grid,panel", [("vggt", "bf16", 3, 1369, 768, 0, 1), ("vggt", "h", 2, 1369, 768, 16, 1), ("mast3r", "h", 9, 672, 768, 8, 8),
                                                             ("vggt", "bf16", 11, 200, 768, 0, 8), ("mast3r", "h", 1, 1369, 768, 0, 1)])
 def test_panel_forward_matches_oracle_and_round4_kernel(variant, mode, P, hw, C, grid, panel):
@@ -170,7 +170,7 @@ def test_panel_forward_matches_oracle_and_round4_kernel(variant, mode, P, hw, C,
         _debug("cv_panel", 0)
         old = run()
     finally:
-        _debug("cv_panel", 0)                      # the default: the experiment is not the product path (it measured slower, profiles/NOTES_r05.md)
+        _debug("cv_panel", 0)                      # the default: the experiment is not the product path (it measured slower: DESIGN.md section 5)
         _debug("cv_grid", 0)
     assert torch.equal(new, new2)
     assert rel_err(new, old) < 2e-6
