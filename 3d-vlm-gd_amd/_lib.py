@@ -52,6 +52,8 @@ SIGNATURES = {
                                   c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p]),
     "gd_tap_mean_norm_fwd_h": (c_int, [c_void_p, c_int, c_long, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "gd_adapter_fused_h_supported": (c_int, [c_int, c_int, c_long]),
+    "gd_adapter_fused_h_ln": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p,
+                                      c_int, c_int, c_int, c_void_p]),
     "gd_adapter_fused_h": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_int, c_int, c_int, c_void_p]),
     "gd_gemm_tn_scaled": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_long, c_long,

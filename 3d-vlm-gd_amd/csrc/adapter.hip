@@ -315,22 +315,34 @@ __global__ __launch_bounds__(256, 1) void adapter_persist_kernel(const bf16* __r
 // load at all.  Before, every tile re-read its 96 KB of x from L2 and streamed the 96 KB second weight from L2, and those loads sat behind the next
 // tile's 48 HBM prefetch loads of the same wave in the in-order vector-memory queue: the phase waited for the prefetch it was meant to hide.  Replaces, per call, a cast pass, the N = 64 GEMM, a second cast and the
 // K = 64 GEMM (whose 129 us are pure residual / result traffic) of the unfused tf32h path.
-template <int D>
+// LN (round 5): the kernel is the only producer of a residual-stream tensor that holds WHOLE rows on chip, so it can also write what the NEXT block's
+// LayerNorm 1 would compute from its result — ln16 = fp16(LayerNorm(out32; ln_w, ln_b, ln_eps)) with the row statistics the backward needs — and that
+// block's 75 us LayerNorm pass (269 MB read again + 135 MB written) shrinks to the 135 MB write here.  Phase 2 writes its fp32 result back over the
+// residual tile in LDS (each thread over exactly the words it read), a third phase takes the rows from there: one wave per 8 rows, a row in registers
+// (12 floats per lane), mean and variance by two wave reductions as ln_fwd_kernel does — the same statistics to the last bit of rounding order.
+template <int D, bool LN = false>
 __global__ __launch_bounds__(256, 1) void adapter_persist_h_kernel(const float* __restrict__ x32, const f16* __restrict__ w1, const f16* __restrict__ w2,
                                                                    const f16* __restrict__ gate, f16* __restrict__ hout, float* __restrict__ out32,
                                                                    f16* __restrict__ out16, const float* in_scale, const float* alpha_dev,
-                                                                   const float* copy_scale, int M) {
+                                                                   const float* copy_scale, int M, const float* __restrict__ ln_w = nullptr,
+                                                                   const float* __restrict__ ln_b = nullptr, float ln_eps = 0.f, f16* __restrict__ ln16 = nullptr,
+                                                                   float* __restrict__ ln_mean = nullptr, float* __restrict__ ln_rstd = nullptr) {
     constexpr int CPR = D / 8, KS = D / 32, NG = D / 256;
     constexpr int PPT = AD_BM * CPR / 256;      // fp16 16-byte chunks (8 elements = two fp32 16-byte loads) of a tile per thread
     static_assert(D <= 768, "both weights and the fp32 prefetch have to fit 512 registers");
     __shared__ __attribute__((aligned(16))) char sX[AD_BM * D * 2];
     __shared__ __attribute__((aligned(16))) char sR[AD_BM * D * 4];      // the same tile in fp32: the residual of phase 2
     __shared__ __attribute__((aligned(16))) char sH[AD_BM * AD_BOT * 2];
+    __shared__ __attribute__((aligned(16))) float sLN[LN ? 2 * D : 4];   // LN: the next block's LayerNorm affine (gamma | beta)
+    if (LN) {
+        for (int i = threadIdx.x; i < D; i += 256) { sLN[i] = ln_w[i]; sLN[D + i] = ln_b[i]; }
+    }
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ntiles = (M + AD_BM - 1) / AD_BM;
-    const bool gated = gate != nullptr;
-    const float sin = in_scale ? *in_scale : 1.0f, alpha = alpha_dev ? *alpha_dev : 1.0f, scp = copy_scale ? *copy_scale : 1.0f;
+    const bool gated = !LN && gate != nullptr;      // (LN: the forward form only — ReLU gate, no scales, no fp16 copy of the un-normed result)
+    const float sin = (!LN && in_scale) ? *in_scale : 1.0f, alpha = (!LN && alpha_dev) ? *alpha_dev : 1.0f, scp = (!LN && copy_scale) ? *copy_scale : 1.0f;
+    if (LN) out16 = nullptr;
 
     int tile = blockIdx.x;
     f32x4 pre[PPT][2];
@@ -454,7 +466,45 @@ __global__ __launch_bounds__(256, 1) void adapter_persist_h_kernel(const float* 
                         const f16x4 h = f16_sat4(o[0] * scp, o[1] * scp, o[2] * scp, o[3] * scp);
                         *(f16x4*)(out16 + (long)(row0 + row) * D + col) = h;
                     }
+                    if (LN) *(f32x4*)(sR + (row * D + col) * 4) = o;      // (the words this thread just read: the result replaces the residual)
                 }
+        }
+        if (LN) {
+            // ---- phase 3: LayerNorm of the tile's result rows for the next block (wave w: rows 8 w .. 8 w + 7) ----
+            __syncthreads();
+            constexpr int NV = D / 256;      // 16-byte chunks of a row per lane
+#pragma unroll 1
+            for (int rr = 0; rr < AD_BM / 4; ++rr) {
+                const int row = (AD_BM / 4) * wave + rr;
+                if (row0 + row >= M) break;
+                // (three passes over the row in LDS instead of the row in registers: the kernel has no 12 registers to spare — both weights and the next
+                //  tile's 96-register prefetch are live here — and an LDS pass of 3 KB per row costs less than the spills did: 188 bytes per lane)
+                const char* rp = sR + (row * D + lane * 4) * 4;
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {
+                    const f32x4 t = *(const f32x4*)(rp + k * 1024);
+                    s += (t[0] + t[1]) + (t[2] + t[3]);
+                }
+                const float mu = wave_sum(s) * (1.0f / (float)D);
+                float q = 0.f;
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {
+                    const f32x4 t = *(const f32x4*)(rp + k * 1024);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float d = t[e] - mu; q = fmaf(d, d, q); }
+                }
+                const float rs = rsqrtf(wave_sum(q) * (1.0f / (float)D) + ln_eps);
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {
+                    const int c0 = (lane + 64 * k) * 4;
+                    const f32x4 t = *(const f32x4*)(rp + k * 1024);
+                    const f32x4 gm = *(const f32x4*)(sLN + c0), bt = *(const f32x4*)(sLN + D + c0);
+                    *(f16x4*)(ln16 + (long)(row0 + row) * D + c0) = f16_sat4(fmaf((t[0] - mu) * rs, gm[0], bt[0]), fmaf((t[1] - mu) * rs, gm[1], bt[1]),
+                                                                           fmaf((t[2] - mu) * rs, gm[2], bt[2]), fmaf((t[3] - mu) * rs, gm[3], bt[3]));
+                }
+                if (lane == 0) { ln_mean[row0 + row] = mu; ln_rstd[row0 + row] = rs; }
+            }
         }
     }
 }
@@ -501,6 +551,31 @@ extern "C" int gd_adapter_fused(const void* x, const void* w1, const void* w2, c
 
 // fp32 x / out with fp16 operands (tf32h engine): out32 = x32 + alpha * gate(fp16(x32 * in_scale) . w1^T) . w2^T, hidden [M, 64] fp16 (the gated
 // first product, still times in_scale), out16 (optional) = fp16(out32 * copy_scale); in_scale / alpha / copy_scale are DEVICE scalars (null = 1).
+// gd_adapter_fused_h plus the NEXT block's LayerNorm 1 of the result, from the rows the kernel still holds on chip: ln16 [M, D] = fp16(LayerNorm(out32)),
+// ln_mean / ln_rstd [M] (what gd_layernorm_bwd* takes).  Forward form only (no gate, no scales).
+extern "C" int gd_adapter_fused_h_ln(const float* x32, const void* w1, const void* w2, void* hidden, float* out32, const float* ln_w, const float* ln_b,
+                                     float ln_eps, void* ln16, float* ln_mean, float* ln_rstd, int M, int D, int bottleneck, void* stream) {
+    GD_REQUIRE(M > 0 && bottleneck == AD_BOT && (D == 256 || D == 512 || D == 768) && M >= 256L * AD_BM,
+               "gd_adapter_fused_h_ln: unsupported configuration M=%d D=%d bottleneck=%d (bottleneck 64, D in {256,512,768}, M >= 8192)", M, D, bottleneck);
+    GD_REQUIRE(ln_w && ln_b && ln16 && ln_mean && ln_rstd, "gd_adapter_fused_h_ln: the LayerNorm affine and all three outputs are required");
+    GD_REQUIRE(((uintptr_t)x32 & 15) == 0 && ((uintptr_t)w1 & 15) == 0 && ((uintptr_t)w2 & 15) == 0 && ((uintptr_t)out32 & 15) == 0 &&
+                   ((uintptr_t)hidden & 15) == 0 && ((uintptr_t)ln16 & 7) == 0,
+               "gd_adapter_fused_h_ln: x32, w1, w2, out32, hidden must be 16-byte aligned, ln16 8-byte");
+    hipStream_t s = (hipStream_t)stream;
+    const int cus = gd_knobs().ncu, blocks = min(cus, gd_cdiv(M, AD_BM));
+#define GD_ADL(DD) hipLaunchKernelGGL((adapter_persist_h_kernel<DD, true>), dim3(blocks), dim3(256), 0, s, x32, (const f16*)w1, (const f16*)w2, (const f16*)nullptr, \
+                                      (f16*)hidden, out32, (f16*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, M, ln_w, ln_b, ln_eps, \
+                                      (f16*)ln16, ln_mean, ln_rstd)
+    switch (D) {
+        case 256: GD_ADL(256); break;
+        case 512: GD_ADL(512); break;
+        default: GD_ADL(768); break;
+    }
+#undef GD_ADL
+    GD_LAUNCH_OK();
+    return 0;
+}
+
 extern "C" int gd_adapter_fused_h_supported(int D, int bottleneck, long M) { return bottleneck == AD_BOT && (D == 256 || D == 512 || D == 768) && M >= 256L * AD_BM; }
 extern "C" int gd_adapter_fused_h(const float* x32, const void* w1, const void* w2, const void* gate_src, void* hidden, float* out32, void* out16,
                                   const float* in_scale, const float* alpha_dev, const float* copy_scale, int M, int D, int bottleneck, void* stream) {

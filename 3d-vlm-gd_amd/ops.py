@@ -606,6 +606,23 @@ def adapter_fused_h(x32, w1, w2, gate_src=None, in_scale=None, alpha_dev=None, c
     return out, hidden, copy
 
 
+def adapter_fused_h_ln(x32, w1, w2, ln_w, ln_b, ln_eps):
+    """adapter_fused_h (forward form) that also writes the NEXT block's LayerNorm 1 of its result: -> (out32, hidden fp16, y16 = fp16(LN(out32)), mean, rstd)
+    (gd_adapter_fused_h_ln)."""
+    M, D = x32.shape
+    bott = w1.shape[0]
+    _req(x32.dtype == torch.float32 and x32.is_contiguous() and w1.dtype == torch.float16 and w2.dtype == torch.float16 and w1.is_contiguous() and
+         w2.is_contiguous() and w1.shape == (bott, D) and w2.shape == (D, bott) and ln_w.dtype == torch.float32 and ln_b.dtype == torch.float32, "adapter_fused_h_ln: layout")
+    out = torch.empty_like(x32)
+    hidden = torch.empty(M, bott, dtype=torch.float16, device=x32.device)
+    y16 = torch.empty(M, D, dtype=torch.float16, device=x32.device)
+    mean = torch.empty(M, dtype=torch.float32, device=x32.device)
+    rstd = torch.empty(M, dtype=torch.float32, device=x32.device)
+    check(lib().gd_adapter_fused_h_ln(ptr(x32), ptr(w1), ptr(w2), ptr(hidden), ptr(out), ptr(ln_w), ptr(ln_b), float(ln_eps), ptr(y16), ptr(mean), ptr(rstd),
+                                      M, D, bott, stream()), "gd_adapter_fused_h_ln")
+    return out, hidden, y16, mean, rstd
+
+
 # ----------------------------------------------------------------------------------------------
 # normalisation
 # ----------------------------------------------------------------------------------------------

@@ -363,6 +363,11 @@ int gd_gemm_tn_scaled(const void* Y, const void* X, float* G, int M, int N, int 
  * out32 = x32 + alpha * gate(fp16(x32 * in_scale) . w1^T) . w2^T; hidden [M,64] fp16 = the gated first product (relu when gate_src is null, else kept
  * where gate_src > 0); out16 (nullable) = fp16(out32 * copy_scale).  in_scale / alpha_dev / copy_scale: DEVICE scalars, null = 1. */
 int gd_adapter_fused_h_supported(int D, int bottleneck, long M);
+/* gd_adapter_fused_h (forward form: ReLU gate, no scales) that ALSO writes the LayerNorm of its result — the next block's `norm1` (timm Block.forward:
+ * x = x + ...; the next block starts with norm1(x)) — from the rows the kernel still holds on chip: ln16 [M, D] = fp16(LayerNorm(out32; ln_w, ln_b, ln_eps)),
+ * ln_mean / ln_rstd [M] = the row statistics gd_layernorm_bwd* takes.  Same shapes as gd_adapter_fused_h. */
+int gd_adapter_fused_h_ln(const float* x32, const void* w1, const void* w2, void* hidden, float* out32, const float* ln_w, const float* ln_b,
+                          float ln_eps, void* ln16, float* ln_mean, float* ln_rstd, int M, int D, int bottleneck, void* stream);
 int gd_adapter_fused_h(const float* x32, const void* w1, const void* w2, const void* gate_src, void* hidden, float* out32, void* out16,
                        const float* in_scale, const float* alpha_dev, const float* copy_scale, int M, int D, int bottleneck, void* stream);
 int gd_tap_mean_norm_fwd_h(const void* const* grids, int ngrid, long bstride, int prefix, float* out, void* out16, float* inv_norm,

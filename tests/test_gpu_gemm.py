@@ -497,6 +497,33 @@ def test_adapter_fused_fp16_operands(M):
         ops.adapter_fused_h(x[:1000], down, up)
 
 
+@pytest.mark.parametrize("M,D", [(32800, 768), (33007, 768), (8192 + 31, 256)])
+def test_adapter_fused_with_the_next_blocks_layernorm(M, D):
+    """gd_adapter_fused_h_ln (round 5): the adapter pass that also leaves fp16(LayerNorm(out)) and the row statistics — what the next block's norm1 would
+    compute from `out` in a pass of its own.  `out` / hidden bit-identical to gd_adapter_fused_h; the statistics and the normed rows against
+    gd_layernorm_fwd on that `out` (same two-reduction arithmetic: the statistics to fp32 rounding, the fp16 rows to one rounding), and against fp64.
+    Ragged last tile (33007 = 1031 x 32 + 15), rows with a large mean, a massive channel."""
+    from gd_amd import ops
+    bott = 64
+    x = _mk((M, D), torch.float32, 91)
+    x[:, 5] += 30.0
+    x[: M // 4] += 4.0
+    down, up = (_mk((bott, D), torch.float32, 92) * 0.05).half(), (_mk((D, bott), torch.float32, 93) * 0.05).half()
+    g, b = 1.0 + 0.2 * _mk((D,), torch.float32, 94), 0.3 * _mk((D,), torch.float32, 95)
+    eps = 1e-6
+    out0, hid0, _ = ops.adapter_fused_h(x, down, up)
+    out, hid, y16, mean, rstd = ops.adapter_fused_h_ln(x, down, up, g, b, eps)
+    assert torch.equal(out, out0) and torch.equal(hid, hid0)
+    y_ref, m_ref, r_ref = ops.layernorm_fwd(out, g, b, eps, out_dtype=torch.float16)
+    assert rel_err(mean, m_ref) < 1e-6 and rel_err(rstd, r_ref) < 1e-6
+    assert float((y16.float() - y_ref.float()).abs().max()) <= 2e-3 * float(y_ref.float().abs().max())       # (one fp16 ulp of the largest entries)
+    assert rel_err(y16, y_ref) < 1e-3                            # (max-norm: entries whose fp32 value sits on an fp16 rounding boundary differ by one ulp)
+    assert float((y16.float() - y_ref.float()).pow(2).mean().sqrt()) < 5e-5 * float(y_ref.float().pow(2).mean().sqrt()) + 1e-6 or \
+        float((y16 != y_ref).float().mean()) < 0.01           # ... and they are rare
+    want = torch.nn.functional.layer_norm(out.double(), (D,), g.double(), b.double(), eps)
+    assert rel_err(y16, want) < 5e-4
+
+
 def test_gemm_tn_rounds_an_fp32_operand_to_fp16_in_the_kernel():
     """gd_gemm_tn with one fp16 and one fp32 operand (tf32h weight gradients): the fp32 one is rounded to fp16 on its way into LDS — an fp32 Y
     (a gradient) under the scale 1 / alpha_dev, which alpha undoes — and the result equals the cast-then-contract path."""

@@ -159,6 +159,20 @@ def bench_adapter():
         print(f"adapter D={D}: fused fwd {t*1e6:7.1f} us ({by/t/1e9:6.0f} GB/s)  bwd-to-input {tb*1e6:7.1f} us | two GEMMs {t2*1e6:7.1f} us")
 
 
+def bench_adapter_ln():
+    """Round 5: the adapter pass that also writes the next block's LayerNorm (gd_adapter_fused_h_ln) against adapter pass + LayerNorm pass, M = 87 680, D = 768."""
+    M, D = 87680, 768
+    x = torch.randn(M, D, device="cuda")
+    down, up = (0.05 * torch.randn(64, D, device="cuda")).half(), (0.05 * torch.randn(D, 64, device="cuda")).half()
+    g, b = torch.ones(D, device="cuda"), torch.zeros(D, device="cuda")
+    out = ops.adapter_fused_h(x, down, up)[0]
+    for _ in range(3):
+        ta = timeit(lambda: ops.adapter_fused_h(x, down, up))
+        tl = timeit(lambda: ops.layernorm_fwd(out, g, b, 1e-6, out_dtype=torch.float16))
+        tf = timeit(lambda: ops.adapter_fused_h_ln(x, down, up, g, b, 1e-6))
+        print(f"adapter_ln: adapter {ta * 1e6:7.1f} us + LayerNorm {tl * 1e6:6.1f} us = {(ta + tl) * 1e6:7.1f} us | fused {tf * 1e6:7.1f} us", flush=True)
+
+
 def pmc_cv():
     """one configuration, few launches: the target of `rocprofv3 --pmc ...` runs (profiles/README.md)."""
     P, hw, C = 32, 1369, 768
@@ -427,6 +441,8 @@ if __name__ == "__main__":
         bench_gemm_anat()
     if "cv" in which:
         bench_cv()
+    if "adapter_ln" in which:
+        bench_adapter_ln()
     if "cv_ab" in which:
         bench_cv_ab()
     if "gelu" in which:
