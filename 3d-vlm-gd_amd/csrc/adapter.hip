@@ -439,7 +439,10 @@ __global__ __launch_bounds__(256, 1) void adapter_persist_h_kernel(const float* 
         const bool full = row0 + AD_BM <= M;
 #pragma unroll
         for (int gq = 0; gq < NG; ++gq) {
-            const int col = wave * (D / 4) + 64 * gq + 4 * c;
+            // (LN: the lane's column offset behind an optimisation barrier — hoisted out of the tile loop, the 64-bit store addresses derived from it were
+            //  spilled and RELOADED here, behind the next tile's 24 HBM prefetch loads in the in-order vector-memory queue: phase 2 waited for the prefetch)
+            int col = wave * (D / 4) + 64 * gq + 4 * c;
+            if (LN) asm volatile("" : "+v"(col));
             f32x4 acc[2][4];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -473,13 +476,15 @@ __global__ __launch_bounds__(256, 1) void adapter_persist_h_kernel(const float* 
             // ---- phase 3: LayerNorm of the tile's result rows for the next block (wave w: rows 8 w .. 8 w + 7) ----
             __syncthreads();
             constexpr int NV = D / 256;      // 16-byte chunks of a row per lane
-#pragma unroll 1
+#pragma unroll 4      // (four rows in flight: a row alone is a chain of LDS and cross-lane latencies)
             for (int rr = 0; rr < AD_BM / 4; ++rr) {
                 const int row = (AD_BM / 4) * wave + rr;
-                if (row0 + row >= M) break;
+                if (row0 + row >= M) continue;
                 // (three passes over the row in LDS instead of the row in registers: the kernel has no 12 registers to spare — both weights and the next
                 //  tile's 96-register prefetch are live here — and an LDS pass of 3 KB per row costs less than the spills did: 188 bytes per lane)
-                const char* rp = sR + (row * D + lane * 4) * 4;
+                int l4 = lane * 4;
+                asm volatile("" : "+v"(l4));      // (as above: nothing lane-derived of this phase may be kept in registers across the tile loop)
+                const char* rp = sR + (row * D + l4) * 4;
                 float s = 0.f;
 #pragma unroll
                 for (int k = 0; k < NV; ++k) {
@@ -497,7 +502,7 @@ __global__ __launch_bounds__(256, 1) void adapter_persist_h_kernel(const float* 
                 const float rs = rsqrtf(wave_sum(q) * (1.0f / (float)D) + ln_eps);
 #pragma unroll
                 for (int k = 0; k < NV; ++k) {
-                    const int c0 = (lane + 64 * k) * 4;
+                    const int c0 = l4 + 256 * k;
                     const f32x4 t = *(const f32x4*)(rp + k * 1024);
                     const f32x4 gm = *(const f32x4*)(sLN + c0), bt = *(const f32x4*)(sLN + D + c0);
                     *(f16x4*)(ln16 + (long)(row0 + row) * D + c0) = f16_sat4(fmaf((t[0] - mu) * rs, gm[0], bt[0]), fmaf((t[1] - mu) * rs, gm[1], bt[1]),
