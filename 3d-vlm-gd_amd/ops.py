@@ -243,6 +243,21 @@ def ln_stats_take(x, eps):
 
 def ln_stats_clear():
     _LN_STATS.clear()
+    _LN_OUT.clear()
+
+
+# The NEXT block's LayerNorm 1 of a block output, written by the producer that still held the rows on chip (adapter_fused_h_ln): keyed by the output's
+# address until the next block's forward takes it (vit._BlockFn.forward) instead of running its own LayerNorm pass.
+_LN_OUT = {}
+
+
+def ln_out_put(x, y, mean, rstd, w):
+    _LN_OUT[x.data_ptr()] = (y, mean, rstd, w.data_ptr(), x.numel())
+
+
+def ln_out_take(x, w):
+    rec = _LN_OUT.pop(x.data_ptr(), None)
+    return rec[:3] if rec is not None and rec[3] == w.data_ptr() and rec[4] == x.numel() else None
 
 
 def cast16(x, scale=1.0, scale_dev=None):

@@ -21,6 +21,9 @@ _DEFS = {
     # instructions per item in a GELU epilogue that is issue-bound): 58.51 -> 58.36 ms per step in one process, 60.30 -> 60.74 ms of kernel time
     # under rocprofv3 — a wash.  Off by default; kept under test (tests/test_gpu_gemm.py, test_gpu_step.py).
     "ln2_fold": ("GD_LN2_FOLD", 0),
+    # tf32h: the fused adapter kernel also writes the NEXT block's LayerNorm 1 (fp16 rows + statistics) from the rows it still holds on chip
+    # (gd_adapter_fused_h_ln; forward_all only): that block then runs no LayerNorm pass of its own
+    "adapter_ln": ("GD_ADAPTER_LN", 1),
     "direct_grads": ("GD_DIRECT_GRADS", 1),      # fit_step: block weight gradients accumulate straight into the flat gradient buffer
     # the blocks' weight-gradient contractions (adapter up / down, LoRA-A: streams over the activations that nothing downstream in the backward reads) on
     # a SECOND stream, with `wgrad_reserve_cus` compute units kept free of the persistent kernels during the backward (csrc/gd_knobs.h reserve_cus).

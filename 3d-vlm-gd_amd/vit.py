@@ -191,7 +191,11 @@ class _BlockFn(torch.autograd.Function):
         x = x.contiguous()
         need = x.requires_grad or any(t is not None and t.requires_grad for t in (a_q, b_q, a_v, b_v, down, up))
         h16 = {"out_dtype": torch.float16} if plan["x3"] == "h" else {}      # tf32h: LN(x) only ever feeds matrix products — written as their fp16 operand
-        y1, mean1, rstd1 = ops.layernorm_fwd(x, plan["ln1_w"], plan["ln1_b"], plan["eps1"], save_stats=need, **h16)
+        pre1 = ops.ln_out_take(x, plan["ln1_w"]) if plan["x3"] == "h" else None     # the block above left this block's LayerNorm 1 (its adapter kernel: options.adapter_ln)
+        if pre1 is not None:
+            y1, mean1, rstd1 = pre1
+        else:
+            y1, mean1, rstd1 = ops.layernorm_fwd(x, plan["ln1_w"], plan["ln1_b"], plan["eps1"], save_stats=need, **h16)
         if need and plan.get("offer_ln_stats"):      # this block's input is a tap: its row statistics serve the tap's `model.norm` too (_TapFn)
             ops.ln_stats_put(x, mean1, rstd1, plan["eps1"])
         t = at = bt = None
@@ -256,7 +260,12 @@ class _BlockFn(torch.autograd.Function):
             elif ad_h:      # tf32h: one pass — x2 read once (rounded to fp16 in flight), both products on the fp16 MFMA, fp32 residual add
                 w_dn = tw["down_w3"] if tw is not None and "down_w3" in tw else _opw(down_T, fmt)
                 w_up = tw["up_w3"] if tw is not None and "up_w3" in tw else _opw(up_T, fmt)
-                out, hd16, _ = ops.adapter_fused_h(x2, w_dn, w_up)
+                nl = plan.get("next_ln")
+                if nl is not None:      # ... and the NEXT block's LayerNorm 1 of the result, from the rows the kernel still holds (that block takes it from the registry)
+                    out, hd16, y1n, mean_n, rstd_n = ops.adapter_fused_h_ln(x2, w_dn, w_up, *nl)
+                    ops.ln_out_put(out, y1n, mean_n, rstd_n, nl[0])
+                else:
+                    out, hd16, _ = ops.adapter_fused_h(x2, w_dn, w_up)
                 hd = hd16
             elif plan["x3"]:        # tf32x: both projections as split-precision products on the bf16 kernels (the fp32 tile kernel: 2 x 370 us)
                 w_dn = tw["down_w3"] if tw is not None and "down_w3" in tw else _opw(down_T, fmt)
@@ -451,9 +460,10 @@ class _BlockFn(torch.autograd.Function):
         return dx, None, None, None, g_aq, g_bq, g_av, g_bv, g_down, g_up
 
 
-def run_block(blk, x, offer_ln_stats=False):
+def run_block(blk, x, offer_ln_stats=False, next_block=None):
     """x [B, Nt, D] (engine dtype) -> block output, fused with its LoRA / adapter wrappers.  offer_ln_stats: the row statistics the block's first
-    LayerNorm takes of x are left in ops' registry for the tap that normalises the same tensor (forward_all)."""
+    LayerNorm takes of x are left in ops' registry for the tap that normalises the same tensor (forward_all).  next_block (forward_all): the block that
+    will consume the output — with options.adapter_ln the fused adapter kernel of the tf32h engine writes that block's LayerNorm 1 as well."""
     inner, lora, adapter = _unwrap(blk)
     B, Nt, D = x.shape
     plan = inner.plan(x.dtype)
@@ -472,6 +482,9 @@ def run_block(blk, x, offer_ln_stats=False):
         plan = dict(plan, tw=tw)
     if offer_ln_stats:
         plan = dict(plan, offer_ln_stats=True)
+    if next_block is not None and adapter is not None and plan["x3"] == "h" and bool(option("adapter_ln")):
+        pn = _unwrap(next_block)[0].plan(x.dtype)
+        plan = dict(plan, next_ln=(pn["ln1_w"], pn["ln1_b"], pn["eps1"]))
     out = _BlockFn.apply(x.reshape(B * Nt, D), plan, B, Nt, a_q, b_q, a_v, b_v, down, up)
     return out.view(B, Nt, D)
 
@@ -865,7 +878,7 @@ class GDViT(nn.Module):
                     and (self.embed_dim * (2 if self.dtype == torch.bfloat16 else 4)) % 16 == 0)
         for i, blk in enumerate(self.blocks):
             x_in = x
-            x = run_block(blk, x, offer_ln_stats=pending is not None)      # not blk(x): a foreign wrapper class (utils/model.py's own) is fused by shape, never called
+            x = run_block(blk, x, offer_ln_stats=pending is not None, next_block=self.blocks[i + 1] if i + 1 < len(self.blocks) else None)      # not blk(x): a foreign wrapper class (utils/model.py's own) is fused by shape, never called
             if pending is not None:
                 st = ops.ln_stats_take(x_in.reshape(-1, x_in.shape[-1]), pending["eps"])
                 if st is not None:

@@ -275,6 +275,44 @@ def test_vit_base_518_tf32x_step_matches_oracle():
 # the fp16-operand TF32-class engine at the benched size: fp32 storage, every big product and the attention on fp16 operands (TF32's 11-bit
 # significand), gradient operands under a per-block power-of-two scale.  Stated tolerances: loss and terms 2e-4, gradient TF32H_GRAD_FRO
 # (+ the kink allowance when a keypoint's depth-L1 residual is inside the engine's feature noise), weights after the step 1e-4.
+def test_vit_base_518_tf32h_adapter_kernel_writes_the_next_layernorm():
+    """options.adapter_ln (default on): in forward_all the fused adapter kernel of blocks 4 .. 10 also writes the NEXT block's LayerNorm 1 (fp16 rows + statistics,
+    gd_adapter_fused_h_ln) and that block runs no LayerNorm pass — at M >= 8192 rows, i.e. from three pairs on (the two-pair oracle cases of this file are below
+    it).  Same loss, same gradient (fp16 rows that differ by one ulp where the fp32 value sits on a rounding boundary) as with the option off."""
+    from gd_amd import ops
+    from gd_amd.finetune import FinetuneGD
+    from gd_amd.options import set_option
+    P, img, N = 3, 518, 300
+    batch = synthetic_batch(P, img, img, N, (img // 14) ** 2, "cuda", seed=77, teacher_patch=14)
+    res = {}
+    for on in (1, 0):
+        torch.manual_seed(0)
+        eng = FinetuneGD(r=4, backbone="vit_base", patch_size=14, img_size=img, variant="mast3r", geometry="shared", dtype="tf32h", teacher_patch=14,
+                         lora_b_std=1e-3, vit_kwargs=dict(init_values=1.0)).cuda()
+        flat = eng.configure_optimizers()
+        calls = {"n": 0}
+        real = ops.adapter_fused_h_ln
+
+        def counted(*a, **k):
+            calls["n"] += 1
+            return real(*a, **k)
+        keep = set_option("adapter_ln", on)
+        ops.adapter_fused_h_ln = counted
+        try:
+            loss, _, norm = eng.fit_step(batch)
+        finally:
+            ops.adapter_fused_h_ln = real
+            set_option("adapter_ln", keep)
+        assert calls["n"] == (7 if on else 0)      # blocks 4 .. 10 hand their LayerNorm to the block above them (block 11 has none)
+        res[on] = (loss.item(), norm.item(), flat["g"].clone())
+        del eng
+    assert abs(res[1][0] - res[0][0]) < 2e-6 * abs(res[0][0])
+    assert abs(res[1][1] - res[0][1]) < 1e-4 * res[0][1]
+    # (two realisations of the same fp16 roundings: they differ from each other by about what each differs from the fp64 oracle — measured 2.6e-3 — and
+    #  both hold the engine's gradient bound against it, test_vit_base_518_tf32h_step_matches_oracle)
+    assert float((res[1][2] - res[0][2]).norm() / res[0][2].norm()) < 0.5 * TF32H_GRAD_FRO
+
+
 @pytest.mark.parametrize("ln2_fold", [0, 1])
 def test_vit_base_518_tf32h_step_matches_oracle(ln2_fold):
     # ln2_fold = 1: the LayerNorm-2 fold (options.ln2_fold, an experiment that is off by default — profiles/r05_ln2_fold_ab.txt) holds the same tolerances
