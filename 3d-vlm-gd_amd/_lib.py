@@ -15,19 +15,12 @@ F32, BF16, F16 = 0, 1, 3
 c_int, c_long, c_float, c_void_p, c_size_t = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
 
 # name -> (restype, argtypes).  Must list every symbol of include/gd_hip.h (tests check this).
-ABI_VERSION = 2      # include/gd_hip.h GD_ABI_VERSION: the version this signature table was written for
+ABI_VERSION = 3      # include/gd_hip.h GD_ABI_VERSION: the version this signature table was written for
 SIGNATURES = {
     "gd_last_error": (ctypes.c_char_p, []),
     "gd_abi_version": (c_int, []),
     "gd_debug_set": (c_int, [ctypes.c_char_p, c_int]),
     "gd_debug_get": (c_int, [ctypes.c_char_p]),
-    "gd_gemm_nt_lnfold_emit": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_long, c_long, c_float,
-                                       c_void_p, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p]),
-    "gd_gemm_nt_lnfold_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_long, c_long, c_float,
-                                        c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p]),
-    "gd_ln_fold_stats": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "gd_stream_create_cu_mask": (c_int, [c_int, ctypes.POINTER(c_void_p)]),
-    "gd_stream_destroy": (c_int, [c_void_p]),
     "gd_gemm_phase_probe": (c_int, [c_int, c_void_p]),
     "gd_gemm_nt": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_long, c_long,
                            c_int, c_long, c_long, c_long, c_int, c_int, c_float,

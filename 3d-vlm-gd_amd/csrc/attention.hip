@@ -397,19 +397,6 @@ __device__ __forceinline__ void attn_block_coords(int& xb, int& h, int& b) {
     b = r / (nx * ny);
 }
 
-// Start-up skew between the workgroups that share a CU (round 5, GD_ATTN_STAGGER = ticks of 64 cycles per slot; default 0 = off).  The PMC pass of
-// round 5 (profiles/r05_pmc_attention_stall.json) shows the matrix pipe busy in 49 % and the vector ALU in ~40 % of the SIMD cycles but the two
-// TOGETHER in only 16 %: the two or three waves of a SIMD — one from each co-resident workgroup, same program, same tile period — run their MFMA and
-// softmax phases at the same time.  Workgroups are dealt round-robin (XCD, then CU), so launch index / 256 mod `slots` is the workgroup's slot on its
-// CU for the first generation, and every later workgroup inherits the phase of the one whose place it takes (equal work per workgroup).
-__device__ __forceinline__ void attn_stagger(int packed) {
-    if (packed == 0) return;
-    const int ticks = packed & 0xffff, slots = packed >> 16;
-    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    const int slot = (lin >> 8) % slots;
-    for (int i = 0; i < slot * ticks; ++i) __builtin_amdgcn_s_sleep(1);
-}
-
 template <typename T>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* qkv, T* o, float* lse, int N, int H, float scale) {
     constexpr int NF = AT<T>::NF, ROWB = AT<T>::ROWB;
@@ -529,8 +516,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const T* qkv, T* o
     __shared__ __attribute__((aligned(16))) char smem[6 * TILE];   // K slots 0..2 | V slots 0..2
     const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    attn_stagger(rot_on >> 8);      // (bits 8..: GD_ATTN_STAGGER ticks | slots << 16)
-    rot_on &= 0xff;
     int xb_, h, b;
     attn_block_coords(xb_, h, b);
     const int q0 = xb_ * 128 + wave * 32;
@@ -690,250 +675,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const T* qkv, T* o
     }
 }
 
-// ------------------------------------------------------------------------------------------ forward on 32 x 32 x 16 MFMA tiles
-// MEASURED SLOWER, kept behind GD_ATTN_MFMA32=1 (default 0) with its tests: 603 us against 550 us for attn_fwd_dma_kernel at 64 x 12 x 1370,
-// 1173 against 1064 at 8 x 12 x 6401 (round 4, same process; with the row sums on an all-ones MFMA and two waves per SIMD: 629 / 1247).  The loop
-// is bound by neither the issue port nor the matrix pipe (a wave-tile takes ~1360 SIMD cycles for 860 port / 576 pipe cycles of work at three
-// waves per SIMD): what the bigger instruction frees on the port is not what the kernel waits for, and a 32 x 32 x 16 loop holds a lower clock
-// than a 16 x 16 x 32 one on this part (MI355X_MICROARCH.md, DVFS give-back item 7).
-// The same transposed flash formulation (S^T = K Q^T, O^T += V^T P^T, lagged softmax reference point, LDS-DMA ring three slots deep) re-tiled for
-// v_mfma_f32_32x32x16_{bf16,f16}: a wave owns 32 queries as ONE 32-wide tile, a 64-key tile is two 32-key S^T tiles.  Why: these loops are bound by
-// the SIMD's instruction-issue port, not by the matrix pipe (ISA census) — a 16x16x32 MFMA holds the port for 8 of its 16 pipe cycles,
-// a 32x32x16 one for 8 of 32, so the same FLOPs leave twice the issue slots to the exp / max / convert work of the softmax (per 64-key tile and
-// wave: 20 MFMAs = 160 port + 640 pipe cycles against 36 = 288 + 576).
-// Layouts (lane l: c = l & 31, hh = l >> 5):
-//   A operand (32 x 16): row c, k = 8 hh + j.   B operand (16 x 32): k = 8 hh + j, column c.   C / D: column c, register r <-> row 8 (r >> 2) + 4 hh + (r & 3).
-//   S^T tile kt2: A = K rows 32 kt2 + c, head dims 16 ks + 8 hh .. + 7 (one ds_read_b128 per k-step), B = the wave's q fragments (registers).
-//   P^T as the B operand of PV: k-step sp = 2 kt2 + s takes registers 8 s .. 8 s + 7 of S^T tile kt2, i.e. the keys 16 sp + {4 hh + 0..3, 8 + 4 hh + 0..3}
-//   in that k-slot order — the accumulator IS the operand (four v_cvt_pk per k-step), and V^T uses the same order: two ds_read_b64_tr_b16 per
-//   fragment, rows 16 sp + 8 e + 4 hh + 0..3 (e = 0, 1), columns 32 dt + 16 ((l >> 4) & 1) + 0..15.
-//   Row sums: fp32 adds of the lane's own p (before rounding), the two lane halves combined once at the end.
-// LDS rows are 128 bytes unpadded; the 16-byte chunk index is XOR-ed with sw32(row) = bit-reversed (row >> 1) & 7 (on the DMA's source address):
-// conflict-free for the ds_read_b128 lane groups {0-3, 12-15, 20-27} ... AND for the 32-lane halves of the transpose reads (4 rows x 64 bytes), which
-// need rows r and r + 2 in different 64-byte halves of the bank row — bit 2 of the XOR is row bit 1 (checked by simulation against the guide's bank rules).
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-template <typename T> struct Mma32;
-template <> struct Mma32<bf16> {
-    static __device__ __forceinline__ f32x16 mma(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
-};
-template <> struct Mma32<f16> {
-    static __device__ __forceinline__ f32x16 mma(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
-};
-__device__ __forceinline__ int sw32(int row) { return (((row >> 1) & 1) << 2) | (((row >> 2) & 1) << 1) | ((row >> 3) & 1); }
-__device__ __forceinline__ float half_swap_max(float v) {      // max(lane l, lane l ^ 32)
-    const unsigned w = __builtin_bit_cast(unsigned, v);
-    const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
-    const unsigned b0 = b[0], b1 = b[1];
-    return fmaxf(__builtin_bit_cast(float, b0), __builtin_bit_cast(float, b1));
-}
-template <typename T> __device__ __forceinline__ typename Mma<T>::Frag pack8(const f32x16& a, int s);
-template <> __device__ __forceinline__ bf16x8 pack8<bf16>(const f32x16& a, int s) {
-    return bf16x8{(bf16)a[8 * s + 0], (bf16)a[8 * s + 1], (bf16)a[8 * s + 2], (bf16)a[8 * s + 3], (bf16)a[8 * s + 4], (bf16)a[8 * s + 5], (bf16)a[8 * s + 6], (bf16)a[8 * s + 7]};
-}
-template <> __device__ __forceinline__ f16x8 pack8<f16>(const f32x16& a, int s) {      // plain conversions: p <= 2^ATT_THR (acc_to_bfrag<f16>)
-    return f16x8{(f16)a[8 * s + 0], (f16)a[8 * s + 1], (f16)a[8 * s + 2], (f16)a[8 * s + 3], (f16)a[8 * s + 4], (f16)a[8 * s + 5], (f16)a[8 * s + 6], (f16)a[8 * s + 7]};
-}
-
-template <typename T>      // bf16 | f16
-__global__ __launch_bounds__(256, 3) void attn_fwd32_kernel(const T* qkv, T* o, float* lse, int N, int H, float scale, int rot_on) {
-    typedef typename Mma<T>::Frag Frag;
-    constexpr int TILE = 64 * 128;                       // one K or V tile: 64 rows x 128 B
-    __shared__ __attribute__((aligned(16))) char smem[6 * TILE];   // K slots 0..2 | V slots 0..2
-    const int lane = threadIdx.x & 63, hh = lane >> 5, c = lane & 31;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int xb_, h, b;
-    attn_block_coords(xb_, h, b);
-    const int q0 = xb_ * 128 + wave * 32;
-    const long ld_b = (long)3 * H * HD * 2;
-    const char* base = (const char*)qkv + (long)b * N * ld_b;
-    const char* qb = base + (long)(0 * H + h) * HD * 2;
-    const char* kb = base + (long)(1 * H + h) * HD * 2;
-    const char* vb = base + (long)(2 * H + h) * HD * 2;
-
-    const float c2 = scale * 1.4426950408889634f;
-    Frag qf[4];           // q * scale * log2(e): head dims 16 ks + 8 hh .. + 7 of query q0 + c
-    {
-        const int q = q0 + c;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            if (q < N) qf[ks] = frag_scale<T>(*(const Frag*)(qb + (long)q * ld_b + ks * 32 + hh * 16), c2);
-            else { Frag z = {}; qf[ks] = z; }
-        }
-    }
-    // DMA: wave w moves pieces 2w, 2w+1 (8 rows each) of the K tile and of the V tile
-    const int prow = lane >> 3, pchunk = lane & 7;
-    const char* kp[2];
-    const char* vp_[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (wave * 2 + i) * 8 + prow;
-        const long off = (long)row * ld_b + ((pchunk ^ sw32(row)) * 16);
-        kp[i] = kb + off;
-        vp_[i] = vb + off;
-    }
-    auto issue = [&](int k0, int slot) {
-        if (k0 + 64 <= N) {
-            const unsigned long t0 = (unsigned)k0 * (unsigned)ld_b;     // 32-bit scalar product (an image's qkv rows span < 2^31 bytes)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kp[i] + t0),
-                                                 (__attribute__((address_space(3))) void*)(smem + slot * TILE + (wave * 2 + i) * 1024), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vp_[i] + t0),
-                                                 (__attribute__((address_space(3))) void*)(smem + (3 + slot) * TILE + (wave * 2 + i) * 1024), 16, 0, 0);
-            }
-            return;
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = (wave * 2 + i) * 8 + prow;
-            const long off = (long)min(k0 + row, N - 1) * ld_b + ((pchunk ^ sw32(row)) * 16);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kb + off),
-                                             (__attribute__((address_space(3))) void*)(smem + slot * TILE + (wave * 2 + i) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vb + off),
-                                             (__attribute__((address_space(3))) void*)(smem + (3 + slot) * TILE + (wave * 2 + i) * 1024), 16, 0, 0);
-        }
-    };
-    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)smem;
-    // K fragment (kt2, ks): row 32 kt2 + c (+4096 bytes per kt2), logical chunk 2 ks + hh
-    unsigned ka[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) ka[ks] = c * 128 + (((2 * ks + hh) ^ sw32(c)) * 16);
-    // V transpose fragment (dt, sp, e): rows 16 sp + 8 e + 4 hh + vq (+2048 bytes per sp), logical chunk 4 dt + 2 dsub + (vp >> 1), 8-byte half vp & 1
-    const int dsub = (lane >> 4) & 1, vq = (lane & 15) >> 2, vp = lane & 3;
-    unsigned va[2][2];
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int row = 8 * e + 4 * hh + vq;
-            va[dt][e] = row * 128 + (((4 * dt + 2 * dsub + (vp >> 1)) ^ sw32(row)) * 16) + 8 * (vp & 1);
-        }
-
-    f32x16 oacc[2], negm;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.f; oacc[1][r] = 0.f; negm[r] = 0.f; }
-    float m = 0.f;                                          // reference point, log2 units (softmax_lagged's rule)
-    // row sum: THIS lane's 32 of the query's 64 scores per tile, summed in fp32 on the VALU (an all-ones MFMA would cost a 32-cycle instruction per
-    // k-step and 16 accumulator registers — the difference between two and three waves per SIMD); the two lane halves are added once, at the end
-    float lpart = 0.f;
-    const int ntile = (N + 63) / 64, nfull = N / 64;
-    const int rot = (nfull > 0 && rot_on) ? (2 * xb_) % nfull : 0;
-    auto pk0 = [&](int t) { return (t < nfull ? (t + rot >= nfull ? t + rot - nfull : t + rot) : t) * 64; };
-    issue(pk0(0), 0);
-    if (ntile > 1) issue(pk0(1), 1);
-    int slot = 0;
-    auto key_tile = [&](int t, auto tail_tag) {
-        constexpr bool tail = decltype(tail_tag)::value;
-        const int k0 = pk0(t);
-        if (t + 1 < ntile) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // tile t landed; tile t+1 may still fly
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (t + 2 < ntile) issue(pk0(t + 2), slot == 0 ? 2 : slot - 1);
-        if (q0 >= N) return;
-        const unsigned kbase = lds0 + slot * TILE, vbase = lds0 + (3 + slot) * TILE;
-        f32x4 kr[2][4];
-        ADS_R128(kr[0][0], kbase + ka[0], 0);    ADS_R128(kr[0][1], kbase + ka[1], 0);    ADS_R128(kr[0][2], kbase + ka[2], 0);    ADS_R128(kr[0][3], kbase + ka[3], 0);
-        ADS_R128(kr[1][0], kbase + ka[0], 4096); ADS_R128(kr[1][1], kbase + ka[1], 4096); ADS_R128(kr[1][2], kbase + ka[2], 4096); ADS_R128(kr[1][3], kbase + ka[3], 4096);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kr[0][0]), "+v"(kr[0][1]), "+v"(kr[0][2]), "+v"(kr[0][3]), "+v"(kr[1][0]), "+v"(kr[1][1]), "+v"(kr[1][2]),
-                     "+v"(kr[1][3]));
-        f32x16 s[2];
-#pragma unroll
-        for (int kt2 = 0; kt2 < 2; ++kt2) {
-            f32x16 a = negm;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) a = Mma32<T>::mma(__builtin_bit_cast(Frag, kr[kt2][ks]), qf[ks], a);
-            s[kt2] = a;
-        }
-        // V fragments: issued now, consumed after the softmax
-        a_u32x2 vr[2][4][2];   // [dt][sp][e]
-#define ADS_V32(dt)                                                                                                  \
-        ADS_TR64(vr[dt][0][0], vbase + va[dt][0], 0);    ADS_TR64(vr[dt][0][1], vbase + va[dt][1], 0);                   \
-        ADS_TR64(vr[dt][1][0], vbase + va[dt][0], 2048); ADS_TR64(vr[dt][1][1], vbase + va[dt][1], 2048);                \
-        ADS_TR64(vr[dt][2][0], vbase + va[dt][0], 4096); ADS_TR64(vr[dt][2][1], vbase + va[dt][1], 4096);                \
-        ADS_TR64(vr[dt][3][0], vbase + va[dt][0], 6144); ADS_TR64(vr[dt][3][1], vbase + va[dt][1], 6144);
-        ADS_V32(0) ADS_V32(1)
-#undef ADS_V32
-        // ---- softmax with the lagged reference point (softmax_lagged, one 32-query tile: this lane holds 32 of its query's 64 scores)
-        {
-            float tmax = -1e30f;
-#pragma unroll
-            for (int kt2 = 0; kt2 < 2; ++kt2)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    if (tail && k0 + 32 * kt2 + 8 * (r >> 2) + 4 * hh + (r & 3) >= N) s[kt2][r] = -1e30f;
-                    tmax = fmaxf(tmax, s[kt2][r]);
-                }
-            const bool first = t == 0;
-            if (first || __any(tmax > ATT_THR)) {
-                tmax = half_swap_max(tmax);
-                const bool need = first || tmax > ATT_THR;
-                const float d = need ? tmax : 0.f;
-#pragma unroll
-                for (int kt2 = 0; kt2 < 2; ++kt2)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) s[kt2][r] -= d;
-                m += d;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) negm[r] = -m;
-                if (!first) {
-                    const float alpha = fast_exp2(-d);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
-                    lpart *= alpha;
-                }
-            }
-#pragma unroll
-            for (int kt2 = 0; kt2 < 2; ++kt2)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s[kt2][r] = fast_exp2(s[kt2][r]);
-            float l0 = 0.f, l1 = 0.f, l2 = 0.f, l3 = 0.f;      // four short chains (a single 32-deep chain of dependent adds stalls the wave)
-#pragma unroll
-            for (int r = 0; r < 16; r += 4) {
-                l0 += s[0][r] + s[1][r]; l1 += s[0][r + 1] + s[1][r + 1]; l2 += s[0][r + 2] + s[1][r + 2]; l3 += s[0][r + 3] + s[1][r + 3];
-            }
-            lpart += (l0 + l1) + (l2 + l3);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vr[0][0][0]), "+v"(vr[0][0][1]), "+v"(vr[0][1][0]), "+v"(vr[0][1][1]), "+v"(vr[0][2][0]), "+v"(vr[0][2][1]),
-                     "+v"(vr[0][3][0]), "+v"(vr[0][3][1]), "+v"(vr[1][0][0]), "+v"(vr[1][0][1]), "+v"(vr[1][1][0]), "+v"(vr[1][1][1]), "+v"(vr[1][2][0]),
-                     "+v"(vr[1][2][1]), "+v"(vr[1][3][0]), "+v"(vr[1][3][1]));
-#pragma unroll
-        for (int sp = 0; sp < 4; ++sp) {
-            const Frag pf = pack8<T>(s[sp >> 1], sp & 1);
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                typedef __attribute__((ext_vector_type(4))) unsigned a_u32x4;
-                const a_u32x4 z = {vr[dt][sp][0][0], vr[dt][sp][0][1], vr[dt][sp][1][0], vr[dt][sp][1][1]};
-                oacc[dt] = Mma32<T>::mma(__builtin_bit_cast(Frag, z), pf, oacc[dt]);
-            }
-        }
-    };
-    int t = 0;
-    for (; (t + 1) * 64 <= N; ++t) {
-        key_tile(t, std::false_type{});
-        slot = slot == 2 ? 0 : slot + 1;
-    }
-    if (t * 64 < N) key_tile(t, std::true_type{});
-    const int q = q0 + c;
-    {   // the other lane half holds the other 32 keys of every tile
-        const unsigned w = __builtin_bit_cast(unsigned, lpart);
-        const auto sw_ = __builtin_amdgcn_permlane32_swap(w, w, false, false);
-        const unsigned s0 = sw_[0], s1 = sw_[1];
-        lpart = __builtin_bit_cast(float, s0) + __builtin_bit_cast(float, s1);
-    }
-    if (q < N) {
-        const float lsum = lpart;
-        const float inv = 1.0f / lsum;
-        T* orow = o + ((long)b * N + q) * H * HD + h * HD;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4)
-                store4<T>(orow + 32 * dt + 8 * r4 + 4 * hh, f32x4{oacc[dt][4 * r4], oacc[dt][4 * r4 + 1], oacc[dt][4 * r4 + 2], oacc[dt][4 * r4 + 3]} * inv);
-        if (hh == 0) lse[((long)b * H + h) * N + q] = (m + log2f(lsum)) * 0.6931471805599453f;
-    }
-}
-
 // dot of two operand fragments (the 16 bytes a lane holds of a row), fp32
 __device__ __forceinline__ float frag_dot(bf16x8 a, bf16x8 b) {
     float s = 0.f;
@@ -958,8 +699,7 @@ __device__ __forceinline__ float frag_dot(const X3Frag& a, const X3Frag& b) {
 // ------------------------------------------------------------------------------------------ backward: dQ
 template <typename T>
 __global__ __launch_bounds__(256, IsX3<T>::v ? 1 : 2) void attn_bwd_dq_kernel(const T* qkv, const T* o, const T* dout, const float* lse,
-                                                          float* delta, T* dqkv, int N, int H, float scale, int stagger = 0) {
-    attn_stagger(stagger);
+                                                          float* delta, T* dqkv, int N, int H, float scale) {
     constexpr int NF = AT<T>::NF, ROWB = AT<T>::ROWB;
     typedef typename Mma<T>::Frag Frag;
     __shared__ __attribute__((aligned(16))) char sK[64 * ROWB];
@@ -1098,7 +838,6 @@ __global__ __launch_bounds__(256, IsX3<T>::v ? 1 : 2) void attn_bwd_dq_kernel(co
 template <typename T, int NW, bool DK = true>
 __global__ __launch_bounds__(64 * NW, (NW >= 8 || IsX3<T>::v) ? 1 : 2) void attn_bwd_dkv_kernel(const T* qkv, const T* dout, const float* lse,
                                                            const float* delta, T* dqkv, int N, int H, float scale, int vfirst) {
-    attn_stagger(vfirst >> 8);      // (bits 8..: GD_ATTN_STAGGER ticks | slots << 16)
     vfirst &= 0xff;
     constexpr int NF = AT<T>::NF, ROWB = AT<T>::ROWB;
     typedef typename Mma<T>::Frag Frag;
@@ -1415,12 +1154,6 @@ extern "C" int gd_cross_view_attn(const void* q, const void* k, float* out, int 
 }
 
 // ------------------------------------------------------------------------------------------ C ABI
-// kernel argument of attn_stagger: GD_ATTN_STAGGER ticks (of 64 cycles) per slot | workgroups per CU << 16; 0 = off
-static inline int attn_stagger_arg(int slots) {
-    const int t = gd_knobs().attn_stagger;
-    return t > 0 ? ((t & 0xffff) | (slots << 16)) : 0;
-}
-
 extern "C" int gd_attention_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, int head_dim, float scale,
                                 int dtype, void* stream) {
     GD_REQUIRE(B > 0 && N > 0 && H > 0, "gd_attention_fwd: bad shape B=%d N=%d H=%d", B, N, H);
@@ -1430,19 +1163,12 @@ extern "C" int gd_attention_fwd(const void* qkv, void* o, float* lse, int B, int
     GD_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)o & 15) == 0, "gd_attention_fwd: pointers must be 16-byte aligned");
     dim3 grid(gd_cdiv(N, 128), H, B);
     const int dma = gd_knobs().attn_dma;   // GD_ATTN_DMA=0: the register-staged forward kernel (A/B testing)
-    const int m32 = gd_knobs().attn_mfma32;   // GD_ATTN_MFMA32=0: the 16 x 16 x 32 forward (A/B testing)
-    if (dtype == GD_BF16 && dma && m32)
+    if (dtype == GD_BF16 && dma)
         { const int ro = gd_knobs().attn_rot;
-          hipLaunchKernelGGL(attn_fwd32_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, ro); }
-    else if (dtype == GD_F16 && m32)
-        { const int ro = gd_knobs().attn_rot;
-          hipLaunchKernelGGL(attn_fwd32_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, (const f16*)qkv, (f16*)o, lse, N, H, scale, ro); }
-    else if (dtype == GD_BF16 && dma)
-        { const int ro = gd_knobs().attn_rot;
-          hipLaunchKernelGGL(attn_fwd_dma_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, ro | attn_stagger_arg(3) << 8); }
+          hipLaunchKernelGGL(attn_fwd_dma_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, ro); }
     else if (dtype == GD_F16 && dma)        // tf32h engine: fp16 q / k / v / p (TF32's significand), the bf16 kernel's layouts
         { const int ro = gd_knobs().attn_rot;
-          hipLaunchKernelGGL(attn_fwd_dma_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, (const f16*)qkv, (f16*)o, lse, N, H, scale, ro | attn_stagger_arg(3) << 8); }
+          hipLaunchKernelGGL(attn_fwd_dma_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, (const f16*)qkv, (f16*)o, lse, N, H, scale, ro); }
     else if (dtype == GD_F16)
         hipLaunchKernelGGL(attn_fwd_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, (const f16*)qkv, (f16*)o, lse, N, H, scale);
     else if (dtype == GD_BF16)
@@ -1459,7 +1185,7 @@ template <typename T>      // bf16 | f16
 static void attn_bwd_launch16(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, float* delta_ws, int B, int N, int H,
                               float scale, int grad_order, bool no_dk, hipStream_t s) {
     dim3 grid(gd_cdiv(N, 128), H, B);
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, grid, dim3(256), 0, s, (const T*)qkv, (const T*)o, (const T*)dout, lse, delta_ws, (T*)dqkv, N, H, scale, attn_stagger_arg(3));
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, grid, dim3(256), 0, s, (const T*)qkv, (const T*)o, (const T*)dout, lse, delta_ws, (T*)dqkv, N, H, scale);
         // 128-key blocks of four waves (two blocks per CU, independent barriers, Q / dO tiles staged twice as often) when the last
         // 256-key block would be less than half full: N = 1370 pads to 1408 keys instead of 1536 (2.7 % instead of 10.8 %):
         // backward 1574 -> 1514 us at 64 x 12 x 1370; at N = 6401 (long sweeps, 0.4 % vs 2 % padding) the 8-wave form is 2 % faster.
@@ -1468,11 +1194,11 @@ static void attn_bwd_launch16(const void* qkv, const void* o, const void* dout, 
         const int tail = N % 256;
         const int dkv_nw = dkv_env ? dkv_env : ((N < 4096 && tail > 0 && tail <= 128) ? 4 : 8);
         if (no_dk && dkv_nw == 4)
-            hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, 4, false>), dim3(gd_cdiv(N, 128), H, B), dim3(256), 0, s, (const T*)qkv, (const T*)dout, lse, delta_ws, (T*)dqkv, N, H, scale, grad_order | attn_stagger_arg(2) << 8);
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, 4, false>), dim3(gd_cdiv(N, 128), H, B), dim3(256), 0, s, (const T*)qkv, (const T*)dout, lse, delta_ws, (T*)dqkv, N, H, scale, grad_order);
         else if (no_dk)
             hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, 8, false>), dim3(gd_cdiv(N, 256), H, B), dim3(512), 0, s, (const T*)qkv, (const T*)dout, lse, delta_ws, (T*)dqkv, N, H, scale, grad_order);
         else if (dkv_nw == 4)       // (two-wave 64-key blocks: 2213 us — the staging registers spill and every block re-stages all of Q / dO)
-            hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, 4>), dim3(gd_cdiv(N, 128), H, B), dim3(256), 0, s, (const T*)qkv, (const T*)dout, lse, delta_ws, (T*)dqkv, N, H, scale, grad_order | attn_stagger_arg(2) << 8);
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, 4>), dim3(gd_cdiv(N, 128), H, B), dim3(256), 0, s, (const T*)qkv, (const T*)dout, lse, delta_ws, (T*)dqkv, N, H, scale, grad_order);
         else
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, 8>), dim3(gd_cdiv(N, 256), H, B), dim3(512), 0, s, (const T*)qkv, (const T*)dout, lse, delta_ws, (T*)dqkv, N, H, scale, grad_order);
 }

@@ -24,14 +24,11 @@ static const KnobDef KNOBS[] = {
     {"gemm_anat", "GD_GEMM_ANAT", &GdKnobs::gemm_anat, 0},                {"gemm_batch_big_m", "GD_GEMM_BATCH_BIG_M", &GdKnobs::gemm_batch_big_m, 384},
     {"gemm_krot", "GD_GEMM_KROT", &GdKnobs::gemm_krot, 1},                {"tn_blocks", "GD_TN_BLOCKS", &GdKnobs::tn_blocks, 0},
     {"attn_dma", "GD_ATTN_DMA", &GdKnobs::attn_dma, 1},                   {"attn_rot", "GD_ATTN_ROT", &GdKnobs::attn_rot, 1},
-    {"attn_mfma32", "GD_ATTN_MFMA32", &GdKnobs::attn_mfma32, 0},         {"attn_stagger", "GD_ATTN_STAGGER", &GdKnobs::attn_stagger, 0},
     {"attn_dkv_nw", "GD_ATTN_DKV_NW", &GdKnobs::attn_dkv_nw, 0},          {"cv_mask_skip", "GD_CV_MASK_SKIP", &GdKnobs::cv_mask_skip, 1},
     {"cv_persist", "GD_CV_PERSIST", &GdKnobs::cv_persist, 1},             {"cv_dbg", "GD_CV_DBG", &GdKnobs::cv_dbg, 0},
     {"cv_grid", "GD_CV_GRID", &GdKnobs::cv_grid, 0},                      {"pair_rank_wave", "GD_PAIR_RANK_WAVE", &GdKnobs::pair_rank_wave, 0},
     {"ln_16b", "GD_LN_16B", &GdKnobs::ln_16b, 1},                         {"adapter_persist", "GD_ADAPTER_PERSIST", &GdKnobs::adapter_persist, 1},
     {"reserve_cus", "GD_RESERVE_CUS", &GdKnobs::reserve_cus, 0},          {"gemm_group_m", "GD_GEMM_GROUP_M", &GdKnobs::gemm_group_m, 1},
-    {"gemm_stagger", "GD_GEMM_STAGGER", &GdKnobs::gemm_stagger, 0},       {"cv_panel", "GD_CV_PANEL", &GdKnobs::cv_panel, 0},
-    {"gemm_k64", "GD_GEMM_K64", &GdKnobs::gemm_k64, 0},
 };
 static void gd_apply_reserve(GdKnobs& v) {
     int r = v.reserve_cus < 0 ? 0 : v.reserve_cus;
@@ -72,27 +69,3 @@ extern "C" int gd_debug_get(const char* name) {
 }
 extern "C" int gd_abi_version(void) { return GD_ABI_VERSION; }
 
-extern "C" int gd_stream_create_cu_mask(int cus, void** stream_out) {
-    GD_REQUIRE(stream_out != nullptr && cus > 0, "gd_stream_create_cu_mask: cus = %d", cus);
-    const int ncu = gd_knobs().ncu_dev;
-    GD_REQUIRE(cus < ncu, "gd_stream_create_cu_mask: %d of %d compute units", cus, ncu);
-    uint32_t mask[32] = {};
-    const int words = (ncu + 31) / 32;
-    GD_REQUIRE(words <= 32, "gd_stream_create_cu_mask: %d compute units", ncu);
-    for (int i = 0; i < cus; ++i) mask[i >> 5] |= 1u << (i & 31);
-    hipStream_t s = nullptr;
-    const hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask);
-    if (e != hipSuccess) {
-        gd_set_error("gd_stream_create_cu_mask: hipExtStreamCreateWithCUMask: %s", hipGetErrorString(e));
-        return -1;
-    }
-    *stream_out = (void*)s;
-    return 0;
-}
-extern "C" int gd_stream_destroy(void* stream) {
-    if (stream && hipStreamDestroy((hipStream_t)stream) != hipSuccess) {
-        gd_set_error("gd_stream_destroy: hipStreamDestroy failed");
-        return -1;
-    }
-    return 0;
-}

@@ -851,22 +851,6 @@ __global__ __launch_bounds__(768) void cv_fwd_rows_kernel(CvTileParams q) {
 }
 
 
-#include "cv_panel.h"
-
-// grid of the panel kernels: one block per CU, a multiple of 8 (XCD-major block ids); 0 = the shape is not theirs (the caller falls back)
-static int cv_panel_grid(long total_tiles, long rowb, int ldt, const void* t1, const void* t2, int nw) {
-    if (!gd_knobs().cv_panel || rowb != 12 * 128 || ldt % 4 != 0 || ldt < 8 || ((uintptr_t)t1 & 15) || ((uintptr_t)t2 & 15)) return 0;
-    int ncu = 256;
-    if (gd_knobs().ncu >= 8) ncu = gd_knobs().ncu / 8 * 8;
-    if (nw == 4) ncu *= 2;      // two 4-wave blocks per CU
-    int grid = (int)(total_tiles < ncu ? (total_tiles + 7) / 8 * 8 : ncu);
-    if (gd_knobs().cv_grid) {      // tests (gd_debug_set): few blocks, so that every block walks many tiles
-        const int gv = gd_knobs().cv_grid / 8 * 8;
-        if (gv >= 8 && gv < grid) grid = gv;
-    }
-    if ((total_tiles + grid - 1) / grid + 40 > CVA_LIST_MAX) return 0;       // (a block's slice of every pair segment of its XCD's range rounds up: margin)
-    return grid;
-}
 
 // kept rows of one (pair, direction) in ascending order -> idx[pd][0 .. cnt), the rest of the kcap entries padded with the last kept row (row 0
 // when nothing is kept); cnt[pd] = the number kept, or -1 when it EXCEEDS kcap (the caller's bound was wrong: the loss of that pair comes out NaN and so do
@@ -944,7 +928,7 @@ __global__ __launch_bounds__(256) void cv_finalize_rows_kernel(const float* part
 __global__ __launch_bounds__(256) void cv_finalize_kernel(const float* part1, const float* part2, const float* tstats,
                                                           const unsigned char* m1, const unsigned char* m2,
                                                           float* stats, double* chunk_loss, int hw, int nslab, int nslab2, int variant) {
-    // (nslab2: slabs of the direction-2 partials — the number of ROW panels of the forward kernel, which the panel kernels choose themselves)
+    // (nslab2: slabs of the direction-2 partials — the number of row panels of the forward kernel)
     const int p = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
     const float masked_const = variant == 1 ? (float)hw * (CV_EPS * logf(CV_EPS * (float)hw)) : 0.f;
     double total = 0.0;
@@ -1320,8 +1304,7 @@ static inline int cv_hwp(int hw) { return (hw + 63) & ~63; }   // K of the two b
 
 extern "C" size_t gd_cost_volume_kl_workspace_bytes(int P, int hw, int C, int dtype, int backward) {
     const size_t es = (size_t)gd_dtype_size(dtype);
-    // (direction-2 partials: one slab per ROW PANEL of the forward kernel — 64-row panels in the round-5 panel kernel: twice the 128-row tile count)
-    if (!backward) return align256((size_t)P * cv_tiles(hw) * hw * 2 * sizeof(float)) + align256((size_t)P * 2 * cv_tiles(hw) * hw * 2 * sizeof(float)) +
+    if (!backward) return align256((size_t)P * cv_tiles(hw) * hw * 2 * sizeof(float)) + align256((size_t)P * cv_tiles(hw) * hw * 2 * sizeof(float)) +
                           align256((size_t)P * CV_FCH * sizeof(double)) + align256((size_t)P * 2 * hw * 4 * sizeof(float));
     const size_t hwp = (size_t)cv_hwp(hw);
     return 2 * align256((size_t)P * hw * hwp * es) + 2 * align256((size_t)P * C * hwp * es) +
@@ -1375,35 +1358,7 @@ static int cv_fwd_common(const void* f1, const void* f2, const float* inv1, cons
     // shelved as tools/experiments/cv_persist256.h)
     const int persist = gd_knobs().cv_persist;     // GD_CV_PERSIST=0: the one-tile-per-block kernel (A/B)
     const long rowb = (long)C * gd_dtype_size(dtype);
-    // round 5: row panels resident in registers, only the column operand streams (cv_panel.h).  GD_CV_PANEL: 1 = 64-row panels, two 4-wave blocks per CU
-    // (default); 8 = 128-row panels, one 8-wave block per CU; 0 = the round-4 kernels.  Teacher entries of masked-out rows are fetched here (no q.m1 /
-    // q.m2 tests in the prefetch).  With GD_CV_DBG set: the 4-wave kernel's anatomy instantiations (-DGD_CV_PANEL_ANAT builds).
-    const int pmode = gd_knobs().cv_panel;
-    const int pnw = pmode == 8 ? 8 : 4;
-    const int pgrid = (persist && pmode && dtype != GD_F32 && (!gd_knobs().cv_dbg || (dtype == GD_F16 && pnw == 4)))
-                          ? cv_panel_grid((long)P * gd_cdiv(hw, 16 * pnw) * tiles, rowb, ldt, t1, t2, pnw) : 0;
-    if (pgrid) {
-        q.m1 = q.m2 = nullptr;
-        nslab2 = gd_cdiv(hw, 16 * pnw);
-        if (gd_knobs().cv_dbg) {
-#ifdef GD_CV_PANEL_ANAT
-            switch (gd_knobs().cv_dbg) {
-#define CVA_AN(M) case M: hipLaunchKernelGGL((cv_fwd_panel_kernel<f16, 12, 4, M>), dim3(pgrid), dim3(256), 0, s, q); break;
-                CVA_AN(1) CVA_AN(2) CVA_AN(3) CVA_AN(4) CVA_AN(5) CVA_AN(6) CVA_AN(7) CVA_AN(8) CVA_AN(12) CVA_AN(15)
-#undef CVA_AN
-                default: hipLaunchKernelGGL((cv_fwd_panel_kernel<f16, 12, 4, 0>), dim3(pgrid), dim3(256), 0, s, q);
-            }
-#else
-            GD_REQUIRE(false, "gd_cost_volume_kl_fwd: the panel kernel's anatomy instantiations need a -DGD_CV_PANEL_ANAT build");
-#endif
-        } else if (pnw == 8) {
-            if (dtype == GD_BF16) hipLaunchKernelGGL((cv_fwd_panel_kernel<bf16, 12, 8>), dim3(pgrid), dim3(512), 0, s, q);
-            else hipLaunchKernelGGL((cv_fwd_panel_kernel<f16, 12, 8>), dim3(pgrid), dim3(512), 0, s, q);
-        } else {
-            if (dtype == GD_BF16) hipLaunchKernelGGL((cv_fwd_panel_kernel<bf16, 12, 4>), dim3(pgrid), dim3(256), 0, s, q);
-            else hipLaunchKernelGGL((cv_fwd_panel_kernel<f16, 12, 4>), dim3(pgrid), dim3(256), 0, s, q);
-        }
-    } else if (persist && rowb % 128 == 0 && rowb / 128 >= 3 && ldt % 4 == 0 && ((uintptr_t)t1 & 15) == 0 && ((uintptr_t)t2 & 15) == 0) {
+    if (persist && rowb % 128 == 0 && rowb / 128 >= 3 && ldt % 4 == 0 && ((uintptr_t)t1 & 15) == 0 && ((uintptr_t)t2 & 15) == 0) {
         int ncu = 256;
         if (gd_knobs().ncu >= 8) ncu = gd_knobs().ncu / 8 * 8;
         const long total = (long)P * tiles * tiles;

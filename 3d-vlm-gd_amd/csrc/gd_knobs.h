@@ -10,20 +10,15 @@ struct GdKnobs {
     int gemm_f32_big;      // GD_GEMM_F32_BIG      1: 256x256 tiles for f32 operands
     int gemm_cstore;       // GD_GEMM_CSTORE       C store policy of the staged kernels (0 LDS-staged, 1 direct)
     int gemm_group_m;      // GD_GEMM_GROUP_M      persistent kernel: row panels per W panel in an XCD's tile walk (1 = row-panel-major)
-    int gemm_stagger;      // GD_GEMM_STAGGER      persistent kernel: start-up skew of block group (b >> 3) & 3, in 10 ns ticks per group (0 none)
     int gemm_krot;         // GD_GEMM_KROT         per-tile K-step rotation of the persistent kernel (0 off)
     int gemm_batch_big_m;  // GD_GEMM_BATCH_BIG_M  batched gemm_nt: smallest M served by the 256 x 256 kernels (384: the kept-row cost-volume contractions, 97 vs 149 us; un-batched: 1024)
-    int gemm_k64;          // GD_GEMM_K64          1: fp16-operand persistent kernel on a four-slot ring of 64-byte stages (three stages in flight) instead of two slots of 128 bytes
     int gemm_anat;         // GD_GEMM_ANAT         anatomy instantiations of the persistent main loop (0 = the product kernel)
     int tn_blocks;         // GD_TN_BLOCKS         target block count of the tile TN GEMM (0 auto)
     int attn_dma;          // GD_ATTN_DMA          1: LDS-DMA attention forward; 0: register-staged
     int attn_rot;          // GD_ATTN_ROT          1: forward x-block xb starts at key tile 2 xb
-    int attn_mfma32;       // GD_ATTN_MFMA32       1: forward on 32 x 32 x 16 MFMA tiles (measured 10 % slower: default 0, the 16 x 16 x 32 kernels)
-    int attn_stagger;      // GD_ATTN_STAGGER      start-up skew between the workgroups that share a CU, in ticks of 64 cycles per slot (0 = off; attention.hip attn_stagger)
     int attn_dkv_nw;       // GD_ATTN_DKV_NW       0 auto | 4 | 8 waves per dK/dV block
     int cv_mask_skip;      // GD_CV_MASK_SKIP      1: masked teacher rows are not fetched
     int cv_persist;        // GD_CV_PERSIST        1: persistent cost-volume forward
-    int cv_panel;          // GD_CV_PANEL          0 (default): the round-2..4 persistent forward; 1 / 8: the row-panel-stationary experiment of round 5 (cv_panel.h; 4- / 8-wave blocks; measured slower)
     int cv_dbg;            // GD_CV_DBG            anatomy switches of the cost-volume forward (tools/cv_anatomy.py)
     int cv_grid;           // GD_CV_GRID           block count cap of the persistent cost-volume forward (tests: many tiles per block)
     int pair_rank_wave;    // GD_PAIR_RANK_WAVE    0 tiled kernel | 1 | 2 | 3 older forms

@@ -32,11 +32,7 @@ struct GemmNtParams {
     int vec_epilogue;                // every epilogue tensor is 16-byte aligned with 16-byte-multiple row strides
     int c_policy;                    // 0 plain C stores, 1 write-through (sc1) C stores (GD_GEMM_CSTORE, default 1)
     unsigned long long* probe;       // gd_gemm_phase_probe accumulators (device) in -DGD_GEMM_STAGE_PROBE builds, else null
-    int stagger;                     // persistent kernel: start-up skew between the four block groups of an XCD, in 10 ns ticks (GD_GEMM_STAGGER; 0 = none)
     int group_m;                     // persistent kernel: tiles of an XCD's chunk walk GM row panels per W panel (GD_GEMM_GROUP_M; 1 = row-panel-major order)
-    float* ln_part;                  // LayerNorm fold, emitting side (gd_gemm_nt_lnfold_emit): per row and 64-column slice (sum v, sum v^2) of the final values, [M][N / 64][2]
-    const float* ln_stats;           // LayerNorm fold, applying side (gd_gemm_nt_lnfold_apply): (mean, rstd) per row of A, [M][2]
-    const float* ln_cs;              // ... and cs[n] = sum_k W'[n][k], [N]
     int k_rot;                       // persistent kernel: per-tile rotation of the K-step order, krot = (tn * k_rot + tm) % nk (GD_GEMM_KROT, default 1, 0 = off: +1.3 % on the step, in-step A/B 525.6 vs 518.8 pairs/s)
 };
 
@@ -823,8 +819,7 @@ static int gemm_nt_impl(const void* A, const void* W, void* C, int M, int N, int
                         int batch, long sA, long sW, long sC, int ab_dtype, int c_dtype, float alpha, const float* alpha_dev,
                         const float* bias, const float* lora_t, const float* lora_b, int lora_rt, void* preact,
                         long ldp, int act, const void* dact_src, long ldd, int dact, const void* residual, long ldr,
-                        int accumulate, void* stream, void* copy16 = nullptr, long ldc16 = 0, const float* copy_scale = nullptr,
-                        float* ln_part = nullptr, const float* ln_stats = nullptr, const float* ln_cs = nullptr) {
+                        int accumulate, void* stream, void* copy16 = nullptr, long ldc16 = 0, const float* copy_scale = nullptr) {
     if (copy16) {       // gd_gemm_nt_copy16: f32 C = ... + residual AND an fp16 copy of it (times *copy_scale): the persistent fp16-operand kernel only
         GD_REQUIRE(ab_dtype == GD_F16 && c_dtype == GD_F32 && residual && !preact && !dact_src && act == 0 && !accumulate && batch == 1 &&
                        ((uintptr_t)copy16 & 15) == 0 && (ldc16 * 2) % 16 == 0,
@@ -859,13 +854,6 @@ static int gemm_nt_impl(const void* A, const void* W, void* C, int M, int N, int
     if (copy16) preact = nullptr;      // (for the dispatch below: not a pre-activation store)
     p.dact_src = dact_src; p.ldd = ldd; p.dact = dact_src ? dact : 0; p.residual = residual; p.ldr = ldr;
     p.accumulate = accumulate;
-    p.ln_part = ln_part; p.ln_stats = ln_stats; p.ln_cs = ln_cs;
-    const bool lnf = ln_part || ln_stats;
-    GD_REQUIRE(!lnf || (ab_dtype == GD_F16 && batch == 1 && N % 256 == 0 && M >= 2 && !lora_t && !accumulate && !dact_src),
-               "gd_gemm_nt_lnfold_*: fp16 operands, N %% 256 == 0, no LoRA / dact / accumulate (M=%d N=%d)", M, N);
-    GD_REQUIRE(!ln_part || copy16, "gd_gemm_nt_lnfold_emit: the fp16 copy is part of the call");
-    GD_REQUIRE(!ln_stats || (ln_cs && !residual && (act == 1 || act == 3) && c_dtype == GD_F16 && (((uintptr_t)ln_stats | (uintptr_t)ln_cs) & 15) == 0),
-               "gd_gemm_nt_lnfold_apply: fp16 C with the GELU (+ stored derivative) epilogue; ln_stats / ln_cs 16-byte aligned");
     const int cs = gd_dtype_size(c_dtype), ccs = csplit ? 2 : cs;
     auto al = [&](const void* q, long ld) { return q == nullptr || ((((uintptr_t)q) & 15) == 0 && (ld * cs) % 16 == 0); };
     p.vec_epilogue = ((uintptr_t)C & 15) == 0 && (ldc * ccs) % 16 == 0 && (sC * ccs) % 16 == 0 && al(preact, ldp) && al(dact_src, ldd) && al(residual, ldr) &&
@@ -877,10 +865,6 @@ static int gemm_nt_impl(const void* A, const void* W, void* C, int M, int N, int
     p.probe = gd_probe_buffer();
     p.k_rot = gd_knobs().gemm_krot;
     p.group_m = gd_knobs().gemm_group_m > 0 ? gd_knobs().gemm_group_m : 1;
-    // start-up skew of the persistent kernel (gemm_persist.h), an experiment knob: back-to-back stand-alone launches of the K = 768 shapes gain 6 ... 24 us
-    // (proj + fp32 residual 176 -> 152 us: the CUs stop running their epilogues in lockstep), the step does not (58.2 vs 58.2 ms, two alternating pairs of
-    // runs: in the step a launch starts on CUs that the previous kernel releases at different times) — profiles/r04_gemm_stagger.txt.  Default 0.
-    p.stagger = gd_knobs().gemm_stagger > 0 ? gd_knobs().gemm_stagger : 0;
     const bool big = dma && N >= 256 && M >= (batch > 1 ? gd_knobs().gemm_batch_big_m : 1024) && !gd_force_small_tiles();
     dim3 gridb(gd_cdiv(M, 256) * gd_cdiv(N, 256), batch);
     hipStream_t st = (hipStream_t)stream;
@@ -924,17 +908,13 @@ static int gemm_nt_impl(const void* A, const void* W, void* C, int M, int N, int
     } else if (ab_dtype == GD_F16 && !accumulate && !(dact_src && residual)) {
         // fp16 operands (tf32h engine): f32 results with f32 epilogue tensors, or fp16 results with fp16 preact / dact_src (as the bf16 engine's)
         const bool ch = c_dtype == GD_F16;
-        // GD_GEMM_K64 (round 5): the four-slot ring of 64-byte stages (gemm_persist.h KS) instead of two slots of 128 bytes
-        const bool k64 = gd_knobs().gemm_k64 != 0;
-#define GD_PK(S, A, P, C, L) (k64 ? gemm_nt_persist_kernel<f16, S, A, P, C, 0, 0, L, 64> : gemm_nt_persist_kernel<f16, S, A, P, C, 0, 0, L, 128>)
+#define GD_PK(S, A, P, C, L) gemm_nt_persist_kernel<f16, S, A, P, C>
         if (!dact_src && !residual) {
             if (act == 0 && !preact) pk = ch ? GD_PK(0, 0, 0, false, 0) : GD_PK(0, 0, 0, true, 0);
             else if ((act == 1 || act == 3) && !preact) pk = ch ? GD_PK(0, 1, 0, false, 0) : GD_PK(0, 1, 0, true, 0);
             else if (act == 3 && preact) pk = ch ? GD_PK(0, 1, 2, false, 0) : GD_PK(0, 1, 2, true, 0);
         } else if (dact_src && dact == 3 && act == 0 && !preact) pk = ch ? GD_PK(3, 0, 0, false, 0) : GD_PK(3, 0, 0, true, 0);
         else if (residual && act == 0 && !preact && !ch) pk = copy16 ? GD_PK(2, 0, 3, true, 0) : GD_PK(2, 0, 0, true, 0);
-        if (ln_part) pk = GD_PK(2, 0, 3, true, 1);
-        if (ln_stats) pk = (act == 3 && preact) ? GD_PK(0, 1, 2, false, 2) : !preact ? GD_PK(0, 1, 0, false, 2) : nullptr;
 #undef GD_PK
     }
     // (the bf16 f32-output instantiations serve the tf32x engine: 3K-wide split operands, fp32 C / preact / dact_src / residual)
@@ -943,7 +923,6 @@ static int gemm_nt_impl(const void* A, const void* W, void* C, int M, int N, int
                "gd_gemm_nt: split output (c_dtype 2) is served by the persistent kernel only: bf16 operands, M >= 1024, N >= 256, K %% 64 == 0, "
                "ldc >= 3N, and the GELU(+derivative) or dact 3 epilogues (M=%d N=%d K=%d act=%d dact=%d)", M, N, K, act, dact);
     GD_REQUIRE(!copy16 || persist_ok, "gd_gemm_nt_copy16: served by the persistent kernel only (M >= 1024, N >= 256, K %% 64 == 0): M=%d N=%d K=%d", M, N, K);
-    GD_REQUIRE(!lnf || persist_ok, "gd_gemm_nt_lnfold_*: served by the persistent kernel only (M >= 1024, N >= 256, K %% 64 == 0): M=%d N=%d K=%d", M, N, K);
 #ifdef GD_GEMM_EXPERIMENT32
     if (persist == 32 && big && ab_dtype == GD_BF16 && c_dtype == GD_BF16 && !bias && !lora_t && !preact && act == 0 && !dact_src && !residual &&
         !accumulate && (K * 2) % 128 == 0) {
@@ -1000,45 +979,6 @@ extern "C" int gd_gemm_nt_scaled(const void* A, const void* W, void* C, int M, i
                                  int accumulate, void* stream) {
     return gemm_nt_impl(A, W, C, M, N, K, lda, ldw, ldc, batch, sA, sW, sC, ab_dtype, c_dtype, alpha, alpha_dev, bias, lora_t, lora_b, lora_rt,
                         preact, ldp, act, dact_src, ldd, dact, residual, ldr, accumulate, stream);
-}
-
-// ---- LayerNorm fold of the tf32h forward (gemm_persist.h LNF) ----
-// emit: C (f32) = alpha A W^T + bias + residual, copy16 = fp16(C) — the UN-normalised left operand of the GEMM behind the LayerNorm — and
-// ln_part [M][N / 64][2] = per 64-column slice (sum, sum of squares) of the C values; gd_ln_fold_stats finishes them.
-extern "C" int gd_gemm_nt_lnfold_emit(const void* A, const void* W, float* C, int M, int N, int K, long lda, long ldw, long ldc, float alpha,
-                                      const float* bias, const float* residual, long ldr, void* copy16, long ldc16, float* ln_part, void* stream) {
-    GD_REQUIRE(ln_part != nullptr && ((uintptr_t)ln_part & 7) == 0, "gd_gemm_nt_lnfold_emit: ln_part");
-    return gemm_nt_impl(A, W, C, M, N, K, lda, ldw, ldc, 1, 0, 0, 0, GD_F16, GD_F32, alpha, nullptr, bias, nullptr, nullptr, 0, nullptr, 0, 0,
-                        nullptr, 0, 0, residual, ldr, 0, stream, copy16, ldc16, nullptr, ln_part);
-}
-// apply: C (fp16) = GELU(rstd_m (alpha A16 W'^T - mean_m cs) + bias') [act 1], with preact receiving GELU'(.) [act 3] — LayerNorm(x) W^T + b
-// for the fp16 rows A16 = fp16(x), W' = W diag(gamma) in fp16, cs[n] = sum_k W'[n][k], bias' = b + W beta, ln_stats [M][2] = (mean, rstd) of x.
-extern "C" int gd_gemm_nt_lnfold_apply(const void* A16, const void* Wp, void* C, int M, int N, int K, long lda, long ldw, long ldc, float alpha,
-                                       const float* bias_p, const float* ln_stats, const float* ln_cs, void* preact, long ldp, int act, void* stream) {
-    GD_REQUIRE(ln_stats != nullptr && ln_cs != nullptr, "gd_gemm_nt_lnfold_apply: ln_stats / ln_cs");
-    return gemm_nt_impl(A16, Wp, C, M, N, K, lda, ldw, ldc, 1, 0, 0, 0, GD_F16, GD_F16, alpha, nullptr, bias_p, nullptr, nullptr, 0, preact, ldp, act,
-                        nullptr, 0, 0, nullptr, 0, 0, stream, nullptr, 0, nullptr, nullptr, ln_stats, ln_cs);
-}
-// partial sums -> statistics: stats [M][2] = (mean, rstd) for the applying GEMM, mean [M] / rstd [M] for the LayerNorm backward (either may be null).
-// var = E[x^2] - mean^2 in fp32 from sums of at most 64 terms added in a fixed order: for LayerNorm inputs (|mean| of the order of the standard
-// deviation or below) the cancellation costs ~1e-7 relative, the same order as the two-pass form's rounding.
-__global__ __launch_bounds__(256) void ln_fold_stats_kernel(const float* __restrict__ part, int M, int np, float inv_n, float eps, float* __restrict__ stats,
-                                                            float* __restrict__ mean, float* __restrict__ rstd) {
-    const int row = blockIdx.x * 256 + threadIdx.x;
-    if (row >= M) return;
-    const f32x2* pr = (const f32x2*)(part + (long)row * np * 2);
-    float s1 = 0.f, s2 = 0.f;
-    for (int i = 0; i < np; ++i) { const f32x2 v = pr[i]; s1 += v[0]; s2 += v[1]; }
-    const float mu = s1 * inv_n, var = fmaxf(s2 * inv_n - mu * mu, 0.f), rs = rsqrtf(var + eps);
-    if (stats) *(f32x2*)(stats + (long)row * 2) = f32x2{mu, rs};
-    if (mean) mean[row] = mu;
-    if (rstd) rstd[row] = rs;
-}
-extern "C" int gd_ln_fold_stats(const float* ln_part, int M, int N, float eps, float* stats, float* mean, float* rstd, void* stream) {
-    GD_REQUIRE(ln_part != nullptr && M > 0 && N > 0 && N % 64 == 0, "gd_ln_fold_stats: M=%d N=%d", M, N);
-    hipLaunchKernelGGL(ln_fold_stats_kernel, dim3(gd_cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, ln_part, M, N / 64, 1.0f / (float)N, eps, stats, mean, rstd);
-    GD_LAUNCH_OK();
-    return 0;
 }
 
 static int gemm_tn_impl(const void* Y, const void* X, float* G, int M, int N, int K, long ldy, long ldx, long ldg,

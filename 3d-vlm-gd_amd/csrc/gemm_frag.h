@@ -71,40 +71,6 @@ __device__ __forceinline__ void chunk_rows67(const FragHead& h, const FragTail& 
     mma_row<T>(acc[7], t.a7, h.b0, h.b1, h.b2, h.b3);
 }
 
-// ---- the same chunk on a 64-BYTE-row LDS image (gemm_persist.h KS = 64: one chunk per ring stage, four slots): m-tiles / n-tiles are 1 KB apart ----
-__device__ __forceinline__ void frag_head_issue64(FragHead& h, unsigned aaddr, unsigned baddr) {
-    GD_DSR128(h.b0, baddr, 0); GD_DSR128(h.b1, baddr, 1024); GD_DSR128(h.b2, baddr, 2048); GD_DSR128(h.b3, baddr, 3072);
-    GD_DSR128(h.a0, aaddr, 0);
-}
-template <typename T>
-__device__ __forceinline__ void chunk_rows05_64(FragHead& h, FragTail& t, unsigned aaddr, f32x4 (&acc)[8][4]) {
-    f32x4 a1, a2, a3, a4, a5;
-    GD_DSR128(a1, aaddr, 1024); GD_DSR128(a2, aaddr, 2048); GD_DSR128(a3, aaddr, 3072); GD_DSR128(a4, aaddr, 4096);
-    GD_DSR128(a5, aaddr, 5120); GD_DSR128(t.a6, aaddr, 6144); GD_DSR128(t.a7, aaddr, 7168);
-    asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(h.b0), "+v"(h.b1), "+v"(h.b2), "+v"(h.b3), "+v"(h.a0));
-    mma_row<T>(acc[0], h.a0, h.b0, h.b1, h.b2, h.b3);
-    asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a1));
-    mma_row<T>(acc[1], a1, h.b0, h.b1, h.b2, h.b3);
-    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a2), "+v"(a3));
-    mma_row<T>(acc[2], a2, h.b0, h.b1, h.b2, h.b3);
-    mma_row<T>(acc[3], a3, h.b0, h.b1, h.b2, h.b3);
-    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a4), "+v"(a5));
-    mma_row<T>(acc[4], a4, h.b0, h.b1, h.b2, h.b3);
-    mma_row<T>(acc[5], a5, h.b0, h.b1, h.b2, h.b3);
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t.a6), "+v"(t.a7));
-}
-// 16-byte slot of (row, logical chunk g) in a 64-byte-row image: g ^ swz64(row).  ds_read_b128 serves four groups of 16 lanes, each group the rows
-// {a, a + 4, a + 8, a + 12} x 4 of one or two logical chunks; with f = (0, 3, 2, 1)[(row >> 2) & 3] every group touches 16 distinct 16-byte slots of the
-// 256-byte bank row (derivation: DESIGN.md section 5, round 5)
-__device__ __forceinline__ int swz64(int row) { return (0 - (row >> 2)) & 3; }
-// wait until at most n vector-memory operations of this wave are outstanding, n rounded DOWN to a multiple of 4 (at most 60)
-__device__ __forceinline__ void wait_vm_le4(int n) {
-#define GD_W4(k) else if (n >= k) asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory")
-    if (n >= 60) asm volatile("s_waitcnt vmcnt(60)" ::: "memory");
-    GD_W4(56); GD_W4(52); GD_W4(48); GD_W4(44); GD_W4(40); GD_W4(36); GD_W4(32); GD_W4(28); GD_W4(24); GD_W4(20); GD_W4(16); GD_W4(12); GD_W4(8); GD_W4(4);
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#undef GD_W4
-}
 
 // wait until at most n vector-memory operations of this wave are outstanding (n rounded DOWN to a multiple of 8:
 // conservative).  VMEM operations retire in issue order on gfx9-family parts, so "the S youngest may stay in flight"

@@ -32,30 +32,15 @@
 // Instantiated only in -DGD_GEMM_ANATOMY builds (gemm.hip); round-3 results: profiles/r03_gemm_anatomy.txt.
 // COUT (with CF32; 0 = C has the side tensors' type): 1 = C leaves as the three-plane bf16 operand split of the f32 result — [hi | lo | hi] over 3N columns of row stride
 // ldc (gd_split3 'a' layout), the A operand of the next tf32x GEMM — instead of f32 followed by a gd_split3 pass; side / preact stay f32.
-// LNF (round 5, the LayerNorm FOLD of the tf32h forward: the LayerNorm pass between a residual GEMM and the GEMM that consumes the normalised rows
-// disappears).  1 = this GEMM's C is a residual-stream tensor that a LayerNorm follows: beside C (f32) and its fp16 copy (PREACT 3) every wave
-// stores, per row and 64-column slice, the partial sums (sum v, sum v^2) of the FINAL values — p.ln_part [M][N / 64][2], finished into (mean, rstd)
-// by ln_fold_stats_kernel.  2 = this GEMM's A operand is that UN-normalised fp16 copy and its W is W' = W diag(gamma) (fp16): the epilogue applies
-// the normalisation to the product, v = rstd_m (alpha acc - mean_m cs_n) + bias'_n with cs_n = sum_k W'[n][k] (of the ROUNDED W') and
-// bias' = bias + W beta — LayerNorm(x) W^T + b exactly, for the fp16-rounded x.  The tile's 256 (mean, rstd) pairs and its cs slice arrive by
-// LDS-DMA with the bias slice.
-// KS (round 5): bytes of an operand row per ring stage.  128 = the two-slot ring of rounds 1-4 (a K step of two MFMA chunks per stage, ONE stage in flight
-// while a step computes: the loop waits ~40 % of its time for that stage to land).  64 = FOUR slots of one chunk each, the same 128 KB: the stage
-// barrier comes after every chunk and releases the slot just read to the stage four chunks ahead, so THREE half-size stages are in flight under a
-// chunk's MFMAs (96 KB against 64 KB).  The LDS image has 64-byte rows (16 rows per 1-KB DMA piece, swz64).
-template <typename T, int SIDE, int ACT, int PREACT, bool CF32, int ANAT = 0, int COUT = 0, int LNF = 0, int KS = 128>
+template <typename T, int SIDE, int ACT, int PREACT, bool CF32, int ANAT = 0, int COUT = 0>
 __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
     constexpr int NWN = 4, WMT = 8, NW = 8, BM = 256, BN = 256;
-    static_assert(KS == 128 || (KS == 64 && ANAT == 0), "ring stage: 128-byte rows (two slots) or 64-byte rows (four slots)");
-    constexpr int RPP = 1024 / KS, NSLOT = KS == 64 ? 4 : 2;      // rows per 1-KB DMA piece; ring slots
+    constexpr int KS = 128, RPP = 1024 / KS, NSLOT = 2;      // bytes of an operand row per ring stage; rows per 1-KB DMA piece; ring slots
     constexpr int ABYTES = BM * KS, STAGE = (BM + BN) * KS, APW = BM / RPP / NW, BPW = BN / RPP / NW;
     constexpr int SDEP = CF32 ? GD_SDEP32 : 16;   // side-input prefetch depth (items per lane in flight: 8 bytes each for bf16 side tensors, 16 for f32)
     constexpr int ssz = CF32 ? 4 : 2;     // element size of the side tensor (dact_src / residual): the dtype of C
     constexpr int LORA_OFF = NSLOT * STAGE, BIAS_OFF = LORA_OFF + (BM + BN) * 32;
-    constexpr int LNCS_OFF = BIAS_OFF + 2 * BN * 4, LNST_OFF = LNCS_OFF + 2 * BN * 4;      // LNF 2: cs slices [2][BN] f32, (mean, rstd) [2][BM][2] f32
-    static_assert(LNF == 0 || (LNF == 1 && SIDE == 2 && PREACT == 3 && CF32) || (LNF == 2 && SIDE == 0), "LayerNorm fold: emit with the residual + fp16 copy, apply without a side tensor");
-    constexpr int LNP_OFF = BIAS_OFF + 2 * BN * 4;      // LNF 1: the tile's row partials [BM][4 waves across N][2] f32, written by the epilogue, flushed to global at the top of the next tile
-    __shared__ __attribute__((aligned(16))) char smem[LNF == 2 ? LNST_OFF + 2 * BM * 8 : LNF == 1 ? LNP_OFF + BM * 4 * 8 : BIAS_OFF + 2 * BN * 4];
+    __shared__ __attribute__((aligned(16))) char smem[BIAS_OFF + 2 * BN * 4];
     typedef typename Mma<T>::Frag Frag;
     constexpr int KPL = sizeof(Frag) / sizeof(T);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -93,20 +78,19 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
     // moment, rotated one tile fetches a slice and the others hit it.
     int krot = 0;
     auto set_tile = [&](int tm, int tn) {
-        // (KS = 64: the rotation is taken in 128-byte steps and applied in chunks, so both ring forms walk K in the same order: bit-identical sums)
-        krot = p.k_rot ? ((tn * p.k_rot + tm) % (nk * KS / 128)) * (128 / KS) : 0;
+        krot = p.k_rot ? (tn * p.k_rot + tm) % nk : 0;
         abase_t = Ab + (long)tm * BM * lda_b;
         wbase_t = Wb + (long)tn * BN * ldw_b;
         const int av = min(BM, p.M - tm * BM) - 1, wv = min(BN, p.N - tn * BN) - 1;
 #pragma unroll
         for (int i = 0; i < APW; ++i) {
-            const int row = (wave * APW + i) * RPP + (KS == 64 ? lane >> 2 : lane >> 3);
-            aoff[i] = (unsigned)(min(row, av) * (int)lda_b + (KS == 64 ? (lane & 3) ^ swz64(row) : (lane & 7) ^ swz(row)) * 16);
+            const int row = (wave * APW + i) * RPP + (lane >> 3);
+            aoff[i] = (unsigned)(min(row, av) * (int)lda_b + ((lane & 7) ^ swz(row)) * 16);
         }
 #pragma unroll
         for (int i = 0; i < BPW; ++i) {
-            const int row = (wave * BPW + i) * RPP + (KS == 64 ? lane >> 2 : lane >> 3);
-            woff[i] = (unsigned)(min(nperm64(row), wv) * (int)ldw_b + (KS == 64 ? (lane & 3) ^ swz64(row) : (lane & 7) ^ swz(row)) * 16);
+            const int row = (wave * BPW + i) * RPP + (lane >> 3);
+            woff[i] = (unsigned)(min(nperm64(row), wv) * (int)ldw_b + ((lane & 7) ^ swz(row)) * 16);
         }
     };
     auto issue = [&](int kt0, int buf) {
@@ -141,18 +125,6 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bias + bc),
                                              (__attribute__((address_space(3))) void*)(smem + BIAS_OFF + slot * BN * 4), 16, 0, 0);
         }
-        if (LNF == 2 && wave == 1) {
-            const int bc = min(tn * BN + lane * 4, p.N - 4);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.ln_cs + bc),
-                                             (__attribute__((address_space(3))) void*)(smem + LNCS_OFF + slot * BN * 4), 16, 0, 0);
-        }
-        if (LNF == 2 && (wave == 2 || wave == 3)) {      // rows 2 l, 2 l + 1 of the tile per lane (16 bytes); rows past M re-read the last pair (never stored)
-            // (the pair stays EVEN-aligned — a 16-byte LDS-DMA from an 8-byte-aligned address delivers garbage for the whole instruction — so with an odd M
-            //  the last pair is (M - 1, M): ln_stats has room for an even number of rows, gd_hip.h)
-            const int r0 = min(tm * BM + 2 * (lane + 64 * (wave - 2)), (p.M - 1) & ~1);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.ln_stats + (long)r0 * 2),
-                                             (__attribute__((address_space(3))) void*)(smem + LNST_OFF + slot * BM * 8 + (wave - 2) * 1024), 16, 0, 0);
-        }
     };
 
     const int abase = (wm * WMT * 16 + fr) * KS, bbase = ABYTES + (wn * 64 + fr) * KS;
@@ -181,35 +153,10 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
         issue(0, 0);
         issue_side(tm_, tn_, slot_);
         if (nk > 1) issue(1, 1);
-        if (KS == 64) {
-            if (nk > 2) issue(2, 2);
-            if (nk > 3) issue(3, 3);
-        }
     };
     prologue(tm, tn, slot);
-    if (p.stagger) {
-        // start-up skew (experiment): the CUs run their epilogues at P different phases of a tile instead of all at once.
-        // p.stagger = ticks (10 ns) | P << 16 (0: 4) | mode << 24 (0: phase = CU slot within its XCD; 1: phase = XCD)
-        const int P = ((p.stagger >> 16) & 0xff) ? ((p.stagger >> 16) & 0xff) : 4, mode = p.stagger >> 24;
-        const int ph = (mode == 1 ? (int)blockIdx.x : (int)(blockIdx.x >> 3)) % P;
-        const unsigned long long until = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(ph * (p.stagger & 0xffff));
-        while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(8);
-    }
     // VMEM instructions every wave issues unconditionally in one epilogue (buffer ops, range-checked by the hardware)
     int after = 0;   // of those, how many were issued after this tile's stage-1 DMA (0 for the block's first tile)
-
-    // LNF 1: the previous tile's row partials, LDS -> p.ln_part [M][N / 64][2]: thread (row = tid / 2, half = tid & 1) moves the 16 bytes of two 64-column
-    // slices — ONE store per wave and tile instead of one per output item (32 four-lane stores per wave cost 14 us per projection launch)
-    int ptm = -1, ptn = 0;
-    auto ln_flush = [&]() {
-        if (LNF != 1 || ptm < 0) return;
-        const int row = tid >> 1, half = tid & 1;
-        f32x4 q;
-        GD_DSR128(q, lds_off(smem + LNP_OFF) + (row * 4 + half * 2) * 8, 0);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q));
-        if (ptm * BM + row < p.M)
-            *(__attribute__((address_space(1))) f32x4*)((uintptr_t)(p.ln_part + (((long)ptm * BM + row) * (p.N >> 6) + ptn * 4 + half * 2) * 2)) = q;
-    };
 
     GD_PROBE_DECL(unsigned long long pc0 = 0; unsigned long long pw = 0; unsigned long long pm = 0; unsigned long long pe = 0; unsigned long long pn = 0; unsigned long long pd = 0; unsigned long long pb = 0;)
     for (;;) {
@@ -220,12 +167,9 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         // stage 0, LoRA tiles and bias of this tile have landed
-        if (KS == 64) wait_vm_le4(min(60, after + (APW + BPW) * min(3, nk - 1)));
-        else wait_vm_le(after + (nk > 1 ? APW + BPW : 0));
-        if (LNF == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's LDS partials of the previous tile have landed before the others read them
+        wait_vm_le(after + (nk > 1 ? APW + BPW : 0));
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        ln_flush();      // (every wave's LDS partials of the previous tile are complete behind this barrier; the K-step barriers below keep the next epilogue's writes behind these reads)
         GD_PROBE({ const unsigned long long c = __builtin_amdgcn_s_memtime(); pw += c - pc0; pc0 = c; })
         if (lora) {
             // bf16 operands with f32 results (the tf32x engine): the chunk's 24 spare k slots carry the split-precision terms — lane groups
@@ -272,29 +216,6 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
         FragHead P, Q;
         FragTail tl;
         constexpr bool AN_MM = ANAT == 0 || ANAT == 1 || ANAT == 4, AN_RD = AN_MM || ANAT == 2;
-        if constexpr (KS == 64) {
-            // Four-slot ring, one chunk per stage.  Program order of a wave: [prologue: stages 0-3] [previous epilogue: `after` operations] then per
-            // chunk c: reads + MFMAs of stage c | wait(stage c + 1) | barrier | DMA of stage c + 4 into the slot just read | ...  When stage c + 1 is
-            // waited for, the stages c + 2 and c + 3 are younger (2 x 4 pieces; fewer at the end of the tile), and so are the previous epilogue's
-            // operations as long as c + 1 is a prologue stage (c <= 2).
-            const int co = (g ^ swz64(fr)) * 16;
-            frag_head_issue64(P, lds0 + abase + co, lds0 + bbase + co);
-            auto chunk = [&](FragHead& cur, FragHead& nxt, int c) __attribute__((always_inline)) {
-                const unsigned sbo = lds0 + (c & 3) * STAGE, nsbo = lds0 + ((c + 1) & 3) * STAGE;
-                chunk_rows05_64<T>(cur, tl, sbo + abase + co, acc);
-                const int ahead = min(2, max(0, nk - 2 - c));      // stages younger than stage c + 1 that have been issued
-                wait_vm_le4(min(60, (APW + BPW) * ahead + (c <= 2 ? after : 0)));
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                if (c + 4 < nk) issue(c + 4, c & 3);
-                if (c + 1 < nk) frag_head_issue64(nxt, nsbo + abase + co, nsbo + bbase + co);
-                chunk_rows67<T>(cur, tl, acc);
-            };
-            for (int c = 0; c < nk; c += 2) {      // (nk is even: the host takes this form only then)
-                chunk(P, Q, c);
-                chunk(Q, P, c + 1);
-            }
-        } else {
         if (AN_RD) frag_head_issue(P, lds0 + abase + co0, lds0 + bbase + co0);
         for (int kt = 0; kt < nk; ++kt) {
             const unsigned sbo = lds0 + (kt & 1) * STAGE, nsbo = lds0 + ((kt + 1) & 1) * STAGE;
@@ -316,7 +237,6 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
             if (kt + 1 < nk && AN_RD) frag_head_issue(P, nsbo + abase + co0, nsbo + bbase + co0);
             if (AN_MM) chunk_rows67<T>(Q, tl, acc);
         }
-        }
         const int ctm = tm, ctn = tn, cslot = slot;
         GD_PROBE({ const unsigned long long c = __builtin_amdgcn_s_memtime(); pm += c - pc0; pc0 = c; })
         // ---- epilogue from the accumulators.  Item (i, r) = row 16i + 4g + r of the wave tile, this lane's four columns
@@ -336,13 +256,6 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
             GD_DSR128(bv, biasaddr, 0);
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bv));
         }
-        f32x4 csv = {0.f, 0.f, 0.f, 0.f};
-        if (LNF == 2) {
-            const unsigned csaddr = lds_off(smem + LNCS_OFF) + cslot * BN * 4 + (wn * 64 + fr * 4) * 4;
-            GD_DSR128(csv, csaddr, 0);
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(csv));
-        }
-        const unsigned lnst_addr = lds_off(smem + (LNF == 2 ? LNST_OFF : 0)) + cslot * BM * 8 + (wm * WMT * 16 + g * 4) * 8;      // (mean, rstd) of item (0, 0)'s row
         int rloc = wm * WMT * 16 + g * 4, col0 = ctn * BN + wn * 64 + fr * 4;
         asm volatile("" : "+v"(rloc), "+v"(col0));   // keep the per-item byte offsets out of the main loop's live range (LICM)
         const int OOB = 0x7ffffff0;   // beyond every num_records: the hardware drops the access
@@ -388,13 +301,6 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
         t += gridDim.x;
         const bool more = t < ntiles;
         after = (NITEM - DMA_AT) * ((CSPLIT ? 3 : 1) + (PREACT ? 1 : 0));   // epilogue VMEM instructions younger than the stage-1 DMA
-        // (LNF 1: the flush store of the NEXT tile's top is one more instruction younger than that DMA: counting one too few is the safe direction)
-        const unsigned lnp_addr = lds_off(smem + (LNF == 1 ? LNP_OFF : 0)) + (rloc * 4 + wn) * 8;      // LNF 1: this wave's slot of row rloc in the LDS partials
-        if (LNF == 1) { ptm = ctm; ptn = ctn; }
-        // LNF 2: (mean, rstd) of the four rows r of m-tile i — two 16-byte LDS reads per m-tile, issued one m-tile AHEAD (a read waited for on the spot
-        // cost its full latency eight times per tile: +21 ... +34 us per fc1 launch)
-        f32x4 lnst[2] = {}, lnxt[2] = {};
-        if (LNF == 2) { GD_DSR128(lnxt[0], lnst_addr, 0); GD_DSR128(lnxt[1], lnst_addr, 16); }
 #pragma unroll
         for (int idx = 0; idx < NITEM; ++idx) {
             const int i = idx >> 2, r = idx & 3;
@@ -409,24 +315,8 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
             }
             const int coff = cbase + (i * 16 + r) * ccsz * ldc_i, poff = pbase + (i * 16 + r) * psz * ldp_i;
             float v[4];
-            if (LNF == 2) {
-                if (r == 0) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lnxt[0]), "+v"(lnxt[1]));
-                    lnst[0] = lnxt[0]; lnst[1] = lnxt[1];
-                    if (i + 1 < WMT) {
-                        const unsigned sa_ = lnst_addr + (i + 1) * 128;      // 16 rows x 8 bytes per m-tile
-                        GD_DSR128(lnxt[0], sa_, 0); GD_DSR128(lnxt[1], sa_, 16);
-                    }
-                }
-                // v = rstd (alpha acc - mean cs) + b' = (rstd alpha) acc + (b' - rstd mean cs)
-                const float mu = lnst[r >> 1][2 * (r & 1)], rs = lnst[r >> 1][2 * (r & 1) + 1];
-                const float c1 = rs * alpha, c2 = -rs * mu;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = fmaf(c1, acc[i][j][r], fmaf(c2, csv[j], bv[j]));
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = fmaf(alpha, acc[i][j][r], bv[j]);
-            }
+            for (int j = 0; j < 4; ++j) v[j] = fmaf(alpha, acc[i][j][r], bv[j]);
             if (PREACT == 1) bst4_aux<GD_PERSIST_STORE_AUX>(prs, poff, cdt, v);
             if (ACT == 1 && PREACT == 2) {   // GELU and its derivative from one shared exponential; the derivative is what is stored
                 float dv[4];
@@ -460,17 +350,6 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
                 const float c16[4] = {v[0] * cscale, v[1] * cscale, v[2] * cscale, v[3] * cscale};
                 bst4_aux<GD_PERSIST_STORE_AUX>(prs, poff, GD_F16, c16);
             }
-            if (LNF == 1) {
-                // (of the f32 values C receives: the statistics the LayerNorm backward will use for this row)
-                float s1 = (v[0] + v[1]) + (v[2] + v[3]);
-                float s2 = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], v[3] * v[3])));
-                s1 = row16_sum(s1); s2 = row16_sum(s2);
-                if (fr == 0) {
-                    const f32x2 sv = {s1, s2};
-                    const unsigned a_ = lnp_addr + (i * 16 + r) * 32;
-                    asm volatile("ds_write_b64 %0, %1" : : "v"(a_), "v"(sv) : "memory");
-                }
-            }
             if (CSPLIT) {
                 float lo[4];
 #pragma unroll
@@ -486,11 +365,6 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(GemmNtParams p) {
         }
         GD_PROBE({ const unsigned long long c = __builtin_amdgcn_s_memtime(); pe += c - pc0; pn += 1; })
         if (!more) break;
-    }
-    if (LNF == 1) {      // the last tile's partials
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        ln_flush();
     }
     GD_PROBE(if (tid == 0) {
         atomicAdd(p.probe + 0, pw); atomicAdd(p.probe + 1, pm); atomicAdd(p.probe + 2, pe); atomicAdd(p.probe + 3, pn); atomicAdd(p.probe + 4, pd); atomicAdd(p.probe + 5, pb);

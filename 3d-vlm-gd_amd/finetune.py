@@ -197,36 +197,7 @@ class FinetuneGD(nn.Module):
         for p in ps:
             p.grad = None
         self._flat["g"].zero_()          # BEFORE the backward: blocks prepared with the flat record accumulate straight into it
-        # the blocks' weight-gradient contractions on a second stream, on a few compute units the persistent kernels leave free for the duration
-        # of the backward (options.py wgrad_stream / wgrad_reserve_cus; vit._wgrad_side).  Armed only when the blocks write into the flat buffer.
-        wg = getattr(self.model, "_wgrad", None)
-        side, prev = None, 0
-        if wg is not None and option("wgrad_stream") and loss.is_cuda and getattr(self.model, "_direct", None) is not None:
-            from ._lib import check, lib
-            k = int(option("wgrad_reserve_cus"))
-            masked = option("wgrad_stream") == 2 and k > 0
-            key = (k if masked else 0, loss.device)
-            if getattr(self, "_wgrad_stream", None) is None or self._wgrad_stream[0] != key:
-                if masked:
-                    # confined to the k compute units the persistent kernels stay off: without the mask the side kernels' blocks spread over every CU
-                    # and a one-block-per-CU launch (149 KB of LDS) cannot start until they have drained
-                    import ctypes
-                    h = ctypes.c_void_p()
-                    check(lib().gd_stream_create_cu_mask(k, ctypes.byref(h)), "gd_stream_create_cu_mask")
-                    self._wgrad_stream = (key, torch.cuda.ExternalStream(h.value, device=loss.device))      # (lives as long as the engine)
-                else:
-                    self._wgrad_stream = (key, torch.cuda.Stream(device=loss.device))
-            side = wg["stream"] = self._wgrad_stream[1]
-            prev = lib().gd_debug_get(b"reserve_cus")
-            check(lib().gd_debug_set(b"reserve_cus", max(prev, k)), "gd_debug_set(reserve_cus)")
-        try:
-            loss.backward()
-        finally:
-            if side is not None:
-                torch.cuda.current_stream().wait_stream(side)      # every weight gradient has landed before anyone reads the flat buffer
-                wg["stream"] = None
-                wg["keep"].clear()
-                check(lib().gd_debug_set(b"reserve_cus", prev), "gd_debug_set(reserve_cus)")
+        loss.backward()
         ops.amax_clear()                 # (tf32h: a gradient scale nobody consumed must not outlive its backward pass)
         self.model.finish_trainable_grads()
         if pre_gather is not None:       # e.g. OverlappedGradReducer.wait_early: hook-launched all-reduces of some p.grad
@@ -352,7 +323,7 @@ class FinetuneGD(nn.Module):
         if key not in self._fwd_cache:
             P = self.patch_size
             if getattr(self, "_fuse_taps", False):   # training_step: every tap is also wanted final-normed
-                taps, x, normed = self.model.forward_all(rgbs, (4, 5, 6, 7), size=(gh * P, gw * P), norm_taps=True)
+                taps, x, normed = self.model.forward_all(rgbs, (4, 5, 6, 7), size=(gh * P, gw * P), norm_taps="deferred")
                 self._norm_cache[key] = normed
             else:
                 taps, x = self.model.forward_all(rgbs, (4, 5, 6, 7), size=(gh * P, gw * P))

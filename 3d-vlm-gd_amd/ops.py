@@ -319,48 +319,6 @@ def gemm_tn(y, x, out=None, *, alpha=1.0, alpha_dev=None):
     return out
 
 
-def lnfold_ok(M, N, K):
-    """shapes the LayerNorm-fold GEMMs serve (the persistent fp16-operand kernel, whole 256-column tiles)."""
-    return M >= 1024 and N >= 256 and N % 256 == 0 and K % 64 == 0
-
-
-def gemm_nt_lnfold_emit(a16, w16, residual, bias=None, alpha=1.0):
-    """C [M, N] f32 = alpha a16 . w16^T + bias + residual, its fp16 copy, and the per-row partial sums a LayerNorm of C needs
-    (gd_gemm_nt_lnfold_emit) -> (C, C16, part [M, N / 64, 2])."""
-    M, K = a16.shape
-    N = w16.shape[0]
-    _req(a16.dtype == torch.float16 and w16.dtype == torch.float16 and residual.dtype == torch.float32 and lnfold_ok(M, N, K), "gemm_nt_lnfold_emit: bad operands")
-    c = torch.empty(M, N, dtype=torch.float32, device=a16.device)
-    c16 = torch.empty(M, N, dtype=torch.float16, device=a16.device)
-    part = torch.empty(M, N // 64, 2, dtype=torch.float32, device=a16.device)
-    check(lib().gd_gemm_nt_lnfold_emit(ptr(a16), ptr(w16), ptr(c), M, N, K, a16.stride(0), w16.stride(0), N, float(alpha), ptr(bias), ptr(residual),
-                                       residual.stride(0), ptr(c16), N, ptr(part), stream()), "gd_gemm_nt_lnfold_emit")
-    return c, c16, part
-
-
-def ln_fold_stats(part, N, eps, want_rows=True):
-    """partial sums -> (stats [M, 2] = (mean, rstd) for gemm_nt_lnfold_apply, mean [M], rstd [M] for the LayerNorm backward — None unless want_rows)."""
-    M = part.shape[0]
-    stats = torch.zeros(M + (M & 1), 2, dtype=torch.float32, device=part.device)[:M]      # (room for an even number of rows: the applying GEMM fetches row pairs)
-    mean = torch.empty(M, dtype=torch.float32, device=part.device) if want_rows else None
-    rstd = torch.empty(M, dtype=torch.float32, device=part.device) if want_rows else None
-    check(lib().gd_ln_fold_stats(ptr(part), M, N, float(eps), ptr(stats), ptr(mean), ptr(rstd), stream()), "gd_ln_fold_stats")
-    return stats, mean, rstd
-
-
-def gemm_nt_lnfold_apply(a16, wp16, bias_p, stats, cs, preact=None, alpha=1.0):
-    """GELU(LayerNorm(x) . W^T + b) as fp16 from the UN-normalised fp16 rows a16 = fp16(x): wp16 = fp16(W diag(gamma)), cs = its row sums,
-    bias_p = b + W beta, stats = (mean, rstd) of x; preact (fp16 [M, N], optional) receives GELU'(.) (gd_gemm_nt_lnfold_apply)."""
-    M, K = a16.shape
-    N = wp16.shape[0]
-    _req(a16.dtype == torch.float16 and wp16.dtype == torch.float16 and lnfold_ok(M, N, K) and stats.shape == (M, 2), "gemm_nt_lnfold_apply: bad operands")
-    _req(preact is None or (preact.dtype == torch.float16 and preact.shape == (M, N) and preact.is_contiguous()), "gemm_nt_lnfold_apply: preact")
-    c = torch.empty(M, N, dtype=torch.float16, device=a16.device)
-    check(lib().gd_gemm_nt_lnfold_apply(ptr(a16), ptr(wp16), ptr(c), M, N, K, a16.stride(0), wp16.stride(0), N, float(alpha), ptr(bias_p), ptr(stats),
-                                        ptr(cs), ptr(preact), N, 3 if preact is not None else 1, stream()), "gd_gemm_nt_lnfold_apply")
-    return c
-
-
 VARIANTS = {"vggt": 0, "mast3r": 1}
 
 

@@ -20,8 +20,6 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-import contextlib
-
 from . import ops
 from .options import option
 from .model import Adapter, BlockWithAdapter, _LoRA_qkv  # noqa: F401
@@ -144,13 +142,6 @@ class GDBlock(nn.Module):
         p["wproj"], p["wproj_t"] = both(wproj)
         p["w1"], p["w1_t"] = both(w1)
         p["w2"], p["w2_t"] = both(wfc2)
-        if x3 == "h":
-            # LayerNorm fold (options.ln2_fold): norm2 -> fc1 as ONE product on the un-normalised fp16 rows.  W' = W diag(gamma) rounded to fp16, cs = the
-            # row sums of the ROUNDED W' (what the MFMA multiplies the row mean with), b' = b + W beta in fp32.
-            g2w, b2w = p["ln2_w"], p["ln2_b"]
-            wf = (w1 * g2w[None, :]).to(torch.float16).contiguous()
-            p["w1_fold"], p["w1_fold_cs"] = wf, wf.float().sum(1).contiguous()
-            p["b1_fold"] = (p["b1"] + w1 @ b2w).contiguous()
         self._plan = p
         return p
 
@@ -167,20 +158,31 @@ def _unwrap(blk):
     return blk, lora, adapter
 
 
-@contextlib.contextmanager
-def _wgrad_side(wg, *keep):
-    """Weight-gradient work of a block on the engine's second stream (FinetuneGD.backward arms `wg["stream"]`; None: stay on the current stream).
-    The side stream first waits for everything the current stream has been given so far (the operands are then complete); `keep` holds the operands
-    until the backward's closing wait — autograd drops its references when the node returns, and the caching allocator would hand a freed block to
-    the next allocation of the MAIN stream while the side stream is still reading it."""
-    s = None if wg is None else wg["stream"]
-    if s is None:
-        yield False
-        return
-    s.wait_stream(torch.cuda.current_stream())
-    wg["keep"].extend(t for t in keep if t is not None)
-    with torch.cuda.stream(s):
-        yield True
+class BlockGradGate:
+    """When may a block's slices of the flat gradient buffer be exchanged?  When the LAST backward node the block owes this step has run — not the
+    first.  geometry="reference" runs two `forward_all` passes per step through the same blocks (the 80 x 80 keypoint grid and the cost grid:
+    FinetuneGD.training_step), so every block has two backward nodes per `loss.backward()` and both accumulate into the same slices (`gemm_tn(out=)`
+    is +=): an all-reduce started after the first would race with the second's accumulation and exchange its share twice.  `_BlockFn.forward`
+    calls `armed()` for every node it records, `_BlockFn.backward` calls `node_done()`; the hook (dp.OverlappedGradReducer._block_done) fires at zero.
+    A node whose backward never runs (its output did not reach the loss) leaves the count above zero: the hook then never fires and the slices
+    travel with the reducer's late ranges after the backward (`remaining_late`) — late, never wrong."""
+
+    def __init__(self, hook, block_index, spans):
+        self.hook, self.block_index, self.spans, self.pending, self.fired = hook, block_index, spans, 0, False
+
+    def armed(self):
+        if self.fired:
+            raise RuntimeError("BlockGradGate: a forward through a block whose gradient slices were already handed to the exchange this step")
+        self.pending += 1
+
+    def node_done(self):
+        """-> True when this was the block's last outstanding backward node (the hook has then been called)."""
+        self.pending -= 1
+        if self.pending == 0 and not self.fired:
+            self.fired = True
+            self.hook(self.block_index, self.spans)
+            return True
+        return False
 
 
 class _BlockFn(torch.autograd.Function):
@@ -217,33 +219,21 @@ class _BlockFn(torch.autograd.Function):
                 t = ops.gemm_nt(y1s, tw["at_w3"] if tw is not None and "at_w3" in tw else _opw(at.contiguous(), fmt), out_dtype=torch.float32)
             else:
                 t = ops.gemm_nt(y1, at_T, out_dtype=torch.float32)  # [M, 2r]
-        fold2 = False
         if fmt == "h":     # tf32h: q / k / v, the attention output and their gradients live as fp16 — they are operands of matrix products only
             qkv = _mm(y1, plan, "wqkv", xs=y1s, bias=plan["bqkv"], lora_t=t, lora_b=bt, out_dtype=torch.float16)
             o, lse = ops.attention_fwd(qkv, B, Nt, H)
-            fold2 = bool(option("ln2_fold")) and "w1_fold" in plan and ops.lnfold_ok(M, D, D) and ops.lnfold_ok(M, plan["w1"].shape[0], D)
-            if fold2:      # the projection leaves x1, its fp16 copy and the row sums LayerNorm 2 needs: no LayerNorm pass (below)
-                x1, x1h, part2 = ops.gemm_nt_lnfold_emit(o, plan["wproj"], x, bias=plan["bproj"])
-            else:
-                x1 = _mm(None, plan, "wproj", xs=o, bias=plan["bproj"], residual=x)
+            x1 = _mm(None, plan, "wproj", xs=o, bias=plan["bproj"], residual=x)
         else:
             qkv = _mm(y1, plan, "wqkv", xs=y1s, bias=plan["bqkv"], lora_t=t, lora_b=bt)
             o, lse = ops.attention_fwd(qkv, B, Nt, H, x3=bool(fmt))
             x1 = _mm(o, plan, "wproj", bias=plan["bproj"], residual=x)
-        fold2 = fmt == "h" and fold2
-        if not fold2:
-            y2, mean2, rstd2 = ops.layernorm_fwd(x1, plan["ln2_w"], plan["ln2_b"], plan["eps2"], save_stats=need, **h16)
+        y2, mean2, rstd2 = ops.layernorm_fwd(x1, plan["ln2_w"], plan["ln2_b"], plan["eps2"], save_stats=need, **h16)
         # tf32x: fc1 writes GELU(.) directly as the split left operand of fc2 (no f32 [M, 4D] round trip + split pass)
         # (tf32h: as fp16, and the stored GELU'(.) — a factor of an elementwise product in the backward — as fp16 too)
         hs = bool(fmt) and ops.split_out_ok(M, plan["w1"].shape[0], plan["w1"].shape[1])
         pre = torch.empty(M, plan["w1"].shape[0], dtype=torch.float16 if (fmt == "h" and hs) else T, device=x.device) if need else None
         hkw = {} if not hs else {"out_split": True} if fmt == "x3" else {"out_dtype": torch.float16}
-        if fold2:       # fc1 on the un-normalised rows against W diag(gamma); (mean, rstd) applied to the product in its epilogue
-            st2, mean2, rstd2 = ops.ln_fold_stats(part2, D, plan["eps2"], want_rows=need)
-            h = ops.gemm_nt_lnfold_apply(x1h, plan["w1_fold"], plan["b1_fold"], st2, plan["w1_fold_cs"], preact=pre)
-            del x1h, part2, st2
-        else:
-            h = _mm(None if fmt == "h" else y2, plan, "w1", xs=y2 if fmt == "h" else None, bias=plan["b1"], act=3, preact=pre, **hkw)   # pre <- GELU'(fc1 output): all the backward needs
+        h = _mm(None if fmt == "h" else y2, plan, "w1", xs=y2 if fmt == "h" else None, bias=plan["b1"], act=3, preact=pre, **hkw)   # pre <- GELU'(fc1 output): all the backward needs
         x2a = None
         ad_h = fmt == "h" and down is not None and ops.adapter_fused_h_supported(M, D, down.shape[0])      # the fused fp16-operand adapter kernel
         if fmt == "h" and hs and down is not None and not ad_h and ops.copy16_ok(M, D, plan["w2"].shape[1]):
@@ -282,6 +272,9 @@ class _BlockFn(torch.autograd.Function):
                 out = ops.gemm_nt(hd, up_T, residual=x2)
         if need:
             ctx.plan, ctx.dims, ctx.tw = plan, (B, Nt), tw
+            ctx.gate = tw.get("on_grads") if tw is not None else None      # (data parallelism: this node is one the block owes before its slices may travel)
+            if ctx.gate is not None:
+                ctx.gate.armed()
             ctx.has_lora, ctx.has_ad = a_q is not None, down is not None
             ctx.hd16 = hd16
             ctx.save_for_backward(x, mean1, rstd1, y1, t, at, bt, qkv, o, lse, x1, mean2, rstd2, pre, x2, hd,
@@ -312,7 +305,6 @@ class _BlockFn(torch.autograd.Function):
         bott = down.shape[0] if ctx.has_ad else 0
         r2 = at.shape[0] if ctx.has_lora else 0
         direct = tw is not None and "g_at" in tw       # weight gradients accumulate straight into the flat gradient buffer
-        wgs = tw.get("wgrad") if direct else None      # ... and may then be computed on the second stream (_wgrad_side)
         if direct:
             z_up, z_down, z_bt, z_at = tw["g_up"], tw["g_down"], tw["g_bt"], tw["g_at"]
         else:
@@ -333,9 +325,8 @@ class _BlockFn(torch.autograd.Function):
                 w_dt = tw["down_tw3"] if tw is not None and "down_tw3" in tw else _opw(down_tT, fmt)
                 dx2, dhpa, dx2a = ops.adapter_fused_h(dout.view(-1, D), w_ut, w_dt, gate_src=hd, in_scale=sc[0:1], alpha_dev=sc[1:2], copy_scale=sc[0:1],
                                                       want_copy=True)
-                with _wgrad_side(wgs, dout, hd, dhpa, x2, sc):      # (second stream when armed: under the fc2 / fc1 backward GEMMs)
-                    g_up = ops.gemm_tn(dout.view(-1, D), hd, out=z_up, alpha_dev=sc[1:2])             # [D, 64]  (dOut rounded to fp16 under s inside the kernel)
-                    g_down = ops.gemm_tn(dhpa, x2, out=z_down, alpha_dev=sc[1:2])                     # [64, D]
+                g_up = ops.gemm_tn(dout.view(-1, D), hd, out=z_up, alpha_dev=sc[1:2])             # [D, 64]  (dOut rounded to fp16 under s inside the kernel)
+                g_down = ops.gemm_tn(dhpa, x2, out=z_down, alpha_dev=sc[1:2])                     # [64, D]
             elif plan["x3"]:
                 w_ut = tw["up_tw3"] if tw is not None and "up_tw3" in tw else _opw(up_tT, fmt)
                 w_dt = tw["down_tw3"] if tw is not None and "down_tw3" in tw else _opw(down_tT, fmt)
@@ -354,14 +345,12 @@ class _BlockFn(torch.autograd.Function):
                 pass      # (weight gradients taken above)
             elif fmt == "h" and ctx.hd16 is not None and x2.dtype == torch.float16:
                 # the weight gradients on the fp16 MFMA kernel from the operands at hand: (dout s)^T hd and (dhp s)^T x2, times 1/s on the device
-                with _wgrad_side(wgs, douta, ctx.hd16, dhpa, x2, sc):
-                    g_up = ops.gemm_tn(douta, ctx.hd16, out=z_up, alpha_dev=sc[1:2])                  # [D, 64]
-                    g_down = ops.gemm_tn(dhpa, x2, out=z_down, alpha_dev=sc[1:2])                     # [64, D]
+                g_up = ops.gemm_tn(douta, ctx.hd16, out=z_up, alpha_dev=sc[1:2])                  # [D, 64]
+                g_down = ops.gemm_tn(dhpa, x2, out=z_down, alpha_dev=sc[1:2])                     # [64, D]
                 del douta, dhpa
             else:
-                with _wgrad_side(wgs, dout, hd, dhp, x2):
-                    g_up = ops.gemm_tn(dout, hd, out=z_up)                                            # [D, 64]
-                    g_down = ops.gemm_tn(dhp, x2, out=z_down)                                         # [64, D]
+                g_up = ops.gemm_tn(dout, hd, out=z_up)                                            # [D, 64]
+                g_down = ops.gemm_tn(dhp, x2, out=z_down)                                         # [64, D]
         hs = bool(fmt) and ops.split_out_ok(dx2.shape[0], plan["w2_t"].shape[0], plan["w2_t"].shape[1]) and (fmt != "h" or pre.dtype == torch.float16)
         hkw = {} if not hs else {"out_split": True} if fmt == "x3" else {"out_dtype": torch.float16}      # (tf32h: fp16, still times s)
         dpre = _mm(dx2, plan, "w2_t", xs=dx2a, sc=sc, dact_src=pre, dact=3, **hkw)                # [M, 4D] (x stored GELU')
@@ -395,11 +384,10 @@ class _BlockFn(torch.autograd.Function):
                 bt16 = tw["bt_qv_w3"] if tw is not None and "bt_qv_w3" in tw and tw["bt_qv_w3"].dtype == torch.float16 else ops.cast16(bt_qv.float().contiguous())
                 dt = ops.lora_bwd_fused_h(dqv, t, bt16, z_bt, out_mul=sc[1:2], dt_scaled=h16dy)
                 gbt = z_bt
-                with _wgrad_side(wgs, y1, dt, sc):      # the LoRA-A gradient: nothing in the backward reads it (second stream when armed)
-                    if ops.lora_bwd_fused_h_supported(y1, dt, None, z_at):
-                        ops.lora_bwd_fused_h(y1, dt, None, z_at, t_mul=None if h16dy else sc[0:1], out_mul=sc[1:2])
-                    else:       # (D not a multiple of 256, e.g. ViT-S: the streaming N = 8 kernel, fp32 dt against the fp16 LN(x))
-                        ops.gemm_tn(dt, y1, out=z_at, alpha_dev=sc[1:2] if h16dy else None)
+                if ops.lora_bwd_fused_h_supported(y1, dt, None, z_at):
+                    ops.lora_bwd_fused_h(y1, dt, None, z_at, t_mul=None if h16dy else sc[0:1], out_mul=sc[1:2])
+                else:       # (D not a multiple of 256, e.g. ViT-S: the streaming N = 8 kernel, fp32 dt against the fp16 LN(x))
+                    ops.gemm_tn(dt, y1, out=z_at, alpha_dev=sc[1:2] if h16dy else None)
                 gat = z_at
                 dqkv_s = dqkv
                 dt_is_scaled = h16dy
@@ -430,19 +418,16 @@ class _BlockFn(torch.autograd.Function):
             if gat is not None:
                 pass                                                                              # (tf32h: taken above)
             else:
-                with _wgrad_side(wgs, dt, y1):
-                    if ops.lora_bwd_fused_supported(y1, dt, None, z_at):
-                        gat = ops.skinny_tn_mfma(dt, y1, z_at)                                    # [2r, D] on the same slab kernel
-                    else:
-                        gat = ops.gemm_tn(dt, y1, out=z_at)                                       # [2r, D]
+                if ops.lora_bwd_fused_supported(y1, dt, None, z_at):
+                    gat = ops.skinny_tn_mfma(dt, y1, z_at)                                    # [2r, D] on the same slab kernel
+                else:
+                    gat = ops.gemm_tn(dt, y1, out=z_at)                                       # [2r, D]
             g_bq, g_bv = gbt[:r, :D].t(), gbt[r:, D:].t()          # strided views: the gradient gather copies them anyway
             g_aq, g_av = gat[:r], gat[r:]
         if direct:       # already in the flat buffer (LoRA-B: GDViT.finish_trainable_grads transposes the stash once per step)
             g_aq = g_bq = g_av = g_bv = g_down = g_up = None
-            if "on_grads" in tw:      # this block's LoRA-A / adapter slices of the flat gradient buffer are final: their exchange may start under the blocks below
-                hook, bi, spans = tw["on_grads"]
-                with _wgrad_side(wgs):      # (issued from the stream that wrote them: the collective orders itself behind that stream)
-                    hook(bi, spans)
+            if ctx.gate is not None:      # the block's LAST backward node of the step: its LoRA-A / adapter slices of the flat gradient buffer are final,
+                ctx.gate.node_done()      # their exchange may start under the blocks below (BlockGradGate)
         if not ctx.needs_input_grad[0]:   # first trainable block: nothing below it learns, skip dX (one GEMM + one LN backward)
             return None, None, None, None, g_aq, g_bq, g_av, g_bv, g_down, g_up
         if ctx.has_lora:
@@ -582,9 +567,22 @@ class _DeferredNormFn(torch.autograd.Function):
         return dy, None
 
 
-def deferred_norm(t):
-    """the materialised `model.norm` of a deferred tap (consumers other than an all-deferred kp_gather; not on the step's path)."""
-    return _DeferredNormFn.apply(t, t._gd_ln)
+class DeferredTapNorm:
+    """`model.norm(tap)` that has NOT been computed: what `forward_all(norm_taps="deferred")` hands out in place of a normed tap.  Deliberately not a
+    tensor — nothing can slice, cast or stack it and silently get un-normalised features.  Its one cheap consumer is `kp_gather`, which applies the
+    norm at the sampled rows (gd_kp_gather_fwd_ln) when every grid of the call is deferred; anybody else calls `.materialize()` for the normed tensor
+    (one LayerNorm pass; its gradient reaches the tap's node as the gradient of the NORMED tap)."""
+    __slots__ = ("raw", "rec")
+
+    def __init__(self, raw, rec):
+        self.raw, self.rec = raw, rec      # raw: the tap's third alias out of _TapFn (it carries the normed tap's gradient); rec: the deferred-norm record
+
+    shape = property(lambda self: self.raw.shape)
+    dtype = property(lambda self: self.raw.dtype)
+    device = property(lambda self: self.raw.device)
+
+    def materialize(self):
+        return _DeferredNormFn.apply(self.raw, self.rec)
 
 
 class GDLayerNorm(nn.LayerNorm):
@@ -711,7 +709,7 @@ class GDViT(nn.Module):
                 if hook is not None:
                     nA, nAd = 2 * r * D, 2 * bott * D
                     for i in range(L):
-                        extra[i]["on_grads"] = (hook, i, [(sp["A"] + i * nA, sp["A"] + (i + 1) * nA), (sp["ad"] + i * nAd, sp["ad"] + (i + 1) * nAd)])
+                        extra[i]["on_grads"] = BlockGradGate(hook, i, [(sp["A"] + i * nA, sp["A"] + (i + 1) * nA), (sp["ad"] + i * nAd, sp["ad"] + (i + 1) * nAd)])
                 self._direct = {"gbt": gbt, "gB": fg[sp["B"]:sp["B"] + L * 2 * D * r].view(L, 2, D, r), "r": r, "D": D}
             else:
                 at = torch.stack([torch.cat([l.linear_a_q.weight, l.linear_a_v.weight], 0) for _, l, _ in lo]).float()   # [L, 2r, D]
@@ -734,11 +732,9 @@ class GDViT(nn.Module):
                 if self.opfmt == "h":      # (only the fp16-operand LoRA backward reads a formatted B: the tf32x one takes the plain tensors)
                     for i, w in enumerate(w3(bt_qv.float())):
                         extra[i]["bt_qv_w3"] = w
-        if getattr(self, "_wgrad", None) is None:
-            self._wgrad = {"stream": None, "keep": []}      # armed per backward pass by FinetuneGD.backward (option wgrad_stream)
         for i, (inner, _, _) in enumerate(lo):
             inner._tw = {"dtype": T, "at": at[i], "bt": bt[i], "at_T": at_T[i], "bt_T": bt_T[i], "bt_qv": bt_qv[i], "down_T": down_T[i],
-                         "up_T": up_T[i], "down_tT": down_tT[i], "up_tT": up_tT[i], "wgrad": self._wgrad, **extra[i]}
+                         "up_T": up_T[i], "down_tT": down_tT[i], "up_tT": up_tT[i], **extra[i]}
 
     def finish_trainable_grads(self):
         """After the backward of a step prepared with `prepare_trainables(flat)`: the LoRA-B gradients were accumulated as
@@ -869,12 +865,16 @@ class GDViT(nn.Module):
     def forward_all(self, x, taps, size=None, norm_taps=False):
         """One pass: (tap outputs in `taps` order, last block output) — the shared-forward mode.  With norm_taps the
         final norm of every tap is taken on the way (`_TapFn`: one fused gradient sum per tap in the backward) and the
-        result is (taps, last, normed taps)."""
+        result is (taps, last, normed taps): with norm_taps=True the third list holds the normed TENSORS.
+        norm_taps="deferred" (FinetuneGD's step; GD_TAP_NORM_FUSED, default on): a tap that has a block above it is not normalised here — its entry
+        of the third list is a `DeferredTapNorm` (not a tensor: `kp_gather` applies the norm where it samples, `.materialize()` gives the tensor);
+        entries that cannot be deferred (the last block's tap, autograd off, `tap_norm_dtype` set) are normed tensors as with True."""
+        ops.ln_stats_clear()      # (both registries are keyed by tensor address: nothing of an earlier pass — an exception mid-forward, a skipped block — may be taken)
         x = self.embed(x, size)
         outs, normed = {}, {}
         pending = None            # (tapped tensor, its deferred-norm record): the next block's LayerNorm fills in the statistics
-        # deferred tap norms (GD_TAP_NORM_FUSED, default on): fp32 / bf16 token rows of 16-byte multiples, autograd on (the consumer is the step's kp_gather)
-        defer_ok = (bool(option("tap_norm_fused")) and norm_taps and torch.is_grad_enabled() and self.tap_norm_dtype is None
+        # deferred tap norms: fp32 / bf16 token rows of 16-byte multiples, autograd on (the consumer is the step's kp_gather)
+        defer_ok = (norm_taps == "deferred" and bool(option("tap_norm_fused")) and torch.is_grad_enabled() and self.tap_norm_dtype is None
                     and (self.embed_dim * (2 if self.dtype == torch.bfloat16 else 4)) % 16 == 0)
         for i, blk in enumerate(self.blocks):
             x_in = x
@@ -892,7 +892,7 @@ class GDViT(nn.Module):
                         inner = _unwrap(self.blocks[i + 1])[0]
                         if inner.norm1.eps == self.norm.eps:
                             pending = rec
-                        normed[i]._gd_ln = rec
+                        normed[i] = DeferredTapNorm(normed[i], rec)
                 else:
                     outs[i] = x
                     if norm_taps:
@@ -1109,14 +1109,11 @@ class _GatherFn(torch.autograd.Function):
 def kp_gather(grids, kp, gh, gw, sx, sy, img_h, img_w, patch, stride=None, pitch=None):
     """interpolate_features on token-major grids [B, prefix+gh*pitch, D] (mean over the list) -> [B, Nk, D] fp32; pitch = tokens
     per grid line in memory (default gw; gw + 1 for conv3x3_tokens' separator-column output)."""
-    recs = [getattr(g, "_gd_ln", None) for g in grids]
-    if any(r is not None for r in recs):
-        if all(r is not None for r in recs) and len(grids) <= 4 and grids[0].dtype in (torch.float32, torch.bfloat16):
-            recs = tuple(recs)
+    recs = None
+    if any(isinstance(g, DeferredTapNorm) for g in grids):
+        if all(isinstance(g, DeferredTapNorm) for g in grids) and len(grids) <= 4 and grids[0].dtype in (torch.float32, torch.bfloat16):
+            recs, grids = tuple(g.rec for g in grids), [g.raw for g in grids]
         else:      # mixed / unsupported: materialise the deferred norms (not the step's path)
-            grids = [deferred_norm(g) if r is not None else g for g, r in zip(grids, recs)]
-            recs = None
-    else:
-        recs = None
+            grids = [g.materialize() if isinstance(g, DeferredTapNorm) else g for g in grids]
     return _GatherFn.apply(kp, (gh, gw, float(sx), float(sy), int(img_h), int(img_w), int(patch),
                                 int(patch if stride is None else stride), int(gw if pitch is None else pitch)), recs, *grids)

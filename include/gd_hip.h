@@ -25,9 +25,11 @@ extern "C" {
 #define GD_F16 3     /* IEEE half: the operand format of the tf32h engine (gd_cast_f16 -> gd_gemm_nt_scaled, gd_attention_*): 11-bit significands = TF32's */
 
 const char* gd_last_error(void);
-/* Bumped whenever an exported signature changes (round 4: gd_amax_scale and gd_lora_bwd_fused_scaled took one more argument -> 2); the Python
- * loader refuses a library whose version differs from the one its signature table was written for. */
-#define GD_ABI_VERSION 2
+/* Bumped whenever the exported surface changes (round 4: gd_amax_scale and gd_lora_bwd_fused_scaled took one more argument -> 2; round 6: the
+ * entry points of five shelved experiments — gd_gemm_nt_lnfold_emit / _apply, gd_ln_fold_stats, gd_stream_create_cu_mask, gd_stream_destroy — left the
+ * library, and round 5's gd_adapter_fused_h_ln / gd_kp_gather_fwd_ln are counted -> 3); the Python loader refuses a library whose version differs
+ * from the one its signature table was written for. */
+#define GD_ABI_VERSION 3
 int gd_abi_version(void);
 
 /* Debug hooks (no reference counterpart; NOT for production use, process-wide, not thread-safe).
@@ -41,13 +43,6 @@ int gd_abi_version(void);
 int gd_debug_set(const char* name, int value);
 int gd_debug_get(const char* name);
 int gd_gemm_phase_probe(int enable, unsigned long long* out6);
-
-/* A HIP stream confined to `cus` compute units of the current device (hipExtStreamCreateWithCUMask, the first `cus` mask bits: on MI355X the mask
- * bits go round the eight XCDs, so a multiple of 8 takes cus / 8 CUs of every XCD — tools/micro/cu_mask_probe.hip).  No reference counterpart: the
- * engine's backward runs the blocks' weight-gradient contractions on such a stream, on CUs that `reserve_cus` keeps the persistent kernels off, so
- * that they run under the dX GEMMs / the attention backward (FinetuneGD.backward, options.py wgrad_stream).  *stream_out: a hipStream_t. */
-int gd_stream_create_cu_mask(int cus, void** stream_out);
-int gd_stream_destroy(void* stream);
 
 /* C[M,N] = epilogue(alpha * A[M,K] . W[N,K]^T); replaces torch nn.Linear / torch.bmm on the student path
  * (timm VisionTransformer qkv/proj/fc1/fc2, utils/model.py:57-71 LoRA, :7-25 Adapter; src/finetune_timm_vggt.py:516-517).
@@ -338,20 +333,6 @@ int gd_cost_volume_kl_bwd_h(const float* f1, const float* f2, const void* f1h, c
 int gd_gemm_nt_copy16(const void* A, const void* W, void* C, int M, int N, int K, long lda, long ldw, long ldc, float alpha,
                       const float* alpha_dev, const float* bias, const void* residual, long ldr, void* copy16, long ldc16,
                       const float* copy_scale_dev, void* stream);
-/* LayerNorm fold of the tf32h forward (no LayerNorm pass between a residual GEMM and the GEMM that consumes the normalised rows; replaces
- * timm Block.norm2 -> mlp.fc1 and, for blocks without LoRA, norm1 -> attn.qkv: the nn.LayerNorm + nn.Linear pairs of the student's blocks).
- *   gd_gemm_nt_lnfold_emit : C[M,N] (f32) = alpha A.W^T + bias + residual on fp16 operands, copy16 = fp16(C), and ln_part [M][N/64][2] = the
- *                            (sum, sum of squares) of every row's 64-column slices (N % 256 == 0; persistent-kernel shapes);
- *   gd_ln_fold_stats       : ln_part -> stats [M][2] = (mean, rstd), and / or mean [M], rstd [M] (what gd_layernorm_bwd* takes); the stats buffer
- *                            must have room for an EVEN number of rows (M + (M & 1)) and be 16-byte aligned: the applying GEMM fetches row pairs;
- *   gd_gemm_nt_lnfold_apply: C[M,N] (fp16) = GELU(rstd_m (alpha A16.W'^T - mean_m cs_n) + bias'_n) (act 1; act 3: preact receives GELU'),
- *                            A16 = the fp16 copy above, W' = W diag(gamma) as fp16, cs_n = sum_k W'[n][k], bias' = bias + W beta (host side, once:
- *                            the affine and W are frozen). */
-int gd_gemm_nt_lnfold_emit(const void* A, const void* W, float* C, int M, int N, int K, long lda, long ldw, long ldc, float alpha,
-                           const float* bias, const float* residual, long ldr, void* copy16, long ldc16, float* ln_part, void* stream);
-int gd_gemm_nt_lnfold_apply(const void* A16, const void* Wp, void* C, int M, int N, int K, long lda, long ldw, long ldc, float alpha,
-                            const float* bias_p, const float* ln_stats, const float* ln_cs, void* preact, long ldp, int act, void* stream);
-int gd_ln_fold_stats(const float* ln_part, int M, int N, float eps, float* stats, float* mean, float* rstd, void* stream);
 /* gd_gemm_tn with alpha multiplied by the device scalar *alpha_dev (weight gradients contracted from SCALED fp16 gradient operands);
  * gd_gemm_tn takes fp16 Y and X on the MFMA kernel (N, K >= 64) and fp16 X on the N = 8 streaming kernel; with ONE of Y / X fp16 and the other fp32
  * (N, K >= 64) the fp32 one is rounded to fp16 inside the kernel — an fp32 Y times 1 / *alpha_dev first (a gradient under the scale its alpha undoes). */

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in include/ but not exported"
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
-    assert _lib.lib().gd_abi_version() == _lib.ABI_VERSION == 2
+    assert _lib.lib().gd_abi_version() == _lib.ABI_VERSION == 3
 
 
 def _header_prototypes():

@@ -129,55 +129,6 @@ def _debug(name, value):
     check(lib().gd_debug_set(name.encode(), value), "gd_debug_set")
 
 
-# Round 5: the row-panel-stationary forward (csrc/cv_panel.h — a wave's 16 rows of the view-1 panel live in registers for a sweep of column tiles,
-# only the view-2 rows stream through an 8-slot LDS ring, teacher entries by hand-counted inline-asm loads).  16-bit features with 768- or 1536-byte
-# rows and cached (padded) teacher maps.  Checked against the fp64 oracle on the rounded inputs, against the round-4 persistent kernel
-# (gd_debug_set("cv_panel", 0)) to fp32 summation order, and for run-to-run bit-reproducibility — on the full grid and on 8 / 16 blocks, where a block
-# walks dozens of tiles: ring slots, panel reloads in the middle of a slice, slices that end inside a pair, the statistics / partial-sum
-# buffers and the one-tile-ahead teacher prefetch all wrap around many times.  hw = 1369 has a ragged last tile (89 rows / columns), hw = 768 none,
-# hw = 200 two tiles per side (a pair's tiles < blocks per XCD: empty slices).
-# The kernel is an EXPERIMENT behind GD_CV_PANEL (1: two 4-wave blocks per CU, 64-row panels; 8: one 8-wave block, 128-row panels); the default
-# forward is the round-4 persistent kernel.  Kept under test so that the measurements in DESIGN.md section 5 / profiles/r05_cv_panel_*.txt can be re-run on a correct kernel.
-@pytest.mark.parametrize("variant,mode,P,hw,C,grid,panel", [("vggt", "bf16", 3, 1369, 768, 0, 1), ("vggt", "h", 2, 1369, 768, 16, 1), ("mast3r", "h", 9, 672, 768, 8, 8),
-                                                            ("vggt", "bf16", 11, 200, 768, 0, 8), ("mast3r", "h", 1, 1369, 768, 0, 1)])
-def test_panel_forward_matches_oracle_and_round4_kernel(variant, mode, P, hw, C, grid, panel):
-    from gd_amd import ops
-    gen = torch.Generator(device="cuda").manual_seed(hw + C + P)
-    f1 = torch.randn(P, hw, C, generator=gen, device="cuda")
-    f2 = torch.randn(P, hw, C, generator=gen, device="cuda")
-    f1[0, 5] *= 30.0                               # row norms that differ by orders of magnitude
-    f2[P - 1, hw - 1] *= 0.01
-    t1 = torch.softmax(3 * torch.randn(P, hw, hw, generator=gen, device="cuda"), -1)
-    t2 = torch.softmax(3 * torch.randn(P, hw, hw, generator=gen, device="cuda"), -1)
-    t1[0, 3] = 0.0                                 # a teacher row whose sum hits the 1e-8 clamp
-    m1 = torch.rand(P, hw, generator=gen, device="cuda") > 0.3
-    m2 = torch.rand(P, hw, generator=gen, device="cuda") > 0.3
-    if P > 1:
-        m2[1] = False                              # a fully masked direction
-    c1, c2, ts = _teacher("cached", t1, t2)
-    if mode == "h":                                # tf32h engine: fp32 features, their inverse norms, the similarity from fp16 copies
-        inv = (1.0 / f1.norm(dim=-1).clamp_min(1e-12), 1.0 / f2.norm(dim=-1).clamp_min(1e-12))
-        run = lambda: ops.cost_volume_kl(f1, f2, c1, c2, m1, m2, variant, tstats=ts, inv_norms=inv, x3="h")
-        o1, o2, tol = f1, f2, 2e-4
-    else:
-        b1, b2 = f1.bfloat16(), f2.bfloat16()
-        run = lambda: ops.cost_volume_kl(b1, b2, c1, c2, m1, m2, variant, tstats=ts)
-        o1, o2, tol = b1.float(), b2.float(), 1e-3
-    _debug("cv_grid", grid)
-    try:
-        _debug("cv_panel", panel)
-        new, new2 = run(), run()
-        _debug("cv_panel", 0)
-        old = run()
-    finally:
-        _debug("cv_panel", 0)                      # the default: the experiment is not the product path (it measured slower: DESIGN.md section 5)
-        _debug("cv_grid", 0)
-    assert torch.equal(new, new2)
-    assert rel_err(new, old) < 2e-6
-    ol, _, _ = _oracle(o1, o2, t1, t2, m1, m2, variant)
-    assert rel_err(new, ol) < tol
-
-
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_producer_side_row_norms(dtype):
     """ops.tap_mean(with_norm=True) hands out the inverse L2 norms of the rows it writes, and cost_volume_kl(inv_norms=...) uses them

@@ -313,15 +313,8 @@ def test_vit_base_518_tf32h_adapter_kernel_writes_the_next_layernorm():
     assert float((res[1][2] - res[0][2]).norm() / res[0][2].norm()) < 0.5 * TF32H_GRAD_FRO
 
 
-@pytest.mark.parametrize("ln2_fold", [0, 1])
-def test_vit_base_518_tf32h_step_matches_oracle(ln2_fold):
-    # ln2_fold = 1: the LayerNorm-2 fold (options.ln2_fold, an experiment that is off by default — profiles/r05_ln2_fold_ab.txt) holds the same tolerances
-    from gd_amd.options import set_option
-    keep = set_option("ln2_fold", ln2_fold)
-    try:
-        rec = _run_case("vit_base_518_mast3r_tf32h" + ("_ln2_fold" if ln2_fold else ""), "vit_base", "mast3r", "tf32h", counts=[300, 211])
-    finally:
-        set_option("ln2_fold", keep)
+def test_vit_base_518_tf32h_step_matches_oracle():
+    rec = _run_case("vit_base_518_mast3r_tf32h", "vit_base", "mast3r", "tf32h", counts=[300, 211])
     assert rec["rel_err"] < 2e-4, rec
     for k, t in rec["terms"].items():
         assert t["rel_err"] < 2e-4, (k, t)

@@ -178,7 +178,7 @@ def test_gemm_nt_persistent_ragged_n_and_batched():
 
 
 def test_gemm_nt_persistent_schedule_knobs_do_not_change_results():
-    """the persistent kernel's schedule options — grouped tile order (gemm_group_m), start-up skew of the blocks (gemm_stagger), compute units left to
+    """the persistent kernel's schedule options — grouped tile order (gemm_group_m), compute units left to
     collectives (reserve_cus) — change WHEN and WHERE a tile is computed, never its value: outputs are bit-identical to the default schedule, with a
     side tensor and a ragged last tile row in play."""
     from gd_amd import ops
@@ -189,39 +189,14 @@ def test_gemm_nt_persistent_schedule_knobs_do_not_change_results():
     run = lambda: ops.gemm_nt(a, w, bias=bias, residual=res, out_dtype=torch.float32)
     ref = run()
     try:
-        for name, val in [("gemm_group_m", 4), ("gemm_stagger", 150 | (8 << 16)), ("gemm_stagger", 300 | (4 << 16) | (1 << 24)), ("reserve_cus", 200)]:
+        for name, val in [("gemm_group_m", 4), ("reserve_cus", 200)]:
             assert lib().gd_debug_set(name.encode(), val) == 0
             out = run()
             assert lib().gd_debug_set(name.encode(), 1 if name == "gemm_group_m" else 0) == 0
             assert torch.equal(out, ref), name
     finally:
-        for name, val in [("gemm_group_m", 1), ("gemm_stagger", 0), ("reserve_cus", 0)]:
+        for name, val in [("gemm_group_m", 1), ("reserve_cus", 0)]:
             lib().gd_debug_set(name.encode(), val)
-
-
-@pytest.mark.parametrize("M,N,K", [(256 * 37 + 19, 768, 768), (4096, 3072, 768), (2048 + 77, 768, 3072)])
-def test_gemm_nt_four_slot_ring_equals_the_two_slot_ring(M, N, K):
-    """GD_GEMM_K64 (round 5, an experiment that measured SLOWER — +2.9 ms per step, profiles/README.md round 5 — and is off): the fp16-operand
-    persistent kernel on a four-slot ring of 64-byte stages (64-byte-row LDS image, swz64, one barrier per MFMA chunk) walks K in the same order
-    as the two-slot ring: bit-identical results, with each of the step's epilogues."""
-    from gd_amd import ops
-    from gd_amd._lib import lib
-    a, w = _mk((M, K), torch.float16, 81), _mk((N, K), torch.float16, 82) * 0.05
-    bias, res = _mk((N,), torch.float32, 83), _mk((M, N), torch.float32, 84)
-    gate = _mk((M, N), torch.float16, 85)
-    runs = {"plain fp16 C": lambda: ops.gemm_nt(a, w, bias=bias, out_dtype=torch.float16),
-            "residual, f32 C": lambda: ops.gemm_nt(a, w, bias=bias, residual=res, out_dtype=torch.float32),
-            "residual + fp16 copy": lambda: torch.cat([t.float() for t in ops.gemm_nt_copy16(a, w, res, bias=bias)], 1),
-            "gated (dact 3)": lambda: ops.gemm_nt(a, w, dact_src=gate, dact=3, out_dtype=torch.float16)}
-    pre = torch.empty(M, N, dtype=torch.float16, device="cuda")
-    runs["GELU + stored derivative"] = lambda: torch.cat([ops.gemm_nt(a, w, bias=bias, act=3, preact=pre, out_dtype=torch.float16), pre.clone()], 1)
-    ref = {k: f() for k, f in runs.items()}
-    try:
-        assert lib().gd_debug_set(b"gemm_k64", 1) == 0
-        for k, f in runs.items():
-            assert torch.equal(f(), ref[k]), k
-    finally:
-        lib().gd_debug_set(b"gemm_k64", 0)
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 1e-2)])
@@ -543,54 +518,3 @@ def test_gemm_tn_rounds_an_fp32_operand_to_fp16_in_the_kernel():
     assert rel_err(got, y16.double().t() @ x32.half().double()) < 1e-5
 
 
-@pytest.mark.parametrize("M,D,H4", [(2740, 768, 3072), (1370 * 3 + 5, 256, 1024)])
-def test_layernorm_fold_gemms_equal_layernorm_then_linear(M, D, H4):
-    """Round 5, the LayerNorm fold of the tf32h forward (gd_gemm_nt_lnfold_emit / gd_ln_fold_stats / gd_gemm_nt_lnfold_apply): the projection GEMM
-    leaves x1 = o Wp^T + b + x (f32), fp16(x1) and per-row partial sums; fc1 multiplies the UN-normalised fp16 rows with W diag(gamma) and normalises
-    the product in its epilogue.  Against fp64 torch: x1 and its statistics to fp32 accuracy; GELU(LN(fp16(x1)) W^T + b) and its derivative to fp16
-    output rounding — the same tolerance as LayerNorm -> fp16 -> GEMM (reference below: 'unfused').  Rows with a large common offset (mean = 6 sigma)
-    and a massive channel exercise the cancellation in rstd (acc - mean cs)."""
-    from gd_amd import ops
-    g = torch.Generator(device="cuda").manual_seed(M + D)
-    o = torch.randn(M, D, generator=g, device="cuda").half()
-    x = torch.randn(M, D, generator=g, device="cuda")
-    x[:, 7] += 40.0                                       # a massive channel
-    x[: M // 3] += 6.0                                    # rows whose mean is several standard deviations
-    wp = (0.05 * torch.randn(D, D, generator=g, device="cuda")).half()
-    bp = 0.1 * torch.randn(D, generator=g, device="cuda")
-    gamma = 1.0 + 0.3 * torch.randn(D, generator=g, device="cuda")
-    beta = 0.2 * torch.randn(D, generator=g, device="cuda")
-    w1 = 0.05 * torch.randn(H4, D, generator=g, device="cuda")
-    b1 = 0.1 * torch.randn(H4, generator=g, device="cuda")
-    eps = 1e-6
-    x1, x1h, part = ops.gemm_nt_lnfold_emit(o, wp, x, bias=bp)
-    ref1 = o.double() @ wp.double().t() + bp.double() + x.double()
-    assert rel_err(x1, ref1) < 2e-6
-    assert torch.equal(x1h, x1.half())
-    assert part.shape == (M, D // 64, 2)
-    sl = x1.double().view(M, D // 64, 64)
-    assert rel_err(part[..., 0], sl.sum(-1)) < 1e-5 and rel_err(part[..., 1], (sl * sl).sum(-1)) < 1e-5
-    st, mean, rstd = ops.ln_fold_stats(part, D, eps)
-    mu = x1.double().mean(-1)
-    rs = 1.0 / torch.sqrt(x1.double().var(-1, unbiased=False) + eps)
-    assert rel_err(mean, mu) < 1e-5 and rel_err(rstd, rs) < 2e-5
-    assert torch.equal(st[:, 0], mean) and torch.equal(st[:, 1], rstd)
-    # the fold
-    wf = (w1 * gamma[None, :]).half().contiguous()
-    cs = wf.float().sum(1).contiguous()
-    bf = (b1 + w1 @ beta).contiguous()
-    pre = torch.empty(M, H4, dtype=torch.float16, device="cuda")
-    h = ops.gemm_nt_lnfold_apply(x1h, wf, bf, st, cs, preact=pre)
-    h_plain = ops.gemm_nt_lnfold_apply(x1h, wf, bf, st, cs)
-    assert torch.equal(h, h_plain)
-    xn = (x1h.double() - mu[:, None]) * rs[:, None]                                  # LayerNorm of the fp16-rounded rows, exact statistics
-    z = (xn * gamma.double() + beta.double()) @ w1.double().t() + b1.double()
-    want = torch.nn.functional.gelu(z)
-    zz = z.clone().requires_grad_(True)
-    torch.nn.functional.gelu(zz).sum().backward()
-    # reference path of the engine without the fold: LayerNorm pass -> fp16 -> GEMM with GELU
-    y2, _, _ = ops.layernorm_fwd(x1, gamma, beta, eps, out_dtype=torch.float16)
-    unf = ops.gemm_nt(y2, w1.half().contiguous(), bias=b1, act=1, out_dtype=torch.float16)
-    e_fold, e_unf = rel_err(h, want), rel_err(unf, want)
-    assert e_fold < 2e-3 and e_fold < 2.0 * e_unf + 2e-4, (e_fold, e_unf)
-    assert rel_err(pre, zz.grad) < 3e-3

@@ -503,36 +503,6 @@ def test_direct_weight_gradients_equal_the_autograd_path(dtype, monkeypatch):
         assert abs(na.item() - ref_norm.item()) < 2e-3 * ref_norm.item()
 
 
-@pytest.mark.parametrize("mode", [1, 2])
-@pytest.mark.parametrize("dtype", ["f32", "tf32h"])
-def test_weight_gradients_on_the_second_stream_equal_the_single_stream_step(dtype, mode):
-    """options.wgrad_stream (an experiment, default off — profiles/r05_wgrad_stream_ab.txt): the blocks' weight-gradient contractions on a second
-    stream (1: plain, 2: confined to `wgrad_reserve_cus` compute units by a CU mask) while the backward goes on; FinetuneGD.backward joins the
-    streams before anyone reads the flat gradient buffer.  Same loss, same gradient (float atomics aside), same updated weights as the default
-    step, over three steps — a missing wait or an operand freed under the side stream shows up as garbage here."""
-    from gd_amd.options import set_option
-    P, h, w, N = 2, 56, 70, 12
-    a = _engine("vggt", "shared", dtype, teacher_patch=14)
-    b = _engine("vggt", "shared", dtype, teacher_patch=14)
-    fa, fb = a.configure_optimizers(), b.configure_optimizers()
-    tol = 1e-5 if dtype == "f32" else 2e-3
-    for step in range(3):
-        batch = synthetic_batch(P, h, w, N, 20, "cuda", seed=30 + step, counts=[12, 9])
-        la, _, na = a.fit_step(batch)
-        keep = set_option("wgrad_stream", mode)
-        try:
-            lb, _, nb = b.fit_step(batch)
-        finally:
-            set_option("wgrad_stream", keep)
-        assert b.model._wgrad["stream"] is None and b.model._wgrad["keep"] == []      # disarmed, nothing pinned after the backward
-        assert abs(la.item() - lb.item()) < 1e-5 * abs(la.item())
-        assert float((fa["g"] - fb["g"]).abs().max()) < tol * float(fa["g"].abs().max())
-        assert abs(na.item() - nb.item()) < tol * na.item()
-    assert float((fa["p"] - fb["p"]).abs().max()) <= 2.1 * fa["lr"] * 3
-    from gd_amd._lib import lib
-    assert lib().gd_debug_get(b"reserve_cus") == 0                                   # the backward's CU reservation does not outlive it
-
-
 # ---------------------------------------------------------------------------------------------------------------------
 # G18: the engine against a full optimisation step WRITTEN BY THE REFERENCE (tools/make_golden_g18.py) — no oracle in between
 # ---------------------------------------------------------------------------------------------------------------------

@@ -15,7 +15,7 @@ from gd_amd.options import option, set_option  # noqa: E402
 
 
 def main():
-    specs = sys.argv[1:] or ["wgrad_stream=0,1", "wgrad_reserve_cus=4,8,16,32", "tap_norm_fused=0,1"]
+    specs = sys.argv[1:] or ["tap_norm_fused=0,1", "adapter_ln=0,1"]
     dev = torch.device("cuda", 0)
     job = bench.Job("vit_base", "mast3r", os.environ.get("AB_DTYPE", "tf32h"), "shared", 32, 518, 300, dev, 0, 1)
 

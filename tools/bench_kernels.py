@@ -103,42 +103,6 @@ def bench_cv():
                   f"fwd+bwd {tfb*1e6/P:8.1f} us/pair {(fwd_bytes+bwd_bytes)/tfb/1e9:8.1f} GB/s")
 
 
-def bench_cv_ab(rounds=3):
-    """Round 5: the row-panel-stationary forward kernels (gd_debug_set("cv_panel", 1), csrc/cv_panel.h) against the round-4 persistent kernels (0) in ONE
-    process, interleaved rounds (cdna_hip_programming.md rule 24): the tf32h trainer's call (fp16 feature copies, producer-side norms, cached teacher
-    statistics) at 32 pairs, hw = 1369, C = 768 — every row kept (the dense sweep), and with the MASt3R trainer's keypoint-patch masks (the kept-row form).
-    Forward only, whole op (statistics init + tile kernel + finalize + loss), what bench.py's roofline_cost_volume times."""
-    L = gd_amd._lib.lib()
-    P, hw, C, img, patch = 32, 1369, 768, 518, 14
-    g = torch.Generator(device="cuda").manual_seed(0)
-    f1 = torch.randn(P, hw, C, device="cuda", generator=g)
-    f2 = torch.randn(P, hw, C, device="cuda", generator=g)
-    t1 = torch.softmax(3 * torch.randn(P, hw, hw, device="cuda", generator=g), -1)
-    t2 = torch.softmax(3 * torch.randn(P, hw, hw, device="cuda", generator=g), -1)
-    kp1 = torch.rand(P, 300, 2, device="cuda", generator=g) * (img - 1)
-    kp2 = torch.rand(P, 300, 2, device="cuda", generator=g) * (img - 1)
-    mk1, mk2 = ops.patch_mask(kp1, img, img, patch), ops.patch_mask(kp2, img, img, patch)
-    on1, on2 = torch.ones_like(mk1), torch.ones_like(mk2)
-    t1, t2 = ops.pad_teacher_maps(t1), ops.pad_teacher_maps(t2)
-    ts = ops.cost_volume_teacher_stats(t1, t2)
-    inv = (1.0 / f1.norm(dim=-1).clamp_min(1e-12), 1.0 / f2.norm(dim=-1).clamp_min(1e-12))
-    h16 = (f1.half(), f2.half())
-    alg = P * (2 * hw * C * 2 + 2 * hw * hw * 4 + 2 * hw)
-    cases = {"dense (every row kept)": lambda: ops.cost_volume_kl(f1, f2, t1, t2, on1, on2, "mast3r", tstats=ts, inv_norms=inv, x3="h", h16=h16),
-             "kept rows (keypoint-patch masks)": lambda: ops.cost_volume_kl(f1, f2, t1, t2, mk1, mk2, "mast3r", tstats=ts, inv_norms=inv, x3="h", h16=h16, kept_rows_max=300)}
-    with torch.no_grad():
-        for name, fn in cases.items():
-            res = {0: [], 1: [], 8: []}
-            for _ in range(rounds):
-                for v in (0, 1, 8):
-                    L.gd_debug_set(b"cv_panel", v)
-                    res[v].append(timeit(fn, warm=3, it=20))
-            L.gd_debug_set(b"cv_panel", 0)
-            a, b = min(res[0]), min(res[1])
-            print(f"cv_ab {name:34s}: round-4 kernel {a * 1e6:7.1f} us ({a * 1e6 / P:5.2f} us/pair, {alg / a / 8e12:5.3f} of 8 TB/s by the dense byte count) | "
-                  f"panel kernel {b * 1e6:7.1f} us ({b * 1e6 / P:5.2f} us/pair, {alg / b / 8e12:5.3f})   | 8-wave panel kernel {min(res[8]) * 1e6:7.1f} us   all rounds: {[round(x * 1e6, 1) for x in res[0]]} vs {[round(x * 1e6, 1) for x in res[1]]} vs {[round(x * 1e6, 1) for x in res[8]]}", flush=True)
-
-
 def bench_adapter():
     """fused adapter kernel against the two-GEMM formulation (M = 87680 rows of the P = 32 step)."""
     for D in (768, 1024):
@@ -381,26 +345,6 @@ def probe_gemm():
         print(f"probe {tag:5s} {M}x{N}x{K}: {t*1e6:7.1f} us {2*M*N*K/t/1e12:7.1f} TF/s | shader-clock cycles per tile: wait {out[0]/n:8.1f}  main {out[1]/n:8.1f}  dma-issue {out[4]/n:8.1f}  epi {out[2]/n:8.1f}  tiles/blk {n/256:5.2f} | of main: stage waits (vmcnt + barrier) {out[5]/n:8.1f} = {out[5]/max(out[1],1):.3f}")
 
 
-def bench_attn_stagger(rounds=3):
-    """Round 5: start-up skew between the workgroups of a CU (gd_debug_set("attn_stagger", ticks of 64 cycles per slot)) — forward, dQ and dK/dV kernels at the
-    benched shape (64 x 12 x 1370, fp16 operands), interleaved rounds in one process; backward = dQ + dK/dV together as the step runs them."""
-    L = gd_amd._lib.lib()
-    B, N, H = 64, 1370, 12
-    qkv = torch.randn(B * N, 3 * H * 64, device="cuda").half()
-    dout = torch.randn(B * N, H * 64, device="cuda").half()
-    o, lse = ops.attention_fwd(qkv, B, N, H)
-    ticks = (0, 4, 8, 12, 16, 24, 32)
-    res = {t: ([], []) for t in ticks}
-    for _ in range(rounds):
-        for t in ticks:
-            L.gd_debug_set(b"attn_stagger", t)
-            res[t][0].append(timeit(lambda: ops.attention_fwd(qkv, B, N, H), warm=2, it=10))
-            res[t][1].append(timeit(lambda: ops.attention_bwd(qkv, o, dout, lse, B, N, H, vfirst=True), warm=2, it=10))
-    L.gd_debug_set(b"attn_stagger", 0)
-    for t in ticks:
-        print(f"attn_stagger {t:3d} ticks: fwd {min(res[t][0]) * 1e6:7.1f} us  bwd {min(res[t][1]) * 1e6:7.1f} us   (all: {[round(x * 1e6, 1) for x in res[t][0]]} / {[round(x * 1e6, 1) for x in res[t][1]]})", flush=True)
-
-
 def pmc_attn():
     import os
     B, N, H = (8, 6401, 12) if os.environ.get("GD_PMC_LONG") else (64, 1370, 12)
@@ -443,8 +387,6 @@ if __name__ == "__main__":
         bench_cv()
     if "adapter_ln" in which:
         bench_adapter_ln()
-    if "cv_ab" in which:
-        bench_cv_ab()
     if "gelu" in which:
         bench_gelu()
     if "pmc_cv" in which:
@@ -457,8 +399,6 @@ if __name__ == "__main__":
         pmc_cv_rows()
     if "attn" in which:
         bench_attn()
-    if "attn_stagger" in which:
-        bench_attn_stagger()
     if "attn_x3" in which:
         bench_attn_x3()
     if "cva" in which:

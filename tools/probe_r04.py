@@ -79,22 +79,14 @@ def shapes():
     wq_t = wqkv.t().contiguous()
     cases[-2] = (cases[-2][0], D, 3 * D, lambda: ops.gemm_nt(dqkv, wq_t, lora_t=t8, lora_b=at, out_dtype=torch.float32, alpha_dev=one))
     cases[-1] = (cases[-1][0], D, 3 * D, lambda: ops.gemm_nt(dqkv, wq_t, lora_t=t8, lora_b=at, out_dtype=torch.float16))
-    # STAGGERS: comma list of ticks[:P[:mode]] (10 ns ticks per phase, P phases, mode 0 = CU slot in XCD, 1 = XCD)
-    def parse(v):
-        f = [int(x) for x in v.split(":")] + [0, 0]
-        return f[0] | (f[1] << 16) | (f[2] << 24)
-    staggers = [parse(v) for v in os.environ.get("STAGGERS", "0").split(",")]
     only = os.environ.get("ONLY")
     if only:
         cases = [c for c in cases if any(o in c[0] for o in only.split(","))]
     from gd_amd._lib import lib
     for name, N, K, fn in cases:
         line = f"shape {name} {M}x{N}x{K}:"
-        for sg in staggers:
-            lib().gd_debug_set(b"gemm_stagger", sg)
-            t = timeit(fn, warm=10, it=60)
-            line += f"  [{(sg & 0xffff) * 10}ns x{(sg >> 16) & 0xff or 4} m{sg >> 24}] {t * 1e6:6.1f}"
-        lib().gd_debug_set(b"gemm_stagger", 0)
+        t = timeit(fn, warm=10, it=60)
+        line += f" {t * 1e6:6.1f} us"
         print(line, flush=True)
 
 
