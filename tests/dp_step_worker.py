@@ -14,12 +14,18 @@ for p_ in (ROOT, HERE):
         sys.path.insert(0, p_)
 
 
-def make_engine():
+def make_engine(geometry=None):
+    """geometry "reference": two forwards per image through the same blocks (a 16 x 20-token keypoint grid — target_res 160 — and the 4 x 5 cost grid):
+    every block has TWO backward nodes per step, and the per-block exchange must wait for the second (vit.BlockGradGate)."""
     import gd_amd  # noqa: F401
     from gd_amd.finetune import FinetuneGD
+    geometry = geometry or os.environ.get("DP_GEOMETRY", "shared")
     torch.manual_seed(0)
-    return FinetuneGD(r=4, backbone="vit_tiny_test", patch_size=14, img_size=56, variant="vggt", geometry="shared", dtype="f32",
-                      lora_b_std=0.05, vit_kwargs=dict(init_values=1.0), teacher_patch=14).cuda()
+    eng = FinetuneGD(r=4, backbone="vit_tiny_test", patch_size=14, img_size=56, variant="vggt", geometry=geometry, dtype="f32",
+                     lora_b_std=0.05, vit_kwargs=dict(init_values=1.0), teacher_patch=14).cuda()
+    if geometry == "reference":
+        eng.target_res = 160
+    return eng
 
 
 def make_batch(lo, hi):

@@ -74,13 +74,19 @@ def _worker_overlap(rank, world, port, out):
     torch.distributed.destroy_process_group()
 
 
-def test_overlapped_grad_reducer_world2():
-    """early chunk from post-accumulate-grad hooks + late ranges of the flat buffer == one mean all-reduce of everything"""
-    world, port = 2, 29613
+import pytest
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_overlapped_grad_reducer_world2(world):
+    """early chunk from post-accumulate-grad hooks + late ranges of the flat buffer == one mean all-reduce of everything
+    (world 8: the node size the bench is launched with, src/main.py:147-151 `devices=-1`)"""
+    port = 29613 + world
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker_overlap, args=(world, port, out), nprocs=world, join=True)
-    want = [1.5 * i for i in range(1, 6)]                            # mean over ranks of x[i] * (rank + 1)
+    mean_rank = sum(r + 1 for r in range(world)) / world
+    want = [mean_rank * i for i in range(1, 6)]                      # mean over ranks of x[i] * (rank + 1)
     for r in range(world):
         assert out[r][:5] == want, out[r]
         assert out[r][5] == [(0, 20), (39, 56)]      # flat layout 12 | 5+3 pad | [12 | 7] +1 pad | 16; the late ranges are the complement
@@ -145,14 +151,15 @@ def _worker_blocks(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_per_block_late_chunks_world2():
-    world, port = 2, 29617
+@pytest.mark.parametrize("world", [2, 8])
+def test_per_block_late_chunks_world2(world):
+    port = 29637 + world
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker_blocks, args=(world, port, out), nprocs=world, join=True)
     L, nA, nB, nE, nAd = 3, 8, 12, 20, 16
     n = L * (nA + nB) + nE + L * nAd
-    want = (torch.arange(n, dtype=torch.float32) * 1.5).tolist()
+    want = (torch.arange(n, dtype=torch.float32) * (sum(r + 1 for r in range(world)) / world)).tolist()
     for r in range(world):
         vals, in_flight, left, seen, unhooked, done = out[r]
         assert vals == want
@@ -214,7 +221,7 @@ def _worker_direct(rank, world, port, out):
 def test_direct_grad_reducer_contract_world2():
     """dp.DirectGradReducer (the `--exchange direct` path) against a communicator stand-in: same wait_early / start / finish
     contract as the overlapped reducer, exactly one exchange per step, the mean of the ranks' buffers for both algorithms."""
-    world, port = 2, 29617
+    world, port = 2, 29619
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker_direct, args=(world, port, out), nprocs=world, join=True)

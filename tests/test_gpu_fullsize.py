@@ -104,8 +104,10 @@ def _stream_statistics(eng, batch):
 
 
 def _run_case(name, backbone, variant, dtype, img=518, P=2, N=300, vit_kwargs=None, counts=None, eng_kwargs=None, geometry="shared", stress=False,
-              build=None, oracle_key=None, oracle_dtype=torch.float64, kink_band=None, lazy_residuals=False):
-    """build: () -> FinetuneGD on the CPU (e.g. config.build_engine of one of the reference's yaml presets) instead of the /14 constructor below
+              build=None, oracle_key=None, oracle_dtype=torch.float64, kink_band=None, lazy_residuals=False, fit_step=False):
+    """fit_step: the step as bench.py runs it — ONE FinetuneGD.fit_step (weight packs as views of the flat parameter buffer, the blocks' weight gradients
+    accumulated straight into the flat gradient buffer, clip + AdamW) instead of training_step + backward + optimizer_step.
+    build: () -> FinetuneGD on the CPU (e.g. config.build_engine of one of the reference's yaml presets) instead of the /14 constructor below
     (oracle_key then names the weights + batch the oracle result is shared under across engine dtypes);
     img: the teacher-side image size, an int (square) or (h, w); the cost grid is img // eng.resize_patch_size per axis."""
     from gd_amd.finetune import FinetuneGD
@@ -165,8 +167,11 @@ def _run_case(name, backbone, variant, dtype, img=518, P=2, N=300, vit_kwargs=No
         assert float(res.min()) >= kink_band * (1 - 1e-3)        # (independent per keypoint: nothing new moved into the band)
     flat = eng.configure_optimizers()
     before = [q.detach().clone() for q in eng.trainable_parameters()]
-    loss, terms = eng.training_step(batch)
-    eng.backward(loss)
+    if fit_step:
+        loss, terms, fit_norm = eng.fit_step(batch)      # (the fused clip + AdamW reads the flat gradient buffer and leaves it as the backward wrote it)
+    else:
+        loss, terms = eng.training_step(batch)
+        eng.backward(loss)
     rec = {"loss": loss.item(), "ref_loss": ref_loss, "rel_err": abs(loss.item() - ref_loss) / abs(ref_loss), "terms": {}}
     for a, b in TERMS:
         for q in range(P):
@@ -187,7 +192,7 @@ def _run_case(name, backbone, variant, dtype, img=518, P=2, N=300, vit_kwargs=No
             rec["fp16_range"] = eng.range_report()
     # (f32 engine: 2e-4; at the reference geometry's 6 401 tokens its fp32 softmax sums and 6 401-term PV dot products sit 4e-4 from the fp64 oracle: 1e-3)
     rec["grad_fro_tol"] = {"bf16": BF16_GRAD_FRO, "tf32h": TF32H_GRAD_FRO, "tf32x": 2e-3}.get(dtype, 1e-3 if geometry == "reference" else 2e-4)
-    norm = eng.optimizer_step()
+    norm = fit_norm if fit_step else eng.optimizer_step()
     rec["grad_norm"], rec["ref_grad_norm"] = norm.item(), ref_norm.item()
     # updated weights: the step moved every element by <= lr; compare the UPDATE vectors (post - pre), not the weights
     upd_hip = torch.cat([(q.detach() - b0).double().cpu().reshape(-1) for q, b0 in zip(ps, before)])
@@ -322,6 +327,50 @@ def test_vit_base_518_tf32h_step_matches_oracle():
         rec["grad_rel_fro"], rec["grad_cos"], rec["groups"])
     assert abs(rec["grad_norm"] - rec["ref_grad_norm"]) < 5e-3 * rec["ref_grad_norm"], rec
     assert rec["weights_rel_fro"] < 1e-4
+
+
+# The code path bench.py TIMES, against the oracle (round 6).  Every other full-size oracle case runs training_step + backward on P <= 2 pairs; the bench
+# runs fit_step (direct_grads: the blocks write their weight gradients into the flat buffer) on 32 pairs, and both fused tf32h adapter kernels are
+# gated at M >= 8192 token rows (csrc/adapter.hip) — two pairs are M = 5480, so gd_adapter_fused_h (forward and backward-to-input) and the
+# gd_adapter_fused_h_ln hand-off of the next block's LayerNorm never ran inside an oracle-checked step.  P = 4 (M = 10 960): ONE fit_step against
+# the fp32 oracle (the reference's arithmetic; attention through torch's fused CPU kernel) — every loss term, the gradient of the whole trainable
+# vector, the pre-clip norm, the weights after clip + AdamW — and, for tf32h, the assertion that the fused kernels are what ran: the hand-off 7 times
+# (blocks 4 .. 10), the plain fused forward once (block 11: no block above it), the fused backward-to-input in all 8 adapted blocks.
+@pytest.mark.parametrize("dtype", ["f32", "tf32h"])
+def test_vit_base_518_fit_step_benched_path_matches_oracle(dtype):
+    from gd_amd import ops
+    from gd_amd.options import option
+    assert option("direct_grads") and option("adapter_ln") and option("adapter_h_fused")      # the defaults the bench runs with
+    calls = {"h_ln": 0, "h_fwd": 0, "h_bwd": 0}
+    real_ln, real_h = ops.adapter_fused_h_ln, ops.adapter_fused_h
+
+    def counted_ln(*a, **k):
+        calls["h_ln"] += 1
+        return real_ln(*a, **k)
+
+    def counted_h(*a, gate_src=None, **k):
+        calls["h_fwd" if gate_src is None else "h_bwd"] += 1
+        return real_h(*a, gate_src=gate_src, **k)
+    ops.adapter_fused_h_ln, ops.adapter_fused_h = counted_ln, counted_h
+    try:
+        rec = _run_case(f"vit_base_518_mast3r_fit_step_p4_{dtype}", "vit_base", "mast3r", dtype, P=4, counts=[300, 211, 300, 257],
+                        oracle_dtype=torch.float32, kink_band=TF32H_KINK_BAND, fit_step=True)
+    finally:
+        ops.adapter_fused_h_ln, ops.adapter_fused_h = real_ln, real_h
+    rec["fused_adapter_calls"] = dict(calls)
+    _record(f"vit_base_518_mast3r_fit_step_p4_{dtype}", rec)
+    if dtype == "tf32h":
+        assert calls == {"h_ln": 7, "h_fwd": 1, "h_bwd": 8}, calls
+        assert rec["rel_err"] < 2e-4, rec
+        for k, t in rec["terms"].items():
+            assert t["rel_err"] < 2e-4, (k, t)
+        assert rec["grad_rel_fro"] < TF32H_GRAD_FRO and rec["grad_cos"] > 1.0 - 0.5 * TF32H_GRAD_FRO ** 2 - 1e-4, (rec["grad_rel_fro"], rec["grad_cos"], rec["groups"])
+        assert abs(rec["grad_norm"] - rec["ref_grad_norm"]) < 5e-3 * rec["ref_grad_norm"], rec
+        assert rec["weights_rel_fro"] < 1e-4 and rec["max_weight_diff_over_lr"] <= 2.1, rec
+    else:
+        assert calls == {"h_ln": 0, "h_fwd": 0, "h_bwd": 0}, calls      # (the exact-f32 engine has no fp16-operand adapter kernel)
+        rec["grad_fro_tol"] = 5e-4                                     # against an fp32 oracle (its own rounding ~1e-6 per product, summed over 1370-token reductions)
+        _check(rec, cos=0.999)
 
 
 # The benched workload on a backbone with PRETRAINED-LIKE statistics (_pretrained_like: peaked attention, massive residual channels, non-trivial

@@ -446,23 +446,26 @@ def test_checkpoint_carries_optimizer_state_and_unused_params_do_not_decay():
     assert max(float((a - b).detach().abs().max()) for a, b in zip(eng.trainable_parameters(), eng3.trainable_parameters())) > 0.2 * eng._flat["lr"]
 
 
-def test_two_ranks_on_one_gpu_equal_one_rank_on_the_whole_batch(tmp_path):
+@pytest.mark.parametrize("geometry", ["shared", "reference"])
+def test_two_ranks_on_one_gpu_equal_one_rank_on_the_whole_batch(tmp_path, geometry):
     """2 ranks (gloo, both on GPU 0) each take half of a 4-pair batch, exchange gradients through
     dp.OverlappedGradReducer and step; the weights equal a 1-rank step on the whole batch.  The ranks run as a child job
-    (tests/dp_step_worker.py under torch.distributed.run) — the pytest process itself never re-execs."""
+    (tests/dp_step_worker.py under torch.distributed.run) — the pytest process itself never re-execs.
+    geometry "reference" (round 6): two forwards per step through the same blocks, i.e. two backward nodes per block accumulating into the same
+    slices of the flat gradient buffer — each block's slices are exchanged once, after its second node (vit.BlockGradGate)."""
     import os
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     out = str(tmp_path / "rank0.pt")
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DP_GEOMETRY=geometry)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29641", os.path.join(here, "dp_step_worker.py"), out]
+           "--master-port", "29641" if geometry == "shared" else "29643", os.path.join(here, "dp_step_worker.py"), out]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     got = torch.load(out)
     from dp_step_worker import make_engine, make_batch
-    eng = make_engine()
+    eng = make_engine(geometry)
     L = len(eng.adapters)
     assert got["blocks"] == list(reversed(range(L))) and L > 0      # every adapted block handed its slices over during the backward, top block first
     flat = eng.configure_optimizers()

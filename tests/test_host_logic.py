@@ -29,3 +29,27 @@ def test_option_table_defaults_and_override():
     assert options.option("cv_bwd_rows") == old
     with pytest.raises(KeyError):
         options.set_option("no_such_option", 1)
+
+
+def test_block_grad_gate_fires_after_the_last_backward_node_only():
+    """vit.BlockGradGate (data parallelism, the per-block gradient exchange): a block that ran in TWO forwards of one step (geometry="reference":
+    the keypoint grid and the cost grid through the same blocks) has two backward nodes accumulating into the same slices of the flat gradient
+    buffer — the exchange hook may only run when the second one is done, and exactly once; a node that never runs backward leaves the slices to
+    the reducer's late ranges (the hook stays silent)."""
+    from gd_amd.vit import BlockGradGate
+    calls = []
+    gate = BlockGradGate(lambda i, spans: calls.append((i, spans)), 5, [(0, 8), (64, 96)])
+    gate.armed()
+    gate.armed()                       # second forward through the block
+    assert gate.node_done() is False and calls == []
+    assert gate.node_done() is True and calls == [(5, [(0, 8), (64, 96)])]
+    import pytest
+    with pytest.raises(RuntimeError):
+        gate.armed()                   # a third forward after the slices were handed over would accumulate into memory under exchange
+    one = BlockGradGate(lambda i, spans: calls.append(i), 1, [])
+    one.armed()
+    assert one.node_done() is True and calls[-1] == 1
+    idle = BlockGradGate(lambda i, spans: calls.append("never"), 2, [])
+    idle.armed()
+    idle.armed()
+    assert idle.node_done() is False and "never" not in calls      # the other node's output did not reach the loss: nothing is exchanged early
