@@ -22,6 +22,10 @@ SIGNATURES = {
     "gd_debug_set": (c_int, [ctypes.c_char_p, c_int]),
     "gd_debug_get": (c_int, [ctypes.c_char_p]),
     "gd_gemm_phase_probe": (c_int, [c_int, c_void_p]),
+    "gd_loss_combine_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_float), c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "gd_loss_combine_bwd": (c_int, [c_void_p, ctypes.POINTER(c_float), c_void_p, c_int, c_void_p, c_void_p]),
+    "gd_depth_bwd_combine": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "gd_scale_and_transpose": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "gd_gemm_nt": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_long, c_long,
                            c_int, c_long, c_long, c_long, c_int, c_int, c_float,
                            c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_long, c_int,

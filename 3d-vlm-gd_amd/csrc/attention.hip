@@ -508,8 +508,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* qkv, T* o, fl
 // Key rows past N are clamped to row N-1: their scores are masked in the (compile-time) tail tile, so p = 0 for them.
 #define ADS_R128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
 #define ADS_TR64(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
+// ... with the offset as a compile-time expression (the steady-state loop below: slot * tile size + row-group offset, one address register per lane)
+#define ADS_R128I(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(imm))
+#define ADS_TR64I(dst, addr, imm) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(imm))
 typedef __attribute__((ext_vector_type(2))) unsigned a_u32x2;
-template <typename T>      // bf16 | f16
+// UNR (round 6): the tiles whose two-ahead prefetch is a full tile run in groups of THREE with the ring slot as a compile-time constant — every LDS
+// read is base register + immediate (no per-tile address arithmetic on the vector ALU), the DMA source is a scalar tile base + one 32-bit lane offset
+// per piece (no 64-bit vector adds), and the slot / wait-kind / full-tile tests leave the loop.  The tile loop of round 5 executed 1.40 scalar and 2.88
+// non-MFMA vector instructions per MFMA (profiles/r05_pmc_attention_stall.json) in a loop that is bound by instruction issue.
+template <typename T, bool UNR = true>      // bf16 | f16
 __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const T* qkv, T* o, float* lse, int N, int H, float scale, int rot_on) {
     typedef typename Mma<T>::Frag Frag;
     constexpr int TILE = 64 * 128;                       // one K or V tile: 64 rows x 128 B
@@ -657,6 +664,86 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const T* qkv, T* o
         }
     };
     int t = 0;
+    if constexpr (UNR) {
+        // ---- steady state: tiles t with t + 2 < nfull, three at a time (slot = t % 3 is the compile-time S of each copy)
+        const int nsteady = nfull > 2 ? (nfull - 2) / 3 * 3 : 0;
+        const bool live = q0 < N;                // (a wave whose 32 queries are all past N only moves its DMA pieces)
+        const unsigned voff[2] = {(unsigned)(kp[0] - kb), (unsigned)(kp[1] - kb)};      // this lane's byte offset inside a tile, per piece (< 64 rows x ld_b < 2^31)
+        int kt2 = nsteady ? pk0(2) : 0;          // first key of the tile two ahead, kept as a running scalar (+64, wrapping at nfull * 64)
+        const int kwrap = nfull * 64;
+        auto step = [&](auto slot_c, bool first) __attribute__((always_inline)) {
+            constexpr int S = decltype(slot_c)::value, S2 = (S + 2) % 3;
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // tile t landed; tile t + 1 may still fly
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            {
+                const unsigned long t0 = (unsigned)kt2 * (unsigned)ld_b;
+                const char* ks = kb + t0;        // scalar tile bases: the pieces go out as saddr + 32-bit voffset
+                const char* vs = vb + t0;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ks + voff[i]),
+                                                     (__attribute__((address_space(3))) void*)(smem + S2 * TILE + (wave * 2 + i) * 1024), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vs + voff[i]),
+                                                     (__attribute__((address_space(3))) void*)(smem + (3 + S2) * TILE + (wave * 2 + i) * 1024), 16, 0, 0);
+                }
+                kt2 += 64;
+                if (kt2 == kwrap) kt2 = 0;
+            }
+            if (!live) return;
+            const unsigned ak0 = lds0 + ka0, ak1 = lds0 + ka1;
+            f32x4 kr[4][2];
+            ADS_R128I(kr[0][0], ak0, S * TILE + 0);    ADS_R128I(kr[0][1], ak1, S * TILE + 0);
+            ADS_R128I(kr[1][0], ak0, S * TILE + 2048); ADS_R128I(kr[1][1], ak1, S * TILE + 2048);
+            ADS_R128I(kr[2][0], ak0, S * TILE + 4096); ADS_R128I(kr[2][1], ak1, S * TILE + 4096);
+            ADS_R128I(kr[3][0], ak0, S * TILE + 6144); ADS_R128I(kr[3][1], ak1, S * TILE + 6144);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kr[0][0]), "+v"(kr[0][1]), "+v"(kr[1][0]), "+v"(kr[1][1]), "+v"(kr[2][0]), "+v"(kr[2][1]),
+                         "+v"(kr[3][0]), "+v"(kr[3][1]));
+            f32x4 s[2][4];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) {
+                    f32x4 a = negm[qt];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) a = Mma<T>::mma(__builtin_bit_cast(Frag, kr[kt][u]), qf[qt][u], a);
+                    s[qt][kt] = a;
+                }
+            a_u32x2 vr[4][2][2];   // [dt][u][row half]
+#define ADS_VI(dt)                                                                                                                   \
+            ADS_TR64I(vr[dt][0][0], lds0 + va[dt], (3 + S) * TILE + 0);    ADS_TR64I(vr[dt][0][1], lds0 + va[dt], (3 + S) * TILE + 2048);       \
+            ADS_TR64I(vr[dt][1][0], lds0 + va[dt], (3 + S) * TILE + 4096); ADS_TR64I(vr[dt][1][1], lds0 + va[dt], (3 + S) * TILE + 6144);
+            ADS_VI(0) ADS_VI(1) ADS_VI(2) ADS_VI(3)
+#undef ADS_VI
+            softmax_lagged<false>(s, m, negm, oacc, lacc, first, 0, g, N);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vr[0][0][0]), "+v"(vr[0][0][1]), "+v"(vr[0][1][0]), "+v"(vr[0][1][1]), "+v"(vr[1][0][0]),
+                         "+v"(vr[1][0][1]), "+v"(vr[1][1][0]), "+v"(vr[1][1][1]), "+v"(vr[2][0][0]), "+v"(vr[2][0][1]), "+v"(vr[2][1][0]),
+                         "+v"(vr[2][1][1]), "+v"(vr[3][0][0]), "+v"(vr[3][0][1]), "+v"(vr[3][1][0]), "+v"(vr[3][1][1]));
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                Frag pf[2];
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) {
+                    pf[qt] = acc_to_bfrag<T>(s[qt], u);
+                    lacc[qt] = Mma<T>::mma(ones, pf[qt], lacc[qt]);
+                }
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    typedef __attribute__((ext_vector_type(4))) unsigned a_u32x4;
+                    const a_u32x4 z = {vr[dt][u][0][0], vr[dt][u][0][1], vr[dt][u][1][0], vr[dt][u][1][1]};
+                    const Frag vf = __builtin_bit_cast(Frag, z);
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt) oacc[dt][qt] = Mma<T>::mma(vf, pf[qt], oacc[dt][qt]);
+                }
+            }
+        };
+        for (; t < nsteady; t += 3) {
+            step(std::integral_constant<int, 0>{}, t == 0);
+            step(std::integral_constant<int, 1>{}, false);
+            step(std::integral_constant<int, 2>{}, false);
+        }
+        // (nsteady is a multiple of three: the generic tiles below start at slot 0 again)
+    }
     for (; (t + 1) * 64 <= N; ++t) {
         key_tile(t, std::false_type{});
         slot = slot == 2 ? 0 : slot + 1;
@@ -1165,10 +1252,12 @@ extern "C" int gd_attention_fwd(const void* qkv, void* o, float* lse, int B, int
     const int dma = gd_knobs().attn_dma;   // GD_ATTN_DMA=0: the register-staged forward kernel (A/B testing)
     if (dtype == GD_BF16 && dma)
         { const int ro = gd_knobs().attn_rot;
-          hipLaunchKernelGGL(attn_fwd_dma_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, ro); }
+          if (gd_knobs().attn_unroll) hipLaunchKernelGGL((attn_fwd_dma_kernel<bf16, true>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, ro);
+          else hipLaunchKernelGGL((attn_fwd_dma_kernel<bf16, false>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, ro); }
     else if (dtype == GD_F16 && dma)        // tf32h engine: fp16 q / k / v / p (TF32's significand), the bf16 kernel's layouts
         { const int ro = gd_knobs().attn_rot;
-          hipLaunchKernelGGL(attn_fwd_dma_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, (const f16*)qkv, (f16*)o, lse, N, H, scale, ro); }
+          if (gd_knobs().attn_unroll) hipLaunchKernelGGL((attn_fwd_dma_kernel<f16, true>), grid, dim3(256), 0, (hipStream_t)stream, (const f16*)qkv, (f16*)o, lse, N, H, scale, ro);
+          else hipLaunchKernelGGL((attn_fwd_dma_kernel<f16, false>), grid, dim3(256), 0, (hipStream_t)stream, (const f16*)qkv, (f16*)o, lse, N, H, scale, ro); }
     else if (dtype == GD_F16)
         hipLaunchKernelGGL(attn_fwd_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, (const f16*)qkv, (f16*)o, lse, N, H, scale);
     else if (dtype == GD_BF16)

@@ -1336,7 +1336,7 @@ static int cv_fwd_common(const void* f1, const void* f2, const float* inv1, cons
     const int tiles = cv_tiles(hw), nslab = tiles;
     float* part1 = (float*)workspace;
     float* part2 = (float*)((char*)workspace + align256((size_t)P * nslab * hw * 2 * sizeof(float)));
-    double* chunk_loss = (double*)((char*)part2 + align256((size_t)P * 2 * nslab * hw * 2 * sizeof(float)));
+    double* chunk_loss = (double*)((char*)part2 + align256((size_t)P * nslab * hw * 2 * sizeof(float)));
     int nslab2 = nslab;
     float* ts_ws = (float*)((char*)chunk_loss + align256((size_t)P * CV_FCH * sizeof(double)));
     if (!tstats) {     // no cached teacher statistics: one extra pass over the teacher maps

@@ -331,8 +331,18 @@ class FinetuneGD(nn.Module):
         return self._fwd_cache[key]
 
     def clear_cache(self):
-        self._fwd_cache, self._norm_cache = {}, {}
+        self._fwd_cache, self._norm_cache, self._kp_cache = {}, {}, {}
         ops.ln_stats_clear()
+
+    def _kp_pair(self, kp_1, kp_2):
+        """cat([kp_1, kp_2], 0), once per step (the depth and the matching loss sample the same keypoints)."""
+        key = (kp_1.data_ptr(), kp_2.data_ptr(), kp_1._version, kp_2._version, tuple(kp_1.shape))
+        c = getattr(self, "_kp_cache", None)
+        if c is None:
+            c = self._kp_cache = {}
+        if key not in c:
+            c[key] = torch.cat([kp_1, kp_2], 0)
+        return c[key]
 
     def get_intermediate_feature(self, rgbs, pts=None, n=(4, 5, 6, 7), normalize=True):
         """src/finetune_timm_vggt.py:256-302 (reshape=True path): mean over taps of bilinear samples of the
@@ -385,7 +395,7 @@ class FinetuneGD(nn.Module):
     def calculate_depth_loss(self, depth_1, depth_2, rgbs, kp_1, kp_2, counts=None, indices=(4, 5, 6, 7)):
         """src/finetune_timm_vggt.py:465-485.  rgbs = cat(rgb_1, rgb_2) [2P,3,h,w]; depth_k [P,H,W]."""
         P = kp_1.shape[0]
-        kp = torch.cat([kp_1, kp_2], 0)
+        kp = self._kp_pair(kp_1, kp_2)
         feat = self.get_intermediate_feature(rgbs, pts=kp, n=indices, normalize=True)       # [2P,N,D]
         d1, d2 = ops.kp_depth(depth_1, kp_1), ops.kp_depth(depth_2, kp_2)
         return ops.depth_losses(feat, d1, d2, self.depth_diff_head.head_params(), counts=counts, depth_threshold=0.05)   # view-major [2P,N,D]
@@ -414,10 +424,8 @@ class FinetuneGD(nn.Module):
         """src/finetune_timm_vggt.py:536-574 / src/finetune_timm_mast3r.py:543-589.  pts3d_k [P,N,3] are the
         teacher's 3-D points already gathered at the keypoints."""
         P = kp_1.shape[0]
-        desc = self.get_feature(rgbs, torch.cat([kp_1, kp_2], 0), normalize=True)
-        d1, d2 = ops.split_pairs(desc, P)
-        return ops.smooth_ap(d1, d2, pts3d_1, pts3d_2, counts, self.variant, self.thres3d_neg, 0.01,
-                             thres3d_pos=self.thresh3d_pos)
+        desc = self.get_feature(rgbs, self._kp_pair(kp_1, kp_2), normalize=True)
+        return ops.smooth_ap_pairs(desc, P, pts3d_1, pts3d_2, counts, self.variant, self.thres3d_neg, 0.01, thres3d_pos=self.thresh3d_pos)
 
     def training_step(self, batch, direct_grads=False):
         """Loss of P pairs = mean over pairs of the reference's per-pair loss (src/finetune_timm_vggt.py:599-616).
@@ -439,25 +447,18 @@ class FinetuneGD(nn.Module):
             self._fuse_taps = False
             self.model.release_trainables()
             zero = torch.zeros_like(ap.detach())
-            return (self.ap_loss_weight * ap).mean(), {"ap_loss": ap.detach(), "depth_loss": zero, "intra_depth_loss": zero,
-                                                       "kl_loss": zero}
+            loss, tm = ops.loss_combine(ap, zero, zero, zero, (self.ap_loss_weight, 0.0, 0.0, 0.0), None)
+            return loss, {"ap_loss": tm[0], "depth_loss": zero, "intra_depth_loss": zero, "kl_loss": zero}
         depth_loss, intra = self.calculate_depth_loss(batch["depth_1"], batch["depth_2"], rgbs, batch["kp_1"],
                                                       batch["kp_2"], counts)
         kl = self.calculate_cost_loss(rgbs, batch["cost_1"], batch["cost_2"], batch["kp_1"], batch["kp_2"],
                                       batch.get("mask_1"), batch.get("mask_2"), batch.get("cost_tstats"))
         ap = self.calculate_matching_loss(rgbs, batch["kp_1"], batch["kp_2"], batch["pts3d_1"], batch["pts3d_2"], counts)
-        per_pair = (self.ap_loss_weight * ap + self.depth_loss_weight * depth_loss
-                    + self.intra_depth_loss_weight * intra + self.kl_loss_weight * kl)
-        if counts is not None:
-            # a pair whose keypoint filter left nothing: the reference returns a constant zero loss for that step
-            # (src/finetune_timm_mast3r.py:604-607, src/finetune_timm_vggt.py:585-597) — zero loss, zero gradient here too
-            per_pair = torch.where(counts.to(per_pair.device) > 0, per_pair, torch.zeros_like(per_pair))
+        # loss = mean over pairs of the weighted sum; a pair whose keypoint filter left nothing contributes the reference's constant zero
+        # (src/finetune_timm_mast3r.py:604-607, src/finetune_timm_vggt.py:585-597: zero loss, zero gradient, zero reported terms) — one kernel each way
+        loss, tm = ops.loss_combine(ap, depth_loss, intra, kl, (self.ap_loss_weight, self.depth_loss_weight, self.intra_depth_loss_weight,
+                                                                self.kl_loss_weight), counts)
         self.clear_cache()
         self._fuse_taps = False
         self.model.release_trainables()
-        terms = {"ap_loss": ap.detach(), "depth_loss": depth_loss.detach(), "intra_depth_loss": intra.detach(),
-                 "kl_loss": kl.detach()}
-        if counts is not None:      # the reported terms of an empty pair are the reference's zeros too (its KL term alone is a non-zero constant)
-            keep = counts.to(per_pair.device) > 0
-            terms = {k: torch.where(keep, v, torch.zeros_like(v)) for k, v in terms.items()}
-        return per_pair.mean(), terms
+        return loss, {"ap_loss": tm[0], "depth_loss": tm[1], "intra_depth_loss": tm[2], "kl_loss": tm[3]}

@@ -865,6 +865,7 @@ class _TapMean(torch.autograd.Function):
         gs = [g.contiguous() for g in grids]
         out = torch.empty(B, Nt - prefix, D, dtype=gs[0].dtype, device=gs[0].device)
         ctx.meta = (prefix, len(gs), B, Nt, D)
+        ctx.set_materialize_grads(False)      # (the inverse norms / the fp16 copy are not differentiable: no zero-filled [B, hw, D] "gradient" for them)
         if with_norm == 2:      # + the fp16 copy of the rows (tf32h engine: the cost-volume products' operands)
             _req(out.dtype == torch.float32 and D % 8 == 0, "tap_mean(with_norm=2): fp32 taps, D % 8 == 0")
             inv = torch.empty(B, Nt - prefix, dtype=torch.float32, device=gs[0].device)
@@ -886,6 +887,8 @@ class _TapMean(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, *unused):
         prefix, ng, B, Nt, D = ctx.meta
+        if dout is None:
+            return (None, None) + (None,) * ng
         dout = dout.contiguous()
         # the ng gradients are identical (dout / ng): one buffer, handed to every grid
         dg = torch.empty(B, Nt, D, dtype=dout.dtype, device=dout.device)
@@ -923,50 +926,82 @@ def patch_mask(kp, H, W, P):
 # ----------------------------------------------------------------------------------------------
 # sparse losses
 # ----------------------------------------------------------------------------------------------
-class _SmoothAP(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, desc1, desc2, pts1, pts2, counts, variant, thr, temp):
-        P, N0, C = desc1.shape
-        N = (N0 + 7) // 8 * 8                                      # gemm_tn wants multiples of 8: zero-pad keypoints
-        dev = desc1.device
-        if counts is None:
-            counts = torch.full((P,), N0, dtype=torch.int32, device=dev)
+_CONST = {}
 
-        def pad(t, w):
-            out = torch.zeros(P, N, w, dtype=torch.float32, device=dev)
-            out[:, :N0] = t
-            return out
-        d1, d2, p1, p2 = pad(desc1, C), pad(desc2, C), pad(pts1, 3), pad(pts2, 3)
+
+def _const(kind, n, value, device):
+    """small constant device vectors (all-ones scales, full keypoint counts), built once per (kind, length, value, device)."""
+    key = (kind, int(n), value, device)
+    t = _CONST.get(key)
+    if t is None:
+        t = _CONST[key] = torch.full((int(n),), value, dtype=torch.int32 if kind == "i" else torch.float32, device=device)
+    return t
+
+
+class _SmoothAP(torch.autograd.Function):
+    """desc [2P, N0, C]: the unit descriptors of view 1 (first P) and view 2 (last P) as the extractor returns them — one buffer in, one gradient
+    buffer out (no per-view slices, concatenations or per-tensor padding passes)."""
+
+    @staticmethod
+    def forward(ctx, desc, pts1, pts2, counts, variant, thr, temp):
+        P2, N0, C = desc.shape
+        P = P2 // 2
+        N = (N0 + 7) // 8 * 8                                      # gemm_tn wants multiples of 8: zero-pad keypoints
+        dev = desc.device
+        if counts is None:
+            counts = _const("i", P, N0, dev)
+        desc = desc.float()
+        if N == N0:
+            d12 = desc.contiguous()
+            pp = torch.stack([pts1, pts2]).float().contiguous()
+        else:      # ONE zero-filled buffer for the padded descriptors and points of both views
+            buf = torch.zeros(P2 * N * (C + 4), dtype=torch.float32, device=dev)
+            d12 = buf[:P2 * N * C].view(P2, N, C)
+            pp = buf[P2 * N * C:P2 * N * (C + 3)].view(2, P, N, 3)
+            d12[:, :N0] = desc
+            pp[0, :, :N0] = pts1
+            pp[1, :, :N0] = pts2
+        d1, d2 = d12[:P], d12[P:]
         sim = gemm_nt(d1, d2)                                     # [P,N,N] fp32, exact-f32 MFMA
         loss = torch.empty(P, dtype=torch.float32, device=dev)
         dsim = torch.empty_like(sim)
         rows = torch.empty(P, N, 2, dtype=torch.float32, device=dev)
         if variant == "me":      # every pair closer than thr[0] is a positive (src/finetune_timm_me.py:191-220)
-            rc = lib().gd_smooth_ap_me(ptr(sim), ptr(p1), ptr(p2), ptr(counts), P, N, float(thr[0]), float(thr[1]),
+            rc = lib().gd_smooth_ap_me(ptr(sim), ptr(pp[0]), ptr(pp[1]), ptr(counts), P, N, float(thr[0]), float(thr[1]),
                                        float(temp), ptr(loss), ptr(dsim), ptr(rows), stream())
             check(rc, "gd_smooth_ap_me")
         else:
-            rc = lib().gd_smooth_ap(ptr(sim), ptr(p1), ptr(p2), ptr(counts), P, N, VARIANTS[variant], float(thr),
+            rc = lib().gd_smooth_ap(ptr(sim), ptr(pp[0]), ptr(pp[1]), ptr(counts), P, N, VARIANTS[variant], float(thr),
                                     float(temp), ptr(loss), ptr(dsim), ptr(rows), stream())
             check(rc, "gd_smooth_ap")
-        ctx.save_for_backward(d1, d2, dsim)
+        ctx.save_for_backward(d12, dsim)
         ctx.n0 = N0
         return loss
 
     @staticmethod
     def backward(ctx, g):
-        d1, d2, dsim = ctx.saved_tensors
-        gs = dsim * g.float().view(-1, 1, 1)
-        dd2 = gemm_tn(gs, d1)                                     # [P,N,C] = dsim^T d1
-        dd1 = gemm_tn(gs.transpose(1, 2).contiguous(), d2)        # [P,N,C] = dsim d2
-        return dd1[:, :ctx.n0], dd2[:, :ctx.n0], None, None, None, None, None, None
+        d12, dsim = ctx.saved_tensors
+        P, N, _ = dsim.shape
+        d1, d2 = d12[:P], d12[P:]
+        gs, gst = torch.empty_like(dsim), torch.empty_like(dsim)
+        check(lib().gd_scale_and_transpose(ptr(dsim), ptr(g.contiguous().float()), ptr(gs), ptr(gst), P, N, N, stream()), "gd_scale_and_transpose")
+        dd = torch.zeros_like(d12)                                 # (gemm_tn accumulates)
+        gemm_tn(gst, d2, out=dd[:P])                              # [P,N,C] = (dsim g) d2
+        gemm_tn(gs, d1, out=dd[P:])                               # [P,N,C] = (dsim g)^T d1
+        return dd[:, :ctx.n0], None, None, None, None, None, None
+
+
+def smooth_ap_pairs(desc, P, pts3d_1, pts3d_2, counts=None, variant="vggt", thres3d_neg=0.1, temp=0.01, thres3d_pos=5e-3):
+    """smooth_ap on the view-major batch the extractor returns: desc [2P, N, C] (view 1 of all pairs, then view 2) -> loss [P]."""
+    _req(desc.shape[0] == 2 * P, "smooth_ap_pairs: desc must be [2P, N, C]")
+    thr = (thres3d_pos, thres3d_neg) if variant == "me" else thres3d_neg
+    return _SmoothAP.apply(desc, pts3d_1, pts3d_2, counts, variant, thr, temp)
 
 
 def smooth_ap(desc1, desc2, pts3d_1, pts3d_2, counts=None, variant="vggt", thres3d_neg=0.1, temp=0.01, thres3d_pos=5e-3):
     """desc [P,N,C] unit descriptors, pts3d [P,N,3], counts int32 [P] (valid keypoints per pair) -> loss [P].
     variant "vggt" | "mast3r": positives on the diagonal; "me": every pair closer than thres3d_pos (finetune_timm_me.py)."""
-    thr = (thres3d_pos, thres3d_neg) if variant == "me" else thres3d_neg
-    return _SmoothAP.apply(desc1, desc2, pts3d_1, pts3d_2, counts, variant, thr, temp)
+    return smooth_ap_pairs(torch.cat([desc1, desc2], 0), desc1.shape[0], pts3d_1, pts3d_2, counts, variant, thres3d_neg, temp, thres3d_pos)
 
 
 HEAD_KEYS = ("w1", "b1", "ln_w", "ln_b", "w2", "b2")
@@ -975,7 +1010,7 @@ HEAD_KEYS = ("w1", "b1", "ln_w", "ln_b", "w2", "b2")
 class _DepthLosses(torch.autograd.Function):
     """depth L1 + intra-view ranking on keypoint features [P,2,N,D] with the DepthAwareFeatureFusion head.
     The loss kernels are fused forward+backward: they emit, per keypoint set, the loss AND its gradients for a
-    unit upstream gradient; backward() only scales and contracts them."""
+    unit upstream gradient; backward() scales and adds them in one pass (gd_depth_bwd_combine) and contracts."""
 
     @staticmethod
     def forward(ctx, feats, d1, d2, counts, thr, w1, b1, ln_w, ln_b, w2, b2):
@@ -988,40 +1023,37 @@ class _DepthLosses(torch.autograd.Function):
         else:
             P, _, N, D = feats.shape
             u = gemm_nt(f.view(P * 2 * N, D), w1.contiguous())         # [P*2*N,128] = W1 f
-        depth = torch.stack([d1, d2], 1).contiguous().float()      # [P,2,N]
-        dv1, dv2 = depth[:, 0].contiguous(), depth[:, 1].contiguous()
+        dv1, dv2 = d1.contiguous().float(), d2.contiguous().float()
+        depth = torch.stack([dv1, dv2], 1)                         # [P,2,N]
         cnt2 = counts.repeat_interleave(2).contiguous() if counts is not None else None
-        ones = torch.ones(2 * P, dtype=torch.float32, device=dev)
         hp = [t.contiguous().float() for t in (b1, ln_w, ln_b, w2.view(-1), b2)]
         rank = torch.empty(2 * P, dtype=torch.float32, device=dev)
         du_r = torch.empty(2 * P, N, 128, dtype=torch.float32, device=dev)
         hg_r = torch.empty(2 * P, 516, dtype=torch.float32, device=dev)
         ws = torch.empty(lib().gd_pair_rank_workspace_bytes(2 * P), dtype=torch.uint8, device=dev)
-        check(lib().gd_pair_rank(ptr(u), ptr(depth), ptr(cnt2), ptr(ones), 2 * P, N, float(thr), *[ptr(t) for t in hp],
+        check(lib().gd_pair_rank(ptr(u), ptr(depth), ptr(cnt2), None, 2 * P, N, float(thr), *[ptr(t) for t in hp],
                                  ptr(rank), ptr(du_r), None, ptr(hg_r), ptr(ws), stream()), "gd_pair_rank")
         l1 = torch.empty(P, dtype=torch.float32, device=dev)
         du_l = torch.empty(P, 2, N, 128, dtype=torch.float32, device=dev)
         hg_l = torch.empty(P, 516, dtype=torch.float32, device=dev)
-        check(lib().gd_depth_l1(ptr(u), ptr(dv1), ptr(dv2), ptr(counts), ptr(ones), P, N, *[ptr(t) for t in hp],
+        check(lib().gd_depth_l1(ptr(u), ptr(dv1), ptr(dv2), ptr(counts), None, P, N, *[ptr(t) for t in hp],
                                 ptr(l1), ptr(du_l), None, ptr(hg_l), None, stream()), "gd_depth_l1")
         ctx.save_for_backward(f, w1, du_r, du_l, hg_r, hg_l)
         ctx.dims = (P, N, D, vm)
-        intra = 0.5 * (rank.view(P, 2)[:, 0] + rank.view(P, 2)[:, 1])
-        return l1, intra
+        return l1, rank.view(P, 2).mean(1)
 
     @staticmethod
     def backward(ctx, g_l1, g_intra):
         f, w1, du_r, du_l, hg_r, hg_l = ctx.saved_tensors
         P, N, D, vm = ctx.dims
-        gi = (0.5 * g_intra.float()).repeat_interleave(2)                       # per keypoint set
-        gl = g_l1.float()
-        du = du_r.view(P, 2, N, 128) * gi.view(P, 2, 1, 1) + du_l * gl.view(P, 1, 1, 1)
-        hg = (hg_r * gi[:, None]).sum(0) + (hg_l * gl[:, None]).sum(0)
-        du = (du.transpose(0, 1).contiguous() if vm else du).view(P * 2 * N, 128)     # rows in the order of f
+        dev = f.device
+        du = torch.empty(P * 2 * N, 128, dtype=torch.float32, device=dev)                # rows in the order of f
+        hg = torch.empty(516, dtype=torch.float32, device=dev)
+        check(lib().gd_depth_bwd_combine(ptr(du_r), ptr(du_l), ptr(hg_r), ptr(hg_l), ptr(g_l1.contiguous().float()), ptr(g_intra.contiguous().float()),
+                                         P, N, 1 if vm else 0, ptr(du), ptr(hg), stream()), "gd_depth_bwd_combine")
         df = gemm_nt(du, w1.t().contiguous()).view(f.shape)        # du . W1
         dw1 = gemm_tn(du, f.view(P * 2 * N, D))                    # du^T f  [128, D]
-        return (df, None, None, None, None, dw1, hg[0:128].clone(), hg[128:256].clone(), hg[256:384].clone(),
-                hg[384:512].view(1, 128).clone(), hg[512:513].clone())
+        return (df, None, None, None, None, dw1, hg[0:128], hg[128:256], hg[256:384], hg[384:512].view(1, 128), hg[512:513])
 
 
 def depth_losses(feats, depth_1, depth_2, head, counts=None, depth_threshold=0.05):
@@ -1111,6 +1143,43 @@ def pair_rank_loss(feats, depths, head, depth_threshold=0.0):
     |d_j - d_i| > depth_threshold (0 when there is none)."""
     return _PairRank.apply(feats, depths, depth_threshold, head["w1"], head["b1"], head["ln_w"], head["ln_b"], head["w2"],
                            head["b2"])
+
+
+class _LossCombine(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ap, depth, intra, kl, counts, weights):
+        P = ap.shape[0]
+        ts = [t.contiguous().float() for t in (ap, depth, intra, kl)]
+        w4 = (ctypes_float_array(weights))
+        loss = torch.empty((), dtype=torch.float32, device=ap.device)
+        terms = torch.empty(4, P, dtype=torch.float32, device=ap.device)
+        cnt = counts.contiguous().to(device=ap.device, dtype=torch.int32) if counts is not None else None
+        check(lib().gd_loss_combine_fwd(*[ptr(t) for t in ts], w4, ptr(cnt), P, ptr(loss), ptr(terms), stream()), "gd_loss_combine_fwd")
+        ctx.cfg = (tuple(float(w) for w in weights), cnt, P)
+        ctx.mark_non_differentiable(terms)
+        ctx.set_materialize_grads(False)
+        return loss, terms
+
+    @staticmethod
+    def backward(ctx, g, _unused=None):
+        weights, cnt, P = ctx.cfg
+        if g is None:
+            return None, None, None, None, None, None
+        grads = torch.empty(4, P, dtype=torch.float32, device=g.device)
+        check(lib().gd_loss_combine_bwd(ptr(g.contiguous().float()), ctypes_float_array(weights), ptr(cnt), P, ptr(grads), stream()), "gd_loss_combine_bwd")
+        return grads[0], grads[1], grads[2], grads[3], None, None
+
+
+def loss_combine(ap, depth, intra, kl, weights, counts=None):
+    """The step's scalar loss = mean over pairs of (w_ap ap + w_depth depth + w_intra intra + w_kl kl), a pair with counts[p] == 0 contributing a
+    constant zero (src/finetune_timm_vggt.py:599-616, src/finetune_timm_mast3r.py:604-607, 650-653) -> (loss [], terms [4, P] masked the same way,
+    not differentiable).  One launch each way instead of ~20 elementwise / reduce launches on [P]-vectors."""
+    return _LossCombine.apply(ap, depth, intra, kl, counts, tuple(weights))
+
+
+def ctypes_float_array(vals):
+    import ctypes
+    return (ctypes.c_float * len(vals))(*[float(v) for v in vals])
 
 
 # ----------------------------------------------------------------------------------------------

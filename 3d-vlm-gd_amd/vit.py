@@ -744,8 +744,10 @@ class GDViT(nn.Module):
             return
         r, D = d["r"], d["D"]
         with torch.no_grad():
-            d["gB"][:, 0] += d["gbt"][:, :r, :D].transpose(1, 2)
-            d["gB"][:, 1] += d["gbt"][:, r:, D:].transpose(1, 2)
+            L = d["gbt"].shape[0]
+            # the (q, q) and (v, v) blocks of the [L, (q | v) r, (q | v) D] stash = the diagonal over the two (q | v) axes -> [L, r, D, 2]: ONE add
+            diag = torch.diagonal(d["gbt"].view(L, 2, r, 2, D), dim1=1, dim2=3)
+            d["gB"] += diag.permute(0, 3, 2, 1)
         self._direct = None
 
     def release_trainables(self):

@@ -237,6 +237,23 @@ int gd_pair_rank(const float* u, const float* depth, const int* counts, const fl
                  float depth_threshold, const float* b1, const float* ln_w, const float* ln_b, const float* w2,
                  const float* b2, float* loss, float* du, float* head_grad, float* head_grad_sets, void* workspace,
                  void* stream);
+/* The step's host-side glue as kernels (round 6; each replaces a handful of torch elementwise / reduce launches on [P]-vectors and small tensors):
+ *   gd_loss_combine_fwd   : loss = mean_p keep_p (w[0] t0[p] + w[1] t1[p] + w[2] t2[p] + w[3] t3[p]) — the weighted loss sum and `.mean()` of
+ *                           training_step (src/finetune_timm_vggt.py:599-616; src/finetune_timm_mast3r.py:650-653); keep_p = counts == NULL || counts[p] > 0
+ *                           (a pair without keypoints: constant zero loss, src/finetune_timm_mast3r.py:604-607); terms_out [4][P] (nullable) = keep_p t_i[p];
+ *                           w4: four HOST floats;
+ *   gd_loss_combine_bwd   : grads [4][P] = g[0] w[i] keep_p / P (the chain rule through it);
+ *   gd_depth_bwd_combine  : the backward of calculate_depth_loss's two terms from the unit-gradient outputs of gd_pair_rank / gd_depth_l1:
+ *                           du_out = 0.5 g_intra[p] du_rank + g_l1[p] du_l1 ([P][2][N][128]; rows written view-major [2][P][N] when view_major), hg_out [516]
+ *                           = sum_p 0.5 g_intra[p] (hg_rank[2p] + hg_rank[2p+1]) + g_l1[p] hg_l1[p];
+ *   gd_scale_and_transpose: out [B][R][C] = in * g[b] and out_t [B][C][R] = its transpose (smooth-AP backward: dsim g contracted from both sides).
+ * gd_pair_rank / gd_depth_l1: gscale may be NULL (= 1 per set). */
+int gd_loss_combine_fwd(const float* t0, const float* t1, const float* t2, const float* t3, const float* w4, const int* counts, int P, float* loss,
+                        float* terms_out, void* stream);
+int gd_loss_combine_bwd(const float* g, const float* w4, const int* counts, int P, float* grads, void* stream);
+int gd_depth_bwd_combine(const float* du_rank, const float* du_l1, const float* hg_rank, const float* hg_l1, const float* g_l1, const float* g_intra, int P,
+                         int N, int view_major, float* du_out, float* hg_out, void* stream);
+int gd_scale_and_transpose(const float* in, const float* g, float* out, float* out_t, int B, int R, int C, void* stream);
 /* F.l1_loss(head(f1 - f2), tanh(d1 - d2)) (src/finetune_timm_vggt.py:475-479); u [P,2,Nmax,128]. */
 int gd_depth_l1(const float* u, const float* d1, const float* d2, const int* counts, const float* gscale, int P,
                 int Nmax, const float* b1, const float* ln_w, const float* ln_b, const float* w2, const float* b2,

@@ -279,14 +279,16 @@ def test_kp_gather_with_the_final_layernorm_applied_at_the_samples(dtype, tol):
 
 @pytest.mark.parametrize("taps", [(3, 4, 5, 6), (4, 5, 6, 7)])
 def test_deferred_tap_norm_equals_the_materialised_one(taps):
-    """vit.forward_all(norm_taps=True) with GD_TAP_NORM_FUSED (default): the taps' `model.norm` is not written — the keypoint gather applies it from
+    """vit.forward_all(norm_taps="deferred") with GD_TAP_NORM_FUSED (default): the taps' `model.norm` is not written — the keypoint gather applies it from
     the row statistics the NEXT block's LayerNorm took of the same tensor (gd_kp_gather_fwd_ln), and _TapFn's backward uses those statistics.  Same
     features and the same gradients as the materialising path (option off), f32 and tf32h engines.  Taps (3, 4, 5, 6) of the 8-block test ViT are all
     deferred (the fused gather kernel); with (4, 5, 6, 7) the last tap has no next block: the deferred ones are materialised for the mixed gather
-    (_DeferredNormFn: the gradient still reaches _TapFn as the gradient of the NORMED tap)."""
+    (_DeferredNormFn: the gradient still reaches _TapFn as the gradient of the NORMED tap).
+    The PUBLIC contract (round 6): norm_taps=True returns normed TENSORS whatever the option says; a deferred entry is a vit.DeferredTapNorm — not a
+    tensor, so nothing can slice / cast / stack it and silently get un-normalised features — whose .materialize() equals the normed tensor."""
     from gd_amd.finetune import FinetuneGD
     from gd_amd.options import set_option
-    from gd_amd.vit import kp_gather
+    from gd_amd.vit import DeferredTapNorm, kp_gather
     for dt, tol in (("f32", 2e-5), ("tf32h", 2e-5)):
         res = {}
         for fused in (1, 0):
@@ -298,9 +300,18 @@ def test_deferred_tap_norm_equals_the_materialised_one(taps):
                 eng.model.prepare_trainables(None)
                 rgb = torch.rand(2, 3, 56, 70, generator=_g(60), device="cuda")
                 kp = torch.rand(2, 9, 2, generator=_g(61), device="cuda") * torch.tensor([69.0, 55.0], device="cuda")
-                raw, x, normed = eng.model.forward_all(rgb, taps, size=(56, 70), norm_taps=True)
-                flags = [hasattr(t, "_gd_ln") for t in normed]
+                if fused:      # the documented contract of norm_taps=True: tensors, equal to model.norm(tap)
+                    with torch.no_grad():
+                        raw_t, _, normed_t = eng.model.forward_all(rgb, taps, size=(56, 70), norm_taps=True)
+                    assert all(isinstance(t, torch.Tensor) for t in normed_t)
+                    for r_, n_ in zip(raw_t, normed_t):
+                        assert rel_err(n_, eng.model.norm(r_)) < 1e-6
+                raw, x, normed = eng.model.forward_all(rgb, taps, size=(56, 70), norm_taps="deferred")
+                flags = [isinstance(t, DeferredTapNorm) for t in normed]
                 assert flags == ([i + 1 < 8 for i in taps] if fused else [False] * 4)
+                if fused:
+                    with torch.no_grad():
+                        assert rel_err(normed[0].materialize(), eng.model.norm(raw[0])) < 1e-6
                 feat = kp_gather(normed, kp, 4, 5, 1.0, 1.0, 56, 70, 14)
                 cw = torch.randn(feat.shape, generator=_g(62), device="cuda")
                 cr = torch.randn(raw[0].shape, generator=_g(63), device="cuda")

@@ -15,7 +15,8 @@ hw = (img // patch) ** 2
 eng = FinetuneGD(r=4, backbone="vit_base", patch_size=patch, img_size=img, variant="mast3r", geometry="shared",
                  dtype=os.environ.get("DT", "tf32h"), teacher_patch=patch, lora_b_std=1e-3, vit_kwargs=dict(init_values=1.0)).to(dev)
 eng.configure_optimizers(lr=1e-4)
-batch = synthetic_batch(P, img, img, N, hw, dev, seed=7, teacher_patch=patch)
+from gd_amd.teacher_cache import cache_cost_targets
+batch = cache_cost_targets(synthetic_batch(P, img, img, N, hw, dev, seed=7, teacher_patch=patch))      # as bench.py's Job holds its batches
 
 
 def step():          # what bench.py times: fit_step (weight gradients accumulate straight into the flat buffer)
