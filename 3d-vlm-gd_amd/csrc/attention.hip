@@ -512,11 +512,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* qkv, T* o, fl
 #define ADS_R128I(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(imm))
 #define ADS_TR64I(dst, addr, imm) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(imm))
 typedef __attribute__((ext_vector_type(2))) unsigned a_u32x2;
-// UNR (round 6): the tiles whose two-ahead prefetch is a full tile run in groups of THREE with the ring slot as a compile-time constant — every LDS
-// read is base register + immediate (no per-tile address arithmetic on the vector ALU), the DMA source is a scalar tile base + one 32-bit lane offset
-// per piece (no 64-bit vector adds), and the slot / wait-kind / full-tile tests leave the loop.  The tile loop of round 5 executed 1.40 scalar and 2.88
-// non-MFMA vector instructions per MFMA (profiles/r05_pmc_attention_stall.json) in a loop that is bound by instruction issue.
-template <typename T, bool UNR = true>      // bf16 | f16
+// Round 6: the tiles whose two-ahead prefetch is a full tile run in groups of THREE with the ring slot as a compile-time constant — every LDS read is
+// base register + immediate (no per-tile address arithmetic on the vector ALU) and the slot / wait-kind / full-tile / rotation tests leave the loop:
+// ~30 scalar instructions per tile instead of ~60 (the round-5 loop executed 1.40 scalar per MFMA, profiles/r05_pmc_attention_stall.json; the non-MFMA
+// vector count per steady-state tile is what it was, ~80: 32 v_exp, 16 v_cvt_pk, 16 v_max3 + the threshold test, 4 64-bit address adds for the DMA —
+// the compiler keeps the per-lane piece pointers as 64-bit pairs whatever the source says).  Bit-identical; 423.0 -> 416.6 us at 64 x 12 x 1370,
+// 1016.8 -> 998.7 us at 8 x 12 x 6401, 57.58 -> 57.50 ms per step in one process (profiles/r06_probe_attn_tn.txt).  The tiles the groups do not
+// cover (the last two full tiles, up to two more, the partial tail) run the generic loop below.
+template <typename T>      // bf16 | f16
 __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const T* qkv, T* o, float* lse, int N, int H, float scale, int rot_on) {
     typedef typename Mma<T>::Frag Frag;
     constexpr int TILE = 64 * 128;                       // one K or V tile: 64 rows x 128 B
@@ -664,7 +667,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(const T* qkv, T* o
         }
     };
     int t = 0;
-    if constexpr (UNR) {
+    {
         // ---- steady state: tiles t with t + 2 < nfull, three at a time (slot = t % 3 is the compile-time S of each copy)
         const int nsteady = nfull > 2 ? (nfull - 2) / 3 * 3 : 0;
         const bool live = q0 < N;                // (a wave whose 32 queries are all past N only moves its DMA pieces)
@@ -1252,12 +1255,10 @@ extern "C" int gd_attention_fwd(const void* qkv, void* o, float* lse, int B, int
     const int dma = gd_knobs().attn_dma;   // GD_ATTN_DMA=0: the register-staged forward kernel (A/B testing)
     if (dtype == GD_BF16 && dma)
         { const int ro = gd_knobs().attn_rot;
-          if (gd_knobs().attn_unroll) hipLaunchKernelGGL((attn_fwd_dma_kernel<bf16, true>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, ro);
-          else hipLaunchKernelGGL((attn_fwd_dma_kernel<bf16, false>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, ro); }
+          hipLaunchKernelGGL(attn_fwd_dma_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv, (bf16*)o, lse, N, H, scale, ro); }
     else if (dtype == GD_F16 && dma)        // tf32h engine: fp16 q / k / v / p (TF32's significand), the bf16 kernel's layouts
         { const int ro = gd_knobs().attn_rot;
-          if (gd_knobs().attn_unroll) hipLaunchKernelGGL((attn_fwd_dma_kernel<f16, true>), grid, dim3(256), 0, (hipStream_t)stream, (const f16*)qkv, (f16*)o, lse, N, H, scale, ro);
-          else hipLaunchKernelGGL((attn_fwd_dma_kernel<f16, false>), grid, dim3(256), 0, (hipStream_t)stream, (const f16*)qkv, (f16*)o, lse, N, H, scale, ro); }
+          hipLaunchKernelGGL(attn_fwd_dma_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, (const f16*)qkv, (f16*)o, lse, N, H, scale, ro); }
     else if (dtype == GD_F16)
         hipLaunchKernelGGL(attn_fwd_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, (const f16*)qkv, (f16*)o, lse, N, H, scale);
     else if (dtype == GD_BF16)
