@@ -455,7 +455,48 @@ def cost_volume_roofline(job, args, dev, variant):
     out["us_per_pair_fwd_bwd"] = round(tfb / P * 1e6, 2)      # (sparse keypoint masks: kept-row forward AND kept-row backward, gd_cost_volume_kl_bwd_rows)
     out["row_norms"] = ("from the feature producer (gd_tap_mean_norm_fwd -> gd_cost_volume_kl_fwd_prenorm), as in the step; with the op's own "
                         f"norm pass over the features: {timed(ones, ones, own_norm=True) / P * 1e6:.2f} us/pair unmasked")
+    out["unmasked"]["attainable"] = cost_volume_attainable(job, dev, variant, fwd_bytes)
     return out
+
+
+def cost_volume_attainable(job, dev, variant, fwd_bytes):
+    """A MEASURED ceiling for the dense cost-volume forward to read `unmasked.frac` against: the persistent kernel's phases timed one at a time through its
+    anatomy instantiation (csrc/cost_volume.hip `cv_fwd_persist_kernel<bf16, true>`, gd_debug_set("cv_dbg", bits): 1 = no teacher loads, 2 = no epilogue
+    arithmetic, 4 = no fragment reads / MFMAs; 7 leaves the LDS-DMA ring that brings the feature tiles in).  With every phase running ALONE the launch cannot
+    be faster than the slowest one; the shipped kernel's time is close to their SUM (profiles/r05_pmc_cost_volume_stall.json: 52 % of the wave cycles parked
+    on waitcnt / barrier, MFMA and VALU co-executing in 1.4 %) — what a kernel of this tile shape (128 x 128 x K = 768, 393 KB of features staged per tile)
+    could reach if the phases overlapped perfectly is bytes / slowest phase.  bf16 features (the anatomy build exists for bf16 only; the fp16 instantiation
+    the tf32h engine runs is the same code on the other 16-bit MFMA)."""
+    from gd_amd import ops
+    from gd_amd._lib import lib
+    P, hw, D = job.P, job.hw, job.eng.embedding_dim
+    if (P * hw * D) <= 0 or (D * 2) % 128 != 0:
+        return None
+    b = job.batches[0]
+    f1 = torch.randn(P, hw, D, device=dev).bfloat16()
+    f2 = torch.randn(P, hw, D, device=dev).bfloat16()
+    inv = (1.0 / f1.float().norm(dim=-1).clamp_min(1e-12), 1.0 / f2.float().norm(dim=-1).clamp_min(1e-12))
+    ones = torch.ones(P, hw, dtype=torch.bool, device=dev)
+
+    def t(bits):
+        lib().gd_debug_set(b"cv_dbg", bits)
+        try:
+            with torch.no_grad():
+                return ops.time_on_stream(lambda: ops.cost_volume_kl(f1, f2, b["cost_1"], b["cost_2"], ones, ones, variant, tstats=b["cost_tstats"], inv_norms=inv), 2, 5) * 1e6
+        finally:
+            lib().gd_debug_set(b"cv_dbg", 0)
+    whole, ring, ring_mfma, ring_teacher, ring_epi = t(32), t(7), t(3), t(6), t(5)
+    phases = {"feature_ring_alone (LDS-DMA, L2 -> LDS)": ring, "fragment_reads_and_mfma (marginal)": max(ring_mfma - ring, 0.0),
+              "teacher_loads (marginal)": max(ring_teacher - ring, 0.0), "softmax_kl_epilogue (marginal)": max(ring_epi - ring, 0.0)}
+    slow, tot = max(phases.values()), sum(phases.values())
+    return {"what": "dense forward, every row kept, 16-bit features: the persistent kernel's phases timed one at a time (anatomy build; whole op = statistics "
+                    "init + tile kernel + finalize + loss, as `unmasked` times it)",
+            "us_per_launch": {"whole_op_anatomy_build_nothing_off": round(whole, 1), **{k: round(v, 1) for k, v in phases.items()}},
+            "sum_of_phases_us": round(tot, 1), "measured_over_sum_of_phases": round(whole / tot, 3) if tot > 0 else None,
+            "slowest_phase_us": round(slow, 1),
+            "frac_if_phases_overlapped": round(fwd_bytes / (slow * 1e-6) / 1e9 / PEAK_HBM_GBS, 4) if slow > 0 else None,
+            "note": "the ceiling of THIS tile shape under perfect overlap, not of the chip: two re-structurings that tried to overlap the phases (256-row tiles on the "
+                    "GEMM skeleton, round 3; row-panel-stationary with the teacher by inline-asm loads, round 5) measured slower and are shelved under tools/experiments/"}
 
 
 def comm_report(job, args, dev, dt):

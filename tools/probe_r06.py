@@ -100,3 +100,4 @@ if __name__ == "__main__":
     specs = [w for w in which if "=" in w]
     if specs:
         probe_step(specs)
+
