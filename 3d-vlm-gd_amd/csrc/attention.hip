@@ -799,6 +799,7 @@ __global__ __launch_bounds__(256, IsX3<T>::v ? 1 : 2) void attn_bwd_dq_kernel(co
     int xb_, h, b;
     attn_block_coords(xb_, h, b);
     const int q0 = xb_ * 128 + wave * 32;
+    const int npad = (N + 63) / 64 * 64;
     const long ld_b = (long)3 * H * HD * sizeof(T);
     const char* base = (const char*)qkv + (long)b * N * ld_b;
     const char* qb = base + (long)(0 * H + h) * HD * sizeof(T);
@@ -829,7 +830,13 @@ __global__ __launch_bounds__(256, IsX3<T>::v ? 1 : 2) void attn_bwd_dq_kernel(co
         dsum += __shfl_xor(dsum, 32, 64);
         lq[qt] = ok ? lse[((long)b * H + h) * N + q] * 1.4426950408889634f : 0.f;   // log2 units
         dl[qt] = dsum;
-        if (ok && g == 0) delta[((long)b * H + h) * N + q] = dsum;
+        // row constants for the dK/dV kernel, in the form its accumulators start from: ws[0] = -delta, ws[1] = -lse (log2 units), rows padded to whole
+        // 64-query tiles — a pad query gets -lse = -1e30, i.e. p = exp2(s - 1e30) = 0 and dS = 0 whatever row its tile slot holds
+        if (g == 0 && q < npad) {
+            const long wi = ((long)b * H + h) * npad + q;
+            delta[wi] = ok ? -dsum : 0.f;
+            delta[(long)gridDim.z * H * npad + wi] = ok ? -lq[qt] : -1e30f;
+        }
     }
     f32x4 dq[4][2];
 #pragma unroll
@@ -975,13 +982,16 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8 || IsX3<T>::v) ? 1 : 2) void attn
     tile_src_init<T, NT>(dsrc, dob, ldo_b, N);
     tile_load<T, NT>(rq, qsrc, pq0(0));
     tile_load<T, NT>(rd, dsrc, pq0(0));
-    float rl = 0.f, rdl = 0.f;   // next tile's lse / delta rows, prefetched with the tile
-    // queries >= N: lse = +1e30 makes p = 2^(0 - 1e30) = 0 (their Q / dO rows are staged as zeros) — no mask in the loop
-    const float LSE_PAD = 1e30f;
+    float rl = 0.f, rdl = 0.f;   // next tile's -lse (log2 units) / -delta rows, prefetched with the tile
+    // the dQ kernel left them in that form in `delta` = ws [2][B * H][npad] (ws[0] = -delta, ws[1] = -lse2), padded to whole tiles: queries >= N have
+    // -lse2 = -1e30, i.e. p = 2^(s - 1e30) = 0 (their Q / dO rows are staged as zeros) — no mask in the loop.  (`lse` itself is not read here any more.)
+    const int npad = (N + 63) / 64 * 64;
+    const float* wsd = delta + ((long)b * H + h) * npad;
+    const float* wsl = delta + (long)gridDim.z * H * npad + ((long)b * H + h) * npad;
     if (threadIdx.x < 64) {
         const int q = pq0(0) + threadIdx.x;
-        rl = q < N ? lse[((long)b * H + h) * N + q] : LSE_PAD;
-        rdl = q < N ? delta[((long)b * H + h) * N + q] : 0.f;
+        rl = wsl[q];
+        rdl = wsd[q];
     }
     for (int t = 0; t < ntile; ++t) {
         __syncthreads();
@@ -991,11 +1001,11 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8 || IsX3<T>::v) ? 1 : 2) void attn
             tile_load<T, NT>(rq, qsrc, pq0(t + 1));
             tile_load<T, NT>(rd, dsrc, pq0(t + 1));
         }
-        if (threadIdx.x < 64) { sL[threadIdx.x] = -rl * 1.4426950408889634f; sDl[threadIdx.x] = -rdl; }   // negated: accumulator seeds
+        if (threadIdx.x < 64) { sL[threadIdx.x] = rl; sDl[threadIdx.x] = rdl; }   // (already negated: accumulator seeds)
         if (t + 1 < ntile && threadIdx.x < 64) {
             const int q = pq0(t + 1) + threadIdx.x;
-            rl = q < N ? lse[((long)b * H + h) * N + q] : LSE_PAD;
-            rdl = q < N ? delta[((long)b * H + h) * N + q] : 0.f;
+            rl = wsl[q];
+            rdl = wsd[q];
         }
         __syncthreads();
         if (!wave_live) continue;   // (this wave's 32 keys are all past N: it only helps staging the tiles — 5 of the 48 waves of an
@@ -1044,6 +1054,226 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8 || IsX3<T>::v) ? 1 : 2) void attn
                 }
             }
         }
+    }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        const int key = key0 + kt * 16 + c;
+        if (key >= N) continue;
+        // column block of dK / dV inside the packed gradient row: (dq, dk, dv) or, with vfirst, (dq, dv, dk)
+        T* rk = dqkv + ((long)b * N + key) * 3 * H * HD + (long)((vfirst ? 2 : 1) * H + h) * HD;
+        T* rv = dqkv + ((long)b * N + key) * 3 * H * HD + (long)((vfirst ? 1 : 2) * H + h) * HD;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            if (DK) store4<T>(rk + dt * 16 + g * 4, dk[dt][kt] * scale);
+            store4<T>(rv + dt * 16 + g * 4, dv[dt][kt]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ backward: dK, dV on an LDS-DMA ring (round 6)
+// attn_bwd_dkv_kernel<T, 4> spends 27 % of its time staging the Q / dO tiles (anatomy, profiles/r06_probe_attn_tn.txt: buffer loads into registers ->
+// ds_write -> two block barriers per 64-query tile; 255 of 935 us at 64 x 12 x 1370).  Here the tiles — and the tile's 64 + 64 row constants, which
+// the dQ kernel leaves negated and in log2 units in ws — travel global -> LDS by LDS-DMA into a THREE-slot ring, two tiles ahead, as in
+// attn_fwd_dma_kernel: no staging registers, no ds_write, no address arithmetic on the vector ALU for full tiles, ONE counted vmcnt wait and ONE barrier
+// per tile.  Same mathematics, register layouts and swizzle (chunk ^ AT<T>::sw(row), applied on the SOURCE address) as the register-staged kernel; every
+// LDS read of the ring is inline asm (a ds_read the compiler can see gets an `s_waitcnt vmcnt(0)` to the LDS-DMA in flight in front of it).
+// Query rows past N are clamped to row N - 1 in the partial last tile: their -lse2 is -1e30 (ws pads), so p = 0 and dS = 0 * finite = 0.
+#define ADS_R128V(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+#define ADS_TR64V(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+template <typename T, bool DK = true>      // bf16 | f16; four waves = 128 keys per block
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_dma_kernel(const T* qkv, const T* dout, const float* ws, T* dqkv, int N, int H, float scale, int vfirst) {
+    typedef typename Mma<T>::Frag Frag;
+    constexpr int TILE = 64 * 128;                    // one Q or dO tile: 64 rows x 128 B
+    constexpr int SLOT = 2 * TILE + 512;              // Q tile | dO tile | -lse2 [64] | -delta [64]
+    __shared__ __attribute__((aligned(16))) char smem[3 * SLOT];
+    const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int xb_, h, b;
+    attn_block_coords(xb_, h, b);
+    const int key0 = xb_ * 128 + wave * 32;
+    const long ld_b = (long)3 * H * HD * 2;
+    const char* base = (const char*)qkv + (long)b * N * ld_b;
+    const char* qb = base + (long)(0 * H + h) * HD * 2;
+    const char* kb = base + (long)(1 * H + h) * HD * 2;
+    const char* vb = base + (long)(2 * H + h) * HD * 2;
+    const long ldo_b = (long)H * HD * 2;
+    const char* dob = (const char*)dout + (long)b * N * ldo_b + (long)h * HD * 2;
+    const int npad = (N + 63) / 64 * 64;
+    const float* wsd = ws + ((long)b * H + h) * npad;                                         // -delta
+    const float* wsl = ws + (long)gridDim.z * H * npad + ((long)b * H + h) * npad;            // -lse (log2 units)
+
+    Frag kf[2][2], vf[2][2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        const int key = key0 + kt * 16 + c;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            Frag z = {};
+            kf[kt][u] = key < N ? frag_scale<T>(load_nfrag<T>(kb + (long)key * ld_b, u, g), scale * 1.4426950408889634f) : z;   // exp2 domain
+            vf[kt][u] = key < N ? load_nfrag<T>(vb + (long)key * ld_b, u, g) : z;
+        }
+    }
+    const bool wave_live = key0 < N;
+    f32x4 dk[4][2], dv[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { dk[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    // DMA: wave w moves pieces 2w, 2w + 1 (8 rows each) of the Q tile and of the dO tile, and one 256-byte piece of row constants (even waves -lse2,
+    // odd waves -delta; waves 2 / 3 repeat what 0 / 1 send — the same bytes to the same place — so that every wave counts FIVE operations per tile)
+    const int prow = lane >> 3, pchunk = lane & 7;
+    const char* qp[2];
+    const char* dp_[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 2 + i) * 8 + prow;
+        qp[i] = qb + (long)row * ld_b + ((pchunk ^ AT<T>::sw(row)) * 16);
+        dp_[i] = dob + (long)row * ldo_b + ((pchunk ^ AT<T>::sw(row)) * 16);
+    }
+    const float* cp = ((wave & 1) ? wsd : wsl) + lane;
+    const int coff = 2 * TILE + (wave & 1) * 256;
+    auto issue = [&](int q0t, int slot) {
+        char* sb = smem + slot * SLOT;
+        if (q0t + 64 <= N) {
+            const unsigned long tq = (unsigned)q0t * (unsigned)ld_b, td = (unsigned)q0t * (unsigned)ldo_b;     // (an image's rows span < 2^31 bytes)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qp[i] + tq),
+                                                 (__attribute__((address_space(3))) void*)(sb + (wave * 2 + i) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dp_[i] + td),
+                                                 (__attribute__((address_space(3))) void*)(sb + TILE + (wave * 2 + i) * 1024), 16, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = (wave * 2 + i) * 8 + prow;
+                const long r = min(q0t + row, N - 1);
+                const int sw16 = (pchunk ^ AT<T>::sw(row)) * 16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qb + r * ld_b + sw16),
+                                                 (__attribute__((address_space(3))) void*)(sb + (wave * 2 + i) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dob + r * ldo_b + sw16),
+                                                 (__attribute__((address_space(3))) void*)(sb + TILE + (wave * 2 + i) * 1024), 16, 0, 0);
+            }
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cp + q0t),
+                                         (__attribute__((address_space(3))) void*)(sb + coff), 4, 0, 0);
+    };
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)smem;
+    // natural fragment (qt, u): row qt * 16 + c, logical chunk 4u + g (row qt * 16 + c has the swizzle of row c)
+    const int swn = AT<T>::sw(c);
+    const unsigned na0 = c * 128 + ((0 + g) ^ swn) * 16, na1 = c * 128 + ((4 + g) ^ swn) * 16;
+    // transposed fragment (dt, u): rows 32u + 4g + q (+16), logical chunk 2dt + (p >> 1), 8-byte half p & 1
+    const int tq_ = c >> 2, tp = c & 3, swt = AT<T>::sw(4 * g + tq_);
+    unsigned ta[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) ta[dt] = (4 * g + tq_) * 128 + (((2 * dt + (tp >> 1)) ^ swt) * 16) + 8 * (tp & 1);
+    const unsigned ca = 2 * TILE + g * 16;            // the four row constants 16 qt + 4g + r of this lane's C rows: one b128 at +64 qt
+
+    const int ntile = (N + 63) / 64;
+    issue(0, 0);
+    if (ntile > 1) issue(64, 1);
+    int slot = 0;
+    for (int t = 0; t < ntile; ++t) {
+        if (t + 1 < ntile) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");   // tile t landed; tile t + 1 may still fly
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();            // everyone's pieces of tile t landed; everyone is done with tile t - 1's slot
+        asm volatile("" ::: "memory");
+        if (t + 2 < ntile) issue((t + 2) * 64, slot == 0 ? 2 : slot - 1);
+        const unsigned sbase = lds0 + slot * SLOT;
+        slot = slot == 2 ? 0 : slot + 1;
+        if (!wave_live) continue;   // (this wave's 32 keys are all past N: it only moves its DMA pieces)
+        // ---- the tile, software-pipelined by hand over the LDS reads (inline asm reads are invisible to the scheduler; at most 14 are outstanding:
+        // lgkmcnt counts to 15).  RA(qt): the natural fragments + row constants of query tile qt; CA(qt): S / dP MFMAs + exp for it; RT(u, dt): the
+        // transposed dO / Q fragments of head-dim tile dt for the 32 queries of half u; MB(u, dt): its four dV / dK MFMAs.  Order:
+        //   RA0 RA1 | CA0 | RA2 | CA1 | RT00 RT01 | MB00 | RT02 | MB01 | RT03 | MB02 | RA3 | MB03 | CA2 | CA3 | RT10 RT11 | MB10 | RT12 | MB11 | RT13 | MB12 | MB13
+        const unsigned qa0 = sbase + na0, qa1 = sbase + na1, da0 = sbase + TILE + na0, da1 = sbase + TILE + na1, cb = sbase + ca;
+        const unsigned dtb = sbase + TILE, qtb = sbase;
+        f32x4 aq0[2], aq1[2], ad0[2], ad1[2], anl[2], and_[2];      // two register sets for RA
+        a_u32x2 tdr[2][2], tqr[2][2];                               // two register sets for RT: [set][row half]
+        f32x4 pp[2][2], dsv[2][2];                                   // [key tile][query tile & 1]: two query tiles at a time
+        Frag pf[2], sf[2];
+        constexpr int NRA = DK ? 6 : 3, NRT = DK ? 4 : 2;            // LDS reads per RA / RT
+#define DKV_RA(qt, S)                                                                                                                   \
+        ADS_R128V(aq0[S], qa0, qt * 2048); ADS_R128V(aq1[S], qa1, qt * 2048); ADS_R128V(anl[S], cb, qt * 64);                           \
+        if (DK) { ADS_R128V(ad0[S], da0, qt * 2048); ADS_R128V(ad1[S], da1, qt * 2048); ADS_R128V(and_[S], cb, 256 + qt * 64); }
+#define DKV_WAIT_A(n, S)                                                                                                                \
+        if (DK) asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(aq0[S]), "+v"(aq1[S]), "+v"(ad0[S]), "+v"(ad1[S]), "+v"(anl[S]), "+v"(and_[S]) : "i"(n)); \
+        else asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(aq0[S]), "+v"(aq1[S]), "+v"(anl[S]) : "i"(n));
+#define DKV_CA(qt, S)                                                                                                                   \
+        {                                                                                                                               \
+            const Frag qf0 = __builtin_bit_cast(Frag, aq0[S]), qf1 = __builtin_bit_cast(Frag, aq1[S]);                                  \
+            _Pragma("unroll") for (int kt = 0; kt < 2; ++kt) {                                                                          \
+                f32x4 sacc = anl[S], dpa = anl[S];                                                                                      \
+                sacc = Mma<T>::mma(qf0, kf[kt][0], sacc);    /* rows: queries, cols: keys */                                            \
+                sacc = Mma<T>::mma(qf1, kf[kt][1], sacc);                                                                               \
+                if (DK) {                                                                                                               \
+                    dpa = and_[S];                                                                                                      \
+                    dpa = Mma<T>::mma(__builtin_bit_cast(Frag, ad0[S]), vf[kt][0], dpa);                                                \
+                    dpa = Mma<T>::mma(__builtin_bit_cast(Frag, ad1[S]), vf[kt][1], dpa);                                                \
+                }                                                                                                                       \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                                         \
+                    const float pv = fast_exp2(sacc[r]);                                                                                \
+                    pp[kt][qt & 1][r] = pv;                                                                                             \
+                    if (DK) dsv[kt][qt & 1][r] = pv * dpa[r];          /* the 1/sqrt(d) factor is applied once, to dK */                \
+                }                                                                                                                       \
+            }                                                                                                                           \
+        }
+        // the B fragments of half u from the two query tiles just computed (contraction index = 16 (qt & 1) + 4g + r within the half)
+#define DKV_FRAGS()                                                                                                                     \
+        _Pragma("unroll") for (int kt = 0; kt < 2; ++kt) {                                                                              \
+            const f32x4 t4[4] = {pp[kt][0], pp[kt][1], pp[kt][0], pp[kt][1]};                                                           \
+            pf[kt] = acc_to_bfrag<T>(t4, 0);                                                                                            \
+            if (DK) { const f32x4 d4[4] = {dsv[kt][0], dsv[kt][1], dsv[kt][0], dsv[kt][1]}; sf[kt] = acc_to_bfrag<T>(d4, 0); }          \
+        }
+#define DKV_RT(u, dt, S)                                                                                                                \
+        ADS_TR64V(tdr[S][0], dtb + ta[dt], u * 4096); ADS_TR64V(tdr[S][1], dtb + ta[dt], u * 4096 + 2048);                              \
+        if (DK) { ADS_TR64V(tqr[S][0], qtb + ta[dt], u * 4096); ADS_TR64V(tqr[S][1], qtb + ta[dt], u * 4096 + 2048); }
+#define DKV_WAIT_T(n, S)                                                                                                                \
+        if (DK) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(tdr[S][0]), "+v"(tdr[S][1]), "+v"(tqr[S][0]), "+v"(tqr[S][1]) : "i"(n));    \
+        else asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(tdr[S][0]), "+v"(tdr[S][1]) : "i"(n));
+#define DKV_MB(dt, S)                                                                                                                   \
+        {                                                                                                                               \
+            typedef __attribute__((ext_vector_type(4))) unsigned a_u32x4;                                                               \
+            const a_u32x4 zd = {tdr[S][0][0], tdr[S][0][1], tdr[S][1][0], tdr[S][1][1]};                                                \
+            const Frag dot = __builtin_bit_cast(Frag, zd);                                                                              \
+            _Pragma("unroll") for (int kt = 0; kt < 2; ++kt) dv[dt][kt] = Mma<T>::mma(dot, pf[kt], dv[dt][kt]);                         \
+            if (DK) {                                                                                                                   \
+                const a_u32x4 zq = {tqr[S][0][0], tqr[S][0][1], tqr[S][1][0], tqr[S][1][1]};                                            \
+                const Frag qt_ = __builtin_bit_cast(Frag, zq);                                                                          \
+                _Pragma("unroll") for (int kt = 0; kt < 2; ++kt) dk[dt][kt] = Mma<T>::mma(qt_, sf[kt], dk[dt][kt]);                     \
+            }                                                                                                                           \
+        }
+        DKV_RA(0, 0) DKV_RA(1, 1)
+        DKV_WAIT_A(NRA, 0) DKV_CA(0, 0)
+        DKV_RA(2, 0)
+        DKV_WAIT_A(NRA, 1) DKV_CA(1, 1)
+        DKV_FRAGS()
+        DKV_RT(0, 0, 0) DKV_RT(0, 1, 1)
+        DKV_WAIT_T(NRT, 0) DKV_MB(0, 0)            // (RA2 is older than the RTs: it has landed too)
+        DKV_RT(0, 2, 0)
+        DKV_WAIT_T(NRT, 1) DKV_MB(1, 1)
+        DKV_RT(0, 3, 1)
+        DKV_WAIT_T(NRT, 0) DKV_MB(2, 0)
+        DKV_RA(3, 1)
+        DKV_WAIT_T(NRA, 1) DKV_MB(3, 1)
+        DKV_WAIT_A(NRA, 0) DKV_CA(2, 0)            // (landed long ago: the wait only ties the registers)
+        DKV_WAIT_A(0, 1) DKV_CA(3, 1)
+        DKV_FRAGS()
+        DKV_RT(1, 0, 0) DKV_RT(1, 1, 1)
+        DKV_WAIT_T(NRT, 0) DKV_MB(0, 0)
+        DKV_RT(1, 2, 0)
+        DKV_WAIT_T(NRT, 1) DKV_MB(1, 1)
+        DKV_RT(1, 3, 1)
+        DKV_WAIT_T(NRT, 0) DKV_MB(2, 0)
+        DKV_WAIT_T(0, 1) DKV_MB(3, 1)
+#undef DKV_RA
+#undef DKV_WAIT_A
+#undef DKV_CA
+#undef DKV_FRAGS
+#undef DKV_RT
+#undef DKV_WAIT_T
+#undef DKV_MB
     }
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
@@ -1283,7 +1513,12 @@ static void attn_bwd_launch16(const void* qkv, const void* o, const void* dout, 
         const int dkv_env = gd_knobs().attn_dkv_nw;
         const int tail = N % 256;
         const int dkv_nw = dkv_env ? dkv_env : ((N < 4096 && tail > 0 && tail <= 128) ? 4 : 8);
-        if (no_dk && dkv_nw == 4)
+        const bool dkv_dma = gd_knobs().attn_dkv_dma != 0;      // GD_ATTN_DKV_DMA=0: the register-staged kernels (A/B)
+        if (no_dk && dkv_nw == 4 && dkv_dma)
+            hipLaunchKernelGGL((attn_bwd_dkv_dma_kernel<T, false>), dim3(gd_cdiv(N, 128), H, B), dim3(256), 0, s, (const T*)qkv, (const T*)dout, delta_ws, (T*)dqkv, N, H, scale, grad_order);
+        else if (dkv_nw == 4 && dkv_dma)
+            hipLaunchKernelGGL((attn_bwd_dkv_dma_kernel<T, true>), dim3(gd_cdiv(N, 128), H, B), dim3(256), 0, s, (const T*)qkv, (const T*)dout, delta_ws, (T*)dqkv, N, H, scale, grad_order);
+        else if (no_dk && dkv_nw == 4)
             hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, 4, false>), dim3(gd_cdiv(N, 128), H, B), dim3(256), 0, s, (const T*)qkv, (const T*)dout, lse, delta_ws, (T*)dqkv, N, H, scale, grad_order);
         else if (no_dk)
             hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, 8, false>), dim3(gd_cdiv(N, 256), H, B), dim3(512), 0, s, (const T*)qkv, (const T*)dout, lse, delta_ws, (T*)dqkv, N, H, scale, grad_order);

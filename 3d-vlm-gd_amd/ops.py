@@ -490,7 +490,8 @@ def attention_bwd(qkv, o, dout, lse, B, N, H, vfirst=False, need_dk=True, x3=Fal
     columns are left unwritten (bf16: the dK/dV kernel then runs its dV half only)."""
     _req(dout.is_contiguous() and dout.shape == o.shape and dout.dtype == qkv.dtype, "attention_bwd: bad dout")
     dqkv = torch.empty_like(qkv)
-    delta = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device)
+    npad = (N + 63) // 64 * 64      # workspace: the dQ kernel leaves [-delta | -lse in log2 units] per query for the dK/dV kernel, rows padded to whole 64-query tiles
+    delta = torch.empty(2, B, H, npad, dtype=torch.float32, device=qkv.device)
     rc = lib().gd_attention_bwd(ptr(qkv), ptr(o), ptr(dout), ptr(lse), ptr(dqkv), ptr(delta), B, N, H, 64,
                                 64 ** -0.5, F32X3 if x3 else dtype_code(qkv), (1 if vfirst else 0) | (0 if need_dk else 2), stream())
     check(rc, "gd_attention_bwd")

@@ -69,7 +69,8 @@ int gd_gemm_tn(const void* Y, const void* X, float* G, int M, int N, int K, long
  * (grad_order 0) or (dq, dv, dk) (grad_order 1: the q and v gradients, the only ones the q/v LoRA factors contract, become
  * one contiguous 2*H*64-column block); grad_order bit 1 (values 2, 3): dK is not needed (a block whose input receives no
  * gradient: only the q / v LoRA factors learn there) — its columns are left unwritten and the dK/dV kernel runs the dV half only;
- * delta_ws [B,H,N] f32 scratch. */
+ * delta_ws: f32 scratch of 2 * B * H * Npad floats, Npad = N rounded up to a multiple of 64 (ABI version 3; it was B * H * N): the dQ kernel leaves, per
+ * (image, head) row of Npad queries, [-delta | -lse in log2 units] for the dK/dV kernel (pads: 0 / -1e30). */
 int gd_attention_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, int head_dim, float scale, int dtype,
                      void* stream);
 int gd_attention_bwd(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, float* delta_ws,

@@ -97,7 +97,32 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["tn"]
     if "tn" in which:
         probe_tn()
-    specs = [w for w in which if "=" in w]
+    specs = [w for w in which if "=" in w and not w.startswith("attnbwd:")]
     if specs:
         probe_step(specs)
 
+
+
+def probe_attn_bwd(knob, vals, rounds=3):
+    """attention backward (dQ + dK/dV as the step runs them), 64 x 12 x 1370 and 8 x 12 x 6401 fp16, under a library knob"""
+    for B, N, H in ((64, 1370, 12), (8, 6401, 12)):
+        qkv = torch.randn(B * N, 3 * H * 64, device="cuda").half()
+        dout = (torch.randn(B * N, H * 64, device="cuda") * 0.1).half()
+        o, lse = ops.attention_fwd(qkv, B, N, H)
+        res, outs = {v: [] for v in vals}, {}
+        for _ in range(rounds):
+            for v in vals:
+                lib().gd_debug_set(knob.encode(), v)
+                res[v].append(timeit(lambda: ops.attention_bwd(qkv, o, dout, lse, B, N, H, vfirst=True), warm=3, it=15))
+                outs[v] = ops.attention_bwd(qkv, o, dout, lse, B, N, H, vfirst=True)
+        lib().gd_debug_set(knob.encode(), vals[-1])
+        d = float((outs[vals[0]].float() - outs[vals[-1]].float()).abs().max()) / float(outs[vals[0]].float().abs().max())
+        print(f"attn bwd {B} x {H} x {N} fp16, {knob}: " + " | ".join(f"{v}: {min(r) * 1e6:7.1f} us (all {[round(x * 1e6, 1) for x in r]})" for v, r in res.items())
+              + f"   max |difference| / max |dqkv| between {vals[0]} and {vals[-1]}: {d:.2e}", flush=True)
+
+
+if __name__ == "__main__":
+    for w in sys.argv[1:]:
+        if w.startswith("attnbwd:"):
+            k, vs = w[8:].split("=")
+            probe_attn_bwd(k, [int(x) for x in vs.split(",")])
