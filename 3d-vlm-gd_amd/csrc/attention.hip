@@ -929,6 +929,201 @@ __global__ __launch_bounds__(256, IsX3<T>::v ? 1 : 2) void attn_bwd_dq_kernel(co
     }
 }
 
+// ------------------------------------------------------------------------------------------ backward: dQ on an LDS-DMA ring (round 6)
+// attn_bwd_dq_kernel with the K / V tiles on the forward's three-slot LDS-DMA ring (two tiles ahead, one counted vmcnt wait + one barrier per tile, no
+// staging registers) and every LDS read inline asm, pipelined by hand under the MFMAs — the dK/dV kernel's recipe (attn_bwd_dkv_dma_kernel, below).
+// Key rows past N are clamped to row N - 1 in the partial last tile (the register-staged kernel stages zeros): their dS is set to zero there, as before.
+#define ADS_R128V(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+#define ADS_TR64V(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+template <typename T>      // bf16 | f16
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_dma_kernel(const T* qkv, const T* o, const T* dout, const float* lse, float* delta, T* dqkv, int N, int H,
+                                                                 float scale) {
+    typedef typename Mma<T>::Frag Frag;
+    constexpr int TILE = 64 * 128;
+    __shared__ __attribute__((aligned(16))) char smem[6 * TILE];      // K slots 0..2 | V slots 0..2
+    const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int xb_, h, b;
+    attn_block_coords(xb_, h, b);
+    const int q0 = xb_ * 128 + wave * 32;
+    const int npad = (N + 63) / 64 * 64;
+    const long ld_b = (long)3 * H * HD * 2;
+    const char* base = (const char*)qkv + (long)b * N * ld_b;
+    const char* qb = base + (long)(0 * H + h) * HD * 2;
+    const char* kb = base + (long)(1 * H + h) * HD * 2;
+    const char* vb = base + (long)(2 * H + h) * HD * 2;
+    const long ldo_b = (long)H * HD * 2;
+    const char* dob = (const char*)dout + (long)b * N * ldo_b + (long)h * HD * 2;
+    const char* ob = (const char*)o + (long)b * N * ldo_b + (long)h * HD * 2;
+
+    // delta = rowsum(dO * O), from the dO fragments this wave loads anyway; left for the dK/dV kernel with -lse2 (see attn_bwd_dq_kernel)
+    Frag qf[2][2], dof[2][2];
+    f32x4 nlq[2], ndl[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int q = q0 + qt * 16 + c;
+        const bool ok = q < N;
+        float dsum = 0.f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            Frag z = {};
+            qf[qt][u] = ok ? frag_scale<T>(load_nfrag<T>(qb + (long)q * ld_b, u, g), scale * 1.4426950408889634f) : z;   // exp2 domain
+            dof[qt][u] = ok ? load_nfrag<T>(dob + (long)q * ldo_b, u, g) : z;
+            const Frag of_ = ok ? load_nfrag<T>(ob + (long)q * ldo_b, u, g) : z;
+            dsum += frag_dot(dof[qt][u], of_);
+        }
+        dsum += __shfl_xor(dsum, 16, 64);
+        dsum += __shfl_xor(dsum, 32, 64);
+        const float lq = ok ? lse[((long)b * H + h) * N + q] * 1.4426950408889634f : 0.f;   // log2 units
+        if (g == 0 && q < npad) {
+            const long wi = ((long)b * H + h) * npad + q;
+            delta[wi] = ok ? -dsum : 0.f;
+            delta[(long)gridDim.z * H * npad + wi] = ok ? -lq : -1e30f;
+        }
+        nlq[qt] = f32x4{-lq, -lq, -lq, -lq};
+        ndl[qt] = f32x4{-dsum, -dsum, -dsum, -dsum};
+    }
+    f32x4 dq[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) dq[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // DMA: wave w moves pieces 2w, 2w + 1 (8 rows each) of the K tile and of the V tile: four operations per wave and tile
+    const int prow = lane >> 3, pchunk = lane & 7;
+    const char* kp[2];
+    const char* vp_[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 2 + i) * 8 + prow;
+        const long off = (long)row * ld_b + ((pchunk ^ AT<T>::sw(row)) * 16);
+        kp[i] = kb + off;
+        vp_[i] = vb + off;
+    }
+    auto issue = [&](int k0, int slot) {
+        if (k0 + 64 <= N) {
+            const unsigned long t0 = (unsigned)k0 * (unsigned)ld_b;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kp[i] + t0),
+                                                 (__attribute__((address_space(3))) void*)(smem + slot * TILE + (wave * 2 + i) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vp_[i] + t0),
+                                                 (__attribute__((address_space(3))) void*)(smem + (3 + slot) * TILE + (wave * 2 + i) * 1024), 16, 0, 0);
+            }
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (wave * 2 + i) * 8 + prow;
+            const long off = (long)min(k0 + row, N - 1) * ld_b + ((pchunk ^ AT<T>::sw(row)) * 16);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kb + off),
+                                             (__attribute__((address_space(3))) void*)(smem + slot * TILE + (wave * 2 + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vb + off),
+                                             (__attribute__((address_space(3))) void*)(smem + (3 + slot) * TILE + (wave * 2 + i) * 1024), 16, 0, 0);
+        }
+    };
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)smem;
+    const int swn = AT<T>::sw(c);
+    const unsigned na0 = c * 128 + ((0 + g) ^ swn) * 16, na1 = c * 128 + ((4 + g) ^ swn) * 16;      // natural fragment (kt, u): row 16 kt + c, chunk 4u + g
+    const int tq_ = c >> 2, tp = c & 3, swt = AT<T>::sw(4 * g + tq_);
+    unsigned ta[4];                                                                                  // transposed fragment (dt, u): rows 32u + 4g + q (+16), chunk 2dt + (p >> 1)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) ta[dt] = (4 * g + tq_) * 128 + (((2 * dt + (tp >> 1)) ^ swt) * 16) + 8 * (tp & 1);
+
+    const int ntile = (N + 63) / 64;
+    const bool live = q0 < N;      // a wave whose 32 queries are all past N only moves its DMA pieces
+    issue(0, 0);
+    if (ntile > 1) issue(64, 1);
+    int slot = 0;
+    auto key_tile = [&](int t, auto tail_tag) __attribute__((always_inline)) {
+        constexpr bool tail = decltype(tail_tag)::value;
+        if (t + 1 < ntile) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // tile t landed; tile t + 1 may still fly
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + 2 < ntile) issue((t + 2) * 64, slot == 0 ? 2 : slot - 1);
+        const unsigned kbase = lds0 + slot * TILE, vbase = lds0 + (3 + slot) * TILE;
+        slot = slot == 2 ? 0 : slot + 1;
+        if (!live) return;
+        // RK(kt): the K and V natural fragments of key tile kt; CK(kt): S / dP MFMAs + exp for it (both query tiles); RT(u, dt): the transposed K fragments
+        // of head-dim tile dt for the 32 keys of half u; MQ(u, dt): its two dQ MFMAs.  Order (at most 12 reads outstanding):
+        //   RK0 RK1 | CK0 | RK2 | CK1 | RT00 RT01 | MQ00 | RT02 | MQ01 | RT03 | MQ02 | RK3 | MQ03 | CK2 | CK3 | RT10 RT11 | MQ10 | RT12 | MQ11 | RT13 | MQ12 | MQ13
+        const unsigned ka0 = kbase + na0, ka1 = kbase + na1, va0 = vbase + na0, va1 = vbase + na1;
+        f32x4 rk0[2], rk1[2], rv0[2], rv1[2];
+        a_u32x2 tr_[2][2];
+        f32x4 ds[2][2];      // [query tile][key tile & 1]
+        Frag df[2];
+#define DQ_RK(kt, S) ADS_R128V(rk0[S], ka0, kt * 2048); ADS_R128V(rk1[S], ka1, kt * 2048); ADS_R128V(rv0[S], va0, kt * 2048); ADS_R128V(rv1[S], va1, kt * 2048);
+#define DQ_WAIT_K(n, S) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(rk0[S]), "+v"(rk1[S]), "+v"(rv0[S]), "+v"(rv1[S]) : "i"(n));
+#define DQ_CK(kt, S)                                                                                                                    \
+        _Pragma("unroll") for (int qt = 0; qt < 2; ++qt) {                                                                              \
+            f32x4 sacc = nlq[qt], dpa = ndl[qt];                                                                                        \
+            sacc = Mma<T>::mma(__builtin_bit_cast(Frag, rk0[S]), qf[qt][0], sacc);                                                      \
+            dpa = Mma<T>::mma(__builtin_bit_cast(Frag, rv0[S]), dof[qt][0], dpa);                                                       \
+            sacc = Mma<T>::mma(__builtin_bit_cast(Frag, rk1[S]), qf[qt][1], sacc);                                                      \
+            dpa = Mma<T>::mma(__builtin_bit_cast(Frag, rv1[S]), dof[qt][1], dpa);                                                       \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                                             \
+                ds[qt][kt & 1][r] = fast_exp2(sacc[r]) * dpa[r];       /* the 1/sqrt(d) factor is applied once, to dQ */                \
+                if (tail && t * 64 + kt * 16 + g * 4 + r >= N) ds[qt][kt & 1][r] = 0.f;                                                 \
+            }                                                                                                                           \
+        }
+#define DQ_FRAGS()                                                                                                                      \
+        _Pragma("unroll") for (int qt = 0; qt < 2; ++qt) { const f32x4 t4[4] = {ds[qt][0], ds[qt][1], ds[qt][0], ds[qt][1]}; df[qt] = acc_to_bfrag<T>(t4, 0); }
+#define DQ_RT(u, dt, S) ADS_TR64V(tr_[S][0], kbase + ta[dt], u * 4096); ADS_TR64V(tr_[S][1], kbase + ta[dt], u * 4096 + 2048);
+#define DQ_WAIT_T(n, S) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(tr_[S][0]), "+v"(tr_[S][1]) : "i"(n));
+#define DQ_MQ(dt, S)                                                                                                                    \
+        {                                                                                                                               \
+            typedef __attribute__((ext_vector_type(4))) unsigned a_u32x4;                                                               \
+            const a_u32x4 z = {tr_[S][0][0], tr_[S][0][1], tr_[S][1][0], tr_[S][1][1]};                                                 \
+            const Frag kt_ = __builtin_bit_cast(Frag, z);                                                                               \
+            _Pragma("unroll") for (int qt = 0; qt < 2; ++qt) dq[dt][qt] = Mma<T>::mma(kt_, df[qt], dq[dt][qt]);                         \
+        }
+        DQ_RK(0, 0) DQ_RK(1, 1)
+        DQ_WAIT_K(4, 0) DQ_CK(0, 0)
+        DQ_RK(2, 0)
+        DQ_WAIT_K(4, 1) DQ_CK(1, 1)
+        DQ_FRAGS()
+        DQ_RT(0, 0, 0) DQ_RT(0, 1, 1)
+        DQ_WAIT_T(2, 0) DQ_MQ(0, 0)
+        DQ_RT(0, 2, 0)
+        DQ_WAIT_T(2, 1) DQ_MQ(1, 1)
+        DQ_RT(0, 3, 1)
+        DQ_WAIT_T(2, 0) DQ_MQ(2, 0)
+        DQ_RK(3, 1)
+        DQ_WAIT_T(4, 1) DQ_MQ(3, 1)
+        DQ_WAIT_K(4, 0) DQ_CK(2, 0)
+        DQ_WAIT_K(0, 1) DQ_CK(3, 1)
+        DQ_FRAGS()
+        DQ_RT(1, 0, 0) DQ_RT(1, 1, 1)
+        DQ_WAIT_T(2, 0) DQ_MQ(0, 0)
+        DQ_RT(1, 2, 0)
+        DQ_WAIT_T(2, 1) DQ_MQ(1, 1)
+        DQ_RT(1, 3, 1)
+        DQ_WAIT_T(2, 0) DQ_MQ(2, 0)
+        DQ_WAIT_T(0, 1) DQ_MQ(3, 1)
+#undef DQ_RK
+#undef DQ_WAIT_K
+#undef DQ_CK
+#undef DQ_FRAGS
+#undef DQ_RT
+#undef DQ_WAIT_T
+#undef DQ_MQ
+    };
+    {
+        int t = 0;
+        for (; (t + 1) * 64 <= N; ++t) key_tile(t, std::false_type{});
+        if (t * 64 < N) key_tile(t, std::true_type{});
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int q = q0 + qt * 16 + c;
+        if (q >= N) continue;
+        T* row = dqkv + ((long)b * N + q) * 3 * H * HD + (long)(0 * H + h) * HD;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) store4<T>(row + dt * 16 + g * 4, dq[dt][qt] * scale);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ backward: dK, dV
 // DK = false: dV only (the first trainable block of the student: nothing below it learns, so dK — and with it dP, dS and the Q^T
 // operand — is never used; half of the kernel's MFMAs)
@@ -1078,8 +1273,6 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8 || IsX3<T>::v) ? 1 : 2) void attn
 // per tile.  Same mathematics, register layouts and swizzle (chunk ^ AT<T>::sw(row), applied on the SOURCE address) as the register-staged kernel; every
 // LDS read of the ring is inline asm (a ds_read the compiler can see gets an `s_waitcnt vmcnt(0)` to the LDS-DMA in flight in front of it).
 // Query rows past N are clamped to row N - 1 in the partial last tile: their -lse2 is -1e30 (ws pads), so p = 0 and dS = 0 * finite = 0.
-#define ADS_R128V(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
-#define ADS_TR64V(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
 template <typename T, bool DK = true>      // bf16 | f16; four waves = 128 keys per block
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_dma_kernel(const T* qkv, const T* dout, const float* ws, T* dqkv, int N, int H, float scale, int vfirst) {
     typedef typename Mma<T>::Frag Frag;
@@ -1505,6 +1698,8 @@ template <typename T>      // bf16 | f16
 static void attn_bwd_launch16(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, float* delta_ws, int B, int N, int H,
                               float scale, int grad_order, bool no_dk, hipStream_t s) {
     dim3 grid(gd_cdiv(N, 128), H, B);
+        if (gd_knobs().attn_dq_dma) hipLaunchKernelGGL(attn_bwd_dq_dma_kernel<T>, grid, dim3(256), 0, s, (const T*)qkv, (const T*)o, (const T*)dout, lse, delta_ws, (T*)dqkv, N, H, scale);
+        else
         hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, grid, dim3(256), 0, s, (const T*)qkv, (const T*)o, (const T*)dout, lse, delta_ws, (T*)dqkv, N, H, scale);
         // 128-key blocks of four waves (two blocks per CU, independent barriers, Q / dO tiles staged twice as often) when the last
         // 256-key block would be less than half full: N = 1370 pads to 1408 keys instead of 1536 (2.7 % instead of 10.8 %):

@@ -24,6 +24,7 @@ static const KnobDef KNOBS[] = {
     {"gemm_anat", "GD_GEMM_ANAT", &GdKnobs::gemm_anat, 0},                {"gemm_batch_big_m", "GD_GEMM_BATCH_BIG_M", &GdKnobs::gemm_batch_big_m, 384},
     {"gemm_krot", "GD_GEMM_KROT", &GdKnobs::gemm_krot, 1},                {"tn_blocks", "GD_TN_BLOCKS", &GdKnobs::tn_blocks, 0},
     {"attn_dma", "GD_ATTN_DMA", &GdKnobs::attn_dma, 1},                   {"attn_rot", "GD_ATTN_ROT", &GdKnobs::attn_rot, 1},
+    {"attn_dq_dma", "GD_ATTN_DQ_DMA", &GdKnobs::attn_dq_dma, 1},
     {"attn_dkv_dma", "GD_ATTN_DKV_DMA", &GdKnobs::attn_dkv_dma, 1},
     {"attn_dkv_nw", "GD_ATTN_DKV_NW", &GdKnobs::attn_dkv_nw, 0},          {"cv_mask_skip", "GD_CV_MASK_SKIP", &GdKnobs::cv_mask_skip, 1},
     {"cv_persist", "GD_CV_PERSIST", &GdKnobs::cv_persist, 1},             {"cv_dbg", "GD_CV_DBG", &GdKnobs::cv_dbg, 0},

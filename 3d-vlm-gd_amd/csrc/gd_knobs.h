@@ -16,6 +16,7 @@ struct GdKnobs {
     int tn_blocks;         // GD_TN_BLOCKS         target block count of the tile TN GEMM (0 auto)
     int attn_dma;          // GD_ATTN_DMA          1: LDS-DMA attention forward; 0: register-staged
     int attn_rot;          // GD_ATTN_ROT          1: forward x-block xb starts at key tile 2 xb
+    int attn_dq_dma;       // GD_ATTN_DQ_DMA       1: dQ (16-bit operands) on the LDS-DMA ring (round 6); 0: register-staged tiles
     int attn_dkv_dma;      // GD_ATTN_DKV_DMA      1: dK/dV (four-wave form, 16-bit operands) on the LDS-DMA ring (round 6); 0: register-staged tiles
     int attn_dkv_nw;       // GD_ATTN_DKV_NW       0 auto | 4 | 8 waves per dK/dV block
     int cv_mask_skip;      // GD_CV_MASK_SKIP      1: masked teacher rows are not fetched

@@ -298,14 +298,15 @@ def main():
             out["roofline"] = gemm_roofline(prof, args.dtype, dt, args.steps)
             # memory-side bytes per launch: PMC counters cannot be read from inside the timed run, so this REPLAYS the committed
             # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE measurement of this same command (profiles/README.md), default workload only
-            pmc = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_gemm_traffic_{args.dtype}.json") for r in (5, 4, 3)) if os.path.exists(q)), None)
+            pmc = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_gemm_traffic_{args.dtype}.json") for r in (6, 5, 4, 3)) if os.path.exists(q)), None)
             if (pmc is not None and backbone == "vit_base" and P == 32
                     and args.geometry == "shared" and variant == "mast3r"):
                 with open(pmc) as fh:
                     t = json.load(fh)
                 out["roofline"]["traffic"] = round(t["hbm_side_mb_per_launch"] * 1e6)
                 out["roofline"]["traffic_replayed_from"] = (f"profiles/{os.path.basename(pmc)} (2 x FETCH_SIZE + WRITE_SIZE per "
-                                                            "persistent-kernel launch, separate --pmc passes; NOT measured in this run)")
+                                                            "persistent-kernel launch, separate --pmc passes; NOT measured in this run"
+                                                            + (f"; taken on commit {t['commit']}, libgd_hip.so sha256 {t['libgd_hip_sha256_16']}" if "commit" in t else "") + ")")
                 if out["roofline"].get("algorithmic_bytes_per_launch"):
                     out["roofline"]["traffic_over_algorithmic"] = round(out["roofline"]["traffic"] / out["roofline"]["algorithmic_bytes_per_launch"], 3)
             if args.gemm_shapes:
@@ -419,7 +420,8 @@ def cost_volume_roofline(job, args, dev, variant):
             ops.cost_volume_kl(f1, f2, b["cost_1"], b["cost_2"], ma, mb, variant, **kw).sum().backward()
         return ops.time_on_stream(fb if backward else fwd, 2, 5)
 
-    def replay(name):    # HBM traffic per launch: PMC counters cannot be read inside the run; committed passes of this configuration
+    def replay(name):    # HBM traffic per launch: PMC counters cannot be read inside the run; committed passes of this configuration (the newest round's file)
+        name = next((n for n in (name.replace("r05_", f"r{r:02d}_") for r in (6, 5)) if os.path.exists(os.path.join(ROOT, "profiles", n))), name)
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path) and (P, hw, D) == (32, 1369, 768) and es == 2:      # (one kernel template on the two 16-bit types: same traffic)
             with open(path) as fh:
