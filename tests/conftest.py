@@ -12,6 +12,12 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# The CPU oracle is where the GPU suite's time goes.  torch defaults to one thread per core; on the GPU box (128 cores, 2 sockets) its CPU ops stop
+# scaling — and start tripping over each other — long before that: bench.py's cpu_baseline runs the same oracle at 1.9 s per pair on 32 threads, the
+# suite measured ~12 s per pair at the default.  Same cap here.
+if (os.cpu_count() or 1) > 32:
+    torch.set_num_threads(32)
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
