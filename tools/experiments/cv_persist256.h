@@ -62,7 +62,7 @@ __device__ __forceinline__ f32x2 cv256_tab(unsigned addr) {
 // compile-time index loop (array indices and instruction offsets are constants when the IR is built)
 template <typename F, int... I>
 __device__ __forceinline__ void cv_static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
-template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) { cv_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+template <int N, typename F> __device__ __forceinline__ void cv_static_for(F&& f) { cv_static_for_impl(f, std::make_integer_sequence<int, N>{}); }      // (gd_common.h has a static_for of its own since round 4)
 
 template <typename T>
 __global__ __launch_bounds__(512) void cv_fwd_p256_kernel(Cv256Params p) {
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(512) void cv_fwd_p256_kernel(Cv256Params p) {
         // accumulator registers).  Pass 1: the exponentials (both directions' Z) and direction 1; pass 2: direction 2.
         float inv2[4], zc[4];
         float fnic = 0.f;
-        static_for<4>([&](auto JB) __attribute__((always_inline)) {
+        cv_static_for<4>([&](auto JB) __attribute__((always_inline)) {
             constexpr int jb = decltype(JB)::value;
             const f32x2 v = cv256_tab<8 * jb>(tcol);
             inv2[jb] = v[0] * 1.4426950408889634f;                  // log2(e) folded into the column scale
@@ -211,14 +211,14 @@ __global__ __launch_bounds__(512) void cv_fwd_p256_kernel(Cv256Params p) {
             const bool keep = cv256_tab<8 * (16 * i + r)>(trow)[1] != 0.f;
             tA[(4 * i + r) % (4 * DA)] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1, keep ? c1off + (16 * i + r) * ldt * 4 : 0, 0, 0));
         };
-        static_for<DA>([&](auto I) __attribute__((always_inline)) {
-            static_for<4>([&](auto R) __attribute__((always_inline)) { tloadA(I, R); });
+        cv_static_for<DA>([&](auto I) __attribute__((always_inline)) {
+            cv_static_for<4>([&](auto R) __attribute__((always_inline)) { tloadA(I, R); });
         });
         float fnir = 0.f;
         const int prow8 = row0 * 8;
-        static_for<WMT>([&](auto I) __attribute__((always_inline)) {
+        cv_static_for<WMT>([&](auto I) __attribute__((always_inline)) {
             constexpr int i = decltype(I)::value;
-            static_for<4>([&](auto R) __attribute__((always_inline)) {
+            cv_static_for<4>([&](auto R) __attribute__((always_inline)) {
                 constexpr int r = decltype(R)::value;
                 const f32x2 rv = cv256_tab<8 * (16 * i + r)>(trow);
                 const float inv1 = rv[0], ir1 = rv[1];
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(512) void cv_fwd_p256_kernel(Cv256Params p) {
         // unconditionally) younger: `after` = 16 (a lower bound is the safe side)
         float ir2[4], b2[4];
         int c2off[4], c2step[4];                                   // byte offset of T2[col0 + jb][row0] (the map's first line when the column is masked out)
-        static_for<4>([&](auto JB) __attribute__((always_inline)) {
+        cv_static_for<4>([&](auto JB) __attribute__((always_inline)) {
             constexpr int jb = decltype(JB)::value;
             ir2[jb] = cv256_tab<8 * jb>(tcol)[1];
             b2[jb] = 0.f;
@@ -254,13 +254,13 @@ __global__ __launch_bounds__(512) void cv_fwd_p256_kernel(Cv256Params p) {
         f32x4 tB[DB][4];
         auto tloadB = [&](auto I) __attribute__((always_inline)) {
             constexpr int i = decltype(I)::value, b = i % DB;
-            static_for<4>([&](auto JB) __attribute__((always_inline)) {
+            cv_static_for<4>([&](auto JB) __attribute__((always_inline)) {
                 constexpr int jb = decltype(JB)::value;
                 // (everything in the per-lane offset: a per-lane value in the instruction's scalar offset makes the compiler build a waterfall loop)
                 tB[b][jb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r2, c2off[jb] + i * c2step[jb], 0, 0));
             });
         };
-        static_for<DB>([&](auto I) __attribute__((always_inline)) { tloadB(I); });
+        cv_static_for<DB>([&](auto I) __attribute__((always_inline)) { tloadB(I); });
         t += gridDim.x;
         const bool more = t < ntiles;
         after = 4 * (WMT - DB) >= 16 ? 16 : 8;
@@ -271,9 +271,9 @@ __global__ __launch_bounds__(512) void cv_fwd_p256_kernel(Cv256Params p) {
             prologue(pp, tm, tn, slot);
         }
         asm volatile("" ::: "memory");   // nothing younger may be hoisted above the DMA: `after` counts on it
-        static_for<WMT>([&](auto I) __attribute__((always_inline)) {
+        cv_static_for<WMT>([&](auto I) __attribute__((always_inline)) {
             constexpr int i = decltype(I)::value, b = i % DB;
-            static_for<4>([&](auto R) __attribute__((always_inline)) {
+            cv_static_for<4>([&](auto R) __attribute__((always_inline)) {
                 constexpr int r = decltype(R)::value;
                 const float inv1 = cv256_tab<8 * (16 * i + r)>(trow)[0];
 #pragma unroll
