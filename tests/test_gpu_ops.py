@@ -350,15 +350,16 @@ def test_smooth_ap_golden(variant):
 
 
 @pytest.mark.parametrize("variant", ["vggt", "mast3r"])
-def test_smooth_ap_batched_ragged(variant):
+@pytest.mark.parametrize("N", [300, 296])      # 296: a multiple of 8 — the op then takes its operands without the zero-padded copy
+def test_smooth_ap_batched_ragged(variant, N):
     from gd_amd import ops
-    P, N, C = 3, 300, 128
+    P, C = 3, 128
     r1 = torch.randn(P, N, C, generator=_g(40), device="cuda")
     d1 = F.normalize(r1, dim=-1)
     d2 = F.normalize(d1 + 0.04 * torch.randn(P, N, C, generator=_g(41), device="cuda"), dim=-1)
     p1 = torch.rand(P, N, 3, generator=_g(42), device="cuda") * 2
     p2 = p1 + 0.02 * torch.randn(P, N, 3, generator=_g(43), device="cuda")
-    counts = torch.tensor([300, 123, 1], dtype=torch.int32, device="cuda")
+    counts = torch.tensor([N, 123, 1], dtype=torch.int32, device="cuda")
     a, b = d1.clone().requires_grad_(True), d2.clone().requires_grad_(True)
     loss = ops.smooth_ap(a, b, p1, p2, counts, variant)
     (loss * torch.tensor([1.0, 2.0, 0.5], device="cuda")).sum().backward()
@@ -597,3 +598,29 @@ def test_fp16_operand_outputs_of_the_gather_and_im2col_kernels_equal_their_f32_f
         c32 = ops.patch_im2col(img, 56, 70, P, 640, mean, std, torch.float32, stride=stride)
         c16 = ops.patch_im2col(img, 56, 70, P, 640, mean, std, torch.float16, stride=stride)
         assert c16.dtype == torch.float16 and c16.shape == c32.shape and torch.equal(c16, c32.half()), stride
+
+
+def test_loss_combine_matches_the_weighted_sum_and_mean():
+    """ops.loss_combine (gd_loss_combine_fwd / _bwd) = mean over pairs of w_ap ap + w_depth depth + w_intra intra + w_kl kl with the pairs whose keypoint
+    count is zero contributing a constant zero (src/finetune_timm_vggt.py:599-616, src/finetune_timm_mast3r.py:604-607): value, reported terms and the
+    gradient of every term against the torch expression, with and without counts, a zero weight included."""
+    from gd_amd import ops
+    P = 37
+    g = _g(70)
+    ts = [torch.rand(P, generator=g, device="cuda").requires_grad_(True) for _ in range(4)]
+    w = (1.0, 0.0, 0.7, 2.5)
+    for counts in (None, torch.tensor([0 if i % 5 == 2 else 7 for i in range(P)], dtype=torch.int32, device="cuda")):
+        for t in ts:
+            t.grad = None
+        loss, terms = ops.loss_combine(*ts, w, counts)
+        (3.0 * loss).backward()
+        got = [t.grad.clone() for t in ts]
+        keep = torch.ones(P, device="cuda") if counts is None else (counts > 0).float()
+        rs = [t.detach().clone().requires_grad_(True) for t in ts]
+        ref = (keep * sum(wi * r for wi, r in zip(w, rs))).mean()
+        (3.0 * ref).backward()
+        assert abs(loss.item() - ref.item()) < 1e-6 * max(1.0, abs(ref.item()))
+        assert terms.shape == (4, P) and not terms.requires_grad
+        for i in range(4):
+            assert torch.allclose(terms[i], keep * ts[i].detach(), rtol=0, atol=0)
+            assert torch.allclose(got[i], rs[i].grad, rtol=1e-6, atol=1e-9)
