@@ -365,7 +365,16 @@ __device__ __forceinline__ CvpTile cvp_tile(int l, int tiles) {
     return t;
 }
 
-template <typename T, bool DBG>      // DBG: the GD_CV_DBG anatomy switches (parts of the kernel turned off); never instantiated into the product path
+// BWD (round 6): the same tile walk, ring, teacher prefetch and main loop with the BACKWARD's epilogue — G = dloss/dS of both directions from the
+// accumulators and the two teacher tiles in registers, stored straight from the accumulator layout as G1[i][j] = G inv2[j] (four consecutive columns per
+// lane: 16 lanes write one 128-byte row segment of 16-bit G) and G2[j][i] = G inv1[i] (four consecutive rows per lane).  It replaces the one-tile-per-block
+// cv_bwd_tile_kernel (dword teacher loads, two LDS round trips, 2-byte stores) wherever the forward's persistent kernel runs.
+template <typename T> __device__ __forceinline__ void cv_st4(T* p, f32x4 v);
+template <> __device__ __forceinline__ void cv_st4<float>(float* p, f32x4 v) { *(f32x4*)p = v; }
+template <> __device__ __forceinline__ void cv_st4<bf16>(bf16* p, f32x4 v) { *(bf16x4*)p = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]}; }
+template <> __device__ __forceinline__ void cv_st4<f16>(f16* p, f32x4 v) { *(f16x4*)p = f16x4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]}; }
+
+template <typename T, bool DBG, bool BWD = false>      // DBG: the GD_CV_DBG anatomy switches (parts of the kernel turned off); never instantiated into the product path
 __global__ __launch_bounds__(768) void cv_fwd_persist_kernel(CvTileParams q) {
     __shared__ __attribute__((aligned(16))) char smem[CVP_SMEM];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -392,7 +401,7 @@ __global__ __launch_bounds__(768) void cv_fwd_persist_kernel(CvTileParams q) {
         const char* ssrc = nullptr;
         int it_i = 0, k_i = 0;                 // (tile, K-step) of the next step to issue
         auto issue = [&](int n) {
-            char* sA = smem + (n & (CVP_SLOTS - 1)) * CVP_STAGE;
+            char* sA = smem + ((DBG && (q.dbg & 1024)) ? n % 3 : (n & (CVP_SLOTS - 1))) * CVP_STAGE;      // (anatomy bit 1024: a THREE-slot ring, two steps ahead)
             char* sB = sA + 128 * 128;
             if (k_i == 0) {
                 const CvpTile t = cvp_tile(beg + kb + it_i * nbx, tiles);
@@ -412,14 +421,16 @@ __global__ __launch_bounds__(768) void cv_fwd_persist_kernel(CvTileParams q) {
                                                  (__attribute__((address_space(3))) void*)(smem + CVP_STAT_OFF + (it_i & 1) * 4096 + lw * 1024),
                                                  16, 0, 0);
             }
+            if (!(DBG && (q.dbg & 64))) {      // (anatomy bit 64: no feature DMA — the teacher stream alone)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + (long)k_i * 128),
-                                                 (__attribute__((address_space(3))) void*)(sA + (lw * 4 + i) * 1024), 16, 0, 0);
+                for (int i = 0; i < 4; ++i)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + (long)k_i * 128),
+                                                     (__attribute__((address_space(3))) void*)(sA + (lw * 4 + i) * 1024), 16, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + (long)k_i * 128),
-                                                 (__attribute__((address_space(3))) void*)(sB + (lw * 4 + i) * 1024), 16, 0, 0);
+                for (int i = 0; i < 4; ++i)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + (long)k_i * 128),
+                                                     (__attribute__((address_space(3))) void*)(sB + (lw * 4 + i) * 1024), 16, 0, 0);
+            }
             if (++k_i == nk) { k_i = 0; ++it_i; }
         };
         // previous tile's partial sums: LDS (written by the compute waves before the barrier just passed) -> slabs
@@ -443,23 +454,24 @@ __global__ __launch_bounds__(768) void cv_fwd_persist_kernel(CvTileParams q) {
             if (idx < hw)       // explicitly a GLOBAL store: a flat store is out of order with respect to vmcnt
                 *(__attribute__((address_space(1))) f32x2*)(base + ((((long)t.p * q.nslab + slab) * hw + idx) * 2) * sizeof(float)) = f32x2{Z, B};
         };
-        for (int n = 0; n < 3 && n < n_total; ++n) issue(n);
+        const int ahead = (DBG && (q.dbg & 1024)) ? 2 : 3;
+        for (int n = 0; n < ahead && n < n_total; ++n) issue(n);
         int kk = 0, it = 0;
         for (int n = 0; n < n_total; ++n) {
             const int rem = n_total - 1 - n;
             // every operation older than the two youngest steps (8 DMA pieces each) has landed: step n is in LDS
-            if (rem >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            else if (rem == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if (rem >= 2 && ahead == 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (rem >= 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (n + 3 < n_total) issue(n + 3);
-            if (kk == 0 && it > 0) flush(it - 1);
+            if (n + ahead < n_total) issue(n + ahead);
+            if (!BWD && kk == 0 && it > 0) flush(it - 1);
             if (++kk == nk) { kk = 0; ++it; }
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        flush(n_tiles - 1);
+        if (!BWD) flush(n_tiles - 1);
         return;
     }
 
@@ -473,6 +485,7 @@ __global__ __launch_bounds__(768) void cv_fwd_persist_kernel(CvTileParams q) {
     f32x4 t2v[2][4];         // direction 2: T2[row = tn*128 + wn*64 + 4c + jb][col = tm*128 + wm*32 + ib*16 + 4g .. +3]   ([ib][jb], element r)
     // branch-free: every address is clamped into the pair's map (rows / columns past hw re-read valid entries; the
     // epilogue multiplies them by a zeroed s), so the 16 loads of a tile go out back to back with no wait between them
+    unsigned keepbits = 0xfffu;
     auto prefetch = [&](int it) {
         const CvpTile t = cvp_tile(beg + kb + it * nbx, tiles);
         const float* T1 = q.t1 + (long)t.p * hw * ldt;
@@ -499,6 +512,28 @@ __global__ __launch_bounds__(768) void cv_fwd_persist_kernel(CvTileParams q) {
 #pragma unroll
             for (int jb = 0; jb < 4; ++jb) ck[jb] = true;
         }
+        if (BWD) {      // the backward's epilogue needs the masks themselves: one bit per row / column of this lane, valid until the next prefetch
+            keepbits = 0;
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) keepbits |= rk[ib][r] ? 1u << (ib * 4 + r) : 0u;
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) keepbits |= ck[jb] ? 256u << jb : 0u;
+        }
+        if (DBG && (q.dbg & 128)) {      // (anatomy bit 128, timing only: the two teacher tiles as CONTIGUOUS 64 KB blocks — what a pre-tiled map layout would read)
+            const long nblk = (long)q.P * hw * ldt / 16384, L = (long)(beg + kb + it * nbx) % nblk;
+            const float* B1 = q.t1 + L * 16384;
+            const float* B2 = q.t2 + L * 16384;
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib) {
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb) t2v[ib][jb] = *(const f32x4*)(B2 + (wn * 64 + 4 * c + jb) * 128 + wm * 32 + ib * 16 + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t1v[ib][r] = *(const f32x4*)(B1 + (wm * 32 + ib * 16 + 4 * g + r) * 128 + wn * 64 + 4 * c);
+            }
+            return;
+        }
         const int col0 = min(t.tn * 128 + wn * 64 + 4 * c, ldt - 4);          // ldt % 4 == 0: aligned, inside the row
 #pragma unroll
         for (int ib = 0; ib < 2; ++ib) {
@@ -506,10 +541,11 @@ __global__ __launch_bounds__(768) void cv_fwd_persist_kernel(CvTileParams q) {
 #pragma unroll
             for (int jb = 0; jb < 4; ++jb) {
                 const int col = min(t.tn * 128 + wn * 64 + 4 * c + jb, hw - 1);
-                t2v[ib][jb] = *(const f32x4*)(T2 + (ck[jb] ? (long)col * ldt + min(row0, ldt - 4) : 0L));
+                if (!(DBG && (q.dbg & 256))) t2v[ib][jb] = *(const f32x4*)(T2 + (ck[jb] ? (long)col * ldt + min(row0, ldt - 4) : 0L));
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) t1v[ib][r] = *(const f32x4*)(T1 + (rk[ib][r] ? (long)min(row0 + r, hw - 1) * ldt + col0 : 0L));
+            for (int r = 0; r < 4; ++r)
+                if (!(DBG && (q.dbg & 512))) t1v[ib][r] = *(const f32x4*)(T1 + (rk[ib][r] ? (long)min(row0 + r, hw - 1) * ldt + col0 : 0L));
         }
     };
     const int dbg = DBG ? q.dbg : 0;     // diagnostics (GD_CV_DBG): 1 = no teacher loads, 2 = no epilogue math, 4 = no MFMAs
@@ -528,7 +564,7 @@ __global__ __launch_bounds__(768) void cv_fwd_persist_kernel(CvTileParams q) {
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int k = 0; k < nk; ++k, ++n) {
             cvp_barrier();
-            const char* sb = smem + (n & (CVP_SLOTS - 1)) * CVP_STAGE;
+            const char* sb = smem + ((DBG && (q.dbg & 1024)) ? n % 3 : (n & (CVP_SLOTS - 1))) * CVP_STAGE;
 #pragma unroll
             for (int kc = 0; kc < 2; ++kc) {
                 const int co = (((kc * 4 + g) ^ sa) * 16);
@@ -559,7 +595,60 @@ __global__ __launch_bounds__(768) void cv_fwd_persist_kernel(CvTileParams q) {
         const CvpTile t = cvp_tile(beg + kb + it * nbx, tiles);
         const f32x4* sSt = (const f32x4*)(smem + CVP_STAT_OFF + (it & 1) * 4096);
         float* sP = (float*)(smem + CVP_PART_OFF + (it & 1) * 6144);
-        {
+        if (BWD) {
+            // G[i][j] = coef ( e^S (W1_i / Z1_i + W2_j / Z2_j) - max(T1[i][j], eps R1_i) / R1_i - max(T2[j][i], eps R2_j) / R2_j ), a direction's terms only for
+            // its kept rows (W, R: the teacher row's clamped sums; Z: the student's softmax denominator saved by the forward; coef = dloss_p / (2 hw), times the
+            // fp16 range scale of the tf32h engine).  Entries past the ragged edge: the zeroed inverse norm of their row / column makes what is stored 0.
+            constexpr float LOG2E = 1.4426950408889634f;
+            const int hwp = q.hwp;
+            const float coef = q.gloss[t.p] * 0.5f / (float)hw * (q.gscale ? q.gscale[0] : 1.0f);
+            T* G1 = (T*)q.G1 + (long)t.p * hw * hwp;
+            T* G2 = (T*)q.G2 + (long)t.p * hw * hwp;
+            float inv2[4], thr2[4], u2[4], q2[4];
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) {
+                const int cl = wn * 64 + 4 * c + jb;
+                const f32x4 v = sSt[128 + cl];
+                const bool ok = t.tn * 128 + cl < hw, keep = ok && (keepbits & (256u << jb));
+                inv2[jb] = ok ? v[0] : 0.f; thr2[jb] = CV_EPS * v[1];
+                u2[jb] = keep ? coef * v[3] * __builtin_amdgcn_exp2f(-v[2] * LOG2E) : 0.f;
+                q2[jb] = keep ? coef * __builtin_amdgcn_rcpf(v[1]) : 0.f;
+            }
+            const int colg = t.tn * 128 + wn * 64 + 4 * c;
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib) {
+                f32x4 inv1, inv1l, thr1, u1, q1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rl = wm * 32 + ib * 16 + 4 * g + r;
+                    const f32x4 v = sSt[rl];
+                    const bool ok = t.tm * 128 + rl < hw, keep = ok && (keepbits & (1u << (ib * 4 + r)));
+                    inv1[r] = ok ? v[0] : 0.f; inv1l[r] = inv1[r] * LOG2E; thr1[r] = CV_EPS * v[1];
+                    u1[r] = keep ? coef * v[3] * __builtin_amdgcn_exp2f(-v[2] * LOG2E) : 0.f;
+                    q1[r] = keep ? coef * __builtin_amdgcn_rcpf(v[1]) : 0.f;
+                }
+                const int rowg = t.tm * 128 + wm * 32 + ib * 16 + 4 * g;
+                f32x4 g1[4];      // [r], element jb: four consecutive columns of one row
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb) {
+                    const f32x4 sv = acc[ib][jb] * inv1l * inv2[jb];
+                    f32x4 gg;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = __builtin_amdgcn_exp2f(sv[r]);
+                        gg[r] = e * (u1[r] + u2[jb]) - fmaxf(t1v[ib][r][jb], thr1[r]) * q1[r] - fmaxf(t2v[ib][jb][r], thr2[jb]) * q2[jb];
+                        g1[r][jb] = gg[r] * inv2[jb];
+                    }
+                    const int col = colg + jb;
+                    if (col < hw && rowg < hwp) cv_st4<T>(G2 + (long)col * hwp + rowg, gg * inv1);
+                }
+                if (colg < hwp) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (rowg + r < hw) cv_st4<T>(G1 + (long)(rowg + r) * hwp + colg, g1[r]);
+                }
+            }
+        } else {
             constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
             // Entries past the ragged edge (tile rows / columns >= hw; their operands are clamped re-reads): the row's / column's inverse norm is
             // zeroed, which makes s' = 0 — nothing enters a B sum — and e = exp2(0) = 1 exactly; the Z sums of the VALID rows and columns are
@@ -1400,6 +1489,26 @@ extern "C" int gd_cost_volume_kl_fwd_prenorm(const void* f1, const void* f2, con
     return cv_fwd_common(f1, f2, inv_norm1, inv_norm2, t1, t2, ldt, tstats, m1, m2, P, hw, C, variant, dtype, loss, stats, workspace, stream);
 }
 
+// the dense backward's tile pass: the persistent kernel's BWD instantiation where the forward's persistent kernel would run (rows of whole 128-byte
+// K steps, 16-byte aligned teacher rows), else one tile per block
+template <typename T>
+static void cv_bwd_tiles_launch(CvTileParams& q, hipStream_t s) {
+    const long rowb = (long)q.C * sizeof(T);
+    if (gd_knobs().cv_persist && rowb % 128 == 0 && rowb / 128 >= 3 && q.ldt % 4 == 0 && ((uintptr_t)q.t1 & 15) == 0 && ((uintptr_t)q.t2 & 15) == 0 &&
+        ((uintptr_t)q.stats & 15) == 0) {
+        int ncu = 256;
+        if (gd_knobs().ncu >= 8) ncu = gd_knobs().ncu / 8 * 8;
+        const long total = (long)q.P * q.tiles * q.tiles;
+        int grid = (int)(total < ncu ? (total + 7) / 8 * 8 : ncu);
+        if (gd_knobs().cv_grid) {
+            const int gv = gd_knobs().cv_grid / 8 * 8;
+            if (gv >= 8 && gv < grid) grid = gv;
+        }
+        hipLaunchKernelGGL((cv_fwd_persist_kernel<T, false, true>), dim3(grid), dim3(768), 0, s, q);
+    } else
+        hipLaunchKernelGGL(cv_bwd_tile_kernel<T>, dim3(q.tiles * q.tiles, q.P), dim3(256), 0, s, q);
+}
+
 extern "C" int gd_cost_volume_kl_bwd(const void* f1, const void* f2, const float* t1, const float* t2, int ldt,
                                      const unsigned char* m1, const unsigned char* m2, int P, int hw, int C,
                                      int dtype, const float* gloss, const float* stats, void* df1, void* df2,
@@ -1413,33 +1522,29 @@ extern "C" int gd_cost_volume_kl_bwd(const void* f1, const void* f2, const float
     hipStream_t s = (hipStream_t)stream;
     const size_t es = (size_t)gd_dtype_size(dtype);
     const int tiles = cv_tiles(hw), hwp = cv_hwp(hw);
+    // G1 | G2, b^T | a^T and d a_hat | d b_hat are each ONE contiguous batch of 2P problems: the two contractions run as one launch (1 152 tiles = 4.5
+    // rounds of the chip at the benched size instead of 2 x 2.25)
     char* w = (char*)workspace;
-    void* G1 = w; w += align256((size_t)P * hw * hwp * es);
-    void* G2 = w; w += align256((size_t)P * hw * hwp * es);
-    void* at = w; w += align256((size_t)P * C * hwp * es);
-    void* bt = w; w += align256((size_t)P * C * hwp * es);
-    float* da = (float*)w; w += align256((size_t)P * hw * C * sizeof(float));
-    float* db = (float*)w;
+    void* G1 = w; void* G2 = w + (size_t)P * hw * hwp * es; w += align256((size_t)2 * P * hw * hwp * es);
+    void* bt = w; void* at = w + (size_t)P * C * hwp * es; w += align256((size_t)2 * P * C * hwp * es);
+    float* da = (float*)w; float* db = da + (size_t)P * hw * C;
     CvTileParams q = {};
     q.f1 = f1; q.f2 = f2; q.t1 = t1; q.t2 = t2; q.stats = (float*)stats; q.hw = hw; q.C = C; q.tiles = tiles;
     q.m1 = m1; q.m2 = m2; q.gloss = gloss; q.G1 = G1; q.G2 = G2; q.hwp = hwp; q.ldt = ldt; q.P = P;
     dim3 tgrid(hwp / 64, gd_cdiv(C, 64), 2 * P);
     if (dtype == GD_BF16) {
-        hipLaunchKernelGGL(cv_bwd_tile_kernel<bf16>, dim3(tiles * tiles, P), dim3(256), 0, s, q);
+        cv_bwd_tiles_launch<bf16>(q, s);
         hipLaunchKernelGGL(cv_transpose_kernel<bf16>, tgrid, dim3(256), 0, s, (const bf16*)f1, (const bf16*)f2,
                            (bf16*)at, (bf16*)bt, hw, hwp, C);
     } else {
-        hipLaunchKernelGGL(cv_bwd_tile_kernel<float>, dim3(tiles * tiles, P), dim3(256), 0, s, q);
+        cv_bwd_tiles_launch<float>(q, s);
         hipLaunchKernelGGL(cv_transpose_kernel<float>, tgrid, dim3(256), 0, s, (const float*)f1, (const float*)f2,
                            (float*)at, (float*)bt, hw, hwp, C);
     }
     GD_LAUNCH_OK();
     // d a_hat = G1 . b ,  d b_hat = G2 . a   (contraction over the padded hw axis)
-    int rc = gd_gemm_nt(G1, bt, da, hw, C, hwp, hwp, hwp, C, P, (long)hw * hwp, (long)C * hwp, (long)hw * C, dtype,
+    int rc = gd_gemm_nt(G1, bt, da, hw, C, hwp, hwp, hwp, C, 2 * P, (long)hw * hwp, (long)C * hwp, (long)hw * C, dtype,
                         GD_F32, 1.0f, nullptr, nullptr, nullptr, 0, nullptr, 0, 0, nullptr, 0, 0, nullptr, 0, 0, stream);
-    if (rc) return rc;
-    rc = gd_gemm_nt(G2, at, db, hw, C, hwp, hwp, hwp, C, P, (long)hw * hwp, (long)C * hwp, (long)hw * C, dtype,
-                    GD_F32, 1.0f, nullptr, nullptr, nullptr, 0, nullptr, 0, 0, nullptr, 0, 0, nullptr, 0, 0, stream);
     if (rc) return rc;
     if (dtype == GD_BF16)
         hipLaunchKernelGGL(cv_norm_bwd_kernel<bf16>, dim3(gd_cdiv(hw, 4), 2, P), dim3(256), 0, s, (const bf16*)f1,
@@ -1487,27 +1592,21 @@ extern "C" int gd_cost_volume_kl_bwd_h(const float* f1, const float* f2, const v
                "gd_cost_volume_kl_bwd_h: features and gradients must be 16-byte aligned, the workspace 256-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const int tiles = cv_tiles(hw), hwp = cv_hwp(hw);
-    char* w = (char*)workspace;
-    void* G1 = w; w += align256((size_t)P * hw * hwp * 2);
-    void* G2 = w; w += align256((size_t)P * hw * hwp * 2);
-    void* at = w; w += align256((size_t)P * C * hwp * 2);
-    void* bt = w; w += align256((size_t)P * C * hwp * 2);
-    float* da = (float*)w; w += align256((size_t)P * hw * C * sizeof(float));
-    float* db = (float*)w; w += align256((size_t)P * hw * C * sizeof(float));
+    char* w = (char*)workspace;      // (contiguous batches of 2P, as in gd_cost_volume_kl_bwd)
+    void* G1 = w; void* G2 = w + (size_t)P * hw * hwp * 2; w += align256((size_t)2 * P * hw * hwp * 2);
+    void* bt = w; void* at = w + (size_t)P * C * hwp * 2; w += align256((size_t)2 * P * C * hwp * 2);
+    float* da = (float*)w; float* db = da + (size_t)P * hw * C; w += align256((size_t)2 * P * hw * C * sizeof(float));
     float* gs = (float*)w;
     hipLaunchKernelGGL(cv_gscale_kernel, dim3(1), dim3(64), 0, s, gloss, P, hw, gs);
     CvTileParams q = {};
     q.f1 = f1h; q.f2 = f2h; q.t1 = t1; q.t2 = t2; q.stats = (float*)stats; q.hw = hw; q.C = C; q.tiles = tiles;
     q.m1 = m1; q.m2 = m2; q.gloss = gloss; q.G1 = G1; q.G2 = G2; q.hwp = hwp; q.ldt = ldt; q.P = P; q.gscale = gs;
     dim3 tgrid(hwp / 64, gd_cdiv(C, 64), 2 * P);
-    hipLaunchKernelGGL(cv_bwd_tile_kernel<f16>, dim3(tiles * tiles, P), dim3(256), 0, s, q);
+    cv_bwd_tiles_launch<f16>(q, s);
     hipLaunchKernelGGL(cv_transpose_kernel<f16>, tgrid, dim3(256), 0, s, (const f16*)f1h, (const f16*)f2h, (f16*)at, (f16*)bt, hw, hwp, C);
     GD_LAUNCH_OK();
-    int rc = gd_gemm_nt_scaled(G1, bt, da, hw, C, hwp, hwp, hwp, C, P, (long)hw * hwp, (long)C * hwp, (long)hw * C, GD_F16, GD_F32, 1.0f, gs + 1,
+    int rc = gd_gemm_nt_scaled(G1, bt, da, hw, C, hwp, hwp, hwp, C, 2 * P, (long)hw * hwp, (long)C * hwp, (long)hw * C, GD_F16, GD_F32, 1.0f, gs + 1,
                                nullptr, nullptr, nullptr, 0, nullptr, 0, 0, nullptr, 0, 0, nullptr, 0, 0, stream);
-    if (rc) return rc;
-    rc = gd_gemm_nt_scaled(G2, at, db, hw, C, hwp, hwp, hwp, C, P, (long)hw * hwp, (long)C * hwp, (long)hw * C, GD_F16, GD_F32, 1.0f, gs + 1,
-                           nullptr, nullptr, nullptr, 0, nullptr, 0, 0, nullptr, 0, 0, nullptr, 0, 0, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(cv_norm_bwd_kernel<float>, dim3(gd_cdiv(hw, 4), 2, P), dim3(256), 0, s, f1, f2, da, db, stats, df1, df2, hw, C);
     GD_LAUNCH_OK();

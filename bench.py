@@ -487,13 +487,20 @@ def cost_volume_attainable(job, dev, variant, fwd_bytes):
                 return ops.time_on_stream(lambda: ops.cost_volume_kl(f1, f2, b["cost_1"], b["cost_2"], ones, ones, variant, tstats=b["cost_tstats"], inv_norms=inv), 2, 5) * 1e6
         finally:
             lib().gd_debug_set(b"cv_dbg", 0)
-    whole, ring, ring_mfma, ring_teacher, ring_epi = t(32), t(7), t(3), t(6), t(5)
+    whole, ring, ring_mfma, ring_teacher, ring_epi, teacher = t(32), t(7), t(3), t(6), t(5), t(64 | 6)
     phases = {"feature_ring_alone (LDS-DMA, L2 -> LDS)": ring, "fragment_reads_and_mfma (marginal)": max(ring_mfma - ring, 0.0),
               "teacher_loads (marginal)": max(ring_teacher - ring, 0.0), "softmax_kl_epilogue (marginal)": max(ring_epi - ring, 0.0)}
     slow, tot = max(phases.values()), sum(phases.values())
+    streams = {"teacher_loads_alone (no feature DMA)": round(teacher, 1), "feature_ring_alone": round(ring, 1), "both (measured)": round(ring_teacher, 1),
+               "both_over_sum": round(ring_teacher / (ring + teacher), 3) if ring + teacher > 0 else None,
+               "frac_of_both_alone": round(fwd_bytes / (ring_teacher * 1e-6) / 1e9 / PEAK_HBM_GBS, 4) if ring_teacher > 0 else None,
+               "reading": "the kernel's two memory streams (feature tiles L2 -> LDS, teacher tiles HBM -> registers) with no arithmetic at all: when `both` is "
+                          "close to the SUM of the two alone, the streams do not overlap with each other — each is bound by latency x the CU's outstanding-request "
+                          "capacity, which they share — and `frac_of_both_alone` is the ceiling of this tile shape, not `frac_if_phases_overlapped`"}
     return {"what": "dense forward, every row kept, 16-bit features: the persistent kernel's phases timed one at a time (anatomy build; whole op = statistics "
                     "init + tile kernel + finalize + loss, as `unmasked` times it)",
             "us_per_launch": {"whole_op_anatomy_build_nothing_off": round(whole, 1), **{k: round(v, 1) for k, v in phases.items()}},
+            "memory_streams_us": streams,
             "sum_of_phases_us": round(tot, 1), "measured_over_sum_of_phases": round(whole / tot, 3) if tot > 0 else None,
             "slowest_phase_us": round(slow, 1),
             "frac_if_phases_overlapped": round(fwd_bytes / (slow * 1e-6) / 1e9 / PEAK_HBM_GBS, 4) if slow > 0 else None,

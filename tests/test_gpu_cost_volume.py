@@ -129,6 +129,58 @@ def _debug(name, value):
     check(lib().gd_debug_set(name.encode(), value), "gd_debug_set")
 
 
+@pytest.mark.parametrize("mode,P,hw,C,masked", [("f32", 3, 672, 96, True), ("bf16", 3, 1369, 768, True), ("bf16", 5, 700, 384, False),
+                                                ("h", 3, 1369, 768, True), ("h", 2, 1369, 1024, False)])
+def test_persistent_backward_matches_the_tile_kernel_and_the_oracle(mode, P, hw, C, masked):
+    """The dense backward's G pass on the persistent kernel (cv_fwd_persist_kernel<.., BWD>: G1 / G2 stored from the accumulator layout; the two
+    contractions as ONE batch of 2P) against (a) the one-tile-per-block kernel it replaces (GD_CV_PERSIST=0) and (b) the fp64 oracle — with few
+    blocks (cv_grid 8: every block walks many tiles, the keep bits and the teacher prefetch wrap), row masks on both views, a ragged last tile
+    (hw = 1369, 700, 672 = 5.25 tiles), per-pair loss gradients four decades apart, and bit-identical results run to run."""
+    from gd_amd import ops
+    gen = torch.Generator(device="cuda").manual_seed(hw + C + P)
+    dt = torch.bfloat16 if mode == "bf16" else torch.float32
+    f1 = torch.randn(P, hw, C, generator=gen, device="cuda").to(dt).requires_grad_(True)
+    f2 = torch.randn(P, hw, C, generator=gen, device="cuda").to(dt).requires_grad_(True)
+    t1 = torch.softmax(3 * torch.randn(P, hw, hw, generator=gen, device="cuda"), -1)
+    t2 = torch.softmax(3 * torch.randn(P, hw, hw, generator=gen, device="cuda"), -1)
+    if masked:
+        m1 = torch.rand(P, hw, generator=gen, device="cuda") > 0.4
+        m2 = torch.rand(P, hw, generator=gen, device="cuda") > 0.4
+    else:
+        m1 = m2 = torch.ones(P, hw, dtype=torch.bool, device="cuda")
+    c1, c2, ts = _teacher("cached", t1, t2)
+    kw = dict(tstats=ts)
+    if mode == "h":
+        kw.update(inv_norms=(1.0 / f1.detach().norm(dim=-1).clamp_min(1e-12), 1.0 / f2.detach().norm(dim=-1).clamp_min(1e-12)), x3="h")
+    wts = torch.logspace(0, -4, P, device="cuda")
+
+    def grads():
+        f1.grad = f2.grad = None
+        (ops.cost_volume_kl(f1, f2, c1, c2, m1, m2, "vggt", **kw) * wts).sum().backward()
+        return f1.grad.clone(), f2.grad.clone()
+
+    _debug("cv_grid", 8)
+    try:
+        g1, g2 = grads()
+        h1, h2 = grads()
+    finally:
+        _debug("cv_grid", 0)
+    assert torch.equal(g1, h1) and torch.equal(g2, h2)
+    _debug("cv_persist", 0)
+    try:
+        o1, o2 = grads()
+    finally:
+        _debug("cv_persist", 1)
+    tol = {"f32": 2e-5, "bf16": 1e-2, "h": 2e-3}[mode]       # (the two kernels round G at different points: exp(S) / Z against exp(S - log Z))
+    for p in range(P):
+        assert rel_err(g1[p], o1[p]) < tol and rel_err(g2[p], o2[p]) < tol, p
+    _, og1, og2 = _oracle(f1.detach().float(), f2.detach().float(), t1, t2, m1, m2, "vggt")
+    otol = {"f32": 1e-4, "bf16": 2e-2, "h": 4e-3}[mode]
+    w = wts.double().view(P, 1, 1).cpu()
+    for p in range(P):
+        assert rel_err(g1[p], (og1.cpu() * w)[p]) < otol and rel_err(g2[p], (og2.cpu() * w)[p]) < otol, p
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_producer_side_row_norms(dtype):
     """ops.tap_mean(with_norm=True) hands out the inverse L2 norms of the rows it writes, and cost_volume_kl(inv_norms=...) uses them
