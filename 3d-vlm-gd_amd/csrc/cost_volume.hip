@@ -374,6 +374,128 @@ template <> __device__ __forceinline__ void cv_st4<float>(float* p, f32x4 v) { *
 template <> __device__ __forceinline__ void cv_st4<bf16>(bf16* p, f32x4 v) { *(bf16x4*)p = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]}; }
 template <> __device__ __forceinline__ void cv_st4<f16>(f16* p, f32x4 v) { *(f16x4*)p = f16x4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]}; }
 
+// The two epilogues of the persistent kernel, from the accumulators (wave tile 32 x 64: rows wm*32 + ib*16 + 4g + r, columns wn*64 + 4c + jb).
+__device__ __forceinline__ void cvp_epilogue_fwd(const f32x4 (&acc)[2][4], const f32x4 (&t1v)[2][4], const f32x4 (&t2v)[2][4], const f32x4* sSt, float* sP,
+                                                 const CvpTile& t, int hw, int wm, int wn, int g, int c) {
+        constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+        // Entries past the ragged edge (tile rows / columns >= hw; their operands are clamped re-reads): the row's / column's inverse norm is
+        // zeroed, which makes s' = 0 — nothing enters a B sum — and e = exp2(0) = 1 exactly; the Z sums of the VALID rows and columns are
+        // corrected by the count of ones they collected (those of invalid rows / columns are never stored).  No per-entry test or select.
+        float inv2[4], thr2[4], badc = 0.f, badr = 0.f;
+        f32x2 zc[4], b2[4];
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+            const int cl = wn * 64 + 4 * c + jb;
+            const f32x4 v = sSt[128 + cl];
+            const bool ok = t.tn * 128 + cl < hw;
+            inv2[jb] = ok ? v[0] : 0.f; thr2[jb] = CV_EPS * v[1];
+            badc += ok ? 0.f : 1.f;
+            zc[jb] = f32x2{0.f, 0.f}; b2[jb] = f32x2{0.f, 0.f};
+        }
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) {
+            f32x4 inv1, thr1, zr = {-badc, -badc, -badc, -badc}, b1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rl = wm * 32 + ib * 16 + 4 * g + r;
+                const f32x4 v = sSt[rl];
+                const bool ok = t.tm * 128 + rl < hw;
+                inv1[r] = ok ? v[0] * LOG2E : 0.f; thr1[r] = CV_EPS * v[1];
+                badr += ok ? 0.f : 1.f;
+            }
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) {
+                const f32x4 sv = acc[ib][jb] * inv1 * inv2[jb];
+                f32x4 e;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(sv[r]);
+                zr += e;
+                zc[jb] += f32x2{e[0], e[1]};
+                zc[jb] += f32x2{e[2], e[3]};
+                f32x4 m2;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) m2[r] = fmaxf(t2v[ib][jb][r], thr2[jb]);
+                b2[jb] = __builtin_elementwise_fma(f32x2{m2[0], m2[1]}, f32x2{sv[0], sv[1]}, b2[jb]);
+                b2[jb] = __builtin_elementwise_fma(f32x2{m2[2], m2[3]}, f32x2{sv[2], sv[3]}, b2[jb]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) b1[r] = fmaf(fmaxf(t1v[ib][r][jb], thr1[r]), sv[r], b1[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rl = wm * 32 + ib * 16 + 4 * g + r;
+                const float z = row16_sum(zr[r]), b = row16_sum(b1[r]);
+                if (c == 0) { sP[wn * 128 + rl] = z; sP[256 + wn * 128 + rl] = b * (LN2 * __builtin_amdgcn_rcpf(sSt[rl][1])); }      // (the sum re-read: a register less per row)
+            }
+        }
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+            float z = (zc[jb][0] + zc[jb][1]) - badr, b = b2[jb][0] + b2[jb][1];
+            z += __shfl_xor(z, 16, 64); z += __shfl_xor(z, 32, 64);
+            b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+            if (g == 0) {
+                const int cl = wn * 64 + 4 * c + jb;
+                sP[512 + wm * 128 + cl] = z; sP[1024 + wm * 128 + cl] = b * (LN2 * __builtin_amdgcn_rcpf(sSt[128 + cl][1]));
+            }
+        }
+}
+
+template <typename T>
+__device__ __forceinline__ void cvp_epilogue_bwd(const CvTileParams& q, const f32x4 (&acc)[2][4], const f32x4 (&t1v)[2][4], const f32x4 (&t2v)[2][4], const f32x4* sSt,
+                                                 const CvpTile& t, int hw, int wm, int wn, int g, int c, unsigned keepbits) {
+        // G[i][j] = coef ( e^S (W1_i / Z1_i + W2_j / Z2_j) - max(T1[i][j], eps R1_i) / R1_i - max(T2[j][i], eps R2_j) / R2_j ), a direction's terms only for
+        // its kept rows (W, R: the teacher row's clamped sums; Z: the student's softmax denominator saved by the forward; coef = dloss_p / (2 hw), times the
+        // fp16 range scale of the tf32h engine).  Entries past the ragged edge: the zeroed inverse norm of their row / column makes what is stored 0.
+        constexpr float LOG2E = 1.4426950408889634f;
+        const int hwp = q.hwp;
+        const float coef = q.gloss[t.p] * 0.5f / (float)hw * (q.gscale ? q.gscale[0] : 1.0f);
+        T* G1 = (T*)q.G1 + (long)t.p * hw * hwp;
+        T* G2 = (T*)q.G2 + (long)t.p * hw * hwp;
+        float inv2[4], thr2[4], u2[4], q2[4];
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+            const int cl = wn * 64 + 4 * c + jb;
+            const f32x4 v = sSt[128 + cl];
+            const bool ok = t.tn * 128 + cl < hw, keep = ok && (keepbits & (256u << jb));
+            inv2[jb] = ok ? v[0] : 0.f; thr2[jb] = CV_EPS * v[1];
+            u2[jb] = keep ? coef * v[3] * __builtin_amdgcn_exp2f(-v[2] * LOG2E) : 0.f;
+            q2[jb] = keep ? coef * __builtin_amdgcn_rcpf(v[1]) : 0.f;
+        }
+        const int colg = t.tn * 128 + wn * 64 + 4 * c;
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) {
+            f32x4 inv1, inv1l, thr1, u1, q1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rl = wm * 32 + ib * 16 + 4 * g + r;
+                const f32x4 v = sSt[rl];
+                const bool ok = t.tm * 128 + rl < hw, keep = ok && (keepbits & (1u << (ib * 4 + r)));
+                inv1[r] = ok ? v[0] : 0.f; inv1l[r] = inv1[r] * LOG2E; thr1[r] = CV_EPS * v[1];
+                u1[r] = keep ? coef * v[3] * __builtin_amdgcn_exp2f(-v[2] * LOG2E) : 0.f;
+                q1[r] = keep ? coef * __builtin_amdgcn_rcpf(v[1]) : 0.f;
+            }
+            const int rowg = t.tm * 128 + wm * 32 + ib * 16 + 4 * g;
+            f32x4 g1[4];      // [r], element jb: four consecutive columns of one row
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) {
+                const f32x4 sv = acc[ib][jb] * inv1l * inv2[jb];
+                f32x4 gg;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(sv[r]);
+                    gg[r] = e * (u1[r] + u2[jb]) - fmaxf(t1v[ib][r][jb], thr1[r]) * q1[r] - fmaxf(t2v[ib][jb][r], thr2[jb]) * q2[jb];
+                    g1[r][jb] = gg[r] * inv2[jb];
+                }
+                const int col = colg + jb;
+                if (col < hw && rowg < hwp) cv_st4<T>(G2 + (long)col * hwp + rowg, gg * inv1);
+            }
+            if (colg < hwp) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (rowg + r < hw) cv_st4<T>(G1 + (long)(rowg + r) * hwp + colg, g1[r]);
+            }
+        }
+}
+
 template <typename T, bool DBG, bool BWD = false>      // DBG: the GD_CV_DBG anatomy switches (parts of the kernel turned off); never instantiated into the product path
 __global__ __launch_bounds__(768) void cv_fwd_persist_kernel(CvTileParams q) {
     __shared__ __attribute__((aligned(16))) char smem[CVP_SMEM];
@@ -401,7 +523,7 @@ __global__ __launch_bounds__(768) void cv_fwd_persist_kernel(CvTileParams q) {
         const char* ssrc = nullptr;
         int it_i = 0, k_i = 0;                 // (tile, K-step) of the next step to issue
         auto issue = [&](int n) {
-            char* sA = smem + ((DBG && (q.dbg & 1024)) ? n % 3 : (n & (CVP_SLOTS - 1))) * CVP_STAGE;      // (anatomy bit 1024: a THREE-slot ring, two steps ahead)
+            char* sA = smem + (n & (CVP_SLOTS - 1)) * CVP_STAGE;
             char* sB = sA + 128 * 128;
             if (k_i == 0) {
                 const CvpTile t = cvp_tile(beg + kb + it_i * nbx, tiles);
@@ -454,18 +576,17 @@ __global__ __launch_bounds__(768) void cv_fwd_persist_kernel(CvTileParams q) {
             if (idx < hw)       // explicitly a GLOBAL store: a flat store is out of order with respect to vmcnt
                 *(__attribute__((address_space(1))) f32x2*)(base + ((((long)t.p * q.nslab + slab) * hw + idx) * 2) * sizeof(float)) = f32x2{Z, B};
         };
-        const int ahead = (DBG && (q.dbg & 1024)) ? 2 : 3;
-        for (int n = 0; n < ahead && n < n_total; ++n) issue(n);
+        for (int n = 0; n < 3 && n < n_total; ++n) issue(n);
         int kk = 0, it = 0;
         for (int n = 0; n < n_total; ++n) {
             const int rem = n_total - 1 - n;
             // every operation older than the two youngest steps (8 DMA pieces each) has landed: step n is in LDS
-            if (rem >= 2 && ahead == 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            else if (rem >= 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if (rem >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (rem == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (n + ahead < n_total) issue(n + ahead);
+            if (n + 3 < n_total) issue(n + 3);
             if (!BWD && kk == 0 && it > 0) flush(it - 1);
             if (++kk == nk) { kk = 0; ++it; }
         }
@@ -521,19 +642,6 @@ __global__ __launch_bounds__(768) void cv_fwd_persist_kernel(CvTileParams q) {
 #pragma unroll
             for (int jb = 0; jb < 4; ++jb) keepbits |= ck[jb] ? 256u << jb : 0u;
         }
-        if (DBG && (q.dbg & 128)) {      // (anatomy bit 128, timing only: the two teacher tiles as CONTIGUOUS 64 KB blocks — what a pre-tiled map layout would read)
-            const long nblk = (long)q.P * hw * ldt / 16384, L = (long)(beg + kb + it * nbx) % nblk;
-            const float* B1 = q.t1 + L * 16384;
-            const float* B2 = q.t2 + L * 16384;
-#pragma unroll
-            for (int ib = 0; ib < 2; ++ib) {
-#pragma unroll
-                for (int jb = 0; jb < 4; ++jb) t2v[ib][jb] = *(const f32x4*)(B2 + (wn * 64 + 4 * c + jb) * 128 + wm * 32 + ib * 16 + 4 * g);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) t1v[ib][r] = *(const f32x4*)(B1 + (wm * 32 + ib * 16 + 4 * g + r) * 128 + wn * 64 + 4 * c);
-            }
-            return;
-        }
         const int col0 = min(t.tn * 128 + wn * 64 + 4 * c, ldt - 4);          // ldt % 4 == 0: aligned, inside the row
 #pragma unroll
         for (int ib = 0; ib < 2; ++ib) {
@@ -541,11 +649,10 @@ __global__ __launch_bounds__(768) void cv_fwd_persist_kernel(CvTileParams q) {
 #pragma unroll
             for (int jb = 0; jb < 4; ++jb) {
                 const int col = min(t.tn * 128 + wn * 64 + 4 * c + jb, hw - 1);
-                if (!(DBG && (q.dbg & 256))) t2v[ib][jb] = *(const f32x4*)(T2 + (ck[jb] ? (long)col * ldt + min(row0, ldt - 4) : 0L));
+                t2v[ib][jb] = *(const f32x4*)(T2 + (ck[jb] ? (long)col * ldt + min(row0, ldt - 4) : 0L));
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (!(DBG && (q.dbg & 512))) t1v[ib][r] = *(const f32x4*)(T1 + (rk[ib][r] ? (long)min(row0 + r, hw - 1) * ldt + col0 : 0L));
+            for (int r = 0; r < 4; ++r) t1v[ib][r] = *(const f32x4*)(T1 + (rk[ib][r] ? (long)min(row0 + r, hw - 1) * ldt + col0 : 0L));
         }
     };
     const int dbg = DBG ? q.dbg : 0;     // diagnostics (GD_CV_DBG): 1 = no teacher loads, 2 = no epilogue math, 4 = no MFMAs
@@ -564,7 +671,7 @@ __global__ __launch_bounds__(768) void cv_fwd_persist_kernel(CvTileParams q) {
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int k = 0; k < nk; ++k, ++n) {
             cvp_barrier();
-            const char* sb = smem + ((DBG && (q.dbg & 1024)) ? n % 3 : (n & (CVP_SLOTS - 1))) * CVP_STAGE;
+            const char* sb = smem + (n & (CVP_SLOTS - 1)) * CVP_STAGE;
 #pragma unroll
             for (int kc = 0; kc < 2; ++kc) {
                 const int co = (((kc * 4 + g) ^ sa) * 16);
@@ -595,121 +702,8 @@ __global__ __launch_bounds__(768) void cv_fwd_persist_kernel(CvTileParams q) {
         const CvpTile t = cvp_tile(beg + kb + it * nbx, tiles);
         const f32x4* sSt = (const f32x4*)(smem + CVP_STAT_OFF + (it & 1) * 4096);
         float* sP = (float*)(smem + CVP_PART_OFF + (it & 1) * 6144);
-        if (BWD) {
-            // G[i][j] = coef ( e^S (W1_i / Z1_i + W2_j / Z2_j) - max(T1[i][j], eps R1_i) / R1_i - max(T2[j][i], eps R2_j) / R2_j ), a direction's terms only for
-            // its kept rows (W, R: the teacher row's clamped sums; Z: the student's softmax denominator saved by the forward; coef = dloss_p / (2 hw), times the
-            // fp16 range scale of the tf32h engine).  Entries past the ragged edge: the zeroed inverse norm of their row / column makes what is stored 0.
-            constexpr float LOG2E = 1.4426950408889634f;
-            const int hwp = q.hwp;
-            const float coef = q.gloss[t.p] * 0.5f / (float)hw * (q.gscale ? q.gscale[0] : 1.0f);
-            T* G1 = (T*)q.G1 + (long)t.p * hw * hwp;
-            T* G2 = (T*)q.G2 + (long)t.p * hw * hwp;
-            float inv2[4], thr2[4], u2[4], q2[4];
-#pragma unroll
-            for (int jb = 0; jb < 4; ++jb) {
-                const int cl = wn * 64 + 4 * c + jb;
-                const f32x4 v = sSt[128 + cl];
-                const bool ok = t.tn * 128 + cl < hw, keep = ok && (keepbits & (256u << jb));
-                inv2[jb] = ok ? v[0] : 0.f; thr2[jb] = CV_EPS * v[1];
-                u2[jb] = keep ? coef * v[3] * __builtin_amdgcn_exp2f(-v[2] * LOG2E) : 0.f;
-                q2[jb] = keep ? coef * __builtin_amdgcn_rcpf(v[1]) : 0.f;
-            }
-            const int colg = t.tn * 128 + wn * 64 + 4 * c;
-#pragma unroll
-            for (int ib = 0; ib < 2; ++ib) {
-                f32x4 inv1, inv1l, thr1, u1, q1;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int rl = wm * 32 + ib * 16 + 4 * g + r;
-                    const f32x4 v = sSt[rl];
-                    const bool ok = t.tm * 128 + rl < hw, keep = ok && (keepbits & (1u << (ib * 4 + r)));
-                    inv1[r] = ok ? v[0] : 0.f; inv1l[r] = inv1[r] * LOG2E; thr1[r] = CV_EPS * v[1];
-                    u1[r] = keep ? coef * v[3] * __builtin_amdgcn_exp2f(-v[2] * LOG2E) : 0.f;
-                    q1[r] = keep ? coef * __builtin_amdgcn_rcpf(v[1]) : 0.f;
-                }
-                const int rowg = t.tm * 128 + wm * 32 + ib * 16 + 4 * g;
-                f32x4 g1[4];      // [r], element jb: four consecutive columns of one row
-#pragma unroll
-                for (int jb = 0; jb < 4; ++jb) {
-                    const f32x4 sv = acc[ib][jb] * inv1l * inv2[jb];
-                    f32x4 gg;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float e = __builtin_amdgcn_exp2f(sv[r]);
-                        gg[r] = e * (u1[r] + u2[jb]) - fmaxf(t1v[ib][r][jb], thr1[r]) * q1[r] - fmaxf(t2v[ib][jb][r], thr2[jb]) * q2[jb];
-                        g1[r][jb] = gg[r] * inv2[jb];
-                    }
-                    const int col = colg + jb;
-                    if (col < hw && rowg < hwp) cv_st4<T>(G2 + (long)col * hwp + rowg, gg * inv1);
-                }
-                if (colg < hwp) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (rowg + r < hw) cv_st4<T>(G1 + (long)(rowg + r) * hwp + colg, g1[r]);
-                }
-            }
-        } else {
-            constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
-            // Entries past the ragged edge (tile rows / columns >= hw; their operands are clamped re-reads): the row's / column's inverse norm is
-            // zeroed, which makes s' = 0 — nothing enters a B sum — and e = exp2(0) = 1 exactly; the Z sums of the VALID rows and columns are
-            // corrected by the count of ones they collected (those of invalid rows / columns are never stored).  No per-entry test or select.
-            float inv2[4], thr2[4], badc = 0.f, badr = 0.f;
-            f32x2 zc[4], b2[4];
-#pragma unroll
-            for (int jb = 0; jb < 4; ++jb) {
-                const int cl = wn * 64 + 4 * c + jb;
-                const f32x4 v = sSt[128 + cl];
-                const bool ok = t.tn * 128 + cl < hw;
-                inv2[jb] = ok ? v[0] : 0.f; thr2[jb] = CV_EPS * v[1];
-                badc += ok ? 0.f : 1.f;
-                zc[jb] = f32x2{0.f, 0.f}; b2[jb] = f32x2{0.f, 0.f};
-            }
-#pragma unroll
-            for (int ib = 0; ib < 2; ++ib) {
-                f32x4 inv1, thr1, zr = {-badc, -badc, -badc, -badc}, b1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int rl = wm * 32 + ib * 16 + 4 * g + r;
-                    const f32x4 v = sSt[rl];
-                    const bool ok = t.tm * 128 + rl < hw;
-                    inv1[r] = ok ? v[0] * LOG2E : 0.f; thr1[r] = CV_EPS * v[1];
-                    badr += ok ? 0.f : 1.f;
-                }
-#pragma unroll
-                for (int jb = 0; jb < 4; ++jb) {
-                    const f32x4 sv = acc[ib][jb] * inv1 * inv2[jb];
-                    f32x4 e;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(sv[r]);
-                    zr += e;
-                    zc[jb] += f32x2{e[0], e[1]};
-                    zc[jb] += f32x2{e[2], e[3]};
-                    f32x4 m2;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) m2[r] = fmaxf(t2v[ib][jb][r], thr2[jb]);
-                    b2[jb] = __builtin_elementwise_fma(f32x2{m2[0], m2[1]}, f32x2{sv[0], sv[1]}, b2[jb]);
-                    b2[jb] = __builtin_elementwise_fma(f32x2{m2[2], m2[3]}, f32x2{sv[2], sv[3]}, b2[jb]);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) b1[r] = fmaf(fmaxf(t1v[ib][r][jb], thr1[r]), sv[r], b1[r]);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int rl = wm * 32 + ib * 16 + 4 * g + r;
-                    const float z = row16_sum(zr[r]), b = row16_sum(b1[r]);
-                    if (c == 0) { sP[wn * 128 + rl] = z; sP[256 + wn * 128 + rl] = b * (LN2 * __builtin_amdgcn_rcpf(sSt[rl][1])); }      // (the sum re-read: a register less per row)
-                }
-            }
-#pragma unroll
-            for (int jb = 0; jb < 4; ++jb) {
-                float z = (zc[jb][0] + zc[jb][1]) - badr, b = b2[jb][0] + b2[jb][1];
-                z += __shfl_xor(z, 16, 64); z += __shfl_xor(z, 32, 64);
-                b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
-                if (g == 0) {
-                    const int cl = wn * 64 + 4 * c + jb;
-                    sP[512 + wm * 128 + cl] = z; sP[1024 + wm * 128 + cl] = b * (LN2 * __builtin_amdgcn_rcpf(sSt[128 + cl][1]));
-                }
-            }
-        }
+        if (BWD) cvp_epilogue_bwd<T>(q, acc, t1v, t2v, sSt, t, hw, wm, wn, g, c, keepbits);
+        else cvp_epilogue_fwd(acc, t1v, t2v, sSt, sP, t, hw, wm, wn, g, c);
         if (it + 1 < n_tiles && !(dbg & 1)) prefetch(it + 1);
     }
     cvp_barrier();

@@ -35,17 +35,9 @@ def t(bits, ncu=0):
         lib().gd_debug_set(b"reserve_cus", 0)
 
 
-for name, bits in (("whole", 32), ("ring alone", 7), ("teacher alone", 64 | 6), ("ring + teacher", 6), ("ring + mfma", 3), ("ring + epilogue", 5),
-                   ("teacher + epilogue (no ring, no mfma)", 64 | 4), ("all but ring DMA", 64)):
-    print(f"{name:40s} {t(bits):8.1f} us")
-for name, bits in (("tiled teacher: alone", 128 | 64 | 6), ("tiled teacher: ring + teacher", 128 | 6), ("tiled teacher: whole", 128 | 32),
-                   ("no mask look-up: teacher alone", 32 | 64 | 6), ("tiled + no mask look-up: teacher alone", 128 | 32 | 64 | 6)):
-    print(f"{name:40s} {t(bits):8.1f} us")
-for name, bits in (("T1 only (256 B row segments), alone", 256 | 32 | 64 | 6), ("T2 only (64 B pieces of 16 rows), alone", 512 | 32 | 64 | 6),
-                   ("T1 only + ring", 256 | 32 | 6), ("T2 only + ring", 512 | 32 | 6)):
-    print(f"{name:40s} {t(bits):8.1f} us")
-for name, bits in (("3-slot ring: ring alone", 1024 | 7), ("3-slot ring: ring + mfma", 1024 | 3), ("3-slot ring: whole", 1024 | 32), ("3-slot: ring+mfma+epilogue (no teacher)", 1024 | 1),
-                   ("4-slot: ring+mfma+epilogue (no teacher)", 1)):
-    print(f"{name:40s} {t(bits):8.1f} us")
-for ncu in ():
-    print(f"ncu {ncu}: ring alone {t(7, ncu):8.1f}  teacher alone {t(64 | 6, ncu):8.1f}  both {t(6, ncu):8.1f}")
+for name, bits in (("whole op (anatomy build, nothing off)", 32), ("ring alone", 7), ("teacher alone", 64 | 6), ("teacher alone, no mask look-up", 32 | 64 | 6), ("ring + teacher", 6),
+                   ("ring + mfma", 3), ("ring + epilogue", 5), ("ring + mfma + epilogue (no teacher)", 1), ("teacher + epilogue (no ring, no mfma)", 64 | 4),
+                   ("all but the ring DMA", 64)):
+    print(f"{name:44s} {t(bits):8.1f} us")
+for ncu in (64, 128, 192):
+    print(f"{ncu} CUs: ring alone {t(7, ncu):8.1f}  teacher alone {t(64 | 6, ncu):8.1f}  both {t(6, ncu):8.1f}")
