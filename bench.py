@@ -487,16 +487,19 @@ def cost_volume_attainable(job, dev, variant, fwd_bytes):
                 return ops.time_on_stream(lambda: ops.cost_volume_kl(f1, f2, b["cost_1"], b["cost_2"], ones, ones, variant, tstats=b["cost_tstats"], inv_norms=inv), 2, 5) * 1e6
         finally:
             lib().gd_debug_set(b"cv_dbg", 0)
-    whole, ring, ring_mfma, ring_teacher, ring_epi, teacher = t(32), t(7), t(3), t(6), t(5), t(64 | 6)
+    whole, ring, ring_mfma, ring_teacher, ring_epi, teacher, no_ring = t(32), t(7), t(3), t(6), t(5), t(64 | 6), t(64)
     phases = {"feature_ring_alone (LDS-DMA, L2 -> LDS)": ring, "fragment_reads_and_mfma (marginal)": max(ring_mfma - ring, 0.0),
               "teacher_loads (marginal)": max(ring_teacher - ring, 0.0), "softmax_kl_epilogue (marginal)": max(ring_epi - ring, 0.0)}
     slow, tot = max(phases.values()), sum(phases.values())
-    streams = {"teacher_loads_alone (no feature DMA)": round(teacher, 1), "feature_ring_alone": round(ring, 1), "both (measured)": round(ring_teacher, 1),
-               "both_over_sum": round(ring_teacher / (ring + teacher), 3) if ring + teacher > 0 else None,
-               "frac_of_both_alone": round(fwd_bytes / (ring_teacher * 1e-6) / 1e9 / PEAK_HBM_GBS, 4) if ring_teacher > 0 else None,
-               "reading": "the kernel's two memory streams (feature tiles L2 -> LDS, teacher tiles HBM -> registers) with no arithmetic at all: when `both` is "
-                          "close to the SUM of the two alone, the streams do not overlap with each other — each is bound by latency x the CU's outstanding-request "
-                          "capacity, which they share — and `frac_of_both_alone` is the ceiling of this tile shape, not `frac_if_phases_overlapped`"}
+    # round 6 (anatomy bit 64 = no feature DMA): the kernel's two memory streams with no arithmetic, alone and together, and the kernel WITHOUT its feature ring
+    streams = {"teacher_loads_alone (no feature DMA, no arithmetic)": round(teacher, 1), "feature_ring_alone": round(ring, 1),
+               "both_streams_no_arithmetic": round(ring_teacher, 1), "everything_but_the_feature_DMA": round(no_ring, 1),
+               "frac_of_teacher_stream_alone": round(fwd_bytes / (teacher * 1e-6) / 1e9 / PEAK_HBM_GBS, 4) if teacher > 0 else None,
+               "reading": "the two streams DO overlap (both ~ the slower one); the slower one is the teacher stream, which by itself — 480 MB as one 131 KB "
+                          "burst per tile and CU into the 64 registers the epilogue frees — runs at 2.3-2.5 TB/s (the same maps stream at 5.9 TB/s through "
+                          "gd_cost_volume_teacher_stats, profiles/r06_probe_cv_streams.txt), and the kernel without any feature DMA takes ~0.9 of the whole: "
+                          "the chain burst -> land -> epilogue -> next burst is the critical path, `frac_of_teacher_stream_alone` its ceiling for this kernel "
+                          "family.  A form that streams the teacher through two loader waves and LDS was built (tools/experiments/cv_stream.h): -6 %, shelved"}
     return {"what": "dense forward, every row kept, 16-bit features: the persistent kernel's phases timed one at a time (anatomy build; whole op = statistics "
                     "init + tile kernel + finalize + loss, as `unmasked` times it)",
             "us_per_launch": {"whole_op_anatomy_build_nothing_off": round(whole, 1), **{k: round(v, 1) for k, v in phases.items()}},
